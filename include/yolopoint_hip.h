@@ -1,0 +1,199 @@
+/*
+ * yolopoint_hip.h — C ABI of libyolopoint_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (UniBwTAS/YOLOPoint) has no FFI layer: its hot path is Python calling
+ * stock ATen/torchvision ops.  Each entry point below replaces one of those call sites;
+ * the citation after "replaces:" is the reference file:line (relative to /root/reference).
+ *
+ * Conventions
+ *   - every function returns 0 (YP_OK) or a negative YP_ERR_* code; yp_last_error() gives
+ *     a thread-local human-readable message.  Nothing throws, nothing aborts.
+ *   - all pointers are DEVICE pointers unless the parameter name ends in _host.
+ *   - no hidden allocation on the data path: the caller owns every buffer; kernels that
+ *     need scratch take a workspace sized by the matching *_workspace_bytes() query.
+ *   - every launch function takes the hipStream_t to enqueue on (passed as void*).
+ *   - activations are NHWC ("pixels x channels"); a YpView describes a channel slice of
+ *     an NHWC buffer so that torch.cat (reference models/common.py:135,229 and
+ *     models/YOLOPoint.py:216,232,236,239,242) and nn.Upsample (models/YOLOPoint.py:192)
+ *     never materialise: producers write into a slice, consumers read (y>>1,x>>1).
+ */
+#ifndef YOLOPOINT_HIP_H
+#define YOLOPOINT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    YP_OK = 0,
+    YP_ERR_INVALID = -1,        /* bad argument / unsupported shape            */
+    YP_ERR_HIP = -2,            /* a HIP runtime call failed                    */
+    YP_ERR_UNSUPPORTED = -3,    /* valid request the library cannot serve       */
+    YP_ERR_WORKSPACE = -4,      /* workspace too small                          */
+    YP_ERR_OVERFLOW = -5        /* an output list was truncated at max_out      */
+};
+
+/* arithmetic type of activations / packed weights */
+enum { YP_F16 = 0, YP_BF16 = 1, YP_F32 = 2 };
+/* fused activation */
+enum { YP_ACT_NONE = 0, YP_ACT_SILU = 1 };
+
+const char* yp_last_error(void);
+int yp_version(void);
+/* number of HIP devices visible, 0 when none (never fails, usable on a CPU-only host) */
+int yp_device_count(void);
+
+/* ------------------------------------------------------------------------------------
+ * NHWC channel-slice view.
+ *   ptr      base of the NHWC buffer (pixel 0, channel 0)
+ *   H, W     physical spatial size of the buffer
+ *   cstride  channels per pixel in the buffer (multiple of 8)
+ *   coff     first channel of this view (multiple of 8)
+ *   C        channels in this view (multiple of 8; pad channels hold zeros)
+ *   ups      0 or 1: when read as a conv INPUT the logical size is (H<<ups, W<<ups) and
+ *            pixel (y,x) reads physical (y>>ups, x>>ups)  == nn.Upsample(2,'nearest')
+ * ---------------------------------------------------------------------------------- */
+typedef struct YpView {
+    void* ptr;
+    int32_t H, W;
+    int32_t cstride, coff, C;
+    int32_t ups;
+} YpView;
+
+/* ------------------------------------------------------------------------------------
+ * Fused implicit-GEMM convolution (MFMA, no im2col buffer).
+ *   out = [res +] act( conv(cat(in0,in1), W) + bias )
+ * replaces: models/common.py:22-34 (Conv: Conv2d+BatchNorm2d+SiLU, BN folded by
+ *           utils/torch_utils_yolo.py:194-214), :88-89 (Bottleneck residual add),
+ *           :135/:229 + models/YOLOPoint.py:216,232,236,239,242 (torch.cat),
+ *           models/YOLOPoint.py:186,195 (ConvDet/ConvDesc), models/yolo.py:46,51 (Detect.m)
+ *   weight   packed [Npad][Kpad] row-major in `dtype`, k = (r*S + s)*Cin + c (yp_conv_pack_*)
+ *   bias     fp32 [Npad] or NULL
+ *   Cin      = in0.C + in1.C (in1.C == 0 for a single source)
+ *   Cout     = out.C (multiple of 8; rows >= real Cout are zero in `weight`)
+ *   out_f32  write fp32 instead of `dtype` (head outputs: logits / descriptors)
+ * ---------------------------------------------------------------------------------- */
+typedef struct YpConvDesc {
+    YpView in0, in1, out, res;       /* res.C == 0: no residual                       */
+    const void* weight;
+    const float* bias;
+    int32_t dtype;                   /* YP_F16 | YP_BF16 | YP_F32                     */
+    int32_t out_f32;
+    int32_t B;
+    int32_t Hi, Wi;                  /* logical input size                             */
+    int32_t Ho, Wo;
+    int32_t R, S;                    /* filter taps                                    */
+    int32_t stride_h, stride_w, pad_h, pad_w;
+    int32_t Kpad, Npad;              /* packed weight dims                             */
+    int32_t act;                     /* YP_ACT_*                                       */
+    int32_t tile;                    /* 0 = auto, else forced tile config id (testing) */
+} YpConvDesc;
+
+int yp_conv2d(const YpConvDesc* d, void* stream);
+/* K padding granule the packer must use for `dtype` */
+int yp_conv_kpad(int K, int dtype);
+
+/* ------------------------------------------------------------------------------------
+ * Layout / elementwise kernels
+ * ---------------------------------------------------------------------------------- */
+/* NCHW fp32 image -> NHWC `dtype`, channels zero-padded to out.cstride.
+ * replaces: the implicit layout of `model(inp)` input, demo.py:129-135 / train.py:208 */
+int yp_pack_input(const float* x_nchw, int B, int C, int H, int W, YpView out, int dtype, void* stream);
+/* NHWC view (`dtype` or fp32 when src_f32) -> dense NCHW fp32 [B,C,H,W] */
+int yp_unpack_nchw(YpView in, int src_dtype, int B, int C, float* out_nchw, void* stream);
+/* SPPF pyramid: three chained MaxPool2d(5,1,2) of view `x`, written to y1,y2,y3 (same dims).
+ * replaces: models/common.py:220-229 */
+int yp_sppf_pool(YpView x, YpView y1, YpView y2, YpView y3, int B, int dtype, void* stream);
+/* per-pixel channel L2 normalisation of an fp32 NHWC view, no epsilon, in place or out of place.
+ * replaces: models/YOLOPoint.py:219-220 */
+int yp_l2norm_f32(YpView in, YpView out, int B, int C, void* stream);
+/* Detect head decode of one level.
+ *   raw      fp32 NHWC view [B,ny,nx, na*no (+pad)], channel = a*no + o
+ *   x_out    fp32 [B,na,ny,nx,no]   (the permuted raw tensor the reference returns)
+ *   z_out    fp32 [B,rows_total,no] (decoded, written at row_offset) or NULL in train mode
+ *   anchors_px  host array na*2: anchor (w,h) in pixels (= anchors*stride)
+ * replaces: models/yolo.py:49-70 */
+int yp_detect_decode(YpView raw, int B, int na, int no, float stride, const float* anchors_px_host,
+                     float* x_out, float* z_out, int rows_total, int row_offset, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Post-processing
+ * ---------------------------------------------------------------------------------- */
+/* Keypoint heat-map decode: softmax over 65 channels, drop dustbin, depth-to-space(8).
+ *   semi: fp32, element (b,c,y,x) at semi[b*sb + c*sc + y*sy + x*sx]  (any layout)
+ *   mode 0: torch softmax (max-subtracted)              replaces utils/utils.py:232-262
+ *   mode 1: exp(x)/(sum+1e-5) without max subtraction   replaces demo.py:140-150
+ *   heat: fp32 [B, 8*Hc, 8*Wc] */
+int yp_kp_decode(const float* semi, int B, int Hc, int Wc, int64_t sb, int64_t sc, int64_t sy, int64_t sx,
+                 int mode, float* heat, void* stream);
+
+/* Greedy grid NMS of heat-map peaks, bit-exact with the sequential reference for distinct scores.
+ *   heat [B,H,W] fp32; candidates are pixels with heat >= conf_thresh; a kept point suppresses every
+ *   lower-scored candidate inside its (2r+1)^2 window; kept points within `border` px of the image
+ *   edge are dropped afterwards; survivors are returned sorted by score (desc, ties by index asc).
+ *   out_xyc [B,max_out,3] fp32 (x, y, conf); out_count [B] int32
+ * replaces: utils/utils.py:118-182 (nms_fast) + :465-485 (getPtsFromHeatmap) */
+size_t yp_kp_nms_workspace_bytes(int B, int H, int W);
+int yp_kp_nms(const float* heat, int B, int H, int W, float conf_thresh, int radius, int border,
+              float* out_xyc, int32_t* out_count, int max_out, void* workspace, size_t workspace_bytes,
+              void* stream);
+
+/* Batched box NMS on decoded predictions.
+ *   pred [B,N,5+nc] fp32 (xywh, obj, cls...).  Output rows (x1,y1,x2,y2,conf,cls) sorted by conf desc.
+ *   out_det [B,max_det,6] fp32; out_count [B] int32
+ * replaces: utils/general_yolo.py:124-235 incl. torchvision.ops.nms (:218) */
+size_t yp_box_nms_workspace_bytes(int B, int N, int nc, int multi_label, int max_nms);
+int yp_box_nms(const float* pred, int B, int N, int nc, float conf_thres, float iou_thres,
+               int multi_label, int agnostic, int max_det, int max_nms, float max_wh,
+               float* out_det, int32_t* out_count, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Bilinear descriptor sampling (grid_sample align_corners=True with the reference's
+ * full-resolution normalisation) + L2 renormalisation.
+ *   desc: fp32, element (c,y,x) at desc[c*sc + y*sy + x*sx]; pts [N,2] fp32 (x,y) in pixels;
+ *   out [D,N] fp32 column-per-point (reference layout)
+ * replaces: evaluations/descriptor_evaluation.py:148-181, demo.py:200-215 */
+int yp_desc_sample(const float* desc, int D, int Hc, int Wc, int64_t sc, int64_t sy, int64_t sx,
+                   const float* pts_xy, int N, int cell, float* out, void* stream);
+
+/* Mutual nearest-neighbour matcher on unit descriptors.
+ *   d1 [D,N1], d2 [D,N2] fp32 column-per-point.  dist = sqrt(2-2*clip(d1^T d2,-1,1)).
+ *   out_match [3, min(N1,max_out)] fp32 rows (idx1, idx2, dist) compacted in idx1 order.
+ * replaces: models/model_wrap.py:434-476 == demo.py:300-341 */
+size_t yp_mnn_workspace_bytes(int N1, int N2);
+int yp_mnn_match(const float* d1, int N1, const float* d2, int N2, int D, float nn_thresh,
+                 float* out_match, int32_t* out_count, int max_out, void* workspace,
+                 size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Execution plan: an immutable, caller-owned list of the launches above, replayed with
+ * one call (optionally through a captured hipGraph).  Buffers referenced by the
+ * descriptors must stay alive and fixed for the life of the plan.
+ * replaces: the Python module-by-module dispatch of models/YOLOPoint.py:198-246
+ * ---------------------------------------------------------------------------------- */
+typedef struct YpPlan YpPlan;
+int yp_plan_create(YpPlan** plan);
+int yp_plan_destroy(YpPlan* plan);
+int yp_plan_add_conv(YpPlan* plan, const YpConvDesc* d);
+int yp_plan_add_sppf_pool(YpPlan* plan, YpView x, YpView y1, YpView y2, YpView y3, int B, int dtype);
+int yp_plan_add_l2norm(YpPlan* plan, YpView in, YpView out, int B, int C);
+int yp_plan_add_detect_decode(YpPlan* plan, YpView raw, int B, int na, int no, float stride,
+                              const float* anchors_px_host, float* x_out, float* z_out,
+                              int rows_total, int row_offset);
+int yp_plan_num_ops(const YpPlan* plan);
+/* capture the op list into a hipGraph on `stream` (call once, after the last add) */
+int yp_plan_instantiate_graph(YpPlan* plan, void* stream);
+/* enqueue all ops (graph launch when instantiated) */
+int yp_plan_run(YpPlan* plan, void* stream);
+/* enqueue all ops eagerly and time each with hip events; ms_out[num_ops] (host) */
+int yp_plan_profile(YpPlan* plan, void* stream, float* ms_out_host);
+/* enqueue the plan `iters` times and return the mean wall ms per iteration measured with hip
+ * events on `stream` (events recorded on the launch stream itself) */
+int yp_plan_time(YpPlan* plan, void* stream, int iters, float* ms_per_iter_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLOPOINT_HIP_H */

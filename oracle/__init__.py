@@ -1,0 +1,5 @@
+"""oracle/ — CPU restatement of the reference algorithms.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package,
+and only as the checker / the timed CPU baseline.  Nothing under yolopoint_amd/ imports it.
+"""

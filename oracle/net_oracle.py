@@ -1,0 +1,167 @@
+"""CPU fp32 restatement of the YOLOPoint network forward.  TEST INFRASTRUCTURE ONLY (see
+oracle/__init__.py): never imported by the product path.
+
+Written as pure functions over a reference-layout state_dict (fp32 OIHW tensors, keys
+`model.<Block>...`), using torch's CPU conv / batch_norm as the arithmetic substrate — the same
+substrate the reference itself runs on (ATen CPU), since this is a floating-point path whose
+parity bar is a tolerance, not bit equality.  Pinned against golden outputs of the imported
+reference: tests/golden/make_golden.py, tests/test_oracle_golden.py.
+
+Each function cites the reference code it restates (paths relative to /root/reference/src).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+BN_EPS, BN_MOMENTUM = 1e-3, 0.03          # models/common.py:18-20
+
+VERSIONS = {'n': (0.33, 0.25), 's': (0.33, 0.5), 'm': (0.67, 0.75), 'l': (1., 1.), 'x': (1.33, 1.25)}   # models/YOLOPoint.py:36-49
+ANCHORS = [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]           # models/YOLOPoint.py:11-15
+STRIDES = (8.0, 16.0, 32.0)
+
+
+def arch(version):
+    """Channel widths and C3 repeat counts (models/YOLOPoint.py:152-153)."""
+    dm, wm = VERSIONS[version]
+    c = [int(math.ceil(2 ** k * wm / 8) * 8) for k in range(6, 11)]
+    n = [max(round(k * dm), 1) for k in (3, 6, 9)]
+    return c, n
+
+
+def conv_block(sd, p, x, k, s, pad, training=False, stats=None):
+    """Conv: SiLU(BN(conv(x))) or, after fuse(), SiLU(conv(x)+b)   (models/common.py:22-34)."""
+    w = sd[p + ".conv.weight"]
+    if p + ".bn.weight" in sd:
+        y = F.conv2d(x, w, None, s, pad)
+        rm, rv = sd[p + ".bn.running_mean"], sd[p + ".bn.running_var"]
+        if training:      # batch statistics; running stats updated in place on clones kept in `stats`
+            rm, rv = rm.clone(), rv.clone()
+            y = F.batch_norm(y, rm, rv, sd[p + ".bn.weight"], sd[p + ".bn.bias"], True, BN_MOMENTUM, BN_EPS)
+            if stats is not None:
+                stats[p + ".bn.running_mean"], stats[p + ".bn.running_var"] = rm, rv
+        else:
+            y = F.batch_norm(y, rm, rv, sd[p + ".bn.weight"], sd[p + ".bn.bias"], False, BN_MOMENTUM, BN_EPS)
+    else:
+        y = F.conv2d(x, w, sd[p + ".conv.bias"], s, pad)
+    return F.silu(y)
+
+
+def bottleneck(sd, p, x, **kw):
+    """x + cv2(cv1(x)), cv1 1x1, cv2 3x3 (models/common.py:79-89; always with the add inside C3)."""
+    return x + conv_block(sd, p + ".cv2", conv_block(sd, p + ".cv1", x, 1, 1, 0, **kw), 3, 1, 1, **kw)
+
+
+def c3(sd, p, x, n, **kw):
+    """cv3(cat(m(cv1(x)), cv2(x)))  (models/common.py:123-135)."""
+    a = conv_block(sd, p + ".cv1", x, 1, 1, 0, **kw)
+    for i in range(n):
+        a = bottleneck(sd, f"{p}.m.{i}", a, **kw)
+    b = conv_block(sd, p + ".cv2", x, 1, 1, 0, **kw)
+    return conv_block(sd, p + ".cv3", torch.cat((a, b), 1), 1, 1, 0, **kw)
+
+
+def sppf(sd, p, x, **kw):
+    """cv2(cat(x, m(x), m(m(x)), m(m(m(x))))), m = MaxPool2d(5,1,2)  (models/common.py:213-229)."""
+    x = conv_block(sd, p + ".cv1", x, 1, 1, 0, **kw)
+    y1 = F.max_pool2d(x, 5, 1, 2)
+    y2 = F.max_pool2d(y1, 5, 1, 2)
+    y3 = F.max_pool2d(y2, 5, 1, 2)
+    return conv_block(sd, p + ".cv2", torch.cat((x, y1, y2, y3), 1), 1, 1, 0, **kw)
+
+
+def detect(sd, p, feats, nc, training):
+    """Detect head (models/yolo.py:49-81): 1x1 conv -> [B,na,ny,nx,no]; eval adds the sigmoid /
+    grid / anchor decode and concatenates the levels to [B, sum(na*ny*nx), no]."""
+    no, na = nc + 5, 3
+    anchors = sd[p + ".anchors"]            # [nl, na, 2] in grid units
+    xs, z = [], []
+    for i, f in enumerate(feats):
+        y = F.conv2d(f, sd[f"{p}.m.{i}.weight"], sd[f"{p}.m.{i}.bias"])
+        B, _, ny, nx = y.shape
+        y = y.view(B, na, no, ny, nx).permute(0, 1, 3, 4, 2).contiguous()
+        xs.append(y)
+        if not training:
+            yv, xv = torch.meshgrid(torch.arange(ny), torch.arange(nx), indexing='ij')
+            grid = torch.stack((xv, yv), 2).expand(1, na, ny, nx, 2).float()
+            ag = (anchors[i] * STRIDES[i]).view(1, na, 1, 1, 2).expand(1, na, ny, nx, 2).float()
+            s = y.sigmoid()
+            xy = (s[..., 0:2] * 2 - 0.5 + grid) * STRIDES[i]
+            wh = (s[..., 2:4] * 2) ** 2 * ag
+            z.append(torch.cat((xy, wh, s[..., 4:]), -1).view(B, -1, no))
+    return xs if training else (torch.cat(z, 1), xs)
+
+
+def yolopoint_forward(sd, x, version, nc=80, training=False, stats=None):
+    """models/YOLOPoint.py:198-246.  Returns {'semi','desc','objects'} like the reference."""
+    (c1, c2, c3_, c4, c5), (n1, n2, n3) = arch(version)
+    kw = dict(training=training, stats=stats)
+    P = "model."
+    x = conv_block(sd, P + "Conv1", x, 6, 2, 2, **kw)
+    x = conv_block(sd, P + "Conv2", x, 3, 2, 1, **kw)
+    xa = c3(sd, P + "Bottleneck1", x, n1, **kw)
+    x8 = conv_block(sd, P + "Conv3", xa, 3, 2, 1, **kw)
+    semi = F.conv2d(c3(sd, P + "BottleneckDet", x8, n1, **kw), sd[P + "ConvDet.weight"])
+    xb = c3(sd, P + "Bottleneck2", x8, n2, **kw)
+    dA = conv_block(sd, P + "ConvDescA", xa, 3, 2, 1, **kw)
+    dB = F.interpolate(conv_block(sd, P + "ConvDescB", xb, 3, 2, 1, **kw), scale_factor=2, mode='nearest')
+    desc = F.conv2d(c3(sd, P + "BottleneckDesc", torch.cat((dA, dB), 1), n1, **kw), sd[P + "ConvDesc.weight"], None, 1, 1)
+    desc = desc / torch.norm(desc, p=2, dim=1).unsqueeze(1)          # no epsilon (YOLOPoint.py:219-220)
+    x = conv_block(sd, P + "Conv4", xb, 3, 2, 1, **kw)
+    xc = c3(sd, P + "Bottleneck3", x, n3, **kw)
+    x = conv_block(sd, P + "Conv5", xc, 3, 2, 1, **kw)
+    x = c3(sd, P + "Bottleneck4", x, n1, **kw)
+    x = sppf(sd, P + "SPPooling", x, **kw)
+    xd = conv_block(sd, P + "Conv6", x, 1, 1, 0, **kw)
+    x = c3(sd, P + "Bottleneck5", torch.cat((F.interpolate(xd, scale_factor=2, mode='nearest'), xc), 1), n1, **kw)
+    xe = conv_block(sd, P + "Conv7", x, 1, 1, 0, **kw)
+    xf = c3(sd, P + "Bottleneck6", torch.cat((F.interpolate(xe, scale_factor=2, mode='nearest'), xb), 1), n1, **kw)
+    x = conv_block(sd, P + "Conv8", xf, 3, 2, 1, **kw)
+    xg = c3(sd, P + "Bottleneck7", torch.cat((x, xe), 1), n1, **kw)
+    x = conv_block(sd, P + "Conv9", xg, 3, 2, 1, **kw)
+    p5 = c3(sd, P + "Bottleneck8", torch.cat((x, xd), 1), n1, **kw)
+    return {'semi': semi, 'desc': desc, 'objects': detect(sd, P + "Detect", [xf, xg, p5], nc, training)}
+
+
+def fuse_conv_bn(w, gamma, beta, mean, var, eps=BN_EPS):
+    """utils/torch_utils_yolo.py:194-214: W' = diag(g/sqrt(v+eps)) W ; b' = beta - g*mean/sqrt(v+eps)."""
+    scale = gamma / torch.sqrt(eps + var)
+    return w * scale.view(-1, 1, 1, 1), beta - gamma * mean / torch.sqrt(var + eps)
+
+
+# ---------------------------------------------------------------------------------------------
+# deterministic synthetic weights (numpy PCG64 streams: identical here and on the GPU box)
+# ---------------------------------------------------------------------------------------------
+def synth_state_dict(layout, seed):
+    """layout: list of (key, shape) in reference state_dict order -> fp32 tensors.  BN affine /
+    running statistics are randomised so that BN folding is exercised."""
+    import numpy as np
+    sd = {}
+    for idx, (key, shape) in enumerate(layout):
+        rng = np.random.default_rng([seed, idx])
+        shape = tuple(shape)
+        if key.endswith("num_batches_tracked"):
+            sd[key] = torch.tensor(0, dtype=torch.int64)
+            continue
+        if key.endswith("anchors"):
+            a = torch.tensor(ANCHORS, dtype=torch.float32).view(3, 3, 2)
+            sd[key] = a / torch.tensor(STRIDES).view(3, 1, 1)
+            continue
+        if key.endswith("running_var"):
+            v = rng.uniform(0.5, 1.5, shape)
+        elif key.endswith("running_mean"):
+            v = rng.normal(0.0, 0.1, shape)
+        elif key.endswith("bn.weight"):
+            v = rng.uniform(0.7, 1.3, shape)
+        elif key.endswith("bn.bias") or key.endswith(".bias"):
+            v = rng.normal(0.0, 0.1, shape)
+        else:   # conv weight OIHW: He-style scale keeps activations O(1) through ~30 layers
+            fan_in = shape[1] * shape[2] * shape[3]
+            v = rng.normal(0.0, 1.0, shape) * (1.6 / math.sqrt(fan_in))
+        sd[key] = torch.from_numpy(np.asarray(v, dtype=np.float32).reshape(shape))
+    return sd
+
+
+def synth_image(B, C, H, W, seed):
+    import numpy as np
+    return torch.from_numpy(np.random.default_rng([seed, 777]).random((B, C, H, W), dtype=np.float32))

@@ -1,0 +1,229 @@
+"""numpy restatement of the reference's post-processing.  TEST INFRASTRUCTURE ONLY (see
+oracle/__init__.py): never imported by the product path.
+
+Index-selection work (keypoint grid NMS, box NMS, mutual nearest neighbours) is restated as the
+plain sequential algorithm; the HIP kernels must reproduce its selections bit for bit.  Sort
+ties, which the reference leaves to unstable sorts (np.argsort / Tensor.argsort), are resolved
+here as "higher score first, then lower index" — the golden vectors use distinct scores.
+
+Pinned against outputs of the imported reference: tests/golden/make_golden.py,
+tests/test_oracle_golden.py.  Citations are relative to /root/reference/src.
+"""
+import numpy as np
+
+
+# ------------------------------------------------------------------------------------------
+# keypoint heat map
+# ------------------------------------------------------------------------------------------
+def depth_to_space8(cells):
+    """[64,Hc,Wc] -> [8Hc,8Wc]; channel c lands at pixel (8h + c//8, 8w + c%8) (nn.PixelShuffle(8))."""
+    _, Hc, Wc = cells.shape
+    return cells.reshape(8, 8, Hc, Wc).transpose(2, 0, 3, 1).reshape(Hc * 8, Wc * 8)
+
+
+def flatten_detection(semi):
+    """utils/utils.py:232-262: softmax over 65 channels, drop the dustbin, depth-to-space.
+    semi [65,Hc,Wc] -> [1,H,W]; [B,65,Hc,Wc] -> [B,1,H,W]   (float32)."""
+    semi = np.asarray(semi, dtype=np.float32)
+    batch = semi.ndim == 4
+    s = semi if batch else semi[None]
+    e = np.exp(s - s.max(axis=1, keepdims=True))
+    dense = e / e.sum(axis=1, keepdims=True)
+    heat = np.stack([depth_to_space8(d[:-1]) for d in dense])[:, None]
+    return heat if batch else heat[0]
+
+
+def flatten_detection_demo(semi):
+    """demo.py:140-150: exp(x) / (sum + 1e-5) without max subtraction.  semi [65,Hc,Wc] -> [H,W]."""
+    semi = np.asarray(semi, dtype=np.float32)
+    dense = np.exp(semi)
+    dense = dense / (np.sum(dense, axis=0) + np.float32(.00001))
+    return depth_to_space8(dense[:-1])
+
+
+def nms_fast(in_corners, H, W, dist_thresh):
+    """utils/utils.py:118-182.  Visit corners by descending confidence on the rounded grid; a corner
+    whose pixel is still pending is kept and clears the (2r+1)^2 window around it.  Returns
+    (3xN' survivors sorted by conf desc, their indices into in_corners)."""
+    in_corners = np.asarray(in_corners)
+    order = np.argsort(-in_corners[2, :], kind="stable")
+    corners = in_corners[:, order]
+    rc = corners[:2, :].round().astype(int)
+    n = rc.shape[1]
+    if n == 0:
+        return np.zeros((3, 0)).astype(int), np.zeros(0).astype(int)
+    if n == 1:
+        return np.vstack((rc, in_corners[2])).reshape(3, 1), np.zeros((1)).astype(int)
+    r = dist_thresh
+    PENDING, KEPT = 1, -1
+    state = np.zeros((H + 2 * r, W + 2 * r), dtype=int)
+    owner = np.zeros((H, W), dtype=int)
+    for i in range(n):                      # later (lower-confidence) duplicates overwrite the owner
+        state[rc[1, i] + r, rc[0, i] + r] = PENDING
+        owner[rc[1, i], rc[0, i]] = i
+    for i in range(n):
+        x, y = rc[0, i] + r, rc[1, i] + r
+        if state[y, x] == PENDING:
+            state[y - r:y + r + 1, x - r:x + r + 1] = 0
+            state[y, x] = KEPT
+    ky, kx = np.where(state == KEPT)
+    keep = owner[ky - r, kx - r]
+    out = corners[:, keep]
+    o2 = np.argsort(-out[-1, :], kind="stable")
+    return out[:, o2], order[keep[o2]]
+
+
+def get_pts_from_heatmap(heatmap, conf_thresh, nms_dist, border=4):
+    """utils/utils.py:465-485: threshold (>=) -> nms_fast -> sort desc -> drop the 4-px border."""
+    heatmap = np.asarray(heatmap)
+    H, W = heatmap.shape
+    ys, xs = np.where(heatmap >= conf_thresh)
+    if len(ys) == 0:
+        return np.zeros((3, 0))
+    pts = np.zeros((3, len(ys)))
+    pts[0], pts[1], pts[2] = xs, ys, heatmap[ys, xs]
+    pts, _ = nms_fast(pts, H, W, nms_dist)
+    pts = pts[:, np.argsort(-pts[2, :], kind="stable")]
+    bad = (pts[0] < border) | (pts[0] >= W - border) | (pts[1] < border) | (pts[1] >= H - border)
+    return pts[:, ~bad]
+
+
+def get_pts_from_semi(semi, conf_thresh=0.015, nms_dist=4):
+    """utils/utils.py:94-101."""
+    return get_pts_from_heatmap(np.squeeze(flatten_detection(semi)), conf_thresh, nms_dist)
+
+
+def labels2d_to_3d(labels, cell=8, add_dustbin=True):
+    """utils/utils.py:184-209: PixelUnshuffle(8) (+ dustbin, normalise).  [B,1,H,W] -> [B,65|64,Hc,Wc]."""
+    labels = np.asarray(labels, dtype=np.float32)
+    B, _, H, W = labels.shape
+    Hc, Wc = H // cell, W // cell
+    cells = labels.reshape(B, Hc, cell, Wc, cell).transpose(0, 2, 4, 1, 3).reshape(B, cell * cell, Hc, Wc)
+    if add_dustbin:
+        dust = 1 - cells.sum(axis=1)
+        dust[dust < 1.] = 0
+        cells = np.concatenate((cells, dust[:, None]), axis=1)
+        cells = cells / cells.sum(axis=1, keepdims=True)
+    return cells
+
+
+def get_masks(mask_2d, cell=8):
+    """utils/utils.py:103-116."""
+    return np.prod(labels2d_to_3d(mask_2d, cell, add_dustbin=False), axis=1)
+
+
+# ------------------------------------------------------------------------------------------
+# box NMS
+# ------------------------------------------------------------------------------------------
+def xywh2xyxy(x):
+    """utils/general_yolo.py:623-630 (fp32 arithmetic preserved)."""
+    y = np.copy(x)
+    y[:, 0] = x[:, 0] - x[:, 2] / 2
+    y[:, 1] = x[:, 1] - x[:, 3] / 2
+    y[:, 2] = x[:, 0] + x[:, 2] / 2
+    y[:, 3] = x[:, 1] + x[:, 3] / 2
+    return y
+
+
+def nms_greedy(boxes, scores, iou_thres):
+    """torchvision.ops.nms as pinned in SURVEY.md 8c (the package itself is not in the reference tree):
+    visit boxes by descending score; a box is kept unless an earlier kept box has
+    inter / (area_i + area_j - inter) > iou_thres, all in fp32."""
+    boxes = np.asarray(boxes, dtype=np.float32)
+    order = np.argsort(-np.asarray(scores, dtype=np.float32), kind="stable")
+    x1, y1, x2, y2 = boxes[:, 0], boxes[:, 1], boxes[:, 2], boxes[:, 3]
+    area = (x2 - x1) * (y2 - y1)
+    dead = np.zeros(len(boxes), dtype=bool)
+    keep = []
+    thr = np.float32(iou_thres)
+    for a, i in enumerate(order):
+        if dead[i]:
+            continue
+        keep.append(i)
+        rest = order[a + 1:]
+        w = np.maximum(np.float32(0), np.minimum(x2[i], x2[rest]) - np.maximum(x1[i], x1[rest]))
+        h = np.maximum(np.float32(0), np.minimum(y2[i], y2[rest]) - np.maximum(y1[i], y1[rest]))
+        inter = w * h
+        with np.errstate(divide='ignore', invalid='ignore'):
+            ovr = inter / (area[i] + area[rest] - inter)
+        dead[rest[ovr > thr]] = True
+    return np.asarray(keep, dtype=np.int64)
+
+
+def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, agnostic=False, multi_label=False, max_det=300):
+    """utils/general_yolo.py:124-235 for classes=None, labels=(), nm=0.
+    prediction [B,N,5+nc] fp32 -> list of B arrays [n,6] (x1,y1,x2,y2,conf,cls)."""
+    prediction = np.asarray(prediction, dtype=np.float32)
+    nc = prediction.shape[2] - 5
+    max_wh, max_nms = np.float32(7680), 30000
+    multi_label = multi_label and nc > 1
+    ct = np.float32(conf_thres)
+    out = []
+    for x in prediction:
+        x = x[x[:, 4] > ct].copy()
+        if not x.shape[0]:
+            out.append(np.zeros((0, 6), dtype=np.float32))
+            continue
+        x[:, 5:] *= x[:, 4:5]
+        box = xywh2xyxy(x[:, :4])
+        if multi_label:
+            i, j = np.nonzero(x[:, 5:] > ct)
+            x = np.concatenate((box[i], x[i, 5 + j, None], j[:, None].astype(np.float32)), 1)
+        else:
+            j = x[:, 5:].argmax(1)
+            conf = x[np.arange(len(x)), 5 + j]
+            x = np.concatenate((box, conf[:, None], j[:, None].astype(np.float32)), 1)[conf > ct]
+        if not x.shape[0]:
+            out.append(np.zeros((0, 6), dtype=np.float32))
+            continue
+        x = x[np.argsort(-x[:, 4], kind="stable")[:max_nms]]
+        c = x[:, 5:6] * (np.float32(0) if agnostic else max_wh)
+        keep = nms_greedy(x[:, :4] + c, x[:, 4], iou_thres)[:max_det]
+        out.append(x[keep])
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# descriptors
+# ------------------------------------------------------------------------------------------
+def sample_desc_from_points(coarse_desc, pts, cell=8):
+    """evaluations/descriptor_evaluation.py:148-181 (== demo.py:200-215): bilinear grid_sample with
+    align_corners=True at coordinates normalised by the FULL resolution (x/(W/2)-1), zero padding,
+    then per-point L2 normalisation.  coarse_desc [D,Hc,Wc] fp32, pts [>=2,N] -> [D,N] fp32."""
+    d = np.asarray(coarse_desc, dtype=np.float32)
+    if d.ndim == 4:
+        d = d[0]
+    D, Hc, Wc = d.shape
+    pts = np.asarray(pts)
+    if pts.ndim != 2 or pts.shape[1] == 0:
+        return np.empty((D, 0))
+    W, H = float(Wc * cell), float(Hc * cell)
+    gx = (pts[0].astype(np.float64) / (W / 2.) - 1.).astype(np.float32)
+    gy = (pts[1].astype(np.float64) / (H / 2.) - 1.).astype(np.float32)
+    ix = ((gx + np.float32(1)) / np.float32(2)) * np.float32(Wc - 1)
+    iy = ((gy + np.float32(1)) / np.float32(2)) * np.float32(Hc - 1)
+    x0, y0 = np.floor(ix).astype(int), np.floor(iy).astype(int)
+    x1, y1 = x0 + 1, y0 + 1
+    out = np.zeros((D, pts.shape[1]), dtype=np.float32)
+    for (xx, yy, wgt) in ((x0, y0, (x1 - ix) * (y1 - iy)), (x1, y0, (ix - x0) * (y1 - iy)),
+                          (x0, y1, (x1 - ix) * (iy - y0)), (x1, y1, (ix - x0) * (iy - y0))):
+        ok = (xx >= 0) & (xx < Wc) & (yy >= 0) & (yy < Hc)
+        out[:, ok] += d[:, yy[ok], xx[ok]] * wgt[ok].astype(np.float32)
+    return out / np.linalg.norm(out, axis=0)[None, :]
+
+
+def nn_match_two_way(desc1, desc2, nn_thresh):
+    """models/model_wrap.py:434-476 (== demo.py:300-341).  desc [D,N] unit columns ->
+    [3,L] rows (idx1, idx2, distance): nearest neighbour both ways and distance < nn_thresh."""
+    assert desc1.shape[0] == desc2.shape[0]
+    if desc1.shape[1] == 0 or desc2.shape[1] == 0:
+        return np.zeros((3, 0))
+    assert nn_thresh > 0.0
+    dmat = np.sqrt(2 - 2 * np.clip(desc1.T @ desc2, -1, 1))
+    fwd = dmat.argmin(axis=1)
+    score = dmat[np.arange(dmat.shape[0]), fwd]
+    back = dmat.argmin(axis=0)
+    keep = (score < nn_thresh) & (np.arange(len(fwd)) == back[fwd])
+    m = np.zeros((3, int(keep.sum())))
+    m[0], m[1], m[2] = np.arange(desc1.shape[1])[keep], fwd[keep], score[keep]
+    return m

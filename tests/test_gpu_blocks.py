@@ -1,0 +1,117 @@
+"""GPU parity of the conv / block kernels against the CPU oracle (called through the C ABI via
+the module API).  Tolerances: TOL in helpers.py (fp32 path 1e-4, f16 4e-3, bf16 3e-2 of max|ref|)."""
+import pytest
+import torch
+
+from helpers import block_state, rel_err, TOL
+from oracle import net_oracle
+from yolopoint_amd import _hip
+from yolopoint_amd.models.common import Conv, Bottleneck, C3, SPPF
+from yolopoint_amd.plan import PlanBuilder, pack_input, unpack_nchw, round_up
+
+pytestmark = pytest.mark.gpu
+
+CONV_CASES = [
+    # c1, c2, k, s, p, B, H, W
+    (3, 16, 6, 2, 2, 2, 64, 64),      # stem (paired-pixel path for 16-bit types)
+    (3, 32, 6, 2, 2, 1, 96, 160),
+    (16, 32, 3, 2, 1, 2, 32, 32),
+    (32, 32, 1, 1, 0, 2, 40, 24),
+    (64, 64, 3, 1, 1, 1, 20, 20),
+    (128, 64, 1, 1, 0, 3, 17, 13),    # ragged M
+    (64, 128, 3, 2, 1, 2, 18, 22),
+    (256, 512, 3, 2, 1, 1, 12, 12),
+    (512, 256, 1, 1, 0, 1, 7, 9),
+    (8, 8, 3, 1, 1, 1, 9, 9),         # C3 hidden width of YOLOPoint-n
+]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_block(cuda, case, dtype):
+    c1, c2, k, s, p, B, H, W = case
+    m = Conv(c1, c2, k, s, p).eval()
+    m.compute_dtype = dtype
+    sd = block_state(m, 11, "blk.")
+    x = net_oracle.synth_image(B, c1, H, W, 5) - 0.5
+    ref = net_oracle.conv_block(sd, "blk", x, k, s, p)
+    got = m.to(cuda)(x.to(cuda))
+    e_max, e_l2 = rel_err(got, ref)
+    assert e_max < TOL[dtype], (case, dtype, e_max, e_l2)
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_conv_every_tile_config(cuda, tile, dtype):
+    """Force each tile template on a shape with ragged M / N tails, a residual and a sliced output."""
+    torch.manual_seed(0)
+    B, H, W, c1, c2 = 2, 19, 23, 64, 136
+    code = _hip.dtype_code(dtype)
+    w = torch.randn(c2, c1, 3, 3) * 0.05
+    b = torch.randn(c2) * 0.1
+    x = torch.randn(B, c1, H, W)
+    r = torch.randn(B, c2, H, W)
+    ref = torch.nn.functional.silu(torch.nn.functional.conv2d(x, w, b, 1, 1)) + r
+    pb = PlanBuilder(B, code, cuda)
+    xin = pb.new_buf(H, W, c1)
+    res = pb.new_buf(H, W, c2)
+    big = pb.new_buf(H, W, c2 + 16)
+    out = pb.conv(xin.view(), w, b, 3, 1, 1, _hip.YP_ACT_SILU, out=big.view(8, c2), res=res.view(), tile=tile)
+    plan = pb.finish()
+    pack_input(x.to(cuda), xin.view(), code)
+    pack_input(r.to(cuda), res.view(), code)
+    plan.run()
+    got = unpack_nchw(out, code, B, c2)
+    e_max, _ = rel_err(got, ref)
+    assert e_max < TOL[dtype], (tile, dtype, e_max)
+    # the 8 channels either side of the slice must stay untouched (zero)
+    assert float(big.t[..., :8].abs().max()) == 0.0 and float(big.t[..., 8 + c2:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_conv_two_sources_and_upsample(cuda, dtype):
+    """cat((ups(a), b), 1) -> 1x1 conv without materialising either the upsample or the concat."""
+    torch.manual_seed(1)
+    B, H, W = 2, 10, 14
+    code = _hip.dtype_code(dtype)
+    a = torch.randn(B, 32, H // 2, W // 2)
+    b2 = torch.randn(B, 24, H, W)
+    w = torch.randn(40, 56, 3, 3) * 0.05
+    ref = torch.nn.functional.conv2d(torch.cat((torch.nn.functional.interpolate(a, scale_factor=2, mode="nearest"), b2), 1), w, None, 1, 1)
+    pb = PlanBuilder(B, code, cuda)
+    ba, bb = pb.new_buf(H // 2, W // 2, 32), pb.new_buf(H, W, 24)
+    out = pb.conv([ba.view().up(), bb.view()], w, None, 3, 1, 1, _hip.YP_ACT_NONE)
+    plan = pb.finish()
+    pack_input(a.to(cuda), ba.view(), code)
+    pack_input(b2.to(cuda), bb.view(), code)
+    plan.run()
+    e_max, _ = rel_err(unpack_nchw(out, code, B, 40), ref)
+    assert e_max < TOL[dtype], e_max
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("kind", ["bottleneck", "c3_n1", "c3_n3", "sppf"])
+def test_blocks(cuda, kind, dtype):
+    B, H, W = 2, 20, 20
+    if kind == "bottleneck":
+        m, c1 = Bottleneck(32, 32, True, e=1.0), 32
+        fn = lambda sd, x: net_oracle.bottleneck(sd, "blk", x)
+    elif kind == "c3_n1":
+        m, c1 = C3(64, 64, 1), 64
+        fn = lambda sd, x: net_oracle.c3(sd, "blk", x, 1)
+    elif kind == "c3_n3":
+        m, c1 = C3(128, 64, 3), 128
+        fn = lambda sd, x: net_oracle.c3(sd, "blk", x, 3)
+    else:
+        m, c1 = SPPF(128, 128, 5), 128
+        fn = lambda sd, x: net_oracle.sppf(sd, "blk", x)
+    m.eval()
+    for mod in m.modules():
+        if hasattr(mod, "compute_dtype"):
+            mod.compute_dtype = dtype
+    sd = block_state(m, 3, "blk.")
+    x = net_oracle.synth_image(B, c1, H, W, 9) - 0.5
+    ref = fn(sd, x)
+    got = m.to(cuda)(x.to(cuda))
+    e_max, _ = rel_err(got, ref)
+    assert e_max < TOL[dtype] * 2, (kind, dtype, e_max)

@@ -1,0 +1,117 @@
+"""ctypes binding of libyolopoint_hip.so (the C ABI declared in include/yolopoint_hip.h).
+
+The library is the product: there is no CPU fallback.  Importing this module never touches a
+GPU (so the symbol table can be checked on a CPU-only host); calling a compute entry point
+without a HIP device raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libyolopoint_hip.so")
+
+YP_F16, YP_BF16, YP_F32 = 0, 1, 2
+YP_ACT_NONE, YP_ACT_SILU = 0, 1
+
+
+class YpError(RuntimeError):
+    pass
+
+
+class YpView(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("H", C.c_int32), ("W", C.c_int32), ("cstride", C.c_int32),
+                ("coff", C.c_int32), ("C", C.c_int32), ("ups", C.c_int32)]
+
+
+class YpConvDesc(C.Structure):
+    _fields_ = [("in0", YpView), ("in1", YpView), ("out", YpView), ("res", YpView),
+                ("weight", C.c_void_p), ("bias", C.c_void_p),
+                ("dtype", C.c_int32), ("out_f32", C.c_int32), ("B", C.c_int32),
+                ("Hi", C.c_int32), ("Wi", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
+                ("R", C.c_int32), ("S", C.c_int32),
+                ("stride_h", C.c_int32), ("stride_w", C.c_int32), ("pad_h", C.c_int32), ("pad_w", C.c_int32),
+                ("Kpad", C.c_int32), ("Npad", C.c_int32), ("act", C.c_int32), ("tile", C.c_int32)]
+
+
+_i, _f, _p, _sz, _i64 = C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_int64
+# name -> (restype, argtypes); must list every symbol of include/yolopoint_hip.h
+SIGNATURES = {
+    "yp_last_error": (C.c_char_p, []),
+    "yp_version": (_i, []),
+    "yp_device_count": (_i, []),
+    "yp_conv2d": (_i, [C.POINTER(YpConvDesc), _p]),
+    "yp_conv_kpad": (_i, [_i, _i]),
+    "yp_pack_input": (_i, [_p, _i, _i, _i, _i, YpView, _i, _p]),
+    "yp_unpack_nchw": (_i, [YpView, _i, _i, _i, _p, _p]),
+    "yp_sppf_pool": (_i, [YpView, YpView, YpView, YpView, _i, _i, _p]),
+    "yp_l2norm_f32": (_i, [YpView, YpView, _i, _i, _p]),
+    "yp_detect_decode": (_i, [YpView, _i, _i, _i, _f, C.POINTER(_f), _p, _p, _i, _i, _p]),
+    "yp_kp_decode": (_i, [_p, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _p, _p]),
+    "yp_kp_nms_workspace_bytes": (_sz, [_i, _i, _i]),
+    "yp_kp_nms": (_i, [_p, _i, _i, _i, _f, _i, _i, _p, _p, _i, _p, _sz, _p]),
+    "yp_box_nms_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "yp_box_nms": (_i, [_p, _i, _i, _i, _f, _f, _i, _i, _i, _i, _f, _p, _p, _p, _sz, _p]),
+    "yp_desc_sample": (_i, [_p, _i, _i, _i, _i64, _i64, _i64, _p, _i, _i, _p, _p]),
+    "yp_mnn_workspace_bytes": (_sz, [_i, _i]),
+    "yp_mnn_match": (_i, [_p, _i, _p, _i, _i, _f, _p, _p, _i, _p, _sz, _p]),
+    "yp_plan_create": (_i, [C.POINTER(_p)]),
+    "yp_plan_destroy": (_i, [_p]),
+    "yp_plan_add_conv": (_i, [_p, C.POINTER(YpConvDesc)]),
+    "yp_plan_add_sppf_pool": (_i, [_p, YpView, YpView, YpView, YpView, _i, _i]),
+    "yp_plan_add_l2norm": (_i, [_p, YpView, YpView, _i, _i]),
+    "yp_plan_add_detect_decode": (_i, [_p, YpView, _i, _i, _i, _f, C.POINTER(_f), _p, _p, _i, _i]),
+    "yp_plan_num_ops": (_i, [_p]),
+    "yp_plan_instantiate_graph": (_i, [_p, _p]),
+    "yp_plan_run": (_i, [_p, _p]),
+    "yp_plan_profile": (_i, [_p, _p, C.POINTER(_f)]),
+    "yp_plan_time": (_i, [_p, _p, _i, C.POINTER(_f)]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (built by __graft_entry__.build()); fail loudly when absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise YpError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback)")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise YpError(f"libyolopoint_hip error {rc}: {lib().yp_last_error().decode()}")
+
+
+def require_gpu():
+    if lib().yp_device_count() < 1:
+        raise YpError("no HIP device: the YOLOPoint hot path runs on MI355X only (no CPU fallback)")
+
+
+def stream_ptr(stream=None):
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return C.c_void_p(s.cuda_stream)
+
+
+def dtype_code(dt):
+    import torch
+    if dt in (YP_F16, YP_BF16, YP_F32):
+        return dt
+    table = {torch.float16: YP_F16, torch.bfloat16: YP_BF16, torch.float32: YP_F32,
+             "f16": YP_F16, "fp16": YP_F16, "bf16": YP_BF16, "f32": YP_F32, "fp32": YP_F32}
+    if dt not in table:
+        raise YpError(f"unsupported compute dtype {dt!r}")
+    return table[dt]
+
+
+def torch_dtype(code):
+    import torch
+    return {YP_F16: torch.float16, YP_BF16: torch.bfloat16, YP_F32: torch.float32}[code]

@@ -1,0 +1,413 @@
+// Fused implicit-GEMM convolution for gfx950 (MI355X), NHWC, MFMA 16x16.
+//
+//   out[m, n] = [res[m, n] +] act( sum_k X[m, k] * Wt[n, k] + bias[n] )
+//   m = (b, ho, wo) output pixel, n = output channel, k = (r, s, c) filter tap x input channel.
+//
+// There is no im2col buffer: the loader gathers 16-byte channel chunks of the input pixel each
+// (m, tap) touches straight into LDS (zero-filled where the tap falls into the padding) — the
+// "A" side of the GEMM exists only as an addressing rule.  Two input sources are supported so
+// that torch.cat((a, b), 1) feeding a conv is never materialised, and a source can be read
+// through a 2x nearest upsample (pixel (y,x) -> (y>>1, x>>1)).
+//
+// MFMA operand roles are swapped w.r.t. the textbook GEMM: the weight tile is the MFMA "A"
+// operand (rows = output channels) and the pixel tile the "B" operand (columns = pixels).  The
+// accumulator layout is then D[channel = 4*(lane/16)+reg][pixel = lane%16]: each lane owns 4
+// consecutive channels of one pixel per fragment.  Weight rows are permuted when they are
+// written to LDS so that the FN fragments of a wave interleave to 4*FN *consecutive* channels
+// per lane -> the epilogue stores (and the residual loads) are 16-byte vectors of one pixel,
+// contiguous in NHWC.
+//
+// Reference call sites replaced: models/common.py:22-34 (Conv), :88-89 (Bottleneck add),
+// :135,:229 (cat), models/YOLOPoint.py:186,195 (head convs), models/yolo.py:51 (Detect.m).
+#include "yp_internal.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+template <int DT> struct Elem;
+template <> struct Elem<YP_F16> {
+    using frag = f16x8;
+    using scalar = _Float16;
+    static constexpr int BYTES = 2, KPL = 8, KM = 32;
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Elem<YP_BF16> {
+    using frag = bf16x8;
+    using scalar = __bf16;
+    static constexpr int BYTES = 2, KPL = 8, KM = 32;
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Elem<YP_F32> {
+    using frag = float;
+    using scalar = float;
+    static constexpr int BYTES = 4, KPL = 1, KM = 4;
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+};
+
+struct ConvKArgs {
+    const char* in0;
+    const char* in1;
+    const char* wgt;
+    const float* bias;
+    const char* res;
+    char* out;
+    int in0_cs, in0_co, in0_C, in0_ups, in0_H, in0_W;
+    int in1_cs, in1_co, in1_ups, in1_H, in1_W;
+    int res_cs, res_co, has_res;
+    int out_cs, out_co;
+    int Hi, Wi, Wo, HoWo;
+    int Cin, Cout, Kreal, Kpad, Npad;
+    int R, S, sh, sw, ph, pw;
+    int act;
+    int M, tiles_n;
+};
+
+__device__ __forceinline__ float yp_silu(float x) {
+    // x * sigmoid(x); __expf -> v_exp_f32, the divide -> v_rcp_f32 (rel. error ~1e-7)
+    return x * __frcp_rn(1.0f + __expf(-x));
+}
+
+template <int DT, bool OUT_F32, int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
+    using E = Elem<DT>;
+    using frag_t = typename E::frag;
+    constexpr int EB = E::BYTES;
+    constexpr int CE = 16 / EB;          // elements per 16-byte chunk
+    constexpr int BK = 64 / EB;          // k elements per tile (64 bytes of k per row)
+    constexpr int CH = 4;                // chunks per LDS row
+    constexpr int ROWB = 64 + 16;        // padded LDS row pitch in bytes
+    constexpr int RPP = 256 / CH;        // rows filled per loader pass (64)
+    constexpr int AI = BM / RPP;
+    constexpr int BI = (BN + RPP - 1) / RPP;
+    constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N;
+    constexpr int FM = TM / 16, FN = TN / 16;
+    constexpr int LPG = 4 * FN;          // consecutive channels owned by one lane
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    static_assert(AI >= 1 && FM >= 1 && FN >= 1, "tile too small");
+
+    __shared__ __attribute__((aligned(16))) char smem[2][(BM + BN) * ROWB];
+
+    // ---- XCD-aware tile mapping: workgroup b runs on XCD b%8; give each XCD a contiguous run of
+    // logical tiles so that tiles sharing input pixels / filter rows hit the same L2.
+    const int nblk = gridDim.x;
+    int logical;
+    {
+        const int bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = logical % a.tiles_n;
+    const int tile_m = logical / a.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int t = threadIdx.x;
+    const int jc = t & (CH - 1);         // chunk column handled by this thread
+    const int r0 = t / CH;               // first row handled by this thread
+
+    // ---- per-row gather state (fixed for the whole k loop)
+    int hi0[AI], wi0[AI], bb[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int m = m0 + r0 + i * RPP;
+        if (m < a.M) {
+            const int b = m / a.HoWo;
+            const int rem = m - b * a.HoWo;
+            const int ho = rem / a.Wo;
+            const int wo = rem - ho * a.Wo;
+            hi0[i] = ho * a.sh - a.ph;
+            wi0[i] = wo * a.sw - a.pw;
+            bb[i] = b;
+        } else {
+            hi0[i] = -(1 << 28);
+            wi0[i] = 0;
+            bb[i] = 0;
+        }
+    }
+    // ---- per-thread filter-tap state for chunk column jc: k = kt*BK + jc*CE = (r*S + s)*Cin + c
+    int kc, ks, kr;
+    {
+        const int k = jc * CE;
+        const int tap = k / a.Cin;
+        kc = k - tap * a.Cin;
+        kr = tap / a.S;
+        ks = tap - kr * a.S;
+    }
+
+    // ---- LDS write offsets
+    int a_wr[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) a_wr[i] = (r0 + i * RPP) * ROWB + jc * 16;
+    int b_wr[BI];
+    bool b_ok[BI];
+    const char* b_src[BI];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const int nl = r0 + i * RPP;     // tile-local output channel
+        const int n = n0 + nl;
+        b_ok[i] = (nl < BN) && (n < a.Npad);
+        // permute: channel c' = g*LPG + f*4 + r (within a wave's TN span) -> MFMA row f*16 + g*4 + r
+        const int wn = nl / TN, cp = nl % TN;
+        const int g = cp / LPG, f = (cp % LPG) >> 2, r = cp & 3;
+        b_wr[i] = BM * ROWB + (wn * TN + f * 16 + g * 4 + r) * ROWB + jc * 16;
+        b_src[i] = a.wgt + ((size_t)n * a.Kpad + jc * CE) * EB;
+    }
+
+    u32x4 areg[AI], breg[BI];
+    auto load_tile = [&](int kt) {
+        const bool tapok = kr < a.R;
+        const bool s0 = kc < a.in0_C;
+        const char* base = s0 ? a.in0 : a.in1;
+        const int cs = s0 ? a.in0_cs : a.in1_cs;
+        const int cc = s0 ? (a.in0_co + kc) : (a.in1_co + kc - a.in0_C);
+        const int ups = s0 ? a.in0_ups : a.in1_ups;
+        const int Hp = s0 ? a.in0_H : a.in1_H;
+        const int Wp = s0 ? a.in0_W : a.in1_W;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int hi = hi0[i] + kr, wi = wi0[i] + ks;
+            const bool ok = tapok && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (ok) {
+                const size_t pix = ((size_t)bb[i] * Hp + (hi >> ups)) * Wp + (wi >> ups);
+                v = *reinterpret_cast<const u32x4*>(base + (pix * cs + cc) * EB);
+            }
+            areg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (b_ok[i]) v = *reinterpret_cast<const u32x4*>(b_src[i] + (size_t)kt * BK * EB);
+            breg[i] = v;
+        }
+        // advance the tap state to the next k tile
+        kc += BK;
+        while (kc >= a.Cin) {
+            kc -= a.Cin;
+            if (++ks == a.S) { ks = 0; ++kr; }
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char* s = smem[buf];
+#pragma unroll
+        for (int i = 0; i < AI; ++i) *reinterpret_cast<u32x4*>(s + a_wr[i]) = areg[i];
+#pragma unroll
+        for (int i = 0; i < BI; ++i)
+            if (BN >= RPP * (i + 1) || (r0 + i * RPP) < BN) *reinterpret_cast<u32x4*>(s + b_wr[i]) = breg[i];
+    };
+
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+    const int p = lane & 15, g = lane >> 4;
+    const int a_rd = (wm * TM + p) * ROWB + g * E::KPL * EB;
+    const int b_rd = BM * ROWB + (wn * TN + p) * ROWB + g * E::KPL * EB;
+
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int f = 0; f < FN; ++f)
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) acc[f][fm] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (a.Kreal + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const char* s = smem[cur];
+#pragma unroll
+        for (int kk = 0; kk < BK / E::KM; ++kk) {
+            frag_t wf[FN], xf[FM];
+#pragma unroll
+            for (int f = 0; f < FN; ++f)
+                wf[f] = *reinterpret_cast<const frag_t*>(s + b_rd + f * 16 * ROWB + kk * E::KM * EB);
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm)
+                xf[fm] = *reinterpret_cast<const frag_t*>(s + a_rd + fm * 16 * ROWB + kk * E::KM * EB);
+#pragma unroll
+            for (int f = 0; f < FN; ++f)
+#pragma unroll
+                for (int fm = 0; fm < FM; ++fm) acc[f][fm] = E::mma(wf[f], xf[fm], acc[f][fm]);
+        }
+        if (kt + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias -> activation -> (+ residual) -> store, 16-byte vectors per pixel
+    constexpr int CW = LPG < 8 ? LPG : 8;    // channels per store chunk
+    constexpr int NCH = LPG / CW;
+    const int nb = n0 + wn * TN + g * LPG;
+    float bias[LPG];
+#pragma unroll
+    for (int j = 0; j < LPG; ++j) bias[j] = (a.bias != nullptr && nb + j < a.Cout) ? a.bias[nb + j] : 0.f;
+
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) {
+        const int m = m0 + wm * TM + fm * 16 + p;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int h = 0; h < NCH; ++h) {
+            const int nc = nb + h * CW;
+            if (nc >= a.Cout) continue;
+            float v[CW];
+#pragma unroll
+            for (int j = 0; j < CW; ++j) {
+                const int cj = h * CW + j;            // lane-local channel = f*4 + r
+                float x = acc[cj >> 2][fm][cj & 3] + bias[cj];
+                if (a.act == YP_ACT_SILU) x = yp_silu(x);
+                v[j] = x;
+            }
+            if (a.has_res) {
+                const char* rp = a.res + ((size_t)m * a.res_cs + a.res_co + nc) * EB;
+                if constexpr (DT == YP_F32) {
+#pragma unroll
+                    for (int j = 0; j < CW; j += 4) {
+                        const f32x4 r4 = *reinterpret_cast<const f32x4*>(rp + j * 4);
+                        v[j] += r4[0]; v[j + 1] += r4[1]; v[j + 2] += r4[2]; v[j + 3] += r4[3];
+                    }
+                } else {
+                    using sc = typename E::scalar;
+                    if constexpr (CW == 8) {
+                        const u32x4 raw = *reinterpret_cast<const u32x4*>(rp);
+                        const sc* e = reinterpret_cast<const sc*>(&raw);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
+                    } else {
+                        const u32x2 raw = *reinterpret_cast<const u32x2*>(rp);
+                        const sc* e = reinterpret_cast<const sc*>(&raw);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += (float)e[j];
+                    }
+                }
+            }
+            if constexpr (OUT_F32 || DT == YP_F32) {
+                char* op = a.out + ((size_t)m * a.out_cs + a.out_co + nc) * 4;
+#pragma unroll
+                for (int j = 0; j < CW; j += 4)
+                    *reinterpret_cast<f32x4*>(op + j * 4) = f32x4{v[j], v[j + 1], v[j + 2], v[j + 3]};
+            } else {
+                using sc = typename E::scalar;
+                char* op = a.out + ((size_t)m * a.out_cs + a.out_co + nc) * 2;
+                if constexpr (CW == 8) {
+                    u32x4 pk;
+                    sc* e = reinterpret_cast<sc*>(&pk);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) e[j] = (sc)v[j];
+                    *reinterpret_cast<u32x4*>(op) = pk;
+                } else {
+                    u32x2 pk;
+                    sc* e = reinterpret_cast<sc*>(&pk);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) e[j] = (sc)v[j];
+                    *reinterpret_cast<u32x2*>(op) = pk;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct TileCfg { int id, bm, bn; };
+constexpr TileCfg kTiles[] = {{1, 128, 32}, {2, 128, 64}, {3, 128, 128}, {4, 64, 64}, {5, 64, 32}};
+
+template <int DT, bool OUT_F32>
+hipError_t launch_cfg(int tile, const ConvKArgs& a, int nblk, hipStream_t st) {
+    switch (tile) {
+        case 1: conv_igemm_kernel<DT, OUT_F32, 128, 32, 4, 1><<<nblk, 256, 0, st>>>(a); break;
+        case 2: conv_igemm_kernel<DT, OUT_F32, 128, 64, 4, 1><<<nblk, 256, 0, st>>>(a); break;
+        case 3: conv_igemm_kernel<DT, OUT_F32, 128, 128, 2, 2><<<nblk, 256, 0, st>>>(a); break;
+        case 4: conv_igemm_kernel<DT, OUT_F32, 64, 64, 2, 2><<<nblk, 256, 0, st>>>(a); break;
+        case 5: conv_igemm_kernel<DT, OUT_F32, 64, 32, 4, 1><<<nblk, 256, 0, st>>>(a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+int pick_tile(int M, int N) {
+    auto blocks = [&](int bm, int bn) { return (long)yp_cdiv(M, bm) * yp_cdiv(N, bn); };
+    const long fill = 2 * 256;   // >= 2 workgroups per CU before a bigger tile is worth it
+    if (N <= 32) return blocks(128, 32) >= fill ? 1 : 5;
+    if (N >= 128 && blocks(128, 128) >= fill) return 3;
+    if (blocks(128, 64) >= fill) return 2;
+    return 4;
+}
+
+}  // namespace
+
+extern "C" int yp_conv_kpad(int K, int dtype) {
+    const int g = dtype == YP_F32 ? 32 : 64;   // 128 bytes of k per packed row granule
+    return yp_cdiv(K, g) * g;
+}
+
+int yp_conv2d_launch(const YpConvDesc* d, hipStream_t stream) {
+    YP_REQUIRE(d != nullptr, "yp_conv2d: null descriptor");
+    YP_REQUIRE(d->dtype == YP_F16 || d->dtype == YP_BF16 || d->dtype == YP_F32, "yp_conv2d: bad dtype %d", d->dtype);
+    const int ce = d->dtype == YP_F32 ? 4 : 8;
+    const int Cin = d->in0.C + d->in1.C;
+    const int Cout = d->out.C;
+    YP_REQUIRE(d->in0.ptr && d->out.ptr && d->weight, "yp_conv2d: null buffer");
+    YP_REQUIRE(d->in0.C > 0 && d->in0.C % ce == 0 && d->in1.C % ce == 0, "yp_conv2d: input channels (%d,%d) must be multiples of %d", d->in0.C, d->in1.C, ce);
+    YP_REQUIRE(d->in0.cstride % ce == 0 && d->in0.coff % ce == 0, "yp_conv2d: in0 slice not 16-byte aligned");
+    YP_REQUIRE(d->in1.C == 0 || (d->in1.ptr && d->in1.cstride % ce == 0 && d->in1.coff % ce == 0), "yp_conv2d: in1 slice not 16-byte aligned");
+    YP_REQUIRE(Cout > 0 && Cout % 8 == 0 && d->out.cstride % 8 == 0 && d->out.coff % 8 == 0, "yp_conv2d: output slice (C=%d cs=%d co=%d) must be multiples of 8", Cout, d->out.cstride, d->out.coff);
+    YP_REQUIRE(d->res.C == 0 || (d->res.ptr && d->res.C == Cout && d->res.cstride % 8 == 0 && d->res.coff % 8 == 0 && !d->out_f32), "yp_conv2d: bad residual view");
+    YP_REQUIRE(d->B > 0 && d->Ho > 0 && d->Wo > 0 && d->R > 0 && d->S > 0, "yp_conv2d: bad dims");
+    YP_REQUIRE(d->in0.ups >= 0 && d->in0.ups <= 1 && d->in1.ups >= 0 && d->in1.ups <= 1, "yp_conv2d: ups must be 0/1");
+    YP_REQUIRE((d->in0.H << d->in0.ups) == d->Hi && (d->in0.W << d->in0.ups) == d->Wi, "yp_conv2d: in0 %dx%d<<%d != logical %dx%d", d->in0.H, d->in0.W, d->in0.ups, d->Hi, d->Wi);
+    YP_REQUIRE(d->in1.C == 0 || ((d->in1.H << d->in1.ups) == d->Hi && (d->in1.W << d->in1.ups) == d->Wi), "yp_conv2d: in1 dims mismatch");
+    YP_REQUIRE(d->out.H == d->Ho && d->out.W == d->Wo, "yp_conv2d: out view dims mismatch");
+    YP_REQUIRE((d->Hi + 2 * d->pad_h - d->R) / d->stride_h + 1 == d->Ho && (d->Wi + 2 * d->pad_w - d->S) / d->stride_w + 1 == d->Wo, "yp_conv2d: Ho/Wo inconsistent with input, filter, stride, pad");
+    const int Kreal = d->R * d->S * Cin;
+    YP_REQUIRE(d->Kpad >= Kreal && d->Kpad % (d->dtype == YP_F32 ? 16 : 32) == 0, "yp_conv2d: Kpad %d invalid for K=%d", d->Kpad, Kreal);
+    YP_REQUIRE(d->Npad >= Cout, "yp_conv2d: Npad %d < Cout %d", d->Npad, Cout);
+    const long Ml = (long)d->B * d->Ho * d->Wo;
+    YP_REQUIRE(Ml < (1l << 30), "yp_conv2d: too many output pixels");
+
+    ConvKArgs a{};
+    a.in0 = (const char*)d->in0.ptr; a.in1 = (const char*)(d->in1.C ? d->in1.ptr : d->in0.ptr);
+    a.wgt = (const char*)d->weight; a.bias = d->bias; a.res = (const char*)d->res.ptr; a.out = (char*)d->out.ptr;
+    a.in0_cs = d->in0.cstride; a.in0_co = d->in0.coff; a.in0_C = d->in0.C; a.in0_ups = d->in0.ups; a.in0_H = d->in0.H; a.in0_W = d->in0.W;
+    a.in1_cs = d->in1.cstride; a.in1_co = d->in1.coff; a.in1_ups = d->in1.ups; a.in1_H = d->in1.H; a.in1_W = d->in1.W;
+    a.res_cs = d->res.cstride; a.res_co = d->res.coff; a.has_res = d->res.C != 0;
+    a.out_cs = d->out.cstride; a.out_co = d->out.coff;
+    a.Hi = d->Hi; a.Wi = d->Wi; a.Wo = d->Wo; a.HoWo = d->Ho * d->Wo;
+    a.Cin = Cin; a.Cout = Cout; a.Kreal = Kreal; a.Kpad = d->Kpad; a.Npad = d->Npad;
+    a.R = d->R; a.S = d->S; a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w;
+    a.act = d->act; a.M = (int)Ml;
+
+    int tile = d->tile ? d->tile : pick_tile(a.M, Cout);
+    const TileCfg* tc = nullptr;
+    for (const auto& c : kTiles) if (c.id == tile) tc = &c;
+    YP_REQUIRE(tc != nullptr, "yp_conv2d: unknown tile id %d", tile);
+    a.tiles_n = yp_cdiv(Cout, tc->bn);
+    const int nblk = yp_cdiv(a.M, tc->bm) * a.tiles_n;
+
+    hipError_t e;
+    const bool of32 = d->out_f32 != 0;
+    switch (d->dtype) {
+        case YP_F16: e = of32 ? launch_cfg<YP_F16, true>(tile, a, nblk, stream) : launch_cfg<YP_F16, false>(tile, a, nblk, stream); break;
+        case YP_BF16: e = of32 ? launch_cfg<YP_BF16, true>(tile, a, nblk, stream) : launch_cfg<YP_BF16, false>(tile, a, nblk, stream); break;
+        default: e = launch_cfg<YP_F32, false>(tile, a, nblk, stream); break;
+    }
+    if (e != hipSuccess) {
+        yp_set_error("yp_conv2d: launch failed: %s", hipGetErrorString(e));
+        return YP_ERR_HIP;
+    }
+    return YP_OK;
+}
+
+extern "C" int yp_conv2d(const YpConvDesc* d, void* stream) { return yp_conv2d_launch(d, (hipStream_t)stream); }

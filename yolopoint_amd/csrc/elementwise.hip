@@ -1,0 +1,243 @@
+// Layout, pooling, normalisation and Detect-decode kernels (HBM-bound, gfx950).
+#include "yp_internal.h"
+#include <cfloat>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+template <int DT> struct Sc;
+template <> struct Sc<YP_F16> { using t = _Float16; };
+template <> struct Sc<YP_BF16> { using t = __bf16; };
+template <> struct Sc<YP_F32> { using t = float; };
+
+// ------------------------------------------------------------------ NCHW fp32 -> NHWC dtype
+template <int DT>
+__global__ void pack_input_kernel(const float* __restrict__ x, int B, int C, int H, int W,
+                                  typename Sc<DT>::t* __restrict__ out, int cs, int co, int Cpad) {
+    using T = typename Sc<DT>::t;
+    const size_t npix = (size_t)B * H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t hw = (size_t)H * W;
+        const size_t b = i / hw, p = i - b * hw;
+        T* o = out + i * cs + co;
+        for (int c = 0; c < Cpad; ++c) {
+            const float v = c < C ? x[(b * C + c) * hw + p] : 0.f;
+            o[c] = (T)v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ NHWC view -> NCHW fp32
+template <int DT>
+__global__ void unpack_nchw_kernel(const typename Sc<DT>::t* __restrict__ in, int cs, int co, int B, int C,
+                                   int H, int W, float* __restrict__ out) {
+    const size_t hw = (size_t)H * W;
+    const size_t n = (size_t)B * C * hw;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i % hw;
+        const size_t bc = i / hw;
+        const size_t c = bc % C, b = bc / C;
+        out[i] = (float)in[(b * hw + p) * cs + co + c];
+    }
+}
+
+// ------------------------------------------------------------------ SPPF: 5/9/13 max windows
+// Chained MaxPool2d(5,1,2) with -inf padding equals direct 5x5 / 9x9 / 13x13 windows of x.
+// One thread per (pixel, 8-channel chunk); rows of the 13x13 window are reduced horizontally
+// once and folded into the three nested vertical windows.
+template <int DT>
+__global__ void sppf_pool_kernel(const char* __restrict__ x, int xcs, int xco, char* __restrict__ y1, int y1cs, int y1co,
+                                 char* __restrict__ y2, int y2cs, int y2co, char* __restrict__ y3, int y3cs, int y3co,
+                                 int B, int H, int W, int C) {
+    using T = typename Sc<DT>::t;
+    constexpr int CE = 16 / sizeof(T);
+    const int chunks = C / CE;
+    const size_t n = (size_t)B * H * W * chunks;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % chunks);
+        const size_t pix = i / chunks;
+        const int w = (int)(pix % W);
+        const int h = (int)((pix / W) % H);
+        const int b = (int)(pix / ((size_t)W * H));
+        float m5[CE], m9[CE], m13[CE];
+#pragma unroll
+        for (int j = 0; j < CE; ++j) m5[j] = m9[j] = m13[j] = -FLT_MAX;
+        for (int dy = -6; dy <= 6; ++dy) {
+            const int yy = h + dy;
+            if (yy < 0 || yy >= H) continue;
+            float r5[CE], r9[CE], r13[CE];
+#pragma unroll
+            for (int j = 0; j < CE; ++j) r5[j] = r9[j] = r13[j] = -FLT_MAX;
+            for (int dx = -6; dx <= 6; ++dx) {
+                const int xx = w + dx;
+                if (xx < 0 || xx >= W) continue;
+                const u32x4 raw = *reinterpret_cast<const u32x4*>(
+                    x + (((size_t)b * H + yy) * W + xx) * xcs * sizeof(T) + (size_t)(xco + ch * CE) * sizeof(T));
+                const T* e = reinterpret_cast<const T*>(&raw);
+                const int ax = dx < 0 ? -dx : dx;
+#pragma unroll
+                for (int j = 0; j < CE; ++j) {
+                    const float v = (float)e[j];
+                    r13[j] = fmaxf(r13[j], v);
+                    if (ax <= 4) r9[j] = fmaxf(r9[j], v);
+                    if (ax <= 2) r5[j] = fmaxf(r5[j], v);
+                }
+            }
+            const int ay = dy < 0 ? -dy : dy;
+#pragma unroll
+            for (int j = 0; j < CE; ++j) {
+                m13[j] = fmaxf(m13[j], r13[j]);
+                if (ay <= 4) m9[j] = fmaxf(m9[j], r9[j]);
+                if (ay <= 2) m5[j] = fmaxf(m5[j], r5[j]);
+            }
+        }
+        u32x4 o1, o2, o3;
+        T* e1 = reinterpret_cast<T*>(&o1);
+        T* e2 = reinterpret_cast<T*>(&o2);
+        T* e3 = reinterpret_cast<T*>(&o3);
+#pragma unroll
+        for (int j = 0; j < CE; ++j) { e1[j] = (T)m5[j]; e2[j] = (T)m9[j]; e3[j] = (T)m13[j]; }
+        const size_t po = pix;
+        *reinterpret_cast<u32x4*>(y1 + (po * y1cs + y1co + ch * CE) * sizeof(T)) = o1;
+        *reinterpret_cast<u32x4*>(y2 + (po * y2cs + y2co + ch * CE) * sizeof(T)) = o2;
+        *reinterpret_cast<u32x4*>(y3 + (po * y3cs + y3co + ch * CE) * sizeof(T)) = o3;
+    }
+}
+
+// ------------------------------------------------------------------ descriptor L2 norm (fp32)
+// one wavefront per pixel: lanes stride over channels, butterfly-reduce the sum of squares.
+__global__ void l2norm_kernel(const float* __restrict__ in, int ics, int ico, float* __restrict__ out, int ocs, int oco,
+                              size_t npix, int C) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t p = wave; p < npix; p += nwaves) {
+        const float* src = in + p * ics + ico;
+        float ss = 0.f;
+        for (int c = lane; c < C; c += 64) { const float v = src[c]; ss += v * v; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        const float nrm = sqrtf(ss);
+        float* dst = out + p * ocs + oco;
+        for (int c = lane; c < C; c += 64) dst[c] = src[c] / nrm;   // no epsilon: models/YOLOPoint.py:219-220
+    }
+}
+
+// ------------------------------------------------------------------ Detect decode
+struct Anchors { float wh[16]; };
+__global__ void detect_decode_kernel(const float* __restrict__ raw, int cs, int co, int B, int na, int no, int ny, int nx,
+                                     float stride, Anchors anc, float* __restrict__ x_out, float* __restrict__ z_out,
+                                     int rows_total, int row_offset) {
+    const size_t n = (size_t)B * na * ny * nx * no;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int o = (int)(i % no);
+        size_t r = i / no;
+        const int xx = (int)(r % nx); r /= nx;
+        const int yy = (int)(r % ny); r /= ny;
+        const int a = (int)(r % na);
+        const int b = (int)(r / na);
+        const float v = raw[(((size_t)b * ny + yy) * nx + xx) * cs + co + a * no + o];
+        x_out[i] = v;
+        if (z_out != nullptr) {
+            const float s = 1.0f / (1.0f + expf(-v));
+            float z;
+            if (o == 0) z = (s * 2.0f - 0.5f + (float)xx) * stride;
+            else if (o == 1) z = (s * 2.0f - 0.5f + (float)yy) * stride;
+            else if (o == 2) { const float t = s * 2.0f; z = t * t * anc.wh[a * 2]; }
+            else if (o == 3) { const float t = s * 2.0f; z = t * t * anc.wh[a * 2 + 1]; }
+            else z = s;
+            const size_t row = (size_t)row_offset + ((size_t)a * ny + yy) * nx + xx;
+            z_out[((size_t)b * rows_total + row) * no + o] = z;
+        }
+    }
+}
+
+inline int grid_for(size_t n, int block) {
+    size_t g = (n + block - 1) / block;
+    const size_t cap = 256 * 16;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" int yp_pack_input(const float* x, int B, int C, int H, int W, YpView out, int dtype, void* stream) {
+    YP_REQUIRE(x && out.ptr && B > 0 && C > 0 && H > 0 && W > 0, "yp_pack_input: bad arguments");
+    YP_REQUIRE(out.H == H && out.W == W && out.C >= C && out.coff + out.C <= out.cstride, "yp_pack_input: view mismatch");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t npix = (size_t)B * H * W;
+    const int g = grid_for(npix, 256);
+    switch (dtype) {
+        case YP_F16: pack_input_kernel<YP_F16><<<g, 256, 0, st>>>(x, B, C, H, W, (_Float16*)out.ptr, out.cstride, out.coff, out.C); break;
+        case YP_BF16: pack_input_kernel<YP_BF16><<<g, 256, 0, st>>>(x, B, C, H, W, (__bf16*)out.ptr, out.cstride, out.coff, out.C); break;
+        case YP_F32: pack_input_kernel<YP_F32><<<g, 256, 0, st>>>(x, B, C, H, W, (float*)out.ptr, out.cstride, out.coff, out.C); break;
+        default: YP_REQUIRE(false, "yp_pack_input: bad dtype %d", dtype);
+    }
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
+extern "C" int yp_unpack_nchw(YpView in, int src_dtype, int B, int C, float* out, void* stream) {
+    YP_REQUIRE(in.ptr && out && B > 0 && C > 0 && C <= in.C, "yp_unpack_nchw: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)B * C * in.H * in.W;
+    const int g = grid_for(n, 256);
+    switch (src_dtype) {
+        case YP_F16: unpack_nchw_kernel<YP_F16><<<g, 256, 0, st>>>((const _Float16*)in.ptr, in.cstride, in.coff, B, C, in.H, in.W, out); break;
+        case YP_BF16: unpack_nchw_kernel<YP_BF16><<<g, 256, 0, st>>>((const __bf16*)in.ptr, in.cstride, in.coff, B, C, in.H, in.W, out); break;
+        case YP_F32: unpack_nchw_kernel<YP_F32><<<g, 256, 0, st>>>((const float*)in.ptr, in.cstride, in.coff, B, C, in.H, in.W, out); break;
+        default: YP_REQUIRE(false, "yp_unpack_nchw: bad dtype %d", src_dtype);
+    }
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
+extern "C" int yp_sppf_pool(YpView x, YpView y1, YpView y2, YpView y3, int B, int dtype, void* stream) {
+    const int ce = dtype == YP_F32 ? 4 : 8;
+    YP_REQUIRE(x.ptr && y1.ptr && y2.ptr && y3.ptr && B > 0, "yp_sppf_pool: null view");
+    YP_REQUIRE(x.C > 0 && x.C % ce == 0 && y1.C == x.C && y2.C == x.C && y3.C == x.C, "yp_sppf_pool: channel mismatch");
+    YP_REQUIRE(y1.H == x.H && y1.W == x.W && y2.H == x.H && y3.H == x.H, "yp_sppf_pool: dims mismatch");
+    YP_REQUIRE(x.cstride % ce == 0 && x.coff % ce == 0 && y1.cstride % ce == 0 && y1.coff % ce == 0 && y2.cstride % ce == 0 &&
+                   y2.coff % ce == 0 && y3.cstride % ce == 0 && y3.coff % ce == 0, "yp_sppf_pool: slices must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)B * x.H * x.W * (x.C / ce);
+    const int g = grid_for(n, 256);
+#define YP_SPPF(DT)                                                                                               \
+    sppf_pool_kernel<DT><<<g, 256, 0, st>>>((const char*)x.ptr, x.cstride, x.coff, (char*)y1.ptr, y1.cstride, y1.coff, \
+                                            (char*)y2.ptr, y2.cstride, y2.coff, (char*)y3.ptr, y3.cstride, y3.coff, B, x.H, x.W, x.C)
+    switch (dtype) {
+        case YP_F16: YP_SPPF(YP_F16); break;
+        case YP_BF16: YP_SPPF(YP_BF16); break;
+        case YP_F32: YP_SPPF(YP_F32); break;
+        default: YP_REQUIRE(false, "yp_sppf_pool: bad dtype %d", dtype);
+    }
+#undef YP_SPPF
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
+extern "C" int yp_l2norm_f32(YpView in, YpView out, int B, int C, void* stream) {
+    YP_REQUIRE(in.ptr && out.ptr && B > 0 && C > 0 && C <= in.C && C <= out.C, "yp_l2norm_f32: bad arguments");
+    YP_REQUIRE(in.H == out.H && in.W == out.W, "yp_l2norm_f32: dims mismatch");
+    const size_t npix = (size_t)B * in.H * in.W;
+    const int g = grid_for(npix * 64, 256);
+    l2norm_kernel<<<g, 256, 0, (hipStream_t)stream>>>((const float*)in.ptr, in.cstride, in.coff, (float*)out.ptr, out.cstride,
+                                                     out.coff, npix, C);
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
+extern "C" int yp_detect_decode(YpView raw, int B, int na, int no, float stride, const float* anchors_px_host, float* x_out,
+                                float* z_out, int rows_total, int row_offset, void* stream) {
+    YP_REQUIRE(raw.ptr && x_out && anchors_px_host && B > 0 && na > 0 && na <= 8 && no > 5, "yp_detect_decode: bad arguments");
+    YP_REQUIRE(raw.C >= na * no, "yp_detect_decode: raw view has %d channels, need %d", raw.C, na * no);
+    Anchors anc{};
+    for (int i = 0; i < na * 2; ++i) anc.wh[i] = anchors_px_host[i];
+    const size_t n = (size_t)B * na * raw.H * raw.W * no;
+    const int g = grid_for(n, 256);
+    detect_decode_kernel<<<g, 256, 0, (hipStream_t)stream>>>((const float*)raw.ptr, raw.cstride, raw.coff, B, na, no, raw.H, raw.W,
+                                                            stride, anc, x_out, z_out, rows_total, row_offset);
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}

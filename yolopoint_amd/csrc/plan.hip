@@ -1,0 +1,200 @@
+// Error plumbing + the execution plan (an immutable launch list replayed natively, optionally
+// through a captured hipGraph).  The plan is what replaces the reference's Python
+// module-by-module dispatch (models/YOLOPoint.py:198-246): the host walks the module tree once,
+// emits descriptors, and every later forward is one C call.
+#include "yp_internal.h"
+#include <vector>
+#include <cstring>
+
+namespace {
+thread_local char g_err[512] = "";
+}
+
+void yp_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* yp_last_error(void) { return g_err; }
+extern "C" int yp_version(void) { return 100; }
+extern "C" int yp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+enum OpKind { OP_CONV = 0, OP_SPPF = 1, OP_L2NORM = 2, OP_DETECT = 3 };
+
+struct PlanOp {
+    int kind;
+    YpConvDesc conv;
+    YpView v[4];
+    int B, dtype, C, na, no, rows_total, row_offset;
+    float stride;
+    float anchors[16];
+    float* x_out;
+    float* z_out;
+};
+
+struct YpPlan {
+    std::vector<PlanOp> ops;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+static int run_op(const PlanOp& op, hipStream_t st) {
+    switch (op.kind) {
+        case OP_CONV: return yp_conv2d_launch(&op.conv, st);
+        case OP_SPPF: return yp_sppf_pool(op.v[0], op.v[1], op.v[2], op.v[3], op.B, op.dtype, st);
+        case OP_L2NORM: return yp_l2norm_f32(op.v[0], op.v[1], op.B, op.C, st);
+        case OP_DETECT:
+            return yp_detect_decode(op.v[0], op.B, op.na, op.no, op.stride, op.anchors, op.x_out, op.z_out, op.rows_total,
+                                    op.row_offset, st);
+    }
+    yp_set_error("plan: unknown op kind %d", op.kind);
+    return YP_ERR_INVALID;
+}
+
+extern "C" int yp_plan_create(YpPlan** plan) {
+    YP_REQUIRE(plan != nullptr, "yp_plan_create: null out pointer");
+    *plan = new (std::nothrow) YpPlan();
+    YP_REQUIRE(*plan != nullptr, "yp_plan_create: out of host memory");
+    return YP_OK;
+}
+
+extern "C" int yp_plan_destroy(YpPlan* plan) {
+    if (!plan) return YP_OK;
+    if (plan->exec) (void)hipGraphExecDestroy(plan->exec);
+    if (plan->graph) (void)hipGraphDestroy(plan->graph);
+    delete plan;
+    return YP_OK;
+}
+
+#define YP_PLAN_MUTABLE(plan)                                                            \
+    YP_REQUIRE((plan) != nullptr, "plan: null handle");                                   \
+    YP_REQUIRE((plan)->exec == nullptr, "plan: immutable after yp_plan_instantiate_graph")
+
+extern "C" int yp_plan_add_conv(YpPlan* plan, const YpConvDesc* d) {
+    YP_PLAN_MUTABLE(plan);
+    YP_REQUIRE(d != nullptr, "yp_plan_add_conv: null descriptor");
+    PlanOp op{};
+    op.kind = OP_CONV;
+    op.conv = *d;
+    plan->ops.push_back(op);
+    return YP_OK;
+}
+
+extern "C" int yp_plan_add_sppf_pool(YpPlan* plan, YpView x, YpView y1, YpView y2, YpView y3, int B, int dtype) {
+    YP_PLAN_MUTABLE(plan);
+    PlanOp op{};
+    op.kind = OP_SPPF;
+    op.v[0] = x; op.v[1] = y1; op.v[2] = y2; op.v[3] = y3;
+    op.B = B; op.dtype = dtype;
+    plan->ops.push_back(op);
+    return YP_OK;
+}
+
+extern "C" int yp_plan_add_l2norm(YpPlan* plan, YpView in, YpView out, int B, int C) {
+    YP_PLAN_MUTABLE(plan);
+    PlanOp op{};
+    op.kind = OP_L2NORM;
+    op.v[0] = in; op.v[1] = out;
+    op.B = B; op.C = C;
+    plan->ops.push_back(op);
+    return YP_OK;
+}
+
+extern "C" int yp_plan_add_detect_decode(YpPlan* plan, YpView raw, int B, int na, int no, float stride,
+                                         const float* anchors_px_host, float* x_out, float* z_out, int rows_total,
+                                         int row_offset) {
+    YP_PLAN_MUTABLE(plan);
+    YP_REQUIRE(anchors_px_host && na > 0 && na <= 8, "yp_plan_add_detect_decode: bad anchors");
+    PlanOp op{};
+    op.kind = OP_DETECT;
+    op.v[0] = raw;
+    op.B = B; op.na = na; op.no = no; op.stride = stride;
+    for (int i = 0; i < na * 2; ++i) op.anchors[i] = anchors_px_host[i];
+    op.x_out = x_out; op.z_out = z_out; op.rows_total = rows_total; op.row_offset = row_offset;
+    plan->ops.push_back(op);
+    return YP_OK;
+}
+
+extern "C" int yp_plan_num_ops(const YpPlan* plan) { return plan ? (int)plan->ops.size() : 0; }
+
+static int run_eager(YpPlan* plan, hipStream_t st) {
+    for (const PlanOp& op : plan->ops) {
+        const int rc = run_op(op, st);
+        if (rc != YP_OK) return rc;
+    }
+    return YP_OK;
+}
+
+extern "C" int yp_plan_instantiate_graph(YpPlan* plan, void* stream) {
+    YP_REQUIRE(plan != nullptr, "yp_plan_instantiate_graph: null plan");
+    YP_REQUIRE(plan->exec == nullptr, "yp_plan_instantiate_graph: already instantiated");
+    hipStream_t st = (hipStream_t)stream;
+    YP_REQUIRE(st != nullptr, "yp_plan_instantiate_graph: capture needs a non-default stream");
+    YP_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    const int rc = run_eager(plan, st);
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(st, &g);
+    if (rc != YP_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+    YP_CHECK_HIP(e);
+    plan->graph = g;
+    YP_CHECK_HIP(hipGraphInstantiate(&plan->exec, g, nullptr, nullptr, 0));
+    return YP_OK;
+}
+
+extern "C" int yp_plan_run(YpPlan* plan, void* stream) {
+    YP_REQUIRE(plan != nullptr, "yp_plan_run: null plan");
+    hipStream_t st = (hipStream_t)stream;
+    if (plan->exec) {
+        YP_CHECK_HIP(hipGraphLaunch(plan->exec, st));
+        return YP_OK;
+    }
+    return run_eager(plan, st);
+}
+
+extern "C" int yp_plan_profile(YpPlan* plan, void* stream, float* ms_out_host) {
+    YP_REQUIRE(plan != nullptr && ms_out_host != nullptr, "yp_plan_profile: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = plan->ops.size();
+    std::vector<hipEvent_t> ev(n + 1);
+    for (auto& e : ev) YP_CHECK_HIP(hipEventCreate(&e));
+    int rc = YP_OK;
+    YP_CHECK_HIP(hipEventRecord(ev[0], st));
+    for (size_t i = 0; i < n && rc == YP_OK; ++i) {
+        rc = run_op(plan->ops[i], st);
+        if (rc == YP_OK && hipEventRecord(ev[i + 1], st) != hipSuccess) rc = YP_ERR_HIP;
+    }
+    if (rc == YP_OK && hipStreamSynchronize(st) != hipSuccess) rc = YP_ERR_HIP;
+    if (rc == YP_OK)
+        for (size_t i = 0; i < n; ++i)
+            if (hipEventElapsedTime(&ms_out_host[i], ev[i], ev[i + 1]) != hipSuccess) rc = YP_ERR_HIP;
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    if (rc == YP_ERR_HIP) yp_set_error("yp_plan_profile: HIP event failure");
+    return rc;
+}
+
+extern "C" int yp_plan_time(YpPlan* plan, void* stream, int iters, float* ms_per_iter_host) {
+    YP_REQUIRE(plan != nullptr && ms_per_iter_host != nullptr && iters > 0, "yp_plan_time: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    YP_CHECK_HIP(hipEventCreate(&e0));
+    YP_CHECK_HIP(hipEventCreate(&e1));
+    YP_CHECK_HIP(hipEventRecord(e0, st));
+    int rc = YP_OK;
+    for (int i = 0; i < iters && rc == YP_OK; ++i) rc = yp_plan_run(plan, st);
+    if (rc == YP_OK) {
+        YP_CHECK_HIP(hipEventRecord(e1, st));
+        YP_CHECK_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        YP_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+        *ms_per_iter_host = ms / (float)iters;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}

@@ -1,0 +1,673 @@
+// Post-processing kernels: keypoint heat-map decode + greedy grid NMS, batched box NMS,
+// descriptor sampling and the mutual-nearest-neighbour matcher.
+//
+// Everything here is index-selection work whose results must equal the sequential reference
+// bit for bit (for distinct scores), so this file is compiled with -ffp-contract=off and the
+// float arithmetic follows the reference's operation order.
+#include "yp_internal.h"
+#include <cfloat>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
+
+namespace {
+
+inline int grid_for(size_t n, int block, size_t cap = 256 * 16) {
+    size_t g = (n + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+// =========================================================================================
+// keypoint decode: softmax(65) -> drop dustbin -> depth-to-space(8)
+// A workgroup owns one row of up to 32 cells; each wavefront reduces one cell at a time (lane c
+// holds channel c, the dustbin is read by every lane) and parks the 64 probabilities in an LDS
+// tile [8][256] that is then written out as whole 1 KiB heat-map rows.
+// =========================================================================================
+__global__ __launch_bounds__(256) void kp_decode_kernel(const float* __restrict__ semi, int B, int Hc, int Wc, long sb, long sc,
+                                                        long sy, long sx, int mode, float* __restrict__ heat) {
+    __shared__ float tile[8][32 * 8 + 1];
+    const int groups = (Wc + 31) / 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long nwork = (long)B * Hc * groups;
+    for (long wk = blockIdx.x; wk < nwork; wk += gridDim.x) {
+        const int gx = (int)(wk % groups);
+        const int hc = (int)((wk / groups) % Hc);
+        const int b = (int)(wk / ((long)groups * Hc));
+        const int w0 = gx * 32;
+        const int ncell = min(32, Wc - w0);
+        for (int ci = wave; ci < ncell; ci += 4) {
+            const float* p = semi + b * sb + hc * sy + (long)(w0 + ci) * sx;
+            const float x = p[lane * sc];
+            const float d = p[64 * sc];
+            float e, ed, s;
+            if (mode == 0) {
+                float m = x;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+                m = fmaxf(m, d);
+                e = expf(x - m);
+                ed = expf(d - m);
+                s = e;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+                s += ed;
+            } else {
+                e = expf(x);
+                ed = expf(d);
+                s = e;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+                s += ed;
+                s += 0.00001f;
+            }
+            tile[lane >> 3][ci * 8 + (lane & 7)] = e / s;
+        }
+        __syncthreads();
+        const int W = Wc * 8;
+        const int ncol = ncell * 8;
+        for (int i = threadIdx.x; i < 8 * ncol; i += 256) {
+            const int r = i / ncol, c = i - r * ncol;
+            heat[((long)b * Hc * 8 + hc * 8 + r) * W + w0 * 8 + c] = tile[r][c];
+        }
+        __syncthreads();
+    }
+}
+
+// =========================================================================================
+// keypoint greedy grid NMS.
+// The sequential reference visits candidates by descending score; a visited candidate that is
+// still alive is kept and kills every other candidate in its (2r+1)^2 window.  Equivalent
+// fix-point: p is KEPT once every higher-priority candidate in its window is SUPPRESSED, and
+// SUPPRESSED once a higher-priority candidate in its window is KEPT.  State transitions are
+// monotone and final, so any asynchronous evaluation order reaches the same fix-point; rounds
+// are separate launches, with an early-out on a per-round undecided counter.
+// =========================================================================================
+enum : unsigned char { KP_EMPTY = 0, KP_UNDECIDED = 1, KP_KEPT = 2, KP_SUPPRESSED = 3 };
+
+__global__ void kp_threshold_kernel(const float* __restrict__ heat, int B, int HW, float thr, unsigned char* __restrict__ state,
+                                    int* __restrict__ cand, int* __restrict__ ncand) {
+    const long n = (long)B * HW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / HW);
+        const bool c = heat[i] >= thr;
+        state[i] = c ? KP_UNDECIDED : KP_EMPTY;
+        if (c) {
+            const int pos = atomicAdd(&ncand[b], 1);
+            cand[(long)b * HW + pos] = (int)(i - (long)b * HW);
+        }
+    }
+}
+
+__device__ __forceinline__ bool kp_higher(float sq, int q, float sp, int p) { return sq > sp || (sq == sp && q < p); }
+
+__global__ void kp_round_kernel(const float* __restrict__ heat, int B, int H, int W, int radius, volatile unsigned char* state,
+                                const int* __restrict__ cand, const int* __restrict__ ncand, const int* prev_left,
+                                int* left) {
+    if (prev_left != nullptr && *prev_left == 0) return;
+    const int HW = H * W;
+    int undecided = 0;
+    for (int b = 0; b < B; ++b) {
+        const int nc = ncand[b];
+        const float* hb = heat + (long)b * HW;
+        volatile unsigned char* sb = state + (long)b * HW;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nc; i += gridDim.x * blockDim.x) {
+            const int p = cand[(long)b * HW + i];
+            if (sb[p] != KP_UNDECIDED) continue;
+            const int py = p / W, px = p - py * W;
+            const float sp = hb[p];
+            const int y0 = max(py - radius, 0), y1 = min(py + radius, H - 1);
+            const int x0 = max(px - radius, 0), x1 = min(px + radius, W - 1);
+            bool killed = false, blocked = false;
+            for (int y = y0; y <= y1 && !killed; ++y) {
+                for (int x = x0; x <= x1; ++x) {
+                    const int q = y * W + x;
+                    const unsigned char s = sb[q];   // a stale UNDECIDED only delays the decision
+                    if (s == KP_EMPTY || s == KP_SUPPRESSED || q == p) continue;
+                    if (!kp_higher(hb[q], q, sp, p)) continue;
+                    if (s == KP_KEPT) { killed = true; break; }
+                    blocked = true;     // an undecided higher-priority neighbour
+                }
+            }
+            if (killed) sb[p] = KP_SUPPRESSED;
+            else if (!blocked) sb[p] = KP_KEPT;
+            else ++undecided;
+        }
+    }
+    if (undecided) atomicAdd(left, undecided);
+}
+
+// kept candidates outside the border strip -> compact list (order arbitrary)
+__global__ void kp_collect_kernel(const float* __restrict__ heat, int B, int H, int W, int border, const unsigned char* __restrict__ state,
+                                  const int* __restrict__ cand, const int* __restrict__ ncand, int* __restrict__ kept,
+                                  int* __restrict__ nkept) {
+    const int HW = H * W;
+    for (int b = 0; b < B; ++b) {
+        const int nc = ncand[b];
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nc; i += gridDim.x * blockDim.x) {
+            const int p = cand[(long)b * HW + i];
+            if (state[(long)b * HW + p] != KP_KEPT) continue;
+            const int y = p / W, x = p - y * W;
+            if (x < border || x >= W - border || y < border || y >= H - border) continue;
+            const int pos = atomicAdd(&nkept[b], 1);
+            kept[(long)b * HW + pos] = p;
+        }
+    }
+}
+
+// rank-by-counting sort (score desc, index asc) of the kept list; writes (x, y, conf) rows.
+__global__ void kp_rank_kernel(const float* __restrict__ heat, int B, int H, int W, const int* __restrict__ kept,
+                               const int* __restrict__ nkept, float* __restrict__ out, int* __restrict__ out_count, int max_out) {
+    const int HW = H * W;
+    for (int b = 0; b < B; ++b) {
+        const int n = nkept[b];
+        const float* hb = heat + (long)b * HW;
+        const int* kb = kept + (long)b * HW;
+        if (blockIdx.x == 0 && threadIdx.x == 0) out_count[b] = min(n, max_out);
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+            const int p = kb[i];
+            const float sp = hb[p];
+            int rank = 0;
+            for (int j = 0; j < n; ++j) {
+                const int q = kb[j];
+                rank += kp_higher(hb[q], q, sp, p) ? 1 : 0;
+            }
+            if (rank < max_out) {
+                float* o = out + ((long)b * max_out + rank) * 3;
+                const int y = p / W;
+                o[0] = (float)(p - y * W);
+                o[1] = (float)y;
+                o[2] = sp;
+            }
+        }
+    }
+}
+
+// =========================================================================================
+// box NMS
+// =========================================================================================
+__device__ __forceinline__ u64 box_key(float conf, unsigned id) {
+    // ascending u64 order == (conf descending, id ascending); conf > 0 so its bits are monotone
+    return ((u64)(0xFFFFFFFFu - __float_as_uint(conf)) << 32) | id;
+}
+
+__global__ void box_candidates_kernel(const float* __restrict__ pred, int B, int N, int nc, float conf_thres, int multi_label,
+                                      u64* __restrict__ keys, int cap, int* __restrict__ count) {
+    const int no = nc + 5;
+    const long n = (long)B * N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / N);
+        const int row = (int)(i - (long)b * N);
+        const float* r = pred + i * no;
+        const float obj = r[4];
+        if (!(obj > conf_thres)) continue;
+        if (multi_label) {
+            for (int j = 0; j < nc; ++j) {
+                const float conf = r[5 + j] * obj;
+                if (conf > conf_thres) {
+                    const int pos = atomicAdd(&count[b], 1);
+                    if (pos < cap) keys[(long)b * cap + pos] = box_key(conf, (unsigned)(row * nc + j));
+                }
+            }
+        } else {
+            float best = r[5] * obj;
+            int bj = 0;
+            for (int j = 1; j < nc; ++j) {
+                const float conf = r[5 + j] * obj;
+                if (conf > best) { best = conf; bj = j; }
+            }
+            if (best > conf_thres) {
+                const int pos = atomicAdd(&count[b], 1);
+                if (pos < cap) keys[(long)b * cap + pos] = box_key(best, (unsigned)(row * nc + bj));
+            }
+        }
+    }
+}
+
+struct BoxF { float x1, y1, x2, y2; };
+
+__device__ __forceinline__ bool iou_gt(const BoxF& a, float aarea, const BoxF& b, float barea, float thr) {
+    // torchvision.ops.nms CPU definition: inter / (area_a + area_b - inter) > thr
+    const float xx1 = fmaxf(a.x1, b.x1), yy1 = fmaxf(a.y1, b.y1);
+    const float xx2 = fminf(a.x2, b.x2), yy2 = fminf(a.y2, b.y2);
+    const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
+    const float inter = w * h;
+    const float ovr = inter / (aarea + barea - inter);
+    return ovr > thr;
+}
+
+constexpr int BOX_THREADS = 1024;
+constexpr int BOX_MAX_DET = 2048;
+
+// one workgroup per image: bitonic sort of the candidate keys, then chunked greedy NMS.
+__global__ __launch_bounds__(BOX_THREADS) void box_sort_nms_kernel(const float* __restrict__ pred, int N, int nc, float iou_thres,
+                                                                    int agnostic, int max_det, int max_nms, float max_wh,
+                                                                    u64* __restrict__ keys_all, int cap, int cap_pow2,
+                                                                    int* __restrict__ count, float* __restrict__ out_det,
+                                                                    int* __restrict__ out_count) {
+    __shared__ BoxF kbox[BOX_MAX_DET];
+    __shared__ float karea[BOX_MAX_DET];
+    __shared__ unsigned kid[BOX_MAX_DET];
+    __shared__ float kconf[BOX_MAX_DET];
+    __shared__ u64 supmask[BOX_THREADS / 64];
+    __shared__ int s_nkept;
+
+    const int b = blockIdx.x;
+    const int t = threadIdx.x;
+    u64* keys = keys_all + (long)b * cap_pow2;
+    const bool overflow = count[b] > cap_pow2;
+    int n = min(count[b], cap_pow2);
+    // ---- bitonic sort (ascending u64), padded with ~0
+    int P = 1;
+    while (P < n) P <<= 1;
+    for (int i = n + t; i < P; i += BOX_THREADS) keys[i] = ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = t; i < P; i += BOX_THREADS) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const u64 a = keys[i], c = keys[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > c) == up) { keys[i] = c; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    n = min(n, max_nms);
+
+    // ---- greedy NMS over sorted candidates, 64 at a time
+    const int no = nc + 5;
+    const float* pb = pred + (long)b * N * no;
+    const int lane = t & 63, wave = t >> 6;
+    constexpr int NW = BOX_THREADS / 64;
+    if (t == 0) s_nkept = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 64) {
+        const int nk0 = s_nkept;
+        if (nk0 >= max_det) break;
+        const int ci = base + lane;
+        const bool valid = ci < n;
+        BoxF bx{0.f, 0.f, 0.f, 0.f};
+        float area = 0.f, conf = 0.f;
+        unsigned id = 0;
+        if (valid) {
+            const u64 key = keys[ci];
+            id = (unsigned)(key & 0xFFFFFFFFu);
+            conf = __uint_as_float(0xFFFFFFFFu - (unsigned)(key >> 32));
+            const unsigned row = id / (unsigned)nc, cls = id - row * (unsigned)nc;
+            const float* r = pb + (long)row * no;
+            const float cx = r[0], cy = r[1], w = r[2], h = r[3];
+            const float off = agnostic ? 0.f : (float)cls * max_wh;
+            // xywh2xyxy (utils/general_yolo.py:623-630) then "+ c" (:216-217), both in fp32
+            bx.x1 = (cx - w / 2) + off; bx.y1 = (cy - h / 2) + off;
+            bx.x2 = (cx + w / 2) + off; bx.y2 = (cy + h / 2) + off;
+            area = (bx.x2 - bx.x1) * (bx.y2 - bx.y1);
+        }
+        // every wave tests the chunk against a strided share of the kept list
+        bool sup = false;
+        for (int k = wave; k < nk0 && !sup; k += NW) sup = iou_gt(kbox[k], karea[k], bx, area, iou_thres);
+        const u64 m = __ballot(sup && valid);
+        if (lane == 0) supmask[wave] = m;
+        __syncthreads();
+        if (wave == 0) {
+            u64 dead = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) dead |= supmask[w];
+            u64 alive = __ballot(valid) & ~dead;
+            int nk = nk0;
+            while (alive != 0 && nk < max_det) {
+                const int i = __ffsll((long long)alive) - 1;
+                BoxF bi;
+                bi.x1 = __shfl(bx.x1, i, 64); bi.y1 = __shfl(bx.y1, i, 64);
+                bi.x2 = __shfl(bx.x2, i, 64); bi.y2 = __shfl(bx.y2, i, 64);
+                const float ai = __shfl(area, i, 64);
+                if (lane == i) { kbox[nk] = bx; karea[nk] = area; kid[nk] = id; kconf[nk] = conf; }
+                ++nk;
+                const bool mine = ((alive >> lane) & 1ull) && lane > i;
+                const bool die = mine && iou_gt(bi, ai, bx, area, iou_thres);
+                alive &= ~(1ull << i);
+                alive &= ~__ballot(die);
+            }
+            if (lane == 0) s_nkept = nk;
+        }
+        __syncthreads();
+    }
+    // ---- emit (x1,y1,x2,y2,conf,cls) without the class offset
+    const int nk = min(s_nkept, max_det);
+    if (t == 0) out_count[b] = overflow ? -1 : nk;   // -1: candidate list truncated, result not exact
+    for (int k = t; k < nk; k += BOX_THREADS) {
+        const unsigned id = kid[k];
+        const unsigned row = id / (unsigned)nc, cls = id - row * (unsigned)nc;
+        const float* r = pb + (long)row * no;
+        const float cx = r[0], cy = r[1], w = r[2], h = r[3];
+        float* o = out_det + ((long)b * max_det + k) * 6;
+        o[0] = cx - w / 2; o[1] = cy - h / 2; o[2] = cx + w / 2; o[3] = cy + h / 2;
+        o[4] = kconf[k];
+        o[5] = (float)cls;
+    }
+}
+
+// =========================================================================================
+// descriptor sampling: bilinear grid_sample(align_corners=True) + L2 renorm, one wave per point
+// =========================================================================================
+__global__ void desc_sample_kernel(const float* __restrict__ desc, int D, int Hc, int Wc, long sc, long sy, long sx,
+                                   const float* __restrict__ pts, int N, int cell, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    const double Wf = (double)(Wc * cell), Hf = (double)(Hc * cell);
+    for (long pi = wave; pi < N; pi += nwaves) {
+        // reference: float64 normalisation by the FULL resolution, then .float()
+        const float gx = (float)((double)pts[pi * 2] / (Wf / 2.) - 1.);
+        const float gy = (float)((double)pts[pi * 2 + 1] / (Hf / 2.) - 1.);
+        const float ix = ((gx + 1.f) / 2.f) * (float)(Wc - 1);
+        const float iy = ((gy + 1.f) / 2.f) * (float)(Hc - 1);
+        const float fx = floorf(ix), fy = floorf(iy);
+        const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+        const float wnw = ((float)x1 - ix) * ((float)y1 - iy);
+        const float wne = (ix - (float)x0) * ((float)y1 - iy);
+        const float wsw = ((float)x1 - ix) * (iy - (float)y0);
+        const float wse = (ix - (float)x0) * (iy - (float)y0);
+        const bool inx0 = x0 >= 0 && x0 < Wc, inx1 = x1 >= 0 && x1 < Wc;
+        const bool iny0 = y0 >= 0 && y0 < Hc, iny1 = y1 >= 0 && y1 < Hc;
+        float ss = 0.f;
+        for (int c = lane; c < D; c += 64) {
+            const float* pc = desc + c * sc;
+            float v = 0.f;
+            if (inx0 && iny0) v += pc[y0 * sy + x0 * sx] * wnw;
+            if (inx1 && iny0) v += pc[y0 * sy + x1 * sx] * wne;
+            if (inx0 && iny1) v += pc[y1 * sy + x0 * sx] * wsw;
+            if (inx1 && iny1) v += pc[y1 * sy + x1 * sx] * wse;
+            out[(long)c * N + pi] = v;
+            ss += v * v;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        const float nrm = sqrtf(ss);
+        for (int c = lane; c < D; c += 64) out[(long)c * N + pi] /= nrm;
+    }
+}
+
+// =========================================================================================
+// mutual nearest neighbour matcher.  fp32 MFMA (v_mfma_f32_16x16x4_f32: an exact f32 fma chain)
+// computes 64x64 tiles of d1^T d2; distances are formed per element exactly like the reference
+// (sqrt(2 - 2*clip(dot,-1,1))) and reduced to per-row / per-column minima through packed
+// (dist_bits << 32 | index) keys, whose u64 minimum is "smallest distance, first index" ==
+// np.argmin's tie rule.  The N1 x N2 distance matrix is never written.
+// =========================================================================================
+__device__ __forceinline__ u64 min_u64(u64 a, u64 b) { return a < b ? a : b; }
+__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int m) {
+    const unsigned lo = __shfl_xor((unsigned)(v & 0xFFFFFFFFu), m, 64);
+    const unsigned hi = __shfl_xor((unsigned)(v >> 32), m, 64);
+    return ((u64)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(256) void mnn_tile_kernel(const float* __restrict__ d1, int N1, const float* __restrict__ d2, int N2,
+                                                       int D, u64* __restrict__ rowmin, u64* __restrict__ colmin) {
+    constexpr int BT = 64, KT = 16;
+    __shared__ float sA[KT][BT + 4];
+    __shared__ float sB[KT][BT + 4];
+    const int i0 = blockIdx.y * BT, j0 = blockIdx.x * BT;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wi = (wave & 1) * 32, wj = (wave >> 1) * 32;
+    const int p = lane & 15, g = lane >> 4;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < D; k0 += KT) {
+        for (int e = t; e < KT * BT; e += 256) {
+            const int kk = e / BT, c = e - kk * BT;
+            const int k = k0 + kk;
+            sA[kk][c] = (k < D && i0 + c < N1) ? d1[(long)k * N1 + i0 + c] : 0.f;
+            sB[kk][c] = (k < D && j0 + c < N2) ? d2[(long)k * N2 + j0 + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KT; kk += 4) {
+            float af[2], bf[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) af[a] = sA[kk + g][wi + a * 16 + p];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) bf[c] = sB[kk + g][wj + c * 16 + p];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bf[c], acc[a][c], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // acc[a][c][r] = dot(row i = i0+wi+a*16+4*g+r, col j = j0+wj+c*16+p)
+    u64 rkey[2][4], ckey[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) ckey[c] = ~0ull;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            rkey[a][r] = ~0ull;
+            const int i = i0 + wi + a * 16 + 4 * g + r;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int j = j0 + wj + c * 16 + p;
+                if (i < N1 && j < N2) {
+                    const float dc = fminf(fmaxf(acc[a][c][r], -1.f), 1.f);
+                    const float dist = __fsqrt_rn(2.f - 2.f * dc);
+                    const u64 bits = (u64)__float_as_uint(dist) << 32;
+                    rkey[a][r] = min_u64(rkey[a][r], bits | (unsigned)j);
+                    ckey[c] = min_u64(ckey[c], bits | (unsigned)i);
+                }
+            }
+        }
+    // rows: reduce over the 16 lanes that share g
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            u64 v = rkey[a][r];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) v = min_u64(v, shfl_xor_u64(v, o));
+            const int i = i0 + wi + a * 16 + 4 * g + r;
+            if (p == 0 && i < N1 && v != ~0ull) atomicMin(&rowmin[i], v);
+        }
+    // columns: reduce over the 4 lane groups
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        u64 v = ckey[c];
+        v = min_u64(v, shfl_xor_u64(v, 16));
+        v = min_u64(v, shfl_xor_u64(v, 32));
+        const int j = j0 + wj + c * 16 + p;
+        if (g == 0 && j < N2 && v != ~0ull) atomicMin(&colmin[j], v);
+    }
+}
+
+__global__ void fill_u64_kernel(u64* p, long n, u64 v) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// single workgroup: mutual check + threshold, compacted in ascending idx1 order
+__global__ __launch_bounds__(1024) void mnn_select_kernel(const u64* __restrict__ rowmin, const u64* __restrict__ colmin, int N1,
+                                                          float nn_thresh, float* __restrict__ out, int* __restrict__ out_count,
+                                                          int max_out) {
+    __shared__ int wsum[16];
+    __shared__ int s_base;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) s_base = 0;
+    __syncthreads();
+    const int cols = min(N1, max_out);
+    for (int c0 = 0; c0 < N1; c0 += 1024) {
+        const int i = c0 + t;
+        bool keep = false;
+        int j = 0;
+        float dist = 0.f;
+        if (i < N1) {
+            const u64 rk = rowmin[i];
+            j = (int)(rk & 0xFFFFFFFFu);
+            dist = __uint_as_float((unsigned)(rk >> 32));
+            keep = dist < nn_thresh && (int)(colmin[j] & 0xFFFFFFFFu) == i;
+        }
+        const u64 bal = __ballot(keep);
+        const int within = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int before = s_base;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        if (keep) {
+            const int pos = before + within;
+            if (pos < cols) {
+                out[pos] = (float)i;
+                out[cols + pos] = (float)j;
+                out[2 * cols + pos] = dist;
+            }
+        }
+        __syncthreads();
+        if (t == 0) {
+            int tot = 0;
+            for (int w = 0; w < 16; ++w) tot += wsum[w];
+            s_base += tot;
+        }
+        __syncthreads();
+    }
+    if (t == 0) *out_count = s_base;
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+}  // namespace
+
+// -------------------------------------------------------------------------------------------
+extern "C" int yp_kp_decode(const float* semi, int B, int Hc, int Wc, int64_t sb, int64_t sc, int64_t sy, int64_t sx, int mode,
+                            float* heat, void* stream) {
+    YP_REQUIRE(semi && heat && B > 0 && Hc > 0 && Wc > 0 && (mode == 0 || mode == 1), "yp_kp_decode: bad arguments");
+    const long nwork = (long)B * Hc * ((Wc + 31) / 32);
+    kp_decode_kernel<<<grid_for(nwork, 1), 256, 0, (hipStream_t)stream>>>(semi, B, Hc, Wc, sb, sc, sy, sx, mode, heat);
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
+// workspace layout: state[B*HW] u8 | cand[B*HW] i32 | kept[B*HW] i32 | ncand[B] | nkept[B] | left[KP_MAX_ROUNDS]
+constexpr int KP_ROUND_BATCH = 8;
+constexpr int KP_MAX_ROUNDS = 4096;
+
+extern "C" size_t yp_kp_nms_workspace_bytes(int B, int H, int W) {
+    const size_t hw = (size_t)B * H * W;
+    return align_up(hw, 256) + 2 * align_up(hw * 4, 256) + 2 * align_up((size_t)B * 4, 256) + align_up((size_t)KP_MAX_ROUNDS * 4, 256);
+}
+
+extern "C" int yp_kp_nms(const float* heat, int B, int H, int W, float conf_thresh, int radius, int border, float* out_xyc,
+                         int32_t* out_count, int max_out, void* workspace, size_t workspace_bytes, void* stream) {
+    YP_REQUIRE(heat && out_xyc && out_count && workspace, "yp_kp_nms: null pointer");
+    YP_REQUIRE(B > 0 && H > 0 && W > 0 && radius >= 0 && border >= 0 && max_out > 0, "yp_kp_nms: bad dims");
+    if (workspace_bytes < yp_kp_nms_workspace_bytes(B, H, W)) {
+        yp_set_error("yp_kp_nms: workspace %zu < %zu", workspace_bytes, yp_kp_nms_workspace_bytes(B, H, W));
+        return YP_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t hw = (size_t)B * H * W;
+    char* ws = (char*)workspace;
+    unsigned char* state = (unsigned char*)ws; ws += align_up(hw, 256);
+    int* cand = (int*)ws; ws += align_up(hw * 4, 256);
+    int* kept = (int*)ws; ws += align_up(hw * 4, 256);
+    int* ncand = (int*)ws; ws += align_up((size_t)B * 4, 256);
+    int* nkept = (int*)ws; ws += align_up((size_t)B * 4, 256);
+    int* left = (int*)ws;
+    // zero the counters (ncand, nkept, left are contiguous)
+    YP_CHECK_HIP(hipMemsetAsync(ncand, 0, 2 * align_up((size_t)B * 4, 256) + (size_t)KP_MAX_ROUNDS * 4, st));
+    kp_threshold_kernel<<<grid_for(hw, 256), 256, 0, st>>>(heat, B, H * W, conf_thresh, state, cand, ncand);
+    YP_CHECK_HIP(hipGetLastError());
+    int round = 0;
+    for (;;) {
+        for (int k = 0; k < KP_ROUND_BATCH; ++k, ++round) {
+            kp_round_kernel<<<512, 256, 0, st>>>(heat, B, H, W, radius, state, cand, ncand, round ? left + round - 1 : nullptr,
+                                                 left + round);
+        }
+        YP_CHECK_HIP(hipGetLastError());
+        int h_left = 0;
+        YP_CHECK_HIP(hipMemcpyAsync(&h_left, left + round - 1, sizeof(int), hipMemcpyDeviceToHost, st));
+        YP_CHECK_HIP(hipStreamSynchronize(st));
+        if (h_left == 0) break;
+        YP_REQUIRE(round + KP_ROUND_BATCH <= KP_MAX_ROUNDS, "yp_kp_nms: no fix-point after %d rounds", round);
+    }
+    kp_collect_kernel<<<256, 256, 0, st>>>(heat, B, H, W, border, state, cand, ncand, kept, nkept);
+    kp_rank_kernel<<<512, 256, 0, st>>>(heat, B, H, W, kept, nkept, out_xyc, out_count, max_out);
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
+// workspace layout: count[B] i32 | keys[B*cap_pow2] u64
+static int box_cap(int N, int nc, int multi_label) {
+    const long full = (long)N * (multi_label ? nc : 1);
+    return (int)(full < (1l << 21) ? full : (1l << 21));
+}
+
+extern "C" size_t yp_box_nms_workspace_bytes(int B, int N, int nc, int multi_label, int max_nms) {
+    (void)max_nms;
+    const int cap2 = next_pow2(box_cap(N, nc, multi_label));
+    return align_up((size_t)B * 4, 256) + (size_t)B * cap2 * 8;
+}
+
+extern "C" int yp_box_nms(const float* pred, int B, int N, int nc, float conf_thres, float iou_thres, int multi_label, int agnostic,
+                          int max_det, int max_nms, float max_wh, float* out_det, int32_t* out_count, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+    YP_REQUIRE(pred && out_det && out_count && workspace, "yp_box_nms: null pointer");
+    YP_REQUIRE(B > 0 && N > 0 && nc > 0 && max_det > 0 && max_det <= BOX_MAX_DET && max_nms > 0, "yp_box_nms: bad dims (max_det <= %d)", BOX_MAX_DET);
+    YP_REQUIRE(conf_thres >= 0.f && conf_thres <= 1.f && iou_thres >= 0.f && iou_thres <= 1.f, "yp_box_nms: thresholds must be in [0,1]");
+    YP_REQUIRE((long)N * nc < (1l << 32), "yp_box_nms: N*nc overflows the candidate id");
+    multi_label = multi_label && nc > 1;      // utils/general_yolo.py:158
+    if (workspace_bytes < yp_box_nms_workspace_bytes(B, N, nc, multi_label, max_nms)) {
+        yp_set_error("yp_box_nms: workspace too small");
+        return YP_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int cap = box_cap(N, nc, multi_label);
+    const int cap2 = next_pow2(cap);
+    int* count = (int*)workspace;
+    u64* keys = (u64*)((char*)workspace + align_up((size_t)B * 4, 256));
+    YP_CHECK_HIP(hipMemsetAsync(count, 0, (size_t)B * 4, st));
+    box_candidates_kernel<<<grid_for((size_t)B * N, 256), 256, 0, st>>>(pred, B, N, nc, conf_thres, multi_label, keys, cap2, count);
+    box_sort_nms_kernel<<<B, BOX_THREADS, 0, st>>>(pred, N, nc, iou_thres, agnostic, max_det, max_nms, max_wh, keys, cap, cap2, count,
+                                                   out_det, out_count);
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
+extern "C" int yp_desc_sample(const float* desc, int D, int Hc, int Wc, int64_t sc, int64_t sy, int64_t sx, const float* pts_xy, int N,
+                              int cell, float* out, void* stream) {
+    YP_REQUIRE(desc && out && D > 0 && Hc > 0 && Wc > 0 && cell > 0 && N >= 0, "yp_desc_sample: bad arguments");
+    if (N == 0) return YP_OK;
+    YP_REQUIRE(pts_xy != nullptr, "yp_desc_sample: null points");
+    desc_sample_kernel<<<grid_for((size_t)N * 64, 256), 256, 0, (hipStream_t)stream>>>(desc, D, Hc, Wc, sc, sy, sx, pts_xy, N, cell, out);
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
+extern "C" size_t yp_mnn_workspace_bytes(int N1, int N2) { return align_up((size_t)N1 * 8, 256) + align_up((size_t)N2 * 8, 256); }
+
+extern "C" int yp_mnn_match(const float* d1, int N1, const float* d2, int N2, int D, float nn_thresh, float* out_match,
+                            int32_t* out_count, int max_out, void* workspace, size_t workspace_bytes, void* stream) {
+    YP_REQUIRE(out_count != nullptr, "yp_mnn_match: null out_count");
+    YP_REQUIRE(N1 >= 0 && N2 >= 0 && D > 0 && max_out >= 0, "yp_mnn_match: bad dims");
+    YP_REQUIRE(nn_thresh > 0.f, "yp_mnn_match: nn_thresh must be > 0");     // models/model_wrap.py:452
+    hipStream_t st = (hipStream_t)stream;
+    if (N1 == 0 || N2 == 0) {   // reference returns zeros((3,0))
+        YP_CHECK_HIP(hipMemsetAsync(out_count, 0, 4, st));
+        return YP_OK;
+    }
+    YP_REQUIRE(d1 && d2 && out_match && workspace, "yp_mnn_match: null pointer");
+    if (workspace_bytes < yp_mnn_workspace_bytes(N1, N2)) {
+        yp_set_error("yp_mnn_match: workspace too small");
+        return YP_ERR_WORKSPACE;
+    }
+    u64* rowmin = (u64*)workspace;
+    u64* colmin = (u64*)((char*)workspace + align_up((size_t)N1 * 8, 256));
+    const long nfill = (long)(align_up((size_t)N1 * 8, 256) / 8) + N2;
+    fill_u64_kernel<<<grid_for(nfill, 256), 256, 0, st>>>(rowmin, nfill, ~0ull);
+    dim3 grid((N2 + 63) / 64, (N1 + 63) / 64);
+    mnn_tile_kernel<<<grid, 256, 0, st>>>(d1, N1, d2, N2, D, rowmin, colmin);
+    mnn_select_kernel<<<1, 1024, 0, st>>>(rowmin, colmin, N1, nn_thresh, out_match, out_count, max_out);
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}

@@ -1,0 +1,281 @@
+"""Model zoo + meta wrapper with the reference's API surface
+(reference: src/models/YOLOPoint.py:17-145 Model, :148-246 YOLOPoint).
+
+Same constructor arguments, same submodule attribute names (model.Conv1 ... model.ConvDesc,
+model.Detect), same state_dict keys/shapes (fp32 OIHW in the file; repacked to NHWC-ordered
+rows in the compute dtype when a plan is built), same forward() contract:
+    {'semi': [B,65,H/8,W/8], 'desc': [B,c3,H/8,W/8], 'objects': list[3] (train) | (pred, list[3]) (eval)}
+The forward itself is one native plan replay (csrc/plan.hip).
+"""
+import math
+from copy import deepcopy
+
+import torch
+from torch import nn
+
+from .. import _hip
+from ..plan import PlanBuilder, pack_input
+from ..utils.general_yolo import make_divisible, LOGGER
+from ..utils.torch_utils_yolo import fuse_conv_and_bn
+from .common import Conv, C3, SPPF, HipModule
+from .yolo import Detect
+
+anchors_default = [
+    [10, 13, 16, 30, 33, 23],
+    [30, 61, 62, 45, 59, 119],
+    [116, 90, 156, 198, 373, 326],
+]
+
+_VERSIONS = {'n': (0.33, 0.25), 's': (0.33, 0.5), 'm': (0.67, 0.75), 'l': (1., 1.), 'x': (1.33, 1.25)}
+
+
+class YOLOPoint(HipModule):
+    """Shared CSPDarknet encoder + YOLO PAN/Detect head + keypoint (semi) head + descriptor head."""
+
+    def __init__(self, width_multiple=1., depth_multiple=1., inp_ch=3, nc=80, anchors=None):
+        super().__init__()
+        c1, c2, c3, c4, c5 = [make_divisible(2 ** k * width_multiple, 8) for k in range(6, 11)]
+        n1, n2, n3 = [max(round(k * depth_multiple), 1) for k in (3, 6, 9)]
+        # shared backbone
+        self.Conv1 = Conv(inp_ch, c1, 6, 2, 2)
+        self.Conv2 = Conv(c1, c2, 3, 2)
+        self.Bottleneck1 = C3(c2, c2, n1)
+        self.Conv3 = Conv(c2, c3, 3, 2)
+        self.Bottleneck2 = C3(c3, c3, n2)
+        # YOLO-exclusive backbone
+        self.Conv4 = Conv(c3, c4, 3, 2)
+        self.Bottleneck3 = C3(c4, c4, n3)
+        self.Conv5 = Conv(c4, c5, 3, 2)
+        self.Bottleneck4 = C3(c5, c5, n1)
+        self.SPPooling = SPPF(c5, c5, 5)
+        # object detector head (PAN)
+        self.Conv6 = Conv(c5, c4, 1, 1, 0)
+        self.Bottleneck5 = C3(c5, c4, n1)
+        self.Conv7 = Conv(c4, c3, 1, 1, 0)
+        self.Bottleneck6 = C3(c4, c3, n1)
+        self.Conv8 = Conv(c3, c3, 3, 2, 1)
+        self.Bottleneck7 = C3(c4, c4, n1)
+        self.Conv9 = Conv(c4, c4, 3, 2, 1)
+        self.Bottleneck8 = C3(c5, c5, n1)
+        self.Detect = Detect(nc, anchors=anchors, ch=(c3, c4, c5))
+        # keypoint detector head
+        self.BottleneckDet = C3(c3, c3, n1)
+        self.ConvDet = nn.Conv2d(c3, 65, 1, 1, 0, bias=False)
+        # descriptor head
+        self.ConvDescB = Conv(c3, c2, 3, 2, 1)
+        self.ConvDescA = Conv(c2, c2, 3, 2, 1)
+        self.ups = torch.nn.Upsample(scale_factor=(2, 2), mode='nearest')
+        self.BottleneckDesc = C3(c3, c3, n1)
+        self.ConvDesc = nn.Conv2d(c3, c3, 3, 1, 1, bias=False)
+        self.static_outputs = False
+
+    # ---------------------------------------------------------------------------------
+    def emit(self, pb, img, decode=True):
+        """Dataflow of reference models/YOLOPoint.py:198-246; cat/ups are views, never copies."""
+        def run(name, mod, x, **kw):
+            pb.scope.append(name)
+            try:
+                return mod.emit(pb, x, **kw)
+            finally:
+                pb.scope.pop()
+
+        x = run("Conv1", self.Conv1, img)
+        x = run("Conv2", self.Conv2, x)
+        xa = run("Bottleneck1", self.Bottleneck1, x)
+        x8 = run("Conv3", self.Conv3, xa)
+        # keypoint head
+        t = run("BottleneckDet", self.BottleneckDet, x8)
+        pb.scope.append("ConvDet")
+        semi = pb.conv(t, self.ConvDet.weight.detach().float(), None, 1, 1, 0, _hip.YP_ACT_NONE, out_f32=True)
+        pb.scope.pop()
+        xb = run("Bottleneck2", self.Bottleneck2, x8)
+        # descriptor head
+        dA = run("ConvDescA", self.ConvDescA, xa)
+        dB = run("ConvDescB", self.ConvDescB, xb)
+        d = run("BottleneckDesc", self.BottleneckDesc, [dA, dB.up()])
+        pb.scope.append("ConvDesc")
+        desc = pb.conv(d, self.ConvDesc.weight.detach().float(), None, 3, 1, 1, _hip.YP_ACT_NONE, out_f32=True)
+        pb.l2norm(desc, desc, self.ConvDesc.out_channels)
+        pb.scope.pop()
+        # YOLO encoder
+        x = run("Conv4", self.Conv4, xb)
+        xc = run("Bottleneck3", self.Bottleneck3, x)
+        x = run("Conv5", self.Conv5, xc)
+        x = run("Bottleneck4", self.Bottleneck4, x)
+        x = run("SPPooling", self.SPPooling, x)
+        # PAN head
+        xd = run("Conv6", self.Conv6, x)
+        x = run("Bottleneck5", self.Bottleneck5, [xd.up(), xc])
+        xe = run("Conv7", self.Conv7, x)
+        xf = run("Bottleneck6", self.Bottleneck6, [xe.up(), xb])
+        x = run("Conv8", self.Conv8, xf)
+        xg = run("Bottleneck7", self.Bottleneck7, [x, xe])
+        x = run("Conv9", self.Conv9, xg)
+        p5 = run("Bottleneck8", self.Bottleneck8, [x, xd])
+        pb.scope.append("Detect")
+        z, xs = self.Detect.emit(pb, [xf, xg, p5], decode=decode)
+        pb.scope.pop()
+        return {"semi": semi, "desc": desc, "z": z, "xs": xs}
+
+    def build_plan(self, B, H, W, device, graph=False):
+        """Build (and cache) the native plan for a [B, inp_ch, H, W] input."""
+        if H % 32 or W % 32:
+            raise _hip.YpError(f"input size {H}x{W} must be a multiple of the max stride 32")
+        if self.Detect.stride is None:
+            raise _hip.YpError("Detect.stride is not set (construct through models.Model)")
+        code = _hip.dtype_code(self.compute_dtype)
+        key = (B, H, W, code, self.training, self._weights_version(), torch.device(device).index, bool(graph))
+        cache = self.__dict__.setdefault("_plans", {})
+        if key not in cache:
+            cache.clear()
+            pb = PlanBuilder(B, code, device)
+            img = pb.new_buf(H, W, 4)
+            outs = self.emit(pb, img.view(), decode=not self.training)
+            plan = pb.finish()
+            if graph:
+                plan.instantiate_graph()
+            cache[key] = (plan, img, outs)
+        return cache[key]
+
+    def forward(self, x):
+        if not (isinstance(x, torch.Tensor) and x.is_cuda):
+            raise _hip.YpError("YOLOPoint.forward needs a cuda (HIP) tensor: the hot path has no CPU fallback")
+        if self.training:
+            raise _hip.YpError("train-mode (batch-statistics) forward is not part of this build yet; call .eval()")
+        x = x.contiguous().float()
+        B, C_, H, W = x.shape
+        if C_ > 4:
+            raise _hip.YpError("inp_ch > 4 is not supported by the stem kernel")
+        plan, img, outs = self.build_plan(B, H, W, x.device, graph=getattr(self, "use_graph", False))
+        pack_input(x, img.view(), plan.code)
+        plan.run()
+        semi = outs["semi"].buf.t[..., :65].permute(0, 3, 1, 2)
+        desc = outs["desc"].buf.t[..., :self.ConvDesc.out_channels].permute(0, 3, 1, 2)
+        xs = list(outs["xs"])
+        z = outs["z"]
+        if not self.static_outputs:
+            semi, desc, xs = semi.clone(), desc.clone(), [t.clone() for t in xs]
+            z = z.clone() if z is not None else None
+        objects = xs if self.training else (z, xs)
+        return {'semi': semi, 'desc': desc, 'objects': objects}
+
+
+class Model(nn.Module):
+    """Meta wrapper (reference: models/YOLOPoint.py:17-145)."""
+
+    def __init__(self, names=(), model_name='YOLOPoint', version=None, inp_ch=3, anchors=None):
+        super().__init__()
+        anchors = anchors or anchors_default
+        nc = len(names) if hasattr(names, '__len__') and len(names) > 0 else 1
+        version = version.lower() if isinstance(version, str) else version
+        if version is None:
+            dm, wm = None, None
+        elif version in _VERSIONS:
+            dm, wm = _VERSIONS[version]
+        else:
+            raise Exception(f'Version {version} is not a valid input. Choose one of n, s, m, l, x.')
+        from ..utils.utils import load_model
+        self.model = load_model(meta_model=False, width_multiple=wm, depth_multiple=dm, inp_ch=inp_ch, nc=nc,
+                                anchors=anchors, model_name=model_name)
+        if hasattr(self.model, 'Detect'):
+            m = self.model.Detect
+            # The reference measures the strides with a dummy 256x256 forward (YOLOPoint.py:61-65); the
+            # three detection levels sit after 3, 4 and 5 stride-2 convolutions, i.e. 8 / 16 / 32.
+            m.stride = torch.tensor([8., 16., 32.])
+            m.anchors /= m.stride.view(-1, 1, 1)
+            self._check_anchor_order(m)
+            self._initialize_biases()
+
+    @staticmethod
+    def _check_anchor_order(m):
+        a = m.anchors.prod(-1).view(-1)
+        da = a[-1] - a[0]
+        ds = m.stride[-1] - m.stride[0]
+        if da.sign() != ds.sign():
+            LOGGER.info('Reversing anchor order')
+            m.anchors[:] = m.anchors.flip(0)
+
+    def forward(self, x):
+        return self.model(x)
+
+    def _apply(self, fn):
+        self = super()._apply(fn)
+        if hasattr(self.model, 'Detect'):
+            m = self.model.Detect
+            m.stride = fn(m.stride)
+            m.grid = list(map(fn, m.grid))
+            if isinstance(m.anchor_grid, list):
+                m.anchor_grid = list(map(fn, m.anchor_grid))
+        return self
+
+    # -- compute precision ----------------------------------------------------------------
+    def set_compute_dtype(self, dt):
+        """'f16' | 'bf16' | 'f32': arithmetic type of activations and packed weights (fp32 accumulate)."""
+        _hip.dtype_code(dt)
+        for m in self.modules():
+            if isinstance(m, HipModule):
+                m.compute_dtype = dt
+        return self
+
+    def half(self):       # parameters stay fp32 masters; .half() selects the f16 compute path
+        return self.set_compute_dtype("f16")
+
+    def bfloat16(self):
+        return self.set_compute_dtype("bf16")
+
+    def float(self):
+        return self.set_compute_dtype("f32")
+
+    def fuse(self):
+        """Fold every Conv's BatchNorm into its Conv2d (reference: YOLOPoint.py:84-90)."""
+        for m in self.model.modules():
+            if isinstance(m, Conv) and hasattr(m, 'bn'):
+                m.conv = fuse_conv_and_bn(m.conv, m.bn)
+                delattr(m, 'bn')
+        return self
+
+    def _initialize_biases(self, cf=None):
+        m = self.model.Detect
+        for mi, s in zip(m.m, m.stride):
+            b = mi.bias.view(m.na, -1)
+            b.data[:, 4] += math.log(8 / (640 / s) ** 2)
+            b.data[:, 5:] += math.log(0.6 / (m.nc - 0.999999)) if cf is None else torch.log(cf / cf.sum())
+            mi.bias = torch.nn.Parameter(b.view(-1), requires_grad=True)
+
+    def load_state_dict(self, target_state_dict, strict=True, verbose=False):
+        """Tolerant loading (reference: YOLOPoint.py:102-120): a changed class count re-initialises Detect."""
+        key = 'model.Detect.m.0.bias' if 'model.Detect.m.0.bias' in target_state_dict else 'Detect.m.0.bias'
+        if key in target_state_dict:
+            if target_state_dict[key].shape == self.state_dict()[key].shape:
+                super().load_state_dict(target_state_dict, strict)
+            else:
+                if verbose:
+                    LOGGER.info("Number of classes have changed. Reinitializing Detect layer.\n")
+                self.load_partial_state_dict(target_state_dict, strict, verbose)
+        else:
+            try:
+                self.model.load_state_dict(target_state_dict, strict=strict)
+            except RuntimeError:
+                super().load_state_dict(target_state_dict, strict=strict)
+
+    def load_partial_state_dict(self, target_state_dict, strict=True, verbose=False):
+        """Copy every tensor whose last-two name components and shape match (reference: YOLOPoint.py:122-135)."""
+        current = self.state_dict()
+        new = deepcopy(current)
+        for k_this, k_new in zip(current, target_state_dict):
+            if '.'.join(k_this.split('.')[-2:]) == '.'.join(k_new.split('.')[-2:]) \
+                    and current[k_this].shape == target_state_dict[k_new].shape:
+                if verbose:
+                    LOGGER.info(f"{k_this} {' ' * (50 - len(k_this))} {k_new}")
+                new[k_new] = target_state_dict[k_this]
+        super().load_state_dict(new, strict)
+
+    def freeze_layers(self, to_freeze, verbose=True):
+        if verbose:
+            LOGGER.info("Freezing weights...")
+        for i, (name, param) in enumerate(self.named_parameters()):
+            freeze = i in to_freeze and hasattr(param, 'requires_grad')
+            if verbose:
+                LOGGER.info(f"{i} {name} {' ' * (45 - len(name) - len(str(i)))} {'--> freeze' if freeze else ''}")
+            if freeze:
+                param.requires_grad = False

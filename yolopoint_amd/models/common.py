@@ -1,0 +1,180 @@
+"""Building blocks with the reference's names, constructor signatures and state_dict layout
+(reference: src/models/common.py:12-34 Conv, :79-89 Bottleneck, :123-135 C3, :213-229 SPPF).
+
+torch.nn.Conv2d / BatchNorm2d instances are kept purely as parameter containers so that
+checkpoints are key- and shape-compatible; their forward() is never called.  Each block knows
+how to `emit` itself into a PlanBuilder; `forward(x)` runs a cached single-block plan so blocks
+can be called (and tested) on their own like the reference's.
+"""
+import torch
+import torch.nn as nn
+
+from .. import _hip
+from ..plan import PlanBuilder, View, pack_input, unpack_nchw, round_up
+
+
+def autopad(k, p=None):
+    """'same' padding for odd kernels (reference: models/common.py:12-16)."""
+    if p is None:
+        p = k // 2 if isinstance(k, int) else [x // 2 for x in k]
+    return p
+
+
+bn_params = {'eps': 1e-3, 'momentum': 0.03}     # reference: models/common.py:18-20
+
+
+def fold_bn(conv, bn):
+    """Inference-time BN folding, same algebra as utils/torch_utils_yolo.py:194-214.
+    Returns (w[O,I,R,S], b[O]) fp32."""
+    w = conv.weight.detach().float()
+    scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+    wf = w * scale.view(-1, 1, 1, 1)
+    b0 = conv.bias.detach().float() if conv.bias is not None else torch.zeros_like(scale)
+    bf = b0 * scale + bn.bias.detach().float() - bn.weight.detach().float() * bn.running_mean.detach().float() / torch.sqrt(
+        bn.running_var.detach().float() + bn.eps)
+    return wf, bf
+
+
+class HipModule(nn.Module):
+    """Base class: standalone forward through a cached native plan."""
+
+    compute_dtype = "f16"
+
+    def _weights_version(self):
+        v = 0
+        for t in list(self.parameters()) + list(self.buffers()):
+            v += t._version + (t.data_ptr() % 1000003)
+        return v
+
+    def _plan_key(self, x):
+        return (tuple(x.shape), _hip.dtype_code(self.compute_dtype), self.training, self._weights_version(), x.device.index)
+
+    def _standalone_out_channels(self):
+        raise NotImplementedError
+
+    def forward(self, x):
+        if not (isinstance(x, torch.Tensor) and x.is_cuda):
+            raise _hip.YpError(f"{type(self).__name__}.forward needs a cuda (HIP) tensor: the hot path has no CPU fallback")
+        if self.training:
+            raise _hip.YpError("train-mode (batch-statistics) forward is not part of this build yet; call .eval()")
+        x = x.contiguous().float()
+        key = self._plan_key(x)
+        cache = self.__dict__.setdefault("_plans", {})
+        if key not in cache:
+            cache.clear()
+            B, C_, H, W = x.shape
+            code = _hip.dtype_code(self.compute_dtype)
+            pb = PlanBuilder(B, code, x.device)
+            ce = pb.ce
+            inb = pb.new_buf(H, W, round_up(C_, ce))
+            out = self.emit(pb, inb.view())
+            cache[key] = (pb.finish(), inb, out)
+        plan, inb, out = cache[key]
+        pack_input(x, inb.view(), plan.code)
+        plan.run()
+        return unpack_nchw(out, plan.code, x.shape[0], self._standalone_out_channels())
+
+
+class Conv(HipModule):
+    """Conv2d(bias=False) + BatchNorm2d + SiLU  (reference: models/common.py:22-34)."""
+
+    def __init__(self, c1, c2, k=1, s=1, p=None, g=1, act=True):
+        super().__init__()
+        if g != 1:
+            raise _hip.YpError("grouped convolutions are not on the YOLOPoint hot path")
+        self.conv = nn.Conv2d(c1, c2, k, s, autopad(k, p), groups=g, bias=False)
+        self.bn = nn.BatchNorm2d(c2, **bn_params)
+        self.act = nn.SiLU(inplace=True) if act is True else (act if isinstance(act, nn.Module) else nn.Identity())
+
+    def _standalone_out_channels(self):
+        return self.conv.out_channels
+
+    def folded(self):
+        if hasattr(self, "bn"):
+            return fold_bn(self.conv, self.bn)
+        return self.conv.weight.detach().float(), (self.conv.bias.detach().float() if self.conv.bias is not None else None)
+
+    def emit(self, pb, x, out=None, res=None):
+        w, b = self.folded()
+        act = _hip.YP_ACT_SILU if isinstance(self.act, nn.SiLU) else _hip.YP_ACT_NONE
+        if not isinstance(self.act, (nn.SiLU, nn.Identity)):
+            raise _hip.YpError(f"unsupported activation {type(self.act).__name__}")
+        k, s, p = self.conv.kernel_size[0], self.conv.stride[0], self.conv.padding[0]
+        pb.scope.append("conv")
+        try:
+            return pb.conv(x, w, b, k, s, p, act, out=out, res=res)
+        finally:
+            pb.scope.pop()
+
+
+class Bottleneck(HipModule):
+    """x + cv2(cv1(x))  (reference: models/common.py:79-89); the add is fused into cv2's epilogue."""
+
+    def __init__(self, c1, c2, shortcut=True, g=1, e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c_, c2, 3, 1, g=g)
+        self.add = shortcut and c1 == c2
+
+    def _standalone_out_channels(self):
+        return self.cv2.conv.out_channels
+
+    def emit(self, pb, x, out=None):
+        pb.scope.append("cv1"); t = self.cv1.emit(pb, x); pb.scope.pop()
+        pb.scope.append("cv2"); y = self.cv2.emit(pb, t, out=out, res=x if self.add else None); pb.scope.pop()
+        return y
+
+
+class C3(HipModule):
+    """cv3(cat(m(cv1(x)), cv2(x)))  (reference: models/common.py:123-135).
+    The concat is a shared buffer: the last Bottleneck writes channels [0,c_), cv2 writes [c_,2c_)."""
+
+    def __init__(self, c1, c2, n=1, shortcut=True, g=1, e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c1, c_, 1, 1)
+        self.cv3 = Conv(2 * c_, c2, 1)
+        self.m = nn.Sequential(*(Bottleneck(c_, c_, shortcut, g, e=1.0) for _ in range(n)))
+
+    def _standalone_out_channels(self):
+        return self.cv3.conv.out_channels
+
+    def emit(self, pb, x, out=None):
+        c_ = self.cv1.conv.out_channels
+        x0 = x[0] if isinstance(x, (list, tuple)) else x
+        cat = pb.new_buf(x0.LH, x0.LW, 2 * c_)
+        pb.scope.append("cv1"); t = self.cv1.emit(pb, x); pb.scope.pop()
+        n = len(self.m)
+        for i, blk in enumerate(self.m):
+            pb.scope.append(f"m.{i}")
+            t = blk.emit(pb, t, out=cat.view(0, c_) if i == n - 1 else None)
+            pb.scope.pop()
+        pb.scope.append("cv2"); self.cv2.emit(pb, x, out=cat.view(c_, c_)); pb.scope.pop()
+        pb.scope.append("cv3"); y = self.cv3.emit(pb, cat.view(), out=out); pb.scope.pop()
+        return y
+
+
+class SPPF(HipModule):
+    """cv2(cat(x, m(x), m(m(x)), m(m(m(x)))))  (reference: models/common.py:213-229)."""
+
+    def __init__(self, c1, c2, k=5):
+        super().__init__()
+        if k != 5:
+            raise _hip.YpError("SPPF pooling kernel is specialised for k=5")
+        c_ = c1 // 2
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c_ * 4, c2, 1, 1)
+        self.m = nn.MaxPool2d(kernel_size=k, stride=1, padding=k // 2)
+
+    def _standalone_out_channels(self):
+        return self.cv2.conv.out_channels
+
+    def emit(self, pb, x, out=None):
+        c_ = self.cv1.conv.out_channels
+        cat = pb.new_buf(x.LH, x.LW, 4 * c_)
+        pb.scope.append("cv1"); self.cv1.emit(pb, x, out=cat.view(0, c_)); pb.scope.pop()
+        pb.sppf_pool(cat.view(0, c_), cat.view(c_, c_), cat.view(2 * c_, c_), cat.view(3 * c_, c_))
+        pb.scope.append("cv2"); y = self.cv2.emit(pb, cat.view(), out=out); pb.scope.pop()
+        return y

@@ -1,0 +1,264 @@
+"""Host side of the execution plan: NHWC buffers, channel-slice views, weight packing and the
+builder that turns a module tree walk into a native launch list (csrc/plan.hip).
+
+Data layout in HBM: every activation is an NHWC buffer [B, H, W, cstride] in
+the compute dtype (f16 / bf16 / f32); a `View` names a channel slice of it, optionally read
+through a 2x nearest upsample.  torch.cat never happens: producers write into slices of a
+shared buffer, or a conv takes two source views.  Weights are packed once per plan as
+[Cout_pad][Kpad] rows with k = (r*S + s)*Cin + c.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _hip
+from ._hip import YpView, YpConvDesc, check, lib
+
+
+def round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+class Buf:
+    """An NHWC device buffer."""
+
+    def __init__(self, B, H, W, C_, tdtype, device, zero=True):
+        self.B, self.H, self.W, self.C = B, H, W, C_
+        self.t = (torch.zeros if zero else torch.empty)((B, H, W, C_), dtype=tdtype, device=device)
+
+    def view(self, coff=0, C_=None, ups=0):
+        return View(self, coff, self.C - coff if C_ is None else C_, ups)
+
+
+class View:
+    """Channel slice [coff, coff+C) of a Buf; ups=1 reads it through nn.Upsample(2,'nearest')."""
+
+    def __init__(self, buf, coff, C_, ups=0, geom=None):
+        self.buf, self.coff, self.C, self.ups = buf, coff, C_, ups
+        # geom overrides (H, W, cstride) for the paired-pixel stem view
+        self.geom = geom
+
+    @property
+    def H(self):
+        return (self.geom[0] if self.geom else self.buf.H)
+
+    @property
+    def W(self):
+        return (self.geom[1] if self.geom else self.buf.W)
+
+    @property
+    def cstride(self):
+        return (self.geom[2] if self.geom else self.buf.C)
+
+    @property
+    def LH(self):   # logical size when read as an input
+        return self.H << self.ups
+
+    @property
+    def LW(self):
+        return self.W << self.ups
+
+    def up(self):
+        return View(self.buf, self.coff, self.C, 1, self.geom)
+
+    def slice(self, coff, C_):
+        assert coff + C_ <= self.C
+        return View(self.buf, self.coff + coff, C_, self.ups, self.geom)
+
+    def c(self):
+        return YpView(self.buf.t.data_ptr(), self.H, self.W, self.cstride, self.coff, self.C, self.ups)
+
+
+NULL_VIEW = YpView(None, 0, 0, 0, 0, 0, 0)
+
+
+def pack_conv_weight(w, bias, code, device):
+    """OIHW fp32 -> [Npad][Kpad] in compute dtype (k = (r*S+s)*Cin + c) + fp32 bias[Npad].
+
+    Pure torch (runs on CPU too, which is how the CPU tests check the layout)."""
+    Cout, Cin, R, S = w.shape
+    K = R * S * Cin
+    Kpad = lib().yp_conv_kpad(K, code)
+    Npad = round_up(Cout, 8)
+    wk = w.detach().to(torch.float32).permute(0, 2, 3, 1).reshape(Cout, K)
+    wp = torch.zeros((Npad, Kpad), dtype=torch.float32, device=wk.device)
+    wp[:Cout, :K] = wk
+    bp = torch.zeros((Npad,), dtype=torch.float32, device=wk.device)
+    if bias is not None:
+        bp[:Cout] = bias.detach().to(torch.float32)
+    return wp.to(device=device, dtype=_hip.torch_dtype(code)).contiguous(), bp.to(device).contiguous(), Kpad, Npad
+
+
+class OpRecord:
+    __slots__ = ("name", "kind", "flops", "bytes", "M", "N", "K")
+
+    def __init__(self, name, kind, flops=0, bytes_=0, M=0, N=0, K=0):
+        self.name, self.kind, self.flops, self.bytes, self.M, self.N, self.K = name, kind, flops, bytes_, M, N, K
+
+
+class PlanBuilder:
+    """Collects launches into a native YpPlan; owns every buffer the plan touches."""
+
+    def __init__(self, B, code, device):
+        _hip.require_gpu()
+        self.B, self.code, self.device = B, code, device
+        self.tdtype = _hip.torch_dtype(code)
+        self.ce = 4 if code == _hip.YP_F32 else 8
+        self.handle = C.c_void_p()
+        check(lib().yp_plan_create(C.byref(self.handle)))
+        self.keep = []          # tensors the native plan points into
+        self.records = []       # per-op algorithmic work (for roofline accounting)
+        self.scope = []
+
+    # -- naming -------------------------------------------------------------------------
+    def name(self, leaf=""):
+        return ".".join(self.scope + ([leaf] if leaf else []))
+
+    # -- buffers ------------------------------------------------------------------------
+    def new_buf(self, H, W, C_, f32=False):
+        b = Buf(self.B, H, W, C_, torch.float32 if f32 else self.tdtype, self.device)
+        self.keep.append(b.t)
+        return b
+
+    def new_tensor(self, shape, dtype=torch.float32):
+        t = torch.zeros(shape, dtype=dtype, device=self.device)
+        self.keep.append(t)
+        return t
+
+    # -- ops ----------------------------------------------------------------------------
+    def conv(self, srcs, w, bias, k, s, p, act, out=None, res=None, out_f32=False, tile=0):
+        """srcs: one or two Views (channel-concatenated); w: OIHW fp32 tensor (BN already folded)."""
+        if isinstance(srcs, View):
+            srcs = [srcs]
+        assert 1 <= len(srcs) <= 2
+        Cout, Cin, R, S = w.shape
+        sh = sw = s
+        ph = pw = p
+        v0 = srcs[0]
+        Hi, Wi = v0.LH, v0.LW
+        Ho = (Hi + 2 * ph - R) // sh + 1
+        Wo = (Wi + 2 * pw - S) // sw + 1
+        thin = len(srcs) == 1 and v0.C == 4 and v0.cstride == 4 and Cin <= 4
+        if thin:
+            # image-like input padded to 4 channels (the 6x6/s2/p2 stem, models/YOLOPoint.py:156)
+            wpad = torch.zeros((Cout, 4, R, S), dtype=torch.float32, device=w.device)
+            wpad[:, :Cin] = w
+            w = wpad
+            if self.ce == 8:
+                # 16-bit: pair adjacent pixels -> view [H, W/2, 8]; taps pair up along s
+                if S % 2 or sw % 2 or pw % 2 or Wi % 2:
+                    raise _hip.YpError("thin-input conv needs even kernel width / stride / pad for 16-bit dtypes")
+                w = w.permute(0, 2, 3, 1).reshape(Cout, R, S // 2, 8).permute(0, 3, 1, 2).contiguous()
+                v0 = View(v0.buf, 0, 8, 0, geom=(v0.H, v0.W // 2, 8))
+                srcs = [v0]
+                S, sw, pw, Wi = S // 2, sw // 2, pw // 2, Wi // 2
+        else:
+            assert sum(v.C for v in srcs) == Cin, (self.name(), [v.C for v in srcs], Cin)
+        Cout_pad = round_up(Cout, 8)
+        if out is None:
+            out = self.new_buf(Ho, Wo, Cout_pad, f32=out_f32).view()
+        assert out.C == Cout_pad and out.H == Ho and out.W == Wo, (self.name(), out.C, Cout_pad, out.H, Ho)
+        wp, bp, Kpad, Npad = pack_conv_weight(w, bias, self.code, self.device)
+        self.keep += [wp, bp]
+        d = YpConvDesc()
+        d.in0 = v0.c()
+        d.in1 = srcs[1].c() if len(srcs) == 2 else NULL_VIEW
+        d.out = out.c()
+        d.res = res.c() if res is not None else NULL_VIEW
+        d.weight = wp.data_ptr()
+        d.bias = bp.data_ptr() if bias is not None else None
+        d.dtype, d.out_f32, d.B = self.code, int(out_f32), self.B
+        d.Hi, d.Wi, d.Ho, d.Wo = Hi, Wi, Ho, Wo
+        d.R, d.S, d.stride_h, d.stride_w, d.pad_h, d.pad_w = R, S, sh, sw, ph, pw
+        d.Kpad, d.Npad, d.act, d.tile = Kpad, Npad, act, tile
+        check(lib().yp_plan_add_conv(self.handle, C.byref(d)))
+        # algorithmic work: MAC*2 with the REAL channel counts (BASELINE.md section 2 convention)
+        Kreal = w.shape[1] * w.shape[2] * w.shape[3] if not thin else Cin * R * (S * (2 if self.ce == 8 else 1))
+        M = self.B * Ho * Wo
+        eb = 4 if self.code == _hip.YP_F32 else 2
+        in_elems = self.B * sum((v.H * v.W * v.C) for v in srcs)
+        bytes_ = in_elems * eb + M * Cout * (4 if out_f32 else eb) + Cout * Kreal * eb
+        self.records.append(OpRecord(self.name(), "conv", 2 * M * Cout * Kreal, bytes_, M, Cout, Kreal))
+        return out
+
+    def sppf_pool(self, x, y1, y2, y3):
+        check(lib().yp_plan_add_sppf_pool(self.handle, x.c(), y1.c(), y2.c(), y3.c(), self.B, self.code))
+        eb = 4 if self.code == _hip.YP_F32 else 2
+        self.records.append(OpRecord(self.name("m"), "pool", 0, 4 * self.B * x.H * x.W * x.C * eb))
+
+    def l2norm(self, src, dst, C_):
+        check(lib().yp_plan_add_l2norm(self.handle, src.c(), dst.c(), self.B, C_))
+        self.records.append(OpRecord(self.name("l2norm"), "l2norm", 0, 2 * self.B * src.H * src.W * C_ * 4))
+
+    def detect_decode(self, raw, na, no, stride, anchors_px, x_out, z_out, rows_total, row_offset):
+        arr = (C.c_float * (na * 2))(*[float(a) for a in anchors_px])
+        check(lib().yp_plan_add_detect_decode(self.handle, raw.c(), self.B, na, no, float(stride), arr,
+                                              x_out.data_ptr(), z_out.data_ptr() if z_out is not None else None,
+                                              rows_total, row_offset))
+        n = self.B * na * raw.H * raw.W * no * 4
+        self.records.append(OpRecord(self.name("decode"), "decode", 0, n * (3 if z_out is not None else 2)))
+
+    def finish(self):
+        return ExecPlan(self)
+
+
+class ExecPlan:
+    """A finished plan: run()/profile()/time() replay it on the current stream."""
+
+    def __init__(self, pb):
+        self.handle, self.keep, self.records = pb.handle, pb.keep, pb.records
+        self.B, self.code, self.device = pb.B, pb.code, pb.device
+        self.graph = False
+
+    def num_ops(self):
+        return lib().yp_plan_num_ops(self.handle)
+
+    def instantiate_graph(self):
+        """Capture the launch list into a hipGraph (needs a non-default stream for capture)."""
+        if self.graph:
+            return
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            check(lib().yp_plan_instantiate_graph(self.handle, _hip.stream_ptr(s)))
+        torch.cuda.current_stream().wait_stream(s)
+        self.graph = True
+
+    def run(self, stream=None):
+        check(lib().yp_plan_run(self.handle, _hip.stream_ptr(stream)))
+
+    def profile(self, stream=None):
+        n = self.num_ops()
+        ms = (C.c_float * n)()
+        check(lib().yp_plan_profile(self.handle, _hip.stream_ptr(stream), ms))
+        return list(ms)
+
+    def time(self, iters, stream=None):
+        ms = C.c_float()
+        check(lib().yp_plan_time(self.handle, _hip.stream_ptr(stream), iters, C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib().yp_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------------------------
+# eager helpers used around a plan
+# ---------------------------------------------------------------------------------------------
+def pack_input(x, view, code, stream=None):
+    """NCHW fp32 cuda tensor -> NHWC view (channels zero padded)."""
+    B, C_, H, W = x.shape
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+    check(lib().yp_pack_input(x.data_ptr(), B, C_, H, W, view.c(), code, _hip.stream_ptr(stream)))
+
+
+def unpack_nchw(view, src_code, B, C_, stream=None):
+    out = torch.empty((B, C_, view.H, view.W), dtype=torch.float32, device=view.buf.t.device)
+    check(lib().yp_unpack_nchw(view.c(), src_code, B, C_, out.data_ptr(), _hip.stream_ptr(stream)))
+    return out
