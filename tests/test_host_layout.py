@@ -1,0 +1,164 @@
+"""CPU: host-side mirror of the reference interface — checkpoint key layout, parameter order,
+fuse(), load_state_dict tolerance, weight packing, and the C-ABI surface (no compute calls)."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import NAMES80, make_model
+from yolopoint_amd import _hip, models
+from yolopoint_amd.plan import pack_conv_weight
+from yolopoint_amd.utils import utils as U
+from yolopoint_amd.utils.general_yolo import make_divisible, xywh2xyxy
+from yolopoint_amd.utils.torch_utils_yolo import fuse_conv_and_bn, de_parallel
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def lay():
+    with open(os.path.join(G, "layouts.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("v", ["n", "s", "m", "l"])
+def test_state_dict_layout_matches_reference(lay, v):
+    m = models.Model(names=NAMES80, model_name="YOLOPoint", version=v)
+    mine = [[k, list(t.shape)] for k, t in m.state_dict().items()]
+    assert mine == lay[v]["state_dict"]
+    assert sum(p.numel() for p in m.parameters()) == lay[v]["n_params"]
+    assert [k for k, _ in m.named_parameters()] == lay[v]["named_parameters"]     # freeze_layers() indices
+
+
+def test_fused_and_single_class_layouts(lay):
+    m = models.Model(names=NAMES80, version="n").eval().fuse()
+    assert [[k, list(t.shape)] for k, t in m.state_dict().items()] == lay["n_fused"]["state_dict"]
+    m1 = models.Model(names=["car"], version="n")
+    assert [[k, list(t.shape)] for k, t in m1.state_dict().items()] == lay["n_nc1"]["state_dict"]
+    assert models.Model(names=(), version="n").model.Detect.nc == 1           # empty names -> 1 dummy class
+
+
+def test_detect_attributes_and_bias_init():
+    m = models.Model(names=NAMES80, version="s")
+    d = m.model.Detect
+    assert (d.nc, d.no, d.nl, d.na) == (80, 85, 3, 3)
+    assert torch.equal(d.stride, torch.tensor([8., 16., 32.]))
+    assert torch.allclose(d.anchors[0, 0], torch.tensor([10 / 8, 13 / 8]))
+    assert torch.allclose(d.anchors[2, 2], torch.tensor([373 / 32, 326 / 32]))
+    fresh = models.YOLOPoint(0.5, 0.33, 3, 80, models.YOLOPoint.__init__.__defaults__ and [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]])
+    torch.manual_seed(0)
+    # obj bias shifted by log(8/(640/s)^2), cls by log(0.6/(nc-0.999999))  (reference YOLOPoint.py:92-100)
+    b = d.m[0].bias.view(3, -1)
+    assert abs(float(b[:, 5:].mean()) - np.log(0.6 / (80 - 0.999999))) < 0.2
+    assert abs(float(b[:, 4].mean()) - np.log(8 / (640 / 8) ** 2)) < 0.2
+
+
+def test_load_state_dict_tolerance():
+    src = models.Model(names=NAMES80, version="n")
+    dst = models.Model(names=["a", "b"], version="n")                  # different class count
+    before = dst.state_dict()["model.Conv2.conv.weight"].clone()
+    dst.load_state_dict(src.state_dict(), strict=True)                 # must not raise: partial load
+    after = dst.state_dict()
+    assert torch.equal(after["model.Conv2.conv.weight"], src.state_dict()["model.Conv2.conv.weight"])
+    assert not torch.equal(after["model.Conv2.conv.weight"], before)
+    assert after["model.Detect.m.0.bias"].shape == (21,)
+    with pytest.raises(Exception):
+        models.Model(names=NAMES80, version="q")
+
+
+def test_freeze_layers_and_versions():
+    m = models.Model(names=NAMES80, version="n")
+    m.freeze_layers([0, 1, 2], verbose=False)
+    ps = list(m.parameters())
+    assert not ps[0].requires_grad and not ps[2].requires_grad and ps[3].requires_grad
+    assert make_divisible(33, 8) == 40 and make_divisible(64 * 0.75, 8) == 48
+    assert de_parallel(m) is m
+    assert U.load_model(names=NAMES80, model_name="YOLOPoint", version="n").model.Conv1.conv.weight.shape == (16, 3, 6, 6)
+
+
+def test_fuse_conv_and_bn_algebra():
+    torch.manual_seed(1)
+    conv = torch.nn.Conv2d(8, 12, 3, 1, 1, bias=False)
+    bn = torch.nn.BatchNorm2d(12, eps=1e-3, momentum=0.03)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.1); bn.running_mean.normal_(0, 0.1); bn.running_var.uniform_(0.5, 1.5)
+    bn.eval()
+    x = torch.randn(2, 8, 7, 7)
+    f = fuse_conv_and_bn(conv, bn)
+    assert torch.allclose(f(x), bn(conv(x)), atol=1e-5)
+
+
+def test_pack_conv_weight_layout():
+    """[Cout][Kpad] rows, k = (r*S + s)*Cin + c, zero padded (CPU check of the layout the kernel reads)."""
+    w = torch.arange(5 * 8 * 3 * 3, dtype=torch.float32).view(5, 8, 3, 3)
+    b = torch.arange(5, dtype=torch.float32)
+    wp, bp, Kpad, Npad = pack_conv_weight(w, b, _hip.YP_F32, "cpu")
+    assert (Kpad, Npad) == (96, 8) and wp.shape == (8, 96)
+    assert float(wp[3, (1 * 3 + 2) * 8 + 5]) == float(w[3, 5, 1, 2])
+    assert float(wp[:, 72:].abs().max()) == 0 and float(wp[5:].abs().max()) == 0 and torch.equal(bp[:5], b)
+    wp16, _, Kpad16, _ = pack_conv_weight(w, None, _hip.YP_F16, "cpu")
+    assert Kpad16 == 128 and wp16.dtype == torch.float16
+
+
+def test_box_format_helper():
+    x = np.array([[10., 20., 4., 6.]], dtype=np.float32)
+    assert np.array_equal(xywh2xyxy(x), np.array([[8., 17., 12., 23.]], dtype=np.float32))
+    assert torch.equal(xywh2xyxy(torch.from_numpy(x)), torch.tensor([[8., 17., 12., 23.]]))
+
+
+def test_labels2Dto3D_roundtrip():
+    post = np.load(os.path.join(G, "postproc.npz"))
+    out = U.labels2Dto3D(torch.from_numpy(post["l2d.labels"]))
+    np.testing.assert_allclose(out.numpy(), post["l2d.out"])
+    np.testing.assert_allclose(U.getMasks(torch.from_numpy(post["l2d.mask"]), "cpu").numpy(), post["l2d.maskout"])
+
+
+# ------------------------------------------------------------------------------ C ABI surface
+def test_cabi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "yolopoint_hip.h")).read()
+    declared = set(re.findall(r"\b(yp_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_hip.SIGNATURES), declared ^ set(_hip.SIGNATURES)
+    l = _hip.lib()                                   # dlopen works without a GPU
+    for name in declared:
+        assert hasattr(l, name), name
+    nm = subprocess.run(["nm", "-D", "--defined-only", _hip.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (yp_[a-z0-9_]+)", nm))
+    assert declared <= exported
+    assert l.yp_version() >= 100 and l.yp_conv_kpad(27, _hip.YP_F16) == 64 and l.yp_conv_kpad(144, _hip.YP_F32) == 160
+
+
+def test_cabi_struct_sizes_and_argument_errors():
+    assert ctypes.sizeof(_hip.YpView) == 32 and ctypes.sizeof(_hip.YpConvDesc) == 4 * 32 + 16 + 17 * 4 + 4
+    l = _hip.lib()
+    # argument validation happens before any device work, so it is testable on a CPU-only host
+    rc = l.yp_conv2d(None, None)
+    assert rc == -1 and b"null descriptor" in l.yp_last_error()
+    d = _hip.YpConvDesc()
+    d.dtype = 7
+    assert l.yp_conv2d(ctypes.byref(d), None) == -1 and b"bad dtype" in l.yp_last_error()
+    assert l.yp_kp_nms_workspace_bytes(1, 640, 640) > 640 * 640 * 9
+    assert l.yp_mnn_workspace_bytes(1000, 2000) >= 8 * 3000
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure: nothing under yolopoint_amd/ may reference it."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "yolopoint_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("# oracle", ""), os.path.join(dirpath, f)
+
+
+def test_cpu_inputs_fail_loudly():
+    m, _ = make_model("n", 1)
+    with pytest.raises(_hip.YpError):
+        m(torch.zeros(1, 3, 64, 64))
+    if _hip.lib().yp_device_count() == 0:
+        with pytest.raises(_hip.YpError):
+            U.getPtsFromHeatmap(np.zeros((16, 16), np.float32), 0.1, 4)

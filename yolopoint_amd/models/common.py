@@ -66,7 +66,7 @@ class HipModule(nn.Module):
             code = _hip.dtype_code(self.compute_dtype)
             pb = PlanBuilder(B, code, x.device)
             ce = pb.ce
-            inb = pb.new_buf(H, W, round_up(C_, ce))
+            inb = pb.new_buf(H, W, 4 if C_ <= 4 else round_up(C_, ce))   # <=4 channels: image-like (stem) input
             out = self.emit(pb, inb.view())
             cache[key] = (pb.finish(), inb, out)
         plan, inb, out = cache[key]
