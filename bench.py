@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""bench.py — images/sec of the YOLOPoint hot path on MI355X.
+
+Workload at N=1 (BASELINE.json configs[1]): YOLOPoint-s inference, batch 8, 640x640, fp16 compute
+(fp32 accumulate, fp32 head outputs), BN folded, synthetic seeded weights + synthetic images that
+are already resident in HBM when the timed region starts.  One "step" = one forward of the
+batch through the native plan: input pack (NCHW fp32 -> NHWC f16), 74 fused implicit-GEMM convs,
+SPPF pooling, descriptor L2 norm, Detect decode to [8, 25200, 85].
+
+N>1 (launched by torch.distributed.run): inference shards by independent images — every rank
+runs its own replica on its own batch ("replicas only", weak scaling, no data-path collective);
+the barrier + max-over-ranks timing is the only communication.
+
+The JSON line also carries
+  roofline      achieved MFMA TFLOP/s of the implicit-GEMM conv kernel = algorithmic conv FLOPs per
+                forward (21.023 GFLOP/img for -s) / sum of the conv launches'
+                durations, measured with HIP events on the launch stream in this process
+  cpu_baseline  the oracle's PyTorch-CPU fp32 forward timed on this host's cores (rank 0, N=1)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+
+PEAK_TFLOPS = {"f16": 2500.0, "bf16": 2500.0, "f32": 157.3}     # MI355X_MICROARCH.md dense MFMA peaks
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--version", default="s")
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--dtype", default="f16")
+    ap.add_argument("--no-graph", action="store_true", help="replay the plan eagerly instead of through a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layers", default="", help="write a per-launch table (us, TFLOP/s, GB/s) to this path")
+    ap.add_argument("--postproc", action="store_true", help="also time the post-processing kernels on planted head outputs")
+    return ap.parse_args()
+
+
+def build_model(version, dtype, dev):
+    from helpers import make_model
+    m, sd = make_model(version, 1234, dtype=dtype)
+    m = m.to(dev)
+    m.fuse()                          # inference path: BN folded (reference demo.py:48-49)
+    m.model.static_outputs = True     # outputs live in the plan's static buffers (graph replay semantics)
+    return m, sd
+
+
+def cpu_baseline(version, B, S, budget_s=12.0):
+    """Oracle forward on the host cores (fp32, eval).  Bounded: stops after `budget_s` or 10 iterations."""
+    from oracle import net_oracle
+    from helpers import NAMES80, layout_of
+    from yolopoint_amd import models
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    layout = layout_of(models.Model(names=NAMES80, version=version))
+    sd = net_oracle.synth_state_dict(layout, 1234)
+    Bc = min(B, 8)
+    x = net_oracle.synth_image(Bc, 3, S, S, 1234)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        net_oracle.yolopoint_forward(sd, x, version)          # warm-up
+        first = time.perf_counter() - t0
+        times = []
+        t_start = time.perf_counter()
+        while len(times) < 10 and (time.perf_counter() - t_start) < budget_s:
+            t0 = time.perf_counter()
+            net_oracle.yolopoint_forward(sd, x, version)
+            times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2] if times else first
+    return {"value": round(Bc / med, 2), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (PyTorch-CPU fp32, eval) forward of YOLOPoint-{version} batch {Bc} {S}x{S}: "
+                      f"1 warm-up + {len(times)} timed iterations, median"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from yolopoint_amd import _hip
+    _hip.require_gpu()
+    m, _ = build_model(a.version, a.dtype, dev)
+    net = m.model
+    B, S = a.batch, a.size
+    from oracle import net_oracle  # synthetic image generator only (data, not compute)
+    x = net_oracle.synth_image(B, 3, S, S, 1234 + rank).to(dev)
+    from yolopoint_amd.plan import pack_input
+
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        plan, img, outs = net.build_plan(B, S, S, dev, graph=not a.no_graph)
+
+        def step():
+            pack_input(x, img.view(), plan.code)
+            plan.run()
+
+        for _ in range(a.warmup):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(a.steps):
+            step()
+        e1.record()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        gpu_ms = e0.elapsed_time(e1)
+
+        # ---- per-launch durations (HIP events between launches on this stream), median of 5 passes
+        passes = [plan.profile() for _ in range(5)]
+        nops = len(passes[0])
+        per_op = [sorted(p[i] for p in passes)[2] for i in range(nops)]
+
+    if world > 1:
+        t = torch.tensor([wall], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+
+    recs = plan.records
+    conv_ms = sum(ms for ms, r in zip(per_op, recs) if r.kind == "conv")
+    conv_flops = sum(r.flops for r in recs if r.kind == "conv")
+    conv_bytes = sum(r.bytes for r in recs if r.kind == "conv")
+    other_ms = sum(ms for ms, r in zip(per_op, recs) if r.kind != "conv")
+    n_conv = sum(1 for r in recs if r.kind == "conv")
+    achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    peak = PEAK_TFLOPS[a.dtype]
+
+    if a.layers and rank == 0:
+        os.makedirs(os.path.dirname(os.path.abspath(a.layers)) or ".", exist_ok=True)
+        with open(a.layers, "w") as f:
+            f.write(f"# per-launch profile, YOLOPoint-{a.version} B={B} {S}x{S} {a.dtype}; eager launches, HIP events, median of 5\n")
+            f.write(f"{'op':52s} {'kind':7s} {'M':>8s} {'N':>5s} {'K':>5s} {'us':>9s} {'TFLOP/s':>9s} {'GB/s(alg)':>10s}\n")
+            for ms, r in zip(per_op, recs):
+                tf = r.flops / (ms * 1e-3) / 1e12 if ms > 0 else 0
+                gb = r.bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0
+                f.write(f"{r.name:52s} {r.kind:7s} {r.M:8d} {r.N:5d} {r.K:5d} {ms * 1e3:9.1f} {tf:9.1f} {gb:10.0f}\n")
+            f.write(f"# conv: {n_conv} launches {conv_ms * 1e3:.1f} us, {conv_flops / 1e9:.2f} GFLOP -> {achieved:.1f} TFLOP/s; "
+                    f"other ops {other_ms * 1e3:.1f} us; graph step {gpu_ms / a.steps * 1e3:.1f} us\n")
+
+    if rank != 0:
+        return
+    imgs = B * a.steps * world
+    out = {
+        "metric": "images/sec at 640x640 (YOLOPoint-s inference, bs=8, fp16)" if (a.version, B, S, a.dtype) == ("s", 8, 640, "f16")
+        else f"images/sec at {S}x{S} (YOLOPoint-{a.version} inference, bs={B}, {a.dtype})",
+        "value": round(imgs / wall, 1),
+        "unit": "images/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": round(wall / a.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": a.dtype,
+        "data": "synthetic",
+        "config": {"workload": f"BASELINE.json configs[1]: YOLOPoint-{a.version} inference forward (backbone + detect/keypoint/descriptor "
+                               f"heads + Detect decode), batch {B}/GPU, {S}x{S}, {a.dtype} compute / fp32 accumulate, BN folded, "
+                               f"seeded synthetic weights, inputs resident in HBM",
+                   "per_gpu_batch": B, "global_batch": B * world, "image": [S, S],
+                   "parallelism": "replicas" if world > 1 else "single",
+                   "launch": "eager" if a.no_graph else "hipGraph", "ops_per_step": nops + 1},
+        "gpu_ms_per_step_events": round(gpu_ms / a.steps, 4),
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                     "frac": round(achieved / peak, 4), "traffic": None,
+                     "kernel": "conv_igemm_kernel (all tile instantiations)",
+                     "launches_per_step": n_conv, "conv_us_per_step": round(conv_ms * 1e3, 1),
+                     "algorithmic_gflop_per_step": round(conv_flops / 1e9, 3),
+                     "algorithmic_hbm_frac": round(conv_bytes / (conv_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if conv_ms > 0 else None,
+                     "whole_step_tflops": round(conv_flops / (gpu_ms / a.steps * 1e-3) / 1e12, 2)},
+    }
+    if a.postproc:
+        out["postproc"] = bench_postproc(dev)
+    if world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a.version, B, S)
+    print(json.dumps(out), flush=True)
+
+
+def bench_postproc(dev):
+    """Post-processing kernels on planted head outputs; microseconds per call, GPU events."""
+    import numpy as np
+    from helpers import planted_heatmap, planted_predictions, planted_descriptors
+    from yolopoint_amd.utils import utils as U
+    from yolopoint_amd.utils.general_yolo import non_max_suppression
+    from yolopoint_amd.models.model_wrap import PointTracker
+    res = {}
+
+    def timeit(fn, n=10):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return round((time.perf_counter() - t0) / n * 1e6, 1)
+
+    semi = torch.randn(8, 65, 80, 80, device=dev)
+    res["kp_decode_b8_us"] = timeit(lambda: U.flattenDetection(semi))
+    heat = torch.from_numpy(planted_heatmap(640, 640, 1000, 1)).to(dev)
+    res["kp_nms_640_1000peaks_us"] = timeit(lambda: U.getPtsFromHeatmap(heat, 0.015, 4))
+    pred = torch.from_numpy(planted_predictions(8, 25200, 80, 2000, 1)).to(dev)
+    res["box_nms_b8_25200x85_2000cand_us"] = timeit(lambda: non_max_suppression(pred, 0.25, 0.45, labels=[], multi_label=True, agnostic=True, max_det=1000), 5)
+    d1, d2 = planted_descriptors(256, 1000, 1000, 0.7, 1)
+    d1, d2 = torch.from_numpy(d1).to(dev), torch.from_numpy(d2).to(dev)
+    tr = PointTracker()
+    res["mnn_256d_1000x1000_us"] = timeit(lambda: tr.nn_match_two_way(d1, d2, 0.7))
+    return res
+
+
+if __name__ == "__main__":
+    main()

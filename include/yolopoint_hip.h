@@ -183,6 +183,11 @@ int yp_plan_add_detect_decode(YpPlan* plan, YpView raw, int B, int na, int no, f
                               const float* anchors_px_host, float* x_out, float* z_out,
                               int rows_total, int row_offset);
 int yp_plan_num_ops(const YpPlan* plan);
+/* true data dependencies of op `op`: the earlier ops it must wait for.  When every op has a
+ * dependency list, yp_plan_instantiate_graph replaces the captured chain's edges by these, so
+ * independent branches run concurrently.  Eager yp_plan_run ignores them (single stream order). */
+int yp_plan_set_deps(YpPlan* plan, int op, const int* deps, int ndeps);
+int yp_plan_graph_is_parallel(const YpPlan* plan);
 /* capture the op list into a hipGraph on `stream` (call once, after the last add) */
 int yp_plan_instantiate_graph(YpPlan* plan, void* stream);
 /* enqueue all ops (graph launch when instantiated) */

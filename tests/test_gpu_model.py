@@ -84,3 +84,20 @@ def test_cpu_tensor_raises():
     m, _ = make_model("n", 1)
     with pytest.raises(_hip.YpError):
         m(torch.zeros(1, 3, 64, 64))
+
+
+def test_multistream_graph_equals_eager(cuda):
+    """The hipGraph replay (branches captured on forked streams) must reproduce the eager, single-stream
+    launch order bit for bit — the schedule only reorders independent launches."""
+    m, _ = make_model("s", 9, dtype="f16")
+    m = m.to(cuda)
+    x = net_oracle.synth_image(2, 3, 128, 128, 9).to(cuda)
+    a = m(x)
+    m.model.use_graph = True
+    b = m(x)
+    c = m(x)      # replay
+    plan = next(iter(m.model._plans.values()))[0]
+    assert plan.graph and plan.parallel
+    for k in ("semi", "desc"):
+        assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k
+    assert torch.equal(a["objects"][0], b["objects"][0]) and torch.equal(a["objects"][0], c["objects"][0])

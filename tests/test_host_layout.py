@@ -162,3 +162,18 @@ def test_cpu_inputs_fail_loudly():
     if _hip.lib().yp_device_count() == 0:
         with pytest.raises(_hip.YpError):
             U.getPtsFromHeatmap(np.zeros((16, 16), np.float32), 0.1, 4)
+
+
+def test_graph_schedule_respects_dependencies():
+    """Pure host logic: graph edges = RAW/WAR/WAW conflicts on overlapping buffer slices, nothing else."""
+    from yolopoint_amd.plan import PlanBuilder
+    pb = PlanBuilder.__new__(PlanBuilder)
+    pb.accesses = []
+    A, B_, Cc, D = 0x1000, 0x2000, 0x3000, 0x4000
+    pb.accesses.append(([], [(A, 0, 64)]))                       # 0: produce x
+    pb.accesses.append(([(A, 0, 64)], [(B_, 0, 32)]))            # 1: cv1(x)  -> cat[0:32]
+    pb.accesses.append(([(A, 0, 64)], [(B_, 32, 64)]))           # 2: cv2(x)  -> cat[32:64]  (independent of 1)
+    pb.accesses.append(([(B_, 0, 64)], [(Cc, 0, 64)]))           # 3: cv3(cat) needs both
+    pb.accesses.append(([(Cc, 0, 64)], [(Cc, 0, 64)]))           # 4: in-place on the result
+    pb.accesses.append(([(A, 0, 64)], [(D, 0, 8)]))              # 5: another reader of x
+    assert pb.dependencies() == [[], [0], [0], [1, 2], [3], [0]]

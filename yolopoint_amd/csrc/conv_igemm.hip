@@ -66,7 +66,7 @@ struct ConvKArgs {
     int out_cs, out_co;
     int Hi, Wi, Wo, HoWo;
     int Cin, Cout, Kreal, Kpad, Npad;
-    int R, S, sh, sw, ph, pw;
+    int R, S, RS, invS, dt, dc, sh, sw, ph, pw;
     int act;
     int M, tiles_n;
 };
@@ -76,25 +76,52 @@ __device__ __forceinline__ float yp_silu(float x) {
     return x * __frcp_rn(1.0f + __expf(-x));
 }
 
-template <int DT, bool OUT_F32, int BM, int BN, int WAVES_M, int WAVES_N>
+// 16 zero bytes: out-of-image taps / padded k / padded filter rows are fetched from here, so every
+// LDS-DMA lane always has a valid source and no predication or LDS pre-clearing is needed.
+__device__ __attribute__((aligned(16))) unsigned int yp_zero16[4] = {0u, 0u, 0u, 0u};
+
+// One LDS-DMA instruction: 64 lanes x 16 B -> 1 KiB at LDS byte address `lds_dst` (wave-uniform, in
+// an SGPR), lane l landing at lds_dst + 16*l.  Issued through inline asm so that the compiler's
+// LDS-DMA alias tracking does not put s_waitcnt vmcnt(0) in front of the fragment reads; the
+// pipeline below counts these loads itself (they are the only VMEM operations inside the k loop).
+__device__ __forceinline__ void yp_glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+// Pipeline: NS LDS stages; k tile t+NS-1 is in flight (LDS-DMA, global_load_lds_dwordx4: no VGPR
+// round trip) while tile t is multiplied.  One raw s_barrier per k tile; waits are counted
+// s_waitcnt vmcnt(N) so younger tiles stay in flight across the barrier.
+//
+// LDS image of one stage: (BM + BN) dense 64-byte rows (pixels first, then filter rows).  One DMA
+// instruction moves 1 KiB = 16 rows x 4 chunks, lane l -> row l/4, physical chunk l%4 (the hardware
+// places lanes linearly).  Bank conflicts of the 16-byte fragment reads are removed by an XOR
+// swizzle applied on the SOURCE side: physical chunk j of row r holds logical chunk j ^ swz(r),
+// swz(r) = {0,0,3,3}[(r/4)%4]; readers apply the same involution.
+template <int DT, bool OUT_F32, int BM, int BN, int WAVES_M, int WAVES_N, int NS>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     using E = Elem<DT>;
     using frag_t = typename E::frag;
     constexpr int EB = E::BYTES;
     constexpr int CE = 16 / EB;          // elements per 16-byte chunk
     constexpr int BK = 64 / EB;          // k elements per tile (64 bytes of k per row)
-    constexpr int CH = 4;                // chunks per LDS row
-    constexpr int ROWB = 64 + 16;        // padded LDS row pitch in bytes
-    constexpr int RPP = 256 / CH;        // rows filled per loader pass (64)
-    constexpr int AI = BM / RPP;
-    constexpr int BI = (BN + RPP - 1) / RPP;
+    constexpr int ROWB = 64;
+    constexpr int SLOTS_A = BM / 16, SLOTS_B = BN / 16, SLOTS = SLOTS_A + SLOTS_B;
+    constexpr int NLA = SLOTS_A / 4;                 // DMA instructions per wave per tile (pixels)
+    constexpr int NLB = (SLOTS_B + 3) / 4;           //                                   (filter rows)
+    constexpr int NL = NLA + NLB;
+    constexpr int STAGE = SLOTS * 1024;
     constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N;
     constexpr int FM = TM / 16, FN = TN / 16;
     constexpr int LPG = 4 * FN;          // consecutive channels owned by one lane
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
-    static_assert(AI >= 1 && FM >= 1 && FN >= 1, "tile too small");
+    static_assert(BM % 64 == 0 && FM >= 1 && FN >= 1 && NS >= 2 && NS <= 4, "unsupported tile");
+    static_assert(NL * (NS - 2) <= 60, "vmcnt immediate range");
 
-    __shared__ __attribute__((aligned(16))) char smem[2][(BM + BN) * ROWB];
+    __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE];
 
     // ---- XCD-aware tile mapping: workgroup b runs on XCD b%8; give each XCD a contiguous run of
     // logical tiles so that tiles sharing input pixels / filter rows hit the same L2.
@@ -111,14 +138,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int t = threadIdx.x;
-    const int jc = t & (CH - 1);         // chunk column handled by this thread
-    const int r0 = t / CH;               // first row handled by this thread
+    const int lane = t & 63, wave = t >> 6;
+    const int lrow = lane >> 2;                                   // row inside a 16-row DMA slot
+    const int jl = (lane & 3) ^ ((0x3300 >> ((lane >> 4) * 4)) & 3);   // logical chunk this lane fetches
 
-    // ---- per-row gather state (fixed for the whole k loop)
-    int hi0[AI], wi0[AI], bb[AI];
+    // ---- per-slot gather state (fixed for the whole k loop)
+    int hi0[NLA], wi0[NLA], bb[NLA];
 #pragma unroll
-    for (int i = 0; i < AI; ++i) {
-        const int m = m0 + r0 + i * RPP;
+    for (int i = 0; i < NLA; ++i) {
+        const int m = m0 + (wave + 4 * i) * 16 + lrow;
         if (m < a.M) {
             const int b = m / a.HoWo;
             const int rem = m - b * a.HoWo;
@@ -133,83 +161,83 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
             bb[i] = 0;
         }
     }
-    // ---- per-thread filter-tap state for chunk column jc: k = kt*BK + jc*CE = (r*S + s)*Cin + c
-    int kc, ks, kr;
+    const char* b_src[NLB];
+    int b_slot[NLB];
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+        int sl = __builtin_amdgcn_readfirstlane(wave) + 4 * i;
+        if (sl > SLOTS_B - 1) sl = SLOTS_B - 1;       // surplus instructions re-fetch the last slot (same bytes)
+        b_slot[i] = SLOTS_A + sl;
+        const int rho = sl * 16 + lrow;               // LDS row = MFMA row order
+        // MFMA row (wn, f, g, r) holds channel wn*TN + g*LPG + f*4 + r, so that a lane's FN fragments
+        // interleave to LPG consecutive channels in the epilogue
+        const int wn = rho / TN, q = rho % TN;
+        const int f = q >> 4, g = (q & 15) >> 2, r = q & 3;
+        const int n = n0 + wn * TN + g * LPG + f * 4 + r;
+        b_src[i] = (n < a.Npad) ? a.wgt + ((size_t)n * a.Kpad + jl * CE) * EB : nullptr;
+    }
+    // ---- per-lane filter-tap state for logical chunk jl: k = kt*BK + jl*CE = tap*Cin + kc, tap = r*S + s
+    int kc, tap;
     {
-        const int k = jc * CE;
-        const int tap = k / a.Cin;
+        const int k = jl * CE;
+        tap = k / a.Cin;
         kc = k - tap * a.Cin;
-        kr = tap / a.S;
-        ks = tap - kr * a.S;
     }
+    const char* const zero = reinterpret_cast<const char*>(yp_zero16);
 
-    // ---- LDS write offsets
-    int a_wr[AI];
+    // Pin the per-source kernel arguments in SGPRs.  Without this, clang turns `s0 ? a.in0_x : a.in1_x`
+    // into a VECTOR load from a selected kernarg address — a VMEM operation inside the k loop that
+    // would both stall it and corrupt the hand-counted vmcnt waits below.
+#define YP_PIN(T, name) T name = a.name; asm volatile("" : "+s"(name))
+    YP_PIN(const char*, in0); YP_PIN(const char*, in1);
+    YP_PIN(int, in0_cs); YP_PIN(int, in1_cs); YP_PIN(int, in0_co); YP_PIN(int, in1_co); YP_PIN(int, in0_C);
+    YP_PIN(int, in0_ups); YP_PIN(int, in1_ups); YP_PIN(int, in0_H); YP_PIN(int, in1_H); YP_PIN(int, in0_W); YP_PIN(int, in1_W);
+    YP_PIN(int, Hi); YP_PIN(int, Wi); YP_PIN(int, Cin); YP_PIN(int, S); YP_PIN(int, RS); YP_PIN(int, invS); YP_PIN(int, dt); YP_PIN(int, dc);
+#undef YP_PIN
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto issue_tile = [&](int kt, int stage) {
+        const unsigned sbase = lds0 + stage * STAGE;
+        const int kr = (tap * invS) >> 16;          // tap / S (exact: tap < 128, S <= 8)
+        const int ks = tap - kr * S;
+        const bool tapok = tap < RS;
+        const bool s0 = kc < in0_C;
+        const char* base = s0 ? in0 : in1;
+        const int cs = s0 ? in0_cs : in1_cs;
+        const int cc = s0 ? (in0_co + kc) : (in1_co + kc - in0_C);
+        const int ups = s0 ? in0_ups : in1_ups;
+        const int Hp = s0 ? in0_H : in1_H;
+        const int Wp = s0 ? in0_W : in1_W;
 #pragma unroll
-    for (int i = 0; i < AI; ++i) a_wr[i] = (r0 + i * RPP) * ROWB + jc * 16;
-    int b_wr[BI];
-    bool b_ok[BI];
-    const char* b_src[BI];
-#pragma unroll
-    for (int i = 0; i < BI; ++i) {
-        const int nl = r0 + i * RPP;     // tile-local output channel
-        const int n = n0 + nl;
-        b_ok[i] = (nl < BN) && (n < a.Npad);
-        // permute: channel c' = g*LPG + f*4 + r (within a wave's TN span) -> MFMA row f*16 + g*4 + r
-        const int wn = nl / TN, cp = nl % TN;
-        const int g = cp / LPG, f = (cp % LPG) >> 2, r = cp & 3;
-        b_wr[i] = BM * ROWB + (wn * TN + f * 16 + g * 4 + r) * ROWB + jc * 16;
-        b_src[i] = a.wgt + ((size_t)n * a.Kpad + jc * CE) * EB;
-    }
-
-    u32x4 areg[AI], breg[BI];
-    auto load_tile = [&](int kt) {
-        const bool tapok = kr < a.R;
-        const bool s0 = kc < a.in0_C;
-        const char* base = s0 ? a.in0 : a.in1;
-        const int cs = s0 ? a.in0_cs : a.in1_cs;
-        const int cc = s0 ? (a.in0_co + kc) : (a.in1_co + kc - a.in0_C);
-        const int ups = s0 ? a.in0_ups : a.in1_ups;
-        const int Hp = s0 ? a.in0_H : a.in1_H;
-        const int Wp = s0 ? a.in0_W : a.in1_W;
-#pragma unroll
-        for (int i = 0; i < AI; ++i) {
+        for (int i = 0; i < NLA; ++i) {
             const int hi = hi0[i] + kr, wi = wi0[i] + ks;
-            const bool ok = tapok && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (ok) {
-                const size_t pix = ((size_t)bb[i] * Hp + (hi >> ups)) * Wp + (wi >> ups);
-                v = *reinterpret_cast<const u32x4*>(base + (pix * cs + cc) * EB);
-            }
-            areg[i] = v;
+            const bool ok = tapok && (unsigned)hi < (unsigned)Hi && (unsigned)wi < (unsigned)Wi;
+            const long pix = ((long)bb[i] * Hp + (hi >> ups)) * Wp + (wi >> ups);
+            const char* src = base + (pix * cs + cc) * EB;       // only dereferenced when ok
+            yp_glds16(ok ? src : zero, sbase + (wave_u + 4 * i) * 1024);
         }
 #pragma unroll
-        for (int i = 0; i < BI; ++i) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (b_ok[i]) v = *reinterpret_cast<const u32x4*>(b_src[i] + (size_t)kt * BK * EB);
-            breg[i] = v;
+        for (int i = 0; i < NLB; ++i) {
+            const char* src = b_src[i] + (size_t)kt * BK * EB;
+            yp_glds16(b_src[i] != nullptr ? src : zero, sbase + b_slot[i] * 1024);
         }
-        // advance the tap state to the next k tile
-        kc += BK;
-        while (kc >= a.Cin) {
-            kc -= a.Cin;
-            if (++ks == a.S) { ks = 0; ++kr; }
-        }
-    };
-    auto store_tile = [&](int buf) {
-        char* s = smem[buf];
-#pragma unroll
-        for (int i = 0; i < AI; ++i) *reinterpret_cast<u32x4*>(s + a_wr[i]) = areg[i];
-#pragma unroll
-        for (int i = 0; i < BI; ++i)
-            if (BN >= RPP * (i + 1) || (r0 + i * RPP) < BN) *reinterpret_cast<u32x4*>(s + b_wr[i]) = breg[i];
+        // advance to the next k tile: k += BK  ->  (tap, kc) += (BK / Cin, BK % Cin) with carry
+        kc += dc;
+        const bool carry = kc >= Cin;
+        kc -= carry ? Cin : 0;
+        tap += dt + (carry ? 1 : 0);
     };
 
-    const int lane = t & 63, wave = t >> 6;
     const int wm = wave % WAVES_M, wn = wave / WAVES_M;
     const int p = lane & 15, g = lane >> 4;
-    const int a_rd = (wm * TM + p) * ROWB + g * E::KPL * EB;
-    const int b_rd = BM * ROWB + (wn * TN + p) * ROWB + g * E::KPL * EB;
+    const int swr = (0x3300 >> ((p >> 2) * 4)) & 3;               // read-side swizzle of row p (+16k)
+    // byte offset of this lane's fragment inside a row, for k step kk
+    auto koff = [&](int kk) -> int {
+        if constexpr (DT == YP_F32) return ((kk ^ swr) << 4) + g * 4;   // chunk = k step, element g
+        else return ((g ^ swr) << 4);                                    // chunk = lane group (8 elements)
+    };
+    const int a_rd = (wm * TM + p) * ROWB;
+    const int b_rd = (BM + wn * TN + p) * ROWB;
 
     f32x4 acc[FN][FM];
 #pragma unroll
@@ -218,29 +246,34 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
         for (int fm = 0; fm < FM; ++fm) acc[f][fm] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (a.Kreal + BK - 1) / BK;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nk) issue_tile(s, s);
+
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
-        const char* s = smem[cur];
+        // tile kt must have landed; up to NS-2 younger tiles may stay in flight
+        int younger = nk - 1 - kt;
+        if (younger > NS - 2) younger = NS - 2;
+        if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
+        __builtin_amdgcn_s_barrier();
+        // every wave has finished reading tile kt-1: its stage can be refilled
+        if (kt + NS - 1 < nk) issue_tile(kt + NS - 1, (kt + NS - 1) % NS);
+        const char* s = smem + (kt % NS) * STAGE;
 #pragma unroll
         for (int kk = 0; kk < BK / E::KM; ++kk) {
             frag_t wf[FN], xf[FM];
+            const int ko = koff(kk);
 #pragma unroll
-            for (int f = 0; f < FN; ++f)
-                wf[f] = *reinterpret_cast<const frag_t*>(s + b_rd + f * 16 * ROWB + kk * E::KM * EB);
+            for (int f = 0; f < FN; ++f) wf[f] = *reinterpret_cast<const frag_t*>(s + b_rd + f * 16 * ROWB + ko);
 #pragma unroll
-            for (int fm = 0; fm < FM; ++fm)
-                xf[fm] = *reinterpret_cast<const frag_t*>(s + a_rd + fm * 16 * ROWB + kk * E::KM * EB);
+            for (int fm = 0; fm < FM; ++fm) xf[fm] = *reinterpret_cast<const frag_t*>(s + a_rd + fm * 16 * ROWB + ko);
 #pragma unroll
             for (int f = 0; f < FN; ++f)
 #pragma unroll
                 for (int fm = 0; fm < FM; ++fm) acc[f][fm] = E::mma(wf[f], xf[fm], acc[f][fm]);
         }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
-        __syncthreads();
     }
 
     // ---- epilogue: bias -> activation -> (+ residual) -> store, 16-byte vectors per pixel
@@ -249,7 +282,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     const int nb = n0 + wn * TN + g * LPG;
     float bias[LPG];
 #pragma unroll
-    for (int j = 0; j < LPG; ++j) bias[j] = (a.bias != nullptr && nb + j < a.Cout) ? a.bias[nb + j] : 0.f;
+    for (int q = 0; q < LPG / 4; ++q) {     // Cout is a multiple of 8: groups of 4 channels are all-or-nothing
+        f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.bias != nullptr && nb + 4 * q < a.Cout) b4 = *reinterpret_cast<const f32x4*>(a.bias + nb + 4 * q);
+        bias[4 * q] = b4[0]; bias[4 * q + 1] = b4[1]; bias[4 * q + 2] = b4[2]; bias[4 * q + 3] = b4[3];
+    }
 
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm) {
@@ -327,11 +364,11 @@ constexpr TileCfg kTiles[] = {{1, 128, 32}, {2, 128, 64}, {3, 128, 128}, {4, 64,
 template <int DT, bool OUT_F32>
 hipError_t launch_cfg(int tile, const ConvKArgs& a, int nblk, hipStream_t st) {
     switch (tile) {
-        case 1: conv_igemm_kernel<DT, OUT_F32, 128, 32, 4, 1><<<nblk, 256, 0, st>>>(a); break;
-        case 2: conv_igemm_kernel<DT, OUT_F32, 128, 64, 4, 1><<<nblk, 256, 0, st>>>(a); break;
-        case 3: conv_igemm_kernel<DT, OUT_F32, 128, 128, 2, 2><<<nblk, 256, 0, st>>>(a); break;
-        case 4: conv_igemm_kernel<DT, OUT_F32, 64, 64, 2, 2><<<nblk, 256, 0, st>>>(a); break;
-        case 5: conv_igemm_kernel<DT, OUT_F32, 64, 32, 4, 1><<<nblk, 256, 0, st>>>(a); break;
+        case 1: conv_igemm_kernel<DT, OUT_F32, 128, 32, 4, 1, 4><<<nblk, 256, 0, st>>>(a); break;
+        case 2: conv_igemm_kernel<DT, OUT_F32, 128, 64, 4, 1, 4><<<nblk, 256, 0, st>>>(a); break;
+        case 3: conv_igemm_kernel<DT, OUT_F32, 128, 128, 2, 2, 4><<<nblk, 256, 0, st>>>(a); break;
+        case 4: conv_igemm_kernel<DT, OUT_F32, 64, 64, 2, 2, 4><<<nblk, 256, 0, st>>>(a); break;
+        case 5: conv_igemm_kernel<DT, OUT_F32, 64, 32, 4, 1, 4><<<nblk, 256, 0, st>>>(a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -365,7 +402,7 @@ int yp_conv2d_launch(const YpConvDesc* d, hipStream_t stream) {
     YP_REQUIRE(d->in1.C == 0 || (d->in1.ptr && d->in1.cstride % ce == 0 && d->in1.coff % ce == 0), "yp_conv2d: in1 slice not 16-byte aligned");
     YP_REQUIRE(Cout > 0 && Cout % 8 == 0 && d->out.cstride % 8 == 0 && d->out.coff % 8 == 0, "yp_conv2d: output slice (C=%d cs=%d co=%d) must be multiples of 8", Cout, d->out.cstride, d->out.coff);
     YP_REQUIRE(d->res.C == 0 || (d->res.ptr && d->res.C == Cout && d->res.cstride % 8 == 0 && d->res.coff % 8 == 0 && !d->out_f32), "yp_conv2d: bad residual view");
-    YP_REQUIRE(d->B > 0 && d->Ho > 0 && d->Wo > 0 && d->R > 0 && d->S > 0, "yp_conv2d: bad dims");
+    YP_REQUIRE(d->B > 0 && d->Ho > 0 && d->Wo > 0 && d->R > 0 && d->S > 0 && d->S <= 8 && d->R * d->S <= 64, "yp_conv2d: bad dims (filter up to 8 wide, 64 taps)");
     YP_REQUIRE(d->in0.ups >= 0 && d->in0.ups <= 1 && d->in1.ups >= 0 && d->in1.ups <= 1, "yp_conv2d: ups must be 0/1");
     YP_REQUIRE((d->in0.H << d->in0.ups) == d->Hi && (d->in0.W << d->in0.ups) == d->Wi, "yp_conv2d: in0 %dx%d<<%d != logical %dx%d", d->in0.H, d->in0.W, d->in0.ups, d->Hi, d->Wi);
     YP_REQUIRE(d->in1.C == 0 || ((d->in1.H << d->in1.ups) == d->Hi && (d->in1.W << d->in1.ups) == d->Wi), "yp_conv2d: in1 dims mismatch");
@@ -386,7 +423,9 @@ int yp_conv2d_launch(const YpConvDesc* d, hipStream_t stream) {
     a.out_cs = d->out.cstride; a.out_co = d->out.coff;
     a.Hi = d->Hi; a.Wi = d->Wi; a.Wo = d->Wo; a.HoWo = d->Ho * d->Wo;
     a.Cin = Cin; a.Cout = Cout; a.Kreal = Kreal; a.Kpad = d->Kpad; a.Npad = d->Npad;
-    a.R = d->R; a.S = d->S; a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w;
+    a.R = d->R; a.S = d->S; a.RS = d->R * d->S; a.invS = (65536 + d->S - 1) / d->S;
+    { const int bk = d->dtype == YP_F32 ? 16 : 32; a.dt = bk / Cin; a.dc = bk % Cin; }
+    a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w;
     a.act = d->act; a.M = (int)Ml;
 
     int tile = d->tile ? d->tile : pick_tile(a.M, Cout);

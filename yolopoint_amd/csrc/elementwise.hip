@@ -106,6 +106,66 @@ __global__ void sppf_pool_kernel(const char* __restrict__ x, int xcs, int xco, c
     }
 }
 
+// LDS-resident version: one workgroup owns one image x one 16-byte channel chunk; the whole H x W
+// plane of that chunk sits in LDS and the three MaxPool2d(5,1,2) are applied exactly as the
+// reference chains them (separable: 5-wide row max, then 5-tall column max), ping-ponging between
+// three LDS planes.  6 passes x 5 LDS reads per pixel instead of 169 global reads.
+template <int DT>
+__global__ __launch_bounds__(256) void sppf_pool_lds_kernel(const char* __restrict__ x, int xcs, int xco, char* __restrict__ y1,
+                                                            int y1cs, int y1co, char* __restrict__ y2, int y2cs, int y2co,
+                                                            char* __restrict__ y3, int y3cs, int y3co, int H, int W, int C) {
+    using T = typename Sc<DT>::t;
+    constexpr int CE = 16 / sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) char pool_smem[];
+    const int HW = H * W;
+    u32x4* p0 = reinterpret_cast<u32x4*>(pool_smem);
+    u32x4* p1 = p0 + HW;
+    u32x4* p2 = p1 + HW;
+    const int chunks = C / CE;
+    const int b = blockIdx.x / chunks, ch = blockIdx.x % chunks;
+    const size_t pix0 = (size_t)b * HW;
+    for (int i = threadIdx.x; i < HW; i += 256)
+        p0[i] = *reinterpret_cast<const u32x4*>(x + ((pix0 + i) * xcs + xco + ch * CE) * sizeof(T));
+    __syncthreads();
+    auto vmax = [](u32x4 a, u32x4 c) -> u32x4 {
+        const T* ea = reinterpret_cast<const T*>(&a);
+        const T* ec = reinterpret_cast<const T*>(&c);
+        u32x4 r;
+        T* er = reinterpret_cast<T*>(&r);
+#pragma unroll
+        for (int j = 0; j < CE; ++j) er[j] = (float)ea[j] >= (float)ec[j] ? ea[j] : ec[j];
+        return r;
+    };
+    auto rowpass = [&](const u32x4* src, u32x4* dst) {
+        for (int i = threadIdx.x; i < HW; i += 256) {
+            const int w = i % W;
+            u32x4 m = src[i];
+            for (int d = 1; d <= 2; ++d) {
+                if (w - d >= 0) m = vmax(m, src[i - d]);
+                if (w + d < W) m = vmax(m, src[i + d]);
+            }
+            dst[i] = m;
+        }
+        __syncthreads();
+    };
+    auto colpass = [&](const u32x4* src, u32x4* dst, char* y, int ycs, int yco) {
+        for (int i = threadIdx.x; i < HW; i += 256) {
+            const int h = i / W;
+            u32x4 m = src[i];
+            for (int d = 1; d <= 2; ++d) {
+                if (h - d >= 0) m = vmax(m, src[i - d * W]);
+                if (h + d < H) m = vmax(m, src[i + d * W]);
+            }
+            dst[i] = m;
+            *reinterpret_cast<u32x4*>(y + ((pix0 + i) * ycs + yco + ch * CE) * sizeof(T)) = m;
+        }
+        __syncthreads();
+    };
+    rowpass(p0, p1); colpass(p1, p2, y1, y1cs, y1co);     // y1 = m(x)
+    rowpass(p2, p1); colpass(p1, p0, y2, y2cs, y2co);     // y2 = m(y1)
+    rowpass(p0, p1); colpass(p1, p2, y3, y3cs, y3co);     // y3 = m(y2)
+}
+
 // ------------------------------------------------------------------ descriptor L2 norm (fp32)
 // one wavefront per pixel: lanes stride over channels, butterfly-reduce the sum of squares.
 __global__ void l2norm_kernel(const float* __restrict__ in, int ics, int ico, float* __restrict__ out, int ocs, int oco,
@@ -201,6 +261,22 @@ extern "C" int yp_sppf_pool(YpView x, YpView y1, YpView y2, YpView y3, int B, in
     YP_REQUIRE(x.cstride % ce == 0 && x.coff % ce == 0 && y1.cstride % ce == 0 && y1.coff % ce == 0 && y2.cstride % ce == 0 &&
                    y2.coff % ce == 0 && y3.cstride % ce == 0 && y3.coff % ce == 0, "yp_sppf_pool: slices must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)3 * x.H * x.W * 16;
+    if (lds <= 96 * 1024) {     // the plane fits in LDS three times: cascaded separable pooling
+        const int nb = B * (x.C / ce);
+#define YP_SPPF_LDS(DT)                                                                                                      \
+    sppf_pool_lds_kernel<DT><<<nb, 256, lds, st>>>((const char*)x.ptr, x.cstride, x.coff, (char*)y1.ptr, y1.cstride, y1.coff, \
+                                                   (char*)y2.ptr, y2.cstride, y2.coff, (char*)y3.ptr, y3.cstride, y3.coff, x.H, x.W, x.C)
+        switch (dtype) {
+            case YP_F16: YP_SPPF_LDS(YP_F16); break;
+            case YP_BF16: YP_SPPF_LDS(YP_BF16); break;
+            case YP_F32: YP_SPPF_LDS(YP_F32); break;
+            default: YP_REQUIRE(false, "yp_sppf_pool: bad dtype %d", dtype);
+        }
+#undef YP_SPPF_LDS
+        YP_CHECK_HIP(hipGetLastError());
+        return YP_OK;
+    }
     const size_t n = (size_t)B * x.H * x.W * (x.C / ce);
     const int g = grid_for(n, 256);
 #define YP_SPPF(DT)                                                                                               \

@@ -36,12 +36,15 @@ struct PlanOp {
     float anchors[16];
     float* x_out;
     float* z_out;
+    bool has_deps = false;
+    std::vector<int> deps;      // earlier op indices this op must wait for (true data dependencies)
 };
 
 struct YpPlan {
     std::vector<PlanOp> ops;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    bool parallel = false;              // graph edges rewired to the data dependencies
 };
 
 static int run_op(const PlanOp& op, hipStream_t st) {
@@ -131,11 +134,30 @@ static int run_eager(YpPlan* plan, hipStream_t st) {
     return YP_OK;
 }
 
+extern "C" int yp_plan_set_deps(YpPlan* plan, int op, const int* deps, int ndeps) {
+    YP_PLAN_MUTABLE(plan);
+    YP_REQUIRE(op >= 0 && op < (int)plan->ops.size() && ndeps >= 0, "yp_plan_set_deps: bad argument");
+    PlanOp& o = plan->ops[op];
+    o.deps.clear();
+    o.has_deps = true;
+    for (int i = 0; i < ndeps; ++i) {
+        YP_REQUIRE(deps[i] >= 0 && deps[i] < op, "yp_plan_set_deps: dependency %d of op %d is not an earlier op", deps[i], op);
+        o.deps.push_back(deps[i]);
+    }
+    return YP_OK;
+}
+
+// Capture the launch list into a hipGraph.  The ops are captured as a linear chain on `stream`
+// (one kernel node per op); when every op carries a dependency list the chain's edges are then
+// replaced by the true data dependencies, so independent branches of the network (keypoint head,
+// descriptor head, YOLO encoder, C3.cv2 beside the bottleneck chain, the three Detect levels) become
+// parallel branches of the graph and overlap on the GPU.
 extern "C" int yp_plan_instantiate_graph(YpPlan* plan, void* stream) {
     YP_REQUIRE(plan != nullptr, "yp_plan_instantiate_graph: null plan");
     YP_REQUIRE(plan->exec == nullptr, "yp_plan_instantiate_graph: already instantiated");
     hipStream_t st = (hipStream_t)stream;
     YP_REQUIRE(st != nullptr, "yp_plan_instantiate_graph: capture needs a non-default stream");
+    const size_t n = plan->ops.size();
     YP_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     const int rc = run_eager(plan, st);
     hipGraph_t g = nullptr;
@@ -143,9 +165,41 @@ extern "C" int yp_plan_instantiate_graph(YpPlan* plan, void* stream) {
     if (rc != YP_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
     YP_CHECK_HIP(e);
     plan->graph = g;
+
+    bool rewire = n > 1;
+    for (const PlanOp& op : plan->ops) rewire = rewire && op.has_deps;
+    size_t nn = 0, ne = 0;
+    YP_CHECK_HIP(hipGraphGetNodes(g, nullptr, &nn));
+    YP_CHECK_HIP(hipGraphGetEdges(g, nullptr, nullptr, &ne));
+    if (rewire && nn == n && ne == n - 1) {
+        std::vector<hipGraphNode_t> from(ne), to(ne), chain;
+        YP_CHECK_HIP(hipGraphGetEdges(g, from.data(), to.data(), &ne));
+        size_t nroot = 0;
+        YP_CHECK_HIP(hipGraphGetRootNodes(g, nullptr, &nroot));
+        if (nroot == 1) {
+            hipGraphNode_t cur;
+            YP_CHECK_HIP(hipGraphGetRootNodes(g, &cur, &nroot));
+            chain.push_back(cur);
+            for (size_t step = 0; step + 1 < n; ++step) {
+                bool found = false;
+                for (size_t k = 0; k < ne && !found; ++k)
+                    if (from[k] == cur) { cur = to[k]; found = true; }
+                if (!found) break;
+                chain.push_back(cur);
+            }
+        }
+        if (chain.size() == n) {
+            YP_CHECK_HIP(hipGraphRemoveDependencies(g, from.data(), to.data(), ne));
+            for (size_t j = 0; j < n; ++j)
+                for (int d : plan->ops[j].deps) YP_CHECK_HIP(hipGraphAddDependencies(g, &chain[d], &chain[j], 1));
+            plan->parallel = true;
+        }
+    }
     YP_CHECK_HIP(hipGraphInstantiate(&plan->exec, g, nullptr, nullptr, 0));
     return YP_OK;
 }
+
+extern "C" int yp_plan_graph_is_parallel(const YpPlan* plan) { return plan && plan->parallel ? 1 : 0; }
 
 extern "C" int yp_plan_run(YpPlan* plan, void* stream) {
     YP_REQUIRE(plan != nullptr, "yp_plan_run: null plan");

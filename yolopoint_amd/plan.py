@@ -109,6 +109,7 @@ class PlanBuilder:
         check(lib().yp_plan_create(C.byref(self.handle)))
         self.keep = []          # tensors the native plan points into
         self.records = []       # per-op algorithmic work (for roofline accounting)
+        self.accesses = []      # per-op (reads, writes) as (buffer key, lo, hi) ranges, for the graph schedule
         self.scope = []
 
     # -- naming -------------------------------------------------------------------------
@@ -125,6 +126,33 @@ class PlanBuilder:
         t = torch.zeros(shape, dtype=dtype, device=self.device)
         self.keep.append(t)
         return t
+
+    # -- dependency tracking (feeds the multi-stream graph schedule) ---------------------------
+    @staticmethod
+    def _rng(v):
+        if isinstance(v, View):
+            if v.geom is not None:                      # paired-pixel stem view: the whole buffer
+                return (v.buf.t.data_ptr(), 0, 1 << 30)
+            return (v.buf.t.data_ptr(), v.coff, v.coff + v.C)
+        t, lo, hi = v                                   # (tensor, lo, hi) for plain output tensors
+        return (t.data_ptr(), lo, hi)
+
+    def _track(self, reads, writes):
+        self.accesses.append(([self._rng(v) for v in reads if v is not None], [self._rng(v) for v in writes if v is not None]))
+
+    def dependencies(self):
+        """deps[j] = sorted earlier op indices j must wait for (RAW, WAR, WAW on overlapping slices)."""
+        def overlap(a, b):
+            return a[0] == b[0] and a[1] < b[2] and b[1] < a[2]
+        deps = []
+        for j, (rd, wr) in enumerate(self.accesses):
+            d = set()
+            for i in range(j):
+                ri, wi = self.accesses[i]
+                if any(overlap(r, w) for r in rd for w in wi) or any(overlap(w, x) for w in wr for x in ri + wi):
+                    d.add(i)
+            deps.append(sorted(d))
+        return deps
 
     # -- ops ----------------------------------------------------------------------------
     def conv(self, srcs, w, bias, k, s, p, act, out=None, res=None, out_f32=False, tile=0):
@@ -173,6 +201,7 @@ class PlanBuilder:
         d.R, d.S, d.stride_h, d.stride_w, d.pad_h, d.pad_w = R, S, sh, sw, ph, pw
         d.Kpad, d.Npad, d.act, d.tile = Kpad, Npad, act, tile
         check(lib().yp_plan_add_conv(self.handle, C.byref(d)))
+        self._track(list(srcs) + [res], [out])
         # algorithmic work: MAC*2 with the REAL channel counts (BASELINE.md section 2 convention)
         Kreal = w.shape[1] * w.shape[2] * w.shape[3] if not thin else Cin * R * (S * (2 if self.ce == 8 else 1))
         M = self.B * Ho * Wo
@@ -184,11 +213,13 @@ class PlanBuilder:
 
     def sppf_pool(self, x, y1, y2, y3):
         check(lib().yp_plan_add_sppf_pool(self.handle, x.c(), y1.c(), y2.c(), y3.c(), self.B, self.code))
+        self._track([x], [y1, y2, y3])
         eb = 4 if self.code == _hip.YP_F32 else 2
         self.records.append(OpRecord(self.name("m"), "pool", 0, 4 * self.B * x.H * x.W * x.C * eb))
 
     def l2norm(self, src, dst, C_):
         check(lib().yp_plan_add_l2norm(self.handle, src.c(), dst.c(), self.B, C_))
+        self._track([src], [dst])
         self.records.append(OpRecord(self.name("l2norm"), "l2norm", 0, 2 * self.B * src.H * src.W * C_ * 4))
 
     def detect_decode(self, raw, na, no, stride, anchors_px, x_out, z_out, rows_total, row_offset):
@@ -196,10 +227,19 @@ class PlanBuilder:
         check(lib().yp_plan_add_detect_decode(self.handle, raw.c(), self.B, na, no, float(stride), arr,
                                               x_out.data_ptr(), z_out.data_ptr() if z_out is not None else None,
                                               rows_total, row_offset))
+        rows = na * raw.H * raw.W
+        self._track([raw], [(x_out, 0, 1 << 30)] + ([(z_out, row_offset, row_offset + rows)] if z_out is not None else []))
         n = self.B * na * raw.H * raw.W * no * 4
         self.records.append(OpRecord(self.name("decode"), "decode", 0, n * (3 if z_out is not None else 2)))
 
-    def finish(self):
+    def finish(self, parallel=True):
+        """Freeze the plan; attach the data dependencies used when it is captured into a hipGraph."""
+        assert len(self.accesses) == len(self.records) == lib().yp_plan_num_ops(self.handle)
+        self.deps = self.dependencies() if parallel else None
+        if self.deps is not None:
+            for j, d in enumerate(self.deps):
+                arr = (C.c_int * max(len(d), 1))(*d)
+                check(lib().yp_plan_set_deps(self.handle, j, arr, len(d)))
         return ExecPlan(self)
 
 
@@ -209,6 +249,7 @@ class ExecPlan:
     def __init__(self, pb):
         self.handle, self.keep, self.records = pb.handle, pb.keep, pb.records
         self.B, self.code, self.device = pb.B, pb.code, pb.device
+        self.deps = pb.deps
         self.graph = False
 
     def num_ops(self):
@@ -224,6 +265,7 @@ class ExecPlan:
             check(lib().yp_plan_instantiate_graph(self.handle, _hip.stream_ptr(s)))
         torch.cuda.current_stream().wait_stream(s)
         self.graph = True
+        self.parallel = bool(lib().yp_plan_graph_is_parallel(self.handle))
 
     def run(self, stream=None):
         check(lib().yp_plan_run(self.handle, _hip.stream_ptr(stream)))
