@@ -90,6 +90,8 @@ typedef struct YpConvDesc {
     int32_t Kpad, Npad;              /* packed weight dims                             */
     int32_t act;                     /* YP_ACT_*                                       */
     int32_t tile;                    /* 0 = auto, else forced tile config id (testing) */
+    int32_t tail_zero;               /* 1: each input buffer is followed by >= 16 zero bytes and `weight` by one
+                                      * zero row [Kpad] -> the kernel may use its fast 32-bit DMA addressing    */
 } YpConvDesc;
 
 int yp_conv2d(const YpConvDesc* d, void* stream);

@@ -99,7 +99,7 @@ def test_pack_conv_weight_layout():
     w = torch.arange(5 * 8 * 3 * 3, dtype=torch.float32).view(5, 8, 3, 3)
     b = torch.arange(5, dtype=torch.float32)
     wp, bp, Kpad, Npad = pack_conv_weight(w, b, _hip.YP_F32, "cpu")
-    assert (Kpad, Npad) == (96, 8) and wp.shape == (8, 96)
+    assert (Kpad, Npad) == (96, 8) and wp.shape == (9, 96)      # + the zero row behind the filter
     assert float(wp[3, (1 * 3 + 2) * 8 + 5]) == float(w[3, 5, 1, 2])
     assert float(wp[:, 72:].abs().max()) == 0 and float(wp[5:].abs().max()) == 0 and torch.equal(bp[:5], b)
     wp16, _, Kpad16, _ = pack_conv_weight(w, None, _hip.YP_F16, "cpu")
@@ -134,7 +134,7 @@ def test_cabi_exports_every_declared_symbol():
 
 
 def test_cabi_struct_sizes_and_argument_errors():
-    assert ctypes.sizeof(_hip.YpView) == 32 and ctypes.sizeof(_hip.YpConvDesc) == 4 * 32 + 16 + 17 * 4 + 4
+    assert ctypes.sizeof(_hip.YpView) == 32 and ctypes.sizeof(_hip.YpConvDesc) == 4 * 32 + 16 + 18 * 4
     l = _hip.lib()
     # argument validation happens before any device work, so it is testable on a CPU-only host
     rc = l.yp_conv2d(None, None)

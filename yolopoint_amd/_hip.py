@@ -30,7 +30,7 @@ class YpConvDesc(C.Structure):
                 ("Hi", C.c_int32), ("Wi", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
                 ("R", C.c_int32), ("S", C.c_int32),
                 ("stride_h", C.c_int32), ("stride_w", C.c_int32), ("pad_h", C.c_int32), ("pad_w", C.c_int32),
-                ("Kpad", C.c_int32), ("Npad", C.c_int32), ("act", C.c_int32), ("tile", C.c_int32)]
+                ("Kpad", C.c_int32), ("Npad", C.c_int32), ("act", C.c_int32), ("tile", C.c_int32), ("tail_zero", C.c_int32)]
 
 
 _i, _f, _p, _sz, _i64 = C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_int64

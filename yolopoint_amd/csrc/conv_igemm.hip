@@ -67,6 +67,7 @@ struct ConvKArgs {
     int Hi, Wi, Wo, HoWo;
     int Cin, Cout, Kreal, Kpad, Npad;
     int R, S, RS, invS, dt, dc, sh, sw, ph, pw;
+    unsigned in0_zoff, in1_zoff, wgt_zrow;   // FAST path: byte offsets of the 16 zero bytes behind each input / the zero filter row
     int act;
     int M, tiles_n;
 };
@@ -92,6 +93,15 @@ __device__ __forceinline__ void yp_glds16(const void* gsrc, unsigned lds_dst) {
                  : "memory");
 }
 
+// Same, with the source given as a wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset.
+__device__ __forceinline__ void yp_glds16_s(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+
 // Pipeline: NS LDS stages; k tile t+NS-1 is in flight (LDS-DMA, global_load_lds_dwordx4: no VGPR
 // round trip) while tile t is multiplied.  One raw s_barrier per k tile; waits are counted
 // s_waitcnt vmcnt(N) so younger tiles stay in flight across the barrier.
@@ -101,7 +111,7 @@ __device__ __forceinline__ void yp_glds16(const void* gsrc, unsigned lds_dst) {
 // places lanes linearly).  Bank conflicts of the 16-byte fragment reads are removed by an XOR
 // swizzle applied on the SOURCE side: physical chunk j of row r holds logical chunk j ^ swz(r),
 // swz(r) = {0,0,3,3}[(r/4)%4]; readers apply the same involution.
-template <int DT, bool OUT_F32, int BM, int BN, int WAVES_M, int WAVES_N, int NS>
+template <int DT, bool OUT_F32, bool FAST, int BM, int BN, int WAVES_M, int WAVES_N, int NS>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     using E = Elem<DT>;
     using frag_t = typename E::frag;
@@ -162,6 +172,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
         }
     }
     const char* b_src[NLB];
+    unsigned b_off[NLB];
     int b_slot[NLB];
 #pragma unroll
     for (int i = 0; i < NLB; ++i) {
@@ -175,6 +186,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
         const int f = q >> 4, g = (q & 15) >> 2, r = q & 3;
         const int n = n0 + wn * TN + g * LPG + f * 4 + r;
         b_src[i] = (n < a.Npad) ? a.wgt + ((size_t)n * a.Kpad + jl * CE) * EB : nullptr;
+        b_off[i] = ((n < a.Npad) ? (unsigned)n * (unsigned)a.Kpad * EB : a.wgt_zrow) + jl * 16;
     }
     // ---- per-lane filter-tap state for logical chunk jl: k = kt*BK + jl*CE = tap*Cin + kc, tap = r*S + s
     int kc, tap;
@@ -194,10 +206,43 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     YP_PIN(int, in0_ups); YP_PIN(int, in1_ups); YP_PIN(int, in0_H); YP_PIN(int, in1_H); YP_PIN(int, in0_W); YP_PIN(int, in1_W);
     YP_PIN(int, Hi); YP_PIN(int, Wi); YP_PIN(int, Cin); YP_PIN(int, S); YP_PIN(int, RS); YP_PIN(int, invS); YP_PIN(int, dt); YP_PIN(int, dc);
 #undef YP_PIN
+#define YP_PIN2(T, name) T name = a.name; asm volatile("" : "+s"(name))
     const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // FAST path state: every lane of the workgroup is in the same filter tap (Cin % BK == 0), so the tap
+    // decode, the source select and the channel offset live on the scalar unit.
+    int s_tap = 0, s_c0 = 0;
+    YP_PIN2(unsigned, in0_zoff); YP_PIN2(unsigned, in1_zoff); YP_PIN2(const char*, wgt);
     auto issue_tile = [&](int kt, int stage) {
         const unsigned sbase = lds0 + stage * STAGE;
+        if constexpr (FAST) {
+            const int kr = (s_tap * invS) >> 16;
+            const int ks = s_tap - kr * S;
+            const bool s0 = s_c0 < in0_C;
+            const char* base = s0 ? in0 : in1;
+            const int cs = s0 ? in0_cs : in1_cs;
+            const int ups = s0 ? in0_ups : in1_ups;
+            const int Hp = s0 ? in0_H : in1_H;
+            const int Wp = s0 ? in0_W : in1_W;
+            const unsigned zoff = s0 ? in0_zoff : in1_zoff;
+            const int cbyte = ((s0 ? in0_co + s_c0 : in1_co + s_c0 - in0_C)) * EB;     // scalar
+            const int csb = cs * EB;
+            const unsigned lanec = (unsigned)jl * 16u;
+#pragma unroll
+            for (int i = 0; i < NLA; ++i) {
+                const int hi = hi0[i] + kr, wi = wi0[i] + ks;
+                const bool ok = (unsigned)hi < (unsigned)Hi && (unsigned)wi < (unsigned)Wi;
+                const int pix = (bb[i] * Hp + (hi >> ups)) * Wp + (wi >> ups);
+                const unsigned off = (unsigned)(pix * csb + cbyte) + lanec;
+                yp_glds16_s(base, ok ? off : zoff, sbase + (wave_u + 4 * i) * 1024);
+            }
+            const char* wk = wgt + (size_t)kt * (BK * EB);
+#pragma unroll
+            for (int i = 0; i < NLB; ++i) yp_glds16_s(wk, b_off[i], sbase + b_slot[i] * 1024);
+            s_c0 += BK;
+            if (s_c0 >= Cin) { s_c0 -= Cin; ++s_tap; }
+            return;
+        }
         const int kr = (tap * invS) >> 16;          // tap / S (exact: tap < 128, S <= 8)
         const int ks = tap - kr * S;
         const bool tapok = tap < RS;
@@ -361,14 +406,14 @@ namespace {
 struct TileCfg { int id, bm, bn; };
 constexpr TileCfg kTiles[] = {{1, 128, 32}, {2, 128, 64}, {3, 128, 128}, {4, 64, 64}, {5, 64, 32}};
 
-template <int DT, bool OUT_F32>
+template <int DT, bool OUT_F32, bool FAST>
 hipError_t launch_cfg(int tile, const ConvKArgs& a, int nblk, hipStream_t st) {
     switch (tile) {
-        case 1: conv_igemm_kernel<DT, OUT_F32, 128, 32, 4, 1, 4><<<nblk, 256, 0, st>>>(a); break;
-        case 2: conv_igemm_kernel<DT, OUT_F32, 128, 64, 4, 1, 4><<<nblk, 256, 0, st>>>(a); break;
-        case 3: conv_igemm_kernel<DT, OUT_F32, 128, 128, 2, 2, 4><<<nblk, 256, 0, st>>>(a); break;
-        case 4: conv_igemm_kernel<DT, OUT_F32, 64, 64, 2, 2, 4><<<nblk, 256, 0, st>>>(a); break;
-        case 5: conv_igemm_kernel<DT, OUT_F32, 64, 32, 4, 1, 4><<<nblk, 256, 0, st>>>(a); break;
+        case 1: conv_igemm_kernel<DT, OUT_F32, FAST, 128, 32, 4, 1, 4><<<nblk, 256, 0, st>>>(a); break;
+        case 2: conv_igemm_kernel<DT, OUT_F32, FAST, 128, 64, 4, 1, 4><<<nblk, 256, 0, st>>>(a); break;
+        case 3: conv_igemm_kernel<DT, OUT_F32, FAST, 128, 128, 2, 2, 4><<<nblk, 256, 0, st>>>(a); break;
+        case 4: conv_igemm_kernel<DT, OUT_F32, FAST, 64, 64, 2, 2, 4><<<nblk, 256, 0, st>>>(a); break;
+        case 5: conv_igemm_kernel<DT, OUT_F32, FAST, 64, 32, 4, 1, 4><<<nblk, 256, 0, st>>>(a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -435,13 +480,28 @@ int yp_conv2d_launch(const YpConvDesc* d, hipStream_t stream) {
     a.tiles_n = yp_cdiv(Cout, tc->bn);
     const int nblk = yp_cdiv(a.M, tc->bm) * a.tiles_n;
 
+    // FAST DMA addressing: wave-uniform taps (k tile never straddles a tap or the source boundary), 16 zero
+    // bytes behind each input buffer and a zero filter row behind the packed weights, 32-bit byte offsets.
+    const int bk = d->dtype == YP_F32 ? 16 : 32;
+    const int eb = yp_dtype_bytes(d->dtype);
+    const size_t in0_bytes = (size_t)d->B * d->in0.H * d->in0.W * d->in0.cstride * eb;
+    const size_t in1_bytes = d->in1.C ? (size_t)d->B * d->in1.H * d->in1.W * d->in1.cstride * eb : 0;
+    const size_t wgt_bytes = (size_t)d->Npad * d->Kpad * eb;
+    const bool fast = d->tail_zero && Cin % bk == 0 && d->in0.C % bk == 0 && in0_bytes < (1ull << 31) && in1_bytes < (1ull << 31) &&
+                      wgt_bytes < (1ull << 31);
+    a.in0_zoff = (unsigned)in0_bytes; a.in1_zoff = (unsigned)in1_bytes; a.wgt_zrow = (unsigned)wgt_bytes;
+
     hipError_t e;
     const bool of32 = d->out_f32 != 0;
+#define YP_DISPATCH(DT)                                                                                             \
+    (of32 ? (fast ? launch_cfg<DT, true, true>(tile, a, nblk, stream) : launch_cfg<DT, true, false>(tile, a, nblk, stream)) \
+          : (fast ? launch_cfg<DT, false, true>(tile, a, nblk, stream) : launch_cfg<DT, false, false>(tile, a, nblk, stream)))
     switch (d->dtype) {
-        case YP_F16: e = of32 ? launch_cfg<YP_F16, true>(tile, a, nblk, stream) : launch_cfg<YP_F16, false>(tile, a, nblk, stream); break;
-        case YP_BF16: e = of32 ? launch_cfg<YP_BF16, true>(tile, a, nblk, stream) : launch_cfg<YP_BF16, false>(tile, a, nblk, stream); break;
-        default: e = launch_cfg<YP_F32, false>(tile, a, nblk, stream); break;
+        case YP_F16: e = YP_DISPATCH(YP_F16); break;
+        case YP_BF16: e = YP_DISPATCH(YP_BF16); break;
+        default: e = fast ? launch_cfg<YP_F32, false, true>(tile, a, nblk, stream) : launch_cfg<YP_F32, false, false>(tile, a, nblk, stream); break;
     }
+#undef YP_DISPATCH
     if (e != hipSuccess) {
         yp_set_error("yp_conv2d: launch failed: %s", hipGetErrorString(e));
         return YP_ERR_HIP;

@@ -25,7 +25,10 @@ class Buf:
 
     def __init__(self, B, H, W, C_, tdtype, device, zero=True):
         self.B, self.H, self.W, self.C = B, H, W, C_
-        self.t = (torch.zeros if zero else torch.empty)((B, H, W, C_), dtype=tdtype, device=device)
+        # 64 zero elements behind the pixels: the conv kernel's DMA fetches padding / out-of-image taps from there
+        n = B * H * W * C_
+        self.flat = torch.zeros((n + 64,), dtype=tdtype, device=device)
+        self.t = self.flat[:n].view(B, H, W, C_)
 
     def view(self, coff=0, C_=None, ups=0):
         return View(self, coff, self.C - coff if C_ is None else C_, ups)
@@ -82,7 +85,7 @@ def pack_conv_weight(w, bias, code, device):
     Kpad = lib().yp_conv_kpad(K, code)
     Npad = round_up(Cout, 8)
     wk = w.detach().to(torch.float32).permute(0, 2, 3, 1).reshape(Cout, K)
-    wp = torch.zeros((Npad, Kpad), dtype=torch.float32, device=wk.device)
+    wp = torch.zeros((Npad + 1, Kpad), dtype=torch.float32, device=wk.device)     # + one zero row (see tail_zero)
     wp[:Cout, :K] = wk
     bp = torch.zeros((Npad,), dtype=torch.float32, device=wk.device)
     if bias is not None:
@@ -119,7 +122,7 @@ class PlanBuilder:
     # -- buffers ------------------------------------------------------------------------
     def new_buf(self, H, W, C_, f32=False):
         b = Buf(self.B, H, W, C_, torch.float32 if f32 else self.tdtype, self.device)
-        self.keep.append(b.t)
+        self.keep.append(b.flat)
         return b
 
     def new_tensor(self, shape, dtype=torch.float32):
@@ -199,7 +202,7 @@ class PlanBuilder:
         d.dtype, d.out_f32, d.B = self.code, int(out_f32), self.B
         d.Hi, d.Wi, d.Ho, d.Wo = Hi, Wi, Ho, Wo
         d.R, d.S, d.stride_h, d.stride_w, d.pad_h, d.pad_w = R, S, sh, sw, ph, pw
-        d.Kpad, d.Npad, d.act, d.tile = Kpad, Npad, act, tile
+        d.Kpad, d.Npad, d.act, d.tile, d.tail_zero = Kpad, Npad, act, tile, 1
         check(lib().yp_plan_add_conv(self.handle, C.byref(d)))
         self._track(list(srcs) + [res], [out])
         # algorithmic work: MAC*2 with the REAL channel counts (BASELINE.md section 2 convention)
