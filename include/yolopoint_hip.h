@@ -75,9 +75,13 @@ typedef struct YpView {
  *   Cin      = in0.C + in1.C (in1.C == 0 for a single source)
  *   Cout     = out.C (multiple of 8; rows >= real Cout are zero in `weight`)
  *   out_f32  write fp32 instead of `dtype` (head outputs: logits / descriptors)
+ *   out2     optional second destination: output channels [out.C, out.C + out2.C) go to `out2`
+ *            (two convolutions of the same input fused into one launch, e.g. C3.cv1 + C3.cv2,
+ *            reference models/common.py:135); out2.C == 0 when unused
  * ---------------------------------------------------------------------------------- */
 typedef struct YpConvDesc {
     YpView in0, in1, out, res;       /* res.C == 0: no residual                       */
+    YpView out2;                     /* out2.C == 0: single destination               */
     const void* weight;
     const float* bias;
     int32_t dtype;                   /* YP_F16 | YP_BF16 | YP_F32                     */
@@ -90,8 +94,9 @@ typedef struct YpConvDesc {
     int32_t Kpad, Npad;              /* packed weight dims                             */
     int32_t act;                     /* YP_ACT_*                                       */
     int32_t tile;                    /* 0 = auto, else forced tile config id (testing) */
-    int32_t tail_zero;               /* 1: each input buffer is followed by >= 16 zero bytes and `weight` by one
-                                      * zero row [Kpad] -> the kernel may use its fast 32-bit DMA addressing    */
+    int32_t tail_zero;               /* 1: each input buffer is followed by >= (cstride + 64) zero elements and
+                                      * `weight` by one zero row [Kpad] -> the kernels may use their fast 32-bit
+                                      * DMA addressing (padding taps are fetched from those zeros)              */
 } YpConvDesc;
 
 int yp_conv2d(const YpConvDesc* d, void* stream);

@@ -115,3 +115,59 @@ def test_blocks(cuda, kind, dtype):
     got = m.to(cuda)(x.to(cuda))
     e_max, _ = rel_err(got, ref)
     assert e_max < TOL[dtype] * 2, (kind, dtype, e_max)
+
+
+HALO_CASES = [
+    # c1, c2, stride, B, H, W, tile(10: BN=32, 11: BN=64, 12: BN=128, 0: auto)
+    (32, 32, 1, 2, 24, 40, 10), (64, 64, 1, 1, 20, 20, 11), (64, 64, 1, 2, 19, 23, 0), (128, 128, 1, 1, 17, 33, 12),
+    (32, 64, 2, 2, 32, 48, 11), (64, 128, 2, 1, 22, 18, 12), (128, 64, 2, 1, 40, 40, 0), (256, 256, 1, 1, 9, 11, 0),
+    (64, 72, 1, 1, 16, 16, 12),       # Cout not a multiple of the channel tile
+]
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("case", HALO_CASES)
+def test_conv3x3_halo_kernel(cuda, case, dtype):
+    """The LDS halo-reuse 3x3 kernel against torch fp32 conv: ragged tiles, both strides, every channel tile,
+    residual + sliced output, and equality with the generic kernel's result within 16-bit rounding."""
+    c1, c2, s, B, H, W, tile = case
+    torch.manual_seed(c1 + c2 + H)
+    code = _hip.dtype_code(dtype)
+    w = torch.randn(c2, c1, 3, 3) * (1.0 / (3 * c1 ** 0.5))
+    b = torch.randn(c2) * 0.1
+    x = torch.randn(B, c1, H, W)
+    Ho, Wo = (H + 2 - 3) // s + 1, (W + 2 - 3) // s + 1
+    r = torch.randn(B, c2, Ho, Wo)
+    ref = torch.nn.functional.silu(torch.nn.functional.conv2d(x, w, b, s, 1)) + r
+    outs = {}
+    for name, t in (("halo", tile), ("generic", 4)):
+        pb = PlanBuilder(B, code, cuda)
+        xin, res = pb.new_buf(H, W, c1), pb.new_buf(Ho, Wo, round_up(c2, 8))
+        big = pb.new_buf(Ho, Wo, round_up(c2, 8) + 16)
+        out = pb.conv(xin.view(), w, b, 3, s, 1, _hip.YP_ACT_SILU, out=big.view(8, round_up(c2, 8)), res=res.view(), tile=t)
+        plan = pb.finish()
+        pack_input(x.to(cuda), xin.view(), code)
+        pack_input(r.to(cuda), res.view(), code)
+        plan.run()
+        outs[name] = unpack_nchw(out, code, B, c2)
+        assert float(big.t[..., :8].abs().max()) == 0.0 and float(big.t[..., 8 + round_up(c2, 8):].abs().max()) == 0.0
+    e_max, _ = rel_err(outs["halo"], ref)
+    assert e_max < TOL[dtype], (case, dtype, e_max)
+    assert rel_err(outs["halo"], outs["generic"])[0] < TOL[dtype]
+
+
+def test_conv3x3_halo_fp32_head_output(cuda):
+    """ConvDesc-style use: 3x3, no bias, no activation, fp32 output from f16 operands."""
+    torch.manual_seed(3)
+    B, C, H, W = 1, 128, 20, 28
+    w = torch.randn(C, C, 3, 3) * 0.03
+    x = torch.randn(B, C, H, W)
+    ref = torch.nn.functional.conv2d(x, w, None, 1, 1)
+    pb = PlanBuilder(B, _hip.YP_F16, cuda)
+    xin = pb.new_buf(H, W, C)
+    out = pb.conv(xin.view(), w, None, 3, 1, 1, _hip.YP_ACT_NONE, out_f32=True)
+    plan = pb.finish()
+    pack_input(x.to(cuda), xin.view(), _hip.YP_F16)
+    plan.run()
+    assert out.buf.t.dtype == torch.float32
+    assert rel_err(unpack_nchw(out, _hip.YP_F32, B, C), ref)[0] < TOL["f16"]

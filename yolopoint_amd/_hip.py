@@ -24,7 +24,7 @@ class YpView(C.Structure):
 
 
 class YpConvDesc(C.Structure):
-    _fields_ = [("in0", YpView), ("in1", YpView), ("out", YpView), ("res", YpView),
+    _fields_ = [("in0", YpView), ("in1", YpView), ("out", YpView), ("res", YpView), ("out2", YpView),
                 ("weight", C.c_void_p), ("bias", C.c_void_p),
                 ("dtype", C.c_int32), ("out_f32", C.c_int32), ("B", C.c_int32),
                 ("Hi", C.c_int32), ("Wi", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),

@@ -53,6 +53,8 @@ template <> struct Elem<YP_F32> {
     }
 };
 
+#define YP_PIN2(T, name) T name = a.name; asm volatile("" : "+s"(name))
+
 struct ConvKArgs {
     const char* in0;
     const char* in1;
@@ -64,17 +66,104 @@ struct ConvKArgs {
     int in1_cs, in1_co, in1_ups, in1_H, in1_W;
     int res_cs, res_co, has_res;
     int out_cs, out_co;
+    char* out2; int out2_cs, out2_co, split;      // channels >= split go to out2 (split == Cout: unused)
     int Hi, Wi, Wo, HoWo;
     int Cin, Cout, Kreal, Kpad, Npad;
     int R, S, RS, invS, dt, dc, sh, sw, ph, pw;
     unsigned in0_zoff, in1_zoff, wgt_zrow;   // FAST path: byte offsets of the 16 zero bytes behind each input / the zero filter row
     int act;
     int M, tiles_n;
+    int tiles_x, tiles_y, Ho;      // 3x3 halo kernel: 8x16 output tiles
 };
 
 __device__ __forceinline__ float yp_silu(float x) {
     // x * sigmoid(x); __expf -> v_exp_f32, the divide -> v_rcp_f32 (rel. error ~1e-7)
     return x * __frcp_rn(1.0f + __expf(-x));
+}
+
+// Epilogue tail shared by the convolution kernels: (+ residual) -> convert -> store CW consecutive
+// channels [nc, nc+CW) of output pixel m as 8/16-byte vectors, into `out` or (nc >= split) `out2`.
+template <int DT, bool OUT_F32, int CW>
+__device__ __forceinline__ void yp_store_chunk(const ConvKArgs& a, int m, int nc, float (&v)[CW]) {
+    using E = Elem<DT>;
+    constexpr int EB = E::BYTES;
+    if (a.has_res) {
+        const char* rp = a.res + ((size_t)m * a.res_cs + a.res_co + nc) * EB;
+        if constexpr (DT == YP_F32) {
+#pragma unroll
+            for (int j = 0; j < CW; j += 4) {
+                const f32x4 r4 = *reinterpret_cast<const f32x4*>(rp + j * 4);
+                v[j] += r4[0]; v[j + 1] += r4[1]; v[j + 2] += r4[2]; v[j + 3] += r4[3];
+            }
+        } else {
+            using sc = typename E::scalar;
+            if constexpr (CW == 8) {
+                const u32x4 raw = *reinterpret_cast<const u32x4*>(rp);
+                const sc* e = reinterpret_cast<const sc*>(&raw);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
+            } else {
+                const u32x2 raw = *reinterpret_cast<const u32x2*>(rp);
+                const sc* e = reinterpret_cast<const sc*>(&raw);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += (float)e[j];
+            }
+        }
+    }
+    const bool second = nc >= a.split;
+    char* const obase = second ? a.out2 : a.out;
+    const size_t oidx = second ? (size_t)m * a.out2_cs + a.out2_co + (nc - a.split) : (size_t)m * a.out_cs + a.out_co + nc;
+    if constexpr (OUT_F32 || DT == YP_F32) {
+        char* op = obase + oidx * 4;
+#pragma unroll
+        for (int j = 0; j < CW; j += 4) *reinterpret_cast<f32x4*>(op + j * 4) = f32x4{v[j], v[j + 1], v[j + 2], v[j + 3]};
+    } else {
+        using sc = typename E::scalar;
+        char* op = obase + oidx * 2;
+        if constexpr (CW == 8) {
+            u32x4 pk;
+            sc* e = reinterpret_cast<sc*>(&pk);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = (sc)v[j];
+            *reinterpret_cast<u32x4*>(op) = pk;
+        } else {
+            u32x2 pk;
+            sc* e = reinterpret_cast<sc*>(&pk);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = (sc)v[j];
+            *reinterpret_cast<u32x2*>(op) = pk;
+        }
+    }
+}
+
+// bias -> activation -> yp_store_chunk for the LPG consecutive channels [nb, nb+LPG) a lane owns at pixel m;
+// acc(j) returns the accumulator of lane-local channel j.
+template <int DT, bool OUT_F32, int LPG, typename AccFn>
+__device__ __forceinline__ void yp_epilogue_pixel(const ConvKArgs& a, int m, int nb, const float (&bias)[LPG], AccFn acc) {
+    constexpr int CW = LPG < 8 ? LPG : 8;
+#pragma unroll
+    for (int h = 0; h < LPG / CW; ++h) {
+        const int nc = nb + h * CW;
+        if (nc >= a.Cout) continue;
+        float v[CW];
+#pragma unroll
+        for (int j = 0; j < CW; ++j) {
+            float x = acc(h * CW + j) + bias[h * CW + j];
+            if (a.act == YP_ACT_SILU) x = yp_silu(x);
+            v[j] = x;
+        }
+        yp_store_chunk<DT, OUT_F32, CW>(a, m, nc, v);
+    }
+}
+
+template <int LPG>
+__device__ __forceinline__ void yp_load_bias(const ConvKArgs& a, int nb, float (&bias)[LPG]) {
+#pragma unroll
+    for (int q = 0; q < LPG / 4; ++q) {     // Cout is a multiple of 8: groups of 4 channels are all-or-nothing
+        f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.bias != nullptr && nb + 4 * q < a.Cout) b4 = *reinterpret_cast<const f32x4*>(a.bias + nb + 4 * q);
+        bias[4 * q] = b4[0]; bias[4 * q + 1] = b4[1]; bias[4 * q + 2] = b4[2]; bias[4 * q + 3] = b4[3];
+    }
 }
 
 // 16 zero bytes: out-of-image taps / padded k / padded filter rows are fetched from here, so every
@@ -206,7 +295,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     YP_PIN(int, in0_ups); YP_PIN(int, in1_ups); YP_PIN(int, in0_H); YP_PIN(int, in1_H); YP_PIN(int, in0_W); YP_PIN(int, in1_W);
     YP_PIN(int, Hi); YP_PIN(int, Wi); YP_PIN(int, Cin); YP_PIN(int, S); YP_PIN(int, RS); YP_PIN(int, invS); YP_PIN(int, dt); YP_PIN(int, dc);
 #undef YP_PIN
-#define YP_PIN2(T, name) T name = a.name; asm volatile("" : "+s"(name))
     const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     // FAST path state: every lane of the workgroup is in the same filter tap (Cin % BK == 0), so the tap
@@ -290,6 +378,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
 #pragma unroll
         for (int fm = 0; fm < FM; ++fm) acc[f][fm] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // bias is fetched before the pipeline starts (older than every DMA, so the counted waits stay valid)
+    const int nb = n0 + wn * TN + g * LPG;
+    float bias[LPG];
+    yp_load_bias<LPG>(a, nb, bias);
+
     const int nk = (a.Kreal + BK - 1) / BK;
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
@@ -322,79 +415,180 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     }
 
     // ---- epilogue: bias -> activation -> (+ residual) -> store, 16-byte vectors per pixel
-    constexpr int CW = LPG < 8 ? LPG : 8;    // channels per store chunk
-    constexpr int NCH = LPG / CW;
-    const int nb = n0 + wn * TN + g * LPG;
-    float bias[LPG];
-#pragma unroll
-    for (int q = 0; q < LPG / 4; ++q) {     // Cout is a multiple of 8: groups of 4 channels are all-or-nothing
-        f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (a.bias != nullptr && nb + 4 * q < a.Cout) b4 = *reinterpret_cast<const f32x4*>(a.bias + nb + 4 * q);
-        bias[4 * q] = b4[0]; bias[4 * q + 1] = b4[1]; bias[4 * q + 2] = b4[2]; bias[4 * q + 3] = b4[3];
-    }
-
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm) {
         const int m = m0 + wm * TM + fm * 16 + p;
         if (m >= a.M) continue;
+        yp_epilogue_pixel<DT, OUT_F32, LPG>(a, m, nb, bias, [&](int cj) { return acc[cj >> 2][fm][cj & 3]; });
+    }
+}
+
+
+// ==========================================================================================
+// 3x3 convolution (stride 1 or 2, pad 1) with LDS halo reuse.
+//
+// A workgroup owns an 8 x 16 tile of output pixels x BN output channels.  Per 32-channel chunk of
+// the input, the (8*S+2) x (16*S+2) input halo of that tile is DMA'd into LDS ONCE and serves all
+// nine filter taps (the generic kernel re-fetches every input pixel once per tap); the filter is
+// streamed one filter ROW (3 taps x BN rows x 32 channels) per pipeline step through a 3-stage ring.
+// One raw barrier per step = 24..48 MFMAs per wave between barriers; DMA issue costs no VALU work
+// (per-lane byte offsets are precomputed once, the channel / tap offset rides in the SGPR base).
+//
+// A 16-pixel MFMA fragment is 16 consecutive x positions of one output row, so for tap (r, s) its
+// LDS rows are consecutive: stride 1: (y+r)*18 + (x+s); stride 2: the halo row stores even input
+// columns at [0,17) and odd ones at [17,33) (pitch 34), so (2y+r)*34 + {0,17,1}[s] + x.
+// Same source-side XOR swizzle as the generic kernel (keyed on the LDS row index).
+// ==========================================================================================
+template <int STRIDE> struct Halo;
+template <> struct Halo<1> { static constexpr int HH = 10, HP = 18; };
+template <> struct Halo<2> { static constexpr int HH = 17, HP = 34; };
+
+template <int DT, bool OUT_F32, int STRIDE, int BN, int WAVES_M>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvKArgs a) {
+    using E = Elem<DT>;
+    using frag_t = typename E::frag;
+    static_assert(E::BYTES == 2, "halo kernel: 16-bit element types");
+    constexpr int EB = 2, BK = 32;
+    constexpr int TH = 8, TW = 16;
+    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int FM = TH / WAVES_M;                 // output rows (16-pixel fragments) per wave
+    constexpr int TN = BN / WAVES_N, FN = TN / 16, LPG = 4 * FN;
+    constexpr int HH = Halo<STRIDE>::HH, HP = Halo<STRIDE>::HP;
+    constexpr int HROWS = HH * HP, HSLOTS = (HROWS + 15) / 16, NH = (HSLOTS + 3) / 4, HBYTES = HSLOTS * 1024;
+    constexpr int WSLOTS_TAP = BN / 16, WSLOTS = 3 * WSLOTS_TAP, NW = (WSLOTS + 3) / 4, WBYTES = WSLOTS * 1024;
+    static_assert(FN >= 1 && FM >= 1 && NW + NH <= 60, "unsupported tile");
+
+    extern __shared__ __attribute__((aligned(1024))) char hsm[];      // [halo 0][halo 1][filter row 0][1][2]
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)hsm);
+    const unsigned ldsW = lds0 + 2 * HBYTES;
+
+    // ---- tile decode (channel tiles fastest: neighbours share the input halo in L2)
+    int bid = blockIdx.x;
+    const int tn = bid % a.tiles_n; bid /= a.tiles_n;
+    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y;
+    const int b = bid / a.tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW, n0 = tn * BN;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int lrow = lane >> 2;
+    const int jl = (lane & 3) ^ ((0x3300 >> ((lane >> 4) * 4)) & 3);
+
+    YP_PIN2(const char*, in0); YP_PIN2(const char*, wgt);
+    YP_PIN2(int, in0_cs); YP_PIN2(int, in0_co); YP_PIN2(int, Cin); YP_PIN2(int, Hi); YP_PIN2(int, Wi);
+    YP_PIN2(unsigned, in0_zoff);
+
+    // ---- per-lane DMA byte offsets, computed once
+    unsigned hoff[NH];
+    int hslot[NH];
 #pragma unroll
-        for (int h = 0; h < NCH; ++h) {
-            const int nc = nb + h * CW;
-            if (nc >= a.Cout) continue;
-            float v[CW];
+    for (int i = 0; i < NH; ++i) {
+        int sl = wave + 4 * i;
+        if (sl > HSLOTS - 1) sl = HSLOTS - 1;
+        hslot[i] = sl;
+        const int rho = sl * 16 + lrow;
+        const int hy = rho / HP, rem = rho - hy * HP;
+        int hx;
+        bool valid = rho < HROWS;
+        if constexpr (STRIDE == 1) hx = rem;
+        else { hx = rem < 17 ? 2 * rem : 2 * (rem - 17) + 1; valid = valid && rem < 33; }
+        const int iy = y0 * STRIDE - 1 + hy, ix = x0 * STRIDE - 1 + hx;
+        valid = valid && (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi;
+        hoff[i] = valid ? (unsigned)(((b * Hi + iy) * Wi + ix) * in0_cs * EB) + (unsigned)jl * 16u : in0_zoff;
+    }
+    unsigned woff[NW];
+    int wslot[NW];
 #pragma unroll
-            for (int j = 0; j < CW; ++j) {
-                const int cj = h * CW + j;            // lane-local channel = f*4 + r
-                float x = acc[cj >> 2][fm][cj & 3] + bias[cj];
-                if (a.act == YP_ACT_SILU) x = yp_silu(x);
-                v[j] = x;
-            }
-            if (a.has_res) {
-                const char* rp = a.res + ((size_t)m * a.res_cs + a.res_co + nc) * EB;
-                if constexpr (DT == YP_F32) {
+    for (int i = 0; i < NW; ++i) {
+        int sl = wave + 4 * i;
+        if (sl > WSLOTS - 1) sl = WSLOTS - 1;
+        wslot[i] = sl;
+        const int tap_s = sl / WSLOTS_TAP, rs = sl - tap_s * WSLOTS_TAP;
+        const int rho = rs * 16 + lrow;
+        const int wn_ = rho / TN, q = rho % TN;
+        const int f = q >> 4, g_ = (q & 15) >> 2, r_ = q & 3;
+        const int n = n0 + wn_ * TN + g_ * LPG + f * 4 + r_;
+        woff[i] = ((n < a.Npad) ? (unsigned)n * (unsigned)a.Kpad * EB : a.wgt_zrow) + (unsigned)jl * 16u + (unsigned)(tap_s * Cin * EB);
+    }
+    auto issueW = [&](int c, int r) {      // filter row r of chunk c -> ring stage r
+        const char* wk = wgt + ((size_t)(r * 3) * Cin + (size_t)c * BK) * EB;
 #pragma unroll
-                    for (int j = 0; j < CW; j += 4) {
-                        const f32x4 r4 = *reinterpret_cast<const f32x4*>(rp + j * 4);
-                        v[j] += r4[0]; v[j + 1] += r4[1]; v[j + 2] += r4[2]; v[j + 3] += r4[3];
-                    }
-                } else {
-                    using sc = typename E::scalar;
-                    if constexpr (CW == 8) {
-                        const u32x4 raw = *reinterpret_cast<const u32x4*>(rp);
-                        const sc* e = reinterpret_cast<const sc*>(&raw);
+        for (int i = 0; i < NW; ++i) yp_glds16_s(wk, woff[i], ldsW + r * WBYTES + wslot[i] * 1024);
+    };
+    auto issueH = [&](int c) {
+        const char* hk = in0 + (size_t)(in0_co + c * BK) * EB;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
-                    } else {
-                        const u32x2 raw = *reinterpret_cast<const u32x2*>(rp);
-                        const sc* e = reinterpret_cast<const sc*>(&raw);
+        for (int i = 0; i < NH; ++i) yp_glds16_s(hk, hoff[i], lds0 + (c & 1) * HBYTES + hslot[i] * 1024);
+    };
+
+    const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+    const int p = lane & 15, g = lane >> 4;
+    const int swr = (0x3300 >> ((p >> 2) * 4)) & 3;
+    const int w_rd = (wn * TN + p) * 64 + ((g ^ swr) << 4);          // + (s*BN + f*16)*64 per fragment
+    int x_row[FM];                                                     // halo row index of (local row, x = p) for r = s = 0
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] += (float)e[j];
-                    }
+    for (int fm = 0; fm < FM; ++fm) x_row[fm] = ((wm * FM + fm) * STRIDE) * HP + p;
+
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int f = 0; f < FN; ++f)
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) acc[f][fm] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nb = n0 + wn * TN + g * LPG;
+    float bias[LPG];
+    yp_load_bias<LPG>(a, nb, bias);      // older than every DMA: the counted waits below stay valid
+
+    const int nchunks = Cin / BK;
+    const int nsteps = 3 * nchunks;
+    issueH(0);
+    issueW(0, 0);
+    issueW(0, 1);
+    for (int c = 0; c < nchunks; ++c) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int st = 3 * c + r;
+            // DMAs younger than filter row `st`: the next filter row, and (r != 0) the next chunk's halo
+            const bool moreW = st + 1 < nsteps;
+            const bool moreH = (r != 0) && (c + 1 < nchunks);
+            if (moreW && moreH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW + NH) : "memory");
+            else if (moreH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NH) : "memory");
+            else if (moreW) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (st + 2 < nsteps) { const int s2 = st + 2; issueW(s2 / 3, s2 % 3); }
+            if (r == 0 && c + 1 < nchunks) issueH(c + 1);
+            const char* hb = hsm + (c & 1) * HBYTES;
+            const char* wb = hsm + 2 * HBYTES + r * WBYTES;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                constexpr int XC1[3] = {0, 1, 2};
+                constexpr int XC2[3] = {0, 17, 1};
+                const int xc = (STRIDE == 1 ? XC1[s] : XC2[s]) + r * HP;
+                frag_t wf[FN], xf[FM];
+#pragma unroll
+                for (int f = 0; f < FN; ++f) wf[f] = *reinterpret_cast<const frag_t*>(wb + w_rd + (s * BN + f * 16) * 64);
+#pragma unroll
+                for (int fm = 0; fm < FM; ++fm) {
+                    const int rho = x_row[fm] + xc;
+                    const int sw = (0x3300 >> (((rho >> 2) & 3) * 4)) & 3;
+                    xf[fm] = *reinterpret_cast<const frag_t*>(hb + rho * 64 + ((g ^ sw) << 4));
                 }
-            }
-            if constexpr (OUT_F32 || DT == YP_F32) {
-                char* op = a.out + ((size_t)m * a.out_cs + a.out_co + nc) * 4;
 #pragma unroll
-                for (int j = 0; j < CW; j += 4)
-                    *reinterpret_cast<f32x4*>(op + j * 4) = f32x4{v[j], v[j + 1], v[j + 2], v[j + 3]};
-            } else {
-                using sc = typename E::scalar;
-                char* op = a.out + ((size_t)m * a.out_cs + a.out_co + nc) * 2;
-                if constexpr (CW == 8) {
-                    u32x4 pk;
-                    sc* e = reinterpret_cast<sc*>(&pk);
+                for (int f = 0; f < FN; ++f)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) e[j] = (sc)v[j];
-                    *reinterpret_cast<u32x4*>(op) = pk;
-                } else {
-                    u32x2 pk;
-                    sc* e = reinterpret_cast<sc*>(&pk);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) e[j] = (sc)v[j];
-                    *reinterpret_cast<u32x2*>(op) = pk;
-                }
+                    for (int fm = 0; fm < FM; ++fm) acc[f][fm] = E::mma(wf[f], xf[fm], acc[f][fm]);
             }
         }
+    }
+
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) {
+        const int oy = y0 + wm * FM + fm, ox = x0 + p;
+        if (oy >= a.Ho || ox >= a.Wo) continue;
+        const int m = (b * a.Ho + oy) * a.Wo + ox;
+        yp_epilogue_pixel<DT, OUT_F32, LPG>(a, m, nb, bias, [&](int cj) { return acc[cj >> 2][fm][cj & 3]; });
     }
 }
 
@@ -419,6 +613,34 @@ hipError_t launch_cfg(int tile, const ConvKArgs& a, int nblk, hipStream_t st) {
     return hipGetLastError();
 }
 
+
+template <int DT, bool OUT_F32, int STRIDE, int BN, int WAVES_M>
+hipError_t launch_halo(const ConvKArgs& a, int nblk, hipStream_t st) {
+    constexpr int HSLOTS = (Halo<STRIDE>::HH * Halo<STRIDE>::HP + 15) / 16;
+    constexpr size_t lds = (size_t)2 * HSLOTS * 1024 + (size_t)3 * 3 * (BN / 16) * 1024;
+    auto kern = conv3x3_halo_kernel<DT, OUT_F32, STRIDE, BN, WAVES_M>;
+    static bool attr_set = false;        // per instantiation
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    kern<<<nblk, 256, lds, st>>>(a);
+    return hipGetLastError();
+}
+
+template <int DT, bool OUT_F32>
+hipError_t dispatch_halo(int stride, int bn, const ConvKArgs& a, int nblk, hipStream_t st) {
+    if (stride == 1) {
+        if (bn == 128) return launch_halo<DT, OUT_F32, 1, 128, 2>(a, nblk, st);
+        if (bn == 64) return launch_halo<DT, OUT_F32, 1, 64, 4>(a, nblk, st);
+        return launch_halo<DT, OUT_F32, 1, 32, 4>(a, nblk, st);
+    }
+    if (bn == 128) return launch_halo<DT, OUT_F32, 2, 128, 2>(a, nblk, st);
+    if (bn == 64) return launch_halo<DT, OUT_F32, 2, 64, 4>(a, nblk, st);
+    return launch_halo<DT, OUT_F32, 2, 32, 4>(a, nblk, st);
+}
+
 int pick_tile(int M, int N) {
     auto blocks = [&](int bm, int bn) { return (long)yp_cdiv(M, bm) * yp_cdiv(N, bn); };
     const long fill = 2 * 256;   // >= 2 workgroups per CU before a bigger tile is worth it
@@ -440,13 +662,14 @@ int yp_conv2d_launch(const YpConvDesc* d, hipStream_t stream) {
     YP_REQUIRE(d->dtype == YP_F16 || d->dtype == YP_BF16 || d->dtype == YP_F32, "yp_conv2d: bad dtype %d", d->dtype);
     const int ce = d->dtype == YP_F32 ? 4 : 8;
     const int Cin = d->in0.C + d->in1.C;
-    const int Cout = d->out.C;
+    const int Cout = d->out.C + d->out2.C;
     YP_REQUIRE(d->in0.ptr && d->out.ptr && d->weight, "yp_conv2d: null buffer");
     YP_REQUIRE(d->in0.C > 0 && d->in0.C % ce == 0 && d->in1.C % ce == 0, "yp_conv2d: input channels (%d,%d) must be multiples of %d", d->in0.C, d->in1.C, ce);
     YP_REQUIRE(d->in0.cstride % ce == 0 && d->in0.coff % ce == 0, "yp_conv2d: in0 slice not 16-byte aligned");
     YP_REQUIRE(d->in1.C == 0 || (d->in1.ptr && d->in1.cstride % ce == 0 && d->in1.coff % ce == 0), "yp_conv2d: in1 slice not 16-byte aligned");
-    YP_REQUIRE(Cout > 0 && Cout % 8 == 0 && d->out.cstride % 8 == 0 && d->out.coff % 8 == 0, "yp_conv2d: output slice (C=%d cs=%d co=%d) must be multiples of 8", Cout, d->out.cstride, d->out.coff);
-    YP_REQUIRE(d->res.C == 0 || (d->res.ptr && d->res.C == Cout && d->res.cstride % 8 == 0 && d->res.coff % 8 == 0 && !d->out_f32), "yp_conv2d: bad residual view");
+    YP_REQUIRE(d->out.C > 0 && d->out.C % 8 == 0 && d->out.cstride % 8 == 0 && d->out.coff % 8 == 0, "yp_conv2d: output slice (C=%d cs=%d co=%d) must be multiples of 8", d->out.C, d->out.cstride, d->out.coff);
+    YP_REQUIRE(d->out2.C == 0 || (d->out2.ptr && d->out2.C % 8 == 0 && d->out2.cstride % 8 == 0 && d->out2.coff % 8 == 0 && d->out2.H == d->Ho && d->out2.W == d->Wo && d->res.C == 0), "yp_conv2d: bad second output view");
+    YP_REQUIRE(d->res.C == 0 || (d->res.ptr && d->res.C == d->out.C && d->res.cstride % 8 == 0 && d->res.coff % 8 == 0 && !d->out_f32), "yp_conv2d: bad residual view");
     YP_REQUIRE(d->B > 0 && d->Ho > 0 && d->Wo > 0 && d->R > 0 && d->S > 0 && d->S <= 8 && d->R * d->S <= 64, "yp_conv2d: bad dims (filter up to 8 wide, 64 taps)");
     YP_REQUIRE(d->in0.ups >= 0 && d->in0.ups <= 1 && d->in1.ups >= 0 && d->in1.ups <= 1, "yp_conv2d: ups must be 0/1");
     YP_REQUIRE((d->in0.H << d->in0.ups) == d->Hi && (d->in0.W << d->in0.ups) == d->Wi, "yp_conv2d: in0 %dx%d<<%d != logical %dx%d", d->in0.H, d->in0.W, d->in0.ups, d->Hi, d->Wi);
@@ -466,6 +689,7 @@ int yp_conv2d_launch(const YpConvDesc* d, hipStream_t stream) {
     a.in1_cs = d->in1.cstride; a.in1_co = d->in1.coff; a.in1_ups = d->in1.ups; a.in1_H = d->in1.H; a.in1_W = d->in1.W;
     a.res_cs = d->res.cstride; a.res_co = d->res.coff; a.has_res = d->res.C != 0;
     a.out_cs = d->out.cstride; a.out_co = d->out.coff;
+    a.out2 = (char*)d->out2.ptr; a.out2_cs = d->out2.cstride; a.out2_co = d->out2.coff; a.split = d->out.C;
     a.Hi = d->Hi; a.Wi = d->Wi; a.Wo = d->Wo; a.HoWo = d->Ho * d->Wo;
     a.Cin = Cin; a.Cout = Cout; a.Kreal = Kreal; a.Kpad = d->Kpad; a.Npad = d->Npad;
     a.R = d->R; a.S = d->S; a.RS = d->R * d->S; a.invS = (65536 + d->S - 1) / d->S;
@@ -473,7 +697,7 @@ int yp_conv2d_launch(const YpConvDesc* d, hipStream_t stream) {
     a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w;
     a.act = d->act; a.M = (int)Ml;
 
-    int tile = d->tile ? d->tile : pick_tile(a.M, Cout);
+    int tile = (d->tile >= 1 && d->tile <= 5) ? d->tile : pick_tile(a.M, Cout);
     const TileCfg* tc = nullptr;
     for (const auto& c : kTiles) if (c.id == tile) tc = &c;
     YP_REQUIRE(tc != nullptr, "yp_conv2d: unknown tile id %d", tile);
@@ -493,6 +717,28 @@ int yp_conv2d_launch(const YpConvDesc* d, hipStream_t stream) {
 
     hipError_t e;
     const bool of32 = d->out_f32 != 0;
+    // 3x3 / pad 1 / stride 1|2, single un-upsampled source, 16-bit types, Cin % 32 == 0: LDS halo-reuse kernel
+    // (tile ids 10..12 force it with BN = 32/64/128; tile 0 picks BN by the channel count; ids 1..5 force the generic kernel)
+    const bool halo_ok = fast && d->dtype != YP_F32 && d->R == 3 && d->S == 3 && d->pad_h == 1 && d->pad_w == 1 &&
+                         d->stride_h == d->stride_w && (d->stride_h == 1 || d->stride_h == 2) && d->in1.C == 0 && d->in0.ups == 0 &&
+                         in0_bytes + (size_t)d->in0.cstride * eb + 64 < (1ull << 31);
+    if (halo_ok && (d->tile == 0 || d->tile >= 10)) {
+        int bn = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128);
+        if (d->tile == 10) bn = 32; else if (d->tile == 11) bn = 64; else if (d->tile == 12) bn = 128;
+        a.tiles_n = yp_cdiv(Cout, bn);
+        a.tiles_x = yp_cdiv(d->Wo, 16);
+        a.tiles_y = yp_cdiv(d->Ho, 8);
+        a.Ho = d->Ho;
+        const int nb3 = d->B * a.tiles_y * a.tiles_x * a.tiles_n;
+        if (d->dtype == YP_F16) e = of32 ? dispatch_halo<YP_F16, true>(d->stride_h, bn, a, nb3, stream) : dispatch_halo<YP_F16, false>(d->stride_h, bn, a, nb3, stream);
+        else e = of32 ? dispatch_halo<YP_BF16, true>(d->stride_h, bn, a, nb3, stream) : dispatch_halo<YP_BF16, false>(d->stride_h, bn, a, nb3, stream);
+        if (e != hipSuccess) {
+            yp_set_error("yp_conv2d: halo kernel launch failed: %s", hipGetErrorString(e));
+            return YP_ERR_HIP;
+        }
+        return YP_OK;
+    }
+    YP_REQUIRE(d->tile < 10, "yp_conv2d: tile %d (3x3 halo kernel) does not apply to this convolution", d->tile);
 #define YP_DISPATCH(DT)                                                                                             \
     (of32 ? (fast ? launch_cfg<DT, true, true>(tile, a, nblk, stream) : launch_cfg<DT, true, false>(tile, a, nblk, stream)) \
           : (fast ? launch_cfg<DT, false, true>(tile, a, nblk, stream) : launch_cfg<DT, false, false>(tile, a, nblk, stream)))

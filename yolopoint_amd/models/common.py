@@ -145,13 +145,18 @@ class C3(HipModule):
         c_ = self.cv1.conv.out_channels
         x0 = x[0] if isinstance(x, (list, tuple)) else x
         cat = pb.new_buf(x0.LH, x0.LW, 2 * c_)
-        pb.scope.append("cv1"); t = self.cv1.emit(pb, x); pb.scope.pop()
+        # cv1 and cv2 are 1x1 convolutions of the same input: one launch, N = 2*c_, split destination
+        # (cv1 -> its own buffer feeding the bottleneck chain, cv2 -> channels [c_, 2c_) of the concat)
+        (w1, b1), (w2, b2) = self.cv1.folded(), self.cv2.folded()
+        t = pb.new_buf(x0.LH, x0.LW, c_).view()
+        pb.scope.append("cv1+cv2")
+        pb.conv(x, torch.cat((w1, w2), 0), torch.cat((b1, b2), 0), 1, 1, 0, _hip.YP_ACT_SILU, out=t, out2=cat.view(c_, c_))
+        pb.scope.pop()
         n = len(self.m)
         for i, blk in enumerate(self.m):
             pb.scope.append(f"m.{i}")
             t = blk.emit(pb, t, out=cat.view(0, c_) if i == n - 1 else None)
             pb.scope.pop()
-        pb.scope.append("cv2"); self.cv2.emit(pb, x, out=cat.view(c_, c_)); pb.scope.pop()
         pb.scope.append("cv3"); y = self.cv3.emit(pb, cat.view(), out=out); pb.scope.pop()
         return y
 

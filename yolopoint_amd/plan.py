@@ -25,9 +25,9 @@ class Buf:
 
     def __init__(self, B, H, W, C_, tdtype, device, zero=True):
         self.B, self.H, self.W, self.C = B, H, W, C_
-        # 64 zero elements behind the pixels: the conv kernel's DMA fetches padding / out-of-image taps from there
+        # a zero tail behind the pixels: the conv kernels' DMA fetches padding / out-of-image taps from there
         n = B * H * W * C_
-        self.flat = torch.zeros((n + 64,), dtype=tdtype, device=device)
+        self.flat = torch.zeros((n + C_ + 64,), dtype=tdtype, device=device)   # tail >= one pixel of channels + 64
         self.t = self.flat[:n].view(B, H, W, C_)
 
     def view(self, coff=0, C_=None, ups=0):
@@ -100,8 +100,17 @@ class OpRecord:
         self.name, self.kind, self.flops, self.bytes, self.M, self.N, self.K = name, kind, flops, bytes_, M, N, K
 
 
+# conv signature -> fastest kernel/tile id, measured once per process (see PlanBuilder._autotune)
+_TUNE_CACHE = {}
+# candidate ids: 1..5 generic implicit-GEMM tiles (128x32, 128x64, 128x128, 64x64, 64x32); 10..12 the 3x3 halo kernel
+# with 32/64/128 output channels per workgroup (rejected by the library when it does not apply)
+_TUNE_CANDIDATES = (1, 2, 3, 4, 5, 10, 11, 12)
+
+
 class PlanBuilder:
     """Collects launches into a native YpPlan; owns every buffer the plan touches."""
+
+    autotune = True     # time the applicable conv kernel variants on the real buffers when a plan is built
 
     def __init__(self, B, code, device):
         _hip.require_gpu()
@@ -158,7 +167,7 @@ class PlanBuilder:
         return deps
 
     # -- ops ----------------------------------------------------------------------------
-    def conv(self, srcs, w, bias, k, s, p, act, out=None, res=None, out_f32=False, tile=0):
+    def conv(self, srcs, w, bias, k, s, p, act, out=None, res=None, out_f32=False, tile=0, out2=None):
         """srcs: one or two Views (channel-concatenated); w: OIHW fp32 tensor (BN already folded)."""
         if isinstance(srcs, View):
             srcs = [srcs]
@@ -188,8 +197,10 @@ class PlanBuilder:
             assert sum(v.C for v in srcs) == Cin, (self.name(), [v.C for v in srcs], Cin)
         Cout_pad = round_up(Cout, 8)
         if out is None:
+            assert out2 is None
             out = self.new_buf(Ho, Wo, Cout_pad, f32=out_f32).view()
-        assert out.C == Cout_pad and out.H == Ho and out.W == Wo, (self.name(), out.C, Cout_pad, out.H, Ho)
+        c2 = out2.C if out2 is not None else 0      # channels [out.C, out.C + c2) are written to out2
+        assert out.C + c2 == Cout_pad and out.H == Ho and out.W == Wo, (self.name(), out.C, c2, Cout_pad, out.H, Ho)
         wp, bp, Kpad, Npad = pack_conv_weight(w, bias, self.code, self.device)
         self.keep += [wp, bp]
         d = YpConvDesc()
@@ -197,14 +208,18 @@ class PlanBuilder:
         d.in1 = srcs[1].c() if len(srcs) == 2 else NULL_VIEW
         d.out = out.c()
         d.res = res.c() if res is not None else NULL_VIEW
+        d.out2 = out2.c() if out2 is not None else NULL_VIEW
         d.weight = wp.data_ptr()
         d.bias = bp.data_ptr() if bias is not None else None
         d.dtype, d.out_f32, d.B = self.code, int(out_f32), self.B
         d.Hi, d.Wi, d.Ho, d.Wo = Hi, Wi, Ho, Wo
         d.R, d.S, d.stride_h, d.stride_w, d.pad_h, d.pad_w = R, S, sh, sw, ph, pw
         d.Kpad, d.Npad, d.act, d.tile, d.tail_zero = Kpad, Npad, act, tile, 1
+        if tile == 0 and self.autotune:
+            d.tile = self._autotune(d, (self.code, self.B, Hi, Wi, tuple((v.C, v.ups) for v in srcs), Cout_pad, R, S, sh, sw,
+                                        int(out_f32), res is not None, c2, act))
         check(lib().yp_plan_add_conv(self.handle, C.byref(d)))
-        self._track(list(srcs) + [res], [out])
+        self._track(list(srcs) + [res], [out, out2])
         # algorithmic work: MAC*2 with the REAL channel counts (BASELINE.md section 2 convention)
         Kreal = w.shape[1] * w.shape[2] * w.shape[3] if not thin else Cin * R * (S * (2 if self.ce == 8 else 1))
         M = self.B * Ho * Wo
@@ -213,6 +228,31 @@ class PlanBuilder:
         bytes_ = in_elems * eb + M * Cout * (4 if out_f32 else eb) + Cout * Kreal * eb
         self.records.append(OpRecord(self.name(), "conv", 2 * M * Cout * Kreal, bytes_, M, Cout, Kreal))
         return out
+
+    def _autotune(self, d, key):
+        """Pick the fastest kernel variant for this convolution by timing each candidate on the plan's own buffers
+        (HIP events on the current stream).  Every variant computes the same convolution; the choice is cached per
+        signature so that equal layers always run the same kernel within a process."""
+        if key in _TUNE_CACHE:
+            return _TUNE_CACHE[key]
+        st = _hip.stream_ptr()
+        best, best_ms = 0, None
+        for cand in _TUNE_CANDIDATES:
+            d.tile = cand
+            if lib().yp_conv2d(C.byref(d), st) != 0:
+                continue                              # variant does not apply to this convolution
+            lib().yp_conv2d(C.byref(d), st)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(8):
+                lib().yp_conv2d(C.byref(d), st)
+            e1.record()
+            e1.synchronize()
+            ms = e0.elapsed_time(e1)
+            if best_ms is None or ms < best_ms:
+                best, best_ms = cand, ms
+        _TUNE_CACHE[key] = best
+        return best
 
     def sppf_pool(self, x, y1, y2, y3):
         check(lib().yp_plan_add_sppf_pool(self.handle, x.c(), y1.c(), y2.c(), y3.c(), self.B, self.code))
