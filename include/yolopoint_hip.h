@@ -100,6 +100,20 @@ typedef struct YpConvDesc {
 } YpConvDesc;
 
 int yp_conv2d(const YpConvDesc* d, void* stream);
+
+/* Detect-head convolution with the decode fused into its epilogue: the 1x1 conv of one detection level writes
+ * the permuted raw tensor x_out [B,na,ny,nx,no] and (eval mode) its rows of the decoded prediction
+ * z_out [B,rows_total,no] directly; `d->out` only supplies the level's geometry (ptr may be NULL, out_f32 = 1,
+ * no activation / residual / out2).  replaces: models/yolo.py:51-68 in one launch. */
+typedef struct YpDetectDesc {
+    int32_t na, no;
+    float stride;
+    float anchors_px[16];           /* na x (w, h) in pixels */
+    float* x_out;
+    float* z_out;                   /* NULL in train mode */
+    int32_t rows_total, row_offset;
+} YpDetectDesc;
+int yp_conv2d_detect(const YpConvDesc* d, const YpDetectDesc* det, void* stream);
 /* K padding granule the packer must use for `dtype` */
 int yp_conv_kpad(int K, int dtype);
 
@@ -184,6 +198,7 @@ typedef struct YpPlan YpPlan;
 int yp_plan_create(YpPlan** plan);
 int yp_plan_destroy(YpPlan* plan);
 int yp_plan_add_conv(YpPlan* plan, const YpConvDesc* d);
+int yp_plan_add_conv_detect(YpPlan* plan, const YpConvDesc* d, const YpDetectDesc* det);
 int yp_plan_add_sppf_pool(YpPlan* plan, YpView x, YpView y1, YpView y2, YpView y3, int B, int dtype);
 int yp_plan_add_l2norm(YpPlan* plan, YpView in, YpView out, int B, int C);
 int yp_plan_add_detect_decode(YpPlan* plan, YpView raw, int B, int na, int no, float stride,

@@ -33,6 +33,11 @@ class YpConvDesc(C.Structure):
                 ("Kpad", C.c_int32), ("Npad", C.c_int32), ("act", C.c_int32), ("tile", C.c_int32), ("tail_zero", C.c_int32)]
 
 
+class YpDetectDesc(C.Structure):
+    _fields_ = [("na", C.c_int32), ("no", C.c_int32), ("stride", C.c_float), ("anchors_px", C.c_float * 16),
+                ("x_out", C.c_void_p), ("z_out", C.c_void_p), ("rows_total", C.c_int32), ("row_offset", C.c_int32)]
+
+
 _i, _f, _p, _sz, _i64 = C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_int64
 # name -> (restype, argtypes); must list every symbol of include/yolopoint_hip.h
 SIGNATURES = {
@@ -40,6 +45,7 @@ SIGNATURES = {
     "yp_version": (_i, []),
     "yp_device_count": (_i, []),
     "yp_conv2d": (_i, [C.POINTER(YpConvDesc), _p]),
+    "yp_conv2d_detect": (_i, [C.POINTER(YpConvDesc), C.POINTER(YpDetectDesc), _p]),
     "yp_conv_kpad": (_i, [_i, _i]),
     "yp_pack_input": (_i, [_p, _i, _i, _i, _i, YpView, _i, _p]),
     "yp_unpack_nchw": (_i, [YpView, _i, _i, _i, _p, _p]),
@@ -57,6 +63,7 @@ SIGNATURES = {
     "yp_plan_create": (_i, [C.POINTER(_p)]),
     "yp_plan_destroy": (_i, [_p]),
     "yp_plan_add_conv": (_i, [_p, C.POINTER(YpConvDesc)]),
+    "yp_plan_add_conv_detect": (_i, [_p, C.POINTER(YpConvDesc), C.POINTER(YpDetectDesc)]),
     "yp_plan_add_sppf_pool": (_i, [_p, YpView, YpView, YpView, YpView, _i, _i]),
     "yp_plan_add_l2norm": (_i, [_p, YpView, YpView, _i, _i]),
     "yp_plan_add_detect_decode": (_i, [_p, YpView, _i, _i, _i, _f, C.POINTER(_f), _p, _p, _i, _i]),

@@ -74,6 +74,12 @@ struct ConvKArgs {
     int act;
     int M, tiles_n;
     int tiles_x, tiles_y, Ho;      // 3x3 halo kernel: 8x16 output tiles
+    // fused Detect decode (EPI_DETECT instantiations)
+    int det_na, det_no, det_invno, det_rows_total, det_row_off;
+    float det_stride;
+    float det_anchor[16];
+    float* det_x;
+    float* det_z;
 };
 
 __device__ __forceinline__ float yp_silu(float x) {
@@ -156,6 +162,27 @@ __device__ __forceinline__ void yp_epilogue_pixel(const ConvKArgs& a, int m, int
     }
 }
 
+// Detect-head decode of one element (reference models/yolo.py:53-68): channel n = a*no + o of pixel
+// (b, rem = y*nx + x) goes to x_out[b, a, y, x, o] untouched and, decoded, to z[b, row_off + (a*ny + y)*nx + x, o]:
+//   xy = (2*sigmoid - 0.5 + grid) * stride, wh = (2*sigmoid)^2 * anchor_px, the rest = sigmoid.
+__device__ __forceinline__ void yp_detect_store(const ConvKArgs& a, int b, int rem, int y, int x, int n, float v) {
+    const int no = a.det_no;
+    const int an = (n * a.det_invno) >> 16, o = n - an * no;
+    const size_t cell = (size_t)(b * a.det_na + an) * a.HoWo + rem;
+    a.det_x[cell * no + o] = v;
+    if (a.det_z != nullptr) {
+        const float s = 1.0f / (1.0f + expf(-v));
+        float z;
+        if (o == 0) z = (s * 2.0f - 0.5f + (float)x) * a.det_stride;
+        else if (o == 1) z = (s * 2.0f - 0.5f + (float)y) * a.det_stride;
+        else if (o == 2) { const float t2 = s * 2.0f; z = t2 * t2 * a.det_anchor[an * 2]; }
+        else if (o == 3) { const float t2 = s * 2.0f; z = t2 * t2 * a.det_anchor[an * 2 + 1]; }
+        else z = s;
+        const size_t row = (size_t)a.det_row_off + (size_t)an * a.HoWo + rem;
+        a.det_z[((size_t)b * a.det_rows_total + row) * no + o] = z;
+    }
+}
+
 template <int LPG>
 __device__ __forceinline__ void yp_load_bias(const ConvKArgs& a, int nb, float (&bias)[LPG]) {
 #pragma unroll
@@ -200,7 +227,7 @@ __device__ __forceinline__ void yp_glds16_s(const void* sbase, unsigned voff, un
 // places lanes linearly).  Bank conflicts of the 16-byte fragment reads are removed by an XOR
 // swizzle applied on the SOURCE side: physical chunk j of row r holds logical chunk j ^ swz(r),
 // swz(r) = {0,0,3,3}[(r/4)%4]; readers apply the same involution.
-template <int DT, bool OUT_F32, bool FAST, int BM, int BN, int WAVES_M, int WAVES_N, int NS>
+template <int DT, bool OUT_F32, bool FAST, bool DETECT, int BM, int BN, int WAVES_M, int WAVES_N, int NS>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     using E = Elem<DT>;
     using frag_t = typename E::frag;
@@ -419,7 +446,65 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     for (int fm = 0; fm < FM; ++fm) {
         const int m = m0 + wm * TM + fm * 16 + p;
         if (m >= a.M) continue;
-        yp_epilogue_pixel<DT, OUT_F32, LPG>(a, m, nb, bias, [&](int cj) { return acc[cj >> 2][fm][cj & 3]; });
+        if constexpr (!DETECT) yp_epilogue_pixel<DT, OUT_F32, LPG>(a, m, nb, bias, [&](int cj) { return acc[cj >> 2][fm][cj & 3]; });
+    }
+    if constexpr (DETECT) {
+        // The (pixel x channel) tile is staged through the now idle pipeline LDS so that each wave writes one
+        // pixel's channels as a contiguous run of x_out / z (both are o-contiguous per (pixel, anchor)).
+        constexpr int PITCH = BN + (BN < 128 ? 1 : 0);
+        static_assert(BM * PITCH * 4 <= NS * STAGE, "detect staging tile must fit the pipeline LDS");
+        float* tile = reinterpret_cast<float*>(smem);
+        __syncthreads();                  // every wave has consumed the last k tile (its DMAs were drained above)
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+            for (int j = 0; j < LPG; ++j)
+                tile[(wm * TM + fm * 16 + p) * PITCH + wn * TN + g * LPG + j] = acc[j >> 2][fm][j & 3] + bias[j];
+        __syncthreads();
+        const int nreal = a.det_na * a.det_no, no = a.det_no;
+        constexpr int GPP = BN / 4;           // 4-channel groups per pixel
+        for (int idx = t; idx < BM * GPP; idx += 256) {
+            const int pix = idx / GPP, grp = idx - pix * GPP;
+            const int m = m0 + pix;
+            if (m >= a.M) break;
+            const int n = n0 + grp * 4;
+            if (n >= nreal) continue;
+            const int b = m / a.HoWo, rem = m - b * a.HoWo;
+            const int y = rem / a.Wo, x = rem - y * a.Wo;
+            const float* src = tile + pix * PITCH + grp * 4;
+            const int an = (n * a.det_invno) >> 16, o = n - an * no;
+            if (o + 3 < no) {                 // the 4 channels stay inside one anchor: two 16-byte stores
+                const float v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+                const size_t cell = (size_t)(b * a.det_na + an) * a.HoWo + rem;
+                float* xp = a.det_x + cell * no + o;
+                __builtin_nontemporal_store(v0, xp); __builtin_nontemporal_store(v1, xp + 1);
+                __builtin_nontemporal_store(v2, xp + 2); __builtin_nontemporal_store(v3, xp + 3);
+                if (a.det_z != nullptr) {
+                    float zz[4];
+                    const float vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float sg = 1.0f / (1.0f + expf(-vv[j]));
+                        const int oj = o + j;
+                        float z;
+                        if (oj == 0) z = (sg * 2.0f - 0.5f + (float)x) * a.det_stride;
+                        else if (oj == 1) z = (sg * 2.0f - 0.5f + (float)y) * a.det_stride;
+                        else if (oj == 2) { const float t2 = sg * 2.0f; z = t2 * t2 * a.det_anchor[an * 2]; }
+                        else if (oj == 3) { const float t2 = sg * 2.0f; z = t2 * t2 * a.det_anchor[an * 2 + 1]; }
+                        else z = sg;
+                        zz[j] = z;
+                    }
+                    const size_t row = (size_t)a.det_row_off + (size_t)an * a.HoWo + rem;
+                    float* zp = a.det_z + ((size_t)b * a.det_rows_total + row) * no + o;
+                    __builtin_nontemporal_store(zz[0], zp); __builtin_nontemporal_store(zz[1], zp + 1);
+                    __builtin_nontemporal_store(zz[2], zp + 2); __builtin_nontemporal_store(zz[3], zp + 3);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (n + j < nreal) yp_detect_store(a, b, rem, y, x, n + j, src[j]);
+            }
+        }
     }
 }
 
@@ -600,14 +685,14 @@ namespace {
 struct TileCfg { int id, bm, bn; };
 constexpr TileCfg kTiles[] = {{1, 128, 32}, {2, 128, 64}, {3, 128, 128}, {4, 64, 64}, {5, 64, 32}};
 
-template <int DT, bool OUT_F32, bool FAST>
+template <int DT, bool OUT_F32, bool FAST, bool DETECT = false>
 hipError_t launch_cfg(int tile, const ConvKArgs& a, int nblk, hipStream_t st) {
     switch (tile) {
-        case 1: conv_igemm_kernel<DT, OUT_F32, FAST, 128, 32, 4, 1, 4><<<nblk, 256, 0, st>>>(a); break;
-        case 2: conv_igemm_kernel<DT, OUT_F32, FAST, 128, 64, 4, 1, 4><<<nblk, 256, 0, st>>>(a); break;
-        case 3: conv_igemm_kernel<DT, OUT_F32, FAST, 128, 128, 2, 2, 4><<<nblk, 256, 0, st>>>(a); break;
-        case 4: conv_igemm_kernel<DT, OUT_F32, FAST, 64, 64, 2, 2, 4><<<nblk, 256, 0, st>>>(a); break;
-        case 5: conv_igemm_kernel<DT, OUT_F32, FAST, 64, 32, 4, 1, 4><<<nblk, 256, 0, st>>>(a); break;
+        case 1: conv_igemm_kernel<DT, OUT_F32, FAST, DETECT, 128, 32, 4, 1, 4><<<nblk, 256, 0, st>>>(a); break;
+        case 2: conv_igemm_kernel<DT, OUT_F32, FAST, DETECT, 128, 64, 4, 1, 4><<<nblk, 256, 0, st>>>(a); break;
+        case 3: conv_igemm_kernel<DT, OUT_F32, FAST, DETECT, 128, 128, 2, 2, 4><<<nblk, 256, 0, st>>>(a); break;
+        case 4: conv_igemm_kernel<DT, OUT_F32, FAST, DETECT, 64, 64, 2, 2, 4><<<nblk, 256, 0, st>>>(a); break;
+        case 5: conv_igemm_kernel<DT, OUT_F32, FAST, DETECT, 64, 32, 4, 1, 4><<<nblk, 256, 0, st>>>(a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -657,13 +742,13 @@ extern "C" int yp_conv_kpad(int K, int dtype) {
     return yp_cdiv(K, g) * g;
 }
 
-int yp_conv2d_launch(const YpConvDesc* d, hipStream_t stream) {
+int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t stream) {
     YP_REQUIRE(d != nullptr, "yp_conv2d: null descriptor");
     YP_REQUIRE(d->dtype == YP_F16 || d->dtype == YP_BF16 || d->dtype == YP_F32, "yp_conv2d: bad dtype %d", d->dtype);
     const int ce = d->dtype == YP_F32 ? 4 : 8;
     const int Cin = d->in0.C + d->in1.C;
     const int Cout = d->out.C + d->out2.C;
-    YP_REQUIRE(d->in0.ptr && d->out.ptr && d->weight, "yp_conv2d: null buffer");
+    YP_REQUIRE(d->in0.ptr && (d->out.ptr || det) && d->weight, "yp_conv2d: null buffer");
     YP_REQUIRE(d->in0.C > 0 && d->in0.C % ce == 0 && d->in1.C % ce == 0, "yp_conv2d: input channels (%d,%d) must be multiples of %d", d->in0.C, d->in1.C, ce);
     YP_REQUIRE(d->in0.cstride % ce == 0 && d->in0.coff % ce == 0, "yp_conv2d: in0 slice not 16-byte aligned");
     YP_REQUIRE(d->in1.C == 0 || (d->in1.ptr && d->in1.cstride % ce == 0 && d->in1.coff % ce == 0), "yp_conv2d: in1 slice not 16-byte aligned");
@@ -717,6 +802,22 @@ int yp_conv2d_launch(const YpConvDesc* d, hipStream_t stream) {
 
     hipError_t e;
     const bool of32 = d->out_f32 != 0;
+    if (det != nullptr) {
+        YP_REQUIRE(det->na > 0 && det->na <= 8 && det->no > 5 && det->na * det->no <= Cout && det->x_out != nullptr, "yp_conv2d_detect: bad detect descriptor");
+        YP_REQUIRE(d->act == YP_ACT_NONE && d->res.C == 0 && d->out2.C == 0 && fast, "yp_conv2d_detect: plain fast-path convolution required");
+        a.det_na = det->na; a.det_no = det->no; a.det_invno = (65536 + det->no - 1) / det->no;
+        YP_REQUIRE((long)Cout * (a.det_invno * det->no - 65536) < 65536, "yp_conv2d_detect: channel decode out of range");
+        a.det_rows_total = det->rows_total; a.det_row_off = det->row_offset; a.det_stride = det->stride;
+        for (int i = 0; i < 16; ++i) a.det_anchor[i] = det->anchors_px[i];
+        a.det_x = det->x_out; a.det_z = det->z_out;
+        switch (d->dtype) {
+            case YP_F16: e = launch_cfg<YP_F16, true, true, true>(tile, a, nblk, stream); break;
+            case YP_BF16: e = launch_cfg<YP_BF16, true, true, true>(tile, a, nblk, stream); break;
+            default: e = launch_cfg<YP_F32, false, true, true>(tile, a, nblk, stream); break;
+        }
+        if (e != hipSuccess) { yp_set_error("yp_conv2d_detect: launch failed: %s", hipGetErrorString(e)); return YP_ERR_HIP; }
+        return YP_OK;
+    }
     // 3x3 / pad 1 / stride 1|2, single un-upsampled source, 16-bit types, Cin % 32 == 0: LDS halo-reuse kernel
     // (tile ids 10..12 force it with BN = 32/64/128; tile 0 picks BN by the channel count; ids 1..5 force the generic kernel)
     const bool halo_ok = fast && d->dtype != YP_F32 && d->R == 3 && d->S == 3 && d->pad_h == 1 && d->pad_w == 1 &&
@@ -755,4 +856,8 @@ int yp_conv2d_launch(const YpConvDesc* d, hipStream_t stream) {
     return YP_OK;
 }
 
-extern "C" int yp_conv2d(const YpConvDesc* d, void* stream) { return yp_conv2d_launch(d, (hipStream_t)stream); }
+extern "C" int yp_conv2d(const YpConvDesc* d, void* stream) { return yp_conv2d_launch(d, nullptr, (hipStream_t)stream); }
+extern "C" int yp_conv2d_detect(const YpConvDesc* d, const YpDetectDesc* det, void* stream) {
+    YP_REQUIRE(det != nullptr, "yp_conv2d_detect: null detect descriptor");
+    return yp_conv2d_launch(d, det, (hipStream_t)stream);
+}

@@ -30,6 +30,8 @@ enum OpKind { OP_CONV = 0, OP_SPPF = 1, OP_L2NORM = 2, OP_DETECT = 3 };
 struct PlanOp {
     int kind;
     YpConvDesc conv;
+    YpDetectDesc det;
+    bool has_det = false;
     YpView v[4];
     int B, dtype, C, na, no, rows_total, row_offset;
     float stride;
@@ -49,7 +51,7 @@ struct YpPlan {
 
 static int run_op(const PlanOp& op, hipStream_t st) {
     switch (op.kind) {
-        case OP_CONV: return yp_conv2d_launch(&op.conv, st);
+        case OP_CONV: return yp_conv2d_launch(&op.conv, op.has_det ? &op.det : nullptr, st);
         case OP_SPPF: return yp_sppf_pool(op.v[0], op.v[1], op.v[2], op.v[3], op.B, op.dtype, st);
         case OP_L2NORM: return yp_l2norm_f32(op.v[0], op.v[1], op.B, op.C, st);
         case OP_DETECT:
@@ -85,6 +87,18 @@ extern "C" int yp_plan_add_conv(YpPlan* plan, const YpConvDesc* d) {
     PlanOp op{};
     op.kind = OP_CONV;
     op.conv = *d;
+    plan->ops.push_back(op);
+    return YP_OK;
+}
+
+extern "C" int yp_plan_add_conv_detect(YpPlan* plan, const YpConvDesc* d, const YpDetectDesc* det) {
+    YP_PLAN_MUTABLE(plan);
+    YP_REQUIRE(d != nullptr && det != nullptr, "yp_plan_add_conv_detect: null descriptor");
+    PlanOp op{};
+    op.kind = OP_CONV;
+    op.conv = *d;
+    op.det = *det;
+    op.has_det = true;
     plan->ops.push_back(op);
     return YP_OK;
 }

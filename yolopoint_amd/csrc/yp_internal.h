@@ -30,4 +30,4 @@ static inline int yp_dtype_bytes(int dtype) { return dtype == YP_F32 ? 4 : 2; }
 static inline int yp_cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // launchers living in other translation units (used by the plan)
-int yp_conv2d_launch(const YpConvDesc* d, hipStream_t stream);
+int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t stream);

@@ -40,12 +40,14 @@ class Detect(HipModule):
         off = 0
         for i, v in enumerate(xs):
             pb.scope.append(f"m.{i}")
-            raw = pb.conv(v, self.m[i].weight.detach().float(), self.m[i].bias.detach().float(), 1, 1, 0,
-                          _hip.YP_ACT_NONE, out_f32=True)
-            xo = pb.new_tensor((B, self.na, raw.H, raw.W, self.no))
+            ny, nx = v.LH, v.LW
+            xo = pb.new_tensor((B, self.na, ny, nx, self.no))
             stride = float(self.stride[i])
             anchors_px = (self.anchors[i].detach().float().cpu() * stride).reshape(-1).tolist()
-            pb.detect_decode(raw, self.na, self.no, stride, anchors_px, xo, z, total, off)
+            # 1x1 conv + (view/permute/sigmoid/grid decode/concat) in ONE launch: the raw logits never round-trip HBM
+            pb.conv(v, self.m[i].weight.detach().float(), self.m[i].bias.detach().float(), 1, 1, 0, _hip.YP_ACT_NONE, out_f32=True,
+                    detect=dict(na=self.na, no=self.no, stride=stride, anchors_px=anchors_px, x_out=xo, z_out=z,
+                                rows_total=total, row_offset=off))
             pb.scope.pop()
             outs.append(xo)
             off += rows[i]

@@ -13,7 +13,7 @@ import math
 import torch
 
 from . import _hip
-from ._hip import YpView, YpConvDesc, check, lib
+from ._hip import YpView, YpConvDesc, YpDetectDesc, check, lib
 
 
 def round_up(v, m):
@@ -74,6 +74,16 @@ class View:
 
 
 NULL_VIEW = YpView(None, 0, 0, 0, 0, 0, 0)
+
+
+class GeomView:
+    """Geometry-only stand-in for an output view (fused Detect decode: nothing is written through it)."""
+
+    def __init__(self, H, W, C_):
+        self.H, self.W, self.C = H, W, C_
+
+    def c(self):
+        return YpView(None, self.H, self.W, self.C, 0, self.C, 0)
 
 
 def pack_conv_weight(w, bias, code, device):
@@ -167,7 +177,7 @@ class PlanBuilder:
         return deps
 
     # -- ops ----------------------------------------------------------------------------
-    def conv(self, srcs, w, bias, k, s, p, act, out=None, res=None, out_f32=False, tile=0, out2=None):
+    def conv(self, srcs, w, bias, k, s, p, act, out=None, res=None, out_f32=False, tile=0, out2=None, detect=None):
         """srcs: one or two Views (channel-concatenated); w: OIHW fp32 tensor (BN already folded)."""
         if isinstance(srcs, View):
             srcs = [srcs]
@@ -196,7 +206,11 @@ class PlanBuilder:
         else:
             assert sum(v.C for v in srcs) == Cin, (self.name(), [v.C for v in srcs], Cin)
         Cout_pad = round_up(Cout, 8)
-        if out is None:
+        if detect is not None:
+            # fused Detect decode: the conv writes x_out / z directly, `out` only carries the geometry
+            assert out is None and out2 is None and res is None and out_f32
+            out = GeomView(Ho, Wo, Cout_pad)
+        elif out is None:
             assert out2 is None
             out = self.new_buf(Ho, Wo, Cout_pad, f32=out_f32).view()
         c2 = out2.C if out2 is not None else 0      # channels [out.C, out.C + c2) are written to out2
@@ -215,37 +229,58 @@ class PlanBuilder:
         d.Hi, d.Wi, d.Ho, d.Wo = Hi, Wi, Ho, Wo
         d.R, d.S, d.stride_h, d.stride_w, d.pad_h, d.pad_w = R, S, sh, sw, ph, pw
         d.Kpad, d.Npad, d.act, d.tile, d.tail_zero = Kpad, Npad, act, tile, 1
+        det = None
+        if detect is not None:
+            det = YpDetectDesc()
+            det.na, det.no, det.stride = detect["na"], detect["no"], float(detect["stride"])
+            for i, v in enumerate(detect["anchors_px"]):
+                det.anchors_px[i] = float(v)
+            det.x_out = detect["x_out"].data_ptr()
+            det.z_out = detect["z_out"].data_ptr() if detect["z_out"] is not None else None
+            det.rows_total, det.row_offset = detect["rows_total"], detect["row_offset"]
         if tile == 0 and self.autotune:
-            d.tile = self._autotune(d, (self.code, self.B, Hi, Wi, tuple((v.C, v.ups) for v in srcs), Cout_pad, R, S, sh, sw,
-                                        int(out_f32), res is not None, c2, act))
-        check(lib().yp_plan_add_conv(self.handle, C.byref(d)))
-        self._track(list(srcs) + [res], [out, out2])
+            d.tile = self._autotune(d, det, (self.code, self.B, Hi, Wi, tuple((v.C, v.ups) for v in srcs), Cout_pad, R, S, sh, sw,
+                                             int(out_f32), res is not None, c2, act, detect is not None))
+        if det is not None:
+            check(lib().yp_plan_add_conv_detect(self.handle, C.byref(d), C.byref(det)))
+            rows = detect["na"] * Ho * Wo
+            self._track(list(srcs), [(detect["x_out"], 0, 1 << 30)] +
+                        ([(detect["z_out"], detect["row_offset"], detect["row_offset"] + rows)] if detect["z_out"] is not None else []))
+        else:
+            check(lib().yp_plan_add_conv(self.handle, C.byref(d)))
+            self._track(list(srcs) + [res], [out, out2])
         # algorithmic work: MAC*2 with the REAL channel counts (BASELINE.md section 2 convention)
         Kreal = w.shape[1] * w.shape[2] * w.shape[3] if not thin else Cin * R * (S * (2 if self.ce == 8 else 1))
         M = self.B * Ho * Wo
         eb = 4 if self.code == _hip.YP_F32 else 2
         in_elems = self.B * sum((v.H * v.W * v.C) for v in srcs)
-        bytes_ = in_elems * eb + M * Cout * (4 if out_f32 else eb) + Cout * Kreal * eb
+        bytes_ = in_elems * eb + M * Cout * (4 if out_f32 else eb) * (2 if (detect is not None and detect['z_out'] is not None) else 1) + Cout * Kreal * eb
         self.records.append(OpRecord(self.name(), "conv", 2 * M * Cout * Kreal, bytes_, M, Cout, Kreal))
         return out
 
-    def _autotune(self, d, key):
+    def _autotune(self, d, det, key):
         """Pick the fastest kernel variant for this convolution by timing each candidate on the plan's own buffers
         (HIP events on the current stream).  Every variant computes the same convolution; the choice is cached per
         signature so that equal layers always run the same kernel within a process."""
         if key in _TUNE_CACHE:
             return _TUNE_CACHE[key]
         st = _hip.stream_ptr()
+        if det is not None:
+            run = lambda: lib().yp_conv2d_detect(C.byref(d), C.byref(det), st)
+        else:
+            run = lambda: lib().yp_conv2d(C.byref(d), st)
         best, best_ms = 0, None
         for cand in _TUNE_CANDIDATES:
+            if det is not None and cand >= 10:
+                continue
             d.tile = cand
-            if lib().yp_conv2d(C.byref(d), st) != 0:
+            if run() != 0:
                 continue                              # variant does not apply to this convolution
-            lib().yp_conv2d(C.byref(d), st)
+            run()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(8):
-                lib().yp_conv2d(C.byref(d), st)
+                run()
             e1.record()
             e1.synchronize()
             ms = e0.elapsed_time(e1)
