@@ -94,6 +94,12 @@ typedef struct YpConvDesc {
     int32_t Kpad, Npad;              /* packed weight dims                             */
     int32_t act;                     /* YP_ACT_*                                       */
     int32_t tile;                    /* 0 = auto, else forced tile config id (testing) */
+    int32_t dil_h, dil_w;            /* filter dilation, 0 = 1 (generic kernel only)   */
+    int32_t in0_zero_stuffed;        /* in0 (ups = 1) is a zero-stuffed tensor: only even logical rows/cols
+                                      * carry data (gradient of a stride-2 convolution w.r.t. its input)       */
+    int32_t ksplit;                  /* > 1: split the reduction over that many workgroups per tile; fp32
+                                      * atomicAdd into `out` (must be zero-initialised, out_f32, no bias/act)  */
+    int32_t atomic_accumulate;       /* 1: accumulate into `out` with fp32 atomics even when ksplit <= 1       */
     int32_t tail_zero;               /* 1: each input buffer is followed by >= (cstride + 64) zero elements and
                                       * `weight` by one zero row [Kpad] -> the kernels may use their fast 32-bit
                                       * DMA addressing (padding taps are fetched from those zeros)              */
@@ -139,6 +145,74 @@ int yp_l2norm_f32(YpView in, YpView out, int B, int C, void* stream);
  * replaces: models/yolo.py:49-70 */
 int yp_detect_decode(YpView raw, int B, int na, int no, float stride, const float* anchors_px_host,
                      float* x_out, float* z_out, int rows_total, int row_offset, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Training path: batch-statistics BatchNorm + SiLU forward / backward and the small backward
+ * pieces of the graph.  The convolution gradients reuse yp_conv2d: dgrad = convolution with the
+ * flipped, channel-transposed filter (stride 2 through in0_zero_stuffed); wgrad = convolution of
+ * the yp_to_chwb copies (batch <-> channel transposed) with dilation + ksplit.
+ * replaces: nn.BatchNorm2d(eps=1e-3, momentum=0.03) train mode + nn.SiLU (models/common.py:18-29)
+ *           and their autograd backward (train.py:245).
+ * ---------------------------------------------------------------------------------- */
+size_t yp_bn_workspace_bytes(int B, int H, int W, int C);
+/* batch mean / 1/sqrt(biased var + eps) of an NHWC view over its B*H*W rows; updates running stats
+ * (momentum, unbiased variance) in place when the pointers are non-NULL */
+int yp_bn_stats(YpView raw, int dtype, int B, float eps, float momentum, float* mean, float* invstd,
+                float* running_mean, float* running_var, void* workspace, size_t workspace_bytes, void* stream);
+/* out = act(gamma*(raw-mean)*invstd + beta) [+ res] */
+int yp_bn_act_apply(YpView raw, YpView out, YpView res, int dtype, int B, const float* mean, const float* invstd,
+                    const float* gamma, const float* beta, int act, void* stream);
+/* backward of yp_bn_act_apply w.r.t. raw (dx), gamma, beta.  workspace >= yp_bn_workspace_bytes + 8*C bytes */
+int yp_bn_act_bwd(YpView raw, YpView dy, YpView dx, int dtype, int B, const float* mean, const float* invstd,
+                  const float* gamma, const float* beta, int act, float* dgamma, float* dbeta, int accumulate_param_grads,
+                  void* workspace, size_t workspace_bytes, void* stream);
+/* out (+)= 2x2 block sums of `in` (backward of nn.Upsample(2,'nearest'), models/YOLOPoint.py:192) */
+int yp_ups2_bwd(YpView in, YpView out, int dtype, int B, int accumulate, void* stream);
+/* dst (+)= src (gradient fan-in) */
+int yp_add_views(YpView src, YpView dst, int dtype, int B, int accumulate, void* stream);
+/* backward of MaxPool2d(5,1,2) (models/common.py:220): dx (+)= dy routed to each window's first maximum */
+int yp_maxpool5_bwd(YpView x, YpView dy, YpView dx, int dtype, int B, int accumulate, void* stream);
+/* backward of the descriptor L2 normalisation (models/YOLOPoint.py:219-220), fp32 views */
+int yp_l2norm_bwd_f32(YpView x, YpView g, YpView dx, int B, int C, void* stream);
+/* fp32 gradient of the permuted Detect output [B,na,ny,nx,no] -> NHWC view in `dtype` (inverse of models/yolo.py:53) */
+int yp_detect_bwd_pack(const float* gx, int B, int na, int no, YpView out, int dtype, void* stream);
+/* NHWC view (optionally through its 2x upsample) -> [C][H][W][Bpad] copy, batch zero-padded (wgrad operand layout) */
+int yp_to_chwb(YpView in, int dtype, int B, int C, void* out, int Bpad, void* stream);
+/* out[c] (+)= sum over the B*H*W rows of view[., c]  (bias gradients); workspace as yp_bn_workspace_bytes */
+/* fp32 NHWC view -> `dtype` NHWC view */
+int yp_cast_from_f32(YpView in, YpView out, int dtype, int B, void* stream);
+int yp_col_sum(YpView v, int dtype, int B, float* out, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
+/* One generic launch record: `op` selects one of the functions above, the slots carry its arguments in the
+ * order documented next to each opcode.  Lets training plans replay any mix of launches (yp_plan_add_op). */
+enum {
+    YP_OP_BN_STATS = 10,      /* v0=raw; i0=dtype i1=B; s0=eps s1=momentum; g0=mean g1=invstd g2=running_mean g3=running_var; p0=ws n0=ws_bytes */
+    YP_OP_BN_APPLY = 11,      /* v0=raw v1=out v2=res; i0=dtype i1=B i2=act; f0=mean f1=invstd f2=gamma f3=beta */
+    YP_OP_BN_BWD = 12,        /* v0=raw v1=dy v2=dx; i0=dtype i1=B i2=act i3=accumulate; f0..f3 as above; g0=dgamma g1=dbeta; p0=ws n0=ws_bytes */
+    YP_OP_UPS2_BWD = 13,      /* v0=in v1=out; i0=dtype i1=B i2=accumulate */
+    YP_OP_ADD_VIEWS = 14,     /* v0=src v1=dst; i0=dtype i1=B i2=accumulate */
+    YP_OP_MAXPOOL5_BWD = 15,  /* v0=x v1=dy v2=dx; i0=dtype i1=B i2=accumulate */
+    YP_OP_L2NORM_BWD = 16,    /* v0=x v1=g v2=dx; i1=B i2=C */
+    YP_OP_DETECT_BWD_PACK = 17, /* f0=gx; v0=out; i0=dtype i1=B i2=na i3=no */
+    YP_OP_TO_CHWB = 18,       /* v0=in; i0=dtype i1=B i2=C i3=Bpad; p0=out */
+    YP_OP_COL_SUM = 19,       /* v0=view; i0=dtype i1=B i2=accumulate; g0=out; p0=ws n0=ws_bytes */
+    YP_OP_MEMSET0 = 20,       /* p0=ptr n0=bytes */
+    YP_OP_PACK_NCHW = 21,     /* f0=x_nchw; v0=out; i0=dtype i1=B i2=C */
+    YP_OP_L2NORM = 22,        /* v0=in v1=out; i1=B i2=C */
+    YP_OP_SPPF_POOL = 23,     /* v0=x v1..v3=y1..y3; i0=dtype i1=B */
+    YP_OP_CAST_F32 = 24       /* v0=in (fp32) v1=out; i0=dtype i1=B */
+};
+typedef struct YpOpArgs {
+    int32_t op, pad_;
+    YpView v[4];
+    const float* f[4];
+    float* g[4];
+    void* p[2];
+    size_t n[2];
+    int32_t i[8];
+    float s[4];
+} YpOpArgs;
+int yp_run_op(const YpOpArgs* a, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Post-processing
@@ -204,6 +278,7 @@ int yp_plan_add_l2norm(YpPlan* plan, YpView in, YpView out, int B, int C);
 int yp_plan_add_detect_decode(YpPlan* plan, YpView raw, int B, int na, int no, float stride,
                               const float* anchors_px_host, float* x_out, float* z_out,
                               int rows_total, int row_offset);
+int yp_plan_add_op(YpPlan* plan, const YpOpArgs* a);
 int yp_plan_num_ops(const YpPlan* plan);
 /* true data dependencies of op `op`: the earlier ops it must wait for.  When every op has a
  * dependency list, yp_plan_instantiate_graph replaces the captured chain's edges by these, so

@@ -1,0 +1,81 @@
+"""GPU parity of the training path: train-mode forward (batch-statistics BN, running-stat update) against the
+golden outputs of the reference, and the full backward (every parameter gradient) against PyTorch-CPU autograd
+through the oracle.  fp32 compute path: forward 1e-3 of max|ref|; gradients 2e-3 relative L2 per tensor."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_model, rel_err
+from oracle import net_oracle
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_train_forward_matches_reference_golden(cuda):
+    net = np.load(os.path.join(G, "network.npz"))
+    m, sd = make_model("n", 21, dtype="f32")
+    m = m.to(cuda).train()
+    x = net_oracle.synth_image(2, 3, 64, 64, 21).to(cuda)
+    with torch.no_grad():
+        o = m(x)
+    assert rel_err(o["semi"], net["n64.train.semi"])[0] < 1e-3
+    assert rel_err(o["desc"], net["n64.train.desc"])[0] < 1e-3
+    for i, t in enumerate(o["objects"]):
+        assert rel_err(t, net[f"n64.train.x{i}"])[0] < 1e-3
+    sd2 = m.state_dict()
+    for k in ("model.Conv1.bn.running_mean", "model.Conv1.bn.running_var", "model.Bottleneck8.cv3.bn.running_mean",
+              "model.Bottleneck8.cv3.bn.running_var"):
+        np.testing.assert_allclose(sd2[k].cpu().numpy(), net["n64.train." + k], rtol=2e-4, atol=1e-5)
+    assert int(sd2["model.Conv1.bn.num_batches_tracked"]) == 1
+
+
+@pytest.mark.parametrize("version,B,S", [("n", 2, 64), ("s", 2, 128)])
+def test_backward_matches_oracle_autograd(cuda, version, B, S):
+    m, sd = make_model(version, 31, dtype="f32")
+    m = m.to(cuda).train()
+    x = net_oracle.synth_image(B, 3, S, S, 31)
+    # random projections of the three outputs as the loss
+    g = torch.Generator().manual_seed(5)
+    leaf = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in sd.items()}
+    ref = net_oracle.yolopoint_forward(leaf, x, version, training=True, stats={})
+    proj = {"semi": torch.randn(ref["semi"].shape, generator=g), "desc": torch.randn(ref["desc"].shape, generator=g),
+            "objects": [torch.randn(t.shape, generator=g) for t in ref["objects"]]}
+
+    def loss_of(o, dev):
+        l = (o["semi"] * proj["semi"].to(dev)).sum() * 0.01 + (o["desc"] * proj["desc"].to(dev)).sum()
+        for t, p in zip(o["objects"], proj["objects"]):
+            l = l + (t * p.to(dev)).sum() * 0.01
+        return l
+    loss_of(ref, "cpu").backward()
+    out = m(x.to(cuda))
+    loss_of(out, cuda).backward()
+    worst = []
+    for name, p in m.named_parameters():
+        gref = leaf[name].grad
+        assert p.grad is not None and gref is not None, name
+        e_max, e_l2 = rel_err(p.grad, gref)
+        worst.append((e_l2, name))
+        assert e_l2 < 2e-3, (name, e_max, e_l2)
+    print("largest gradient rel-L2 errors:", sorted(worst)[-3:])
+
+
+def test_two_forwards_then_backward_like_the_reference_step(cuda):
+    """train.py:208-245: model(img), model(img_warp), one loss, one backward -> gradients add up."""
+    m, sd = make_model("n", 7, dtype="f32")
+    m = m.to(cuda).train()
+    x1 = net_oracle.synth_image(2, 3, 64, 64, 1).to(cuda)
+    x2 = net_oracle.synth_image(2, 3, 64, 64, 2).to(cuda)
+    o1, o2 = m(x1), m(x2)
+    (o1["semi"].sum() * 0.01 + o2["desc"][:, :3].sum()).backward()
+    g_both = m.model.Conv2.conv.weight.grad.clone()
+    m.zero_grad()
+    m(x1)["semi"].sum().mul(0.01).backward()
+    g1 = m.model.Conv2.conv.weight.grad.clone()
+    m.zero_grad()
+    m(x2)["desc"][:, :3].sum().backward()
+    g2 = m.model.Conv2.conv.weight.grad.clone()
+    # BN running statistics moved between the calls, batch statistics did not: gradients are additive
+    assert rel_err(g_both, g1 + g2)[1] < 1e-4

@@ -30,13 +30,23 @@ class YpConvDesc(C.Structure):
                 ("Hi", C.c_int32), ("Wi", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
                 ("R", C.c_int32), ("S", C.c_int32),
                 ("stride_h", C.c_int32), ("stride_w", C.c_int32), ("pad_h", C.c_int32), ("pad_w", C.c_int32),
-                ("Kpad", C.c_int32), ("Npad", C.c_int32), ("act", C.c_int32), ("tile", C.c_int32), ("tail_zero", C.c_int32)]
+                ("Kpad", C.c_int32), ("Npad", C.c_int32), ("act", C.c_int32), ("tile", C.c_int32),
+                ("dil_h", C.c_int32), ("dil_w", C.c_int32), ("in0_zero_stuffed", C.c_int32), ("ksplit", C.c_int32),
+                ("atomic_accumulate", C.c_int32), ("tail_zero", C.c_int32)]
 
 
 class YpDetectDesc(C.Structure):
     _fields_ = [("na", C.c_int32), ("no", C.c_int32), ("stride", C.c_float), ("anchors_px", C.c_float * 16),
                 ("x_out", C.c_void_p), ("z_out", C.c_void_p), ("rows_total", C.c_int32), ("row_offset", C.c_int32)]
 
+
+class YpOpArgs(C.Structure):
+    _fields_ = [("op", C.c_int32), ("pad_", C.c_int32), ("v", YpView * 4), ("f", C.c_void_p * 4), ("g", C.c_void_p * 4),
+                ("p", C.c_void_p * 2), ("n", C.c_size_t * 2), ("i", C.c_int32 * 8), ("s", C.c_float * 4)]
+
+
+(OP_BN_STATS, OP_BN_APPLY, OP_BN_BWD, OP_UPS2_BWD, OP_ADD_VIEWS, OP_MAXPOOL5_BWD, OP_L2NORM_BWD, OP_DETECT_BWD_PACK, OP_TO_CHWB,
+ OP_COL_SUM, OP_MEMSET0, OP_PACK_NCHW, OP_L2NORM, OP_SPPF_POOL, OP_CAST_F32) = range(10, 25)
 
 _i, _f, _p, _sz, _i64 = C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_int64
 # name -> (restype, argtypes); must list every symbol of include/yolopoint_hip.h
@@ -52,6 +62,20 @@ SIGNATURES = {
     "yp_sppf_pool": (_i, [YpView, YpView, YpView, YpView, _i, _i, _p]),
     "yp_l2norm_f32": (_i, [YpView, YpView, _i, _i, _p]),
     "yp_detect_decode": (_i, [YpView, _i, _i, _i, _f, C.POINTER(_f), _p, _p, _i, _i, _p]),
+    "yp_bn_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "yp_bn_stats": (_i, [YpView, _i, _i, _f, _f, _p, _p, _p, _p, _p, _sz, _p]),
+    "yp_bn_act_apply": (_i, [YpView, YpView, YpView, _i, _i, _p, _p, _p, _p, _i, _p]),
+    "yp_bn_act_bwd": (_i, [YpView, YpView, YpView, _i, _i, _p, _p, _p, _p, _i, _p, _p, _i, _p, _sz, _p]),
+    "yp_ups2_bwd": (_i, [YpView, YpView, _i, _i, _i, _p]),
+    "yp_add_views": (_i, [YpView, YpView, _i, _i, _i, _p]),
+    "yp_maxpool5_bwd": (_i, [YpView, YpView, YpView, _i, _i, _i, _p]),
+    "yp_l2norm_bwd_f32": (_i, [YpView, YpView, YpView, _i, _i, _p]),
+    "yp_detect_bwd_pack": (_i, [_p, _i, _i, _i, YpView, _i, _p]),
+    "yp_to_chwb": (_i, [YpView, _i, _i, _i, _p, _i, _p]),
+    "yp_cast_from_f32": (_i, [YpView, YpView, _i, _i, _p]),
+    "yp_col_sum": (_i, [YpView, _i, _i, _p, _i, _p, _sz, _p]),
+    "yp_run_op": (_i, [C.POINTER(YpOpArgs), _p]),
+    "yp_plan_add_op": (_i, [_p, C.POINTER(YpOpArgs)]),
     "yp_kp_decode": (_i, [_p, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _p, _p]),
     "yp_kp_nms_workspace_bytes": (_sz, [_i, _i, _i]),
     "yp_kp_nms": (_i, [_p, _i, _i, _i, _f, _i, _i, _p, _p, _i, _p, _sz, _p]),

@@ -70,6 +70,9 @@ struct ConvKArgs {
     int Hi, Wi, Wo, HoWo;
     int Cin, Cout, Kreal, Kpad, Npad;
     int R, S, RS, invS, dt, dc, sh, sw, ph, pw;
+    int dil_h, dil_w;              // filter dilation (wgrad-as-convolution of a strided conv)
+    int in0_zs;                    // in0 is a zero-stuffed view: logical (2H x 2W), odd rows/cols are zero (dgrad of stride 2)
+    int ksplit, atomic_out;        // split-K over blockIdx.y with fp32 atomicAdd epilogue
     unsigned in0_zoff, in1_zoff, wgt_zrow;   // FAST path: byte offsets of the 16 zero bytes behind each input / the zero filter row
     int act;
     int M, tiles_n;
@@ -304,10 +307,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
         b_src[i] = (n < a.Npad) ? a.wgt + ((size_t)n * a.Kpad + jl * CE) * EB : nullptr;
         b_off[i] = ((n < a.Npad) ? (unsigned)n * (unsigned)a.Kpad * EB : a.wgt_zrow) + jl * 16;
     }
+    // ---- split-K: this workgroup reduces k tiles [kt0, kt1)
+    const int nk_all = (a.Kreal + BK - 1) / BK;
+    const int kt0 = (int)(((long)nk_all * blockIdx.y) / a.ksplit);
+    const int kt1 = (int)(((long)nk_all * (blockIdx.y + 1)) / a.ksplit);
     // ---- per-lane filter-tap state for logical chunk jl: k = kt*BK + jl*CE = tap*Cin + kc, tap = r*S + s
     int kc, tap;
     {
-        const int k = jl * CE;
+        const int k = kt0 * BK + jl * CE;
         tap = k / a.Cin;
         kc = k - tap * a.Cin;
     }
@@ -326,7 +333,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     // FAST path state: every lane of the workgroup is in the same filter tap (Cin % BK == 0), so the tap
     // decode, the source select and the channel offset live on the scalar unit.
-    int s_tap = 0, s_c0 = 0;
+    int s_tap = (kt0 * BK) / a.Cin, s_c0 = kt0 * BK - s_tap * a.Cin;
     YP_PIN2(unsigned, in0_zoff); YP_PIN2(unsigned, in1_zoff); YP_PIN2(const char*, wgt);
     auto issue_tile = [&](int kt, int stage) {
         const unsigned sbase = lds0 + stage * STAGE;
@@ -340,13 +347,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
             const int Hp = s0 ? in0_H : in1_H;
             const int Wp = s0 ? in0_W : in1_W;
             const unsigned zoff = s0 ? in0_zoff : in1_zoff;
+            const bool zs = s0 && a.in0_zs;
             const int cbyte = ((s0 ? in0_co + s_c0 : in1_co + s_c0 - in0_C)) * EB;     // scalar
             const int csb = cs * EB;
             const unsigned lanec = (unsigned)jl * 16u;
 #pragma unroll
             for (int i = 0; i < NLA; ++i) {
                 const int hi = hi0[i] + kr, wi = wi0[i] + ks;
-                const bool ok = (unsigned)hi < (unsigned)Hi && (unsigned)wi < (unsigned)Wi;
+                const bool ok = (unsigned)hi < (unsigned)Hi && (unsigned)wi < (unsigned)Wi && !(zs && ((hi | wi) & 1));
                 const int pix = (bb[i] * Hp + (hi >> ups)) * Wp + (wi >> ups);
                 const unsigned off = (unsigned)(pix * csb + cbyte) + lanec;
                 yp_glds16_s(base, ok ? off : zoff, sbase + (wave_u + 4 * i) * 1024);
@@ -358,7 +366,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
             if (s_c0 >= Cin) { s_c0 -= Cin; ++s_tap; }
             return;
         }
-        const int kr = (tap * invS) >> 16;          // tap / S (exact: tap < 128, S <= 8)
+        const int kr = tap / S;                       // generic path: any filter size (wgrad "filters" are Ho x Wo)
         const int ks = tap - kr * S;
         const bool tapok = tap < RS;
         const bool s0 = kc < in0_C;
@@ -368,10 +376,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
         const int ups = s0 ? in0_ups : in1_ups;
         const int Hp = s0 ? in0_H : in1_H;
         const int Wp = s0 ? in0_W : in1_W;
+        const bool zs = s0 && a.in0_zs;
 #pragma unroll
         for (int i = 0; i < NLA; ++i) {
-            const int hi = hi0[i] + kr, wi = wi0[i] + ks;
-            const bool ok = tapok && (unsigned)hi < (unsigned)Hi && (unsigned)wi < (unsigned)Wi;
+            const int hi = hi0[i] + kr * a.dil_h, wi = wi0[i] + ks * a.dil_w;
+            const bool ok = tapok && (unsigned)hi < (unsigned)Hi && (unsigned)wi < (unsigned)Wi && !(zs && ((hi | wi) & 1));
             const long pix = ((long)bb[i] * Hp + (hi >> ups)) * Wp + (wi >> ups);
             const char* src = base + (pix * cs + cc) * EB;       // only dereferenced when ok
             yp_glds16(ok ? src : zero, sbase + (wave_u + 4 * i) * 1024);
@@ -410,10 +419,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     float bias[LPG];
     yp_load_bias<LPG>(a, nb, bias);
 
-    const int nk = (a.Kreal + BK - 1) / BK;
+    const int nk = kt1 - kt0;              // tiles are numbered relative to kt0 below; the filter offset uses kt0 + kt
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
-        if (s < nk) issue_tile(s, s);
+        if (s < nk) issue_tile(kt0 + s, s);
 
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt must have landed; up to NS-2 younger tiles may stay in flight
@@ -424,7 +433,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
         __builtin_amdgcn_s_barrier();
         // every wave has finished reading tile kt-1: its stage can be refilled
-        if (kt + NS - 1 < nk) issue_tile(kt + NS - 1, (kt + NS - 1) % NS);
+        if (kt + NS - 1 < nk) issue_tile(kt0 + kt + NS - 1, (kt + NS - 1) % NS);
         const char* s = smem + (kt % NS) * STAGE;
 #pragma unroll
         for (int kk = 0; kk < BK / E::KM; ++kk) {
@@ -446,7 +455,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     for (int fm = 0; fm < FM; ++fm) {
         const int m = m0 + wm * TM + fm * 16 + p;
         if (m >= a.M) continue;
-        if constexpr (!DETECT) yp_epilogue_pixel<DT, OUT_F32, LPG>(a, m, nb, bias, [&](int cj) { return acc[cj >> 2][fm][cj & 3]; });
+        if constexpr (!DETECT) {
+            if (a.atomic_out) {          // split-K partial sums (wgrad): fp32 atomics into a zero-initialised buffer
+#pragma unroll
+                for (int j = 0; j < LPG; ++j)
+                    if (nb + j < a.Cout) atomicAdd(reinterpret_cast<float*>(a.out) + (size_t)m * a.out_cs + a.out_co + nb + j, acc[j >> 2][fm][j & 3]);
+            } else {
+                yp_epilogue_pixel<DT, OUT_F32, LPG>(a, m, nb, bias, [&](int cj) { return acc[cj >> 2][fm][cj & 3]; });
+            }
+        }
     }
     if constexpr (DETECT) {
         // The (pixel x channel) tile is staged through the now idle pipeline LDS so that each wave writes one
@@ -688,11 +705,11 @@ constexpr TileCfg kTiles[] = {{1, 128, 32}, {2, 128, 64}, {3, 128, 128}, {4, 64,
 template <int DT, bool OUT_F32, bool FAST, bool DETECT = false>
 hipError_t launch_cfg(int tile, const ConvKArgs& a, int nblk, hipStream_t st) {
     switch (tile) {
-        case 1: conv_igemm_kernel<DT, OUT_F32, FAST, DETECT, 128, 32, 4, 1, 4><<<nblk, 256, 0, st>>>(a); break;
-        case 2: conv_igemm_kernel<DT, OUT_F32, FAST, DETECT, 128, 64, 4, 1, 4><<<nblk, 256, 0, st>>>(a); break;
-        case 3: conv_igemm_kernel<DT, OUT_F32, FAST, DETECT, 128, 128, 2, 2, 4><<<nblk, 256, 0, st>>>(a); break;
-        case 4: conv_igemm_kernel<DT, OUT_F32, FAST, DETECT, 64, 64, 2, 2, 4><<<nblk, 256, 0, st>>>(a); break;
-        case 5: conv_igemm_kernel<DT, OUT_F32, FAST, DETECT, 64, 32, 4, 1, 4><<<nblk, 256, 0, st>>>(a); break;
+        case 1: conv_igemm_kernel<DT, OUT_F32, FAST, DETECT, 128, 32, 4, 1, 4><<<dim3(nblk, a.ksplit), 256, 0, st>>>(a); break;
+        case 2: conv_igemm_kernel<DT, OUT_F32, FAST, DETECT, 128, 64, 4, 1, 4><<<dim3(nblk, a.ksplit), 256, 0, st>>>(a); break;
+        case 3: conv_igemm_kernel<DT, OUT_F32, FAST, DETECT, 128, 128, 2, 2, 4><<<dim3(nblk, a.ksplit), 256, 0, st>>>(a); break;
+        case 4: conv_igemm_kernel<DT, OUT_F32, FAST, DETECT, 64, 64, 2, 2, 4><<<dim3(nblk, a.ksplit), 256, 0, st>>>(a); break;
+        case 5: conv_igemm_kernel<DT, OUT_F32, FAST, DETECT, 64, 32, 4, 1, 4><<<dim3(nblk, a.ksplit), 256, 0, st>>>(a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -755,12 +772,21 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
     YP_REQUIRE(d->out.C > 0 && d->out.C % 8 == 0 && d->out.cstride % 8 == 0 && d->out.coff % 8 == 0, "yp_conv2d: output slice (C=%d cs=%d co=%d) must be multiples of 8", d->out.C, d->out.cstride, d->out.coff);
     YP_REQUIRE(d->out2.C == 0 || (d->out2.ptr && d->out2.C % 8 == 0 && d->out2.cstride % 8 == 0 && d->out2.coff % 8 == 0 && d->out2.H == d->Ho && d->out2.W == d->Wo && d->res.C == 0), "yp_conv2d: bad second output view");
     YP_REQUIRE(d->res.C == 0 || (d->res.ptr && d->res.C == d->out.C && d->res.cstride % 8 == 0 && d->res.coff % 8 == 0 && !d->out_f32), "yp_conv2d: bad residual view");
-    YP_REQUIRE(d->B > 0 && d->Ho > 0 && d->Wo > 0 && d->R > 0 && d->S > 0 && d->S <= 8 && d->R * d->S <= 64, "yp_conv2d: bad dims (filter up to 8 wide, 64 taps)");
+    YP_REQUIRE(d->B > 0 && d->Ho > 0 && d->Wo > 0 && d->R > 0 && d->S > 0, "yp_conv2d: bad dims");
     YP_REQUIRE(d->in0.ups >= 0 && d->in0.ups <= 1 && d->in1.ups >= 0 && d->in1.ups <= 1, "yp_conv2d: ups must be 0/1");
     YP_REQUIRE((d->in0.H << d->in0.ups) == d->Hi && (d->in0.W << d->in0.ups) == d->Wi, "yp_conv2d: in0 %dx%d<<%d != logical %dx%d", d->in0.H, d->in0.W, d->in0.ups, d->Hi, d->Wi);
     YP_REQUIRE(d->in1.C == 0 || ((d->in1.H << d->in1.ups) == d->Hi && (d->in1.W << d->in1.ups) == d->Wi), "yp_conv2d: in1 dims mismatch");
     YP_REQUIRE(d->out.H == d->Ho && d->out.W == d->Wo, "yp_conv2d: out view dims mismatch");
-    YP_REQUIRE((d->Hi + 2 * d->pad_h - d->R) / d->stride_h + 1 == d->Ho && (d->Wi + 2 * d->pad_w - d->S) / d->stride_w + 1 == d->Wo, "yp_conv2d: Ho/Wo inconsistent with input, filter, stride, pad");
+    const int dil_h = d->dil_h > 0 ? d->dil_h : 1, dil_w = d->dil_w > 0 ? d->dil_w : 1;
+    {   // the caller may ask for fewer output rows / columns than the full convolution yields (wgrad of a strided conv)
+        const int fullH = (d->Hi + 2 * d->pad_h - dil_h * (d->R - 1) - 1) / d->stride_h + 1;
+        const int fullW = (d->Wi + 2 * d->pad_w - dil_w * (d->S - 1) - 1) / d->stride_w + 1;
+        YP_REQUIRE(d->Ho <= fullH && d->Wo <= fullW && (dil_h > 1 || dil_w > 1 || (d->Ho == fullH && d->Wo == fullW)),
+                   "yp_conv2d: Ho/Wo (%d,%d) inconsistent with input, filter, stride, pad, dilation (%d,%d)", d->Ho, d->Wo, fullH, fullW);
+    }
+    const int ksplit = d->ksplit > 1 ? d->ksplit : 1;
+    YP_REQUIRE(ksplit == 1 || (d->out_f32 && d->act == YP_ACT_NONE && d->res.C == 0 && d->out2.C == 0 && d->bias == nullptr && ksplit <= 4096), "yp_conv2d: split-K needs a plain fp32 accumulation target");
+    YP_REQUIRE(!d->in0_zero_stuffed || d->in0.ups == 1, "yp_conv2d: a zero-stuffed input is addressed through ups = 1");
     const int Kreal = d->R * d->S * Cin;
     YP_REQUIRE(d->Kpad >= Kreal && d->Kpad % (d->dtype == YP_F32 ? 16 : 32) == 0, "yp_conv2d: Kpad %d invalid for K=%d", d->Kpad, Kreal);
     YP_REQUIRE(d->Npad >= Cout, "yp_conv2d: Npad %d < Cout %d", d->Npad, Cout);
@@ -781,6 +807,7 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
     { const int bk = d->dtype == YP_F32 ? 16 : 32; a.dt = bk / Cin; a.dc = bk % Cin; }
     a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w;
     a.act = d->act; a.M = (int)Ml;
+    a.dil_h = dil_h; a.dil_w = dil_w; a.in0_zs = d->in0_zero_stuffed ? 1 : 0; a.ksplit = ksplit; a.atomic_out = ksplit > 1 || d->atomic_accumulate;
 
     int tile = (d->tile >= 1 && d->tile <= 5) ? d->tile : pick_tile(a.M, Cout);
     const TileCfg* tc = nullptr;
@@ -796,7 +823,7 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
     const size_t in0_bytes = (size_t)d->B * d->in0.H * d->in0.W * d->in0.cstride * eb;
     const size_t in1_bytes = d->in1.C ? (size_t)d->B * d->in1.H * d->in1.W * d->in1.cstride * eb : 0;
     const size_t wgt_bytes = (size_t)d->Npad * d->Kpad * eb;
-    const bool fast = d->tail_zero && Cin % bk == 0 && d->in0.C % bk == 0 && in0_bytes < (1ull << 31) && in1_bytes < (1ull << 31) &&
+    const bool fast = d->tail_zero && Cin % bk == 0 && d->in0.C % bk == 0 && dil_h == 1 && dil_w == 1 && d->S <= 8 && d->R * d->S <= 64 && in0_bytes < (1ull << 31) && in1_bytes < (1ull << 31) &&
                       wgt_bytes < (1ull << 31);
     a.in0_zoff = (unsigned)in0_bytes; a.in1_zoff = (unsigned)in1_bytes; a.wgt_zrow = (unsigned)wgt_bytes;
 
@@ -821,7 +848,7 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
     // 3x3 / pad 1 / stride 1|2, single un-upsampled source, 16-bit types, Cin % 32 == 0: LDS halo-reuse kernel
     // (tile ids 10..12 force it with BN = 32/64/128; tile 0 picks BN by the channel count; ids 1..5 force the generic kernel)
     const bool halo_ok = fast && d->dtype != YP_F32 && d->R == 3 && d->S == 3 && d->pad_h == 1 && d->pad_w == 1 &&
-                         d->stride_h == d->stride_w && (d->stride_h == 1 || d->stride_h == 2) && d->in1.C == 0 && d->in0.ups == 0 &&
+                         d->stride_h == d->stride_w && (d->stride_h == 1 || d->stride_h == 2) && d->in1.C == 0 && d->in0.ups == 0 && ksplit == 1 && !d->atomic_accumulate &&
                          in0_bytes + (size_t)d->in0.cstride * eb + 64 < (1ull << 31);
     if (halo_ok && (d->tile == 0 || d->tile >= 10)) {
         int bn = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128);

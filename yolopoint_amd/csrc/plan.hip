@@ -25,13 +25,14 @@ extern "C" int yp_device_count(void) {
     return n;
 }
 
-enum OpKind { OP_CONV = 0, OP_SPPF = 1, OP_L2NORM = 2, OP_DETECT = 3 };
+enum OpKind { OP_CONV = 0, OP_SPPF = 1, OP_L2NORM = 2, OP_DETECT = 3, OP_GENERIC = 4 };
 
 struct PlanOp {
     int kind;
     YpConvDesc conv;
     YpDetectDesc det;
     bool has_det = false;
+    YpOpArgs gen;
     YpView v[4];
     int B, dtype, C, na, no, rows_total, row_offset;
     float stride;
@@ -58,6 +59,7 @@ static int run_op(const PlanOp& op, hipStream_t st) {
             return yp_detect_decode(op.v[0], op.B, op.na, op.no, op.stride, op.anchors, op.x_out, op.z_out, op.rows_total,
                                     op.row_offset, st);
     }
+    if (op.kind == OP_GENERIC) return yp_run_op(&op.gen, st);
     yp_set_error("plan: unknown op kind %d", op.kind);
     return YP_ERR_INVALID;
 }
@@ -134,6 +136,16 @@ extern "C" int yp_plan_add_detect_decode(YpPlan* plan, YpView raw, int B, int na
     op.B = B; op.na = na; op.no = no; op.stride = stride;
     for (int i = 0; i < na * 2; ++i) op.anchors[i] = anchors_px_host[i];
     op.x_out = x_out; op.z_out = z_out; op.rows_total = rows_total; op.row_offset = row_offset;
+    plan->ops.push_back(op);
+    return YP_OK;
+}
+
+extern "C" int yp_plan_add_op(YpPlan* plan, const YpOpArgs* a) {
+    YP_PLAN_MUTABLE(plan);
+    YP_REQUIRE(a != nullptr, "yp_plan_add_op: null args");
+    PlanOp op{};
+    op.kind = OP_GENERIC;
+    op.gen = *a;
     plan->ops.push_back(op);
     return YP_OK;
 }

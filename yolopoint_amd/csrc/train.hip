@@ -1,0 +1,569 @@
+// Training-path kernels around the convolutions: batch-statistics BatchNorm + SiLU forward, their
+// backward, and the small backward pieces of the graph (upsample, SPPF max-pool, descriptor L2 norm,
+// Detect permute).  All HBM-bound row/column passes over NHWC views.
+//
+// Reference semantics: nn.BatchNorm2d(eps=1e-3, momentum=0.03) in train mode (models/common.py:18-29):
+// normalise with the biased batch variance, update running stats with the unbiased one; nn.SiLU;
+// Bottleneck residual add (common.py:88-89).  Backward = what autograd derives for those ops
+// (train.py:245 `accelerator.backward(loss)`).
+#include "yp_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+template <int DT> struct Sc;
+template <> struct Sc<YP_F16> { using t = _Float16; };
+template <> struct Sc<YP_BF16> { using t = __bf16; };
+template <> struct Sc<YP_F32> { using t = float; };
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline int grid_for(size_t n, int block, size_t cap = 256 * 16) {
+    size_t g = (n + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+constexpr int BN_ROWS = 512;     // rows reduced by one workgroup
+
+// load 8 consecutive channels of a row as floats (CE8: two 16-byte loads for f32)
+template <int DT>
+__device__ __forceinline__ void load8(const char* base, size_t elem_off, float (&v)[8]) {
+    using T = typename Sc<DT>::t;
+    if constexpr (DT == YP_F32) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(base + elem_off * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(base + elem_off * 4 + 16);
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    } else {
+        const u32x4 raw = *reinterpret_cast<const u32x4*>(base + elem_off * 2);
+        const T* e = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)e[j];
+    }
+}
+template <int DT>
+__device__ __forceinline__ void store8(char* base, size_t elem_off, const float (&v)[8]) {
+    using T = typename Sc<DT>::t;
+    if constexpr (DT == YP_F32) {
+        *reinterpret_cast<f32x4*>(base + elem_off * 4) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(base + elem_off * 4 + 16) = f32x4{v[4], v[5], v[6], v[7]};
+    } else {
+        u32x4 pk;
+        T* e = reinterpret_cast<T*>(&pk);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = (T)v[j];
+        *reinterpret_cast<u32x4*>(base + elem_off * 2) = pk;
+    }
+}
+
+__device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + expf(-z)); }
+
+// ---------------------------------------------------------------------------------------------
+// Column reductions over the M = B*H*W rows of an NHWC view.  One workgroup owns BN_ROWS rows and all
+// channels: thread = (row lane, 8-channel chunk); partial sums go to part[blk][2][C] (fp32), a second
+// kernel folds the partials in double precision.
+//   MODE 0: (sum x, sum x^2)                       -> batch statistics
+//   MODE 1: (sum dz, sum dz * xhat), dz = dy*act'  -> BatchNorm / SiLU backward
+// ---------------------------------------------------------------------------------------------
+template <int DT, int MODE>
+__global__ __launch_bounds__(256) void col_reduce_kernel(const char* __restrict__ raw, int rcs, int rco, const char* __restrict__ dy,
+                                                         int dcs, int dco, size_t M, int C, const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, int act, float* __restrict__ part) {
+    __shared__ float red[2][256][8];
+    const int chunks = C / 8;
+    const int rlanes = 256 / chunks;            // row lanes per workgroup (chunks <= 256)
+    const int t = threadIdx.x;
+    const int ch = t % chunks, rl = t / chunks;
+    float s0[8], s1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s0[j] = s1[j] = 0.f;
+    if (rl < rlanes) {
+        float mu[8], is[8], ga[8], be[8];
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                mu[j] = mean[ch * 8 + j]; is[j] = invstd[ch * 8 + j];
+                ga[j] = gamma[ch * 8 + j]; be[j] = beta[ch * 8 + j];
+            }
+        }
+        const size_t r0 = (size_t)blockIdx.x * BN_ROWS;
+        const size_t r1 = r0 + BN_ROWS < M ? r0 + BN_ROWS : M;
+        for (size_t r = r0 + rl; r < r1; r += rlanes) {
+            float x[8];
+            load8<DT>(raw, r * rcs + rco + ch * 8, x);
+            if constexpr (MODE == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s0[j] += x[j]; s1[j] += x[j] * x[j]; }
+            } else {
+                float g[8];
+                load8<DT>(dy, r * dcs + dco + ch * 8, g);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = (x[j] - mu[j]) * is[j];
+                    float dz = g[j];
+                    if (act == YP_ACT_SILU) {
+                        const float z = xh * ga[j] + be[j];
+                        const float sg = sigmoidf_(z);
+                        dz *= sg * (1.0f + z * (1.0f - sg));
+                    }
+                    s0[j] += dz; s1[j] += dz * xh;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[0][t][j] = s0[j]; red[1][t][j] = s1[j]; }
+    __syncthreads();
+    if (rl == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float a0 = 0.f, a1 = 0.f;
+            for (int q = 0; q < rlanes; ++q) { a0 += red[0][q * chunks + ch][j]; a1 += red[1][q * chunks + ch][j]; }
+            part[((size_t)blockIdx.x * 2 + 0) * C + ch * 8 + j] = a0;
+            part[((size_t)blockIdx.x * 2 + 1) * C + ch * 8 + j] = a1;
+        }
+    }
+}
+
+// fold partials -> mean / invstd (+ running statistics), or -> dgamma / dbeta
+__global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int nblk, int C, double M, float eps, float momentum,
+                                         float* __restrict__ mean, float* __restrict__ invstd, float* running_mean,
+                                         float* running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int b = 0; b < nblk; ++b) { s += part[((size_t)b * 2) * C + c]; ss += part[((size_t)b * 2 + 1) * C + c]; }
+    const double mu = s / M;
+    double var = ss / M - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)mu;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean != nullptr) {
+        const double unbiased = M > 1.0 ? var * M / (M - 1.0) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    }
+}
+__global__ void pair_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ o0, float* __restrict__ o1,
+                                     int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int b = 0; b < nblk; ++b) { s += part[((size_t)b * 2) * C + c]; ss += part[((size_t)b * 2 + 1) * C + c]; }
+    o0[c] = (accumulate ? o0[c] : 0.f) + (float)s;
+    o1[c] = (accumulate ? o1[c] : 0.f) + (float)ss;
+}
+
+// ---------------------------------------------------------------------------------------------
+// y = act(gamma*(x-mean)*invstd + beta) [+ res]
+// ---------------------------------------------------------------------------------------------
+template <int DT>
+__global__ void bn_apply_kernel(const char* __restrict__ raw, int rcs, int rco, char* __restrict__ out, int ocs, int oco,
+                                const char* __restrict__ res, int scs, int sco, size_t M, int C, const float* __restrict__ mean,
+                                const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                int act) {
+    const int chunks = C / 8;
+    const size_t n = M * chunks;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % chunks);
+        const size_t r = i / chunks;
+        float x[8], y[8];
+        load8<DT>(raw, r * rcs + rco + ch * 8, x);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = ch * 8 + j;
+            float z = (x[j] - mean[c]) * invstd[c] * gamma[c] + beta[c];
+            if (act == YP_ACT_SILU) z = z * sigmoidf_(z);
+            y[j] = z;
+        }
+        if (res != nullptr) {
+            float rr[8];
+            load8<DT>(res, r * scs + sco + ch * 8, rr);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] += rr[j];
+        }
+        store8<DT>(out, r * ocs + oco + ch * 8, y);
+    }
+}
+
+// dx = gamma*invstd*(dz - dbeta/M - xhat*dgamma/M), dz = dy*act'(z)
+template <int DT>
+__global__ void bn_bwd_apply_kernel(const char* __restrict__ raw, int rcs, int rco, const char* __restrict__ dy, int dcs, int dco,
+                                    char* __restrict__ dx, int xcs, int xco, size_t M, int C, const float* __restrict__ mean,
+                                    const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    int act, const float* __restrict__ dgamma, const float* __restrict__ dbeta) {
+    const int chunks = C / 8;
+    const size_t n = M * chunks;
+    const float invM = 1.0f / (float)M;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % chunks);
+        const size_t r = i / chunks;
+        float x[8], g[8], o[8];
+        load8<DT>(raw, r * rcs + rco + ch * 8, x);
+        load8<DT>(dy, r * dcs + dco + ch * 8, g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = ch * 8 + j;
+            const float xh = (x[j] - mean[c]) * invstd[c];
+            float dz = g[j];
+            if (act == YP_ACT_SILU) {
+                const float z = xh * gamma[c] + beta[c];
+                const float sg = sigmoidf_(z);
+                dz *= sg * (1.0f + z * (1.0f - sg));
+            }
+            o[j] = gamma[c] * invstd[c] * (dz - dbeta[c] * invM - xh * dgamma[c] * invM);
+        }
+        store8<DT>(dx, r * xcs + xco + ch * 8, o);
+    }
+}
+
+// out[pix, c] (+)= sum of the 2x2 block of `in` it was upsampled to  (backward of nn.Upsample(2,'nearest'))
+template <int DT>
+__global__ void ups2_bwd_kernel(const char* __restrict__ in, int ics, int ico, char* __restrict__ out, int ocs, int oco, int B, int H,
+                                int W, int C, int accumulate) {
+    const int chunks = C / 8;
+    const size_t n = (size_t)B * H * W * chunks;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % chunks);
+        const size_t pix = i / chunks;
+        const int w = (int)(pix % W), h = (int)((pix / W) % H);
+        const size_t b = pix / ((size_t)W * H);
+        float acc[8];
+        if (accumulate) load8<DT>(out, pix * ocs + oco + ch * 8, acc);
+        else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        }
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                float v[8];
+                load8<DT>(in, ((b * 2 * H + 2 * h + dy) * 2 * W + 2 * w + dx) * ics + ico + ch * 8, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += v[j];
+            }
+        store8<DT>(out, pix * ocs + oco + ch * 8, acc);
+    }
+}
+
+// dst (+)= src elementwise over an NHWC view (gradient fan-in of a tensor with several consumers)
+template <int DT>
+__global__ void add_views_kernel(const char* __restrict__ src, int scs, int sco, char* __restrict__ dst, int dcs, int dco, size_t M,
+                                 int C, int accumulate) {
+    const int chunks = C / 8;
+    const size_t n = M * chunks;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % chunks);
+        const size_t r = i / chunks;
+        float a[8];
+        load8<DT>(src, r * scs + sco + ch * 8, a);
+        if (accumulate) {
+            float d[8];
+            load8<DT>(dst, r * dcs + dco + ch * 8, d);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += d[j];
+        }
+        store8<DT>(dst, r * dcs + dco + ch * 8, a);
+    }
+}
+
+// backward of MaxPool2d(5,1,2): the gradient of each output pixel goes to the first maximum of its window
+// (row-major scan, like ATen's CPU kernel); dx is accumulated per input pixel by gathering: an input pixel
+// collects dy of every output whose window argmax is that pixel.  One thread per (input pixel, channel).
+template <int DT>
+__global__ void maxpool5_bwd_kernel(const char* __restrict__ x, int xcs, int xco, const char* __restrict__ dy, int dcs, int dco,
+                                    char* __restrict__ dx, int gcs, int gco, int B, int H, int W, int C, int accumulate) {
+    using T = typename Sc<DT>::t;
+    const size_t n = (size_t)B * H * W * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const size_t pix = i / C;
+        const int w = (int)(pix % W), h = (int)((pix / W) % H);
+        const size_t b = pix / ((size_t)W * H);
+        const T* xb = reinterpret_cast<const T*>(x) + (b * H * W) * xcs + xco + c;
+        const T* gb = reinterpret_cast<const T*>(dy) + (b * H * W) * dcs + dco + c;
+        float acc = 0.f;
+        // outputs (oh, ow) whose 5x5 window contains (h, w)
+        for (int oh = max(h - 2, 0); oh <= min(h + 2, H - 1); ++oh)
+            for (int ow = max(w - 2, 0); ow <= min(w + 2, W - 1); ++ow) {
+                // argmax of the window of (oh, ow): first maximum in row-major order
+                float best = -3.0e38f;
+                int bh = -1, bw = -1;
+                for (int yy = max(oh - 2, 0); yy <= min(oh + 2, H - 1); ++yy)
+                    for (int xx = max(ow - 2, 0); xx <= min(ow + 2, W - 1); ++xx) {
+                        const float v = (float)xb[((size_t)yy * W + xx) * xcs];
+                        if (v > best) { best = v; bh = yy; bw = xx; }
+                    }
+                if (bh == h && bw == w) acc += (float)gb[((size_t)oh * W + ow) * dcs];
+            }
+        T* o = reinterpret_cast<T*>(dx) + pix * gcs + gco + c;
+        *o = (T)((accumulate ? (float)*o : 0.f) + acc);
+    }
+}
+
+// descriptor L2-norm backward: d = x/|x|  ->  dx = (g - d*(d.g)) / |x|   (fp32 views, one wave per pixel)
+__global__ void l2norm_bwd_kernel(const float* __restrict__ x, int xcs, int xco, const float* __restrict__ g, int gcs, int gco,
+                                  float* __restrict__ dx, int dcs, int dco, size_t npix, int C) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t p = wave; p < npix; p += nwaves) {
+        const float* xs = x + p * xcs + xco;
+        const float* gs = g + p * gcs + gco;
+        float ss = 0.f, dg = 0.f;
+        for (int c = lane; c < C; c += 64) { const float v = xs[c]; ss += v * v; dg += v * gs[c]; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { ss += __shfl_xor(ss, o, 64); dg += __shfl_xor(dg, o, 64); }
+        const float nrm = sqrtf(ss);
+        const float k = dg / (nrm * nrm * nrm);
+        float* ds = dx + p * dcs + dco;
+        for (int c = lane; c < C; c += 64) ds[c] = gs[c] / nrm - xs[c] * k;
+    }
+}
+
+// fp32 [B,na,ny,nx,no] gradient of the permuted Detect output -> NHWC view [B,ny,nx,na*no (+pad)] in dtype
+template <int DT>
+__global__ void detect_bwd_pack_kernel(const float* __restrict__ gx, int B, int na, int no, int ny, int nx,
+                                       typename Sc<DT>::t* __restrict__ out, int cs, int co, int Cpad) {
+    using T = typename Sc<DT>::t;
+    const size_t n = (size_t)B * ny * nx * Cpad;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cpad);
+        const size_t pix = i / Cpad;
+        const size_t hw = (size_t)ny * nx;
+        const size_t b = pix / hw, rem = pix - b * hw;
+        float v = 0.f;
+        if (c < na * no) {
+            const int a = c / no, o = c - a * no;
+            v = gx[((b * na + a) * hw + rem) * no + o];
+        }
+        out[pix * cs + co + c] = (T)v;
+    }
+}
+
+// NHWC view (optionally read through the 2x nearest upsample) -> channel-major, batch-minor copy
+// out[c][h][w][b] (b padded with zeros to Bpad): the operand layout of "wgrad as a convolution", where
+// the channel axis becomes the batch and the batch becomes the (contiguous) channel axis.
+template <int DT>
+__global__ void to_chwb_kernel(const typename Sc<DT>::t* __restrict__ in, int cs, int co, int ups, int B, int H, int W, int C,
+                               typename Sc<DT>::t* __restrict__ out, int Bpad) {
+    using T = typename Sc<DT>::t;
+    const int Hp = H >> ups, Wp = W >> ups;
+    const size_t n = (size_t)C * H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);                       // consecutive threads: consecutive channels of one pixel
+        const size_t pix = i / C;
+        const int w = (int)(pix % W), h = (int)(pix / W);
+        T* o = out + (((size_t)c * H + h) * W + w) * Bpad;
+        for (int b = 0; b < Bpad; ++b) {
+            T v = (T)0.f;
+            if (b < B) v = in[(((size_t)b * Hp + (h >> ups)) * Wp + (w >> ups)) * cs + co + c];
+            o[b] = v;
+        }
+    }
+}
+
+// fp32 NHWC view -> dtype NHWC view (gradient hand-over from the fp32 head outputs to the 16-bit conv operands)
+template <int DT>
+__global__ void cast_from_f32_kernel(const float* __restrict__ in, int ics, int ico, char* __restrict__ out, int ocs, int oco, size_t M, int C) {
+    const int chunks = C / 8;
+    const size_t n = M * chunks;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % chunks);
+        const size_t r = i / chunks;
+        float v[8];
+        load8<YP_F32>(reinterpret_cast<const char*>(in), r * ics + ico + ch * 8, v);
+        store8<DT>(out, r * ocs + oco + ch * 8, v);
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+#define YP_DT_SWITCH(dtype, CALL)                                             \
+    switch (dtype) {                                                          \
+        case YP_F16: { constexpr int DT = YP_F16; CALL; } break;              \
+        case YP_BF16: { constexpr int DT = YP_BF16; CALL; } break;            \
+        case YP_F32: { constexpr int DT = YP_F32; CALL; } break;              \
+        default: YP_REQUIRE(false, "bad dtype %d", dtype);                    \
+    }
+
+static int check_view8(const YpView& v, const char* what) {
+    YP_REQUIRE(v.ptr && v.C > 0 && v.C % 8 == 0 && v.cstride % 8 == 0 && v.coff % 8 == 0, "%s: view must be 8-channel aligned", what);
+    return YP_OK;
+}
+
+extern "C" size_t yp_bn_workspace_bytes(int B, int H, int W, int C) {
+    const size_t M = (size_t)B * H * W;
+    return align_up(((M + BN_ROWS - 1) / BN_ROWS) * 2 * (size_t)C * sizeof(float), 256);
+}
+
+extern "C" int yp_bn_stats(YpView raw, int dtype, int B, float eps, float momentum, float* mean, float* invstd, float* running_mean,
+                           float* running_var, void* ws, size_t ws_bytes, void* stream) {
+    if (int rc = check_view8(raw, "yp_bn_stats")) return rc;
+    YP_REQUIRE(mean && invstd && ws && B > 0 && raw.C <= 2048, "yp_bn_stats: bad arguments");
+    YP_REQUIRE(ws_bytes >= yp_bn_workspace_bytes(B, raw.H, raw.W, raw.C), "yp_bn_stats: workspace too small");
+    const size_t M = (size_t)B * raw.H * raw.W;
+    const int nblk = (int)((M + BN_ROWS - 1) / BN_ROWS);
+    hipStream_t st = (hipStream_t)stream;
+    YP_DT_SWITCH(dtype, (col_reduce_kernel<DT, 0><<<nblk, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, nullptr, 0, 0, M, raw.C,
+                                                                        nullptr, nullptr, nullptr, nullptr, 0, (float*)ws)));
+    bn_stats_finalize_kernel<<<yp_cdiv(raw.C, 64), 64, 0, st>>>((const float*)ws, nblk, raw.C, (double)M, eps, momentum, mean, invstd,
+                                                               running_mean, running_var);
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
+extern "C" int yp_bn_act_apply(YpView raw, YpView out, YpView res, int dtype, int B, const float* mean, const float* invstd,
+                               const float* gamma, const float* beta, int act, void* stream) {
+    if (int rc = check_view8(raw, "yp_bn_act_apply")) return rc;
+    if (int rc = check_view8(out, "yp_bn_act_apply")) return rc;
+    YP_REQUIRE(out.C == raw.C && (res.C == 0 || res.C == raw.C) && mean && invstd && gamma && beta, "yp_bn_act_apply: bad arguments");
+    const size_t M = (size_t)B * raw.H * raw.W;
+    hipStream_t st = (hipStream_t)stream;
+    const int g = grid_for(M * (raw.C / 8), 256);
+    YP_DT_SWITCH(dtype, (bn_apply_kernel<DT><<<g, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, (char*)out.ptr, out.cstride, out.coff,
+                                                                res.C ? (const char*)res.ptr : nullptr, res.cstride, res.coff, M, raw.C, mean,
+                                                                invstd, gamma, beta, act)));
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
+extern "C" int yp_bn_act_bwd(YpView raw, YpView dy, YpView dx, int dtype, int B, const float* mean, const float* invstd,
+                             const float* gamma, const float* beta, int act, float* dgamma, float* dbeta, int accumulate_param_grads,
+                             void* ws, size_t ws_bytes, void* stream) {
+    if (int rc = check_view8(raw, "yp_bn_act_bwd")) return rc;
+    if (int rc = check_view8(dy, "yp_bn_act_bwd")) return rc;
+    if (int rc = check_view8(dx, "yp_bn_act_bwd")) return rc;
+    YP_REQUIRE(dy.C == raw.C && dx.C == raw.C && mean && invstd && gamma && beta && dgamma && dbeta && ws && raw.C <= 2048, "yp_bn_act_bwd: bad arguments");
+    YP_REQUIRE(ws_bytes >= yp_bn_workspace_bytes(B, raw.H, raw.W, raw.C) + 2 * (size_t)raw.C * 4, "yp_bn_act_bwd: workspace too small");
+    const size_t M = (size_t)B * raw.H * raw.W;
+    const int nblk = (int)((M + BN_ROWS - 1) / BN_ROWS);
+    hipStream_t st = (hipStream_t)stream;
+    // this call's own sums live at the end of the workspace (the parameter gradients may be accumulated)
+    float* dg = (float*)((char*)ws + yp_bn_workspace_bytes(B, raw.H, raw.W, raw.C));
+    float* db = dg + raw.C;
+    YP_DT_SWITCH(dtype, (col_reduce_kernel<DT, 1><<<nblk, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, (const char*)dy.ptr, dy.cstride,
+                                                                        dy.coff, M, raw.C, mean, invstd, gamma, beta, act, (float*)ws)));
+    pair_finalize_kernel<<<yp_cdiv(raw.C, 64), 64, 0, st>>>((const float*)ws, nblk, raw.C, db, dg, 0);      // (sum dz, sum dz*xhat)
+    const int g = grid_for(M * (raw.C / 8), 256);
+    YP_DT_SWITCH(dtype, (bn_bwd_apply_kernel<DT><<<g, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, (const char*)dy.ptr, dy.cstride, dy.coff,
+                                                                    (char*)dx.ptr, dx.cstride, dx.coff, M, raw.C, mean, invstd, gamma, beta, act, dg, db)));
+    // parameter gradients: dbeta = sum dz, dgamma = sum dz*xhat
+    pair_finalize_kernel<<<yp_cdiv(raw.C, 64), 64, 0, st>>>((const float*)ws, nblk, raw.C, dbeta, dgamma, accumulate_param_grads);
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
+extern "C" int yp_ups2_bwd(YpView in, YpView out, int dtype, int B, int accumulate, void* stream) {
+    if (int rc = check_view8(in, "yp_ups2_bwd")) return rc;
+    if (int rc = check_view8(out, "yp_ups2_bwd")) return rc;
+    YP_REQUIRE(in.C == out.C && in.H == 2 * out.H && in.W == 2 * out.W, "yp_ups2_bwd: dims mismatch");
+    const size_t n = (size_t)B * out.H * out.W * (out.C / 8);
+    YP_DT_SWITCH(dtype, (ups2_bwd_kernel<DT><<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>((const char*)in.ptr, in.cstride, in.coff, (char*)out.ptr,
+                                                                                               out.cstride, out.coff, B, out.H, out.W, out.C, accumulate)));
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
+extern "C" int yp_add_views(YpView src, YpView dst, int dtype, int B, int accumulate, void* stream) {
+    if (int rc = check_view8(src, "yp_add_views")) return rc;
+    if (int rc = check_view8(dst, "yp_add_views")) return rc;
+    YP_REQUIRE(src.C == dst.C && src.H == dst.H && src.W == dst.W, "yp_add_views: dims mismatch");
+    const size_t M = (size_t)B * src.H * src.W;
+    YP_DT_SWITCH(dtype, (add_views_kernel<DT><<<grid_for(M * (src.C / 8), 256), 256, 0, (hipStream_t)stream>>>((const char*)src.ptr, src.cstride, src.coff,
+                                                                                                              (char*)dst.ptr, dst.cstride, dst.coff, M, src.C, accumulate)));
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
+extern "C" int yp_maxpool5_bwd(YpView x, YpView dy, YpView dx, int dtype, int B, int accumulate, void* stream) {
+    YP_REQUIRE(x.ptr && dy.ptr && dx.ptr && x.C == dy.C && x.C == dx.C && x.H == dy.H && x.H == dx.H && x.W == dy.W, "yp_maxpool5_bwd: bad views");
+    const size_t n = (size_t)B * x.H * x.W * x.C;
+    YP_DT_SWITCH(dtype, (maxpool5_bwd_kernel<DT><<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>((const char*)x.ptr, x.cstride, x.coff, (const char*)dy.ptr,
+                                                                                                   dy.cstride, dy.coff, (char*)dx.ptr, dx.cstride, dx.coff, B, x.H,
+                                                                                                   x.W, x.C, accumulate)));
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
+extern "C" int yp_l2norm_bwd_f32(YpView x, YpView g, YpView dx, int B, int C, void* stream) {
+    YP_REQUIRE(x.ptr && g.ptr && dx.ptr && C > 0 && C <= x.C && C <= g.C && C <= dx.C && x.H == g.H && x.W == g.W, "yp_l2norm_bwd_f32: bad views");
+    const size_t npix = (size_t)B * x.H * x.W;
+    l2norm_bwd_kernel<<<grid_for(npix * 64, 256), 256, 0, (hipStream_t)stream>>>((const float*)x.ptr, x.cstride, x.coff, (const float*)g.ptr, g.cstride, g.coff,
+                                                                                  (float*)dx.ptr, dx.cstride, dx.coff, npix, C);
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
+extern "C" int yp_detect_bwd_pack(const float* gx, int B, int na, int no, YpView out, int dtype, void* stream) {
+    YP_REQUIRE(gx && out.ptr && B > 0 && na > 0 && no > 0 && out.C >= na * no, "yp_detect_bwd_pack: bad arguments");
+    const size_t n = (size_t)B * out.H * out.W * out.C;
+    YP_DT_SWITCH(dtype, (detect_bwd_pack_kernel<DT><<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(gx, B, na, no, out.H, out.W,
+                                                                                                      (typename Sc<DT>::t*)out.ptr, out.cstride, out.coff, out.C)));
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
+extern "C" int yp_to_chwb(YpView in, int dtype, int B, int C, void* out, int Bpad, void* stream) {
+    YP_REQUIRE(in.ptr && out && B > 0 && C > 0 && C <= in.C && Bpad >= B, "yp_to_chwb: bad arguments");
+    const int H = in.H << in.ups, W = in.W << in.ups;
+    const size_t n = (size_t)C * H * W;
+    YP_DT_SWITCH(dtype, (to_chwb_kernel<DT><<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>((const typename Sc<DT>::t*)in.ptr, in.cstride, in.coff, in.ups, B, H, W, C,
+                                                                                              (typename Sc<DT>::t*)out, Bpad)));
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
+extern "C" int yp_col_sum(YpView v, int dtype, int B, float* out, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    if (int rc = check_view8(v, "yp_col_sum")) return rc;
+    YP_REQUIRE(out && ws && v.C <= 2048 && ws_bytes >= yp_bn_workspace_bytes(B, v.H, v.W, v.C) + (size_t)v.C * 4, "yp_col_sum: bad arguments / workspace");
+    const size_t M = (size_t)B * v.H * v.W;
+    const int nblk = (int)((M + BN_ROWS - 1) / BN_ROWS);
+    hipStream_t st = (hipStream_t)stream;
+    float* scratch = (float*)((char*)ws + yp_bn_workspace_bytes(B, v.H, v.W, v.C));      // receives the sum of squares (unused)
+    YP_DT_SWITCH(dtype, (col_reduce_kernel<DT, 0><<<nblk, 256, 0, st>>>((const char*)v.ptr, v.cstride, v.coff, nullptr, 0, 0, M, v.C, nullptr, nullptr,
+                                                                        nullptr, nullptr, 0, (float*)ws)));
+    // pair_finalize accumulates both outputs or neither; the sum of squares goes to scratch either way
+    if (accumulate) YP_CHECK_HIP(hipMemsetAsync(scratch, 0, (size_t)v.C * 4, st));
+    pair_finalize_kernel<<<yp_cdiv(v.C, 64), 64, 0, st>>>((const float*)ws, nblk, v.C, out, scratch, accumulate);
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
+extern "C" int yp_cast_from_f32(YpView in, YpView out, int dtype, int B, void* stream) {
+    if (int rc = check_view8(in, "yp_cast_from_f32")) return rc;
+    if (int rc = check_view8(out, "yp_cast_from_f32")) return rc;
+    YP_REQUIRE(in.C == out.C && in.H == out.H && in.W == out.W, "yp_cast_from_f32: dims mismatch");
+    const size_t M = (size_t)B * in.H * in.W;
+    YP_DT_SWITCH(dtype, (cast_from_f32_kernel<DT><<<grid_for(M * (in.C / 8), 256), 256, 0, (hipStream_t)stream>>>((const float*)in.ptr, in.cstride, in.coff,
+                                                                                                                 (char*)out.ptr, out.cstride, out.coff, M, in.C)));
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
+extern "C" int yp_run_op(const YpOpArgs* a, void* stream) {
+    YP_REQUIRE(a != nullptr, "yp_run_op: null args");
+    const int dt = a->i[0], B = a->i[1];
+    switch (a->op) {
+        case YP_OP_BN_STATS: return yp_bn_stats(a->v[0], dt, B, a->s[0], a->s[1], a->g[0], a->g[1], a->g[2], a->g[3], a->p[0], a->n[0], stream);
+        case YP_OP_BN_APPLY: return yp_bn_act_apply(a->v[0], a->v[1], a->v[2], dt, B, a->f[0], a->f[1], a->f[2], a->f[3], a->i[2], stream);
+        case YP_OP_BN_BWD: return yp_bn_act_bwd(a->v[0], a->v[1], a->v[2], dt, B, a->f[0], a->f[1], a->f[2], a->f[3], a->i[2], a->g[0], a->g[1], a->i[3], a->p[0], a->n[0], stream);
+        case YP_OP_UPS2_BWD: return yp_ups2_bwd(a->v[0], a->v[1], dt, B, a->i[2], stream);
+        case YP_OP_ADD_VIEWS: return yp_add_views(a->v[0], a->v[1], dt, B, a->i[2], stream);
+        case YP_OP_MAXPOOL5_BWD: return yp_maxpool5_bwd(a->v[0], a->v[1], a->v[2], dt, B, a->i[2], stream);
+        case YP_OP_L2NORM_BWD: return yp_l2norm_bwd_f32(a->v[0], a->v[1], a->v[2], B, a->i[2], stream);
+        case YP_OP_DETECT_BWD_PACK: return yp_detect_bwd_pack(a->f[0], B, a->i[2], a->i[3], a->v[0], dt, stream);
+        case YP_OP_TO_CHWB: return yp_to_chwb(a->v[0], dt, B, a->i[2], a->p[0], a->i[3], stream);
+        case YP_OP_COL_SUM: return yp_col_sum(a->v[0], dt, B, a->g[0], a->i[2], a->p[0], a->n[0], stream);
+        case YP_OP_MEMSET0: YP_CHECK_HIP(hipMemsetAsync(a->p[0], 0, a->n[0], (hipStream_t)stream)); return YP_OK;
+        case YP_OP_PACK_NCHW: return yp_pack_input(a->f[0], B, a->i[2], a->v[0].H, a->v[0].W, a->v[0], dt, stream);
+        case YP_OP_L2NORM: return yp_l2norm_f32(a->v[0], a->v[1], B, a->i[2], stream);
+        case YP_OP_SPPF_POOL: return yp_sppf_pool(a->v[0], a->v[1], a->v[2], a->v[3], B, dt, stream);
+        case YP_OP_CAST_F32: return yp_cast_from_f32(a->v[0], a->v[1], dt, B, stream);
+    }
+    yp_set_error("yp_run_op: unknown opcode %d", a->op);
+    return YP_ERR_INVALID;
+}

@@ -137,11 +137,31 @@ class YOLOPoint(HipModule):
             cache[key] = (plan, img, outs)
         return cache[key]
 
+    def _train_graph(self, x):
+        """A free TrainGraph (static forward + backward plans and all their buffers) for this input shape.  The two
+        forwards of one training step (image, warped image: reference train.py:208,220) get two graphs."""
+        from ..training import TrainGraph
+        code = _hip.dtype_code(self.compute_dtype)
+        key = (tuple(x.shape), code, x.device.index, tuple(p.data_ptr() for p in self.parameters()))
+        pool = self.__dict__.setdefault("_train_graphs", {})
+        graphs = pool.setdefault(key, [])
+        for g in graphs:
+            if not g.busy:
+                return g
+        if len(graphs) >= 4:
+            raise _hip.YpError("more than 4 un-backpropagated train-mode forwards in flight for one input shape")
+        g = TrainGraph(self, x.shape[0], x.shape[2], x.shape[3], code, x.device)
+        graphs.append(g)
+        return g
+
     def forward(self, x):
         if not (isinstance(x, torch.Tensor) and x.is_cuda):
             raise _hip.YpError("YOLOPoint.forward needs a cuda (HIP) tensor: the hot path has no CPU fallback")
         if self.training:
-            raise _hip.YpError("train-mode (batch-statistics) forward is not part of this build yet; call .eval()")
+            if any(not hasattr(m, "bn") for m in self.modules() if isinstance(m, Conv)):
+                raise _hip.YpError("a fused model (Model.fuse()) cannot run in train mode")
+            from ..training import train_forward
+            return train_forward(self, x.contiguous().float())
         x = x.contiguous().float()
         B, C_, H, W = x.shape
         if C_ > 4:

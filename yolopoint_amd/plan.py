@@ -13,7 +13,7 @@ import math
 import torch
 
 from . import _hip
-from ._hip import YpView, YpConvDesc, YpDetectDesc, check, lib
+from ._hip import YpView, YpConvDesc, YpDetectDesc, YpOpArgs, check, lib
 
 
 def round_up(v, m):
@@ -132,6 +132,7 @@ class PlanBuilder:
         self.keep = []          # tensors the native plan points into
         self.records = []       # per-op algorithmic work (for roofline accounting)
         self.accesses = []      # per-op (reads, writes) as (buffer key, lo, hi) ranges, for the graph schedule
+        self.refreshers = []    # callables that re-pack weights from their (changing) sources: training plans
         self.scope = []
 
     # -- naming -------------------------------------------------------------------------
@@ -177,34 +178,61 @@ class PlanBuilder:
         return deps
 
     # -- ops ----------------------------------------------------------------------------
-    def conv(self, srcs, w, bias, k, s, p, act, out=None, res=None, out_f32=False, tile=0, out2=None, detect=None):
-        """srcs: one or two Views (channel-concatenated); w: OIHW fp32 tensor (BN already folded)."""
+    def conv(self, srcs, w, bias, k, s, p, act, out=None, res=None, out_f32=False, tile=0, out2=None, detect=None, extra=None):
+        """srcs: one or two Views (channel-concatenated); w: OIHW fp32 tensor (BN already folded), or a callable
+        returning (w, bias) — then the packed copy is re-derived by refresh() before every training step.
+        k/s/p: square kernel, stride, padding.  extra: raw descriptor overrides used by dgrad / wgrad:
+          out_hw=(Ho,Wo), dil=int, zero_stuffed=bool (in0 read as a zero-stuffed 2x tensor), ksplit=int,
+          kernel_hw=(R,S) for non-square "filters", raw_weight=(tensor [Npad+1][Kpad], Kpad, Npad) to bypass packing."""
         if isinstance(srcs, View):
             srcs = [srcs]
         assert 1 <= len(srcs) <= 2
-        Cout, Cin, R, S = w.shape
+        extra = extra or {}
+        w_fn = None
+        if callable(w):
+            w_fn = w
+            w, bias = w_fn()
+        raw_weight = extra.get("raw_weight")
+        if raw_weight is not None:
+            Cout, Cin = extra["cout"], sum(v.C for v in srcs)
+            R, S = extra["kernel_hw"]
+        else:
+            Cout, Cin, R, S = w.shape
         sh = sw = s
         ph = pw = p
+        dil = extra.get("dil", 1)
         v0 = srcs[0]
+        zs = bool(extra.get("zero_stuffed", False))
+        if zs:
+            v0 = v0.up()
+            srcs = [v0] + list(srcs[1:])
         Hi, Wi = v0.LH, v0.LW
-        Ho = (Hi + 2 * ph - R) // sh + 1
-        Wo = (Wi + 2 * pw - S) // sw + 1
-        thin = len(srcs) == 1 and v0.C == 4 and v0.cstride == 4 and Cin <= 4
-        if thin:
-            # image-like input padded to 4 channels (the 6x6/s2/p2 stem, models/YOLOPoint.py:156)
-            wpad = torch.zeros((Cout, 4, R, S), dtype=torch.float32, device=w.device)
-            wpad[:, :Cin] = w
-            w = wpad
-            if self.ce == 8:
-                # 16-bit: pair adjacent pixels -> view [H, W/2, 8]; taps pair up along s
-                if S % 2 or sw % 2 or pw % 2 or Wi % 2:
-                    raise _hip.YpError("thin-input conv needs even kernel width / stride / pad for 16-bit dtypes")
-                w = w.permute(0, 2, 3, 1).reshape(Cout, R, S // 2, 8).permute(0, 3, 1, 2).contiguous()
-                v0 = View(v0.buf, 0, 8, 0, geom=(v0.H, v0.W // 2, 8))
-                srcs = [v0]
-                S, sw, pw, Wi = S // 2, sw // 2, pw // 2, Wi // 2
-        else:
+        Ho = (Hi + 2 * ph - dil * (R - 1) - 1) // sh + 1
+        Wo = (Wi + 2 * pw - dil * (S - 1) - 1) // sw + 1
+        if "out_hw" in extra:
+            Ho, Wo = extra["out_hw"]
+        thin = raw_weight is None and len(srcs) == 1 and v0.C == 4 and v0.cstride == 4 and Cin <= 4
+        pair = thin and self.ce == 8
+        if pair:
+            # 16-bit stem (6x6/s2/p2, models/YOLOPoint.py:156): pair adjacent pixels -> view [H, W/2, 8]; taps pair up along s
+            if S % 2 or sw % 2 or pw % 2 or Wi % 2:
+                raise _hip.YpError("thin-input conv needs even kernel width / stride / pad for 16-bit dtypes")
+            v0 = View(v0.buf, 0, 8, 0, geom=(v0.H, v0.W // 2, 8))
+            srcs = [v0]
+            S, sw, pw, Wi = S // 2, sw // 2, pw // 2, Wi // 2
+        elif not thin:
             assert sum(v.C for v in srcs) == Cin, (self.name(), [v.C for v in srcs], Cin)
+
+        def prep(w_, b_):
+            """master OIHW weights -> packed device copy (image-like inputs: pad to 4 channels, pair pixels)."""
+            if thin:
+                wpad = torch.zeros((w_.shape[0], 4, w_.shape[2], w_.shape[3]), dtype=torch.float32, device=w_.device)
+                wpad[:, :w_.shape[1]] = w_
+                w_ = wpad
+                if pair:
+                    w_ = w_.permute(0, 2, 3, 1).reshape(w_.shape[0], w_.shape[2], w_.shape[3] // 2, 8).permute(0, 3, 1, 2).contiguous()
+            return pack_conv_weight(w_, b_, self.code, self.device)
+
         Cout_pad = round_up(Cout, 8)
         if detect is not None:
             # fused Detect decode: the conv writes x_out / z directly, `out` only carries the geometry
@@ -215,8 +243,20 @@ class PlanBuilder:
             out = self.new_buf(Ho, Wo, Cout_pad, f32=out_f32).view()
         c2 = out2.C if out2 is not None else 0      # channels [out.C, out.C + c2) are written to out2
         assert out.C + c2 == Cout_pad and out.H == Ho and out.W == Wo, (self.name(), out.C, c2, Cout_pad, out.H, Ho)
-        wp, bp, Kpad, Npad = pack_conv_weight(w, bias, self.code, self.device)
-        self.keep += [wp, bp]
+        if raw_weight is not None:
+            wp, Kpad, Npad = raw_weight
+            bp = None
+            self.keep += [wp]
+        else:
+            wp, bp, Kpad, Npad = prep(w, bias)
+            self.keep += [wp, bp]
+            if w_fn is not None:
+                def refresh(wp=wp, bp=bp, w_fn=w_fn, prep=prep):
+                    w2, b2 = w_fn()
+                    nw, nb, _, _ = prep(w2, b2)
+                    wp.copy_(nw)
+                    bp.copy_(nb)
+                self.refreshers.append(refresh)
         d = YpConvDesc()
         d.in0 = v0.c()
         d.in1 = srcs[1].c() if len(srcs) == 2 else NULL_VIEW
@@ -224,10 +264,14 @@ class PlanBuilder:
         d.res = res.c() if res is not None else NULL_VIEW
         d.out2 = out2.c() if out2 is not None else NULL_VIEW
         d.weight = wp.data_ptr()
-        d.bias = bp.data_ptr() if bias is not None else None
-        d.dtype, d.out_f32, d.B = self.code, int(out_f32), self.B
+        d.bias = bp.data_ptr() if (bias is not None and bp is not None) else None
+        d.dtype, d.out_f32, d.B = self.code, int(out_f32), extra.get("batch", self.B)
         d.Hi, d.Wi, d.Ho, d.Wo = Hi, Wi, Ho, Wo
         d.R, d.S, d.stride_h, d.stride_w, d.pad_h, d.pad_w = R, S, sh, sw, ph, pw
+        d.dil_h = d.dil_w = dil
+        d.in0_zero_stuffed = int(zs)
+        d.ksplit = int(extra.get("ksplit", 1))
+        d.atomic_accumulate = int(extra.get("atomic", 0))
         d.Kpad, d.Npad, d.act, d.tile, d.tail_zero = Kpad, Npad, act, tile, 1
         det = None
         if detect is not None:
@@ -238,8 +282,8 @@ class PlanBuilder:
             det.x_out = detect["x_out"].data_ptr()
             det.z_out = detect["z_out"].data_ptr() if detect["z_out"] is not None else None
             det.rows_total, det.row_offset = detect["rows_total"], detect["row_offset"]
-        if tile == 0 and self.autotune:
-            d.tile = self._autotune(d, det, (self.code, self.B, Hi, Wi, tuple((v.C, v.ups) for v in srcs), Cout_pad, R, S, sh, sw,
+        if tile == 0 and self.autotune and d.ksplit == 1 and not d.atomic_accumulate:
+            d.tile = self._autotune(d, det, (self.code, d.B, Hi, Wi, tuple((v.C, v.ups) for v in srcs), Cout_pad, R, S, sh, sw, dil, zs,
                                              int(out_f32), res is not None, c2, act, detect is not None))
         if det is not None:
             check(lib().yp_plan_add_conv_detect(self.handle, C.byref(d), C.byref(det)))
@@ -248,15 +292,42 @@ class PlanBuilder:
                         ([(detect["z_out"], detect["row_offset"], detect["row_offset"] + rows)] if detect["z_out"] is not None else []))
         else:
             check(lib().yp_plan_add_conv(self.handle, C.byref(d)))
-            self._track(list(srcs) + [res], [out, out2])
+            self._track(list(srcs) + [res] + ([extra["weight_view"]] if "weight_view" in extra else []), [out, out2])
         # algorithmic work: MAC*2 with the REAL channel counts (BASELINE.md section 2 convention)
-        Kreal = w.shape[1] * w.shape[2] * w.shape[3] if not thin else Cin * R * (S * (2 if self.ce == 8 else 1))
-        M = self.B * Ho * Wo
+        Kreal = Cin * R * (S * (2 if pair else 1))
+        if thin:
+            Kreal = (w.shape[1]) * w.shape[2] * w.shape[3]
+        M = d.B * Ho * Wo
         eb = 4 if self.code == _hip.YP_F32 else 2
-        in_elems = self.B * sum((v.H * v.W * v.C) for v in srcs)
+        in_elems = d.B * sum((v.H * v.W * v.C) for v in srcs)
         bytes_ = in_elems * eb + M * Cout * (4 if out_f32 else eb) * (2 if (detect is not None and detect['z_out'] is not None) else 1) + Cout * Kreal * eb
         self.records.append(OpRecord(self.name(), "conv", 2 * M * Cout * Kreal, bytes_, M, Cout, Kreal))
         return out
+
+    def op(self, code, reads, writes, name, **kw):
+        """Append a generic launch record (training-path kernels); kw: v=[Views], f/g/p=[tensors|ptr], n=[sizes], i=[ints], s=[floats]."""
+        a = YpOpArgs()
+        a.op = code
+        for j, v in enumerate(kw.get("v", [])):
+            a.v[j] = v.c() if v is not None else NULL_VIEW
+        for key in ("f", "g", "p"):
+            arr = getattr(a, key)
+            for j, t in enumerate(kw.get(key, [])):
+                arr[j] = (t.data_ptr() if isinstance(t, torch.Tensor) else t) if t is not None else None
+        for j, t in enumerate(kw.get("n", [])):
+            a.n[j] = int(t)
+        for j, t in enumerate(kw.get("i", [])):
+            a.i[j] = int(t)
+        for j, t in enumerate(kw.get("s", [])):
+            a.s[j] = float(t)
+        check(lib().yp_plan_add_op(self.handle, C.byref(a)))
+        self._track(reads, writes)
+        self.records.append(OpRecord(self.name(name), "aux"))
+
+    def refresh(self):
+        """Re-derive every packed weight from its source (call before each training step)."""
+        for fn in self.refreshers:
+            fn()
 
     def _autotune(self, d, det, key):
         """Pick the fastest kernel variant for this convolution by timing each candidate on the plan's own buffers
@@ -328,6 +399,7 @@ class ExecPlan:
         self.handle, self.keep, self.records = pb.handle, pb.keep, pb.records
         self.B, self.code, self.device = pb.B, pb.code, pb.device
         self.deps = pb.deps
+        self.refreshers = pb.refreshers
         self.graph = False
 
     def num_ops(self):
@@ -344,6 +416,10 @@ class ExecPlan:
         torch.cuda.current_stream().wait_stream(s)
         self.graph = True
         self.parallel = bool(lib().yp_plan_graph_is_parallel(self.handle))
+
+    def refresh(self):
+        for fn in self.refreshers:
+            fn()
 
     def run(self, stream=None):
         check(lib().yp_plan_run(self.handle, _hip.stream_ptr(stream)))

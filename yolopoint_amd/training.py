@@ -1,0 +1,356 @@
+"""Training path of the YOLOPoint hot path: train-mode forward (batch-statistics BatchNorm) and the
+backward pass, both as static native plans, exposed to PyTorch autograd through one Function.
+
+Reference: src/train.py:208-252 — `model(img)`, `model(img_warp)`, losses in PyTorch, `backward()`,
+`optimizer.step()`.  The losses stay PyTorch autograd; everything between the input
+image and the three head outputs runs here:
+
+  forward   conv (implicit-GEMM kernels, no bias) -> yp_bn_stats -> yp_bn_act_apply (+ residual)
+  backward  yp_bn_act_bwd -> dgrad = the SAME conv kernels with the flipped / channel-transposed
+            filter (stride 2: zero-stuffed input view) -> wgrad = a convolution too: the layer input and
+            the output gradient are copied batch<->channel transposed ([C][H][W][B], yp_to_chwb); the
+            gradient copy then plays the filter ([Cout][Ho*Wo*B]) of a dilated convolution over the input
+            copy whose k x k "output pixels" are the filter taps; split-K + fp32 atomics fill the chip.
+
+A TrainGraph owns every buffer of one forward/backward pair; two forwards of the same step (image
++ warped image) use two graphs from a small pool.  Packed weights are re-derived from the fp32
+master parameters before every forward (`refresh`).
+"""
+import ctypes as C
+
+import torch
+
+from . import _hip
+from ._hip import lib
+from .plan import PlanBuilder, Buf, View, round_up, pack_input
+
+
+class TrainGraph:
+    def __init__(self, net, B, H, W, code, device):
+        if H % 64 or W % 64:
+            raise _hip.YpError("training needs image sizes that are multiples of 64")
+        self.net, self.B, self.H, self.W, self.code, self.device = net, B, H, W, code, device
+        self.tdtype = _hip.torch_dtype(code)
+        self.fwd = PlanBuilder(B, code, device)
+        self.bwd = PlanBuilder(B, code, device)
+        self.tape = []
+        self.gbufs = {}            # data_ptr of an activation buffer -> its gradient Buf
+        self.gwritten = {}         # data_ptr -> list of written (lo, hi) channel ranges
+        self.collect = []          # callables run after the backward plan: native buffers -> parameter gradients
+        self.pgrads = {}           # parameter -> fp32 gradient tensor (reference layout)
+        self.keep = []
+        self.busy = False
+        wsb = lib().yp_bn_workspace_bytes(B, H // 2, W // 2, 1024) + 8 * 2048 + 4096
+        self.ws = torch.empty(wsb, dtype=torch.uint8, device=device)
+        self.Bpad = round_up(B, 8)
+        self._build()
+
+    # ------------------------------------------------------------------ helpers
+    def pgrad(self, param):
+        if param not in self.pgrads:
+            self.pgrads[param] = torch.zeros_like(param, dtype=torch.float32)
+        return self.pgrads[param]
+
+    def gview(self, v):
+        """Gradient view matching activation view `v` (same slice); returns (view, accumulate?) and marks it written."""
+        key = v.buf.t.data_ptr()
+        if key not in self.gbufs:
+            gb = Buf(v.buf.B, v.buf.H, v.buf.W, v.buf.C, v.buf.t.dtype, self.device)
+            self.gbufs[key] = gb
+            self.keep.append(gb.flat)
+            self.gwritten[key] = []
+        lo, hi = v.coff, v.coff + v.C
+        acc = any(a < hi and lo < b for a, b in self.gwritten[key])
+        self.gwritten[key].append((lo, hi))
+        return View(self.gbufs[key], v.coff, v.C, 0), acc
+
+    def gread(self, v):
+        """Gradient view of `v` for reading (must have been written by the consumers' backward)."""
+        key = v.buf.t.data_ptr()
+        assert key in self.gbufs and any(a <= v.coff and v.coff + v.C <= b for a, b in self._merged(key)), "gradient read before write"
+        return View(self.gbufs[key], v.coff, v.C, 0)
+
+    def _merged(self, key):
+        rs = sorted(self.gwritten[key])
+        out = []
+        for a, b in rs:
+            if out and a <= out[-1][1]:
+                out[-1] = (out[-1][0], max(out[-1][1], b))
+            else:
+                out.append((a, b))
+        return out
+
+    def T(self, t):
+        return (t, 0, 1 << 30)
+
+    # ------------------------------------------------------------------ forward emitters (+ tape)
+    def conv_bn_act(self, m, x, out=None, res=None):
+        srcs = list(x) if isinstance(x, (list, tuple)) else [x]
+        conv, bn = m.conv, m.bn
+        k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        act = _hip.YP_ACT_SILU if isinstance(m.act, torch.nn.SiLU) else _hip.YP_ACT_NONE
+        f, B, code = self.fwd, self.B, self.code
+        raw = f.conv(srcs, lambda: (conv.weight.detach().float(), None), None, k, s, p, _hip.YP_ACT_NONE)
+        Cc = conv.out_channels
+        mean, invstd = f.new_tensor((Cc,)), f.new_tensor((Cc,))
+        f.op(_hip.OP_BN_STATS, [raw], [self.T(mean), self.T(invstd)], "bn_stats", v=[raw], i=[code, B], s=[bn.eps, bn.momentum],
+             g=[mean, invstd, bn.running_mean, bn.running_var], p=[self.ws], n=[self.ws.numel()])
+        if out is None:
+            out = f.new_buf(raw.H, raw.W, raw.C).view()
+        f.op(_hip.OP_BN_APPLY, [raw, res, self.T(mean), self.T(invstd)], [out], "bn_act", v=[raw, out, res], i=[code, B, act],
+             f=[mean, invstd, bn.weight, bn.bias])
+
+        def backward():
+            b = self.bwd
+            gy = self.gread(out)
+            if res is not None:
+                gr, acc = self.gview(res)
+                b.op(_hip.OP_ADD_VIEWS, [gy, gr], [gr], "res_add", v=[gy, gr], i=[code, B, int(acc)])
+            draw = b.new_buf(raw.H, raw.W, raw.C).view()
+            b.op(_hip.OP_BN_BWD, [raw, gy], [draw], "bn_act_bwd", v=[raw, gy, draw], i=[code, B, act, 0],
+                 f=[mean, invstd, bn.weight, bn.bias], g=[self.pgrad(bn.weight), self.pgrad(bn.bias)], p=[self.ws], n=[self.ws.numel()])
+            self.conv_backward(srcs, conv.weight, None, draw, k, s, p)
+        self.tape.append(backward)
+        return out
+
+    def conv_plain(self, weight, bias, x, k, s, p, name):
+        """Head convolution without BN/activation, fp32 output (ConvDet / ConvDesc)."""
+        f = self.fwd
+        out = f.conv([x], lambda: (weight.detach().float(), bias.detach().float() if bias is not None else None), bias, k, s, p,
+                     _hip.YP_ACT_NONE, out_f32=True)
+
+        def backward():
+            b = self.bwd
+            g32 = self.gread(out)                       # fp32 NHWC gradient of the head output
+            if self.code == _hip.YP_F32:
+                draw = g32
+            else:
+                draw = b.new_buf(out.H, out.W, out.C).view()
+                b.op(_hip.OP_CAST_F32, [g32], [draw], "cast", v=[g32, draw], i=[self.code, self.B])
+            self.conv_backward([x], weight, bias, draw, k, s, p)
+        self.tape.append(backward)
+        return out
+
+    def conv_backward(self, srcs, weight, bias, draw, k, s, p):
+        """Emit wgrad (+ bias grad) and dgrad of a convolution whose output gradient is `draw` [B,Ho,Wo,Cout_pad]."""
+        b, B, code, Bpad = self.bwd, self.B, self.code, self.Bpad
+        Cout, Cout_pad = weight.shape[0], draw.C
+        Ho, Wo = draw.H, draw.W
+        K = Ho * Wo * Bpad
+        assert K % 32 == 0, "wgrad needs Ho*Wo*round_up(B,8) to be a multiple of 32"
+        gw = self.pgrad(weight)
+        if bias is not None:
+            gb_full = b.new_tensor((Cout_pad,))
+            b.op(_hip.OP_COL_SUM, [draw], [self.T(gb_full)], "bias_grad", v=[draw], i=[code, B, 0], g=[gb_full], p=[self.ws], n=[self.ws.numel()])
+            gbias = self.pgrad(bias)
+            self.collect.append(lambda: gbias.copy_(gb_full[:Cout]))
+        # ---- wgrad: output gradient as the "filter" [Cout_pad (+1 zero row)][K]
+        dyp = torch.zeros(((Cout_pad + 1) * K,), dtype=self.tdtype, device=self.device)
+        self.keep.append(dyp)
+        b.op(_hip.OP_TO_CHWB, [draw], [self.T(dyp)], "dy_chwb", v=[draw], i=[code, B, Cout_pad, Bpad], p=[dyp])
+        c0 = 0
+        for src in srcs:
+            image = src.geom is None and src.cstride == 4 and src.C == 4
+            Cj = src.C
+            Hi, Wi = src.LH, src.LW
+            xp = Buf(Cj, Hi, Wi, Bpad, self.tdtype, self.device)
+            self.keep.append(xp.flat)
+            b.op(_hip.OP_TO_CHWB, [src], [xp.view()], "x_chwb", v=[src], i=[code, B, Cj, Bpad], p=[xp.t])
+            dwb = Buf(Cj, k, k, Cout_pad, torch.float32, self.device)
+            self.keep.append(dwb.flat)
+            b.op(_hip.OP_MEMSET0, [], [dwb.view()], "zero_dw", p=[dwb.flat], n=[dwb.t.numel() * 4])
+            blocks = -(-(Cj * k * k) // 64) * -(-Cout_pad // 64)
+            nk = K // (16 if code == _hip.YP_F32 else 32)
+            ksplit = max(1, min(-(-1024 // blocks), max(1, nk // 8), 2048))
+            b.conv([xp.view()], None, None, 0, 1, p, _hip.YP_ACT_NONE, out=dwb.view(), out_f32=True,
+                   extra=dict(raw_weight=(dyp, K, Cout_pad), cout=Cout_pad, kernel_hw=(Ho, Wo), dil=s, out_hw=(k, k), ksplit=ksplit,
+                              atomic=1, batch=Cj, weight_view=self.T(dyp)))
+            creal = weight.shape[1] - c0 if image else Cj
+            self.collect.append(lambda dwb=dwb, c0=c0, creal=creal: gw[:, c0:c0 + creal].copy_(dwb.t.permute(3, 0, 1, 2)[:Cout, :creal]))
+            # ---- dgrad (no gradient flows into the image)
+            if not image:
+                cs, ce_ = c0, c0 + Cj
+
+                def w_dgrad(cs=cs, ce_=ce_):
+                    wd = weight.detach().float()[:, cs:ce_].flip(2, 3).permute(1, 0, 2, 3)      # [Cj, Cout, k, k]
+                    if Cout_pad != Cout:
+                        wd = torch.nn.functional.pad(wd, (0, 0, 0, 0, 0, Cout_pad - Cout))
+                    return wd.contiguous(), None
+                base = View(src.buf, src.coff, src.C, 0, src.geom)
+                if src.ups:
+                    tmp = b.new_buf(Hi, Wi, Cj).view()
+                    b.conv([draw], w_dgrad, None, k, 1, k - 1 - p, _hip.YP_ACT_NONE, out=tmp, extra=dict(zero_stuffed=(s == 2)))
+                    gv, acc = self.gview(base)
+                    b.op(_hip.OP_UPS2_BWD, [tmp, gv], [gv], "ups_bwd", v=[tmp, gv], i=[code, B, int(acc)])
+                else:
+                    gv, acc = self.gview(base)
+                    b.conv([draw], w_dgrad, None, k, 1, k - 1 - p, _hip.YP_ACT_NONE, out=gv, res=gv if acc else None,
+                           extra=dict(zero_stuffed=(s == 2)))
+            c0 += Cj
+
+    def bottleneck(self, m, x, out=None):
+        t = self.conv_bn_act(m.cv1, x)
+        return self.conv_bn_act(m.cv2, t, out=out, res=x if m.add else None)
+
+    def c3(self, m, x, out=None):
+        c_ = m.cv1.conv.out_channels
+        x0 = x[0] if isinstance(x, (list, tuple)) else x
+        cat = self.fwd.new_buf(x0.LH, x0.LW, 2 * c_)
+        t = self.conv_bn_act(m.cv1, x)
+        n = len(m.m)
+        for i, blk in enumerate(m.m):
+            t = self.bottleneck(blk, t, out=cat.view(0, c_) if i == n - 1 else None)
+        self.conv_bn_act(m.cv2, x, out=cat.view(c_, c_))
+        return self.conv_bn_act(m.cv3, cat.view(), out=out)
+
+    def sppf(self, m, x):
+        c_ = m.cv1.conv.out_channels
+        f, code, B = self.fwd, self.code, self.B
+        cat = f.new_buf(x.LH, x.LW, 4 * c_)
+        s0, s1, s2, s3 = (cat.view(i * c_, c_) for i in range(4))
+        self.conv_bn_act(m.cv1, x, out=s0)
+        f.op(_hip.OP_SPPF_POOL, [s0], [s1, s2, s3], "pool", v=[s0, s1, s2, s3], i=[code, B])
+
+        def backward():
+            b = self.bwd
+            g0, g1, g2, g3 = (self.gread(v) for v in (s0, s1, s2, s3))
+            b.op(_hip.OP_MAXPOOL5_BWD, [s2, g3, g2], [g2], "pool_bwd3", v=[s2, g3, g2], i=[code, B, 1])
+            b.op(_hip.OP_MAXPOOL5_BWD, [s1, g2, g1], [g1], "pool_bwd2", v=[s1, g2, g1], i=[code, B, 1])
+            b.op(_hip.OP_MAXPOOL5_BWD, [s0, g1, g0], [g0], "pool_bwd1", v=[s0, g1, g0], i=[code, B, 1])
+        self.tape.append(backward)
+        return self.conv_bn_act(m.cv2, cat.view())
+
+    # ------------------------------------------------------------------ the graph
+    def _build(self):
+        net, f, b, B, code = self.net, self.fwd, self.bwd, self.B, self.code
+        Hc, Wc = self.H // 8, self.W // 8
+        self.img = f.new_buf(self.H, self.W, 4)
+        x = self.conv_bn_act(net.Conv1, self.img.view())
+        x = self.conv_bn_act(net.Conv2, x)
+        xa = self.c3(net.Bottleneck1, x)
+        x8 = self.conv_bn_act(net.Conv3, xa)
+        # keypoint head
+        t = self.c3(net.BottleneckDet, x8)
+        semi = self.conv_plain(net.ConvDet.weight, None, t, 1, 1, 0, "ConvDet")
+        self.g_semi = torch.zeros((B, 65, Hc, Wc), dtype=torch.float32, device=self.device)
+        gsemi_v, _ = self.gview(semi)
+
+        def semi_seed():
+            b.op(_hip.OP_PACK_NCHW, [self.T(self.g_semi)], [gsemi_v], "seed_semi", f=[self.g_semi], v=[gsemi_v], i=[_hip.YP_F32, B, 65])
+        xb = self.c3(net.Bottleneck2, x8)
+        # descriptor head
+        dA = self.conv_bn_act(net.ConvDescA, xa)
+        dB = self.conv_bn_act(net.ConvDescB, xb)
+        d = self.c3(net.BottleneckDesc, [dA, dB.up()])
+        craw = self.conv_plain(net.ConvDesc.weight, None, d, 3, 1, 1, "ConvDesc")
+        c3ch = net.ConvDesc.out_channels
+        dnorm = f.new_buf(Hc, Wc, craw.C, f32=True).view()
+        f.op(_hip.OP_L2NORM, [craw], [dnorm], "l2norm", v=[craw, dnorm], i=[0, B, c3ch])
+        self.g_desc = torch.zeros((B, c3ch, Hc, Wc), dtype=torch.float32, device=self.device)
+        gd = Buf(B, Hc, Wc, craw.C, torch.float32, self.device)
+        self.keep.append(gd.flat)
+        gcraw, _ = self.gview(craw)
+
+        def desc_seed():
+            b.op(_hip.OP_PACK_NCHW, [self.T(self.g_desc)], [gd.view()], "seed_desc", f=[self.g_desc], v=[gd.view()], i=[_hip.YP_F32, B, c3ch])
+            b.op(_hip.OP_L2NORM_BWD, [craw, gd.view()], [gcraw], "l2norm_bwd", v=[craw, gd.view(), gcraw], i=[0, B, c3ch])
+        # YOLO encoder + PAN
+        x = self.conv_bn_act(net.Conv4, xb)
+        xc = self.c3(net.Bottleneck3, x)
+        x = self.conv_bn_act(net.Conv5, xc)
+        x = self.c3(net.Bottleneck4, x)
+        x = self.sppf(net.SPPooling, x)
+        xd = self.conv_bn_act(net.Conv6, x)
+        x = self.c3(net.Bottleneck5, [xd.up(), xc])
+        xe = self.conv_bn_act(net.Conv7, x)
+        xf = self.c3(net.Bottleneck6, [xe.up(), xb])
+        x = self.conv_bn_act(net.Conv8, xf)
+        xg = self.c3(net.Bottleneck7, [x, xe])
+        x = self.conv_bn_act(net.Conv9, xg)
+        p5 = self.c3(net.Bottleneck8, [x, xd])
+        # Detect (train mode: permuted raw logits only)
+        det = net.Detect
+        self.xs, self.g_xs = [], []
+        det_seeds = []
+        for i, v in enumerate([xf, xg, p5]):
+            ny, nx = v.LH, v.LW
+            xo = f.new_tensor((B, det.na, ny, nx, det.no))
+            stride = float(det.stride[i])
+            mi = det.m[i]
+            f.conv(v, lambda mi=mi: (mi.weight.detach().float(), mi.bias.detach().float()), mi.bias, 1, 1, 0, _hip.YP_ACT_NONE, out_f32=True,
+                   detect=dict(na=det.na, no=det.no, stride=stride, anchors_px=[0.0] * (2 * det.na), x_out=xo, z_out=None, rows_total=0,
+                               row_offset=0))
+            gx = torch.zeros_like(xo)
+            self.xs.append(xo)
+            self.g_xs.append(gx)
+
+            def det_backward(v=v, mi=mi, gx=gx, ny=ny, nx=nx):
+                draw = b.new_buf(ny, nx, round_up(det.na * det.no, 8)).view()
+                b.op(_hip.OP_DETECT_BWD_PACK, [self.T(gx)], [draw], "seed_det", f=[gx], v=[draw], i=[code, B, det.na, det.no])
+                self.conv_backward([v], mi.weight, mi.bias, draw, 1, 1, 0)
+            det_seeds.append(det_backward)
+        self.semi_v, self.desc_v = semi, dnorm
+        # ---- emit the backward plan: seeds first, then the tape in reverse
+        semi_seed()
+        desc_seed()
+        # Detect backward must run before the PAN blocks' backward (it writes their output gradients)
+        for fn in det_seeds:
+            fn()
+        for fn in reversed(self.tape):
+            fn()
+        self.fwd_plan = f.finish(parallel=False)
+        self.bwd_plan = b.finish(parallel=False)
+        self.params = [p_ for p_ in net.parameters()]
+
+    # ------------------------------------------------------------------ run
+    def forward(self, x):
+        self.fwd_plan.refresh()
+        self.bwd_plan.refresh()
+        pack_input(x, self.img.view(), self.code)
+        self.fwd_plan.run()
+        for m in self.net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d) and m.num_batches_tracked is not None:
+                m.num_batches_tracked += 1
+        c3ch = self.net.ConvDesc.out_channels
+        semi = self.semi_v.buf.t[..., :65].permute(0, 3, 1, 2).clone()
+        desc = self.desc_v.buf.t[..., :c3ch].permute(0, 3, 1, 2).clone()
+        return semi, desc, [t.clone() for t in self.xs]
+
+    def backward(self, g_semi, g_desc, g_xs):
+        for dst, src in [(self.g_semi, g_semi), (self.g_desc, g_desc)] + list(zip(self.g_xs, g_xs)):
+            if src is None:
+                dst.zero_()
+            else:
+                dst.copy_(src)
+        self.bwd_plan.run()
+        for fn in self.collect:
+            fn()
+        return [self.pgrads.get(p_) for p_ in self.params]
+
+
+class _YOLOPointTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, x, *params):
+        g = net._train_graph(x)
+        ctx.graph = g
+        semi, desc, xs = g.forward(x)
+        if torch.is_grad_enabled() or any(p.requires_grad for p in params):
+            g.busy = True
+        return (semi, desc, *xs)
+
+    @staticmethod
+    def backward(ctx, g_semi, g_desc, *g_xs):
+        g = ctx.graph
+        grads = g.backward(g_semi, g_desc, list(g_xs))
+        g.busy = False
+        out = []
+        for p_, gr in zip(g.params, grads):
+            out.append(gr.to(p_.dtype).clone() if (gr is not None and p_.requires_grad) else None)
+        return (None, None, *out)
+
+
+def train_forward(net, x):
+    """Train-mode forward of a YOLOPoint module through the native plans, differentiable w.r.t. its parameters."""
+    params = list(net.parameters())
+    outs = _YOLOPointTrainFn.apply(net, x, *params)
+    return {'semi': outs[0], 'desc': outs[1], 'objects': list(outs[2:])}
