@@ -1,0 +1,226 @@
+"""Training losses of the YOLOPoint step, in PyTorch autograd (they are small, data-dependent
+gather/scatter work between the native forward and backward) — same call signatures and values as the
+reference: src/utils/loss_functions.py:90-234 (ComputeObjectLoss), :484-597 (infonce), :600-619
+(ComputeDetectorLoss); train.py:212-241 combines them.
+
+The random draws of `infonce` (match shuffling, negative sampling) can be injected (`perm_fn`, `randint_fn`)
+so that the loss is reproducible in tests; by default they are the reference's torch.randperm / np.random.randint.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .metrics_yolo import bbox_iou
+from .torch_utils_yolo import de_parallel
+from .utils import getMasks
+
+
+def smooth_BCE(eps=0.1):
+    """Label-smoothed BCE targets (positive, negative)."""
+    return 1.0 - 0.5 * eps, 0.5 * eps
+
+
+class ComputeDetectorLoss:
+    """Keypoint-detector loss: BCE between softmax(semi) and the 65-channel cell labels, summed over channels,
+    averaged over valid cells (reference :600-619)."""
+
+    def __init__(self, device):
+        self.device = device
+
+    def __call__(self, inp, target, mask):
+        per_cell = F.binary_cross_entropy(torch.softmax(inp, dim=1), target, reduction='none').sum(dim=1)
+        return (per_cell * mask).sum() / (mask.sum() + 1e-10)
+
+
+class ComputeObjectLoss:
+    """YOLOv5 box (CIoU) + objectness + class loss over the three Detect levels (reference :90-234)."""
+    sort_obj_iou = False
+
+    def __init__(self, model, config, device, autobalance=False):
+        self.hyp = config
+        self.device = device
+        self.BCEcls = nn.BCEWithLogitsLoss(pos_weight=torch.tensor([config['cls_pw']], device=device))
+        self.BCEobj = nn.BCEWithLogitsLoss(pos_weight=torch.tensor([config['obj_pw']], device=device))
+        if config['fl_gamma'] > 0:
+            raise NotImplementedError("focal loss (fl_gamma > 0) is not used by the reference configs")
+        self.cp, self.cn = smooth_BCE(eps=config.get('label_smoothing', 0.0))
+        det = de_parallel(model).model.Detect
+        self.balance = {3: [4.0, 1.0, 0.4]}.get(det.nl, [4.0, 1.0, 0.25, 0.06, 0.02])
+        self.ssi = list(det.stride).index(16) if autobalance else 0
+        self.gr, self.autobalance = 1.0, autobalance
+        self.na, self.nc, self.nl, self.anchors = det.na, det.nc, det.nl, det.anchors
+
+    def __call__(self, p, targets):
+        dev = self.device
+        lcls, lbox, lobj = (torch.zeros(1, device=dev) for _ in range(3))
+        tcls, tbox, indices, anchors = self.build_targets(p, targets)
+        for i, pi in enumerate(p):
+            b, a, gj, gi = indices[i]
+            tobj = torch.zeros(pi.shape[:4], dtype=pi.dtype, device=dev)
+            n = b.shape[0]
+            if n:
+                pxy, pwh, _, pcls = pi[b, a, gj, gi].split((2, 2, 1, self.nc), 1)
+                pxy = pxy.sigmoid() * 2 - 0.5
+                pwh = (pwh.sigmoid() * 2) ** 2 * anchors[i]
+                iou = bbox_iou(torch.cat((pxy, pwh), 1), tbox[i], CIoU=True).squeeze()
+                lbox = lbox + (1.0 - iou).mean()
+                iou = iou.detach().clamp(0).type(tobj.dtype)
+                if self.sort_obj_iou:
+                    j = iou.argsort()
+                    b, a, gj, gi, iou = b[j], a[j], gj[j], gi[j], iou[j]
+                if self.gr < 1:
+                    iou = (1.0 - self.gr) + self.gr * iou
+                tobj[b, a, gj, gi] = iou
+                if self.nc > 1:
+                    t = torch.full_like(pcls, self.cn, device=dev)
+                    t[range(n), tcls[i]] = self.cp
+                    lcls = lcls + self.BCEcls(pcls, t)
+            obji = self.BCEobj(pi[..., 4], tobj)
+            lobj = lobj + obji * self.balance[i]
+            if self.autobalance:
+                self.balance[i] = self.balance[i] * 0.9999 + 0.0001 / obji.detach().item()
+        if self.autobalance:
+            self.balance = [x / self.balance[self.ssi] for x in self.balance]
+        lbox = lbox * self.hyp['box']
+        lobj = lobj * self.hyp['obj']
+        lcls = lcls * self.hyp['cls']
+        return (lbox + lobj + lcls), torch.cat((lbox, lobj, lcls)).detach()
+
+    def build_targets(self, p, targets):
+        """targets [M,6] (image, class, xc, yc, w, h normalised) -> per level: classes, boxes (cell offsets + grid wh),
+        (image, anchor, gy, gx) indices, anchors; each target also claims its two nearest neighbour cells."""
+        dev = self.device
+        na, nt = self.na, targets.shape[0]
+        tcls, tbox, indices, anch = [], [], [], []
+        gain = torch.ones(7, device=dev)
+        ai = torch.arange(na, device=dev).float().view(na, 1).repeat(1, nt)
+        targets = torch.cat((targets.repeat(na, 1, 1), ai[..., None]), 2)          # [na, nt, 7]
+        g = 0.5
+        off = torch.tensor([[0, 0], [1, 0], [0, 1], [-1, 0], [0, -1]], device=dev).float() * g
+        for i in range(self.nl):
+            anchors, shape = self.anchors[i], p[i].shape
+            gain[2:6] = torch.tensor(shape)[[3, 2, 3, 2]]
+            t = targets * gain
+            if nt:
+                r = t[..., 4:6] / anchors[:, None]
+                keep = torch.max(r, 1 / r).max(2)[0] < self.hyp['anchor_t']
+                t = t[keep]
+                gxy = t[:, 2:4]
+                gxi = gain[[2, 3]] - gxy
+                j, k = ((gxy % 1 < g) & (gxy > 1)).T
+                l, m = ((gxi % 1 < g) & (gxi > 1)).T
+                sel = torch.stack((torch.ones_like(j), j, k, l, m))
+                t = t.repeat((5, 1, 1))[sel]
+                offsets = (torch.zeros_like(gxy)[None] + off[:, None])[sel]
+            else:
+                t = targets[0]
+                offsets = 0
+            bc, gxy, gwh, a = t.chunk(4, 1)
+            a, (b, c) = a.long().view(-1), bc.long().T
+            gij = (gxy - offsets).long()
+            gi, gj = gij.T
+            indices.append((b, a, gj.clamp_(0, shape[2] - 1), gi.clamp_(0, shape[3] - 1)))
+            tbox.append(torch.cat((gxy - gij, gwh), 1))
+            anch.append(anchors[a])
+            tcls.append(c)
+        return tcls, tbox, indices, anch
+
+
+# ---------------------------------------------------------------------------------------------
+# InfoNCE descriptor loss and its geometry helpers (reference utils/utils.py:274-295,333-376 and
+# utils/loss_functions.py:339-359,484-597)
+# ---------------------------------------------------------------------------------------------
+def warp_points(points, homographies, device='cpu'):
+    """points [N,2] (x,y) through homographies [3,3] or [B,3,3] -> [N,2] or [B,N,2]."""
+    single = homographies.dim() == 2
+    H = homographies.unsqueeze(0) if single else homographies
+    B = H.shape[0]
+    pts = torch.cat((points.float().to(device), torch.ones((points.shape[0], 1), device=device)), dim=1)
+    w = (H.reshape(B * 3, 3) @ pts.t()).view(B, 3, -1).transpose(2, 1)
+    w = w[:, :, :2] / w[:, :, 2:]
+    return w[0] if single else w
+
+
+def homography_scaling(homography, H, W, device='cpu'):
+    """Homography in normalised [-1,1] coordinates -> pixel coordinates of an HxW grid."""
+    trans = torch.tensor([[2. / W, 0., -1.], [0., 2. / H, -1.], [0., 0., 1.]], dtype=torch.float32, device=device)
+    return trans.inverse() @ homography @ trans
+
+
+def warp_image_batch(img, mat_homo_inv, device='cpu', mode='bilinear', padding_mode='zeros'):
+    """Inverse-warp a batch [B,C,H,W] with normalised inverse homographies [B,3,3] (grid_sample, align_corners=True)."""
+    if img.dim() in (2, 3):
+        img = img.view(1, 1, img.shape[-2], img.shape[-1])
+    if mat_homo_inv.dim() == 2:
+        mat_homo_inv = mat_homo_inv.view(1, 3, 3)
+    B, _, H, W = img.shape
+    ys, xs = torch.meshgrid(torch.linspace(-1, 1, H), torch.linspace(-1, 1, W), indexing='ij')
+    cells = torch.stack((xs, ys), dim=2).to(device).contiguous()
+    src = warp_points(cells.view(-1, 2), mat_homo_inv, device).view(B, H, W, 2).float()
+    return F.grid_sample(img, src, mode=mode, align_corners=True, padding_mode=padding_mode)
+
+
+def get_coor_cells(Hc, Wc, uv=False, device='cpu'):
+    ys, xs = torch.meshgrid(torch.arange(Hc), torch.arange(Wc), indexing='ij')
+    cells = torch.stack((xs, ys) if uv else (ys, xs), dim=2).float().view(-1, 2)
+    return cells.to(device)
+
+
+def normPts(pts, shape):
+    return pts / shape * 2 - 1
+
+
+def infonce(descriptors, descriptors_warped, mask_valid_warp, inv_homographies, num_samples_per_image=1500,
+            num_masked_non_matches_per_match=120, cell_size=8, device='cpu', tau=0.07, perm_fn=None, randint_fn=None):
+    """Cross-image InfoNCE between the descriptors of an image and of its warp: every valid cell of image A is matched
+    to the cell its inverse homography maps it to in image B; `num_masked_non_matches_per_match` random other matches
+    are the negatives; loss = -log softmax(<a,b+>/tau | <a,b->/tau)[0], averaged."""
+    assert descriptors.shape[-1] * descriptors.shape[-2] >= num_samples_per_image, \
+        "Number of samples per image must be greater than number of pixels in image"
+    perm_fn = perm_fn or torch.randperm
+    randint_fn = randint_fn or np.random.randint
+    with torch.no_grad():
+        B, Hc, Wc = descriptors.shape[0], descriptors.shape[2], descriptors.shape[3]
+        uv_a = get_coor_cells(Hc, Wc, uv=True).to(device)
+        inv_h = inv_homographies.to(device)
+        valid = warp_image_batch(mask_valid_warp, inv_h, mode='nearest', device=device)
+        valid = (getMasks(valid, device, cell_size) == 1.).flatten(1, -1)                  # [B, Hc*Wc]
+        uv_b = warp_points(uv_a, homography_scaling(inv_h, Hc, Wc, device=device), device).round_()   # [B, N, 2]
+        a_list = [uv_a[valid[i]] for i in range(B)]
+        b_list = [uv_b[i][valid[i]] for i in range(B)]
+        pool = min(num_samples_per_image, min(x.shape[0] for x in a_list))
+        pa, pb = [], []
+        for i in range(B):
+            choice = perm_fn(a_list[i].shape[0])
+            pa.append(a_list[i][choice][:pool])
+            pb.append(b_list[i][choice][:pool])
+        size = torch.tensor([Wc, Hc]).float().to(device)
+        ua = normPts(torch.stack(pa).to(device), size)
+        ub = normPts(torch.stack(pb).to(device), size)
+
+    def sample(desc, idx):
+        return F.grid_sample(desc, idx.unsqueeze(1), mode='bilinear', align_corners=True).squeeze(2).transpose(1, 2)
+
+    da = sample(descriptors, ua)                       # [B, pool, D]
+    db = sample(descriptors_warped, ub)
+    pos = (da * db).sum(-1).flatten()
+    da, db = da.flatten(0, 1), db.flatten(0, 1)
+    n = da.shape[0]
+    shape = (num_masked_non_matches_per_match, n)
+    ordered = np.broadcast_to(np.arange(n), shape)
+    rnd = randint_fn(0, n, size=shape)
+    same = ordered == rnd
+    if nz := np.count_nonzero(same):                   # a negative must not be the match itself
+        while True:
+            cand = randint_fn(0, nz, nz)
+            if (rnd[same] != cand).any():
+                rnd[same] = cand
+                break
+    neg_b = db[torch.from_numpy(rnd)].transpose(0, 1)                      # [n, negs, D]
+    neg = (da.unsqueeze(1) * neg_b).sum(-1)
+    logits = torch.cat([pos.unsqueeze(1), neg], dim=1) / tau
+    return -F.log_softmax(logits, dim=1)[:, 0].mean()
+
+
+descriptor_loss_sparse = infonce      # the name train.py imports it under (train.py:8)
