@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", default="", help="write a per-launch table (us, TFLOP/s, GB/s) to this path")
     ap.add_argument("--postproc", action="store_true", help="also time the post-processing kernels on planted head outputs")
+    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
+                    help="infer (default, BASELINE.json configs[1]) or train: the reference's optimizer step, data parallel over --gpus")
     return ap.parse_args()
 
 
@@ -108,6 +110,8 @@ def main():
 
     from yolopoint_amd import _hip
     _hip.require_gpu()
+    if a.mode == "train":
+        return bench_train(a, rank, world, dev)
     m, _ = build_model(a.version, a.dtype, dev)
     net = m.model
     B, S = a.batch, a.size
@@ -220,6 +224,41 @@ def main():
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.version, B, S)
     print(json.dumps(out), flush=True)
+
+
+def bench_train(a, rank, world, dev):
+    """BASELINE.json configs[2] shape: YOLOPoint-s training, per-GPU batch a.batch (8 -> global 64 on 8 GPUs), 640x640,
+    bf16 compute: two forwards + detector/object/InfoNCE losses + backward + bucketed gradient all-reduce + Adam per step."""
+    import torch.distributed as dist
+    from helpers import make_model
+    from yolopoint_amd.engine import TrainStep, synthetic_batch
+    from yolopoint_amd.dp import timed_region
+    dtype = a.dtype if a.dtype != "f16" else "bf16"
+    m, _ = make_model(a.version, 1234, dtype=dtype)
+    m = m.to(dev).train()
+    step = TrainStep(m, dev, img_size=a.size)
+    batch = synthetic_batch(a.batch, a.size, dev, 1234 + rank)
+    steps, warmup = min(a.steps, 20), min(a.warmup, 3)
+
+    def reduce_max(t):
+        if world == 1:
+            return t
+        x = torch.tensor([t], device=dev)
+        dist.all_reduce(x, op=dist.ReduceOp.MAX)
+        return float(x.item())
+    wall = timed_region(lambda: step(batch), steps, warmup, torch.cuda.synchronize, (dist.barrier if world > 1 else (lambda: None)), reduce_max)
+    if rank != 0:
+        return
+    samples = a.batch * world * steps
+    print(json.dumps({
+        "metric": f"images/sec at {a.size}x{a.size} (YOLOPoint-{a.version} training, {a.batch} samples/GPU, {dtype}); an image pair counts as 2 images",
+        "value": round(2 * samples / wall, 1), "unit": "images/s", "samples_per_s": round(samples / wall, 1), "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": round(wall / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": dtype, "data": "synthetic",
+        "config": {"workload": f"BASELINE.json configs[2] shape: YOLOPoint-{a.version} optimizer step as src/train.py:189-259 (2 forwards, detector + object + "
+                               f"InfoNCE losses in PyTorch autograd, native backward, gradient all-reduce, Adam), {a.batch} samples/GPU, {a.size}x{a.size}",
+                   "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
+                   "grad_allreduce_bytes": step.reducer.payload_bytes()}}), flush=True)
 
 
 def bench_postproc(dev):

@@ -171,7 +171,8 @@ int yp_ups2_bwd(YpView in, YpView out, int dtype, int B, int accumulate, void* s
 /* dst (+)= src (gradient fan-in) */
 int yp_add_views(YpView src, YpView dst, int dtype, int B, int accumulate, void* stream);
 /* backward of MaxPool2d(5,1,2) (models/common.py:220): dx (+)= dy routed to each window's first maximum */
-int yp_maxpool5_bwd(YpView x, YpView dy, YpView dx, int dtype, int B, int accumulate, void* stream);
+size_t yp_maxpool5_bwd_workspace_bytes(int B, int H, int W, int C);
+int yp_maxpool5_bwd(YpView x, YpView dy, YpView dx, int dtype, int B, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 /* backward of the descriptor L2 normalisation (models/YOLOPoint.py:219-220), fp32 views */
 int yp_l2norm_bwd_f32(YpView x, YpView g, YpView dx, int B, int C, void* stream);
 /* fp32 gradient of the permuted Detect output [B,na,ny,nx,no] -> NHWC view in `dtype` (inverse of models/yolo.py:53) */
@@ -191,7 +192,7 @@ enum {
     YP_OP_BN_BWD = 12,        /* v0=raw v1=dy v2=dx; i0=dtype i1=B i2=act i3=accumulate; f0..f3 as above; g0=dgamma g1=dbeta; p0=ws n0=ws_bytes */
     YP_OP_UPS2_BWD = 13,      /* v0=in v1=out; i0=dtype i1=B i2=accumulate */
     YP_OP_ADD_VIEWS = 14,     /* v0=src v1=dst; i0=dtype i1=B i2=accumulate */
-    YP_OP_MAXPOOL5_BWD = 15,  /* v0=x v1=dy v2=dx; i0=dtype i1=B i2=accumulate */
+    YP_OP_MAXPOOL5_BWD = 15,  /* v0=x v1=dy v2=dx; i0=dtype i1=B i2=accumulate; p0=ws n0=ws_bytes */
     YP_OP_L2NORM_BWD = 16,    /* v0=x v1=g v2=dx; i1=B i2=C */
     YP_OP_DETECT_BWD_PACK = 17, /* f0=gx; v0=out; i0=dtype i1=B i2=na i3=no */
     YP_OP_TO_CHWB = 18,       /* v0=in; i0=dtype i1=B i2=C i3=Bpad; p0=out */

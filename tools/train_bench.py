@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Time the full training step (tools-level probe; bench.py --mode train uses the same TrainStep)."""
+import argparse, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+from helpers import make_model
+from yolopoint_amd.engine import TrainStep, synthetic_batch
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--version", default="s"); ap.add_argument("--batch", type=int, default=8); ap.add_argument("--size", type=int, default=640)
+ap.add_argument("--dtype", default="bf16"); ap.add_argument("--steps", type=int, default=5)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+m, _ = make_model(a.version, 1, dtype=a.dtype)
+m = m.to(dev).train()
+step = TrainStep(m, dev, img_size=a.size)
+batch = synthetic_batch(a.batch, a.size, dev, 1234)
+t0 = time.perf_counter(); l = step(batch); torch.cuda.synchronize(); print(f"first step (plan build + autotune): {time.perf_counter()-t0:.1f}s loss={float(l):.4f}")
+l = step(batch); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(a.steps):
+    l = step(batch)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / a.steps
+print(f"YOLOPoint-{a.version} train step B={a.batch} {a.size}x{a.size} {a.dtype}: {dt*1e3:.1f} ms/step = {a.batch/dt:.1f} samples/s ({2*a.batch/dt:.1f} images/s), loss={float(l):.4f}")
+g = next(iter(m.model._train_graphs.values()))[0]
+for name, plan in (("fwd", g.fwd_plan), ("bwd", g.bwd_plan)):
+    ms = plan.profile()
+    print(f"  {name} plan: {len(ms)} launches, {sum(ms):.2f} ms eager")
+    top = sorted(zip(ms, [r.name for r in plan.records]), reverse=True)[:8]
+    print("    slowest:", ", ".join(f"{n}={t*1e3:.0f}us" for t, n in top))
+
+# ---- host-side breakdown of one step (synchronising between phases)
+import contextlib
+from yolopoint_amd.utils.loss_functions import infonce
+from yolopoint_amd.utils.utils import labels2Dto3D, getMasks
+from yolopoint_amd.engine import SPARSE, LAMBDA_DESC, LAMBDA_OBJ
+def tick(label, t=[time.perf_counter()]):
+    torch.cuda.synchronize(); now = time.perf_counter(); print(f"    {label:28s} {(now - t[0])*1e3:7.1f} ms"); t[0] = now
+print("  phase breakdown (synchronised):")
+step.opt.zero_grad(set_to_none=True); tick("zero_grad")
+o = m(batch['image']); tick("forward 1")
+ow = m(batch['warped_image']); tick("forward 2")
+lo = step.obj_loss(o['objects'], batch['box_labels'])[0]; tick("object loss")
+ld = step.det_loss(o['semi'], labels2Dto3D(batch['labels_2D']), getMasks(batch['valid_mask'], dev)) + step.det_loss(ow['semi'], labels2Dto3D(batch['warped_labels']), getMasks(batch['warped_valid_mask'], dev)); tick("detector losses")
+ln = infonce(o['desc'], ow['desc'], batch['warped_valid_mask'], batch['inv_homographies'], device=dev, **SPARSE); tick("infonce")
+loss = ld + LAMBDA_DESC * ln + LAMBDA_OBJ * lo
+loss.backward(); tick("backward")
+step.opt.step(); tick("adam")
+gg = next(iter(m.model._train_graphs.values()))[0]
+t0 = time.perf_counter(); gg.fwd_plan.refresh(); gg.bwd_plan.refresh(); torch.cuda.synchronize(); print(f"    weight refresh (1 graph)      {(time.perf_counter()-t0)*1e3:7.1f} ms")
+t0 = time.perf_counter(); [fn() for fn in gg.collect]; torch.cuda.synchronize(); print(f"    grad collect (1 graph)        {(time.perf_counter()-t0)*1e3:7.1f} ms")
+t0 = time.perf_counter(); gg.bwd_plan.run(); torch.cuda.synchronize(); print(f"    bwd plan run (1 graph)        {(time.perf_counter()-t0)*1e3:7.1f} ms")

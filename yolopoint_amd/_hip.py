@@ -68,7 +68,8 @@ SIGNATURES = {
     "yp_bn_act_bwd": (_i, [YpView, YpView, YpView, _i, _i, _p, _p, _p, _p, _i, _p, _p, _i, _p, _sz, _p]),
     "yp_ups2_bwd": (_i, [YpView, YpView, _i, _i, _i, _p]),
     "yp_add_views": (_i, [YpView, YpView, _i, _i, _i, _p]),
-    "yp_maxpool5_bwd": (_i, [YpView, YpView, YpView, _i, _i, _i, _p]),
+    "yp_maxpool5_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "yp_maxpool5_bwd": (_i, [YpView, YpView, YpView, _i, _i, _i, _p, _sz, _p]),
     "yp_l2norm_bwd_f32": (_i, [YpView, YpView, YpView, _i, _i, _p]),
     "yp_detect_bwd_pack": (_i, [_p, _i, _i, _i, YpView, _i, _p]),
     "yp_to_chwb": (_i, [YpView, _i, _i, _i, _p, _i, _p]),

@@ -126,14 +126,31 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const char* __restrict_
     }
 }
 
-// fold partials -> mean / invstd (+ running statistics), or -> dgamma / dbeta
-__global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int nblk, int C, double M, float eps, float momentum,
-                                         float* __restrict__ mean, float* __restrict__ invstd, float* running_mean,
-                                         float* running_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, ss = 0.0;
-    for (int b = 0; b < nblk; ++b) { s += part[((size_t)b * 2) * C + c]; ss += part[((size_t)b * 2 + 1) * C + c]; }
+// fold partials -> mean / invstd (+ running statistics), or -> dgamma / dbeta.  One wavefront per channel: lanes
+// stride over the workgroup partials, then a butterfly reduction in double precision.
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int lo = __shfl_xor((int)(__double_as_longlong(v) & 0xffffffffll), o, 64);
+        const int hi = __shfl_xor((int)(__double_as_longlong(v) >> 32), o, 64);
+        v += __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    }
+    return v;
+}
+__device__ __forceinline__ void fold_partials(const float* __restrict__ part, int nblk, int C, int c, double& s, double& ss) {
+    const int lane = threadIdx.x & 63;
+    double a = 0.0, b = 0.0;
+    for (int q = lane; q < nblk; q += 64) { a += part[((size_t)q * 2) * C + c]; b += part[((size_t)q * 2 + 1) * C + c]; }
+    s = wave_sum_d(a);
+    ss = wave_sum_d(b);
+}
+__global__ __launch_bounds__(64) void bn_stats_finalize_kernel(const float* __restrict__ part, int nblk, int C, double M, float eps, float momentum,
+                                                               float* __restrict__ mean, float* __restrict__ invstd, float* running_mean,
+                                                               float* running_var) {
+    const int c = blockIdx.x;
+    double s, ss;
+    fold_partials(part, nblk, C, c, s, ss);
+    if (threadIdx.x != 0) return;
     const double mu = s / M;
     double var = ss / M - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -145,14 +162,17 @@ __global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int nbl
         running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
     }
 }
-__global__ void pair_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ o0, float* __restrict__ o1,
-                                     int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, ss = 0.0;
-    for (int b = 0; b < nblk; ++b) { s += part[((size_t)b * 2) * C + c]; ss += part[((size_t)b * 2 + 1) * C + c]; }
-    o0[c] = (accumulate ? o0[c] : 0.f) + (float)s;
-    o1[c] = (accumulate ? o1[c] : 0.f) + (float)ss;
+// o0 / o1 get the two column sums; when p0 / p1 are given they receive (or accumulate) them as well
+__global__ __launch_bounds__(64) void pair_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ o0, float* __restrict__ o1,
+                                                           float* p0, float* p1, int accumulate) {
+    const int c = blockIdx.x;
+    double s, ss;
+    fold_partials(part, nblk, C, c, s, ss);
+    if (threadIdx.x != 0) return;
+    if (o0) o0[c] = (float)s;
+    if (o1) o1[c] = (float)ss;
+    if (p0) p0[c] = (accumulate ? p0[c] : 0.f) + (float)s;
+    if (p1) p1[c] = (accumulate ? p1[c] : 0.f) + (float)ss;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -270,11 +290,33 @@ __global__ void add_views_kernel(const char* __restrict__ src, int scs, int sco,
 }
 
 // backward of MaxPool2d(5,1,2): the gradient of each output pixel goes to the first maximum of its window
-// (row-major scan, like ATen's CPU kernel); dx is accumulated per input pixel by gathering: an input pixel
-// collects dy of every output whose window argmax is that pixel.  One thread per (input pixel, channel).
+// (row-major scan, like ATen's CPU kernel).  Pass 1 records, per output element, which of the 25 window
+// positions is that maximum; pass 2 gathers: an input element sums dy of the <= 25 outputs that selected it.
 template <int DT>
-__global__ void maxpool5_bwd_kernel(const char* __restrict__ x, int xcs, int xco, const char* __restrict__ dy, int dcs, int dco,
-                                    char* __restrict__ dx, int gcs, int gco, int B, int H, int W, int C, int accumulate) {
+__global__ void maxpool5_argmax_kernel(const char* __restrict__ x, int xcs, int xco, unsigned char* __restrict__ arg, int B, int H, int W, int C) {
+    using T = typename Sc<DT>::t;
+    const size_t n = (size_t)B * H * W * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const size_t pix = i / C;
+        const int ow = (int)(pix % W), oh = (int)((pix / W) % H);
+        const size_t b = pix / ((size_t)W * H);
+        const T* xb = reinterpret_cast<const T*>(x) + (b * H * W) * xcs + xco + c;
+        float best = -3.0e38f;
+        int code = 0;
+        for (int dy = -2; dy <= 2; ++dy)
+            for (int dx = -2; dx <= 2; ++dx) {
+                const int yy = oh + dy, xx = ow + dx;
+                if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+                const float v = (float)xb[((size_t)yy * W + xx) * xcs];
+                if (v > best) { best = v; code = (dy + 2) * 5 + (dx + 2); }
+            }
+        arg[i] = (unsigned char)code;
+    }
+}
+template <int DT>
+__global__ void maxpool5_bwd_kernel(const unsigned char* __restrict__ arg, const char* __restrict__ dy, int dcs, int dco, char* __restrict__ dx,
+                                    int gcs, int gco, int B, int H, int W, int C, int accumulate) {
     using T = typename Sc<DT>::t;
     const size_t n = (size_t)B * H * W * C;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -282,21 +324,12 @@ __global__ void maxpool5_bwd_kernel(const char* __restrict__ x, int xcs, int xco
         const size_t pix = i / C;
         const int w = (int)(pix % W), h = (int)((pix / W) % H);
         const size_t b = pix / ((size_t)W * H);
-        const T* xb = reinterpret_cast<const T*>(x) + (b * H * W) * xcs + xco + c;
         const T* gb = reinterpret_cast<const T*>(dy) + (b * H * W) * dcs + dco + c;
         float acc = 0.f;
-        // outputs (oh, ow) whose 5x5 window contains (h, w)
         for (int oh = max(h - 2, 0); oh <= min(h + 2, H - 1); ++oh)
             for (int ow = max(w - 2, 0); ow <= min(w + 2, W - 1); ++ow) {
-                // argmax of the window of (oh, ow): first maximum in row-major order
-                float best = -3.0e38f;
-                int bh = -1, bw = -1;
-                for (int yy = max(oh - 2, 0); yy <= min(oh + 2, H - 1); ++yy)
-                    for (int xx = max(ow - 2, 0); xx <= min(ow + 2, W - 1); ++xx) {
-                        const float v = (float)xb[((size_t)yy * W + xx) * xcs];
-                        if (v > best) { best = v; bh = yy; bw = xx; }
-                    }
-                if (bh == h && bw == w) acc += (float)gb[((size_t)oh * W + ow) * dcs];
+                const int code = (h - oh + 2) * 5 + (w - ow + 2);          // position of (h, w) inside the window of (oh, ow)
+                if (arg[((b * H + oh) * W + ow) * C + c] == code) acc += (float)gb[((size_t)oh * W + ow) * dcs];
             }
         T* o = reinterpret_cast<T*>(dx) + pix * gcs + gco + c;
         *o = (T)((accumulate ? (float)*o : 0.f) + acc);
@@ -410,7 +443,7 @@ extern "C" int yp_bn_stats(YpView raw, int dtype, int B, float eps, float moment
     hipStream_t st = (hipStream_t)stream;
     YP_DT_SWITCH(dtype, (col_reduce_kernel<DT, 0><<<nblk, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, nullptr, 0, 0, M, raw.C,
                                                                         nullptr, nullptr, nullptr, nullptr, 0, (float*)ws)));
-    bn_stats_finalize_kernel<<<yp_cdiv(raw.C, 64), 64, 0, st>>>((const float*)ws, nblk, raw.C, (double)M, eps, momentum, mean, invstd,
+    bn_stats_finalize_kernel<<<raw.C, 64, 0, st>>>((const float*)ws, nblk, raw.C, (double)M, eps, momentum, mean, invstd,
                                                                running_mean, running_var);
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
@@ -447,12 +480,11 @@ extern "C" int yp_bn_act_bwd(YpView raw, YpView dy, YpView dx, int dtype, int B,
     float* db = dg + raw.C;
     YP_DT_SWITCH(dtype, (col_reduce_kernel<DT, 1><<<nblk, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, (const char*)dy.ptr, dy.cstride,
                                                                         dy.coff, M, raw.C, mean, invstd, gamma, beta, act, (float*)ws)));
-    pair_finalize_kernel<<<yp_cdiv(raw.C, 64), 64, 0, st>>>((const float*)ws, nblk, raw.C, db, dg, 0);      // (sum dz, sum dz*xhat)
+    // (sum dz, sum dz*xhat) -> this call's dbeta / dgamma, and (accumulated) into the parameter gradients
+    pair_finalize_kernel<<<raw.C, 64, 0, st>>>((const float*)ws, nblk, raw.C, db, dg, dbeta, dgamma, accumulate_param_grads);
     const int g = grid_for(M * (raw.C / 8), 256);
     YP_DT_SWITCH(dtype, (bn_bwd_apply_kernel<DT><<<g, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, (const char*)dy.ptr, dy.cstride, dy.coff,
                                                                     (char*)dx.ptr, dx.cstride, dx.coff, M, raw.C, mean, invstd, gamma, beta, act, dg, db)));
-    // parameter gradients: dbeta = sum dz, dgamma = sum dz*xhat
-    pair_finalize_kernel<<<yp_cdiv(raw.C, 64), 64, 0, st>>>((const float*)ws, nblk, raw.C, dbeta, dgamma, accumulate_param_grads);
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
 }
@@ -479,12 +511,16 @@ extern "C" int yp_add_views(YpView src, YpView dst, int dtype, int B, int accumu
     return YP_OK;
 }
 
-extern "C" int yp_maxpool5_bwd(YpView x, YpView dy, YpView dx, int dtype, int B, int accumulate, void* stream) {
-    YP_REQUIRE(x.ptr && dy.ptr && dx.ptr && x.C == dy.C && x.C == dx.C && x.H == dy.H && x.H == dx.H && x.W == dy.W, "yp_maxpool5_bwd: bad views");
+extern "C" size_t yp_maxpool5_bwd_workspace_bytes(int B, int H, int W, int C) { return align_up((size_t)B * H * W * C, 256); }
+
+extern "C" int yp_maxpool5_bwd(YpView x, YpView dy, YpView dx, int dtype, int B, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    YP_REQUIRE(x.ptr && dy.ptr && dx.ptr && ws && x.C == dy.C && x.C == dx.C && x.H == dy.H && x.H == dx.H && x.W == dy.W, "yp_maxpool5_bwd: bad views");
+    YP_REQUIRE(ws_bytes >= yp_maxpool5_bwd_workspace_bytes(B, x.H, x.W, x.C), "yp_maxpool5_bwd: workspace too small");
     const size_t n = (size_t)B * x.H * x.W * x.C;
-    YP_DT_SWITCH(dtype, (maxpool5_bwd_kernel<DT><<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>((const char*)x.ptr, x.cstride, x.coff, (const char*)dy.ptr,
-                                                                                                   dy.cstride, dy.coff, (char*)dx.ptr, dx.cstride, dx.coff, B, x.H,
-                                                                                                   x.W, x.C, accumulate)));
+    hipStream_t st = (hipStream_t)stream;
+    YP_DT_SWITCH(dtype, (maxpool5_argmax_kernel<DT><<<grid_for(n, 256), 256, 0, st>>>((const char*)x.ptr, x.cstride, x.coff, (unsigned char*)ws, B, x.H, x.W, x.C)));
+    YP_DT_SWITCH(dtype, (maxpool5_bwd_kernel<DT><<<grid_for(n, 256), 256, 0, st>>>((const unsigned char*)ws, (const char*)dy.ptr, dy.cstride, dy.coff, (char*)dx.ptr,
+                                                                                   dx.cstride, dx.coff, B, x.H, x.W, x.C, accumulate)));
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
 }
@@ -526,9 +562,8 @@ extern "C" int yp_col_sum(YpView v, int dtype, int B, float* out, int accumulate
     float* scratch = (float*)((char*)ws + yp_bn_workspace_bytes(B, v.H, v.W, v.C));      // receives the sum of squares (unused)
     YP_DT_SWITCH(dtype, (col_reduce_kernel<DT, 0><<<nblk, 256, 0, st>>>((const char*)v.ptr, v.cstride, v.coff, nullptr, 0, 0, M, v.C, nullptr, nullptr,
                                                                         nullptr, nullptr, 0, (float*)ws)));
-    // pair_finalize accumulates both outputs or neither; the sum of squares goes to scratch either way
-    if (accumulate) YP_CHECK_HIP(hipMemsetAsync(scratch, 0, (size_t)v.C * 4, st));
-    pair_finalize_kernel<<<yp_cdiv(v.C, 64), 64, 0, st>>>((const float*)ws, nblk, v.C, out, scratch, accumulate);
+    (void)scratch;
+    pair_finalize_kernel<<<v.C, 64, 0, st>>>((const float*)ws, nblk, v.C, nullptr, nullptr, out, nullptr, accumulate);
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
 }
@@ -553,7 +588,7 @@ extern "C" int yp_run_op(const YpOpArgs* a, void* stream) {
         case YP_OP_BN_BWD: return yp_bn_act_bwd(a->v[0], a->v[1], a->v[2], dt, B, a->f[0], a->f[1], a->f[2], a->f[3], a->i[2], a->g[0], a->g[1], a->i[3], a->p[0], a->n[0], stream);
         case YP_OP_UPS2_BWD: return yp_ups2_bwd(a->v[0], a->v[1], dt, B, a->i[2], stream);
         case YP_OP_ADD_VIEWS: return yp_add_views(a->v[0], a->v[1], dt, B, a->i[2], stream);
-        case YP_OP_MAXPOOL5_BWD: return yp_maxpool5_bwd(a->v[0], a->v[1], a->v[2], dt, B, a->i[2], stream);
+        case YP_OP_MAXPOOL5_BWD: return yp_maxpool5_bwd(a->v[0], a->v[1], a->v[2], dt, B, a->i[2], a->p[0], a->n[0], stream);
         case YP_OP_L2NORM_BWD: return yp_l2norm_bwd_f32(a->v[0], a->v[1], a->v[2], B, a->i[2], stream);
         case YP_OP_DETECT_BWD_PACK: return yp_detect_bwd_pack(a->f[0], B, a->i[2], a->i[3], a->v[0], dt, stream);
         case YP_OP_TO_CHWB: return yp_to_chwb(a->v[0], dt, B, a->i[2], a->p[0], a->i[3], stream);

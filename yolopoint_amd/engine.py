@@ -1,0 +1,73 @@
+"""One optimizer step of YOLOPoint training as the reference runs it (src/train.py:189-259), on synthetic batches.
+
+  outs   = model(image)           outs_w = model(warped_image)                (train.py:208,220)
+  loss   = (det + det_warp) + lambda_loss * infonce + lambda_loss_obj * obj    (train.py:238-241)
+  loss.backward(); [gradient all-reduce over ranks]; optimizer.step()         (train.py:245-252)
+
+Forward/backward of the network run through the native plans (yolopoint_amd/training.py); the losses are PyTorch
+autograd; Adam is torch.optim.Adam (train.py:88).  Data: SURVEY.md 8(d) synthetic recipe, generated on the device.
+"""
+import torch
+
+from .utils.loss_functions import ComputeDetectorLoss, ComputeObjectLoss, infonce
+from .utils.utils import labels2Dto3D, getMasks
+from .dp import GradAllReducer
+
+# reference configs/coco.yaml:113-149
+HYP = dict(box=0.05, cls=0.5, obj=1.0, anchor_t=4.0, fl_gamma=0.0, cls_pw=1.0, obj_pw=1.0)
+LAMBDA_DESC, LAMBDA_OBJ = 0.1, 10.0
+SPARSE = dict(num_samples_per_image=3000, num_masked_non_matches_per_match=200)
+
+
+def synthetic_batch(B, S, device, seed, nc=80):
+    """image / warped image U[0,1); one keypoint label per 8x8 cell with prob 0.12; valid mask with a 4-px zero
+    border; 8 boxes per image; identity homographies (throughput runs)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    r = lambda *shape: torch.rand(*shape, generator=g, device=device)
+    Hc = S // 8
+    img, img_w = r(B, 3, S, S), r(B, 3, S, S)
+
+    def labels():
+        has = (r(B, Hc, Hc) < 0.12)
+        pos = torch.randint(0, 64, (B, Hc, Hc), generator=g, device=device)
+        cell = torch.nn.functional.one_hot(pos, 64).float() * has[..., None]                 # [B,Hc,Hc,64]
+        return cell.view(B, Hc, Hc, 8, 8).permute(0, 1, 3, 2, 4).reshape(B, 1, S, S)
+    mask = torch.zeros(B, 1, S, S, device=device)
+    mask[:, :, 4:-4, 4:-4] = 1
+    nb = 8
+    boxes = torch.cat((torch.arange(B, device=device).repeat_interleave(nb)[:, None].float(),
+                       torch.randint(0, nc, (B * nb, 1), generator=g, device=device).float(),
+                       0.1 + 0.8 * r(B * nb, 2), torch.exp(torch.log(torch.tensor(0.03)) + r(B * nb, 2) * (torch.log(torch.tensor(0.5 / 0.03))))), 1)
+    eye = torch.eye(3, device=device).repeat(B, 1, 1)
+    return dict(image=img, warped_image=img_w, labels_2D=labels(), warped_labels=labels(), valid_mask=mask, warped_valid_mask=mask.clone(),
+                box_labels=boxes, inv_homographies=eye)
+
+
+class TrainStep:
+    def __init__(self, model, device, img_size=640, lr=1e-3, group=None):
+        self.model, self.device = model, device
+        det = model.model.Detect
+        hyp = dict(HYP)
+        hyp['box'] *= 3 / det.nl                                    # train.py:158-165
+        hyp['cls'] *= det.nc / 80
+        hyp['obj'] *= (img_size / 640) ** 2 * 3 / det.nl
+        self.obj_loss = ComputeObjectLoss(model, hyp, device)
+        self.det_loss = ComputeDetectorLoss(device)
+        self.opt = torch.optim.Adam(model.parameters(), lr=lr)
+        self.reducer = GradAllReducer(model.parameters(), group=group)
+        self.reducer.broadcast_parameters(model)
+
+    def __call__(self, batch):
+        m, dev = self.model, self.device
+        self.opt.zero_grad(set_to_none=True)
+        outs = m(batch['image'])
+        outs_w = m(batch['warped_image'])
+        l_obj = self.obj_loss(outs['objects'], batch['box_labels'])[0]
+        l_det = self.det_loss(outs['semi'], labels2Dto3D(batch['labels_2D']), getMasks(batch['valid_mask'], dev))
+        l_det_w = self.det_loss(outs_w['semi'], labels2Dto3D(batch['warped_labels']), getMasks(batch['warped_valid_mask'], dev))
+        l_desc = infonce(outs['desc'], outs_w['desc'], batch['warped_valid_mask'], batch['inv_homographies'], device=dev, **SPARSE)
+        loss = (l_det + l_det_w) + LAMBDA_DESC * l_desc + LAMBDA_OBJ * l_obj
+        loss.backward()
+        self.reducer.all_reduce()
+        self.opt.step()
+        return loss.detach()

@@ -214,9 +214,9 @@ class TrainGraph:
         def backward():
             b = self.bwd
             g0, g1, g2, g3 = (self.gread(v) for v in (s0, s1, s2, s3))
-            b.op(_hip.OP_MAXPOOL5_BWD, [s2, g3, g2], [g2], "pool_bwd3", v=[s2, g3, g2], i=[code, B, 1])
-            b.op(_hip.OP_MAXPOOL5_BWD, [s1, g2, g1], [g1], "pool_bwd2", v=[s1, g2, g1], i=[code, B, 1])
-            b.op(_hip.OP_MAXPOOL5_BWD, [s0, g1, g0], [g0], "pool_bwd1", v=[s0, g1, g0], i=[code, B, 1])
+            b.op(_hip.OP_MAXPOOL5_BWD, [s2, g3, g2], [g2], "pool_bwd3", v=[s2, g3, g2], i=[code, B, 1], p=[self.ws], n=[self.ws.numel()])
+            b.op(_hip.OP_MAXPOOL5_BWD, [s1, g2, g1], [g1], "pool_bwd2", v=[s1, g2, g1], i=[code, B, 1], p=[self.ws], n=[self.ws.numel()])
+            b.op(_hip.OP_MAXPOOL5_BWD, [s0, g1, g0], [g0], "pool_bwd1", v=[s0, g1, g0], i=[code, B, 1], p=[self.ws], n=[self.ws.numel()])
         self.tape.append(backward)
         return self.conv_bn_act(m.cv2, cat.view())
 
@@ -304,8 +304,12 @@ class TrainGraph:
 
     # ------------------------------------------------------------------ run
     def forward(self, x):
-        self.fwd_plan.refresh()
-        self.bwd_plan.refresh()
+        # packed weights (forward + dgrad) are re-derived only when an optimizer step (or a load) changed the masters
+        ver = sum(p_._version for p_ in self.params)
+        if ver != getattr(self, "_packed_version", None):
+            self.fwd_plan.refresh()
+            self.bwd_plan.refresh()
+            self._packed_version = ver
         pack_input(x, self.img.view(), self.code)
         self.fwd_plan.run()
         for m in self.net.modules():
