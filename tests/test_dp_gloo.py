@@ -34,8 +34,9 @@ def _worker(rank, world, port, q):
     lo, hi = shard_batch(64, rank, world)
     dt = timed_region(lambda: time.sleep(0.01 * (rank + 1)), steps=3, warmup=1, sync=lambda: None, barrier=dist.barrier,
                       reduce_max=lambda t: (lambda x: (dist.all_reduce(x, op=dist.ReduceOp.MAX), float(x))[1])(torch.tensor([t])))
-    out = {"w0": w0, "grads": [p.grad.clone() for p in net.parameters()], "rm": net[1].running_mean.clone(), "shard": (lo, hi),
-           "nbuckets": len(red.buckets), "dt": dt}
+    # plain Python payloads: torch tensors in an mp.Queue travel through shared-memory fds that die with the child
+    out = {"w0": w0.flatten().tolist(), "grads": [p.grad.flatten().tolist() for p in net.parameters()],
+           "rm": net[1].running_mean.tolist(), "shard": (lo, hi), "nbuckets": len(red.buckets), "dt": dt}
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -53,13 +54,13 @@ def test_gradient_allreduce_two_ranks():
         p.join(timeout=60)
         assert p.exitcode == 0
     a, b = res[0], res[1]
-    assert torch.equal(a["w0"], b["w0"])                                        # broadcast from rank 0
+    assert a["w0"] == b["w0"]                                                   # broadcast from rank 0
     assert a["nbuckets"] > 1
     n = len(a["grads"])
     for i, (ga, gb) in enumerate(zip(a["grads"], b["grads"])):
-        assert torch.equal(ga, gb)
+        assert ga == gb
         expect = (1 + 2) * (i + 1) / 2.0 if i != n - 1 else 1 * (i + 1) / 2.0  # last param: rank 1 contributed zeros
-        assert torch.allclose(ga, torch.full_like(ga, expect)), (i, float(ga.flatten()[0]), expect)
-    assert float(a["rm"][0]) == 0.0 and float(b["rm"][0]) == 1.0               # per-rank BN statistics
+        assert all(abs(v - expect) < 1e-6 for v in ga), (i, ga[0], expect)
+    assert a["rm"][0] == 0.0 and b["rm"][0] == 1.0                             # per-rank BN statistics
     assert a["shard"] == (0, 32) and b["shard"] == (32, 64)
     assert abs(a["dt"] - b["dt"]) < 1e-9 and a["dt"] >= 0.06 - 1e-3            # max over ranks: rank 1's 3 x 20 ms
