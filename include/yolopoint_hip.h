@@ -134,6 +134,8 @@ int yp_unpack_nchw(YpView in, int src_dtype, int B, int C, float* out_nchw, void
 /* SPPF pyramid: three chained MaxPool2d(5,1,2) of view `x`, written to y1,y2,y3 (same dims).
  * replaces: models/common.py:220-229 */
 int yp_sppf_pool(YpView x, YpView y1, YpView y2, YpView y3, int B, int dtype, void* stream);
+/* MaxPool2d(kernel 2, stride 2): y[h,w] = max of x[2h..2h+1, 2w..2w+1].  replaces: models/YOLOPoint.py:289,311 (YOLOPointv52) */
+int yp_maxpool2(YpView x, YpView y, int B, int dtype, void* stream);
 /* per-pixel channel L2 normalisation of an fp32 NHWC view, no epsilon, in place or out of place.
  * replaces: models/YOLOPoint.py:219-220 */
 int yp_l2norm_f32(YpView in, YpView out, int B, int C, void* stream);
@@ -201,7 +203,8 @@ enum {
     YP_OP_PACK_NCHW = 21,     /* f0=x_nchw; v0=out; i0=dtype i1=B i2=C */
     YP_OP_L2NORM = 22,        /* v0=in v1=out; i1=B i2=C */
     YP_OP_SPPF_POOL = 23,     /* v0=x v1..v3=y1..y3; i0=dtype i1=B */
-    YP_OP_CAST_F32 = 24       /* v0=in (fp32) v1=out; i0=dtype i1=B */
+    YP_OP_CAST_F32 = 24,      /* v0=in (fp32) v1=out; i0=dtype i1=B */
+    YP_OP_MAXPOOL2 = 25       /* v0=x v1=y; i0=dtype i1=B */
 };
 typedef struct YpOpArgs {
     int32_t op, pad_;

@@ -123,6 +123,45 @@ def yolopoint_forward(sd, x, version, nc=80, training=False, stats=None):
     return {'semi': semi, 'desc': desc, 'objects': detect(sd, P + "Detect", [xf, xg, p5], nc, training)}
 
 
+def c2f(sd, p, x, n, **kw):
+    """C2f: cv2(cat(chunk(cv1(x), 2) + [m_i(prev)])), m_i = two 3x3 Convs without shortcut (models/common.py:91-103,151-171)."""
+    y = list(conv_block(sd, p + ".cv1", x, 1, 1, 0, **kw).chunk(2, 1))
+    for i in range(n):
+        t = conv_block(sd, f"{p}.m.{i}.cv1", y[-1], 3, 1, 1, **kw)
+        y.append(conv_block(sd, f"{p}.m.{i}.cv2", t, 3, 1, 1, **kw))
+    return conv_block(sd, p + ".cv2", torch.cat(y, 1), 1, 1, 0, **kw)
+
+
+def yolopointv52_forward(sd, x, version, nc=80, training=False, stats=None):
+    """models/YOLOPoint.py:294-342 (YOLOPointv52)."""
+    (c1, c2, c3_, c4, c5), (n1, n2, n3) = arch(version)
+    kw = dict(training=training, stats=stats)
+    P = "model."
+    up = lambda t: F.interpolate(t, scale_factor=2, mode='nearest')
+    x = conv_block(sd, P + "Conv1", x, 6, 2, 2, **kw)
+    x = conv_block(sd, P + "Conv2", x, 3, 2, 1, **kw)
+    xa = c2f(sd, P + "Bottleneck1", x, n1, **kw)
+    x8 = conv_block(sd, P + "Conv3", xa, 3, 2, 1, **kw)
+    semi = c2f(sd, P + "BottleneckDet", x8, n1, **kw)
+    xb = c2f(sd, P + "Bottleneck2", x8, n2, **kw)
+    dA = F.max_pool2d(xa, 2, 2)
+    dB = up(conv_block(sd, P + "ConvDescB", xb, 3, 2, 1, **kw))
+    desc = c2f(sd, P + "BottleneckDesc", torch.cat((dA, dB), 1), n1, **kw)
+    desc = desc / torch.norm(desc, p=2, dim=1).unsqueeze(1)
+    x = conv_block(sd, P + "Conv4", xb, 3, 2, 1, **kw)
+    xc = c2f(sd, P + "Bottleneck3", x, n3, **kw)
+    x = conv_block(sd, P + "Conv5", xc, 3, 2, 1, **kw)
+    x = c2f(sd, P + "Bottleneck4", x, n1, **kw)
+    xd = sppf(sd, P + "SPPooling", x, **kw)
+    xe = c2f(sd, P + "Bottleneck5", torch.cat((up(xd), xc), 1), n1, **kw)
+    xf = c2f(sd, P + "Bottleneck6", torch.cat((up(xe), xb), 1), n1, **kw)
+    x = conv_block(sd, P + "Conv8", xf, 3, 2, 1, **kw)
+    xg = c2f(sd, P + "Bottleneck7", torch.cat((x, xe), 1), n1, **kw)
+    x = conv_block(sd, P + "Conv9", xg, 3, 2, 1, **kw)
+    p5 = c2f(sd, P + "Bottleneck8", torch.cat((x, xd), 1), n1, **kw)
+    return {'semi': semi, 'desc': desc, 'objects': detect(sd, P + "Detect", [xf, xg, p5], nc, training)}
+
+
 def fuse_conv_bn(w, gamma, beta, mean, var, eps=BN_EPS):
     """utils/torch_utils_yolo.py:194-214: W' = diag(g/sqrt(v+eps)) W ; b' = beta - g*mean/sqrt(v+eps)."""
     scale = gamma / torch.sqrt(eps + var)

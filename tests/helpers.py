@@ -12,9 +12,9 @@ def layout_of(model):
     return [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
 
 
-def make_model(version, seed, names=NAMES80, dtype="f32"):
+def make_model(version, seed, names=NAMES80, dtype="f32", model_name="YOLOPoint"):
     """Product model + the synthetic reference-layout state_dict loaded into it."""
-    m = models.Model(names=names, model_name="YOLOPoint", version=version)
+    m = models.Model(names=names, model_name=model_name, version=version)
     sd = net_oracle.synth_state_dict(layout_of(m), seed)
     m.load_state_dict(sd, strict=True)
     m.set_compute_dtype(dtype)

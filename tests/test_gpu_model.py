@@ -101,3 +101,20 @@ def test_multistream_graph_equals_eager(cuda):
     for k in ("semi", "desc"):
         assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k
     assert torch.equal(a["objects"][0], b["objects"][0]) and torch.equal(a["objects"][0], c["objects"][0])
+
+
+@pytest.mark.parametrize("version,B,S,dtype", [("n", 2, 64, "f32"), ("s", 1, 128, "f32"), ("s", 1, 128, "f16")])
+def test_forward_v52(cuda, version, B, S, dtype):
+    """YOLOPointv52 (C2f blocks, MaxPool2d descriptor branch, 65-channel C2f keypoint head) against the oracle."""
+    m, sd = make_model(version, 23, dtype=dtype, model_name="YOLOPointv52")
+    x = net_oracle.synth_image(B, 3, S, S, 23)
+    with torch.no_grad():
+        ref = net_oracle.yolopointv52_forward(sd, x, version)
+        got = m.to(cuda)(x.to(cuda))
+    tol = 1e-3 if dtype == "f32" else 1e-2
+    for name in ("semi", "desc"):
+        assert got[name].shape == ref[name].shape
+        assert rel_err(got[name], ref[name])[0] < tol, (name, rel_err(got[name], ref[name]))
+    assert rel_err(got["objects"][0], ref["objects"][0])[1 if dtype != "f32" else 0] < (1e-3 if dtype == "f32" else 2e-2)
+    if dtype == "f32":
+        assert torch.equal(got["semi"].argmax(1).cpu(), ref["semi"].argmax(1))

@@ -36,6 +36,14 @@ def test_state_dict_layout_matches_reference(lay, v):
     assert [k for k, _ in m.named_parameters()] == lay[v]["named_parameters"]     # freeze_layers() indices
 
 
+@pytest.mark.parametrize("v", ["n", "s"])
+def test_v52_state_dict_layout_matches_reference(lay, v):
+    m = models.Model(names=NAMES80, model_name="YOLOPointv52", version=v)
+    assert [[k, list(t.shape)] for k, t in m.state_dict().items()] == lay["v52_" + v]["state_dict"]
+    assert sum(p.numel() for p in m.parameters()) == lay["v52_" + v]["n_params"]
+    assert [k for k, _ in m.named_parameters()] == lay["v52_" + v]["named_parameters"]
+
+
 def test_fused_and_single_class_layouts(lay):
     m = models.Model(names=NAMES80, version="n").eval().fuse()
     assert [[k, list(t.shape)] for k, t in m.state_dict().items()] == lay["n_fused"]["state_dict"]

@@ -46,6 +46,18 @@ def test_network_eval(lay, net, tag, v, B, S, seed):
     assert np.array_equal(o["semi"].argmax(1).numpy(), net[f"{tag}.semi"].argmax(1))
 
 
+@pytest.mark.parametrize("tag,v,B,S,seed", [("v52n64", "n", 2, 64, 23), ("v52s128", "s", 1, 128, 23)])
+def test_network_v52(lay, net, tag, v, B, S, seed):
+    layout = [(k, tuple(s)) for k, s in lay["v52_" + v]["state_dict"]]
+    sd = net_oracle.synth_state_dict(layout, seed)
+    x = net_oracle.synth_image(B, 3, S, S, seed)
+    with torch.no_grad():
+        o = net_oracle.yolopointv52_forward(sd, x, v)
+    np.testing.assert_allclose(o["semi"].numpy(), net[f"{tag}.semi"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(o["desc"].numpy(), net[f"{tag}.desc"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(o["objects"][0].numpy(), net[f"{tag}.pred"], rtol=1e-4, atol=1e-4)
+
+
 def test_network_train_mode_and_fuse(lay, net):
     layout = [(k, tuple(s)) for k, s in lay["n"]["state_dict"]]
     sd = net_oracle.synth_state_dict(layout, 21)

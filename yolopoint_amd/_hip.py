@@ -46,7 +46,7 @@ class YpOpArgs(C.Structure):
 
 
 (OP_BN_STATS, OP_BN_APPLY, OP_BN_BWD, OP_UPS2_BWD, OP_ADD_VIEWS, OP_MAXPOOL5_BWD, OP_L2NORM_BWD, OP_DETECT_BWD_PACK, OP_TO_CHWB,
- OP_COL_SUM, OP_MEMSET0, OP_PACK_NCHW, OP_L2NORM, OP_SPPF_POOL, OP_CAST_F32) = range(10, 25)
+ OP_COL_SUM, OP_MEMSET0, OP_PACK_NCHW, OP_L2NORM, OP_SPPF_POOL, OP_CAST_F32, OP_MAXPOOL2) = range(10, 26)
 
 _i, _f, _p, _sz, _i64 = C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_int64
 # name -> (restype, argtypes); must list every symbol of include/yolopoint_hip.h
@@ -60,6 +60,7 @@ SIGNATURES = {
     "yp_pack_input": (_i, [_p, _i, _i, _i, _i, YpView, _i, _p]),
     "yp_unpack_nchw": (_i, [YpView, _i, _i, _i, _p, _p]),
     "yp_sppf_pool": (_i, [YpView, YpView, YpView, YpView, _i, _i, _p]),
+    "yp_maxpool2": (_i, [YpView, YpView, _i, _i, _p]),
     "yp_l2norm_f32": (_i, [YpView, YpView, _i, _i, _p]),
     "yp_detect_decode": (_i, [YpView, _i, _i, _i, _f, C.POINTER(_f), _p, _p, _i, _i, _p]),
     "yp_bn_workspace_bytes": (_sz, [_i, _i, _i, _i]),

@@ -166,6 +166,38 @@ __global__ __launch_bounds__(256) void sppf_pool_lds_kernel(const char* __restri
     rowpass(p0, p1); colpass(p1, p2, y3, y3cs, y3co);     // y3 = m(y2)
 }
 
+// ------------------------------------------------------------------ MaxPool2d(2, 2)  (YOLOPointv52 descriptor branch)
+template <int DT>
+__global__ void maxpool2_kernel(const char* __restrict__ x, int xcs, int xco, char* __restrict__ y, int ycs, int yco, int B, int Ho, int Wo, int C) {
+    using T = typename Sc<DT>::t;
+    constexpr int CE = 16 / sizeof(T);
+    const int chunks = C / CE;
+    const size_t n = (size_t)B * Ho * Wo * chunks;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % chunks);
+        const size_t pix = i / chunks;
+        const int w = (int)(pix % Wo), h = (int)((pix / Wo) % Ho);
+        const size_t b = pix / ((size_t)Wo * Ho);
+        float m[CE];
+#pragma unroll
+        for (int j = 0; j < CE; ++j) m[j] = -FLT_MAX;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const u32x4 raw = *reinterpret_cast<const u32x4*>(x + (((b * 2 * Ho + 2 * h + dy) * 2 * Wo + 2 * w + dx) * xcs + xco + ch * CE) * sizeof(T));
+                const T* e = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+                for (int j = 0; j < CE; ++j) m[j] = fmaxf(m[j], (float)e[j]);
+            }
+        u32x4 o;
+        T* eo = reinterpret_cast<T*>(&o);
+#pragma unroll
+        for (int j = 0; j < CE; ++j) eo[j] = (T)m[j];
+        *reinterpret_cast<u32x4*>(y + (pix * ycs + yco + ch * CE) * sizeof(T)) = o;
+    }
+}
+
 // ------------------------------------------------------------------ descriptor L2 norm (fp32)
 // one wavefront per pixel: lanes stride over channels, butterfly-reduce the sum of squares.
 __global__ void l2norm_kernel(const float* __restrict__ in, int ics, int ico, float* __restrict__ out, int ocs, int oco,
@@ -314,6 +346,23 @@ extern "C" int yp_detect_decode(YpView raw, int B, int na, int no, float stride,
     const int g = grid_for(n, 256);
     detect_decode_kernel<<<g, 256, 0, (hipStream_t)stream>>>((const float*)raw.ptr, raw.cstride, raw.coff, B, na, no, raw.H, raw.W,
                                                             stride, anc, x_out, z_out, rows_total, row_offset);
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
+extern "C" int yp_maxpool2(YpView x, YpView y, int B, int dtype, void* stream) {
+    const int ce = dtype == YP_F32 ? 4 : 8;
+    YP_REQUIRE(x.ptr && y.ptr && B > 0 && x.C > 0 && x.C == y.C && x.C % ce == 0, "yp_maxpool2: bad views");
+    YP_REQUIRE(x.H == 2 * y.H && x.W == 2 * y.W && x.cstride % ce == 0 && x.coff % ce == 0 && y.cstride % ce == 0 && y.coff % ce == 0, "yp_maxpool2: dims / alignment");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)B * y.H * y.W * (x.C / ce);
+    const int g = grid_for(n, 256);
+    switch (dtype) {
+        case YP_F16: maxpool2_kernel<YP_F16><<<g, 256, 0, st>>>((const char*)x.ptr, x.cstride, x.coff, (char*)y.ptr, y.cstride, y.coff, B, y.H, y.W, x.C); break;
+        case YP_BF16: maxpool2_kernel<YP_BF16><<<g, 256, 0, st>>>((const char*)x.ptr, x.cstride, x.coff, (char*)y.ptr, y.cstride, y.coff, B, y.H, y.W, x.C); break;
+        case YP_F32: maxpool2_kernel<YP_F32><<<g, 256, 0, st>>>((const char*)x.ptr, x.cstride, x.coff, (char*)y.ptr, y.cstride, y.coff, B, y.H, y.W, x.C); break;
+        default: YP_REQUIRE(false, "yp_maxpool2: bad dtype %d", dtype);
+    }
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
 }

@@ -598,6 +598,7 @@ extern "C" int yp_run_op(const YpOpArgs* a, void* stream) {
         case YP_OP_L2NORM: return yp_l2norm_f32(a->v[0], a->v[1], B, a->i[2], stream);
         case YP_OP_SPPF_POOL: return yp_sppf_pool(a->v[0], a->v[1], a->v[2], a->v[3], B, dt, stream);
         case YP_OP_CAST_F32: return yp_cast_from_f32(a->v[0], a->v[1], dt, B, stream);
+        case YP_OP_MAXPOOL2: return yp_maxpool2(a->v[0], a->v[1], B, dt, stream);
     }
     yp_set_error("yp_run_op: unknown opcode %d", a->op);
     return YP_ERR_INVALID;

@@ -17,7 +17,7 @@ from .. import _hip
 from ..plan import PlanBuilder, pack_input
 from ..utils.general_yolo import make_divisible, LOGGER
 from ..utils.torch_utils_yolo import fuse_conv_and_bn
-from .common import Conv, C3, SPPF, HipModule
+from .common import Conv, C3, C2f, SPPF, HipModule
 from .yolo import Detect
 
 anchors_default = [
@@ -158,6 +158,8 @@ class YOLOPoint(HipModule):
         if not (isinstance(x, torch.Tensor) and x.is_cuda):
             raise _hip.YpError("YOLOPoint.forward needs a cuda (HIP) tensor: the hot path has no CPU fallback")
         if self.training:
+            if isinstance(self, YOLOPointv52):
+                raise _hip.YpError("YOLOPointv52: the training path is built for YOLOPoint only (DESIGN.md section 7)")
             if any(not hasattr(m, "bn") for m in self.modules() if isinstance(m, Conv)):
                 raise _hip.YpError("a fused model (Model.fuse()) cannot run in train mode")
             from ..training import train_forward
@@ -170,7 +172,8 @@ class YOLOPoint(HipModule):
         pack_input(x, img.view(), plan.code)
         plan.run()
         semi = outs["semi"].buf.t[..., :65].permute(0, 3, 1, 2)
-        desc = outs["desc"].buf.t[..., :self.ConvDesc.out_channels].permute(0, 3, 1, 2)
+        dch = getattr(self, "_desc_channels", None) or self.ConvDesc.out_channels
+        desc = outs["desc"].buf.t[..., :dch].permute(0, 3, 1, 2)
         xs = list(outs["xs"])
         z = outs["z"]
         if not self.static_outputs:
@@ -178,6 +181,83 @@ class YOLOPoint(HipModule):
             z = z.clone() if z is not None else None
         objects = xs if self.training else (z, xs)
         return {'semi': semi, 'desc': desc, 'objects': objects}
+
+
+class YOLOPointv52(YOLOPoint):
+    """C2f variant (reference: models/YOLOPoint.py:248-342): no Conv6/Conv7, a 65-channel C2f as keypoint head, MaxPool2d(2,2)
+    on the stride-4 features for the descriptor branch.  Inference (eval) only in this build."""
+
+    def __init__(self, width_multiple=1., depth_multiple=1., inp_ch=3, nc=80, anchors=None):
+        HipModule.__init__(self)
+        c1, c2, c3, c4, c5 = [make_divisible(2 ** k * width_multiple, 8) for k in range(6, 11)]
+        n1, n2, n3 = [max(round(k * depth_multiple), 1) for k in (3, 6, 9)]
+        self.Conv1 = Conv(inp_ch, c1, 6, 2, 2)
+        self.Conv2 = Conv(c1, c2, 3, 2)
+        self.Bottleneck1 = C2f(c2, c2, n1)
+        self.Conv3 = Conv(c2, c3, 3, 2)
+        self.Bottleneck2 = C2f(c3, c3, n2)
+        self.Conv4 = Conv(c3, c4, 3, 2)
+        self.Bottleneck3 = C2f(c4, c4, n3)
+        self.Conv5 = Conv(c4, c4, 3, 2)
+        self.Bottleneck4 = C2f(c4, c4, n1)
+        self.SPPooling = SPPF(c4, c4, 5)
+        self.Bottleneck5 = C2f(c5, c4, n1)
+        self.Bottleneck6 = C2f(c4 + c3, c3, n1)
+        self.Conv8 = Conv(c3, c3, 3, 2, 1)
+        self.Bottleneck7 = C2f(c4 + c3, c4, n1)
+        self.Conv9 = Conv(c4, c4, 3, 2, 1)
+        self.Bottleneck8 = C2f(c5, c4, n1)
+        self.Detect = Detect(nc, anchors=anchors, ch=(c3, c4, c4))
+        self.BottleneckDet = C2f(c3, 65, n1)
+        self.ConvDescB = Conv(c3, c2, 3, 2, 1)
+        self.MaxPool = torch.nn.MaxPool2d(kernel_size=2, stride=2)
+        self.ups = torch.nn.Upsample(scale_factor=(2, 2), mode='nearest')
+        self.BottleneckDesc = C2f(c3, c3, n1)
+        self.static_outputs = False
+        self._desc_channels = c3
+
+    def emit(self, pb, img, decode=True):
+        """Dataflow of reference models/YOLOPoint.py:294-342."""
+        def run(name, mod, x, **kw):
+            pb.scope.append(name)
+            try:
+                return mod.emit(pb, x, **kw)
+            finally:
+                pb.scope.pop()
+
+        x = run("Conv1", self.Conv1, img)
+        x = run("Conv2", self.Conv2, x)
+        xa = run("Bottleneck1", self.Bottleneck1, x)
+        x8 = run("Conv3", self.Conv3, xa)
+        semi = run("BottleneckDet", self.BottleneckDet, x8, out_f32=True)
+        xb = run("Bottleneck2", self.Bottleneck2, x8)
+        dA = pb.new_buf(xa.LH // 2, xa.LW // 2, xa.C).view()
+        pb.scope.append("MaxPool")
+        pb.op(_hip.OP_MAXPOOL2, [xa], [dA], "", v=[xa, dA], i=[pb.code, pb.B])
+        pb.scope.pop()
+        dB = run("ConvDescB", self.ConvDescB, xb)
+        desc = run("BottleneckDesc", self.BottleneckDesc, [dA, dB.up()], out_f32=True)
+        pb.scope.append("BottleneckDesc")
+        pb.l2norm(desc, desc, self._desc_channels)
+        pb.scope.pop()
+        x = run("Conv4", self.Conv4, xb)
+        xc = run("Bottleneck3", self.Bottleneck3, x)
+        x = run("Conv5", self.Conv5, xc)
+        x = run("Bottleneck4", self.Bottleneck4, x)
+        xd = run("SPPooling", self.SPPooling, x)
+        xe = run("Bottleneck5", self.Bottleneck5, [xd.up(), xc])
+        xf = run("Bottleneck6", self.Bottleneck6, [xe.up(), xb])
+        x = run("Conv8", self.Conv8, xf)
+        xg = run("Bottleneck7", self.Bottleneck7, [x, xe])
+        x = run("Conv9", self.Conv9, xg)
+        p5 = run("Bottleneck8", self.Bottleneck8, [x, xd])
+        pb.scope.append("Detect")
+        z, xs = self.Detect.emit(pb, [xf, xg, p5], decode=decode)
+        pb.scope.pop()
+        return {"semi": semi, "desc": desc, "z": z, "xs": xs}
+
+    def _train_graph(self, x):
+        raise _hip.YpError("YOLOPointv52: the training path is built for YOLOPoint only (DESIGN.md section 7)")
 
 
 class Model(nn.Module):

@@ -1,2 +1,2 @@
 from .YOLOPoint import *   # noqa: F401,F403  (reference: src/models/__init__.py)
-from .YOLOPoint import Model, YOLOPoint
+from .YOLOPoint import Model, YOLOPoint, YOLOPointv52

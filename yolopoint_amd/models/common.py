@@ -94,7 +94,7 @@ class Conv(HipModule):
             return fold_bn(self.conv, self.bn)
         return self.conv.weight.detach().float(), (self.conv.bias.detach().float() if self.conv.bias is not None else None)
 
-    def emit(self, pb, x, out=None, res=None):
+    def emit(self, pb, x, out=None, res=None, out_f32=False):
         w, b = self.folded()
         act = _hip.YP_ACT_SILU if isinstance(self.act, nn.SiLU) else _hip.YP_ACT_NONE
         if not isinstance(self.act, (nn.SiLU, nn.Identity)):
@@ -102,7 +102,7 @@ class Conv(HipModule):
         k, s, p = self.conv.kernel_size[0], self.conv.stride[0], self.conv.padding[0]
         pb.scope.append("conv")
         try:
-            return pb.conv(x, w, b, k, s, p, act, out=out, res=res)
+            return pb.conv(x, w, b, k, s, p, act, out=out, res=res, out_f32=out_f32)
         finally:
             pb.scope.pop()
 
@@ -158,6 +158,52 @@ class C3(HipModule):
             t = blk.emit(pb, t, out=cat.view(0, c_) if i == n - 1 else None)
             pb.scope.pop()
         pb.scope.append("cv3"); y = self.cv3.emit(pb, cat.view(), out=out); pb.scope.pop()
+        return y
+
+
+class Bottleneckv8(HipModule):
+    """cv2(cv1(x)) [+ x], both k x k  (reference: models/common.py:91-103)."""
+
+    def __init__(self, c1, c2, shortcut=True, g=1, k=(3, 3), e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, k[0], 1)
+        self.cv2 = Conv(c_, c2, k[1], 1, g=g)
+        self.add = shortcut and c1 == c2
+
+    def _standalone_out_channels(self):
+        return self.cv2.conv.out_channels
+
+    def emit(self, pb, x, out=None):
+        pb.scope.append("cv1"); t = self.cv1.emit(pb, x); pb.scope.pop()
+        pb.scope.append("cv2"); y = self.cv2.emit(pb, t, out=out, res=x if self.add else None); pb.scope.pop()
+        return y
+
+
+class C2f(HipModule):
+    """cv2(cat(chunk(cv1(x), 2) + [m_i(previous)]))  (reference: models/common.py:151-171).  cv1 writes channels
+    [0, 2c) of the concat buffer, bottleneck i reads slice (1+i) and writes slice (2+i): no chunk / cat copies."""
+
+    def __init__(self, c1, c2, n=1, shortcut=False, g=1, e=0.5):
+        super().__init__()
+        self.c = int(c2 * e)
+        self.cv1 = Conv(c1, 2 * self.c, 1, 1)
+        self.cv2 = Conv((2 + n) * self.c, c2, 1)
+        self.m = nn.ModuleList(Bottleneckv8(self.c, self.c, shortcut, g, k=((3, 3), (3, 3)), e=1.0) for _ in range(n))
+
+    def _standalone_out_channels(self):
+        return self.cv2.conv.out_channels
+
+    def emit(self, pb, x, out=None, out_f32=False):
+        c, n = self.c, len(self.m)
+        if c % 8:
+            raise _hip.YpError(f"C2f hidden width {c} must be a multiple of 8")
+        x0 = x[0] if isinstance(x, (list, tuple)) else x
+        cat = pb.new_buf(x0.LH, x0.LW, (2 + n) * c)
+        pb.scope.append("cv1"); self.cv1.emit(pb, x, out=cat.view(0, 2 * c)); pb.scope.pop()
+        for i, blk in enumerate(self.m):
+            pb.scope.append(f"m.{i}"); blk.emit(pb, cat.view((1 + i) * c, c), out=cat.view((2 + i) * c, c)); pb.scope.pop()
+        pb.scope.append("cv2"); y = self.cv2.emit(pb, cat.view(), out=out, out_f32=out_f32); pb.scope.pop()
         return y
 
 
