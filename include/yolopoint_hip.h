@@ -120,6 +120,12 @@ typedef struct YpDetectDesc {
     int32_t rows_total, row_offset;
 } YpDetectDesc;
 int yp_conv2d_detect(const YpConvDesc* d, const YpDetectDesc* det, void* stream);
+/* Stem convolution (k=6, s=2, p=2, <= 4 input channels, Cout in {16,32,48,64}) straight from an NCHW fp32 image:
+ * out = act(conv(x) + bias) as NHWC `dtype` (f16 / bf16).  `weight` is the packed filter of the 16-bit stem
+ * ([Cout][6][3][8] rows of pitch Kpad, see yolopoint_amd/plan.py).  Replaces yp_pack_input + yp_conv2d for
+ * reference models/YOLOPoint.py:156,200. */
+int yp_stem_conv(const float* x_nchw, int B, int C, int H, int W, const void* weight, int Kpad, const float* bias, int act,
+                 YpView out, int dtype, void* stream);
 /* K padding granule the packer must use for `dtype` */
 int yp_conv_kpad(int K, int dtype);
 

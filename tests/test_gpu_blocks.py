@@ -171,3 +171,20 @@ def test_conv3x3_halo_fp32_head_output(cuda):
     plan.run()
     assert out.buf.t.dtype == torch.float32
     assert rel_err(unpack_nchw(out, _hip.YP_F32, B, C), ref)[0] < TOL["f16"]
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("cout,B,H,W", [(16, 2, 64, 64), (32, 1, 96, 160), (48, 1, 32, 64), (64, 2, 48, 80)])
+def test_fused_stem_kernel(cuda, cout, B, H, W, dtype):
+    """yp_stem_conv (NCHW fp32 image -> Conv 6x6/s2/p2 + bias + SiLU -> NHWC) against the oracle's Conv block."""
+    m = Conv(3, cout, 6, 2, 2).eval()
+    sd = block_state(m, 17, "blk.")
+    x = net_oracle.synth_image(B, 3, H, W, 3) - 0.5
+    ref = net_oracle.conv_block(sd, "blk", x, 6, 2, 2)
+    code = _hip.dtype_code(dtype)
+    pb = PlanBuilder(B, code, cuda)
+    w, b = m.folded()
+    out, launch = pb.stem(w, b, _hip.YP_ACT_SILU, H, W)
+    launch(x.to(cuda).contiguous())
+    got = unpack_nchw(out, code, B, cout)
+    assert rel_err(got, ref)[0] < TOL[dtype], (cout, dtype, rel_err(got, ref))

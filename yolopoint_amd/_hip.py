@@ -57,6 +57,7 @@ SIGNATURES = {
     "yp_conv2d": (_i, [C.POINTER(YpConvDesc), _p]),
     "yp_conv2d_detect": (_i, [C.POINTER(YpConvDesc), C.POINTER(YpDetectDesc), _p]),
     "yp_conv_kpad": (_i, [_i, _i]),
+    "yp_stem_conv": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _i, YpView, _i, _p]),
     "yp_pack_input": (_i, [_p, _i, _i, _i, _i, YpView, _i, _p]),
     "yp_unpack_nchw": (_i, [YpView, _i, _i, _i, _p, _p]),
     "yp_sppf_pool": (_i, [YpView, YpView, YpView, YpView, _i, _i, _p]),

@@ -694,6 +694,136 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvKArgs a) {
     }
 }
 
+
+// ==========================================================================================
+// Stem: Conv(inp_ch<=4 -> Cout, k=6, s=2, p=2) straight from the caller's NCHW fp32 image
+// (reference models/YOLOPoint.py:156 + the implicit layout change of `model(inp)`).
+// A workgroup owns 8 x 16 output pixels x all Cout channels.  Its 20 x 36 input halo is read from the
+// three fp32 planes (coalesced along x), converted and stored in LDS as 4-channel pixels, i.e. 16-byte
+// pixel PAIRS; with stride 2 the pair a tap (r, s' = s/2) needs for output x is pair (x + s') of halo row
+// (2y + r): consecutive lanes read consecutive 16-byte pairs.  K = 6 rows x 3 pairs x 8 = 144 (5 MFMA k
+// steps, the last half empty); the filter ([Cout][6][3][8], the layout the packer already produces for
+// the generic path) stays in registers.  No separate pack kernel, no NHWC copy of the image in HBM.
+// ==========================================================================================
+template <int DT, int FN>
+__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ x, int B, int C, int H, int W, const char* __restrict__ wgt,
+                                                        int Kpad, const float* __restrict__ bias, int act, char* __restrict__ out, int out_cs,
+                                                        int out_co, int Cout, int tiles_x, int tiles_y) {
+    using E = Elem<DT>;
+    using frag_t = typename E::frag;
+    using sc = typename E::scalar;
+    constexpr int TH = 8, TW = 64, HH = 2 * TH + 4, HPAIR = TW + 2;      // halo: 20 rows x 66 pixel pairs (132 columns)
+    constexpr int XF = TW / 16;                                          // x fragments per output row
+    constexpr int LPG = 4 * FN;
+    __shared__ __attribute__((aligned(16))) sc halo[HH * HPAIR * 8];
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int Ho = H / 2, Wo = W / 2;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // ---- halo fill.  A "line" is one (channel, halo row): 66 aligned float2 loads (pair j <- columns 2j, 2j+1 of input row
+    // 2*y0-2+row, starting at column 2*x0-2).  Each wave takes every 4th line, lanes take pairs; 5 lines are in flight at once.
+    const size_t plane = (size_t)H * W;
+    constexpr int LINES = 4 * HH;                 // channel 3 is the zero pad
+    for (int l0 = wave; l0 < LINES; l0 += 4 * 5) {
+        float2 v[5][2];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int line = l0 + 4 * u;
+            const int ch = line / HH, row = line - ch * HH;
+            const int iy = 2 * y0 - 2 + row;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int j = lane + 64 * h;
+                const int ix = 2 * x0 - 2 + 2 * j;
+                v[u][h] = make_float2(0.f, 0.f);
+                if (line < LINES && ch < C && j < HPAIR && (unsigned)iy < (unsigned)H && ix >= 0 && ix + 1 < W)
+                    v[u][h] = *reinterpret_cast<const float2*>(x + ((size_t)b * C + ch) * plane + (size_t)iy * W + ix);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int line = l0 + 4 * u;
+            const int ch = line / HH, row = line - ch * HH;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int j = lane + 64 * h;
+                if (line < LINES && j < HPAIR) {
+                    halo[(row * HPAIR + j) * 8 + ch] = (sc)v[u][h].x;
+                    halo[(row * HPAIR + j) * 8 + 4 + ch] = (sc)v[u][h].y;
+                }
+            }
+        }
+    }
+    // ---- filter fragments: lane (n = lane%16, g = lane/16) holds W[n][(4*kk + g)*8 .. +8] for kk = 0..4
+    const int p = lane & 15, g = lane >> 4;
+    frag_t wf[FN][5];
+#pragma unroll
+    for (int f = 0; f < FN; ++f) {
+        // MFMA row (f, g', r) <-> channel g'*LPG + f*4 + r  (same interleave as the other kernels)
+        const int n = (p >> 2) * LPG + f * 4 + (p & 3);
+#pragma unroll
+        for (int kk = 0; kk < 5; ++kk) {
+            const int q = 4 * kk + g;
+            if (q < 18 && n < Cout) wf[f][kk] = *reinterpret_cast<const frag_t*>(wgt + ((size_t)n * Kpad + q * 8) * 2);
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) wf[f][kk][j] = (sc)0.f;
+            }
+        }
+    }
+    float bv[LPG];
+#pragma unroll
+    for (int j = 0; j < LPG; ++j) bv[j] = (bias != nullptr && g * LPG + j < Cout) ? bias[g * LPG + j] : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int fm = 0; fm < 2; ++fm) {
+        const int yl = wave * 2 + fm;
+        const int oy = y0 + yl;
+#pragma unroll
+        for (int xf_ = 0; xf_ < XF; ++xf_) {
+            f32x4 acc[FN];
+#pragma unroll
+            for (int f = 0; f < FN; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 5; ++kk) {
+                const int q = 4 * kk + g;
+                const int r = q / 3, sp = q - r * 3;
+                frag_t xv;
+                if (q < 18) xv = *reinterpret_cast<const frag_t*>(&halo[((2 * yl + r) * HPAIR + xf_ * 16 + p + sp) * 8]);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xv[j] = (sc)0.f;
+                }
+#pragma unroll
+                for (int f = 0; f < FN; ++f) acc[f] = E::mma(wf[f][kk], xv, acc[f]);
+            }
+            const int ox = x0 + xf_ * 16 + p;
+            if (oy >= Ho || ox >= Wo) continue;
+            const size_t m = ((size_t)b * Ho + oy) * Wo + ox;
+            constexpr int CW = (LPG % 8 == 0) ? 8 : 4;
+#pragma unroll
+            for (int h = 0; h < LPG / CW; ++h) {
+                const int nc = g * LPG + h * CW;
+                if (nc >= Cout) continue;
+                sc o[CW];
+#pragma unroll
+                for (int j = 0; j < CW; ++j) {
+                    const int cj = h * CW + j;
+                    float v = acc[cj >> 2][cj & 3] + bv[cj];
+                    if (act == YP_ACT_SILU) v = yp_silu(v);
+                    o[j] = (sc)v;
+                }
+                char* op = out + (m * out_cs + out_co + nc) * 2;
+                if constexpr (CW == 8) *reinterpret_cast<u32x4*>(op) = *reinterpret_cast<const u32x4*>(o);
+                else *reinterpret_cast<u32x2*>(op) = *reinterpret_cast<const u32x2*>(o);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -887,4 +1017,21 @@ extern "C" int yp_conv2d(const YpConvDesc* d, void* stream) { return yp_conv2d_l
 extern "C" int yp_conv2d_detect(const YpConvDesc* d, const YpDetectDesc* det, void* stream) {
     YP_REQUIRE(det != nullptr, "yp_conv2d_detect: null detect descriptor");
     return yp_conv2d_launch(d, det, (hipStream_t)stream);
+}
+
+extern "C" int yp_stem_conv(const float* x_nchw, int B, int C, int H, int W, const void* weight, int Kpad, const float* bias, int act, YpView out,
+                            int dtype, void* stream) {
+    YP_REQUIRE(x_nchw && weight && out.ptr && B > 0 && C > 0 && C <= 4 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "yp_stem_conv: bad arguments");
+    YP_REQUIRE(dtype == YP_F16 || dtype == YP_BF16, "yp_stem_conv: 16-bit compute types only");
+    YP_REQUIRE(out.H == H / 2 && out.W == W / 2 && out.C % 16 == 0 && out.C <= 64 && out.cstride % 8 == 0 && out.coff % 8 == 0 && Kpad >= 144, "yp_stem_conv: output view / filter mismatch");
+    const int tiles_x = yp_cdiv(W / 2, 64), tiles_y = yp_cdiv(H / 2, 8);
+    const int nblk = B * tiles_x * tiles_y;
+    hipStream_t st = (hipStream_t)stream;
+#define YP_STEM(DT, FN) stem_conv_kernel<DT, FN><<<nblk, 256, 0, st>>>(x_nchw, B, C, H, W, (const char*)weight, Kpad, bias, act, (char*)out.ptr, out.cstride, out.coff, out.C, tiles_x, tiles_y)
+    const int fn = out.C / 16;
+    if (dtype == YP_F16) { if (fn == 1) YP_STEM(YP_F16, 1); else if (fn == 2) YP_STEM(YP_F16, 2); else if (fn == 3) YP_STEM(YP_F16, 3); else YP_STEM(YP_F16, 4); }
+    else { if (fn == 1) YP_STEM(YP_BF16, 1); else if (fn == 2) YP_STEM(YP_BF16, 2); else if (fn == 3) YP_STEM(YP_BF16, 3); else YP_STEM(YP_BF16, 4); }
+#undef YP_STEM
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
 }

@@ -70,6 +70,26 @@ class YOLOPoint(HipModule):
         self.static_outputs = False
 
     # ---------------------------------------------------------------------------------
+    def _emit_stem(self, pb, img):
+        """Conv1.  16-bit eval plans use the fused stem kernel, which reads the caller's NCHW fp32 image directly
+        (no pack kernel, no NHWC image copy); its launch is handed back through pb.stem_launch."""
+        c = self.Conv1.conv
+        fusable = (pb.code != _hip.YP_F32 and c.kernel_size == (6, 6) and c.stride == (2, 2) and c.padding == (2, 2) and c.in_channels <= 4
+                   and c.out_channels % 16 == 0 and c.out_channels <= 64 and isinstance(self.Conv1.act, nn.SiLU) and getattr(self, "fuse_stem", True)
+                   and __import__("os").environ.get("YP_FUSE_STEM", "1") != "0")
+        pb.stem_launch = None
+        if not fusable:
+            pb.scope.append("Conv1")
+            try:
+                return self.Conv1.emit(pb, img)
+            finally:
+                pb.scope.pop()
+        w, b = self.Conv1.folded()
+        pb.scope.append("Conv1")
+        out, pb.stem_launch = pb.stem(w, b, _hip.YP_ACT_SILU, img.H, img.W)
+        pb.scope.pop()
+        return out
+
     def emit(self, pb, img, decode=True):
         """Dataflow of reference models/YOLOPoint.py:198-246; cat/ups are views, never copies."""
         def run(name, mod, x, **kw):
@@ -79,7 +99,7 @@ class YOLOPoint(HipModule):
             finally:
                 pb.scope.pop()
 
-        x = run("Conv1", self.Conv1, img)
+        x = self._emit_stem(pb, img)
         x = run("Conv2", self.Conv2, x)
         xa = run("Bottleneck1", self.Bottleneck1, x)
         x8 = run("Conv3", self.Conv3, xa)
@@ -132,10 +152,20 @@ class YOLOPoint(HipModule):
             img = pb.new_buf(H, W, 4)
             outs = self.emit(pb, img.view(), decode=not self.training)
             plan = pb.finish()
+            plan.stem_launch = pb.stem_launch
+            plan.stem_record = getattr(pb, "stem_record", None) if pb.stem_launch else None
             if graph:
                 plan.instantiate_graph()
             cache[key] = (plan, img, outs)
         return cache[key]
+
+    def run_plan(self, plan, img, x):
+        """Input hand-over + plan replay: the fused stem reads x directly, otherwise x is packed to NHWC first."""
+        if plan.stem_launch is not None:
+            plan.stem_launch(x)
+        else:
+            pack_input(x, img.view(), plan.code)
+        plan.run()
 
     def _train_graph(self, x):
         """A free TrainGraph (static forward + backward plans and all their buffers) for this input shape.  The two
@@ -169,8 +199,7 @@ class YOLOPoint(HipModule):
         if C_ > 4:
             raise _hip.YpError("inp_ch > 4 is not supported by the stem kernel")
         plan, img, outs = self.build_plan(B, H, W, x.device, graph=getattr(self, "use_graph", False))
-        pack_input(x, img.view(), plan.code)
-        plan.run()
+        self.run_plan(plan, img, x)
         semi = outs["semi"].buf.t[..., :65].permute(0, 3, 1, 2)
         dch = getattr(self, "_desc_channels", None) or self.ConvDesc.out_channels
         desc = outs["desc"].buf.t[..., :dch].permute(0, 3, 1, 2)
@@ -225,7 +254,7 @@ class YOLOPointv52(YOLOPoint):
             finally:
                 pb.scope.pop()
 
-        x = run("Conv1", self.Conv1, img)
+        x = self._emit_stem(pb, img)
         x = run("Conv2", self.Conv2, x)
         xa = run("Bottleneck1", self.Bottleneck1, x)
         x8 = run("Conv3", self.Conv3, xa)

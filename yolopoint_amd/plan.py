@@ -103,6 +103,15 @@ def pack_conv_weight(w, bias, code, device):
     return wp.to(device=device, dtype=_hip.torch_dtype(code)).contiguous(), bp.to(device).contiguous(), Kpad, Npad
 
 
+def pack_stem_weight(w, bias, code, device):
+    """OIHW [Cout, <=4, R, S even] -> the paired-pixel filter [Cout][R][S/2][8] the 16-bit stem kernels read."""
+    Cout, Cin, R, S = w.shape
+    wpad = torch.zeros((Cout, 4, R, S), dtype=torch.float32, device=w.device)
+    wpad[:, :Cin] = w
+    wpair = wpad.permute(0, 2, 3, 1).reshape(Cout, R, S // 2, 8).permute(0, 3, 1, 2).contiguous()
+    return pack_conv_weight(wpair, bias, code, device)
+
+
 class OpRecord:
     __slots__ = ("name", "kind", "flops", "bytes", "M", "N", "K")
 
@@ -303,6 +312,24 @@ class PlanBuilder:
         bytes_ = in_elems * eb + M * Cout * (4 if out_f32 else eb) * (2 if (detect is not None and detect['z_out'] is not None) else 1) + Cout * Kreal * eb
         self.records.append(OpRecord(self.name(), "conv", 2 * M * Cout * Kreal, bytes_, M, Cout, Kreal))
         return out
+
+    def stem(self, w, bias, act, H, W):
+        """Fused stem (yp_stem_conv): returns (output view, launch(x_nchw_fp32)).  The launch is NOT part of the plan: it
+        reads the caller's tensor directly, so it is enqueued eagerly right before the plan / graph replay."""
+        Cout = w.shape[0]
+        out = self.new_buf(H // 2, W // 2, Cout).view()
+        wp, bp, Kpad, _ = pack_stem_weight(w, bias, self.code, self.device)
+        self.keep += [wp, bp]
+        ov = out.c()
+        B, code = self.B, self.code
+
+        def launch(x, stream=None):
+            check(lib().yp_stem_conv(x.data_ptr(), B, x.shape[1], x.shape[2], x.shape[3], wp.data_ptr(), Kpad,
+                                     bp.data_ptr() if bias is not None else None, act, ov, code, _hip.stream_ptr(stream)))
+        Kreal = w.shape[1] * w.shape[2] * w.shape[3]
+        M = B * (H // 2) * (W // 2)
+        self.stem_record = OpRecord(self.name("stem"), "conv", 2 * M * Cout * Kreal, B * w.shape[1] * H * W * 4 + M * Cout * 2 + Cout * Kreal * 2, M, Cout, Kreal)
+        return out, launch
 
     def op(self, code, reads, writes, name, **kw):
         """Append a generic launch record (training-path kernels); kw: v=[Views], f/g/p=[tensors|ptr], n=[sizes], i=[ints], s=[floats]."""
