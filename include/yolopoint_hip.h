@@ -103,6 +103,16 @@ typedef struct YpConvDesc {
     int32_t tail_zero;               /* 1: each input buffer is followed by >= (cstride + 64) zero elements and
                                       * `weight` by one zero row [Kpad] -> the kernels may use their fast 32-bit
                                       * DMA addressing (padding taps are fetched from those zeros)              */
+    /* Pointwise prologue (fused Bottleneck, reference models/common.py:79-89): when pre_weight != NULL the 3x3 /
+     * stride-1 convolution reads act(conv1x1(in0, pre_weight) + pre_bias) instead of in0; the hidden tensor lives
+     * only in LDS.  Requires in0.C == out.C == hidden channels in {32, 64, 128}, a 16-bit dtype, tail_zero, no
+     * in1 / out2 / out_f32; `res` (normally in0 itself) is the shortcut.  tile: 0 auto, 10/11/12 = 32/64/128
+     * output channels per workgroup. */
+    const void* pre_weight;          /* packed [pre_Npad][pre_Kpad] 1x1 filter                                */
+    const float* pre_bias;
+    int32_t pre_Kpad, pre_Npad;
+    int32_t pre_act;
+    int32_t reserved_;
 } YpConvDesc;
 
 int yp_conv2d(const YpConvDesc* d, void* stream);

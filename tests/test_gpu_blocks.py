@@ -156,6 +156,63 @@ def test_conv3x3_halo_kernel(cuda, case, dtype):
     assert rel_err(outs["halo"], outs["generic"])[0] < TOL[dtype]
 
 
+BNECK_CASES = [
+    # C, B, H, W, tile (0 auto, 10/11/12 = 32/64/128 output channels per workgroup), shortcut
+    (32, 2, 24, 40, 0, True), (32, 1, 19, 23, 10, False), (64, 2, 20, 20, 11, True), (64, 1, 17, 33, 10, True),
+    (128, 1, 16, 16, 12, True), (128, 2, 9, 21, 11, False), (128, 1, 40, 40, 10, True),
+]
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("case", BNECK_CASES)
+def test_fused_bottleneck_kernel(cuda, case, dtype):
+    """Bottleneck with cv1 as the LDS prologue of cv2's 3x3 kernel (hidden tensor never in HBM) against torch fp32 and
+    against the two-launch form, which it must reproduce EXACTLY (same 16-bit rounding of the hidden tensor, same
+    accumulation order); ragged tiles (image borders inside the halo), every channel tile, sliced output."""
+    C_, B, H, W, tile, shortcut = case
+    torch.manual_seed(C_ + H + W)
+    code = _hip.dtype_code(dtype)
+    w1 = torch.randn(C_, C_, 1, 1) * (1.0 / C_ ** 0.5)
+    b1 = torch.randn(C_) * 0.2
+    w2 = torch.randn(C_, C_, 3, 3) * (1.0 / (3 * C_ ** 0.5))
+    b2 = torch.randn(C_) * 0.1
+    x = torch.randn(B, C_, H, W)
+    F = torch.nn.functional
+    ref = F.silu(F.conv2d(F.silu(F.conv2d(x, w1, b1)), w2, b2, 1, 1)) + (x if shortcut else 0)
+    outs = {}
+    for name in ("fused", "two"):
+        pb = PlanBuilder(B, code, cuda)
+        pb.autotune = False
+        xin = pb.new_buf(H, W, C_ + 8)
+        big = pb.new_buf(H, W, C_ + 16)
+        xv = xin.view(8, C_)
+        res = xv if shortcut else None
+        if name == "fused":
+            out = pb.conv(xv, w2, b2, 3, 1, 1, _hip.YP_ACT_SILU, out=big.view(8, C_), res=res, tile=tile,
+                          extra={"pre": (w1, b1, _hip.YP_ACT_SILU)})
+        else:
+            t = pb.conv(xv, w1, b1, 1, 1, 0, _hip.YP_ACT_SILU)
+            out = pb.conv(t, w2, b2, 3, 1, 1, _hip.YP_ACT_SILU, out=big.view(8, C_), res=res)
+        plan = pb.finish()
+        assert len(plan.records) == (1 if name == "fused" else 2)
+        pack_input(x.to(cuda), xv, code)
+        plan.run()
+        outs[name] = unpack_nchw(out, code, B, C_)
+        assert float(big.t[..., :8].abs().max()) == 0.0 and float(big.t[..., 8 + C_:].abs().max()) == 0.0
+    assert rel_err(outs["fused"], ref)[0] < TOL[dtype] * 2, (case, dtype)
+    assert torch.equal(outs["fused"], outs["two"]), (case, dtype, float((outs["fused"] - outs["two"]).abs().max()))
+
+
+def test_fused_bottleneck_rejects_unsupported(cuda):
+    pb = PlanBuilder(1, _hip.YP_F16, cuda)
+    pb.autotune = False
+    xin = pb.new_buf(8, 8, 256)
+    w1, w2 = torch.zeros(256, 256, 1, 1), torch.zeros(256, 256, 3, 3)
+    with pytest.raises(_hip.YpError):
+        pb.conv(xin.view(), w2, None, 3, 1, 1, _hip.YP_ACT_SILU, extra={"pre": (w1, None, _hip.YP_ACT_SILU)})
+        pb.finish().run()
+
+
 def test_conv3x3_halo_fp32_head_output(cuda):
     """ConvDesc-style use: 3x3, no bias, no activation, fp32 output from f16 operands."""
     torch.manual_seed(3)

@@ -32,7 +32,9 @@ class YpConvDesc(C.Structure):
                 ("stride_h", C.c_int32), ("stride_w", C.c_int32), ("pad_h", C.c_int32), ("pad_w", C.c_int32),
                 ("Kpad", C.c_int32), ("Npad", C.c_int32), ("act", C.c_int32), ("tile", C.c_int32),
                 ("dil_h", C.c_int32), ("dil_w", C.c_int32), ("in0_zero_stuffed", C.c_int32), ("ksplit", C.c_int32),
-                ("atomic_accumulate", C.c_int32), ("tail_zero", C.c_int32)]
+                ("atomic_accumulate", C.c_int32), ("tail_zero", C.c_int32),
+                ("pre_weight", C.c_void_p), ("pre_bias", C.c_void_p), ("pre_Kpad", C.c_int32), ("pre_Npad", C.c_int32),
+                ("pre_act", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class YpDetectDesc(C.Structure):

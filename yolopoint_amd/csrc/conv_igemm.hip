@@ -77,6 +77,9 @@ struct ConvKArgs {
     int act;
     int M, tiles_n;
     int tiles_x, tiles_y, Ho;      // 3x3 halo kernel: 8x16 output tiles
+    const char* pre_wgt;           // fused Bottleneck: 1x1 prologue filter / bias
+    const float* pre_bias;
+    int pre_Kpad, pre_act;
     // fused Detect decode (EPI_DETECT instantiations)
     int det_na, det_no, det_invno, det_rows_total, det_row_off;
     float det_stride;
@@ -247,10 +250,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     constexpr int FM = TM / 16, FN = TN / 16;
     constexpr int LPG = 4 * FN;          // consecutive channels owned by one lane
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
-    static_assert(BM % 64 == 0 && FM >= 1 && FN >= 1 && NS >= 2 && NS <= 4, "unsupported tile");
+    static_assert(BM % 64 == 0 && FM >= 1 && FN >= 1 && NS >= 2 && NS <= 8, "unsupported tile");
     static_assert(NL * (NS - 2) <= 60, "vmcnt immediate range");
 
-    __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE];
+    extern __shared__ __attribute__((aligned(1024))) char smem[];      // NS * STAGE bytes (dynamic: deep rings exceed 64 KiB)
 
     // ---- XCD-aware tile mapping: workgroup b runs on XCD b%8; give each XCD a contiguous run of
     // logical tiles so that tiles sharing input pixels / filter rows hit the same L2.
@@ -430,7 +433,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
         if (younger > NS - 2) younger = NS - 2;
         if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
+        else if (NS <= 4 || younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
+        else if (younger == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS > 4 ? 3 * NL : 0) : "memory");
+        else if (younger == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS > 5 ? 4 * NL : 0) : "memory");
+        else if (younger == 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS > 6 ? 5 * NL : 0) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS > 7 ? 6 * NL : 0) : "memory");
         __builtin_amdgcn_s_barrier();
         // every wave has finished reading tile kt-1: its stage can be refilled
         if (kt + NS - 1 < nk) issue_tile(kt0 + kt + NS - 1, (kt + NS - 1) % NS);
@@ -696,6 +703,249 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvKArgs a) {
 
 
 // ==========================================================================================
+// Fused Bottleneck (reference models/common.py:79-89): out = [x +] act2(conv3x3(act1(conv1x1(x)))) with
+// C = Cin = hidden = Cout in {32, 64, 128}.  Same 8 x 16 output tile as the halo kernel; the hidden tensor
+// never leaves the workgroup:
+//   phase A  the 10 x 18 halo of x (all C channels, NCH = C/32 chunks) and the 1x1 filter are DMA'd into LDS
+//            in ONE burst (no stage reuse -> a single counted wait + barrier per chunk); the four waves
+//            compute hidden[192 halo rows][C] (3 pixel fragments x C/16 channel fragments per wave), apply
+//            bias + activation, zero the rows that fall outside the image (the 3x3's padding acts on the
+//            HIDDEN tensor) and store it as 16-bit rows in exactly the swizzled 64-byte-row format the halo
+//            DMA would have produced;
+//   phase B  the halo kernel's tap loop, reading the halo from that resident LDS copy (no halo DMA at all);
+//            filter rows stream through the 3-stage ring, which re-uses the LDS of phase A's operands.
+// HBM traffic: x once (+ the shortcut re-read of the tile centre, an L2 hit) and out once -- the hidden
+// tensor's write + 9-tap read of the two-launch form disappear, as does one launch.
+// ==========================================================================================
+template <int DT, int C, int BN, int WAVES_M>
+__global__ __launch_bounds__(256) void bottleneck_halo_kernel(const ConvKArgs a) {
+    using E = Elem<DT>;
+    using frag_t = typename E::frag;
+    using sc = typename E::scalar;
+    static_assert(E::BYTES == 2, "fused bottleneck: 16-bit element types");
+    constexpr int EB = 2, BK = 32;
+    constexpr int TH = 8, TW = 16;
+    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int FM = TH / WAVES_M;
+    constexpr int TN = BN / WAVES_N, FN = TN / 16, LPG = 4 * FN;
+    constexpr int HH = 10, HP = 18;
+    constexpr int HROWS = HH * HP, HSLOTS = 12, NH = 3, HBYTES = HSLOTS * 1024;
+    constexpr int NCH = C / BK;                         // 32-channel chunks of x / of the hidden tensor
+    constexpr int NSUB = C / 32;                        // 32-channel sub-tiles of the hidden tensor (2 fragments each)
+    constexpr int WASLOTS = C / 16, NWA = (WASLOTS + 3) / 4, WABYTES = WASLOTS * 1024;
+    constexpr int ASTAGE = HBYTES + WABYTES;
+    constexpr int WSLOTS_TAP = BN / 16, WSLOTS = 3 * WSLOTS_TAP, NW = (WSLOTS + 3) / 4, WBYTES = WSLOTS * 1024;
+    constexpr int NLA = NH + NWA;                       // DMA instructions per wave per phase-A chunk
+    static_assert(HROWS <= HSLOTS * 16 && BN <= C && FN >= 1 && FM >= 1, "unsupported tile");
+
+    extern __shared__ __attribute__((aligned(1024))) char hsm[];      // [hidden: NCH x HBYTES][ring: phase A operands | filter rows]
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)hsm);
+    constexpr int RING = NCH * HBYTES;
+    const unsigned ldsR = lds0 + RING;
+
+    int bid = blockIdx.x;
+    const int tn = bid % a.tiles_n; bid /= a.tiles_n;
+    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y;
+    const int b = bid / a.tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW, n0 = tn * BN;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int lrow = lane >> 2;
+    const int jl = (lane & 3) ^ ((0x3300 >> ((lane >> 4) * 4)) & 3);
+
+    YP_PIN2(const char*, in0); YP_PIN2(const char*, wgt); YP_PIN2(const char*, pre_wgt);
+    YP_PIN2(int, in0_cs); YP_PIN2(int, in0_co); YP_PIN2(int, Hi); YP_PIN2(int, Wi); YP_PIN2(int, pre_Kpad);
+    YP_PIN2(unsigned, in0_zoff);
+
+    // ---- per-lane DMA byte offsets
+    unsigned hoff[NH];
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+        const int rho = (wave + 4 * i) * 16 + lrow;
+        const int hy = rho / HP, hx = rho - hy * HP;
+        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        const bool valid = rho < HROWS && (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi;
+        hoff[i] = valid ? (unsigned)(((b * Hi + iy) * Wi + ix) * in0_cs * EB) + (unsigned)jl * 16u : in0_zoff;
+    }
+    unsigned waoff[NWA];
+    int waslot[NWA];
+#pragma unroll
+    for (int i = 0; i < NWA; ++i) {
+        int sl = wave + 4 * i;
+        if (sl > WASLOTS - 1) sl = WASLOTS - 1;
+        waslot[i] = sl;
+        const int rho = sl * 16 + lrow;                 // LDS row -> hidden channel (lanes own 8 consecutive channels per sub-tile)
+        const int sub = rho >> 5, q = rho & 31;
+        const int n = sub * 32 + ((q & 15) >> 2) * 8 + (q >> 4) * 4 + (q & 3);
+        waoff[i] = (unsigned)n * (unsigned)pre_Kpad * EB + (unsigned)jl * 16u;
+    }
+    unsigned woff[NW];
+    int wslot[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        int sl = wave + 4 * i;
+        if (sl > WSLOTS - 1) sl = WSLOTS - 1;
+        wslot[i] = sl;
+        const int tap_s = sl / WSLOTS_TAP, rs = sl - tap_s * WSLOTS_TAP;
+        const int rho = rs * 16 + lrow;
+        const int wn_ = rho / TN, q = rho % TN;
+        const int f = q >> 4, g_ = (q & 15) >> 2, r_ = q & 3;
+        const int n = n0 + wn_ * TN + g_ * LPG + f * 4 + r_;
+        woff[i] = ((n < a.Npad) ? (unsigned)n * (unsigned)a.Kpad * EB : a.wgt_zrow) + (unsigned)jl * 16u + (unsigned)(tap_s * C * EB);
+    }
+
+    const int p = lane & 15, g = lane >> 4;
+    const int swr = (0x3300 >> ((p >> 2) * 4)) & 3;
+
+    // biases of both convolutions: ordinary loads issued before any DMA (the counted waits stay valid)
+    float b1[NSUB][8];
+#pragma unroll
+    for (int sb = 0; sb < NSUB; ++sb) {
+        f32x4 lo = f32x4{0.f, 0.f, 0.f, 0.f}, hi = lo;
+        if (a.pre_bias != nullptr) {
+            lo = *reinterpret_cast<const f32x4*>(a.pre_bias + sb * 32 + g * 8);
+            hi = *reinterpret_cast<const f32x4*>(a.pre_bias + sb * 32 + g * 8 + 4);
+        }
+        b1[sb][0] = lo[0]; b1[sb][1] = lo[1]; b1[sb][2] = lo[2]; b1[sb][3] = lo[3];
+        b1[sb][4] = hi[0]; b1[sb][5] = hi[1]; b1[sb][6] = hi[2]; b1[sb][7] = hi[3];
+    }
+    const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+    const int nb = n0 + wn * TN + g * LPG;
+    float bias[LPG];
+    yp_load_bias<LPG>(a, nb, bias);
+
+    // ---- phase A: everything in flight at once
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const char* hk = in0 + (size_t)(in0_co + c * BK) * EB;
+        const char* wk = pre_wgt + (size_t)(c * BK) * EB;
+#pragma unroll
+        for (int i = 0; i < NH; ++i) yp_glds16_s(hk, hoff[i], ldsR + c * ASTAGE + (wave + 4 * i) * 1024);
+#pragma unroll
+        for (int i = 0; i < NWA; ++i) yp_glds16_s(wk, waoff[i], ldsR + c * ASTAGE + HBYTES + waslot[i] * 1024);
+    }
+    f32x4 hacc[NSUB][2][3];
+#pragma unroll
+    for (int sb = 0; sb < NSUB; ++sb)
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) hacc[sb][f][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int a_rd = p * 64 + ((g ^ swr) << 4);          // fragment row p, k group g (both operand images use the same swizzle key)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (c == NCH - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (c == NCH - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLA) : "memory");
+        else if (c == NCH - 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NLA) : "memory");
+        __builtin_amdgcn_s_barrier();
+        const char* xb = hsm + RING + c * ASTAGE;
+        const char* wb = xb + HBYTES;
+        frag_t xf[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) xf[i] = *reinterpret_cast<const frag_t*>(xb + (wave * 3 + i) * 1024 + a_rd);
+#pragma unroll
+        for (int sb = 0; sb < NSUB; ++sb) {
+            frag_t wf[2];
+#pragma unroll
+            for (int f = 0; f < 2; ++f) wf[f] = *reinterpret_cast<const frag_t*>(wb + (sb * 32 + f * 16) * 64 + a_rd);
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) hacc[sb][f][i] = E::mma(wf[f], xf[i], hacc[sb][f][i]);
+        }
+    }
+    __builtin_amdgcn_s_barrier();            // every wave is done with phase A's operands: the ring may be overwritten
+#pragma unroll
+    for (int sb = 0; sb < NSUB; ++sb)        // make the compiler's own wait for the bias loads land here, not behind the prefetch below
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(b1[sb][j]));
+
+    auto issueW = [&](int c, int r) {        // filter row r of chunk c -> ring stage r
+        const char* wk = wgt + ((size_t)(r * 3) * C + (size_t)c * BK) * EB;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) yp_glds16_s(wk, woff[i], ldsR + r * WBYTES + wslot[i] * 1024);
+    };
+    issueW(0, 0);
+    issueW(0, 1);
+
+    // ---- hidden = act(hacc + b1), zero outside the image, 16-bit, into the resident halo image
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int rho = (wave * 3 + i) * 16 + p;
+        const int hy = rho / HP, hx = rho - hy * HP;
+        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        const bool inside = (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi;      // rows >= HROWS are never read
+#pragma unroll
+        for (int sb = 0; sb < NSUB; ++sb) {
+            u32x4 pk;
+            sc* e = reinterpret_cast<sc*>(&pk);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = hacc[sb][j >> 2][i][j & 3] + b1[sb][j];
+                if (a.pre_act == YP_ACT_SILU) v = yp_silu(v);
+                e[j] = (sc)(inside ? v : 0.0f);
+            }
+            *reinterpret_cast<u32x4*>(hsm + sb * HBYTES + rho * 64 + ((g ^ swr) << 4)) = pk;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    // ---- phase B: 3x3 over the resident hidden halo
+    const int w_rd = (wn * TN + p) * 64 + ((g ^ swr) << 4);
+    int x_row[FM];
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) x_row[fm] = (wm * FM + fm) * HP + p;
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int f = 0; f < FN; ++f)
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) acc[f][fm] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int nsteps = 3 * NCH;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int st = 3 * c + r;
+            if (st + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (st + 2 < nsteps) { const int s2 = st + 2; issueW(s2 / 3, s2 % 3); }
+            const char* hb = hsm + c * HBYTES;
+            const char* wb = hsm + RING + r * WBYTES;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int xc = s + r * HP;
+                frag_t wf[FN], xf[FM];
+#pragma unroll
+                for (int f = 0; f < FN; ++f) wf[f] = *reinterpret_cast<const frag_t*>(wb + w_rd + (s * BN + f * 16) * 64);
+#pragma unroll
+                for (int fm = 0; fm < FM; ++fm) {
+                    const int rho = x_row[fm] + xc;
+                    const int sw = (0x3300 >> (((rho >> 2) & 3) * 4)) & 3;
+                    xf[fm] = *reinterpret_cast<const frag_t*>(hb + rho * 64 + ((g ^ sw) << 4));
+                }
+#pragma unroll
+                for (int f = 0; f < FN; ++f)
+#pragma unroll
+                    for (int fm = 0; fm < FM; ++fm) acc[f][fm] = E::mma(wf[f], xf[fm], acc[f][fm]);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) {
+        const int oy = y0 + wm * FM + fm, ox = x0 + p;
+        if (oy >= a.Ho || ox >= a.Wo) continue;
+        const int m = (b * a.Ho + oy) * a.Wo + ox;
+        yp_epilogue_pixel<DT, false, LPG>(a, m, nb, bias, [&](int cj) { return acc[cj >> 2][fm][cj & 3]; });
+    }
+}
+
+
+// ==========================================================================================
 // Stem: Conv(inp_ch<=4 -> Cout, k=6, s=2, p=2) straight from the caller's NCHW fp32 image
 // (reference models/YOLOPoint.py:156 + the implicit layout change of `model(inp)`).
 // A workgroup owns 8 x 16 output pixels x all Cout channels.  Its 20 x 36 input halo is read from the
@@ -830,19 +1080,36 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
 namespace {
 
 struct TileCfg { int id, bm, bn; };
+// 4-stage rings.  (8-stage rings -- 7 k tiles in flight -- were measured on every 1x1 layer shape of YOLOPoint-s and were
+// never faster: the k loop is not the latency chain that bounds the short layers.  The kernel keeps NS a parameter.)
 constexpr TileCfg kTiles[] = {{1, 128, 32}, {2, 128, 64}, {3, 128, 128}, {4, 64, 64}, {5, 64, 32}};
+
+template <int DT, bool OUT_F32, bool FAST, bool DETECT, int BM, int BN, int WAVES_M, int WAVES_N, int NS>
+hipError_t launch_tile(const ConvKArgs& a, int nblk, hipStream_t st) {
+    constexpr size_t lds = (size_t)NS * (BM / 16 + BN / 16) * 1024;
+    auto kern = conv_igemm_kernel<DT, OUT_F32, FAST, DETECT, BM, BN, WAVES_M, WAVES_N, NS>;
+    if constexpr (lds > 65536) {
+        static bool attr_set = false;        // per instantiation
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            attr_set = true;
+        }
+    }
+    kern<<<dim3(nblk, a.ksplit), 256, lds, st>>>(a);
+    return hipGetLastError();
+}
 
 template <int DT, bool OUT_F32, bool FAST, bool DETECT = false>
 hipError_t launch_cfg(int tile, const ConvKArgs& a, int nblk, hipStream_t st) {
     switch (tile) {
-        case 1: conv_igemm_kernel<DT, OUT_F32, FAST, DETECT, 128, 32, 4, 1, 4><<<dim3(nblk, a.ksplit), 256, 0, st>>>(a); break;
-        case 2: conv_igemm_kernel<DT, OUT_F32, FAST, DETECT, 128, 64, 4, 1, 4><<<dim3(nblk, a.ksplit), 256, 0, st>>>(a); break;
-        case 3: conv_igemm_kernel<DT, OUT_F32, FAST, DETECT, 128, 128, 2, 2, 4><<<dim3(nblk, a.ksplit), 256, 0, st>>>(a); break;
-        case 4: conv_igemm_kernel<DT, OUT_F32, FAST, DETECT, 64, 64, 2, 2, 4><<<dim3(nblk, a.ksplit), 256, 0, st>>>(a); break;
-        case 5: conv_igemm_kernel<DT, OUT_F32, FAST, DETECT, 64, 32, 4, 1, 4><<<dim3(nblk, a.ksplit), 256, 0, st>>>(a); break;
+        case 1: return launch_tile<DT, OUT_F32, FAST, DETECT, 128, 32, 4, 1, 4>(a, nblk, st);
+        case 2: return launch_tile<DT, OUT_F32, FAST, DETECT, 128, 64, 4, 1, 4>(a, nblk, st);
+        case 3: return launch_tile<DT, OUT_F32, FAST, DETECT, 128, 128, 2, 2, 4>(a, nblk, st);
+        case 4: return launch_tile<DT, OUT_F32, FAST, DETECT, 64, 64, 2, 2, 4>(a, nblk, st);
+        case 5: return launch_tile<DT, OUT_F32, FAST, DETECT, 64, 32, 4, 1, 4>(a, nblk, st);
         default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
 }
 
 
@@ -859,6 +1126,31 @@ hipError_t launch_halo(const ConvKArgs& a, int nblk, hipStream_t st) {
     }
     kern<<<nblk, 256, lds, st>>>(a);
     return hipGetLastError();
+}
+
+template <int DT, int C, int BN, int WAVES_M>
+hipError_t launch_bneck(const ConvKArgs& a, int nblk, hipStream_t st) {
+    constexpr size_t hid = (size_t)(C / 32) * 12 * 1024;
+    constexpr size_t opa = (size_t)(C / 32) * (12 + C / 16) * 1024, opb = (size_t)3 * 3 * (BN / 16) * 1024;
+    constexpr size_t lds = hid + (opa > opb ? opa : opb);
+    auto kern = bottleneck_halo_kernel<DT, C, BN, WAVES_M>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    kern<<<nblk, 256, lds, st>>>(a);
+    return hipGetLastError();
+}
+
+template <int DT>
+hipError_t dispatch_bneck(int c, int bn, const ConvKArgs& a, int nblk, hipStream_t st) {
+    if (c == 32) return launch_bneck<DT, 32, 32, 4>(a, nblk, st);
+    if (c == 64) return bn == 32 ? launch_bneck<DT, 64, 32, 4>(a, nblk, st) : launch_bneck<DT, 64, 64, 4>(a, nblk, st);
+    if (bn == 32) return launch_bneck<DT, 128, 32, 4>(a, nblk, st);
+    if (bn == 64) return launch_bneck<DT, 128, 64, 4>(a, nblk, st);
+    return launch_bneck<DT, 128, 128, 2>(a, nblk, st);
 }
 
 template <int DT, bool OUT_F32>
@@ -961,7 +1253,7 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
     const bool of32 = d->out_f32 != 0;
     if (det != nullptr) {
         YP_REQUIRE(det->na > 0 && det->na <= 8 && det->no > 5 && det->na * det->no <= Cout && det->x_out != nullptr, "yp_conv2d_detect: bad detect descriptor");
-        YP_REQUIRE(d->act == YP_ACT_NONE && d->res.C == 0 && d->out2.C == 0 && fast, "yp_conv2d_detect: plain fast-path convolution required");
+        YP_REQUIRE(d->act == YP_ACT_NONE && d->res.C == 0 && d->out2.C == 0 && fast && d->pre_weight == nullptr, "yp_conv2d_detect: plain fast-path convolution required");
         a.det_na = det->na; a.det_no = det->no; a.det_invno = (65536 + det->no - 1) / det->no;
         YP_REQUIRE((long)Cout * (a.det_invno * det->no - 65536) < 65536, "yp_conv2d_detect: channel decode out of range");
         a.det_rows_total = det->rows_total; a.det_row_off = det->row_offset; a.det_stride = det->stride;
@@ -980,6 +1272,28 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
     const bool halo_ok = fast && d->dtype != YP_F32 && d->R == 3 && d->S == 3 && d->pad_h == 1 && d->pad_w == 1 &&
                          d->stride_h == d->stride_w && (d->stride_h == 1 || d->stride_h == 2) && d->in1.C == 0 && d->in0.ups == 0 && ksplit == 1 && !d->atomic_accumulate &&
                          in0_bytes + (size_t)d->in0.cstride * eb + 64 < (1ull << 31);
+    if (d->pre_weight != nullptr) {      // fused Bottleneck: 1x1 prologue + 3x3, hidden tensor in LDS
+        const int Cc = d->in0.C;
+        YP_REQUIRE(halo_ok && d->stride_h == 1 && !of32 && d->out2.C == 0, "yp_conv2d: the pointwise prologue needs a 16-bit 3x3 / stride 1 / pad 1 convolution with tail_zero buffers");
+        YP_REQUIRE(Cout == Cc && (Cc == 32 || Cc == 64 || Cc == 128), "yp_conv2d: pointwise prologue: in = hidden = out channels must be 32, 64 or 128 (got %d -> %d)", Cc, Cout);
+        YP_REQUIRE(d->pre_Npad >= Cc && d->pre_Kpad >= Cc && d->pre_Kpad % 32 == 0, "yp_conv2d: bad packed prologue filter %dx%d", d->pre_Npad, d->pre_Kpad);
+        YP_REQUIRE(d->tile == 0 || (d->tile >= 10 && d->tile <= 12), "yp_conv2d: tile %d does not apply to the fused bottleneck", d->tile);
+        int bn = Cc < 64 ? Cc : 64;
+        if (d->tile == 10) bn = 32; else if (d->tile == 11) bn = 64; else if (d->tile == 12) bn = 128;
+        YP_REQUIRE(bn <= Cc, "yp_conv2d: fused bottleneck tile of %d channels > %d", bn, Cc);
+        a.pre_wgt = (const char*)d->pre_weight; a.pre_bias = d->pre_bias; a.pre_Kpad = d->pre_Kpad; a.pre_act = d->pre_act;
+        a.tiles_n = yp_cdiv(Cout, bn);
+        a.tiles_x = yp_cdiv(d->Wo, 16);
+        a.tiles_y = yp_cdiv(d->Ho, 8);
+        a.Ho = d->Ho;
+        const int nb3 = d->B * a.tiles_y * a.tiles_x * a.tiles_n;
+        e = d->dtype == YP_F16 ? dispatch_bneck<YP_F16>(Cc, bn, a, nb3, stream) : dispatch_bneck<YP_BF16>(Cc, bn, a, nb3, stream);
+        if (e != hipSuccess) {
+            yp_set_error("yp_conv2d: fused bottleneck launch failed: %s", hipGetErrorString(e));
+            return YP_ERR_HIP;
+        }
+        return YP_OK;
+    }
     if (halo_ok && (d->tile == 0 || d->tile >= 10)) {
         int bn = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128);
         if (d->tile == 10) bn = 32; else if (d->tile == 11) bn = 64; else if (d->tile == 12) bn = 128;

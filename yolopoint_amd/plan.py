@@ -192,7 +192,9 @@ class PlanBuilder:
         returning (w, bias) — then the packed copy is re-derived by refresh() before every training step.
         k/s/p: square kernel, stride, padding.  extra: raw descriptor overrides used by dgrad / wgrad:
           out_hw=(Ho,Wo), dil=int, zero_stuffed=bool (in0 read as a zero-stuffed 2x tensor), ksplit=int,
-          kernel_hw=(R,S) for non-square "filters", raw_weight=(tensor [Npad+1][Kpad], Kpad, Npad) to bypass packing."""
+          kernel_hw=(R,S) for non-square "filters", raw_weight=(tensor [Npad+1][Kpad], Kpad, Npad) to bypass packing,
+          pre=(w1, b1, act1): fused Bottleneck — this 3x3 reads act1(conv1x1(src, w1) + b1), the hidden tensor stays in LDS,
+          dry_run=True: build + autotune the launch but do not add it; returns the measured ms per launch (None if untimed)."""
         if isinstance(srcs, View):
             srcs = [srcs]
         assert 1 <= len(srcs) <= 2
@@ -282,6 +284,14 @@ class PlanBuilder:
         d.ksplit = int(extra.get("ksplit", 1))
         d.atomic_accumulate = int(extra.get("atomic", 0))
         d.Kpad, d.Npad, d.act, d.tile, d.tail_zero = Kpad, Npad, act, tile, 1
+        pre = extra.get("pre")
+        if pre is not None:
+            w1, b1, act1 = pre
+            assert w1.shape[2] == w1.shape[3] == 1 and w1.shape[0] == w1.shape[1] == Cin == Cout, (self.name(), tuple(w1.shape), Cin, Cout)
+            wp1, bp1, Kpad1, Npad1 = pack_conv_weight(w1, b1, self.code, self.device)
+            self.keep += [wp1, bp1]
+            d.pre_weight, d.pre_bias = wp1.data_ptr(), (bp1.data_ptr() if b1 is not None else None)
+            d.pre_Kpad, d.pre_Npad, d.pre_act = Kpad1, Npad1, act1
         det = None
         if detect is not None:
             det = YpDetectDesc()
@@ -291,9 +301,12 @@ class PlanBuilder:
             det.x_out = detect["x_out"].data_ptr()
             det.z_out = detect["z_out"].data_ptr() if detect["z_out"] is not None else None
             det.rows_total, det.row_offset = detect["rows_total"], detect["row_offset"]
+        tuned_ms = None
         if tile == 0 and self.autotune and d.ksplit == 1 and not d.atomic_accumulate:
-            d.tile = self._autotune(d, det, (self.code, d.B, Hi, Wi, tuple((v.C, v.ups) for v in srcs), Cout_pad, R, S, sh, sw, dil, zs,
-                                             int(out_f32), res is not None, c2, act, detect is not None))
+            d.tile, tuned_ms = self._autotune(d, det, (self.code, d.B, Hi, Wi, tuple((v.C, v.ups) for v in srcs), Cout_pad, R, S, sh, sw, dil, zs,
+                                                       int(out_f32), res is not None, c2, act, detect is not None, pre is not None))
+        if extra.get("dry_run"):
+            return tuned_ms
         if det is not None:
             check(lib().yp_plan_add_conv_detect(self.handle, C.byref(d), C.byref(det)))
             rows = detect["na"] * Ho * Wo
@@ -310,7 +323,11 @@ class PlanBuilder:
         eb = 4 if self.code == _hip.YP_F32 else 2
         in_elems = d.B * sum((v.H * v.W * v.C) for v in srcs)
         bytes_ = in_elems * eb + M * Cout * (4 if out_f32 else eb) * (2 if (detect is not None and detect['z_out'] is not None) else 1) + Cout * Kreal * eb
-        self.records.append(OpRecord(self.name(), "conv", 2 * M * Cout * Kreal, bytes_, M, Cout, Kreal))
+        flops = 2 * M * Cout * Kreal
+        if pre is not None:       # the 1x1 of the fused Bottleneck: its algorithmic work (not the halo recompute) and its filter
+            flops += 2 * M * Cin * Cin
+            bytes_ += Cin * Cin * eb
+        self.records.append(OpRecord(self.name(), "conv", flops, bytes_, M, Cout, Kreal))
         return out
 
     def stem(self, w, bias, act, H, W):
@@ -384,8 +401,8 @@ class PlanBuilder:
             ms = e0.elapsed_time(e1)
             if best_ms is None or ms < best_ms:
                 best, best_ms = cand, ms
-        _TUNE_CACHE[key] = best
-        return best
+        _TUNE_CACHE[key] = (best, (best_ms / 8 if best_ms is not None else None))
+        return _TUNE_CACHE[key]
 
     def sppf_pool(self, x, y1, y2, y3):
         check(lib().yp_plan_add_sppf_pool(self.handle, x.c(), y1.c(), y2.c(), y3.c(), self.B, self.code))
