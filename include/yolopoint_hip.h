@@ -201,6 +201,14 @@ int yp_to_chwb(YpView in, int dtype, int B, int C, void* out, int Bpad, void* st
 /* fp32 NHWC view -> `dtype` NHWC view */
 int yp_cast_from_f32(YpView in, YpView out, int dtype, int B, void* stream);
 int yp_col_sum(YpView v, int dtype, int B, float* out, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* fp32 OIHW master filter w[Cout][Cin][R][S] -> the packed [Npad + 1][Kpad] `dtype` filter yp_conv2d reads (zero padded,
+ * zero row last), so a training step re-derives its 16-bit filters on the device without host work:
+ *   mode 0  forward filter of input-channel slice [c0, c0+Cj):  dst[n][(r*S+s)*Cj + c]       = w[n][c0+c][r][s]
+ *   mode 1  dgrad filter (flipped, channel-transposed):         dst[c][(r*S+s)*Cout_pad + n] = w[n][c0+c][R-1-r][S-1-s]
+ * bias (may be NULL) is copied, zero padded, to bias_dst[Npad].
+ * replaces: the conv.weight casts autocast performs every forward (reference train.py:206) + autograd's filter transposes */
+int yp_pack_weight(const float* w, int Cout, int Cin, int R, int S, int c0, int Cj, int mode, int Cout_pad, void* dst, int Kpad,
+                   int Npad, int dtype, const float* bias, float* bias_dst, void* stream);
 
 /* One generic launch record: `op` selects one of the functions above, the slots carry its arguments in the
  * order documented next to each opcode.  Lets training plans replay any mix of launches (yp_plan_add_op). */
@@ -220,7 +228,8 @@ enum {
     YP_OP_L2NORM = 22,        /* v0=in v1=out; i1=B i2=C */
     YP_OP_SPPF_POOL = 23,     /* v0=x v1..v3=y1..y3; i0=dtype i1=B */
     YP_OP_CAST_F32 = 24,      /* v0=in (fp32) v1=out; i0=dtype i1=B */
-    YP_OP_MAXPOOL2 = 25       /* v0=x v1=y; i0=dtype i1=B */
+    YP_OP_MAXPOOL2 = 25,      /* v0=x v1=y; i0=dtype i1=B */
+    YP_OP_PACK_WEIGHT = 26    /* f0=w f1=bias; g0=bias_dst; p0=dst; i0=dtype i1=Cout i2=Cin i3=R i4=S i5=c0 i6=Cj i7=mode; n0=Kpad n1=Npad | Cout_pad<<32 */
 };
 typedef struct YpOpArgs {
     int32_t op, pad_;

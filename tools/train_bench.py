@@ -52,3 +52,18 @@ gg = next(iter(m.model._train_graphs.values()))[0]
 t0 = time.perf_counter(); gg.fwd_plan.refresh(); gg.bwd_plan.refresh(); torch.cuda.synchronize(); print(f"    weight refresh (1 graph)      {(time.perf_counter()-t0)*1e3:7.1f} ms")
 t0 = time.perf_counter(); [fn() for fn in gg.collect]; torch.cuda.synchronize(); print(f"    grad collect (1 graph)        {(time.perf_counter()-t0)*1e3:7.1f} ms")
 t0 = time.perf_counter(); gg.bwd_plan.run(); torch.cuda.synchronize(); print(f"    bwd plan run (1 graph)        {(time.perf_counter()-t0)*1e3:7.1f} ms")
+
+# ---- aggregated per-kind table of both plans
+import collections
+for name, plan in (("fwd", g.fwd_plan), ("bwd", g.bwd_plan)):
+    ms = plan.profile()
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for t, r in zip(ms, plan.records):
+        key = (r.kind, r.name.split(".")[-1] if r.name else "")
+        agg[key][0] += 1; agg[key][1] += t
+    print(f"  {name} plan by kind:")
+    for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print(f"    {k[0]:8s} {k[1]:24s} n={n:4d} {t:8.3f} ms")
+    with open(os.path.join(ROOT, "gpurun_out", f"train_{name}_ops.txt"), "w") as f:
+        for t, r in sorted(zip(ms, plan.records), key=lambda x: -x[0]):
+            f.write(f"{t*1e3:9.1f} us  {r.kind:8s} {r.name:50s} M={r.M} N={r.N} K={r.K} flops={r.flops}\n")

@@ -579,6 +579,40 @@ extern "C" int yp_cast_from_f32(YpView in, YpView out, int dtype, int B, void* s
     return YP_OK;
 }
 
+template <int DT>
+__global__ void pack_weight_kernel(const float* __restrict__ w, int Cout, int Cin, int R, int S, int c0, int Cj, int mode, int Cout_pad,
+                                   char* __restrict__ dst, int Kpad, int Npad, const float* __restrict__ bias, float* __restrict__ bias_dst) {
+    using sc = typename Sc<DT>::t;
+    const size_t total = (size_t)(Npad + 1) * Kpad;
+    const int Cq = mode == 0 ? Cj : Cout_pad;          // channels per tap along k
+    const int Nreal = mode == 0 ? Cout : Cj;
+    const int Kreal = R * S * Cq;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / Kpad), k = (int)(i - (size_t)n * Kpad);
+        float v = 0.f;
+        if (n < Nreal && k < Kreal) {
+            const int tap = k / Cq, c = k - tap * Cq;
+            const int r = tap / S, s_ = tap - r * S;
+            if (mode == 0) v = w[(((size_t)n * Cin + c0 + c) * R + r) * S + s_];
+            else if (c < Cout) v = w[(((size_t)c * Cin + c0 + n) * R + (R - 1 - r)) * S + (S - 1 - s_)];
+        }
+        reinterpret_cast<sc*>(dst)[i] = (sc)v;
+        if (bias_dst != nullptr && i < (size_t)Npad) bias_dst[i] = (bias != nullptr && (int)i < Cout) ? bias[i] : 0.f;
+    }
+}
+
+extern "C" int yp_pack_weight(const float* w, int Cout, int Cin, int R, int S, int c0, int Cj, int mode, int Cout_pad, void* dst, int Kpad,
+                              int Npad, int dtype, const float* bias, float* bias_dst, void* stream) {
+    YP_REQUIRE(w && dst && Cout > 0 && Cin > 0 && R > 0 && S > 0 && c0 >= 0 && Cj > 0 && c0 + Cj <= Cin && (mode == 0 || mode == 1), "yp_pack_weight: bad arguments");
+    const int Cq = mode == 0 ? Cj : Cout_pad, Nreal = mode == 0 ? Cout : Cj;
+    YP_REQUIRE((mode == 0 || Cout_pad >= Cout) && Kpad >= R * S * Cq && Npad >= Nreal, "yp_pack_weight: packed dims %dx%d too small", Npad, Kpad);
+    const size_t total = (size_t)(Npad + 1) * Kpad;
+    YP_DT_SWITCH(dtype, (pack_weight_kernel<DT><<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(w, Cout, Cin, R, S, c0, Cj, mode, Cout_pad, (char*)dst, Kpad, Npad,
+                                                                                                     bias, bias_dst)));
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
 extern "C" int yp_run_op(const YpOpArgs* a, void* stream) {
     YP_REQUIRE(a != nullptr, "yp_run_op: null args");
     const int dt = a->i[0], B = a->i[1];
@@ -599,6 +633,9 @@ extern "C" int yp_run_op(const YpOpArgs* a, void* stream) {
         case YP_OP_SPPF_POOL: return yp_sppf_pool(a->v[0], a->v[1], a->v[2], a->v[3], B, dt, stream);
         case YP_OP_CAST_F32: return yp_cast_from_f32(a->v[0], a->v[1], dt, B, stream);
         case YP_OP_MAXPOOL2: return yp_maxpool2(a->v[0], a->v[1], B, dt, stream);
+        case YP_OP_PACK_WEIGHT:
+            return yp_pack_weight(a->f[0], a->i[1], a->i[2], a->i[3], a->i[4], a->i[5], a->i[6], a->i[7], (int)(a->n[1] >> 32), a->p[0], (int)a->n[0],
+                                  (int)(a->n[1] & 0xffffffffu), dt, a->f[1], a->g[0], stream);
     }
     yp_set_error("yp_run_op: unknown opcode %d", a->op);
     return YP_ERR_INVALID;

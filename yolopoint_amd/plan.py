@@ -112,6 +112,21 @@ def pack_stem_weight(w, bias, code, device):
     return pack_conv_weight(wpair, bias, code, device)
 
 
+class MasterWeight:
+    """An fp32 OIHW master parameter that the plan itself packs (yp_pack_weight) right before the convolution that
+    reads it: training plans re-derive their 16-bit filters on the device every step, with no host work.
+    mode 0: forward filter of input channels [c0, c0+cj); mode 1: the dgrad filter (flipped, channel-transposed,
+    output channels zero-padded to cout_pad) of the same slice."""
+
+    def __init__(self, param, bias=None, mode=0, c0=0, cj=None, cout_pad=None):
+        self.param, self.bias, self.mode, self.c0 = param, bias, mode, c0
+        Cout, Cin, R, S = param.shape
+        self.cj = Cin - c0 if cj is None else cj
+        self.cout_pad = round_up(Cout, 8) if cout_pad is None else cout_pad
+        # logical OIHW shape of the filter the convolution sees
+        self.shape = (Cout, self.cj, R, S) if mode == 0 else (self.cj, self.cout_pad, R, S)
+
+
 class OpRecord:
     __slots__ = ("name", "kind", "flops", "bytes", "M", "N", "K")
 
@@ -200,13 +215,18 @@ class PlanBuilder:
         assert 1 <= len(srcs) <= 2
         extra = extra or {}
         w_fn = None
-        if callable(w):
+        master = w if isinstance(w, MasterWeight) else None
+        if master is not None:
+            bias = master.bias
+        elif callable(w):
             w_fn = w
             w, bias = w_fn()
         raw_weight = extra.get("raw_weight")
         if raw_weight is not None:
             Cout, Cin = extra["cout"], sum(v.C for v in srcs)
             R, S = extra["kernel_hw"]
+        elif master is not None:
+            Cout, Cin, R, S = master.shape
         else:
             Cout, Cin, R, S = w.shape
         sh = sw = s
@@ -258,6 +278,16 @@ class PlanBuilder:
             wp, Kpad, Npad = raw_weight
             bp = None
             self.keep += [wp]
+        elif master is not None:
+            assert not thin, "image-like (thin) inputs keep the host packer"
+            Kpad, Npad = lib().yp_conv_kpad(R * S * Cin, self.code), round_up(Cout, 8)
+            wp = torch.zeros((Npad + 1, Kpad), dtype=self.tdtype, device=self.device)
+            bp = torch.zeros((Npad,), dtype=torch.float32, device=self.device)
+            self.keep += [wp, bp, master.param] + ([master.bias] if master.bias is not None else [])
+            mo, mi, mr, ms = master.param.shape
+            self.op(_hip.OP_PACK_WEIGHT, [], [(wp, 0, 1 << 30)], "pack_w", f=[master.param, master.bias], g=[bp], p=[wp],
+                    i=[self.code, mo, mi, mr, ms, master.c0, master.cj, master.mode], n=[Kpad, Npad | (master.cout_pad << 32)])
+            extra = dict(extra, weight_view=(wp, 0, 1 << 30)) if "weight_view" not in extra else extra
         else:
             wp, bp, Kpad, Npad = prep(w, bias)
             self.keep += [wp, bp]

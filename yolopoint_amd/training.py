@@ -22,7 +22,7 @@ import torch
 
 from . import _hip
 from ._hip import lib
-from .plan import PlanBuilder, Buf, View, round_up, pack_input
+from .plan import PlanBuilder, Buf, View, MasterWeight, round_up, pack_input
 
 
 class TrainGraph:
@@ -90,7 +90,9 @@ class TrainGraph:
         k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
         act = _hip.YP_ACT_SILU if isinstance(m.act, torch.nn.SiLU) else _hip.YP_ACT_NONE
         f, B, code = self.fwd, self.B, self.code
-        raw = f.conv(srcs, lambda: (conv.weight.detach().float(), None), None, k, s, p, _hip.YP_ACT_NONE)
+        image = len(srcs) == 1 and srcs[0].geom is None and srcs[0].cstride == 4 and srcs[0].C == 4      # the stem keeps the host packer
+        wsrc = (lambda: (conv.weight.detach().float(), None)) if image else MasterWeight(conv.weight)
+        raw = f.conv(srcs, wsrc, None, k, s, p, _hip.YP_ACT_NONE)
         Cc = conv.out_channels
         mean, invstd = f.new_tensor((Cc,)), f.new_tensor((Cc,))
         f.op(_hip.OP_BN_STATS, [raw], [self.T(mean), self.T(invstd)], "bn_stats", v=[raw], i=[code, B], s=[bn.eps, bn.momentum],
@@ -116,8 +118,7 @@ class TrainGraph:
     def conv_plain(self, weight, bias, x, k, s, p, name):
         """Head convolution without BN/activation, fp32 output (ConvDet / ConvDesc)."""
         f = self.fwd
-        out = f.conv([x], lambda: (weight.detach().float(), bias.detach().float() if bias is not None else None), bias, k, s, p,
-                     _hip.YP_ACT_NONE, out_f32=True)
+        out = f.conv([x], MasterWeight(weight, bias), bias, k, s, p, _hip.YP_ACT_NONE, out_f32=True)
 
         def backward():
             b = self.bwd
@@ -171,11 +172,8 @@ class TrainGraph:
             if not image:
                 cs, ce_ = c0, c0 + Cj
 
-                def w_dgrad(cs=cs, ce_=ce_):
-                    wd = weight.detach().float()[:, cs:ce_].flip(2, 3).permute(1, 0, 2, 3)      # [Cj, Cout, k, k]
-                    if Cout_pad != Cout:
-                        wd = torch.nn.functional.pad(wd, (0, 0, 0, 0, 0, Cout_pad - Cout))
-                    return wd.contiguous(), None
+                # dgrad = convolution with the flipped, channel-transposed filter [Cj, Cout_pad, k, k], packed on the device
+                w_dgrad = MasterWeight(weight, mode=1, c0=cs, cj=Cj, cout_pad=Cout_pad)
                 base = View(src.buf, src.coff, src.C, 0, src.geom)
                 if src.ups:
                     tmp = b.new_buf(Hi, Wi, Cj).view()

@@ -173,13 +173,19 @@ def normPts(pts, shape):
 
 def infonce(descriptors, descriptors_warped, mask_valid_warp, inv_homographies, num_samples_per_image=1500,
             num_masked_non_matches_per_match=120, cell_size=8, device='cpu', tau=0.07, perm_fn=None, randint_fn=None):
-    """Cross-image InfoNCE between the descriptors of an image and of its warp: every valid cell of image A is matched
-    to the cell its inverse homography maps it to in image B; `num_masked_non_matches_per_match` random other matches
-    are the negatives; loss = -log softmax(<a,b+>/tau | <a,b->/tau)[0], averaged."""
+    """Cross-image InfoNCE between the descriptors of an image and of its warp (reference utils/loss_functions.py:484-597):
+    every valid cell of image A is matched to the cell its inverse homography maps it to in image B;
+    `num_masked_non_matches_per_match` random other matches are the negatives;
+    loss = -log softmax(<a,b+>/tau | <a,b->/tau)[0], averaged.
+
+    The reference materialises the gathered negatives ([n, negs, D]: 1.5 GB at n = 12000, negs = 120, D = 256) and draws the
+    indices with numpy on the host.  Here the negative logits are read out of the Gram matrix da @ db^T (one library GEMM,
+    [n, n]) and, unless the draws are injected (`perm_fn` / `randint_fn`: the parity tests replay the reference's draws),
+    cells and negatives are drawn on the device with the same distributions (uniform permutation of the valid cells;
+    uniform negatives, a negative equal to its own match redrawn from [0, #collisions) exactly as the reference does)."""
     assert descriptors.shape[-1] * descriptors.shape[-2] >= num_samples_per_image, \
         "Number of samples per image must be greater than number of pixels in image"
-    perm_fn = perm_fn or torch.randperm
-    randint_fn = randint_fn or np.random.randint
+    on_device = descriptors.is_cuda
     with torch.no_grad():
         B, Hc, Wc = descriptors.shape[0], descriptors.shape[2], descriptors.shape[3]
         uv_a = get_coor_cells(Hc, Wc, uv=True).to(device)
@@ -187,17 +193,27 @@ def infonce(descriptors, descriptors_warped, mask_valid_warp, inv_homographies, 
         valid = warp_image_batch(mask_valid_warp, inv_h, mode='nearest', device=device)
         valid = (getMasks(valid, device, cell_size) == 1.).flatten(1, -1)                  # [B, Hc*Wc]
         uv_b = warp_points(uv_a, homography_scaling(inv_h, Hc, Wc, device=device), device).round_()   # [B, N, 2]
-        a_list = [uv_a[valid[i]] for i in range(B)]
-        b_list = [uv_b[i][valid[i]] for i in range(B)]
-        pool = min(num_samples_per_image, min(x.shape[0] for x in a_list))
-        pa, pb = [], []
-        for i in range(B):
-            choice = perm_fn(a_list[i].shape[0])
-            pa.append(a_list[i][choice][:pool])
-            pb.append(b_list[i][choice][:pool])
+        if perm_fn is None and on_device:
+            # uniform random subset of the valid cells = the cells with the smallest random keys (one host sync for `pool`)
+            pool = min(num_samples_per_image, int(valid.sum(1).min()))
+            keys = torch.rand(valid.shape, device=valid.device).masked_fill_(~valid, 2.0)
+            idx = torch.topk(keys, pool, dim=1, largest=False).indices                     # [B, pool]
+            pa = uv_a[idx]
+            pb = torch.gather(uv_b, 1, idx.unsqueeze(-1).expand(-1, -1, 2))
+        else:
+            perm = perm_fn or torch.randperm
+            a_list = [uv_a[valid[i]] for i in range(B)]
+            b_list = [uv_b[i][valid[i]] for i in range(B)]
+            pool = min(num_samples_per_image, min(x.shape[0] for x in a_list))
+            pa, pb = [], []
+            for i in range(B):
+                choice = perm(a_list[i].shape[0])
+                pa.append(a_list[i][choice][:pool])
+                pb.append(b_list[i][choice][:pool])
+            pa, pb = torch.stack(pa).to(device), torch.stack(pb).to(device)
         size = torch.tensor([Wc, Hc]).float().to(device)
-        ua = normPts(torch.stack(pa).to(device), size)
-        ub = normPts(torch.stack(pb).to(device), size)
+        ua = normPts(pa, size)
+        ub = normPts(pb, size)
 
     def sample(desc, idx):
         return F.grid_sample(desc, idx.unsqueeze(1), mode='bilinear', align_corners=True).squeeze(2).transpose(1, 2)
@@ -206,19 +222,27 @@ def infonce(descriptors, descriptors_warped, mask_valid_warp, inv_homographies, 
     db = sample(descriptors_warped, ub)
     pos = (da * db).sum(-1).flatten()
     da, db = da.flatten(0, 1), db.flatten(0, 1)
-    n = da.shape[0]
-    shape = (num_masked_non_matches_per_match, n)
-    ordered = np.broadcast_to(np.arange(n), shape)
-    rnd = randint_fn(0, n, size=shape)
-    same = ordered == rnd
-    if nz := np.count_nonzero(same):                   # a negative must not be the match itself
-        while True:
-            cand = randint_fn(0, nz, nz)
-            if (rnd[same] != cand).any():
-                rnd[same] = cand
-                break
-    neg_b = db[torch.from_numpy(rnd)].transpose(0, 1)                      # [n, negs, D]
-    neg = (da.unsqueeze(1) * neg_b).sum(-1)
+    n, negs = da.shape[0], num_masked_non_matches_per_match
+    with torch.no_grad():
+        if randint_fn is None and on_device:
+            rnd = torch.randint(0, n, (n, negs), device=da.device)                     # rnd[i, j]: j-th negative of match i
+            same = rnd == torch.arange(n, device=da.device).unsqueeze(1)               # a negative must not be the match itself
+            cand = (torch.rand(rnd.shape, device=da.device) * same.sum()).long()
+            rnd = torch.where(same, cand, rnd)
+        else:
+            draw = randint_fn or np.random.randint
+            shape = (negs, n)
+            ordered = np.broadcast_to(np.arange(n), shape)
+            rnd = draw(0, n, size=shape)
+            same = ordered == rnd
+            if nz := np.count_nonzero(same):
+                while True:
+                    cand = draw(0, nz, nz)
+                    if (rnd[same] != cand).any():
+                        rnd[same] = cand
+                        break
+            rnd = torch.from_numpy(np.ascontiguousarray(rnd.T)).to(da.device)
+    neg = (da @ db.t()).gather(1, rnd)                 # [n, negs] = <da[i], db[rnd[i, j]]>
     logits = torch.cat([pos.unsqueeze(1), neg], dim=1) / tau
     return -F.log_softmax(logits, dim=1)[:, 0].mean()
 
