@@ -201,6 +201,11 @@ int yp_to_chwb(YpView in, int dtype, int B, int C, void* out, int Bpad, void* st
 /* fp32 NHWC view -> `dtype` NHWC view */
 int yp_cast_from_f32(YpView in, YpView out, int dtype, int B, void* stream);
 int yp_col_sum(YpView v, int dtype, int B, float* out, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* Weight gradient of a stride-1 convolution (k = 1, or k = 3 with pad 1) straight from the NHWC tensors, no transposed
+ * copies: dw[ci][r][s][co] += sum_{b,y,x} x[b, y+r-p, x+s-p, ci] * dy[b, y, x, co]   (fp32 atomics: `dw`
+ * [x.C][k][k][dy.C] must be zero-initialised).  x may be read through its 2x nearest upsample (x.ups = 1).
+ * 16-bit dtypes.  replaces: autograd's conv2d weight gradient (reference train.py:245 loss.backward()). */
+int yp_conv_wgrad(YpView x, YpView dy, int dtype, int B, int k, float* dw, void* stream);
 /* fp32 OIHW master filter w[Cout][Cin][R][S] -> the packed [Npad + 1][Kpad] `dtype` filter yp_conv2d reads (zero padded,
  * zero row last), so a training step re-derives its 16-bit filters on the device without host work:
  *   mode 0  forward filter of input-channel slice [c0, c0+Cj):  dst[n][(r*S+s)*Cj + c]       = w[n][c0+c][r][s]
@@ -229,6 +234,7 @@ enum {
     YP_OP_SPPF_POOL = 23,     /* v0=x v1..v3=y1..y3; i0=dtype i1=B */
     YP_OP_CAST_F32 = 24,      /* v0=in (fp32) v1=out; i0=dtype i1=B */
     YP_OP_MAXPOOL2 = 25,      /* v0=x v1=y; i0=dtype i1=B */
+    YP_OP_WGRAD = 27,         /* v0=x v1=dy; p0=dw; i0=dtype i1=B i2=k */
     YP_OP_PACK_WEIGHT = 26    /* f0=w f1=bias; g0=bias_dst; p0=dst; i0=dtype i1=Cout i2=Cin i3=R i4=S i5=c0 i6=Cj i7=mode; n0=Kpad n1=Npad | Cout_pad<<32 */
 };
 typedef struct YpOpArgs {

@@ -1,0 +1,254 @@
+// Weight gradient of a stride-1 convolution (1x1, or 3x3 with pad 1) straight from the NHWC tensors:
+//
+//   dW[ci][r][s][co] += sum over (b, y, x) of  x[b, y+r-p, x+s-p, ci] * dy[b, y, x, co]
+//
+// The reduction runs over PIXELS, which is the strided axis of both NHWC operands, so neither matches the
+// MFMA fragment layout (8 consecutive k per lane).  Instead of materialising pixel-major copies in HBM, both
+// tiles are DMA'd into LDS as they lie (rows = pixels, 16-channel blocks of 32 bytes) and the fragments are
+// read with gfx950's transposing LDS read: ds_read_b64_tr_b16 hands lane i of each 16-lane group column i of a
+// 4 x 16 block whose four rows are addressed by the group's lanes 4j..4j+3 -- i.e. 4 consecutive pixels of one
+// channel.  Two such reads give the 8 k values of an MFMA 16x16x32 operand; the same pixel order is used for
+// x and dy, so the k permutation inside a fragment cancels in the dot product.
+//
+// A workgroup owns a [64 ci x 64 co] block of dW for every tap and walks a strided subset of the pixel tiles
+// (128 pixels each: 128 consecutive pixels for 1x1, an 8 x 16 patch + halo for 3x3), double buffered through
+// LDS-DMA; partial sums go to the zero-initialised fp32 dW with hardware fp32 atomics.
+//
+// replaces: autograd's conv2d weight gradient for reference models/common.py:22-34 (loss.backward(), train.py:245).
+#include "yp_internal.h"
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __attribute__((aligned(16))) unsigned int wg_zero16[4] = {0u, 0u, 0u, 0u};
+
+struct WgradArgs {
+    const char* x;
+    const char* dy;
+    float* dw;
+    int x_cs, x_co, x_ups, x_H, x_W;      // x buffer: channel stride / offset, 2x-nearest-upsample flag, STORED dims
+    int dy_cs, dy_co;
+    int B, H, W;                           // output map (= logical input map: stride 1, "same" padding)
+    int Cj, Cout_pad;
+    int n_co_blk;
+    int tiles_x, tiles_y, ntiles, M;
+};
+
+__device__ __forceinline__ void wg_glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+template <int DT> __device__ __forceinline__ f32x4 wg_mma(s16x8 a, s16x8 b, f32x4 c) {
+    if constexpr (DT == YP_F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ s16x8 wg_tr8(const char* lds_lo, const char* lds_hi) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lds_lo);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lds_hi);
+    return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <int DT, int TAPS>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
+    constexpr int KS = TAPS == 9 ? 3 : 1;
+    constexpr int HP = 18;
+    constexpr int XR = TAPS == 9 ? 192 : 128;              // LDS rows (pixels) of the x image per 16-channel block
+    constexpr int XI = XR / 32;                            // DMA instructions per channel block (32 rows x 32 B each)
+    constexpr int XBYTES = 4 * XR * 32, DYBYTES = 4 * 128 * 32, STAGE = XBYTES + DYBYTES;
+    constexpr int NDMA = XI + 4;                           // per wave and tile
+
+    extern __shared__ __attribute__((aligned(1024))) char wsm[];      // 2 stages of [x: 4 cb][XR][32 B] [dy: 4 cb][128][32 B]
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)wsm);
+
+    const int ci0 = (blockIdx.x / a.n_co_blk) * 64, co0 = (blockIdx.x % a.n_co_blk) * 64;
+    const int t = threadIdx.x, l = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int half = l & 1, prow = l >> 1;                 // DMA: this lane moves channels [half*8, +8) of row prow of its 32-row slab
+
+    auto issue = [&](int tile, int stage) {
+        const unsigned sb = lds0 + stage * STAGE;
+        int b, y0, x0;
+        if constexpr (TAPS == 9) {
+            int r_ = tile;
+            const int tx = r_ % a.tiles_x; r_ /= a.tiles_x;
+            const int ty = r_ % a.tiles_y;
+            b = r_ / a.tiles_y; y0 = ty * 8; x0 = tx * 16;
+        } else { b = 0; y0 = 0; x0 = 0; }
+        // ---- x rows
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int q = wave + 4 * i;                    // q in [0, 4*XI): channel block q / XI, row slab q % XI
+            const int cb = q / XI, rb = q - cb * XI;
+            const int row = rb * 32 + prow;
+            const int ch = ci0 + cb * 16 + half * 8;
+            bool ok = ch < a.Cj;
+            int bb, iy, ix;
+            if constexpr (TAPS == 9) {
+                const int hy = row / HP, hx = row - hy * HP;
+                bb = b; iy = y0 - 1 + hy; ix = x0 - 1 + hx;
+                ok = ok && row < 10 * HP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            } else {
+                const int m = tile * 128 + row;
+                ok = ok && m < a.M;
+                bb = m / (a.H * a.W);
+                const int rem = m - bb * (a.H * a.W);
+                iy = rem / a.W; ix = rem - iy * a.W;
+            }
+            const long pix = ((long)bb * a.x_H + (iy >> a.x_ups)) * a.x_W + (ix >> a.x_ups);
+            const char* src = a.x + (pix * a.x_cs + a.x_co + ch) * 2;
+            wg_glds16(ok ? (const void*)src : (const void*)wg_zero16, sb + (cb * XR + rb * 32) * 32);
+        }
+        // ---- dy rows: channel block i, row slab = wave
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wave * 32 + prow;
+            const int ch = co0 + i * 16 + half * 8;
+            bool ok = ch < a.Cout_pad;
+            long pix;
+            if constexpr (TAPS == 9) {
+                const int oy = y0 + (row >> 4), ox = x0 + (row & 15);
+                ok = ok && oy < a.H && ox < a.W;
+                pix = ((long)b * a.H + oy) * a.W + ox;
+            } else {
+                pix = (long)tile * 128 + row;
+                ok = ok && pix < a.M;
+            }
+            const char* src = a.dy + (pix * a.dy_cs + a.dy_co + ch) * 2;
+            wg_glds16(ok ? (const void*)src : (const void*)wg_zero16, sb + XBYTES + (i * 128 + wave * 32) * 32);
+        }
+    };
+
+    // ---- fragment read addressing (see the file header): lane i of group g addresses row j = i/4 of its 4-row block,
+    // channels 4*(i%4)..+3; read h covers pixels g*8 + 4*(h ^ (g&1)) + j of a 32-pixel k step (groups alternate the
+    // order of their two 4-row halves so that one read's four 128-byte row blocks spread over all LDS banks)
+    const int li = l & 15, g = l >> 4, j = li >> 2, q4 = li & 3;
+    int xoff[2], yoff[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int k32 = g * 8 + ((h ^ (g & 1)) * 4) + j;
+        if constexpr (TAPS == 9) xoff[h] = (((k32 >> 4) * HP) + (k32 & 15)) * 32 + q4 * 8;
+        else xoff[h] = k32 * 32 + q4 * 8;
+        yoff[h] = k32 * 32 + q4 * 8;
+    }
+    const int wci = wave & 1, wco = wave >> 1;             // wave tile: ci [wci*32, +32), co [wco*32, +32)
+
+    f32x4 acc[TAPS][2][2];
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+        for (int fa = 0; fa < 2; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb) acc[tp][fa][fb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int first = blockIdx.y, step = gridDim.y;
+    if (first < a.ntiles) issue(first, 0);
+    int it = 0;
+    for (int tile = first; tile < a.ntiles; tile += step, ++it) {
+        const bool more = tile + step < a.ntiles;
+        if (more) issue(tile + step, (it + 1) & 1);        // that stage was last read two tiles ago: the barrier below covers it
+        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const char* xs = wsm + (it & 1) * STAGE;
+        const char* ys = xs + XBYTES;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            s16x8 yf[2];
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb) {
+                const char* base = ys + ((wco * 2 + fb) * 128 + kk * 32) * 32;
+                yf[fb] = wg_tr8(base + yoff[0], base + yoff[1]);
+            }
+#pragma unroll
+            for (int tp = 0; tp < TAPS; ++tp) {
+                const int r = tp / KS, s = tp - r * KS;
+                s16x8 xf[2];
+#pragma unroll
+                for (int fa = 0; fa < 2; ++fa) {
+                    const char* base = xs + (wci * 2 + fa) * XR * 32 + (TAPS == 9 ? (kk * 2 * HP + r * HP + s) * 32 : kk * 32 * 32);
+                    xf[fa] = wg_tr8(base + xoff[0], base + xoff[1]);
+                }
+#pragma unroll
+                for (int fa = 0; fa < 2; ++fa)
+#pragma unroll
+                    for (int fb = 0; fb < 2; ++fb) acc[tp][fa][fb] = wg_mma<DT>(xf[fa], yf[fb], acc[tp][fa][fb]);
+            }
+        }
+        __builtin_amdgcn_s_barrier();                      // everyone is done reading this stage before it is refilled
+    }
+
+    // ---- partial sums -> dW[ci][r][s][co] (fp32 atomics); accumulator lane (p, g): rows (ci) 4g..4g+3, column (co) p
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+        for (int fa = 0; fa < 2; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb) {
+                const int co = co0 + (wco * 2 + fb) * 16 + li;
+                if (co >= a.Cout_pad) continue;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int ci = ci0 + (wci * 2 + fa) * 16 + 4 * g + jj;
+                    if (ci < a.Cj) atomicAdd(a.dw + ((size_t)ci * TAPS + tp) * a.Cout_pad + co, acc[tp][fa][fb][jj]);
+                }
+            }
+}
+
+template <int DT, int TAPS>
+hipError_t launch_wgrad(const WgradArgs& a, dim3 grid, hipStream_t st) {
+    constexpr int XR = TAPS == 9 ? 192 : 128;
+    constexpr size_t lds = (size_t)2 * (4 * XR * 32 + 4 * 128 * 32);
+    auto kern = wgrad_kernel<DT, TAPS>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    kern<<<grid, 256, lds, st>>>(a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int yp_conv_wgrad(YpView x, YpView dy, int dtype, int B, int k, float* dw, void* stream) {
+    YP_REQUIRE(dtype == YP_F16 || dtype == YP_BF16, "yp_conv_wgrad: 16-bit element types only");
+    YP_REQUIRE(k == 1 || k == 3, "yp_conv_wgrad: 1x1 or 3x3 (stride 1, same padding) filters only");
+    YP_REQUIRE(x.ptr && dy.ptr && dw && B > 0, "yp_conv_wgrad: null buffer");
+    YP_REQUIRE(x.C > 0 && x.C % 8 == 0 && x.cstride % 8 == 0 && x.coff % 8 == 0 && dy.C > 0 && dy.C % 8 == 0 && dy.cstride % 8 == 0 && dy.coff % 8 == 0,
+               "yp_conv_wgrad: views must be 8-channel aligned");
+    YP_REQUIRE(x.ups >= 0 && x.ups <= 1 && dy.ups == 0 && (x.H << x.ups) == dy.H && (x.W << x.ups) == dy.W, "yp_conv_wgrad: x %dx%d<<%d vs dy %dx%d", x.H, x.W, x.ups, dy.H, dy.W);
+    const long M = (long)B * dy.H * dy.W;
+    YP_REQUIRE(M < (1l << 30), "yp_conv_wgrad: too many pixels");
+    WgradArgs a{};
+    a.x = (const char*)x.ptr; a.dy = (const char*)dy.ptr; a.dw = dw;
+    a.x_cs = x.cstride; a.x_co = x.coff; a.x_ups = x.ups; a.x_H = x.H; a.x_W = x.W;
+    a.dy_cs = dy.cstride; a.dy_co = dy.coff;
+    a.B = B; a.H = dy.H; a.W = dy.W; a.Cj = x.C; a.Cout_pad = dy.C; a.M = (int)M;
+    a.n_co_blk = yp_cdiv(dy.C, 64);
+    const int nblk = yp_cdiv(x.C, 64) * a.n_co_blk;
+    if (k == 3) { a.tiles_x = yp_cdiv(dy.W, 16); a.tiles_y = yp_cdiv(dy.H, 8); a.ntiles = B * a.tiles_x * a.tiles_y; }
+    else a.ntiles = yp_cdiv((int)M, 128);
+    // pixel split: enough workgroups to fill the chip, but every workgroup ends in 64*64*taps atomics -> bound the split
+    int split = yp_cdiv(768, nblk);
+    const int cap = k == 3 ? 96 : 256;
+    if (split > cap) split = cap;
+    if (split > a.ntiles) split = a.ntiles;
+    if (split < 1) split = 1;
+    hipError_t e;
+    const dim3 grid(nblk, split);
+    if (dtype == YP_F16) e = k == 3 ? launch_wgrad<YP_F16, 9>(a, grid, (hipStream_t)stream) : launch_wgrad<YP_F16, 1>(a, grid, (hipStream_t)stream);
+    else e = k == 3 ? launch_wgrad<YP_BF16, 9>(a, grid, (hipStream_t)stream) : launch_wgrad<YP_BF16, 1>(a, grid, (hipStream_t)stream);
+    if (e != hipSuccess) { yp_set_error("yp_conv_wgrad: launch failed: %s", hipGetErrorString(e)); return YP_ERR_HIP; }
+    return YP_OK;
+}

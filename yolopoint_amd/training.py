@@ -145,27 +145,36 @@ class TrainGraph:
             b.op(_hip.OP_COL_SUM, [draw], [self.T(gb_full)], "bias_grad", v=[draw], i=[code, B, 0], g=[gb_full], p=[self.ws], n=[self.ws.numel()])
             gbias = self.pgrad(bias)
             self.collect.append(lambda: gbias.copy_(gb_full[:Cout]))
-        # ---- wgrad: output gradient as the "filter" [Cout_pad (+1 zero row)][K]
-        dyp = torch.zeros(((Cout_pad + 1) * K,), dtype=self.tdtype, device=self.device)
-        self.keep.append(dyp)
-        b.op(_hip.OP_TO_CHWB, [draw], [self.T(dyp)], "dy_chwb", v=[draw], i=[code, B, Cout_pad, Bpad], p=[dyp])
+        # ---- wgrad.  Stride-1 1x1 / 3x3 convolutions in a 16-bit dtype: yp_conv_wgrad reads the NHWC tensors directly
+        # (LDS transpose reads).  Everything else (stride 2, the 6x6 stem, fp32): wgrad as a convolution of pixel-major
+        # copies -- the output gradient becomes the "filter" [Cout_pad (+1 zero row)][K].
+        direct = code != _hip.YP_F32 and s == 1 and k in (1, 3) and p == k // 2
+        dyp = None
         c0 = 0
         for src in srcs:
             image = src.geom is None and src.cstride == 4 and src.C == 4
             Cj = src.C
             Hi, Wi = src.LH, src.LW
-            xp = Buf(Cj, Hi, Wi, Bpad, self.tdtype, self.device)
-            self.keep.append(xp.flat)
-            b.op(_hip.OP_TO_CHWB, [src], [xp.view()], "x_chwb", v=[src], i=[code, B, Cj, Bpad], p=[xp.t])
             dwb = Buf(Cj, k, k, Cout_pad, torch.float32, self.device)
             self.keep.append(dwb.flat)
             b.op(_hip.OP_MEMSET0, [], [dwb.view()], "zero_dw", p=[dwb.flat], n=[dwb.t.numel() * 4])
-            blocks = -(-(Cj * k * k) // 64) * -(-Cout_pad // 64)
-            nk = K // (16 if code == _hip.YP_F32 else 32)
-            ksplit = max(1, min(-(-1024 // blocks), max(1, nk // 8), 2048))
-            b.conv([xp.view()], None, None, 0, 1, p, _hip.YP_ACT_NONE, out=dwb.view(), out_f32=True,
-                   extra=dict(raw_weight=(dyp, K, Cout_pad), cout=Cout_pad, kernel_hw=(Ho, Wo), dil=s, out_hw=(k, k), ksplit=ksplit,
-                              atomic=1, batch=Cj, weight_view=self.T(dyp)))
+            if direct and not image:
+                b.op(_hip.OP_WGRAD, [src, draw], [dwb.view()], "wgrad", v=[src, draw], i=[code, B, k], p=[dwb.flat])
+                b.records[-1].kind, b.records[-1].flops = "conv", 2 * B * Ho * Wo * Cj * k * k * Cout
+            else:
+                if dyp is None:
+                    dyp = torch.zeros(((Cout_pad + 1) * K,), dtype=self.tdtype, device=self.device)
+                    self.keep.append(dyp)
+                    b.op(_hip.OP_TO_CHWB, [draw], [self.T(dyp)], "dy_chwb", v=[draw], i=[code, B, Cout_pad, Bpad], p=[dyp])
+                xp = Buf(Cj, Hi, Wi, Bpad, self.tdtype, self.device)
+                self.keep.append(xp.flat)
+                b.op(_hip.OP_TO_CHWB, [src], [xp.view()], "x_chwb", v=[src], i=[code, B, Cj, Bpad], p=[xp.t])
+                blocks = -(-(Cj * k * k) // 64) * -(-Cout_pad // 64)
+                nk = K // (16 if code == _hip.YP_F32 else 32)
+                ksplit = max(1, min(-(-1024 // blocks), max(1, nk // 8), 2048))
+                b.conv([xp.view()], None, None, 0, 1, p, _hip.YP_ACT_NONE, out=dwb.view(), out_f32=True,
+                       extra=dict(raw_weight=(dyp, K, Cout_pad), cout=Cout_pad, kernel_hw=(Ho, Wo), dil=s, out_hw=(k, k), ksplit=ksplit,
+                                  atomic=1, batch=Cj, weight_view=self.T(dyp)))
             creal = weight.shape[1] - c0 if image else Cj
             self.collect.append(lambda dwb=dwb, c0=c0, creal=creal: gw[:, c0:c0 + creal].copy_(dwb.t.permute(3, 0, 1, 2)[:Cout, :creal]))
             # ---- dgrad (no gradient flows into the image)
