@@ -238,6 +238,157 @@ __global__ void bn_bwd_apply_kernel(const char* __restrict__ raw, int rcs, int r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fast paths of the three BatchNorm passes for C/8 a power of two <= 256 (every BN layer of the YOLOPoint family):
+// a thread keeps ONE 8-channel chunk for all the rows it visits, so the per-channel parameters sit in registers,
+// the index arithmetic is 32-bit shifts and several independent 16-byte loads are in flight per thread.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_sigmoid(float z) { return __frcp_rn(1.0f + __expf(-z)); }
+
+template <int DT, int MODE>
+__global__ __launch_bounds__(256) void col_reduce_fast_kernel(const char* __restrict__ raw, int rcs, int rco, const char* __restrict__ dy,
+                                                              int dcs, int dco, unsigned M, int C, int lg, unsigned rows_per_blk,
+                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+                                                              float* __restrict__ part) {
+    __shared__ float red[256][17];
+    const int t = threadIdx.x;
+    const int ch = t & ((1 << lg) - 1), rl = t >> lg, rlanes = 256 >> lg;
+    float s0[8], s1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s0[j] = s1[j] = 0.f;
+    float mu[8], is[8], ga[8], be[8];
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            mu[j] = mean[ch * 8 + j]; is[j] = invstd[ch * 8 + j];
+            ga[j] = gamma[ch * 8 + j]; be[j] = beta[ch * 8 + j];
+        }
+    }
+    const unsigned r0 = blockIdx.x * rows_per_blk;
+    const unsigned r1 = (r0 + rows_per_blk < M) ? r0 + rows_per_blk : M;
+    auto body = [&](const float (&x)[8], const float (&g)[8]) {
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s0[j] += x[j]; s1[j] += x[j] * x[j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = (x[j] - mu[j]) * is[j];
+                float dz = g[j];
+                if (act == YP_ACT_SILU) {
+                    const float z = xh * ga[j] + be[j];
+                    const float sg = fast_sigmoid(z);
+                    dz *= sg * (1.0f + z * (1.0f - sg));
+                }
+                s0[j] += dz; s1[j] += dz * xh;
+            }
+        }
+    };
+    unsigned r = r0 + rl;
+    for (; r + 3 * rlanes < r1; r += 4 * rlanes) {          // four independent rows in flight
+        float x[4][8], g[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            load8<DT>(raw, (size_t)(r + u * rlanes) * rcs + rco + ch * 8, x[u]);
+            if constexpr (MODE == 1) load8<DT>(dy, (size_t)(r + u * rlanes) * dcs + dco + ch * 8, g[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) body(x[u], g[u]);
+    }
+    for (; r < r1; r += rlanes) {
+        float x[8], g[8];
+        load8<DT>(raw, (size_t)r * rcs + rco + ch * 8, x);
+        if constexpr (MODE == 1) load8<DT>(dy, (size_t)r * dcs + dco + ch * 8, g);
+        body(x, g);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[t][j] = s0[j]; red[t][8 + j] = s1[j]; }
+    __syncthreads();
+    for (int hw = rlanes >> 1; hw > 0; hw >>= 1) {          // tree over the row lanes
+        if (rl < hw) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) red[t][j] += red[t + (hw << lg)][j];
+        }
+        __syncthreads();
+    }
+    if (rl == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            part[((size_t)blockIdx.x * 2 + 0) * C + ch * 8 + j] = red[t][j];
+            part[((size_t)blockIdx.x * 2 + 1) * C + ch * 8 + j] = red[t][8 + j];
+        }
+    }
+}
+
+template <int DT, bool BWD>
+__global__ __launch_bounds__(256) void bn_rows_fast_kernel(const char* __restrict__ raw, int rcs, int rco, const char* __restrict__ dy, int dcs, int dco,
+                                                           char* __restrict__ out, int ocs, int oco, const char* __restrict__ res, int scs, int sco,
+                                                           unsigned M, int lg, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+                                                           const float* __restrict__ dgamma, const float* __restrict__ dbeta) {
+    const int t = threadIdx.x;
+    const int ch = t & ((1 << lg) - 1), rl = t >> lg, rlanes = 256 >> lg;
+    float mu[8], is[8], ga[8], be[8], k0[8], k1[8];
+    const float invM = 1.0f / (float)M;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = ch * 8 + j;
+        mu[j] = mean[c]; is[j] = invstd[c]; ga[j] = gamma[c]; be[j] = beta[c];
+        if constexpr (BWD) { k0[j] = dbeta[c] * invM; k1[j] = dgamma[c] * invM; }
+    }
+    const unsigned stride = gridDim.x * rlanes;
+    auto body = [&](size_t r, const float (&x)[8], const float (&g)[8]) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xh = (x[j] - mu[j]) * is[j];
+            if constexpr (BWD) {
+                float dz = g[j];
+                if (act == YP_ACT_SILU) {
+                    const float z = xh * ga[j] + be[j];
+                    const float sg = fast_sigmoid(z);
+                    dz *= sg * (1.0f + z * (1.0f - sg));
+                }
+                o[j] = ga[j] * is[j] * (dz - k0[j] - xh * k1[j]);
+            } else {
+                float z = xh * ga[j] + be[j];
+                if (act == YP_ACT_SILU) z = z * fast_sigmoid(z);
+                o[j] = z + g[j];
+            }
+        }
+        store8<DT>(out, r * ocs + oco + ch * 8, o);
+    };
+    unsigned r = blockIdx.x * rlanes + rl;
+    for (; (size_t)r + stride < M; r += 2 * stride) {       // two independent rows in flight
+        float x[2][8], g[2][8];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const size_t rr = (size_t)r + u * stride;
+            load8<DT>(raw, rr * rcs + rco + ch * 8, x[u]);
+            if constexpr (BWD) load8<DT>(dy, rr * dcs + dco + ch * 8, g[u]);
+            else if (res != nullptr) load8<DT>(res, rr * scs + sco + ch * 8, g[u]);
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g[u][j] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) body((size_t)r + u * stride, x[u], g[u]);
+    }
+    if (r < M) {
+        float x[8], g[8];
+        load8<DT>(raw, (size_t)r * rcs + rco + ch * 8, x);
+        if constexpr (BWD) load8<DT>(dy, (size_t)r * dcs + dco + ch * 8, g);
+        else if (res != nullptr) load8<DT>(res, (size_t)r * scs + sco + ch * 8, g);
+        else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] = 0.f;
+        }
+        body(r, x, g);
+    }
+}
+
 // out[pix, c] (+)= sum of the 2x2 block of `in` it was upsampled to  (backward of nn.Upsample(2,'nearest'))
 template <int DT>
 __global__ void ups2_bwd_kernel(const char* __restrict__ in, int ics, int ico, char* __restrict__ out, int ocs, int oco, int B, int H,
@@ -428,9 +579,30 @@ static int check_view8(const YpView& v, const char* what) {
     return YP_OK;
 }
 
+// fast-path geometry: log2(C/8) when C/8 is a power of two <= 256 (else -1); partial-sum workgroups for M rows
+static int fast_lg(int C) {
+    const int chunks = C / 8;
+    if (C % 8 || chunks < 1 || chunks > 256 || (chunks & (chunks - 1))) return -1;
+    int lg = 0;
+    while ((1 << lg) < chunks) ++lg;
+    return lg;
+}
+static int fast_reduce_blocks(size_t M, int lg, unsigned* rows_per_blk) {
+    const unsigned rlanes = 256u >> lg;
+    size_t nblk = (M + 4 * rlanes - 1) / (4 * rlanes);       // >= 4 rows per thread
+    if (nblk > 2048) nblk = 2048;
+    if (nblk < 1) nblk = 1;
+    unsigned rpb = (unsigned)((M + nblk - 1) / nblk);
+    rpb = (rpb + rlanes - 1) / rlanes * rlanes;
+    *rows_per_blk = rpb;
+    return (int)((M + rpb - 1) / rpb);
+}
+
 extern "C" size_t yp_bn_workspace_bytes(int B, int H, int W, int C) {
     const size_t M = (size_t)B * H * W;
-    return align_up(((M + BN_ROWS - 1) / BN_ROWS) * 2 * (size_t)C * sizeof(float), 256);
+    size_t nblk = (M + BN_ROWS - 1) / BN_ROWS;
+    if (nblk < 2048) nblk = 2048;                              // the fast reduction uses up to 2048 workgroups
+    return align_up(nblk * 2 * (size_t)C * sizeof(float), 256);
 }
 
 extern "C" int yp_bn_stats(YpView raw, int dtype, int B, float eps, float momentum, float* mean, float* invstd, float* running_mean,
@@ -439,10 +611,18 @@ extern "C" int yp_bn_stats(YpView raw, int dtype, int B, float eps, float moment
     YP_REQUIRE(mean && invstd && ws && B > 0 && raw.C <= 2048, "yp_bn_stats: bad arguments");
     YP_REQUIRE(ws_bytes >= yp_bn_workspace_bytes(B, raw.H, raw.W, raw.C), "yp_bn_stats: workspace too small");
     const size_t M = (size_t)B * raw.H * raw.W;
-    const int nblk = (int)((M + BN_ROWS - 1) / BN_ROWS);
+    int nblk = (int)((M + BN_ROWS - 1) / BN_ROWS);
     hipStream_t st = (hipStream_t)stream;
-    YP_DT_SWITCH(dtype, (col_reduce_kernel<DT, 0><<<nblk, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, nullptr, 0, 0, M, raw.C,
-                                                                        nullptr, nullptr, nullptr, nullptr, 0, (float*)ws)));
+    const int lg = fast_lg(raw.C);
+    if (lg >= 0 && M < (1ull << 31)) {
+        unsigned rpb;
+        nblk = fast_reduce_blocks(M, lg, &rpb);
+        YP_DT_SWITCH(dtype, (col_reduce_fast_kernel<DT, 0><<<nblk, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, nullptr, 0, 0, (unsigned)M, raw.C, lg,
+                                                                                 rpb, nullptr, nullptr, nullptr, nullptr, 0, (float*)ws)));
+    } else {
+        YP_DT_SWITCH(dtype, (col_reduce_kernel<DT, 0><<<nblk, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, nullptr, 0, 0, M, raw.C,
+                                                                            nullptr, nullptr, nullptr, nullptr, 0, (float*)ws)));
+    }
     bn_stats_finalize_kernel<<<raw.C, 64, 0, st>>>((const float*)ws, nblk, raw.C, (double)M, eps, momentum, mean, invstd,
                                                                running_mean, running_var);
     YP_CHECK_HIP(hipGetLastError());
@@ -457,9 +637,17 @@ extern "C" int yp_bn_act_apply(YpView raw, YpView out, YpView res, int dtype, in
     const size_t M = (size_t)B * raw.H * raw.W;
     hipStream_t st = (hipStream_t)stream;
     const int g = grid_for(M * (raw.C / 8), 256);
-    YP_DT_SWITCH(dtype, (bn_apply_kernel<DT><<<g, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, (char*)out.ptr, out.cstride, out.coff,
-                                                                res.C ? (const char*)res.ptr : nullptr, res.cstride, res.coff, M, raw.C, mean,
-                                                                invstd, gamma, beta, act)));
+    const int lg = fast_lg(raw.C);
+    if (lg >= 0 && M < (1ull << 31)) {
+        const int gf = grid_for((M * (raw.C / 8) + 1) / 2, 256);      // ~2 rows per thread
+        YP_DT_SWITCH(dtype, (bn_rows_fast_kernel<DT, false><<<gf, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, nullptr, 0, 0, (char*)out.ptr, out.cstride,
+                                                                               out.coff, res.C ? (const char*)res.ptr : nullptr, res.cstride, res.coff, (unsigned)M, lg,
+                                                                               mean, invstd, gamma, beta, act, nullptr, nullptr)));
+    } else {
+        YP_DT_SWITCH(dtype, (bn_apply_kernel<DT><<<g, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, (char*)out.ptr, out.cstride, out.coff,
+                                                                    res.C ? (const char*)res.ptr : nullptr, res.cstride, res.coff, M, raw.C, mean,
+                                                                    invstd, gamma, beta, act)));
+    }
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
 }
@@ -473,18 +661,34 @@ extern "C" int yp_bn_act_bwd(YpView raw, YpView dy, YpView dx, int dtype, int B,
     YP_REQUIRE(dy.C == raw.C && dx.C == raw.C && mean && invstd && gamma && beta && dgamma && dbeta && ws && raw.C <= 2048, "yp_bn_act_bwd: bad arguments");
     YP_REQUIRE(ws_bytes >= yp_bn_workspace_bytes(B, raw.H, raw.W, raw.C) + 2 * (size_t)raw.C * 4, "yp_bn_act_bwd: workspace too small");
     const size_t M = (size_t)B * raw.H * raw.W;
-    const int nblk = (int)((M + BN_ROWS - 1) / BN_ROWS);
+    int nblk = (int)((M + BN_ROWS - 1) / BN_ROWS);
     hipStream_t st = (hipStream_t)stream;
     // this call's own sums live at the end of the workspace (the parameter gradients may be accumulated)
     float* dg = (float*)((char*)ws + yp_bn_workspace_bytes(B, raw.H, raw.W, raw.C));
     float* db = dg + raw.C;
-    YP_DT_SWITCH(dtype, (col_reduce_kernel<DT, 1><<<nblk, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, (const char*)dy.ptr, dy.cstride,
-                                                                        dy.coff, M, raw.C, mean, invstd, gamma, beta, act, (float*)ws)));
+    const int lg = fast_lg(raw.C);
+    const bool fastp = lg >= 0 && M < (1ull << 31);
+    if (fastp) {
+        unsigned rpb;
+        nblk = fast_reduce_blocks(M, lg, &rpb);
+        YP_DT_SWITCH(dtype, (col_reduce_fast_kernel<DT, 1><<<nblk, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, (const char*)dy.ptr, dy.cstride, dy.coff,
+                                                                                 (unsigned)M, raw.C, lg, rpb, mean, invstd, gamma, beta, act, (float*)ws)));
+    } else {
+        YP_DT_SWITCH(dtype, (col_reduce_kernel<DT, 1><<<nblk, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, (const char*)dy.ptr, dy.cstride,
+                                                                            dy.coff, M, raw.C, mean, invstd, gamma, beta, act, (float*)ws)));
+    }
     // (sum dz, sum dz*xhat) -> this call's dbeta / dgamma, and (accumulated) into the parameter gradients
     pair_finalize_kernel<<<raw.C, 64, 0, st>>>((const float*)ws, nblk, raw.C, db, dg, dbeta, dgamma, accumulate_param_grads);
     const int g = grid_for(M * (raw.C / 8), 256);
-    YP_DT_SWITCH(dtype, (bn_bwd_apply_kernel<DT><<<g, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, (const char*)dy.ptr, dy.cstride, dy.coff,
-                                                                    (char*)dx.ptr, dx.cstride, dx.coff, M, raw.C, mean, invstd, gamma, beta, act, dg, db)));
+    if (fastp) {
+        const int gf = grid_for((M * (raw.C / 8) + 1) / 2, 256);
+        YP_DT_SWITCH(dtype, (bn_rows_fast_kernel<DT, true><<<gf, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, (const char*)dy.ptr, dy.cstride, dy.coff,
+                                                                              (char*)dx.ptr, dx.cstride, dx.coff, nullptr, 0, 0, (unsigned)M, lg, mean, invstd, gamma, beta,
+                                                                              act, dg, db)));
+    } else {
+        YP_DT_SWITCH(dtype, (bn_bwd_apply_kernel<DT><<<g, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, (const char*)dy.ptr, dy.cstride, dy.coff,
+                                                                        (char*)dx.ptr, dx.cstride, dx.coff, M, raw.C, mean, invstd, gamma, beta, act, dg, db)));
+    }
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
 }
