@@ -206,6 +206,9 @@ int yp_col_sum(YpView v, int dtype, int B, float* out, int accumulate, void* wor
  * [x.C][k][k][dy.C] must be zero-initialised).  x may be read through its 2x nearest upsample (x.ups = 1).
  * 16-bit dtypes.  replaces: autograd's conv2d weight gradient (reference train.py:245 loss.backward()). */
 int yp_conv_wgrad(YpView x, YpView dy, int dtype, int B, int k, float* dw, void* stream);
+/* dw[ci][r][s][co] (fp32, Cout_pad channels per tap: the layout yp_conv_wgrad / the wgrad-as-convolution path produce)
+ * -> grad[co][c0+ci][r][s] for ci < creal, co < Cout: the reference layout of conv.weight.grad */
+int yp_wgrad_unpack(const float* dw, float* grad, int Cout, int Cin, int k, int c0, int creal, int Cout_pad, void* stream);
 /* fp32 OIHW master filter w[Cout][Cin][R][S] -> the packed [Npad + 1][Kpad] `dtype` filter yp_conv2d reads (zero padded,
  * zero row last), so a training step re-derives its 16-bit filters on the device without host work:
  *   mode 0  forward filter of input-channel slice [c0, c0+Cj):  dst[n][(r*S+s)*Cj + c]       = w[n][c0+c][r][s]
@@ -235,6 +238,8 @@ enum {
     YP_OP_CAST_F32 = 24,      /* v0=in (fp32) v1=out; i0=dtype i1=B */
     YP_OP_MAXPOOL2 = 25,      /* v0=x v1=y; i0=dtype i1=B */
     YP_OP_WGRAD = 27,         /* v0=x v1=dy; p0=dw; i0=dtype i1=B i2=k */
+    YP_OP_WGRAD_UNPACK = 28,  /* p0=dw [Cj][k][k][Cout_pad] fp32 -> g0=grad OIHW [Cout][Cin][k][k] fp32, input-channel slice [c0, c0+creal):
+                               * i1=Cout i2=Cin i3=k i4=c0 i5=creal i6=Cout_pad */
     YP_OP_PACK_WEIGHT = 26    /* f0=w f1=bias; g0=bias_dst; p0=dst; i0=dtype i1=Cout i2=Cin i3=R i4=S i5=c0 i6=Cj i7=mode; n0=Kpad n1=Npad | Cout_pad<<32 */
 };
 typedef struct YpOpArgs {

@@ -67,3 +67,27 @@ for name, plan in (("fwd", g.fwd_plan), ("bwd", g.bwd_plan)):
     with open(os.path.join(ROOT, "gpurun_out", f"train_{name}_ops.txt"), "w") as f:
         for t, r in sorted(zip(ms, plan.records), key=lambda x: -x[0]):
             f.write(f"{t*1e3:9.1f} us  {r.kind:8s} {r.name:50s} M={r.M} N={r.N} K={r.K} flops={r.flops}\n")
+
+# ---- loss-graph-only timings on detached head outputs
+def det(o):
+    return {'semi': o['semi'].detach().requires_grad_(), 'desc': o['desc'].detach().requires_grad_(), 'objects': [t.detach().requires_grad_() for t in o['objects']]}
+od, owd = det(o), det(ow)
+print("  loss graphs alone (detached heads, synchronised):")
+tick("-")
+for rep in range(2):
+    lo = step.obj_loss(od['objects'], batch['box_labels'])[0]; tick("object loss fwd")
+    lo.backward(); tick("object loss bwd")
+    ln = infonce(od['desc'], owd['desc'], batch['warped_valid_mask'], batch['inv_homographies'], device=dev, **SPARSE); tick("infonce fwd")
+    ln.backward(); tick("infonce bwd")
+    ld = step.det_loss(od['semi'], labels2Dto3D(batch['labels_2D']), getMasks(batch['valid_mask'], dev)); tick("detector loss fwd")
+    ld.backward(); tick("detector loss bwd")
+
+if os.environ.get("YP_PROFILE_LOSS"):
+    from torch.profiler import profile, ProfilerActivity
+    for name, fn in (("infonce", lambda: infonce(od['desc'], owd['desc'], batch['warped_valid_mask'], batch['inv_homographies'], device=dev, **SPARSE)),
+                     ("object", lambda: step.obj_loss(od['objects'], batch['box_labels'])[0])):
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            l = fn(); l.backward(); torch.cuda.synchronize()
+        print(f"==== {name}")
+        print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=14, max_name_column_width=60))
+        print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=8, max_name_column_width=60))

@@ -817,6 +817,24 @@ extern "C" int yp_pack_weight(const float* w, int Cout, int Cin, int R, int S, i
     return YP_OK;
 }
 
+__global__ void wgrad_unpack_kernel(const float* __restrict__ dw, float* __restrict__ grad, int Cout, int Cin, int k, int c0, int creal, int Cout_pad) {
+    const int kk = k * k;
+    const size_t total = (size_t)Cout * creal * kk;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % kk);
+        const int ci = (int)((i / kk) % creal);
+        const int co = (int)(i / ((size_t)kk * creal));
+        grad[((size_t)co * Cin + c0 + ci) * kk + tap] = dw[((size_t)ci * kk + tap) * Cout_pad + co];
+    }
+}
+
+extern "C" int yp_wgrad_unpack(const float* dw, float* grad, int Cout, int Cin, int k, int c0, int creal, int Cout_pad, void* stream) {
+    YP_REQUIRE(dw && grad && Cout > 0 && Cin > 0 && k > 0 && c0 >= 0 && creal > 0 && c0 + creal <= Cin && Cout_pad >= Cout, "yp_wgrad_unpack: bad arguments");
+    wgrad_unpack_kernel<<<grid_for((size_t)Cout * creal * k * k, 256), 256, 0, (hipStream_t)stream>>>(dw, grad, Cout, Cin, k, c0, creal, Cout_pad);
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
 extern "C" int yp_run_op(const YpOpArgs* a, void* stream) {
     YP_REQUIRE(a != nullptr, "yp_run_op: null args");
     const int dt = a->i[0], B = a->i[1];
@@ -837,6 +855,7 @@ extern "C" int yp_run_op(const YpOpArgs* a, void* stream) {
         case YP_OP_SPPF_POOL: return yp_sppf_pool(a->v[0], a->v[1], a->v[2], a->v[3], B, dt, stream);
         case YP_OP_CAST_F32: return yp_cast_from_f32(a->v[0], a->v[1], dt, B, stream);
         case YP_OP_MAXPOOL2: return yp_maxpool2(a->v[0], a->v[1], B, dt, stream);
+        case YP_OP_WGRAD_UNPACK: return yp_wgrad_unpack((const float*)a->p[0], a->g[0], a->i[1], a->i[2], a->i[3], a->i[4], a->i[5], a->i[6], stream);
         case YP_OP_WGRAD: return yp_conv_wgrad(a->v[0], a->v[1], dt, B, a->i[2], (float*)a->p[0], stream);
         case YP_OP_PACK_WEIGHT:
             return yp_pack_weight(a->f[0], a->i[1], a->i[2], a->i[3], a->i[4], a->i[5], a->i[6], a->i[7], (int)(a->n[1] >> 32), a->p[0], (int)a->n[0],

@@ -23,11 +23,15 @@ def round_up(v, m):
 class Buf:
     """An NHWC device buffer."""
 
-    def __init__(self, B, H, W, C_, tdtype, device, zero=True):
+    def __init__(self, B, H, W, C_, tdtype, device, zero=True, storage=None):
         self.B, self.H, self.W, self.C = B, H, W, C_
         # a zero tail behind the pixels: the conv kernels' DMA fetches padding / out-of-image taps from there
         n = B * H * W * C_
-        self.flat = torch.zeros((n + C_ + 64,), dtype=tdtype, device=device)   # tail >= one pixel of channels + 64
+        if storage is not None:        # a slice of a caller-owned arena (output-only buffers: no zero tail needed)
+            assert storage.numel() >= n and storage.dtype == tdtype
+            self.flat = storage
+        else:
+            self.flat = torch.zeros((n + C_ + 64,), dtype=tdtype, device=device)   # tail >= one pixel of channels + 64
         self.t = self.flat[:n].view(B, H, W, C_)
 
     def view(self, coff=0, C_=None, ups=0):

@@ -17,6 +17,7 @@ A TrainGraph owns every buffer of one forward/backward pair; two forwards of the
 master parameters before every forward (`refresh`).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -43,6 +44,10 @@ class TrainGraph:
         wsb = lib().yp_bn_workspace_bytes(B, H // 2, W // 2, 1024) + 8 * 2048 + 4096
         self.ws = torch.empty(wsb, dtype=torch.uint8, device=device)
         self.Bpad = round_up(B, 8)
+        # every per-layer weight-gradient accumulator (fp32 [Cin][k][k][Cout_pad]) lives in one arena that the backward plan
+        # clears with a single memset
+        self.dw_arena = torch.zeros(2 * sum(p_.numel() for p_ in net.parameters()) + (1 << 20), dtype=torch.float32, device=device)
+        self.dw_used = 0
         self._build()
 
     # ------------------------------------------------------------------ helpers
@@ -155,9 +160,10 @@ class TrainGraph:
             image = src.geom is None and src.cstride == 4 and src.C == 4
             Cj = src.C
             Hi, Wi = src.LH, src.LW
-            dwb = Buf(Cj, k, k, Cout_pad, torch.float32, self.device)
-            self.keep.append(dwb.flat)
-            b.op(_hip.OP_MEMSET0, [], [dwb.view()], "zero_dw", p=[dwb.flat], n=[dwb.t.numel() * 4])
+            ndw = Cj * k * k * Cout_pad
+            assert self.dw_used + ndw <= self.dw_arena.numel()
+            dwb = Buf(Cj, k, k, Cout_pad, torch.float32, self.device, storage=self.dw_arena[self.dw_used:self.dw_used + ndw])
+            self.dw_used += round_up(ndw, 64)
             if direct and not image:
                 b.op(_hip.OP_WGRAD, [src, draw], [dwb.view()], "wgrad", v=[src, draw], i=[code, B, k], p=[dwb.flat])
                 b.records[-1].kind, b.records[-1].flops = "conv", 2 * B * Ho * Wo * Cj * k * k * Cout
@@ -176,7 +182,8 @@ class TrainGraph:
                        extra=dict(raw_weight=(dyp, K, Cout_pad), cout=Cout_pad, kernel_hw=(Ho, Wo), dil=s, out_hw=(k, k), ksplit=ksplit,
                                   atomic=1, batch=Cj, weight_view=self.T(dyp)))
             creal = weight.shape[1] - c0 if image else Cj
-            self.collect.append(lambda dwb=dwb, c0=c0, creal=creal: gw[:, c0:c0 + creal].copy_(dwb.t.permute(3, 0, 1, 2)[:Cout, :creal]))
+            b.op(_hip.OP_WGRAD_UNPACK, [dwb.view()], [self.T(gw)], "dw_unpack", p=[dwb.flat], g=[gw],
+                 i=[0, Cout, weight.shape[1], k, c0, creal, Cout_pad])
             # ---- dgrad (no gradient flows into the image)
             if not image:
                 cs, ce_ = c0, c0 + Cj
@@ -297,7 +304,8 @@ class TrainGraph:
                 self.conv_backward([v], mi.weight, mi.bias, draw, 1, 1, 0)
             det_seeds.append(det_backward)
         self.semi_v, self.desc_v = semi, dnorm
-        # ---- emit the backward plan: seeds first, then the tape in reverse
+        # ---- emit the backward plan: clear the weight-gradient arena, seeds, then the tape in reverse
+        b.op(_hip.OP_MEMSET0, [], [self.T(self.dw_arena)], "zero_dw", p=[self.dw_arena], n=[self.dw_arena.numel() * 4])
         semi_seed()
         desc_seed()
         # Detect backward must run before the PAN blocks' backward (it writes their output gradients)
@@ -307,6 +315,9 @@ class TrainGraph:
             fn()
         self.fwd_plan = f.finish(parallel=False)
         self.bwd_plan = b.finish(parallel=False)
+        if os.environ.get("YP_TRAIN_GRAPH", "1") != "0":      # replay both launch lists as hipGraphs (284 / 450 launches per pass)
+            self.fwd_plan.instantiate_graph()
+            self.bwd_plan.instantiate_graph()
         self.params = [p_ for p_ in net.parameters()]
 
     # ------------------------------------------------------------------ run
