@@ -79,3 +79,24 @@ def test_two_forwards_then_backward_like_the_reference_step(cuda):
     g2 = m.model.Conv2.conv.weight.grad.clone()
     # BN running statistics moved between the calls, batch statistics did not: gradients are additive
     assert rel_err(g_both, g1 + g2)[1] < 1e-4
+
+
+def test_train_step_with_precomputed_label_parts(cuda):
+    """engine.TrainStep runs the label-only, host-synchronising parts of the losses (target assignment, InfoNCE sampling)
+    before the forwards; loss and parameter gradients must equal the reference order (train.py:208-245) for the same draws.
+    Tolerance: the fp32 atomics of the weight-gradient kernels make two runs differ at the 1e-4 level."""
+    from yolopoint_amd.engine import TrainStep, synthetic_batch
+    m, _ = make_model("n", 3, dtype="f32")
+    m = m.to(cuda).train()
+    step = TrainStep(m, cuda, img_size=128)
+    step.sparse = dict(num_samples_per_image=100, num_masked_non_matches_per_match=20)
+    batch = synthetic_batch(2, 128, cuda, 5)
+    grads = {}
+    for prepare in (True, False):
+        torch.manual_seed(11)                      # same InfoNCE draws in both runs
+        loss = step.loss_and_grads(batch, prepare=prepare)
+        grads[prepare] = ({n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}, float(loss))
+    assert abs(grads[True][1] - grads[False][1]) <= 1e-5 * abs(grads[False][1])
+    assert grads[True][0].keys() == grads[False][0].keys() and len(grads[True][0]) > 100
+    for n, g in grads[False][0].items():
+        assert rel_err(grads[True][0][n], g)[1] < 2e-3, n

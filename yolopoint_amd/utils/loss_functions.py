@@ -51,10 +51,13 @@ class ComputeObjectLoss:
         self.gr, self.autobalance = 1.0, autobalance
         self.na, self.nc, self.nl, self.anchors = det.na, det.nc, det.nl, det.anchors
 
-    def __call__(self, p, targets):
+    def __call__(self, p, targets, prepared=None):
+        """`prepared`: the result of build_targets(p or [t.shape for t in p], targets) computed ahead of time -- it depends on
+        the labels and the level shapes only and synchronises with the device (boolean-mask indexing), so a training step
+        runs it BEFORE launching the forward passes to keep the rest of the step free of host syncs."""
         dev = self.device
         lcls, lbox, lobj = (torch.zeros(1, device=dev) for _ in range(3))
-        tcls, tbox, indices, anchors = self.build_targets(p, targets)
+        tcls, tbox, indices, anchors = prepared if prepared is not None else self.build_targets(p, targets)
         for i, pi in enumerate(p):
             b, a, gj, gi = indices[i]
             tobj = torch.zeros(pi.shape[:4], dtype=pi.dtype, device=dev)
@@ -99,7 +102,7 @@ class ComputeObjectLoss:
         g = 0.5
         off = torch.tensor([[0, 0], [1, 0], [0, 1], [-1, 0], [0, -1]], device=dev).float() * g
         for i in range(self.nl):
-            anchors, shape = self.anchors[i], p[i].shape
+            anchors, shape = self.anchors[i], (p[i].shape if isinstance(p[i], torch.Tensor) else tuple(p[i]))
             gain[2:6] = torch.tensor(shape)[[3, 2, 3, 2]]
             t = targets * gain
             if nt:
@@ -172,7 +175,7 @@ def normPts(pts, shape):
 
 
 def infonce(descriptors, descriptors_warped, mask_valid_warp, inv_homographies, num_samples_per_image=1500,
-            num_masked_non_matches_per_match=120, cell_size=8, device='cpu', tau=0.07, perm_fn=None, randint_fn=None):
+            num_masked_non_matches_per_match=120, cell_size=8, device='cpu', tau=0.07, perm_fn=None, randint_fn=None, prepared=None):
     """Cross-image InfoNCE between the descriptors of an image and of its warp (reference utils/loss_functions.py:484-597):
     every valid cell of image A is matched to the cell its inverse homography maps it to in image B;
     `num_masked_non_matches_per_match` random other matches are the negatives;
@@ -183,11 +186,32 @@ def infonce(descriptors, descriptors_warped, mask_valid_warp, inv_homographies, 
     [n, n]) and, unless the draws are injected (`perm_fn` / `randint_fn`: the parity tests replay the reference's draws),
     cells and negatives are drawn on the device with the same distributions (uniform permutation of the valid cells;
     uniform negatives, a negative equal to its own match redrawn from [0, #collisions) exactly as the reference does)."""
-    assert descriptors.shape[-1] * descriptors.shape[-2] >= num_samples_per_image, \
+    if prepared is None:
+        prepared = infonce_prepare(mask_valid_warp, inv_homographies, tuple(descriptors.shape), descriptors.is_cuda, num_samples_per_image,
+                                   num_masked_non_matches_per_match, cell_size, device, perm_fn, randint_fn)
+    ua, ub, rnd = prepared
+
+    def sample(desc, idx):
+        return F.grid_sample(desc, idx.unsqueeze(1), mode='bilinear', align_corners=True).squeeze(2).transpose(1, 2)
+
+    da = sample(descriptors, ua)                       # [B, pool, D]
+    db = sample(descriptors_warped, ub)
+    pos = (da * db).sum(-1).flatten()
+    da, db = da.flatten(0, 1), db.flatten(0, 1)
+    neg = (da @ db.t()).gather(1, rnd)                 # [n, negs] = <da[i], db[rnd[i, j]]>
+    logits = torch.cat([pos.unsqueeze(1), neg], dim=1) / tau
+    return -F.log_softmax(logits, dim=1)[:, 0].mean()
+
+
+def infonce_prepare(mask_valid_warp, inv_homographies, desc_shape, on_device, num_samples_per_image=1500,
+                    num_masked_non_matches_per_match=120, cell_size=8, device='cpu', perm_fn=None, randint_fn=None):
+    """The label-only half of `infonce`: which cells are matched (normalised sample coordinates ua, ub [B, pool, 2]) and
+    which matches serve as negatives (rnd [n, negs]).  It needs one host sync (the common pool size), so a training step
+    calls it before the forward passes are launched."""
+    assert desc_shape[-1] * desc_shape[-2] >= num_samples_per_image, \
         "Number of samples per image must be greater than number of pixels in image"
-    on_device = descriptors.is_cuda
     with torch.no_grad():
-        B, Hc, Wc = descriptors.shape[0], descriptors.shape[2], descriptors.shape[3]
+        B, Hc, Wc = desc_shape[0], desc_shape[2], desc_shape[3]
         uv_a = get_coor_cells(Hc, Wc, uv=True).to(device)
         inv_h = inv_homographies.to(device)
         valid = warp_image_batch(mask_valid_warp, inv_h, mode='nearest', device=device)
@@ -214,20 +238,11 @@ def infonce(descriptors, descriptors_warped, mask_valid_warp, inv_homographies, 
         size = torch.tensor([Wc, Hc]).float().to(device)
         ua = normPts(pa, size)
         ub = normPts(pb, size)
-
-    def sample(desc, idx):
-        return F.grid_sample(desc, idx.unsqueeze(1), mode='bilinear', align_corners=True).squeeze(2).transpose(1, 2)
-
-    da = sample(descriptors, ua)                       # [B, pool, D]
-    db = sample(descriptors_warped, ub)
-    pos = (da * db).sum(-1).flatten()
-    da, db = da.flatten(0, 1), db.flatten(0, 1)
-    n, negs = da.shape[0], num_masked_non_matches_per_match
-    with torch.no_grad():
+        n, negs = ua.shape[0] * ua.shape[1], num_masked_non_matches_per_match
         if randint_fn is None and on_device:
-            rnd = torch.randint(0, n, (n, negs), device=da.device)                     # rnd[i, j]: j-th negative of match i
-            same = rnd == torch.arange(n, device=da.device).unsqueeze(1)               # a negative must not be the match itself
-            cand = (torch.rand(rnd.shape, device=da.device) * same.sum()).long()
+            rnd = torch.randint(0, n, (n, negs), device=ua.device)                     # rnd[i, j]: j-th negative of match i
+            same = rnd == torch.arange(n, device=ua.device).unsqueeze(1)               # a negative must not be the match itself
+            cand = (torch.rand(rnd.shape, device=ua.device) * same.sum()).long()
             rnd = torch.where(same, cand, rnd)
         else:
             draw = randint_fn or np.random.randint
@@ -241,10 +256,8 @@ def infonce(descriptors, descriptors_warped, mask_valid_warp, inv_homographies, 
                     if (rnd[same] != cand).any():
                         rnd[same] = cand
                         break
-            rnd = torch.from_numpy(np.ascontiguousarray(rnd.T)).to(da.device)
-    neg = (da @ db.t()).gather(1, rnd)                 # [n, negs] = <da[i], db[rnd[i, j]]>
-    logits = torch.cat([pos.unsqueeze(1), neg], dim=1) / tau
-    return -F.log_softmax(logits, dim=1)[:, 0].mean()
+            rnd = torch.from_numpy(np.ascontiguousarray(rnd.T)).to(ua.device)
+    return ua, ub, rnd
 
 
 descriptor_loss_sparse = infonce      # the name train.py imports it under (train.py:8)
