@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Distil the rocprofv3 CSVs written by tools/profile_round.sh into gpurun_out/prof_<round>/summary files
+(copied into profiles/ by hand after review).  Plan executions per bench run = steps + warmup + 5 profile passes."""
+import collections, csv, glob, json, os, re, sys
+
+R = sys.argv[1] if len(sys.argv) > 1 else "r01"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out", f"prof_{R}")
+CONV = re.compile(r"conv_igemm_kernel|conv3x3_halo_kernel|bottleneck_halo_kernel|stem_conv_kernel")
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    return re.sub(r"^void ", "", name).split("(")[0][:100]
+
+
+def find(sub, pat):
+    fs = glob.glob(os.path.join(OUT, sub, "**", pat), recursive=True)
+    return fs[0] if fs else None
+
+
+def first_step_dispatch(path):
+    """Dispatch id of the first stem_conv_kernel launch: everything before it is plan construction (kernel-variant
+    autotuning launches every candidate of every convolution), everything from it on is the measured plan replays."""
+    ids = [int(r["Dispatch_Id"]) for r in csv.DictReader(open(path)) if "stem_conv_kernel" in r["Kernel_Name"]]
+    return min(ids) if ids else 0
+
+
+def trace_table(path, execs, title, steady=True):
+    d = collections.defaultdict(list)
+    d0 = first_step_dispatch(path) if steady else 0
+    for r in csv.DictReader(open(path)):
+        if int(r["Dispatch_Id"]) < d0:
+            continue
+        d[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    tot = sum(sum(v) for v in d.values())
+    lines = [f"# {title}", f"{'kernel':102s} {'calls':>7s} {'total_us':>11s} {'avg_us':>9s} {'min_us':>8s} {'max_us':>8s} {'%':>6s}"]
+    for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
+        lines.append(f"{k:102s} {len(v):7d} {sum(v)/1e3:11.1f} {sum(v)/len(v)/1e3:9.2f} {min(v)/1e3:8.2f} {max(v)/1e3:8.2f} {100*sum(v)/tot:6.2f}")
+    return d, lines
+
+
+def counter_sum(path, counter, d0):
+    s, n = 0.0, 0
+    for r in csv.DictReader(open(path)):
+        if int(r["Dispatch_Id"]) < d0:
+            continue
+        if r["Counter_Name"] == counter and CONV.search(r["Kernel_Name"]):
+            s += float(r["Counter_Value"]); n += 1
+    return s, n
+
+
+def main():
+    execs = 50 + 10 + 5
+    res = {"round": R, "command": "python bench.py --no-cpu-baseline --steps 50 --warmup 10", "plan_executions": execs}
+    lines = []
+    t = find("trace", "*kernel_trace.csv")
+    if t:
+        d, tl = trace_table(t, execs, "rocprofv3 --kernel-trace of: " + res["command"] + "  (dispatches from the first plan replay on: plan construction / autotuning excluded)")
+        lines += tl
+        conv_ns = sum(sum(v) for k, v in d.items() if CONV.search(k))
+        conv_calls = sum(len(v) for k, v in d.items() if CONV.search(k))
+        res.update(conv_launches_per_step=conv_calls / execs, conv_us_per_step_trace=conv_ns / 1e3 / execs,
+                   conv_avg_us_per_launch_trace=conv_ns / 1e3 / max(conv_calls, 1),
+                   all_kernels_us_per_step_trace=sum(sum(v) for v in d.values()) / 1e3 / execs)
+    f, w = find("pmc_fetch", "*counter_collection.csv"), find("pmc_write", "*counter_collection.csv")
+    if f and w:
+        fs, fn = counter_sum(f, "FETCH_SIZE", first_step_dispatch(find("pmc_fetch", "*kernel_trace.csv")))
+        ws, wn = counter_sum(w, "WRITE_SIZE", first_step_dispatch(find("pmc_write", "*kernel_trace.csv")))
+        # rocprofv3 reports both counters in KiB (check: l2norm writes 51200 px x 128 ch x 4 B = 25 600 KiB per launch, the value it
+        # shows); gfx950 FETCH_SIZE counts 16-B/lane streaming reads at half their bytes (MI355X_MICROARCH.md, HBM section) -> x2.
+        fetch_b, write_b = fs * 1024 / execs, ws * 1024 / execs
+        traffic = {"source": f"gpurun_out/prof_{R}: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, --kernel-trace only) of `{res['command']}`",
+                   "workload": "YOLOPoint-s bs8 640x640 f16", "plan_executions": execs,
+                   "kernels": "conv_igemm_kernel / conv3x3_halo_kernel / bottleneck_halo_kernel / stem_conv_kernel (all instantiations)",
+                   "conv_launches_per_step": res.get("conv_launches_per_step"),
+                   "fetch_bytes_per_step_raw": fetch_b, "fetch_correction": "x2 (gfx950 FETCH_SIZE tallies 128-B requests of 16-B/lane streaming reads at 64 B)",
+                   "write_bytes_per_step_raw": write_b, "hbm_bytes_per_step": 2 * fetch_b + write_b,
+                   "hbm_bytes_per_launch": (2 * fetch_b + write_b) / max(res.get("conv_launches_per_step") or 1, 1),
+                   "conv_us_per_step_trace": res.get("conv_us_per_step_trace")}
+        json.dump(traffic, open(os.path.join(OUT, "conv_traffic.json"), "w"), indent=1)
+        res["traffic"] = traffic
+    open(os.path.join(OUT, f"{R}_infer_kernel_trace.txt"), "w").write("\n".join(lines) + "\n")
+    tt = find("trace_train", "*kernel_trace.csv")
+    if tt:
+        d, tl = trace_table(tt, 7, "rocprofv3 --kernel-trace of: python bench.py --mode train --steps 5 --warmup 2 (7 optimizer steps + plan build/autotune)", steady=False)
+        open(os.path.join(OUT, f"{R}_train_kernel_trace.txt"), "w").write("\n".join(tl[:80]) + "\n")
+    json.dump(res, open(os.path.join(OUT, f"{R}_collect.json"), "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Regenerates the evidence under profiles/ for one round on a GPU box (run through gpurun from the repo root):
+#   tools/profile_round.sh r01
+# 1. the default bench line, 2. rocprofv3 --kernel-trace of the same command, 3. two separate --pmc passes (FETCH_SIZE,
+# WRITE_SIZE; never combined with other trace domains), 4. the training step line + its kernel trace.
+# Writes everything to gpurun_out/prof_<round>/; tools/profile_collect.py then distils profiles/<round>_*.{txt,json}.
+set -u
+R=${1:-r01}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/prof_$R
+mkdir -p $OUT
+export TMPDIR=/tmp
+BENCH="python $ROOT/bench.py --no-cpu-baseline --steps 50 --warmup 10"
+python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+python bench.py --no-cpu-baseline --steps 300 --warmup 30 --layers $OUT/layers.txt > $OUT/bench_long.json 2>> $OUT/bench_default.err
+cd /tmp
+rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o t -- $BENCH > $OUT/trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o f -- $BENCH > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o w -- $BENCH > $OUT/pmc_write.log 2>&1
+cd $ROOT
+python bench.py --mode train --steps 20 --warmup 3 > $OUT/bench_train.json 2> $OUT/bench_train.err
+cd /tmp
+rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_train -o t -- python $ROOT/bench.py --mode train --steps 5 --warmup 2 > $OUT/trace_train.log 2>&1
+cd $ROOT
+python tools/profile_collect.py $R
+# raw traces are large: keep only what profile_collect distilled
+rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/trace_train
+ls -la $OUT
