@@ -62,6 +62,33 @@ def test_backward_matches_oracle_autograd(cuda, version, B, S):
     print("largest gradient rel-L2 errors:", sorted(worst)[-3:])
 
 
+def test_keypoint_only_backward_matches_oracle_autograd(cuda):
+    """A forward whose `objects` take no part in the loss (the warped pass of a training step, train.py:220-241) is
+    back-propagated through the semi / desc sub-graph only: its parameters match PyTorch-CPU autograd through the oracle,
+    and the Detect / PAN / YOLO-encoder parameters receive no gradient at all (as with autograd)."""
+    m, sd = make_model("n", 33, dtype="f32")
+    m = m.to(cuda).train()
+    x = net_oracle.synth_image(2, 3, 64, 64, 33)
+    g = torch.Generator().manual_seed(6)
+    leaf = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in sd.items()}
+    ref = net_oracle.yolopoint_forward(leaf, x, "n", training=True, stats={})
+    ps, pd = torch.randn(ref["semi"].shape, generator=g), torch.randn(ref["desc"].shape, generator=g)
+    ((ref["semi"] * ps).sum() * 0.01 + (ref["desc"] * pd).sum()).backward()
+    out = m(x.to(cuda))
+    ((out["semi"] * ps.to(cuda)).sum() * 0.01 + (out["desc"] * pd.to(cuda)).sum()).backward()
+    reached = 0
+    for name, p in m.named_parameters():
+        gref = leaf[name].grad
+        if gref is None:
+            assert p.grad is None, name
+            continue
+        reached += 1
+        assert p.grad is not None, name
+        assert rel_err(p.grad, gref)[1] < 2e-3, name
+    names = [n for n, p in m.named_parameters() if p.grad is None]
+    assert reached > 60 and any("Detect" in n for n in names) and any("Bottleneck8" in n for n in names) and not any("ConvDesc" in n for n in names)
+
+
 def test_two_forwards_then_backward_like_the_reference_step(cuda):
     """train.py:208-245: model(img), model(img_warp), one loss, one backward -> gradients add up."""
     m, sd = make_model("n", 7, dtype="f32")

@@ -34,7 +34,9 @@ class TrainGraph:
         self.tdtype = _hip.torch_dtype(code)
         self.fwd = PlanBuilder(B, code, device)
         self.bwd = PlanBuilder(B, code, device)
-        self.tape = []
+        self.tape = []             # (branch, emitter): 'kp' feeds the keypoint / descriptor heads, 'yolo' only the Detect head
+        self.branch = "kp"
+        self.touched = set()       # parameters whose gradient the plan being emitted writes
         self.gbufs = {}            # data_ptr of an activation buffer -> its gradient Buf
         self.gwritten = {}         # data_ptr -> list of written (lo, hi) channel ranges
         self.collect = []          # callables run after the backward plan: native buffers -> parameter gradients
@@ -54,6 +56,7 @@ class TrainGraph:
     def pgrad(self, param):
         if param not in self.pgrads:
             self.pgrads[param] = torch.zeros_like(param, dtype=torch.float32)
+        self.touched.add(param)
         return self.pgrads[param]
 
     def gview(self, v):
@@ -117,7 +120,7 @@ class TrainGraph:
             b.op(_hip.OP_BN_BWD, [raw, gy], [draw], "bn_act_bwd", v=[raw, gy, draw], i=[code, B, act, 0],
                  f=[mean, invstd, bn.weight, bn.bias], g=[self.pgrad(bn.weight), self.pgrad(bn.bias)], p=[self.ws], n=[self.ws.numel()])
             self.conv_backward(srcs, conv.weight, None, draw, k, s, p)
-        self.tape.append(backward)
+        self.tape.append((self.branch, backward))
         return out
 
     def conv_plain(self, weight, bias, x, k, s, p, name):
@@ -134,7 +137,7 @@ class TrainGraph:
                 draw = b.new_buf(out.H, out.W, out.C).view()
                 b.op(_hip.OP_CAST_F32, [g32], [draw], "cast", v=[g32, draw], i=[self.code, self.B])
             self.conv_backward([x], weight, bias, draw, k, s, p)
-        self.tape.append(backward)
+        self.tape.append((self.branch, backward))
         return out
 
     def conv_backward(self, srcs, weight, bias, draw, k, s, p):
@@ -231,7 +234,7 @@ class TrainGraph:
             b.op(_hip.OP_MAXPOOL5_BWD, [s2, g3, g2], [g2], "pool_bwd3", v=[s2, g3, g2], i=[code, B, 1], p=[self.ws], n=[self.ws.numel()])
             b.op(_hip.OP_MAXPOOL5_BWD, [s1, g2, g1], [g1], "pool_bwd2", v=[s1, g2, g1], i=[code, B, 1], p=[self.ws], n=[self.ws.numel()])
             b.op(_hip.OP_MAXPOOL5_BWD, [s0, g1, g0], [g0], "pool_bwd1", v=[s0, g1, g0], i=[code, B, 1], p=[self.ws], n=[self.ws.numel()])
-        self.tape.append(backward)
+        self.tape.append((self.branch, backward))
         return self.conv_bn_act(m.cv2, cat.view())
 
     # ------------------------------------------------------------------ the graph
@@ -247,10 +250,10 @@ class TrainGraph:
         t = self.c3(net.BottleneckDet, x8)
         semi = self.conv_plain(net.ConvDet.weight, None, t, 1, 1, 0, "ConvDet")
         self.g_semi = torch.zeros((B, 65, Hc, Wc), dtype=torch.float32, device=self.device)
-        gsemi_v, _ = self.gview(semi)
 
         def semi_seed():
-            b.op(_hip.OP_PACK_NCHW, [self.T(self.g_semi)], [gsemi_v], "seed_semi", f=[self.g_semi], v=[gsemi_v], i=[_hip.YP_F32, B, 65])
+            gsemi_v, _ = self.gview(semi)
+            self.bwd.op(_hip.OP_PACK_NCHW, [self.T(self.g_semi)], [gsemi_v], "seed_semi", f=[self.g_semi], v=[gsemi_v], i=[_hip.YP_F32, B, 65])
         xb = self.c3(net.Bottleneck2, x8)
         # descriptor head
         dA = self.conv_bn_act(net.ConvDescA, xa)
@@ -263,12 +266,14 @@ class TrainGraph:
         self.g_desc = torch.zeros((B, c3ch, Hc, Wc), dtype=torch.float32, device=self.device)
         gd = Buf(B, Hc, Wc, craw.C, torch.float32, self.device)
         self.keep.append(gd.flat)
-        gcraw, _ = self.gview(craw)
 
         def desc_seed():
+            b = self.bwd
+            gcraw, _ = self.gview(craw)
             b.op(_hip.OP_PACK_NCHW, [self.T(self.g_desc)], [gd.view()], "seed_desc", f=[self.g_desc], v=[gd.view()], i=[_hip.YP_F32, B, c3ch])
             b.op(_hip.OP_L2NORM_BWD, [craw, gd.view()], [gcraw], "l2norm_bwd", v=[craw, gd.view(), gcraw], i=[0, B, c3ch])
-        # YOLO encoder + PAN
+        # YOLO encoder + PAN: nothing below feeds semi / desc
+        self.branch = "yolo"
         x = self.conv_bn_act(net.Conv4, xb)
         xc = self.c3(net.Bottleneck3, x)
         x = self.conv_bn_act(net.Conv5, xc)
@@ -299,25 +304,39 @@ class TrainGraph:
             self.g_xs.append(gx)
 
             def det_backward(v=v, mi=mi, gx=gx, ny=ny, nx=nx):
+                b = self.bwd
                 draw = b.new_buf(ny, nx, round_up(det.na * det.no, 8)).view()
                 b.op(_hip.OP_DETECT_BWD_PACK, [self.T(gx)], [draw], "seed_det", f=[gx], v=[draw], i=[code, B, det.na, det.no])
                 self.conv_backward([v], mi.weight, mi.bias, draw, 1, 1, 0)
             det_seeds.append(det_backward)
         self.semi_v, self.desc_v = semi, dnorm
-        # ---- emit the backward plan: clear the weight-gradient arena, seeds, then the tape in reverse
-        b.op(_hip.OP_MEMSET0, [], [self.T(self.dw_arena)], "zero_dw", p=[self.dw_arena], n=[self.dw_arena.numel() * 4])
-        semi_seed()
-        desc_seed()
-        # Detect backward must run before the PAN blocks' backward (it writes their output gradients)
-        for fn in det_seeds:
-            fn()
-        for fn in reversed(self.tape):
-            fn()
         self.fwd_plan = f.finish(parallel=False)
-        self.bwd_plan = b.finish(parallel=False)
-        if os.environ.get("YP_TRAIN_GRAPH", "1") != "0":      # replay both launch lists as hipGraphs (284 / 450 launches per pass)
-            self.fwd_plan.instantiate_graph()
-            self.bwd_plan.instantiate_graph()
+
+        # ---- backward plans: clear the weight-gradient arena, seed the head gradients, then the tape in reverse.
+        # Two variants: the full one, and one that only back-propagates the semi / desc sub-graph -- the reference's second
+        # forward of a step (warped image) has no object loss, so autograd never visits its Detect / PAN / YOLO-encoder
+        # layers (4 F_fwd + 2 F_kp per sample, not 6 F_fwd).
+        def emit(kp_only):
+            self.bwd = bb = PlanBuilder(B, code, self.device)
+            for key in self.gwritten:
+                self.gwritten[key] = []
+            self.touched, self.collect = set(), []
+            bb.op(_hip.OP_MEMSET0, [], [self.T(self.dw_arena)], "zero_dw", p=[self.dw_arena], n=[self.dw_arena.numel() * 4])
+            semi_seed()
+            desc_seed()
+            if not kp_only:
+                for fn in det_seeds:      # Detect backward runs before the PAN blocks' backward (it writes their output gradients)
+                    fn()
+            for branch, fn in reversed(self.tape):
+                if not kp_only or branch == "kp":
+                    fn()
+            plan = bb.finish(parallel=False)
+            return plan, self.touched, self.collect
+        self.bwd_plan, self.bwd_params, self.bwd_collect = emit(False)
+        self.bwd_kp_plan, self.bwd_kp_params, self.bwd_kp_collect = emit(True)
+        if os.environ.get("YP_TRAIN_GRAPH", "1") != "0":      # replay the launch lists as hipGraphs (284 / 455 / 230 launches)
+            for plan in (self.fwd_plan, self.bwd_plan, self.bwd_kp_plan):
+                plan.instantiate_graph()
         self.params = [p_ for p_ in net.parameters()]
 
     # ------------------------------------------------------------------ run
@@ -327,6 +346,7 @@ class TrainGraph:
         if ver != getattr(self, "_packed_version", None):
             self.fwd_plan.refresh()
             self.bwd_plan.refresh()
+            self.bwd_kp_plan.refresh()
             self._packed_version = ver
         pack_input(x, self.img.view(), self.code)
         self.fwd_plan.run()
@@ -339,15 +359,18 @@ class TrainGraph:
         return semi, desc, [t.clone() for t in self.xs]
 
     def backward(self, g_semi, g_desc, g_xs):
-        for dst, src in [(self.g_semi, g_semi), (self.g_desc, g_desc)] + list(zip(self.g_xs, g_xs)):
+        """Head gradients (None = that head took no part in the loss) -> parameter gradients (None = not reached)."""
+        kp_only = all(g is None for g in g_xs)
+        for dst, src in [(self.g_semi, g_semi), (self.g_desc, g_desc)] + ([] if kp_only else list(zip(self.g_xs, g_xs))):
             if src is None:
                 dst.zero_()
             else:
                 dst.copy_(src)
-        self.bwd_plan.run()
-        for fn in self.collect:
+        plan, touched, collect = (self.bwd_kp_plan, self.bwd_kp_params, self.bwd_kp_collect) if kp_only else (self.bwd_plan, self.bwd_params, self.bwd_collect)
+        plan.run()
+        for fn in collect:
             fn()
-        return [self.pgrads.get(p_) for p_ in self.params]
+        return [self.pgrads[p_] if p_ in touched else None for p_ in self.params]
 
 
 class _YOLOPointTrainFn(torch.autograd.Function):
@@ -355,6 +378,7 @@ class _YOLOPointTrainFn(torch.autograd.Function):
     def forward(ctx, net, x, *params):
         g = net._train_graph(x)
         ctx.graph = g
+        ctx.set_materialize_grads(False)       # a head that took no part in the loss arrives as None
         semi, desc, xs = g.forward(x)
         if torch.is_grad_enabled() or any(p.requires_grad for p in params):
             g.busy = True
