@@ -201,11 +201,11 @@ int yp_to_chwb(YpView in, int dtype, int B, int C, void* out, int Bpad, void* st
 /* fp32 NHWC view -> `dtype` NHWC view */
 int yp_cast_from_f32(YpView in, YpView out, int dtype, int B, void* stream);
 int yp_col_sum(YpView v, int dtype, int B, float* out, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
-/* Weight gradient of a stride-1 convolution (k = 1, or k = 3 with pad 1) straight from the NHWC tensors, no transposed
- * copies: dw[ci][r][s][co] += sum_{b,y,x} x[b, y+r-p, x+s-p, ci] * dy[b, y, x, co]   (fp32 atomics: `dw`
- * [x.C][k][k][dy.C] must be zero-initialised).  x may be read through its 2x nearest upsample (x.ups = 1).
+/* Weight gradient of a convolution (k = 1 stride 1, or k = 3 with pad 1 and stride 1 | 2) straight from the NHWC tensors, no
+ * transposed copies: dw[ci][r][s][co] += sum_{b,y,x} x[b, y*stride+r-p, x*stride+s-p, ci] * dy[b, y, x, co]   (fp32 atomics:
+ * `dw` [x.C][k][k][dy.C] must be zero-initialised).  x may be read through its 2x nearest upsample (x.ups = 1).
  * 16-bit dtypes.  replaces: autograd's conv2d weight gradient (reference train.py:245 loss.backward()). */
-int yp_conv_wgrad(YpView x, YpView dy, int dtype, int B, int k, float* dw, void* stream);
+int yp_conv_wgrad(YpView x, YpView dy, int dtype, int B, int k, int stride, float* dw, void* stream);
 /* dw[ci][r][s][co] (fp32, Cout_pad channels per tap: the layout yp_conv_wgrad / the wgrad-as-convolution path produce)
  * -> grad[co][c0+ci][r][s] for ci < creal, co < Cout: the reference layout of conv.weight.grad */
 int yp_wgrad_unpack(const float* dw, float* grad, int Cout, int Cin, int k, int c0, int creal, int Cout_pad, void* stream);
@@ -237,7 +237,7 @@ enum {
     YP_OP_SPPF_POOL = 23,     /* v0=x v1..v3=y1..y3; i0=dtype i1=B */
     YP_OP_CAST_F32 = 24,      /* v0=in (fp32) v1=out; i0=dtype i1=B */
     YP_OP_MAXPOOL2 = 25,      /* v0=x v1=y; i0=dtype i1=B */
-    YP_OP_WGRAD = 27,         /* v0=x v1=dy; p0=dw; i0=dtype i1=B i2=k */
+    YP_OP_WGRAD = 27,         /* v0=x v1=dy; p0=dw; i0=dtype i1=B i2=k i3=stride */
     YP_OP_WGRAD_UNPACK = 28,  /* p0=dw [Cj][k][k][Cout_pad] fp32 -> g0=grad OIHW [Cout][Cin][k][k] fp32, input-channel slice [c0, c0+creal):
                                * i1=Cout i2=Cin i3=k i4=c0 i5=creal i6=Cout_pad */
     YP_OP_PACK_WEIGHT = 26    /* f0=w f1=bias; g0=bias_dst; p0=dst; i0=dtype i1=Cout i2=Cin i3=R i4=S i5=c0 i6=Cj i7=mode; n0=Kpad n1=Npad | Cout_pad<<32 */

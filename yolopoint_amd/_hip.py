@@ -78,7 +78,7 @@ SIGNATURES = {
     "yp_detect_bwd_pack": (_i, [_p, _i, _i, _i, YpView, _i, _p]),
     "yp_to_chwb": (_i, [YpView, _i, _i, _i, _p, _i, _p]),
     "yp_cast_from_f32": (_i, [YpView, YpView, _i, _i, _p]),
-    "yp_conv_wgrad": (_i, [YpView, YpView, _i, _i, _i, _p, _p]),
+    "yp_conv_wgrad": (_i, [YpView, YpView, _i, _i, _i, _i, _p, _p]),
     "yp_wgrad_unpack": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "yp_pack_weight": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _p, _p]),
     "yp_col_sum": (_i, [YpView, _i, _i, _p, _i, _p, _sz, _p]),

@@ -856,7 +856,7 @@ extern "C" int yp_run_op(const YpOpArgs* a, void* stream) {
         case YP_OP_CAST_F32: return yp_cast_from_f32(a->v[0], a->v[1], dt, B, stream);
         case YP_OP_MAXPOOL2: return yp_maxpool2(a->v[0], a->v[1], B, dt, stream);
         case YP_OP_WGRAD_UNPACK: return yp_wgrad_unpack((const float*)a->p[0], a->g[0], a->i[1], a->i[2], a->i[3], a->i[4], a->i[5], a->i[6], stream);
-        case YP_OP_WGRAD: return yp_conv_wgrad(a->v[0], a->v[1], dt, B, a->i[2], (float*)a->p[0], stream);
+        case YP_OP_WGRAD: return yp_conv_wgrad(a->v[0], a->v[1], dt, B, a->i[2], a->i[3] > 0 ? a->i[3] : 1, (float*)a->p[0], stream);
         case YP_OP_PACK_WEIGHT:
             return yp_pack_weight(a->f[0], a->i[1], a->i[2], a->i[3], a->i[4], a->i[5], a->i[6], a->i[7], (int)(a->n[1] >> 32), a->p[0], (int)a->n[0],
                                   (int)(a->n[1] & 0xffffffffu), dt, a->f[1], a->g[0], stream);

@@ -1,6 +1,6 @@
-// Weight gradient of a stride-1 convolution (1x1, or 3x3 with pad 1) straight from the NHWC tensors:
+// Weight gradient of a convolution (1x1 stride 1, or 3x3 with pad 1 and stride 1 | 2) straight from the NHWC tensors:
 //
-//   dW[ci][r][s][co] += sum over (b, y, x) of  x[b, y+r-p, x+s-p, ci] * dy[b, y, x, co]
+//   dW[ci][r][s][co] += sum over (b, y, x) of  x[b, y*st+r-p, x*st+s-p, ci] * dy[b, y, x, co]
 //
 // The reduction runs over PIXELS, which is the strided axis of both NHWC operands, so neither matches the
 // MFMA fragment layout (8 consecutive k per lane).  Instead of materialising pixel-major copies in HBM, both
@@ -11,7 +11,7 @@
 // x and dy, so the k permutation inside a fragment cancels in the dot product.
 //
 // A workgroup owns a [64 ci x 64 co] block of dW for every tap and walks a strided subset of the pixel tiles
-// (128 pixels each: 128 consecutive pixels for 1x1, an 8 x 16 patch + halo for 3x3), double buffered through
+// (128 consecutive pixels for 1x1; an 8 x 16 output patch + halo for 3x3 stride 1, 4 x 16 for stride 2), double buffered through
 // LDS-DMA; partial sums go to the zero-initialised fp32 dW with hardware fp32 atomics.
 //
 // replaces: autograd's conv2d weight gradient for reference models/common.py:22-34 (loss.backward(), train.py:245).
@@ -33,7 +33,7 @@ struct WgradArgs {
     float* dw;
     int x_cs, x_co, x_ups, x_H, x_W;      // x buffer: channel stride / offset, 2x-nearest-upsample flag, STORED dims
     int dy_cs, dy_co;
-    int B, H, W;                           // output map (= logical input map: stride 1, "same" padding)
+    int B, H, W;                           // output map; the logical input map is (H*stride, W*stride)
     int Cj, Cout_pad;
     int n_co_blk;
     int tiles_x, tiles_y, ntiles, M;
@@ -58,16 +58,22 @@ __device__ __forceinline__ s16x8 wg_tr8(const char* lds_lo, const char* lds_hi) 
     return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-template <int DT, int TAPS>
+template <int DT, int TAPS, int ST>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     constexpr int KS = TAPS == 9 ? 3 : 1;
-    constexpr int HP = 18;
-    constexpr int XR = TAPS == 9 ? 192 : 128;              // LDS rows (pixels) of the x image per 16-channel block
+    constexpr int TH = (TAPS == 9 && ST == 2) ? 4 : 8;     // output rows of a 3x3 tile (16 columns)
+    constexpr int HP = 16 * ST + (ST == 1 ? 2 : 1);        // halo pitch: 18 | 33 pixels
+    constexpr int HROWS = (TH * ST + (ST == 1 ? 2 : 1)) * HP;   // 10 x 18 | 9 x 33
+    constexpr int NPIX = TH * 16;                          // pixels (= k extent) of one tile: 128 | 64
+    constexpr int KK = NPIX / 32;                          // MFMA k steps per tile
+    constexpr int XR = TAPS == 9 ? (HROWS + 31) / 32 * 32 : 128;   // LDS rows (pixels) of the x image per 16-channel block
     constexpr int XI = XR / 32;                            // DMA instructions per channel block (32 rows x 32 B each)
-    constexpr int XBYTES = 4 * XR * 32, DYBYTES = 4 * 128 * 32, STAGE = XBYTES + DYBYTES;
-    constexpr int NDMA = XI + 4;                           // per wave and tile
+    constexpr int DYI = NPIX / 32;
+    constexpr int XBYTES = 4 * XR * 32, DYBYTES = 4 * NPIX * 32, STAGE = XBYTES + DYBYTES;
+    constexpr int NDMA = XI + DYI;                         // per wave and tile
+    static_assert(TAPS == 9 || ST == 1, "1x1: stride 1 only");
 
-    extern __shared__ __attribute__((aligned(1024))) char wsm[];      // 2 stages of [x: 4 cb][XR][32 B] [dy: 4 cb][128][32 B]
+    extern __shared__ __attribute__((aligned(1024))) char wsm[];      // 2 stages of [x: 4 cb][XR][32 B] [dy: 4 cb][NPIX][32 B]
     const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)wsm);
 
     const int ci0 = (blockIdx.x / a.n_co_blk) * 64, co0 = (blockIdx.x % a.n_co_blk) * 64;
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
             int r_ = tile;
             const int tx = r_ % a.tiles_x; r_ /= a.tiles_x;
             const int ty = r_ % a.tiles_y;
-            b = r_ / a.tiles_y; y0 = ty * 8; x0 = tx * 16;
+            b = r_ / a.tiles_y; y0 = ty * TH; x0 = tx * 16;
         } else { b = 0; y0 = 0; x0 = 0; }
         // ---- x rows
 #pragma unroll
@@ -95,8 +101,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
             int bb, iy, ix;
             if constexpr (TAPS == 9) {
                 const int hy = row / HP, hx = row - hy * HP;
-                bb = b; iy = y0 - 1 + hy; ix = x0 - 1 + hx;
-                ok = ok && row < 10 * HP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                bb = b; iy = y0 * ST - 1 + hy; ix = x0 * ST - 1 + hx;
+                ok = ok && row < HROWS && (unsigned)iy < (unsigned)(a.H * ST) && (unsigned)ix < (unsigned)(a.W * ST);
             } else {
                 const int m = tile * 128 + row;
                 ok = ok && m < a.M;
@@ -108,11 +114,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
             const char* src = a.x + (pix * a.x_cs + a.x_co + ch) * 2;
             wg_glds16(ok ? (const void*)src : (const void*)wg_zero16, sb + (cb * XR + rb * 32) * 32);
         }
-        // ---- dy rows: channel block i, row slab = wave
+        // ---- dy rows
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = wave * 32 + prow;
-            const int ch = co0 + i * 16 + half * 8;
+        for (int i = 0; i < DYI; ++i) {
+            const int q = wave + 4 * i;                    // q in [0, 4*DYI)
+            const int cb = q / DYI, rb = q - cb * DYI;
+            const int row = rb * 32 + prow;
+            const int ch = co0 + cb * 16 + half * 8;
             bool ok = ch < a.Cout_pad;
             long pix;
             if constexpr (TAPS == 9) {
@@ -124,19 +132,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
                 ok = ok && pix < a.M;
             }
             const char* src = a.dy + (pix * a.dy_cs + a.dy_co + ch) * 2;
-            wg_glds16(ok ? (const void*)src : (const void*)wg_zero16, sb + XBYTES + (i * 128 + wave * 32) * 32);
+            wg_glds16(ok ? (const void*)src : (const void*)wg_zero16, sb + XBYTES + (cb * NPIX + rb * 32) * 32);
         }
     };
 
     // ---- fragment read addressing (see the file header): lane i of group g addresses row j = i/4 of its 4-row block,
     // channels 4*(i%4)..+3; read h covers pixels g*8 + 4*(h ^ (g&1)) + j of a 32-pixel k step (groups alternate the
-    // order of their two 4-row halves so that one read's four 128-byte row blocks spread over all LDS banks)
+    // order of their two 4-row halves so that one read's four row blocks spread over the LDS banks)
     const int li = l & 15, g = l >> 4, j = li >> 2, q4 = li & 3;
     int xoff[2], yoff[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int k32 = g * 8 + ((h ^ (g & 1)) * 4) + j;
-        if constexpr (TAPS == 9) xoff[h] = (((k32 >> 4) * HP) + (k32 & 15)) * 32 + q4 * 8;
+        if constexpr (TAPS == 9) xoff[h] = (((k32 >> 4) * ST * HP) + (k32 & 15) * ST) * 32 + q4 * 8;
         else xoff[h] = k32 * 32 + q4 * 8;
         yoff[h] = k32 * 32 + q4 * 8;
     }
@@ -162,11 +170,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         const char* xs = wsm + (it & 1) * STAGE;
         const char* ys = xs + XBYTES;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int kk = 0; kk < KK; ++kk) {
             s16x8 yf[2];
 #pragma unroll
             for (int fb = 0; fb < 2; ++fb) {
-                const char* base = ys + ((wco * 2 + fb) * 128 + kk * 32) * 32;
+                const char* base = ys + ((wco * 2 + fb) * NPIX + kk * 32) * 32;
                 yf[fb] = wg_tr8(base + yoff[0], base + yoff[1]);
             }
 #pragma unroll
@@ -175,7 +183,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
                 s16x8 xf[2];
 #pragma unroll
                 for (int fa = 0; fa < 2; ++fa) {
-                    const char* base = xs + (wci * 2 + fa) * XR * 32 + (TAPS == 9 ? (kk * 2 * HP + r * HP + s) * 32 : kk * 32 * 32);
+                    const char* base = xs + (wci * 2 + fa) * XR * 32 + (TAPS == 9 ? (kk * 2 * ST * HP + r * HP + s) * 32 : kk * 32 * 32);
                     xf[fa] = wg_tr8(base + xoff[0], base + xoff[1]);
                 }
 #pragma unroll
@@ -204,11 +212,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
             }
 }
 
-template <int DT, int TAPS>
+template <int DT, int TAPS, int ST>
 hipError_t launch_wgrad(const WgradArgs& a, dim3 grid, hipStream_t st) {
-    constexpr int XR = TAPS == 9 ? 192 : 128;
-    constexpr size_t lds = (size_t)2 * (4 * XR * 32 + 4 * 128 * 32);
-    auto kern = wgrad_kernel<DT, TAPS>;
+    constexpr int TH = (TAPS == 9 && ST == 2) ? 4 : 8;
+    constexpr int HP = 16 * ST + (ST == 1 ? 2 : 1);
+    constexpr int HROWS = (TH * ST + (ST == 1 ? 2 : 1)) * HP;
+    constexpr int XR = TAPS == 9 ? (HROWS + 31) / 32 * 32 : 128;
+    constexpr size_t lds = (size_t)2 * (4 * XR * 32 + 4 * TH * 16 * 32);
+    auto kern = wgrad_kernel<DT, TAPS, ST>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -219,15 +230,23 @@ hipError_t launch_wgrad(const WgradArgs& a, dim3 grid, hipStream_t st) {
     return hipGetLastError();
 }
 
+template <int DT>
+hipError_t dispatch_wgrad(int k, int stride, const WgradArgs& a, dim3 grid, hipStream_t st) {
+    if (k == 1) return launch_wgrad<DT, 1, 1>(a, grid, st);
+    return stride == 2 ? launch_wgrad<DT, 9, 2>(a, grid, st) : launch_wgrad<DT, 9, 1>(a, grid, st);
+}
+
 }  // namespace
 
-extern "C" int yp_conv_wgrad(YpView x, YpView dy, int dtype, int B, int k, float* dw, void* stream) {
+extern "C" int yp_conv_wgrad(YpView x, YpView dy, int dtype, int B, int k, int stride, float* dw, void* stream) {
     YP_REQUIRE(dtype == YP_F16 || dtype == YP_BF16, "yp_conv_wgrad: 16-bit element types only");
-    YP_REQUIRE(k == 1 || k == 3, "yp_conv_wgrad: 1x1 or 3x3 (stride 1, same padding) filters only");
+    YP_REQUIRE((k == 1 && stride == 1) || (k == 3 && (stride == 1 || stride == 2)), "yp_conv_wgrad: 1x1 (stride 1) or 3x3 (pad 1, stride 1 | 2) filters only");
     YP_REQUIRE(x.ptr && dy.ptr && dw && B > 0, "yp_conv_wgrad: null buffer");
     YP_REQUIRE(x.C > 0 && x.C % 8 == 0 && x.cstride % 8 == 0 && x.coff % 8 == 0 && dy.C > 0 && dy.C % 8 == 0 && dy.cstride % 8 == 0 && dy.coff % 8 == 0,
                "yp_conv_wgrad: views must be 8-channel aligned");
-    YP_REQUIRE(x.ups >= 0 && x.ups <= 1 && dy.ups == 0 && (x.H << x.ups) == dy.H && (x.W << x.ups) == dy.W, "yp_conv_wgrad: x %dx%d<<%d vs dy %dx%d", x.H, x.W, x.ups, dy.H, dy.W);
+    const int Hi = x.H << x.ups, Wi = x.W << x.ups;
+    YP_REQUIRE(x.ups >= 0 && x.ups <= 1 && dy.ups == 0 && (Hi + stride - 1) / stride == dy.H && (Wi + stride - 1) / stride == dy.W && Hi % stride == 0 && Wi % stride == 0,
+               "yp_conv_wgrad: x %dx%d<<%d vs dy %dx%d at stride %d", x.H, x.W, x.ups, dy.H, dy.W, stride);
     const long M = (long)B * dy.H * dy.W;
     YP_REQUIRE(M < (1l << 30), "yp_conv_wgrad: too many pixels");
     WgradArgs a{};
@@ -237,7 +256,7 @@ extern "C" int yp_conv_wgrad(YpView x, YpView dy, int dtype, int B, int k, float
     a.B = B; a.H = dy.H; a.W = dy.W; a.Cj = x.C; a.Cout_pad = dy.C; a.M = (int)M;
     a.n_co_blk = yp_cdiv(dy.C, 64);
     const int nblk = yp_cdiv(x.C, 64) * a.n_co_blk;
-    if (k == 3) { a.tiles_x = yp_cdiv(dy.W, 16); a.tiles_y = yp_cdiv(dy.H, 8); a.ntiles = B * a.tiles_x * a.tiles_y; }
+    if (k == 3) { a.tiles_x = yp_cdiv(dy.W, 16); a.tiles_y = yp_cdiv(dy.H, stride == 2 ? 4 : 8); a.ntiles = B * a.tiles_x * a.tiles_y; }
     else a.ntiles = yp_cdiv((int)M, 128);
     // pixel split: enough workgroups to fill the chip, but every workgroup ends in 64*64*taps atomics -> bound the split
     int split = yp_cdiv(768, nblk);
@@ -245,10 +264,8 @@ extern "C" int yp_conv_wgrad(YpView x, YpView dy, int dtype, int B, int k, float
     if (split > cap) split = cap;
     if (split > a.ntiles) split = a.ntiles;
     if (split < 1) split = 1;
-    hipError_t e;
     const dim3 grid(nblk, split);
-    if (dtype == YP_F16) e = k == 3 ? launch_wgrad<YP_F16, 9>(a, grid, (hipStream_t)stream) : launch_wgrad<YP_F16, 1>(a, grid, (hipStream_t)stream);
-    else e = k == 3 ? launch_wgrad<YP_BF16, 9>(a, grid, (hipStream_t)stream) : launch_wgrad<YP_BF16, 1>(a, grid, (hipStream_t)stream);
+    const hipError_t e = dtype == YP_F16 ? dispatch_wgrad<YP_F16>(k, stride, a, grid, (hipStream_t)stream) : dispatch_wgrad<YP_BF16>(k, stride, a, grid, (hipStream_t)stream);
     if (e != hipSuccess) { yp_set_error("yp_conv_wgrad: launch failed: %s", hipGetErrorString(e)); return YP_ERR_HIP; }
     return YP_OK;
 }

@@ -154,9 +154,9 @@ class TrainGraph:
             gbias = self.pgrad(bias)
             self.collect.append(lambda: gbias.copy_(gb_full[:Cout]))
         # ---- wgrad.  Stride-1 1x1 / 3x3 convolutions in a 16-bit dtype: yp_conv_wgrad reads the NHWC tensors directly
-        # (LDS transpose reads).  Everything else (stride 2, the 6x6 stem, fp32): wgrad as a convolution of pixel-major
+        # (LDS transpose reads; 3x3 also at stride 2).  Everything else (the 6x6 stem, fp32): wgrad as a convolution of pixel-major
         # copies -- the output gradient becomes the "filter" [Cout_pad (+1 zero row)][K].
-        direct = code != _hip.YP_F32 and s == 1 and k in (1, 3) and p == k // 2
+        direct = code != _hip.YP_F32 and p == k // 2 and ((k == 1 and s == 1) or (k == 3 and s in (1, 2)))
         dyp = None
         c0 = 0
         for src in srcs:
@@ -168,7 +168,7 @@ class TrainGraph:
             dwb = Buf(Cj, k, k, Cout_pad, torch.float32, self.device, storage=self.dw_arena[self.dw_used:self.dw_used + ndw])
             self.dw_used += round_up(ndw, 64)
             if direct and not image:
-                b.op(_hip.OP_WGRAD, [src, draw], [dwb.view()], "wgrad", v=[src, draw], i=[code, B, k], p=[dwb.flat])
+                b.op(_hip.OP_WGRAD, [src, draw], [dwb.view()], "wgrad", v=[src, draw], i=[code, B, k, s], p=[dwb.flat])
                 b.records[-1].kind, b.records[-1].flops = "conv", 2 * B * Ho * Wo * Cj * k * k * Cout
             else:
                 if dyp is None:
