@@ -118,10 +118,13 @@ def test_blocks(cuda, kind, dtype):
 
 
 HALO_CASES = [
-    # c1, c2, stride, B, H, W, tile(10: BN=32, 11: BN=64, 12: BN=128, 0: auto)
+    # c1, c2, stride, B, H, W, tile(10: BN=32, 11: BN=64, 12: BN=128 on 8x16 pixel tiles, 13..15 the same on 4x16, 0: auto)
     (32, 32, 1, 2, 24, 40, 10), (64, 64, 1, 1, 20, 20, 11), (64, 64, 1, 2, 19, 23, 0), (128, 128, 1, 1, 17, 33, 12),
     (32, 64, 2, 2, 32, 48, 11), (64, 128, 2, 1, 22, 18, 12), (128, 64, 2, 1, 40, 40, 0), (256, 256, 1, 1, 9, 11, 0),
     (64, 72, 1, 1, 16, 16, 12),       # Cout not a multiple of the channel tile
+    # 4 x 16 pixel tiles (ids 13..15), incl. single-chunk inputs (one halo buffer in LDS)
+    (32, 32, 1, 2, 22, 40, 13), (32, 64, 2, 2, 32, 48, 14), (64, 128, 2, 1, 22, 18, 15), (128, 128, 1, 1, 17, 33, 15), (256, 64, 2, 1, 18, 22, 14),
+    (32, 64, 2, 1, 40, 24, 11),       # single-chunk input on the 8 x 16 tile
 ]
 
 

@@ -115,10 +115,11 @@ def lib():
     """Load the shared library (built by __graft_entry__.build()); fail loudly when absent."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise YpError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        path = os.environ.get("YP_HIP_LIB", LIB_PATH)      # override: A/B-compare two builds of the library in one session
+        if not os.path.exists(path):
+            raise YpError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback)")
-        l = C.CDLL(LIB_PATH)
+        l = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args

@@ -150,6 +150,14 @@ __device__ __forceinline__ void yp_store_chunk(const ConvKArgs& a, int m, int nc
 
 // bias -> activation -> yp_store_chunk for the LPG consecutive channels [nb, nb+LPG) a lane owns at pixel m;
 // acc(j) returns the accumulator of lane-local channel j.
+// Workgroup b runs on XCD b % 8 (round-robin dispatch) and every XCD has its own L2: give each XCD a contiguous run of
+// logical tile ids so that tiles which share input pixels / filter rows (neighbouring ids) hit the same L2.
+__device__ __forceinline__ int yp_xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 template <int DT, bool OUT_F32, int LPG, typename AccFn>
 __device__ __forceinline__ void yp_epilogue_pixel(const ConvKArgs& a, int m, int nb, const float (&bias)[LPG], AccFn acc) {
     constexpr int CW = LPG < 8 ? LPG : 8;
@@ -548,31 +556,31 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
 // columns at [0,17) and odd ones at [17,33) (pitch 34), so (2y+r)*34 + {0,17,1}[s] + x.
 // Same source-side XOR swizzle as the generic kernel (keyed on the LDS row index).
 // ==========================================================================================
-template <int STRIDE> struct Halo;
-template <> struct Halo<1> { static constexpr int HH = 10, HP = 18; };
-template <> struct Halo<2> { static constexpr int HH = 17, HP = 34; };
+// halo of a TH x 16 output tile: TH*S + (3 - S) rows; pitch 18 pixels (stride 1) / 2 x 17 de-interleaved columns (stride 2)
+template <int STRIDE, int TH> struct Halo { static constexpr int HH = TH * STRIDE + (3 - STRIDE), HP = STRIDE == 1 ? 18 : 34; };
 
-template <int DT, bool OUT_F32, int STRIDE, int BN, int WAVES_M>
+template <int DT, bool OUT_F32, int STRIDE, int BN, int WAVES_M, int TH = 8>
 __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvKArgs a) {
     using E = Elem<DT>;
     using frag_t = typename E::frag;
     static_assert(E::BYTES == 2, "halo kernel: 16-bit element types");
     constexpr int EB = 2, BK = 32;
-    constexpr int TH = 8, TW = 16;
+    constexpr int TW = 16;
     constexpr int WAVES_N = 4 / WAVES_M;
     constexpr int FM = TH / WAVES_M;                 // output rows (16-pixel fragments) per wave
     constexpr int TN = BN / WAVES_N, FN = TN / 16, LPG = 4 * FN;
-    constexpr int HH = Halo<STRIDE>::HH, HP = Halo<STRIDE>::HP;
+    constexpr int HH = Halo<STRIDE, TH>::HH, HP = Halo<STRIDE, TH>::HP;
     constexpr int HROWS = HH * HP, HSLOTS = (HROWS + 15) / 16, NH = (HSLOTS + 3) / 4, HBYTES = HSLOTS * 1024;
     constexpr int WSLOTS_TAP = BN / 16, WSLOTS = 3 * WSLOTS_TAP, NW = (WSLOTS + 3) / 4, WBYTES = WSLOTS * 1024;
     static_assert(FN >= 1 && FM >= 1 && NW + NH <= 60, "unsupported tile");
 
     extern __shared__ __attribute__((aligned(1024))) char hsm[];      // [halo 0][halo 1][filter row 0][1][2]
     const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)hsm);
-    const unsigned ldsW = lds0 + 2 * HBYTES;
+    const int hbufs = a.Cin > BK ? 2 : 1;            // a single 32-channel chunk needs no second halo buffer (host sizes the LDS alike)
+    const unsigned ldsW = lds0 + hbufs * HBYTES;
 
     // ---- tile decode (channel tiles fastest: neighbours share the input halo in L2)
-    int bid = blockIdx.x;
+    int bid = yp_xcd_remap(blockIdx.x, gridDim.x);
     const int tn = bid % a.tiles_n; bid /= a.tiles_n;
     const int tx = bid % a.tiles_x; bid /= a.tiles_x;
     const int ty = bid % a.tiles_y;
@@ -669,7 +677,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvKArgs a) {
             if (st + 2 < nsteps) { const int s2 = st + 2; issueW(s2 / 3, s2 % 3); }
             if (r == 0 && c + 1 < nchunks) issueH(c + 1);
             const char* hb = hsm + (c & 1) * HBYTES;
-            const char* wb = hsm + 2 * HBYTES + r * WBYTES;
+            const char* wb = hsm + hbufs * HBYTES + r * WBYTES;
 #pragma unroll
             for (int s = 0; s < 3; ++s) {
                 constexpr int XC1[3] = {0, 1, 2};
@@ -743,7 +751,7 @@ __global__ __launch_bounds__(256) void bottleneck_halo_kernel(const ConvKArgs a)
     constexpr int RING = NCH * HBYTES;
     const unsigned ldsR = lds0 + RING;
 
-    int bid = blockIdx.x;
+    int bid = yp_xcd_remap(blockIdx.x, gridDim.x);
     const int tn = bid % a.tiles_n; bid /= a.tiles_n;
     const int tx = bid % a.tiles_x; bid /= a.tiles_x;
     const int ty = bid % a.tiles_y;
@@ -1113,19 +1121,33 @@ hipError_t launch_cfg(int tile, const ConvKArgs& a, int nblk, hipStream_t st) {
 }
 
 
-template <int DT, bool OUT_F32, int STRIDE, int BN, int WAVES_M>
+template <int DT, bool OUT_F32, int STRIDE, int BN, int WAVES_M, int TH>
 hipError_t launch_halo(const ConvKArgs& a, int nblk, hipStream_t st) {
-    constexpr int HSLOTS = (Halo<STRIDE>::HH * Halo<STRIDE>::HP + 15) / 16;
-    constexpr size_t lds = (size_t)2 * HSLOTS * 1024 + (size_t)3 * 3 * (BN / 16) * 1024;
-    auto kern = conv3x3_halo_kernel<DT, OUT_F32, STRIDE, BN, WAVES_M>;
+    constexpr int HSLOTS = (Halo<STRIDE, TH>::HH * Halo<STRIDE, TH>::HP + 15) / 16;
+    constexpr size_t lds2 = (size_t)2 * HSLOTS * 1024 + (size_t)3 * 3 * (BN / 16) * 1024;
+    const size_t lds = lds2 - (a.Cin > 32 ? 0 : (size_t)HSLOTS * 1024);
+    auto kern = conv3x3_halo_kernel<DT, OUT_F32, STRIDE, BN, WAVES_M, TH>;
     static bool attr_set = false;        // per instantiation
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     kern<<<nblk, 256, lds, st>>>(a);
     return hipGetLastError();
+}
+
+// th = 8: 8 x 16 output tiles (ids 10..12); th = 4: 4 x 16 tiles (ids 13..15) -- twice the workgroups, half the halo in LDS
+template <int DT, bool OUT_F32>
+hipError_t dispatch_halo(int stride, int bn, int th, const ConvKArgs& a, int nblk, hipStream_t st) {
+#define YP_HALO(S, B, WM, T) launch_halo<DT, OUT_F32, S, B, WM, T>(a, nblk, st)
+    if (th == 8) {
+        if (stride == 1) return bn == 128 ? YP_HALO(1, 128, 2, 8) : (bn == 64 ? YP_HALO(1, 64, 4, 8) : YP_HALO(1, 32, 4, 8));
+        return bn == 128 ? YP_HALO(2, 128, 2, 8) : (bn == 64 ? YP_HALO(2, 64, 4, 8) : YP_HALO(2, 32, 4, 8));
+    }
+    if (stride == 1) return bn == 128 ? YP_HALO(1, 128, 2, 4) : (bn == 64 ? YP_HALO(1, 64, 4, 4) : YP_HALO(1, 32, 4, 4));
+    return bn == 128 ? YP_HALO(2, 128, 2, 4) : (bn == 64 ? YP_HALO(2, 64, 4, 4) : YP_HALO(2, 32, 4, 4));
+#undef YP_HALO
 }
 
 template <int DT, int C, int BN, int WAVES_M>
@@ -1151,18 +1173,6 @@ hipError_t dispatch_bneck(int c, int bn, const ConvKArgs& a, int nblk, hipStream
     if (bn == 32) return launch_bneck<DT, 128, 32, 4>(a, nblk, st);
     if (bn == 64) return launch_bneck<DT, 128, 64, 4>(a, nblk, st);
     return launch_bneck<DT, 128, 128, 2>(a, nblk, st);
-}
-
-template <int DT, bool OUT_F32>
-hipError_t dispatch_halo(int stride, int bn, const ConvKArgs& a, int nblk, hipStream_t st) {
-    if (stride == 1) {
-        if (bn == 128) return launch_halo<DT, OUT_F32, 1, 128, 2>(a, nblk, st);
-        if (bn == 64) return launch_halo<DT, OUT_F32, 1, 64, 4>(a, nblk, st);
-        return launch_halo<DT, OUT_F32, 1, 32, 4>(a, nblk, st);
-    }
-    if (bn == 128) return launch_halo<DT, OUT_F32, 2, 128, 2>(a, nblk, st);
-    if (bn == 64) return launch_halo<DT, OUT_F32, 2, 64, 4>(a, nblk, st);
-    return launch_halo<DT, OUT_F32, 2, 32, 4>(a, nblk, st);
 }
 
 int pick_tile(int M, int N) {
@@ -1295,15 +1305,18 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
         return YP_OK;
     }
     if (halo_ok && (d->tile == 0 || d->tile >= 10)) {
+        YP_REQUIRE(d->tile == 0 || d->tile <= 15, "yp_conv2d: unknown tile id %d", d->tile);
         int bn = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128);
-        if (d->tile == 10) bn = 32; else if (d->tile == 11) bn = 64; else if (d->tile == 12) bn = 128;
+        const int tsel = d->tile >= 13 ? d->tile - 3 : d->tile;
+        if (tsel == 10) bn = 32; else if (tsel == 11) bn = 64; else if (tsel == 12) bn = 128;
+        const int th = d->tile >= 13 ? 4 : 8;
         a.tiles_n = yp_cdiv(Cout, bn);
         a.tiles_x = yp_cdiv(d->Wo, 16);
-        a.tiles_y = yp_cdiv(d->Ho, 8);
+        a.tiles_y = yp_cdiv(d->Ho, th);
         a.Ho = d->Ho;
         const int nb3 = d->B * a.tiles_y * a.tiles_x * a.tiles_n;
-        if (d->dtype == YP_F16) e = of32 ? dispatch_halo<YP_F16, true>(d->stride_h, bn, a, nb3, stream) : dispatch_halo<YP_F16, false>(d->stride_h, bn, a, nb3, stream);
-        else e = of32 ? dispatch_halo<YP_BF16, true>(d->stride_h, bn, a, nb3, stream) : dispatch_halo<YP_BF16, false>(d->stride_h, bn, a, nb3, stream);
+        if (d->dtype == YP_F16) e = of32 ? dispatch_halo<YP_F16, true>(d->stride_h, bn, th, a, nb3, stream) : dispatch_halo<YP_F16, false>(d->stride_h, bn, th, a, nb3, stream);
+        else e = of32 ? dispatch_halo<YP_BF16, true>(d->stride_h, bn, th, a, nb3, stream) : dispatch_halo<YP_BF16, false>(d->stride_h, bn, th, a, nb3, stream);
         if (e != hipSuccess) {
             yp_set_error("yp_conv2d: halo kernel launch failed: %s", hipGetErrorString(e));
             return YP_ERR_HIP;

@@ -141,8 +141,9 @@ class OpRecord:
 # conv signature -> fastest kernel/tile id, measured once per process (see PlanBuilder._autotune)
 _TUNE_CACHE = {}
 # candidate ids: 1..5 generic implicit-GEMM tiles (128x32, 128x64, 128x128, 64x64, 64x32); 10..12 the 3x3 halo kernel
-# with 32/64/128 output channels per workgroup (rejected by the library when it does not apply)
-_TUNE_CANDIDATES = (1, 2, 3, 4, 5, 10, 11, 12)
+# with 32/64/128 output channels per workgroup on 8x16 pixel tiles, 13..15 the same on 4x16 tiles (rejected by the library
+# when it does not apply)
+_TUNE_CANDIDATES = (1, 2, 3, 4, 5, 10, 11, 12, 13, 14, 15)
 
 
 class PlanBuilder:
