@@ -981,38 +981,45 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
     const int Ho = H / 2, Wo = W / 2;
     const int y0 = ty * TH, x0 = tx * TW;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    // ---- halo fill.  A "line" is one (channel, halo row): 66 aligned float2 loads (pair j <- columns 2j, 2j+1 of input row
-    // 2*y0-2+row, starting at column 2*x0-2).  Each wave takes every 4th line, lanes take pairs; 5 lines are in flight at once.
+    // ---- halo fill.  An item is 4 consecutive input columns (= 2 pixel pairs) of one halo row, ALL channels: a thread loads
+    // the (up to) 4 planes as unaligned 16-byte vectors -- every load of the workgroup is issued before the first is
+    // consumed: one HBM round trip -- interleaves them to 4-channel pixels and writes two 16-byte pairs to LDS.
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
     const size_t plane = (size_t)H * W;
-    constexpr int LINES = 4 * HH;                 // channel 3 is the zero pad
-    for (int l0 = wave; l0 < LINES; l0 += 4 * 5) {
-        float2 v[5][2];
+    constexpr int QUADS = HPAIR / 2, ITEMS = HH * QUADS, NIT = (ITEMS + 255) / 256;
+    f32x4 v[NIT][4];
 #pragma unroll
-        for (int u = 0; u < 5; ++u) {
-            const int line = l0 + 4 * u;
-            const int ch = line / HH, row = line - ch * HH;
-            const int iy = 2 * y0 - 2 + row;
+    for (int it = 0; it < NIT; ++it) {
+        const int item = t + 256 * it;
+        const int row = item / QUADS, q = item - row * QUADS;
+        const int iy = 2 * y0 - 2 + row, ix = 2 * x0 - 2 + 4 * q;
+        const bool rowok = item < ITEMS && (unsigned)iy < (unsigned)H;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int j = lane + 64 * h;
-                const int ix = 2 * x0 - 2 + 2 * j;
-                v[u][h] = make_float2(0.f, 0.f);
-                if (line < LINES && ch < C && j < HPAIR && (unsigned)iy < (unsigned)H && ix >= 0 && ix + 1 < W)
-                    v[u][h] = *reinterpret_cast<const float2*>(x + ((size_t)b * C + ch) * plane + (size_t)iy * W + ix);
-            }
-        }
+        for (int ch = 0; ch < 4; ++ch) {
+            v[it][ch] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (rowok && ch < C) {
+                const float* src = x + ((size_t)b * C + ch) * plane + (size_t)iy * W + ix;
+                if (ix >= 0 && ix + 3 < W) v[it][ch] = *reinterpret_cast<const f32x4u*>(src);
+                else {
 #pragma unroll
-        for (int u = 0; u < 5; ++u) {
-            const int line = l0 + 4 * u;
-            const int ch = line / HH, row = line - ch * HH;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int j = lane + 64 * h;
-                if (line < LINES && j < HPAIR) {
-                    halo[(row * HPAIR + j) * 8 + ch] = (sc)v[u][h].x;
-                    halo[(row * HPAIR + j) * 8 + 4 + ch] = (sc)v[u][h].y;
+                    for (int e = 0; e < 4; ++e)
+                        if ((unsigned)(ix + e) < (unsigned)W) v[it][ch][e] = src[e];
                 }
             }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int item = t + 256 * it;
+        if (item >= ITEMS) continue;
+        const int row = item / QUADS, q = item - row * QUADS;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            u32x4 pk;
+            sc* e = reinterpret_cast<sc*>(&pk);
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) { e[ch] = (sc)v[it][ch][2 * pr]; e[4 + ch] = (sc)v[it][ch][2 * pr + 1]; }
+            *reinterpret_cast<u32x4*>(&halo[(row * HPAIR + 2 * q + pr) * 8]) = pk;
         }
     }
     // ---- filter fragments: lane (n = lane%16, g = lane/16) holds W[n][(4*kk + g)*8 .. +8] for kk = 0..4
