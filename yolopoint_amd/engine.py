@@ -43,6 +43,16 @@ def synthetic_batch(B, S, device, seed, nc=80):
                 box_labels=boxes, inv_homographies=eye)
 
 
+def _record_stream(obj, stream):
+    """Tensors made on the side stream are consumed on `stream`: tell the caching allocator."""
+    if isinstance(obj, torch.Tensor):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, (list, tuple)):
+        for o in obj:
+            _record_stream(o, stream)
+
+
 class TrainStep:
     def __init__(self, model, device, img_size=640, lr=1e-3, group=None):
         self.model, self.device = model, device
@@ -56,6 +66,7 @@ class TrainStep:
         self.opt = torch.optim.Adam(model.parameters(), lr=lr)
         self.reducer = GradAllReducer(model.parameters(), group=group)
         self.sparse = dict(SPARSE)
+        self.side_stream = torch.cuda.Stream(device=device)
         self.reducer.broadcast_parameters(model)
 
     def __call__(self, batch):
@@ -67,24 +78,32 @@ class TrainStep:
     def loss_and_grads(self, batch, prepare=True):
         """loss = (det + det_warp) + lambda_desc * infonce + lambda_obj * obj and its backward (reference train.py:208-245).
         With `prepare`, the label-only, host-synchronising parts of the losses (YOLO target assignment, InfoNCE sampling)
-        run BEFORE the forward passes are launched, so nothing between the first forward and the optimizer step waits for
-        the device.  (Measured and dropped: a two-stage backward that launches the warped pass's native backward before the
+        run on a side stream right after both forward passes have been launched: the host never waits for the forwards,
+        and nothing after them synchronises until the optimizer step.  (Measured and dropped: a two-stage backward that launches the warped pass's native backward before the
         object-loss backward is differentiated -- the step is device-bound, the extra autograd entry points cost more than the
         overlap wins: 40-48 ms vs 38 ms per step.)"""
         m, dev = self.model, self.device
         self.opt.zero_grad(set_to_none=True)
         img = batch['image']
         B, S = img.shape[0], img.shape[-1]
-        tgt = nce = None
-        if prepare:
-            det = m.model.Detect
-            shapes = [(B, det.na, img.shape[-2] // int(st), S // int(st), det.no) for st in det.stride]
-            tgt = self.obj_loss.build_targets(shapes, batch['box_labels'])
-            dch = m.model.ConvDesc.out_channels
-            nce = infonce_prepare(batch['warped_valid_mask'], batch['inv_homographies'], (B, dch, img.shape[-2] // 8, S // 8), True,
-                                  self.sparse['num_samples_per_image'], self.sparse['num_masked_non_matches_per_match'], 8, dev)
+        # both forwards are launched first ...
         outs = m(img)
         outs_w = m(batch['warped_image'])
+        # ... then the label-only parts run on a side stream: their host syncs (boolean-mask indexing, .item()) wait for that
+        # stream's few small kernels only, while the device works through the forwards
+        tgt = nce = None
+        if prepare:
+            main = torch.cuda.current_stream(dev)
+            side = self.side_stream
+            with torch.cuda.stream(side):
+                det = m.model.Detect
+                shapes = [(B, det.na, img.shape[-2] // int(st), S // int(st), det.no) for st in det.stride]
+                tgt = self.obj_loss.build_targets(shapes, batch['box_labels'])
+                dch = m.model.ConvDesc.out_channels
+                nce = infonce_prepare(batch['warped_valid_mask'], batch['inv_homographies'], (B, dch, img.shape[-2] // 8, S // 8), True,
+                                      self.sparse['num_samples_per_image'], self.sparse['num_masked_non_matches_per_match'], 8, dev)
+                _record_stream((tgt, nce), main)
+            main.wait_stream(side)
         l_obj = self.obj_loss(outs['objects'], batch['box_labels'], prepared=tgt)[0]
         l_det = self.det_loss(outs['semi'], labels2Dto3D(batch['labels_2D']), getMasks(batch['valid_mask'], dev))
         l_det_w = self.det_loss(outs_w['semi'], labels2Dto3D(batch['warped_labels']), getMasks(batch['warped_valid_mask'], dev))

@@ -16,6 +16,17 @@ from .torch_utils_yolo import de_parallel
 from .utils import getMasks
 
 
+_CONST = {}
+
+
+def _const(key, make):
+    """Small shape-dependent constants (grids, offsets) live on the device once instead of being rebuilt on the host and
+    copied (a synchronising pageable H2D copy) in every training step."""
+    if key not in _CONST:
+        _CONST[key] = make()
+    return _CONST[key]
+
+
 def smooth_BCE(eps=0.1):
     """Label-smoothed BCE targets (positive, negative)."""
     return 1.0 - 0.5 * eps, 0.5 * eps
@@ -77,7 +88,7 @@ class ComputeObjectLoss:
                 tobj[b, a, gj, gi] = iou
                 if self.nc > 1:
                     t = torch.full_like(pcls, self.cn, device=dev)
-                    t[range(n), tcls[i]] = self.cp
+                    t[torch.arange(n, device=dev), tcls[i]] = self.cp
                     lcls = lcls + self.BCEcls(pcls, t)
             obji = self.BCEobj(pi[..., 4], tobj)
             lobj = lobj + obji * self.balance[i]
@@ -100,10 +111,10 @@ class ComputeObjectLoss:
         ai = torch.arange(na, device=dev).float().view(na, 1).repeat(1, nt)
         targets = torch.cat((targets.repeat(na, 1, 1), ai[..., None]), 2)          # [na, nt, 7]
         g = 0.5
-        off = torch.tensor([[0, 0], [1, 0], [0, 1], [-1, 0], [0, -1]], device=dev).float() * g
+        off = _const(("off", str(dev)), lambda: torch.tensor([[0, 0], [1, 0], [0, 1], [-1, 0], [0, -1]], device=dev).float()) * g
         for i in range(self.nl):
             anchors, shape = self.anchors[i], (p[i].shape if isinstance(p[i], torch.Tensor) else tuple(p[i]))
-            gain[2:6] = torch.tensor(shape)[[3, 2, 3, 2]]
+            gain[2:6] = _const(("gain", tuple(shape), str(dev)), lambda shape=shape: torch.tensor([shape[3], shape[2], shape[3], shape[2]], dtype=torch.float32, device=dev))
             t = targets * gain
             if nt:
                 r = t[..., 4:6] / anchors[:, None]
@@ -147,8 +158,9 @@ def warp_points(points, homographies, device='cpu'):
 
 def homography_scaling(homography, H, W, device='cpu'):
     """Homography in normalised [-1,1] coordinates -> pixel coordinates of an HxW grid."""
-    trans = torch.tensor([[2. / W, 0., -1.], [0., 2. / H, -1.], [0., 0., 1.]], dtype=torch.float32, device=device)
-    return trans.inverse() @ homography @ trans
+    trans, inv = _const(("hscale", H, W, str(device)), lambda: (lambda t: (t, t.inverse()))(
+        torch.tensor([[2. / W, 0., -1.], [0., 2. / H, -1.], [0., 0., 1.]], dtype=torch.float32, device=device)))
+    return inv @ homography @ trans
 
 
 def warp_image_batch(img, mat_homo_inv, device='cpu', mode='bilinear', padding_mode='zeros'):
@@ -158,16 +170,19 @@ def warp_image_batch(img, mat_homo_inv, device='cpu', mode='bilinear', padding_m
     if mat_homo_inv.dim() == 2:
         mat_homo_inv = mat_homo_inv.view(1, 3, 3)
     B, _, H, W = img.shape
-    ys, xs = torch.meshgrid(torch.linspace(-1, 1, H), torch.linspace(-1, 1, W), indexing='ij')
-    cells = torch.stack((xs, ys), dim=2).to(device).contiguous()
+    def make():
+        ys, xs = torch.meshgrid(torch.linspace(-1, 1, H), torch.linspace(-1, 1, W), indexing='ij')
+        return torch.stack((xs, ys), dim=2).to(device).contiguous()
+    cells = _const(("warpgrid", H, W, str(device)), make)
     src = warp_points(cells.view(-1, 2), mat_homo_inv, device).view(B, H, W, 2).float()
     return F.grid_sample(img, src, mode=mode, align_corners=True, padding_mode=padding_mode)
 
 
 def get_coor_cells(Hc, Wc, uv=False, device='cpu'):
-    ys, xs = torch.meshgrid(torch.arange(Hc), torch.arange(Wc), indexing='ij')
-    cells = torch.stack((xs, ys) if uv else (ys, xs), dim=2).float().view(-1, 2)
-    return cells.to(device)
+    def make():
+        ys, xs = torch.meshgrid(torch.arange(Hc), torch.arange(Wc), indexing='ij')
+        return torch.stack((xs, ys) if uv else (ys, xs), dim=2).float().view(-1, 2).to(device)
+    return _const(("cells", Hc, Wc, bool(uv), str(device)), make)
 
 
 def normPts(pts, shape):
@@ -235,7 +250,7 @@ def infonce_prepare(mask_valid_warp, inv_homographies, desc_shape, on_device, nu
                 pa.append(a_list[i][choice][:pool])
                 pb.append(b_list[i][choice][:pool])
             pa, pb = torch.stack(pa).to(device), torch.stack(pb).to(device)
-        size = torch.tensor([Wc, Hc]).float().to(device)
+        size = _const(("size", Wc, Hc, str(device)), lambda: torch.tensor([Wc, Hc]).float().to(device))
         ua = normPts(pa, size)
         ub = normPts(pb, size)
         n, negs = ua.shape[0] * ua.shape[1], num_masked_non_matches_per_match

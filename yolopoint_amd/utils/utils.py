@@ -140,7 +140,7 @@ def labels2Dto3D(labels, cell_size=8, add_dustbin=True):
         B, cell_size * cell_size, Hc, Wc)
     if add_dustbin:
         dust = 1 - cells.sum(dim=1)
-        dust[dust < 1.] = 0
+        dust = torch.where(dust < 1., torch.zeros_like(dust), dust)      # (no boolean-mask assignment: that synchronises)
         cells = torch.cat((cells, dust.view(B, 1, Hc, Wc)), dim=1)
         cells = cells.div(cells.sum(dim=1).unsqueeze(1))
     return cells
