@@ -162,6 +162,7 @@ class PlanBuilder:
         self.records = []       # per-op algorithmic work (for roofline accounting)
         self.accesses = []      # per-op (reads, writes) as (buffer key, lo, hi) ranges, for the graph schedule
         self.refreshers = []    # callables that re-pack weights from their (changing) sources: training plans
+        self.pack_target = None # (PlanBuilder, cache dict): where MasterWeight pack ops are emitted (None: into this plan)
         self.scope = []
 
     # -- naming -------------------------------------------------------------------------
@@ -286,12 +287,22 @@ class PlanBuilder:
         elif master is not None:
             assert not thin, "image-like (thin) inputs keep the host packer"
             Kpad, Npad = lib().yp_conv_kpad(R * S * Cin, self.code), round_up(Cout, 8)
-            wp = torch.zeros((Npad + 1, Kpad), dtype=self.tdtype, device=self.device)
-            bp = torch.zeros((Npad,), dtype=torch.float32, device=self.device)
-            self.keep += [wp, bp, master.param] + ([master.bias] if master.bias is not None else [])
-            mo, mi, mr, ms = master.param.shape
-            self.op(_hip.OP_PACK_WEIGHT, [], [(wp, 0, 1 << 30)], "pack_w", f=[master.param, master.bias], g=[bp], p=[wp],
-                    i=[self.code, mo, mi, mr, ms, master.c0, master.cj, master.mode], n=[Kpad, Npad | (master.cout_pad << 32)])
+            # the pack op goes into `pack_target` (a builder shared by every plan over the same parameters, replayed once per
+            # optimizer step) when one is set, else in front of the convolution in this plan
+            tgt, cache = self.pack_target if self.pack_target is not None else (self, None)
+            key = (master.param.data_ptr(), master.bias.data_ptr() if master.bias is not None else 0, master.mode, master.c0, master.cj, master.cout_pad)
+            if cache is not None and key in cache:
+                wp, bp = cache[key]
+            else:
+                wp = torch.zeros((Npad + 1, Kpad), dtype=self.tdtype, device=self.device)
+                bp = torch.zeros((Npad,), dtype=torch.float32, device=self.device)
+                mo, mi, mr, ms = master.param.shape
+                tgt.keep += [wp, bp, master.param] + ([master.bias] if master.bias is not None else [])
+                tgt.op(_hip.OP_PACK_WEIGHT, [], [(wp, 0, 1 << 30)], "pack_w", f=[master.param, master.bias], g=[bp], p=[wp],
+                       i=[self.code, mo, mi, mr, ms, master.c0, master.cj, master.mode], n=[Kpad, Npad | (master.cout_pad << 32)])
+                if cache is not None:
+                    cache[key] = (wp, bp)
+            self.keep += [wp, bp]
             extra = dict(extra, weight_view=(wp, 0, 1 << 30)) if "weight_view" not in extra else extra
         else:
             wp, bp, Kpad, Npad = prep(w, bias)

@@ -22,7 +22,7 @@ import os
 import torch
 
 from . import _hip
-from ._hip import lib
+from ._hip import lib, check
 from .plan import PlanBuilder, Buf, View, MasterWeight, round_up, pack_input
 
 
@@ -34,6 +34,11 @@ class TrainGraph:
         self.tdtype = _hip.torch_dtype(code)
         self.fwd = PlanBuilder(B, code, device)
         self.bwd = PlanBuilder(B, code, device)
+        # packed (16-bit / transposed) copies of the master filters are shared by every graph over these parameters and
+        # re-derived by ONE launch list, replayed once per optimizer step (not per forward / backward)
+        pkey = (code, torch.device(device).index, tuple(p_.data_ptr() for p_ in net.parameters()))
+        self.pack = net.__dict__.setdefault("_pack_states", {}).setdefault(pkey, {"pb": PlanBuilder(B, code, device), "cache": {}, "version": None})
+        self.fwd.pack_target = (self.pack["pb"], self.pack["cache"])
         self.tape = []             # (branch, emitter): 'kp' feeds the keypoint / descriptor heads, 'yolo' only the Detect head
         self.branch = "kp"
         self.touched = set()       # parameters whose gradient the plan being emitted writes
@@ -46,6 +51,7 @@ class TrainGraph:
         wsb = lib().yp_bn_workspace_bytes(B, H // 2, W // 2, 1024) + 8 * 2048 + 4096
         self.ws = torch.empty(wsb, dtype=torch.uint8, device=device)
         self.Bpad = round_up(B, 8)
+        self._nbt = None
         # every per-layer weight-gradient accumulator (fp32 [Cin][k][k][Cout_pad]) lives in one arena that the backward plan
         # clears with a single memset
         self.dw_arena = torch.zeros(2 * sum(p_.numel() for p_ in net.parameters()) + (1 << 20), dtype=torch.float32, device=device)
@@ -318,6 +324,7 @@ class TrainGraph:
         # layers (4 F_fwd + 2 F_kp per sample, not 6 F_fwd).
         def emit(kp_only):
             self.bwd = bb = PlanBuilder(B, code, self.device)
+            bb.pack_target = self.fwd.pack_target
             for key in self.gwritten:
                 self.gwritten[key] = []
             self.touched, self.collect = set(), []
@@ -343,16 +350,22 @@ class TrainGraph:
     def forward(self, x):
         # packed weights (forward + dgrad) are re-derived only when an optimizer step (or a load) changed the masters
         ver = sum(p_._version for p_ in self.params)
-        if ver != getattr(self, "_packed_version", None):
+        if ver != getattr(self, "_packed_version", None):      # host-packed filters of this graph (stem, Detect)
             self.fwd_plan.refresh()
             self.bwd_plan.refresh()
             self.bwd_kp_plan.refresh()
             self._packed_version = ver
+        nops = lib().yp_plan_num_ops(self.pack["pb"].handle)
+        if (ver, nops) != self.pack["version"]:                 # device-packed filters shared by all graphs
+            check(lib().yp_plan_run(self.pack["pb"].handle, _hip.stream_ptr()))
+            self.pack["version"] = (ver, nops)
         pack_input(x, self.img.view(), self.code)
         self.fwd_plan.run()
-        for m in self.net.modules():
-            if isinstance(m, torch.nn.BatchNorm2d) and m.num_batches_tracked is not None:
-                m.num_batches_tracked += 1
+        if self._nbt is None:
+            self._nbt = [m.num_batches_tracked for m in self.net.modules()
+                         if isinstance(m, torch.nn.BatchNorm2d) and m.num_batches_tracked is not None]
+        if self._nbt:
+            torch._foreach_add_(self._nbt, 1)          # one launch for all BatchNorm counters
         c3ch = self.net.ConvDesc.out_channels
         semi = self.semi_v.buf.t[..., :65].permute(0, 3, 1, 2).clone()
         desc = self.desc_v.buf.t[..., :c3ch].permute(0, 3, 1, 2).clone()
@@ -389,10 +402,24 @@ class _YOLOPointTrainFn(torch.autograd.Function):
         g = ctx.graph
         grads = g.backward(g_semi, g_desc, list(g_xs))
         g.busy = False
-        out = []
+        # Parameter gradients are delivered with multi-tensor ops instead of ~215 per-parameter autograd returns (each of
+        # which AccumulateGrad would clone): a fresh copy for parameters without a gradient yet, an in-place add otherwise.
+        new_p, new_g, acc_p, acc_g = [], [], [], []
         for p_, gr in zip(g.params, grads):
-            out.append(gr.to(p_.dtype).clone() if (gr is not None and p_.requires_grad) else None)
-        return (None, None, *out)
+            if gr is None or not p_.requires_grad:
+                continue
+            if p_.grad is None:
+                new_p.append(p_); new_g.append(gr)
+            else:
+                acc_p.append(p_.grad); acc_g.append(gr)
+        if new_p:
+            fresh = [torch.empty_like(p_, dtype=p_.dtype) for p_ in new_p]
+            torch._foreach_copy_(fresh, new_g)
+            for p_, f_ in zip(new_p, fresh):
+                p_.grad = f_
+        if acc_p:
+            torch._foreach_add_(acc_p, acc_g)
+        return (None, None, *([None] * len(g.params)))
 
 
 def train_forward(net, x):
