@@ -55,6 +55,18 @@ template <> struct Elem<YP_F32> {
 
 #define YP_PIN2(T, name) T name = a.name; asm volatile("" : "+s"(name))
 
+// Probe builds (-DYP_TIMELINE, tools/probe/timeline.py): workgroup 0 / lane 0 records the shader clock at phase boundaries.
+#ifdef YP_TIMELINE
+__device__ long long yp_timeline[64];
+extern "C" int yp_debug_timeline(long long* out_host) { return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(yp_timeline), sizeof(long long) * 64); }
+#define YP_TL(i) do { if (blockIdx.x == YP_TL_BLOCK && threadIdx.x == 0) yp_timeline[i] = __builtin_readcyclecounter(); } while (0)
+#ifndef YP_TL_BLOCK
+#define YP_TL_BLOCK 0
+#endif
+#else
+#define YP_TL(i) do {} while (0)
+#endif
+
 struct ConvKArgs {
     const char* in0;
     const char* in1;
@@ -89,8 +101,9 @@ struct ConvKArgs {
 };
 
 __device__ __forceinline__ float yp_silu(float x) {
-    // x * sigmoid(x); __expf -> v_exp_f32, the divide -> v_rcp_f32 (rel. error ~1e-7)
-    return x * __frcp_rn(1.0f + __expf(-x));
+    // x * sigmoid(x) as v_mul, v_exp_f32, v_add, v_rcp_f32, v_mul (rel. error ~1e-7).  NOT __frcp_rn / a plain divide: those
+    // expand to the 12-instruction IEEE division sequence, and every output element of every convolution passes through here.
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
 }
 
 // Epilogue tail shared by the convolution kernels: (+ residual) -> convert -> store CW consecutive
@@ -751,6 +764,7 @@ __global__ __launch_bounds__(256) void bottleneck_halo_kernel(const ConvKArgs a)
     constexpr int RING = NCH * HBYTES;
     const unsigned ldsR = lds0 + RING;
 
+    YP_TL(0);
     int bid = yp_xcd_remap(blockIdx.x, gridDim.x);
     const int tn = bid % a.tiles_n; bid /= a.tiles_n;
     const int tx = bid % a.tiles_x; bid /= a.tiles_x;
@@ -824,6 +838,7 @@ __global__ __launch_bounds__(256) void bottleneck_halo_kernel(const ConvKArgs a)
     float bias[LPG];
     yp_load_bias<LPG>(a, nb, bias);
 
+    YP_TL(1);
     // ---- phase A: everything in flight at once
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -849,6 +864,7 @@ __global__ __launch_bounds__(256) void bottleneck_halo_kernel(const ConvKArgs a)
         else if (c == NCH - 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLA) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NLA) : "memory");
         __builtin_amdgcn_s_barrier();
+        YP_TL(2 + c);
         const char* xb = hsm + RING + c * ASTAGE;
         const char* wb = xb + HBYTES;
         frag_t xf[3];
@@ -866,6 +882,7 @@ __global__ __launch_bounds__(256) void bottleneck_halo_kernel(const ConvKArgs a)
         }
     }
     __builtin_amdgcn_s_barrier();            // every wave is done with phase A's operands: the ring may be overwritten
+    YP_TL(8);
 #pragma unroll
     for (int sb = 0; sb < NSUB; ++sb)        // make the compiler's own wait for the bias loads land here, not behind the prefetch below
 #pragma unroll
@@ -900,6 +917,7 @@ __global__ __launch_bounds__(256) void bottleneck_halo_kernel(const ConvKArgs a)
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    YP_TL(9);
 
     // ---- phase B: 3x3 over the resident hidden halo
     const int w_rd = (wn * TN + p) * 64 + ((g ^ swr) << 4);
@@ -920,6 +938,7 @@ __global__ __launch_bounds__(256) void bottleneck_halo_kernel(const ConvKArgs a)
             if (st + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+            YP_TL(10 + st);
             if (st + 2 < nsteps) { const int s2 = st + 2; issueW(s2 / 3, s2 % 3); }
             const char* hb = hsm + c * HBYTES;
             const char* wb = hsm + RING + r * WBYTES;
@@ -943,6 +962,7 @@ __global__ __launch_bounds__(256) void bottleneck_halo_kernel(const ConvKArgs a)
         }
     }
 
+    YP_TL(40);
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm) {
         const int oy = y0 + wm * FM + fm, ox = x0 + p;
@@ -950,6 +970,7 @@ __global__ __launch_bounds__(256) void bottleneck_halo_kernel(const ConvKArgs a)
         const int m = (b * a.Ho + oy) * a.Wo + ox;
         yp_epilogue_pixel<DT, false, LPG>(a, m, nb, bias, [&](int cj) { return acc[cj >> 2][fm][cj & 3]; });
     }
+    YP_TL(41);
 }
 
 

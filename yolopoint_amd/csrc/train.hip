@@ -243,7 +243,7 @@ __global__ void bn_bwd_apply_kernel(const char* __restrict__ raw, int rcs, int r
 // a thread keeps ONE 8-channel chunk for all the rows it visits, so the per-channel parameters sit in registers,
 // the index arithmetic is 32-bit shifts and several independent 16-byte loads are in flight per thread.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float fast_sigmoid(float z) { return __frcp_rn(1.0f + __expf(-z)); }
+__device__ __forceinline__ float fast_sigmoid(float z) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.4426950408889634f)); }
 
 template <int DT, int MODE>
 __global__ __launch_bounds__(256) void col_reduce_fast_kernel(const char* __restrict__ raw, int rcs, int rco, const char* __restrict__ dy,
