@@ -275,6 +275,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     static_assert(NL * (NS - 2) <= 60, "vmcnt immediate range");
 
     extern __shared__ __attribute__((aligned(1024))) char smem[];      // NS * STAGE bytes (dynamic: deep rings exceed 64 KiB)
+    YP_TL(0);
 
     // ---- XCD-aware tile mapping: workgroup b runs on XCD b%8; give each XCD a contiguous run of
     // logical tiles so that tiles sharing input pixels / filter rows hit the same L2.
@@ -444,6 +445,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     yp_load_bias<LPG>(a, nb, bias);
 
     const int nk = kt1 - kt0;              // tiles are numbered relative to kt0 below; the filter offset uses kt0 + kt
+    YP_TL(1);
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) issue_tile(kt0 + s, s);
@@ -460,6 +462,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
         else if (younger == 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS > 6 ? 5 * NL : 0) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS > 7 ? 6 * NL : 0) : "memory");
         __builtin_amdgcn_s_barrier();
+        if (kt < 24) YP_TL(2 + kt);
         // every wave has finished reading tile kt-1: its stage can be refilled
         if (kt + NS - 1 < nk) issue_tile(kt0 + kt + NS - 1, (kt + NS - 1) % NS);
         const char* s = smem + (kt % NS) * STAGE;
@@ -478,6 +481,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
         }
     }
 
+    YP_TL(40);
     // ---- epilogue: bias -> activation -> (+ residual) -> store, 16-byte vectors per pixel
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm) {
@@ -493,6 +497,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
             }
         }
     }
+    YP_TL(41);
     if constexpr (DETECT) {
         // The (pixel x channel) tile is staged through the now idle pipeline LDS so that each wave writes one
         // pixel's channels as a contiguous run of x_out / z (both are o-contiguous per (pixel, anchor)).
