@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", default="", help="write a per-launch table (us, TFLOP/s, GB/s) to this path")
     ap.add_argument("--postproc", action="store_true", help="also time the post-processing kernels on planted head outputs")
-    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
+    ap.add_argument("--mode", default="infer", choices=["infer", "train", "frame"],
                     help="infer (default, BASELINE.json configs[1]) or train: the reference's optimizer step, data parallel over --gpus")
     return ap.parse_args()
 
@@ -112,6 +112,8 @@ def main():
     _hip.require_gpu()
     if a.mode == "train":
         return bench_train(a, rank, world, dev)
+    if a.mode == "frame":
+        return bench_frame(a, dev)
     m, _ = build_model(a.version, a.dtype, dev)
     net = m.model
     B, S = a.batch, a.size
@@ -267,6 +269,70 @@ def bench_train(a, rank, world, dev):
                                f"InfoNCE losses in PyTorch autograd, native backward, gradient all-reduce, Adam), {a.batch} samples/GPU, {a.size}x{a.size}",
                    "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
                    "grad_allreduce_bytes": step.reducer.payload_bytes()}}), flush=True)
+
+
+def bench_frame(a, dev):
+    """SURVEY.md 8(f) row 2 / BASELINE.json configs[3]: one frame through the GPU-resident front end (forward, keypoint decode +
+    NMS, box NMS, box-mask keypoint filter, descriptor sampling) + mutual-NN matching against the previous frame's descriptors.
+    Random-weight heads: the keypoint / box counts are whatever the seed gives (reported), thresholds are the reference's."""
+    from yolopoint_amd.frontend import YoloPointFrontend
+    from yolopoint_amd.models.model_wrap import PointTracker
+    from oracle import net_oracle
+    m, _ = build_model(a.version, a.dtype, dev)
+    S = a.size
+    fe = YoloPointFrontend(m, dev, yolo_config=dict(conf_thres_box=0.25, iou_thres_box=0.45, max_det=300), filter_pts=True)
+    frames = [net_oracle.synth_image(1, 3, S, S, 100 + i).to(dev) for i in range(4)]
+    # Seeded random heads saturate (every pixel a keypoint, every anchor a box), which is not the load of a trained model: the
+    # network runs in full, but the post-processing is fed PLANTED head outputs (SURVEY.md 8(d)): a heat map with
+    # 1000 x (S/640)^2 Gaussian peaks over U(0, 0.01) noise (as logits of the 65-channel cell softmax) and 2000 box candidates.
+    import numpy as np
+    from helpers import planted_heatmap, planted_predictions
+    nrows = sum(3 * (S // st) ** 2 for st in (8, 16, 32))
+    semis, preds = [], []
+    for i in range(len(frames)):
+        heat = planted_heatmap(S, S, int(1000 * (S / 640) ** 2), 10 + i).astype(np.float64)
+        cells = heat.reshape(S // 8, 8, S // 8, 8).transpose(1, 3, 0, 2).reshape(64, S // 8, S // 8)
+        cells = cells / np.maximum(cells.sum(0, keepdims=True), 1.0) * np.minimum(cells.sum(0, keepdims=True), 0.98)
+        dust = 1.0 - cells.sum(0, keepdims=True)
+        semis.append(torch.from_numpy(np.log(np.concatenate((cells, dust), 0) + 1e-12).astype(np.float32))[None].to(dev))
+        preds.append(torch.from_numpy(planted_predictions(1, nrows, 80, 2000, 20 + i, img=S)).to(dev))
+
+    class PlantedHeads(torch.nn.Module):          # the real forward, then the planted semi / pred (the descriptors stay the model's)
+        def __init__(self, model):
+            super().__init__()
+            self.model, self.i = model, 0
+
+        def forward(self, x):
+            o = self.model(x)
+            k = self.i % len(semis)
+            self.i += 1
+            return {"semi": semis[k], "desc": o["desc"], "objects": (preds[k], o["objects"][1])}
+    fe.model = PlantedHeads(m)
+    tr = PointTracker()
+    prev = [None]
+    stats = {}
+
+    def step(i):
+        r = fe.process_tensor(frames[i % len(frames)])
+        if prev[0] is not None and r["desc"].shape[1] and prev[0].shape[1]:
+            stats["matches"] = tr.nn_match_two_way(r["desc"], prev[0], 0.7).shape[1]
+        prev[0] = r["desc"]
+        stats["keypoints"], stats["boxes"] = int(r["pts"].shape[0]), int(r["boxes"].shape[0])
+    for i in range(a.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    print(json.dumps({"metric": f"frames/sec at {S}x{S} (YOLOPoint-{a.version} frame pipeline: forward + keypoint decode/NMS + box NMS + "
+                                f"box-mask filter + descriptor sampling + MNN matching, bs=1, {a.dtype})",
+                      "value": round(a.steps / wall, 1), "unit": "frames/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+                      "ms_per_step": round(wall / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype,
+                      "data": "synthetic", "config": {"workload": "BASELINE.json configs[3] shape: one frame end to end, device-resident, 2 host syncs per frame "
+                                                                  "(front-end counters, match count)", "image": [S, S],
+                                                      "post_processing_inputs": "planted heat map / predictions (SURVEY.md 8d), model descriptors", **stats}}), flush=True)
 
 
 def bench_postproc(dev):

@@ -285,6 +285,12 @@ int yp_box_nms(const float* pred, int B, int N, int nc, float conf_thres, float 
                int multi_label, int agnostic, int max_det, int max_nms, float max_wh,
                float* out_det, int32_t* out_count, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Drop the keypoints that fall inside a detected box: pts_xyc [n,3] (x, y, conf; order kept) against boxes [n_boxes, box_stride]
+ * (x1,y1,x2,y2,...), bounds = rint(xyxy) with numpy slice semantics on an H x W mask.  Counts may live on the device
+ * (n_pts_dev / n_boxes_dev non-NULL override the host values, which then only bound the launch) so that the whole frame
+ * pipeline runs without a host sync.  At most 512 boxes are honoured.  replaces: demo.py:176-196 (filter_points) */
+int yp_pts_box_filter(const float* pts_xyc, const int* n_pts_dev, int n_pts, const float* boxes, const int* n_boxes_dev, int n_boxes,
+                      int box_stride, int H, int W, float* out_xyc, int* out_count, void* stream);
 /* Bilinear descriptor sampling (grid_sample align_corners=True with the reference's
  * full-resolution normalisation) + L2 renormalisation.
  *   desc: fp32, element (c,y,x) at desc[c*sc + y*sy + x*sx]; pts [N,2] fp32 (x,y) in pixels;

@@ -227,3 +227,26 @@ def nn_match_two_way(desc1, desc2, nn_thresh):
     m = np.zeros((3, int(keep.sum())))
     m[0], m[1], m[2] = np.arange(desc1.shape[1])[keep], fwd[keep], score[keep]
     return m
+
+
+def filter_points(boxes, pts, H, W):
+    """reference demo.py:176-196: keypoints [3,N] inside any rint(xyxy) box are dropped (numpy slice painting of a mask)."""
+    mask = np.ones((H, W))
+    for x0, y0, x1, y1 in np.rint(np.asarray(boxes)[:, :4]).astype(int):
+        mask[y0:y1, x0:x1] = 0
+    p = pts.transpose()
+    keep = mask[p[:, 1].astype(int), p[:, 0].astype(int)] == 1
+    return p[keep].transpose()
+
+
+def frontend_postprocess(semi, coarse_desc, pred, det_thresh=0.015, nms=4, border=4, conf=0.25, iou=0.45, max_det=300, filter_pts=True):
+    """The post-processing chain of reference demo.py:136-215 on given head outputs (semi [65,Hc,Wc], coarse_desc [D,Hc,Wc],
+    pred [N,5+nc]; numpy) -> (pts [3,N], desc [D,N], boxes [n,6])."""
+    heat = flatten_detection_demo(semi)
+    H, W = heat.shape
+    pts = get_pts_from_heatmap(heat, det_thresh, nms, border)
+    boxes = non_max_suppression(pred[None], conf, iou, agnostic=True, multi_label=True, max_det=max_det)[0]
+    if filter_pts and pts.shape[1]:
+        pts = filter_points(boxes, pts, H, W)
+    desc = sample_desc_from_points(coarse_desc, pts) if pts.shape[1] else np.zeros((coarse_desc.shape[0], 0))
+    return pts, desc, boxes

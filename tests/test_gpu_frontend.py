@@ -1,0 +1,72 @@
+"""GPU-resident frame pipeline (yolopoint_amd/frontend.py, reference demo.py:125-230) against the oracle's restatement of the
+same post-processing chain, fed with the SAME head outputs (so index selection must agree exactly), and the box-mask
+keypoint filter kernel against numpy's slice-painting on planted boxes."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_model
+from oracle import net_oracle, postproc_oracle
+from yolopoint_amd import _hip
+from yolopoint_amd.frontend import YoloPointFrontend
+
+pytestmark = pytest.mark.gpu
+
+
+def test_pts_box_filter_matches_numpy_slice_painting(cuda):
+    H, W = 96, 128
+    rng = np.random.default_rng(3)
+    xs, ys = rng.integers(0, W, 700), rng.integers(0, H, 700)
+    pts = np.stack([xs, ys, rng.random(700)]).astype(np.float32)                       # [3,N]
+    boxes = np.array([[10.4, 5.5, 40.6, 30.5, .9, 0], [-7.2, 50.0, 20.0, 200.0, .8, 1], [100.5, -3.0, 127.49, 20.5, .7, 2],
+                      [60.0, 60.0, 60.4, 90.0, .6, 3], [-300.0, -300.0, 5.0, 5.0, .5, 0], [70.0, 40.0, 65.0, 80.0, .4, 0]], dtype=np.float32)
+    ref = postproc_oracle.filter_points(boxes, pts.astype(np.float64), H, W)
+    p = torch.from_numpy(np.ascontiguousarray(pts.T)).to(cuda)
+    b = torch.from_numpy(boxes).to(cuda)
+    out, cnt = torch.empty_like(p), torch.zeros(1, dtype=torch.int32, device=cuda)
+    _hip.check(_hip.lib().yp_pts_box_filter(p.data_ptr(), None, p.shape[0], b.data_ptr(), None, b.shape[0], 6, H, W, out.data_ptr(), cnt.data_ptr(), _hip.stream_ptr()))
+    n = int(cnt.item())
+    assert 0 < n < 700 and n == ref.shape[1]
+    np.testing.assert_array_equal(out[:n].cpu().numpy().T, ref.astype(np.float32))
+    # no boxes: everything is kept, in order
+    _hip.check(_hip.lib().yp_pts_box_filter(p.data_ptr(), None, p.shape[0], None, None, 0, 6, H, W, out.data_ptr(), cnt.data_ptr(), _hip.stream_ptr()))
+    assert int(cnt.item()) == 700 and torch.equal(out, p)
+
+
+@pytest.mark.parametrize("filter_pts", [True, False])
+def test_frontend_matches_oracle_postprocessing(cuda, filter_pts):
+    m, _ = make_model("n", 17, dtype="f32")
+    m = m.to(cuda).eval()
+    x = net_oracle.synth_image(1, 3, 96, 128, 4).to(cuda)
+    with torch.no_grad():
+        outs = m(x)
+    pred = outs["objects"][0][0].float()
+    thr, max_det = 0.5, 10        # the seeded random heads saturate: keep a handful of boxes so that they do not cover the whole frame
+    fe = YoloPointFrontend(m, cuda, yolo_config=dict(conf_thres_box=thr, iou_thres_box=0.45, max_det=max_det), filter_pts=filter_pts)
+    r = fe.process_tensor(x)
+    ref_pts, ref_desc, ref_boxes = postproc_oracle.frontend_postprocess(
+        outs["semi"][0].cpu().numpy(), outs["desc"][0].cpu().numpy(), pred.cpu().numpy(), 0.015, 4, 4, thr, 0.45, max_det, filter_pts)
+    boxes = r["boxes"].cpu().numpy()
+    assert boxes.shape == ref_boxes.shape and boxes.shape[0] > 3
+    np.testing.assert_allclose(boxes, ref_boxes, rtol=1e-5, atol=1e-4)
+    pts = r["pts"].cpu().numpy().T
+    assert pts.shape == ref_pts.shape and pts.shape[1] > 20
+    np.testing.assert_array_equal(pts[:2], ref_pts[:2].astype(np.float32))      # same points, same order
+    np.testing.assert_allclose(pts[2], ref_pts[2], rtol=1e-5)
+    np.testing.assert_allclose(r["desc"].cpu().numpy(), ref_desc, atol=2e-5)
+    assert r["n_before_filter"] >= pts.shape[1]      # (whether these random-weight boxes cover a keypoint is up to the seed; the
+                                                     #  planted-box test above exercises the removal itself)
+
+
+def test_frontend_process_img_reference_formats(cuda):
+    m, _ = make_model("n", 17, dtype="f16")
+    m = m.to(cuda).eval()
+    img = (net_oracle.synth_image(1, 3, 101, 140, 9)[0].permute(1, 2, 0).numpy() * 255).astype(np.uint8)    # not a multiple of 32: centre crop
+    fe = YoloPointFrontend(m, cuda, yolo_config=dict(conf_thres_box=0.9), filter_pts=True)
+    pts, desc, boxes = fe.process_img(img)
+    assert pts.dtype == np.float64 and pts.shape[0] == 3 and desc.shape == (m.model.ConvDesc.out_channels, pts.shape[1])
+    assert isinstance(boxes, list) and boxes[0].shape[1] == 6
+    assert pts[0].min() >= 6 + 4 and pts[1].min() >= 3 + 4                    # crop offsets (ceil(12/2), ceil(5/2)) + border
+    np.testing.assert_allclose(np.linalg.norm(desc, axis=0), 1.0, atol=1e-4)
+    with pytest.raises(_hip.YpError):
+        YoloPointFrontend(m, cuda, crop_resize=[0, 1, 0, 1, 2])

@@ -634,6 +634,69 @@ extern "C" int yp_box_nms(const float* pred, int B, int N, int nc, float conf_th
     return YP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Keypoints that fall inside a detected box are dropped (reference demo.py:176-196 `filter_points`): the reference
+// paints mask[y0:y1, x0:x1] = 0 for rint(xyxy) of every kept detection (numpy slice semantics: a negative bound counts from
+// the end, bounds are clamped to the image) and keeps a point when mask[int(y), int(x)] == 1.  Order-preserving compaction
+// by one workgroup: per 256-point chunk a ballot / prefix-count gives each surviving point its output slot.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int py_slice_bound(int v, int dim) { return v < 0 ? (v + dim < 0 ? 0 : v + dim) : (v > dim ? dim : v); }
+
+__global__ __launch_bounds__(256) void pts_box_filter_kernel(const float* __restrict__ pts, const int* __restrict__ n_in_dev, int n_in_host,
+                                                             const float* __restrict__ boxes, const int* __restrict__ n_boxes_dev, int n_boxes_host,
+                                                             int box_stride, int H, int W, float* __restrict__ out, int* __restrict__ out_count) {
+    __shared__ int sb[4 * 512];            // slice bounds of up to 512 boxes
+    __shared__ int wave_cnt[4];
+    __shared__ int base;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n = n_in_dev ? *n_in_dev : n_in_host;
+    int nb = n_boxes_dev ? *n_boxes_dev : n_boxes_host;
+    if (nb > 512) nb = 512;
+    for (int i = t; i < nb; i += 256) {
+        const float* b = boxes + (size_t)i * box_stride;
+        sb[4 * i + 0] = py_slice_bound((int)rintf(b[0]), W);
+        sb[4 * i + 1] = py_slice_bound((int)rintf(b[1]), H);
+        sb[4 * i + 2] = py_slice_bound((int)rintf(b[2]), W);
+        sb[4 * i + 3] = py_slice_bound((int)rintf(b[3]), H);
+    }
+    if (t == 0) base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        const int i = i0 + t;
+        bool keep = false;
+        float x = 0.f, y = 0.f, c = 0.f;
+        if (i < n) {
+            x = pts[3 * i]; y = pts[3 * i + 1]; c = pts[3 * i + 2];
+            const int xi = (int)x, yi = (int)y;
+            keep = true;
+            for (int k = 0; k < nb; ++k)
+                if (xi >= sb[4 * k] && xi < sb[4 * k + 2] && yi >= sb[4 * k + 1] && yi < sb[4 * k + 3]) { keep = false; break; }
+        }
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+        if (keep) {
+            const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
+            out[3 * slot] = x; out[3 * slot + 1] = y; out[3 * slot + 2] = c;
+        }
+        __syncthreads();
+        if (t == 0) base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+    if (t == 0) *out_count = base;
+}
+
+extern "C" int yp_pts_box_filter(const float* pts_xyc, const int* n_pts_dev, int n_pts, const float* boxes, const int* n_boxes_dev, int n_boxes,
+                                 int box_stride, int H, int W, float* out_xyc, int* out_count, void* stream) {
+    YP_REQUIRE(pts_xyc && out_xyc && out_count && (boxes || (n_boxes == 0 && !n_boxes_dev)) && n_pts >= 0 && n_boxes >= 0 && box_stride >= 4 && H > 0 && W > 0,
+               "yp_pts_box_filter: bad arguments");
+    pts_box_filter_kernel<<<1, 256, 0, (hipStream_t)stream>>>(pts_xyc, n_pts_dev, n_pts, boxes, n_boxes_dev, n_boxes, box_stride, H, W, out_xyc, out_count);
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
 extern "C" int yp_desc_sample(const float* desc, int D, int Hc, int Wc, int64_t sc, int64_t sy, int64_t sx, const float* pts_xy, int N,
                               int cell, float* out, void* stream) {
     YP_REQUIRE(desc && out && D > 0 && Hc > 0 && Wc > 0 && cell > 0 && N >= 0, "yp_desc_sample: bad arguments");

@@ -1,0 +1,110 @@
+"""GPU-resident frame pipeline: the reference's `YoloPointFrontend.process_img` (src/demo.py:58-230) with every stage on the
+device -- forward, keypoint decode (the demo's exp / (sum + 1e-5) softmax), threshold + greedy grid NMS + border removal,
+box NMS, box-mask keypoint filtering, descriptor sampling -- and exactly one host synchronisation per frame (two counters).
+The reference copies `semi` to numpy, runs the decode / NMS loops in Python and copies the points back for grid_sample.
+
+    fe = YoloPointFrontend(model, device)
+    pts, desc, boxes = fe.process_img(img_uint8_hwc)        # reference formats: [3,N] float64, [D,N] float32, [tensor[n,6]]
+    d = fe.process_tensor(x)                                 # device tensors, for the tracker / the next stage
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _hip
+from .utils._ws import workspace
+
+SP_DEFAULT = dict(detection_threshold=0.015, nms=4)                       # reference configs/*_inference.yaml
+YOLO_DEFAULT = dict(conf_thres_box=0.25, iou_thres_box=0.45, max_det=300)
+
+
+class YoloPointFrontend:
+    def __init__(self, model, device, sp_config=None, yolo_config=None, filter_pts=True, border_remove=4, cell=8, crop_resize=None):
+        if crop_resize:
+            raise _hip.YpError("YoloPointFrontend: crop_resize needs cv2.resize and is not part of the device pipeline")
+        if cell != 8:
+            raise _hip.YpError("YoloPointFrontend: the decode kernel is specialised for cell = 8")
+        self.model, self.device = model.eval(), torch.device(device)
+        self.sp_config = dict(SP_DEFAULT, **(sp_config or {}))
+        self.yolo_config = dict(YOLO_DEFAULT, **(yolo_config or {}))
+        self.filter_pts, self.border_remove, self.cell = filter_pts, border_remove, cell
+
+    # -- demo.py:111-121: make both dims divisible by 32 by a centred crop
+    @staticmethod
+    def preprocess(img):
+        h0, w0 = img.shape[:2]
+        cut_h, cut_w = (h0 % 32) / 2, (w0 % 32) / 2
+        cut_h0, cut_h1 = int(np.ceil(cut_h)), int(np.floor(cut_h))
+        cut_w0, cut_w1 = int(np.ceil(cut_w)), int(np.floor(cut_w))
+        return img[cut_h0:h0 - cut_h1, cut_w0:w0 - cut_w1], cut_h0, cut_w0, 1.0
+
+    @torch.no_grad()
+    def process_tensor(self, inp):
+        """inp: float [1,3,H,W] on the device, values in [0,1].  Returns dict(pts [N,3] (x, y, conf; conf descending),
+        desc [D,N] L2-normalised columns, boxes [n,6] (xyxy, conf, cls)) -- all device tensors."""
+        if inp.dim() != 4 or inp.shape[0] != 1:
+            raise _hip.YpError("YoloPointFrontend.process_tensor: one frame per call ([1,3,H,W])")
+        l, st, dev = _hip.lib(), _hip.stream_ptr(), inp.device
+        outs = self.model(inp)
+        semi, coarse, (pred, _) = outs["semi"], outs["desc"], outs["objects"]
+        B, _, Hc, Wc = semi.shape
+        H, W = Hc * 8, Wc * 8
+        # keypoints: demo softmax -> heat map -> threshold, grid NMS, border removal, sort by confidence
+        heat = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+        sb, sc, sy, sx = semi.stride()
+        _hip.check(l.yp_kp_decode(semi.data_ptr(), 1, Hc, Wc, sb, sc, sy, sx, 1, heat.data_ptr(), st))
+        radius = int(self.sp_config["nms"])
+        step = radius + 1
+        max_pts = max(1, -(-H // step) * -(-W // step))
+        pts = torch.empty((max_pts, 3), dtype=torch.float32, device=dev)
+        counts = torch.zeros((3,), dtype=torch.int32, device=dev)            # [points after NMS, boxes, points after filtering]
+        ws = workspace(dev, l.yp_kp_nms_workspace_bytes(1, H, W), "kp_nms")
+        _hip.check(l.yp_kp_nms(heat.data_ptr(), 1, H, W, float(self.sp_config["detection_threshold"]), radius, int(self.border_remove),
+                               pts.data_ptr(), counts.data_ptr(), max_pts, ws.data_ptr(), ws.numel(), st))
+        # boxes: multi-label, class-agnostic NMS as the demo calls it (demo.py:168-174)
+        p = pred if (pred.dtype == torch.float32 and pred.is_contiguous()) else pred.float().contiguous()
+        N, no = p.shape[1], p.shape[2]
+        nc, max_det = no - 5, int(self.yolo_config["max_det"])
+        ml = int(nc > 1)
+        boxes = torch.empty((1, max_det, 6), dtype=torch.float32, device=dev)
+        ws2 = workspace(dev, l.yp_box_nms_workspace_bytes(1, N, nc, ml, 30000), "box_nms")
+        cnt_boxes = counts[1:2]
+        _hip.check(l.yp_box_nms(p.data_ptr(), 1, N, nc, float(self.yolo_config["conf_thres_box"]), float(self.yolo_config["iou_thres_box"]), ml, 1,
+                                max_det, 30000, 7680.0, boxes.data_ptr(), cnt_boxes.data_ptr(), ws2.data_ptr(), ws2.numel(), st))
+        # keypoints inside a detected box are dropped (dynamic objects)
+        if self.filter_pts:
+            kept = torch.empty_like(pts)
+            _hip.check(l.yp_pts_box_filter(pts.data_ptr(), counts[0:1].data_ptr(), max_pts, boxes.data_ptr(), cnt_boxes.data_ptr(), max_det, 6, H, W,
+                                           kept.data_ptr(), counts[2:3].data_ptr(), st))
+        else:
+            kept = pts
+            counts[2:3].copy_(counts[0:1])
+        n_nms, n_box, n_pts = counts.cpu().tolist()                               # the frame's only host sync
+        if n_box < 0:
+            raise _hip.YpError("YoloPointFrontend: box NMS candidate list overflowed its workspace")
+        kept, boxes = kept[:n_pts], boxes[0, :n_box]
+        D = coarse.shape[1]
+        desc = torch.empty((D, n_pts), dtype=torch.float32, device=dev)
+        if n_pts:
+            xy = kept[:, :2].contiguous()
+            _, dc, dy, dx = coarse.stride()
+            _hip.check(l.yp_desc_sample(coarse.data_ptr(), D, Hc, Wc, dc, dy, dx, xy.data_ptr(), n_pts, 8, desc.data_ptr(), st))
+        return {"pts": kept, "desc": desc, "boxes": boxes, "n_before_filter": n_nms, "heat": heat[0]}
+
+    @torch.no_grad()
+    def process_img(self, img):
+        """img: HxWx3 uint8 (numpy).  Returns (pts [3,N] float64, desc [D,N] float32, [boxes tensor]) in the coordinates of the
+        original image, or (zeros((3,0)), None, None) when no keypoint survives -- the reference's return convention."""
+        img, cth, ctw, fac = self.preprocess(img)
+        x = torch.from_numpy(np.ascontiguousarray(img.transpose(2, 0, 1))).to(self.device).float().div_(255.).unsqueeze(0)
+        r = self.process_tensor(x)
+        if r["n_before_filter"] == 0:
+            return np.zeros((3, 0)), None, None
+        pts = r["pts"].cpu().numpy().astype(np.float64).T.copy()
+        desc = r["desc"].cpu().numpy()
+        pts[0] = (pts[0] + ctw) / fac
+        pts[1] = (pts[1] + cth) / fac
+        boxes = r["boxes"].clone()
+        boxes[:, :4] = (boxes[:, :4] + torch.tensor([ctw, cth, ctw, cth], device=boxes.device)) / fac
+        return pts, desc, [boxes]
