@@ -116,6 +116,9 @@ def lib():
     """Load the shared library (built by __graft_entry__.build()); fail loudly when absent."""
     global _lib
     if _lib is None:
+        # PyTorch-ROCm bundles its own libamdhip64: it must be in the process first, so that this library binds to the SAME
+        # HIP runtime (loading ours first pulls /opt/rocm's copy in, and torch then finds no usable device)
+        import torch  # noqa: F401
         path = os.environ.get("YP_HIP_LIB", LIB_PATH)      # override: A/B-compare two builds of the library in one session
         if not os.path.exists(path):
             raise YpError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
