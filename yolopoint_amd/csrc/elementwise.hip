@@ -233,7 +233,7 @@ __global__ void detect_decode_kernel(const float* __restrict__ raw, int cs, int 
         const float v = raw[(((size_t)b * ny + yy) * nx + xx) * cs + co + a * no + o];
         x_out[i] = v;
         if (z_out != nullptr) {
-            const float s = 1.0f / (1.0f + expf(-v));
+            const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));   // as the fused Detect epilogue
             float z;
             if (o == 0) z = (s * 2.0f - 0.5f + (float)xx) * stride;
             else if (o == 1) z = (s * 2.0f - 0.5f + (float)yy) * stride;

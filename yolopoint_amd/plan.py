@@ -8,6 +8,7 @@ shared buffer, or a conv takes two source views.  Weights are packed once per pl
 [Cout_pad][Kpad] rows with k = (r*S + s)*Cin + c.
 """
 import ctypes as C
+import os
 import math
 
 import torch
@@ -445,6 +446,8 @@ class PlanBuilder:
             e1.record()
             e1.synchronize()
             ms = e0.elapsed_time(e1)
+            if os.environ.get("YP_TUNE_DEBUG"):
+                print(f"[tune] {self.name():40s} cand {cand:2d}: {ms / 8 * 1e3:7.1f} us", flush=True)
             if best_ms is None or ms < best_ms:
                 best, best_ms = cand, ms
         _TUNE_CACHE[key] = (best, (best_ms / 8 if best_ms is not None else None))
