@@ -337,14 +337,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     }
     // ---- split-K: this workgroup reduces k tiles [kt0, kt1)
     const int nk_all = (a.Kreal + BK - 1) / BK;
-    const int kt0 = (int)(((long)nk_all * blockIdx.y) / a.ksplit);
-    const int kt1 = (int)(((long)nk_all * (blockIdx.y + 1)) / a.ksplit);
+    int kt0 = 0, kt1 = nk_all;
+    if (a.ksplit > 1) {                   // (keeps the two 64-bit divisions out of the setup of every ordinary launch)
+        kt0 = (int)(((long)nk_all * blockIdx.y) / a.ksplit);
+        kt1 = (int)(((long)nk_all * (blockIdx.y + 1)) / a.ksplit);
+    }
     // ---- per-lane filter-tap state for logical chunk jl: k = kt*BK + jl*CE = tap*Cin + kc, tap = r*S + s
     int kc, tap;
     {
         const int k = kt0 * BK + jl * CE;
-        tap = k / a.Cin;
-        kc = k - tap * a.Cin;
+        if (k < a.Cin) { tap = 0; kc = k; }          // the common case (first k tile, Cin >= 64 bytes of channels): no division
+        else { tap = k / a.Cin; kc = k - tap * a.Cin; }
     }
     const char* const zero = reinterpret_cast<const char*>(yp_zero16);
 
@@ -361,7 +364,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     // FAST path state: every lane of the workgroup is in the same filter tap (Cin % BK == 0), so the tap
     // decode, the source select and the channel offset live on the scalar unit.
-    int s_tap = (kt0 * BK) / a.Cin, s_c0 = kt0 * BK - s_tap * a.Cin;
+    int s_tap = 0, s_c0 = 0;
+    if (kt0 > 0) { s_tap = (kt0 * BK) / a.Cin; s_c0 = kt0 * BK - s_tap * a.Cin; }
     YP_PIN2(unsigned, in0_zoff); YP_PIN2(unsigned, in1_zoff); YP_PIN2(const char*, wgt);
     auto issue_tile = [&](int kt, int stage) {
         const unsigned sbase = lds0 + stage * STAGE;
