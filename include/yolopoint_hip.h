@@ -112,7 +112,14 @@ typedef struct YpConvDesc {
     const float* pre_bias;
     int32_t pre_Kpad, pre_Npad;
     int32_t pre_act;
-    int32_t reserved_;
+    int32_t post_act;
+    /* C3 tail (reference models/common.py:135 `cv3(cat(m(cv1(x)), cv2(x)))`) fused behind the fused Bottleneck: when post_weight !=
+     * NULL, `in1` is the cv2 branch (in0.C channels at the output size), `out` the C3 output (2 * in0.C channels) and the kernel
+     * writes out = post_act(conv1x1(cat(bottleneck output, in1), post_weight) + post_bias); the bottleneck output stays in LDS.
+     * Requires pre_weight and in0.C <= 64. */
+    const void* post_weight;         /* packed [post_Npad][post_Kpad] 1x1 filter over 2 * in0.C input channels */
+    const float* post_bias;
+    int32_t post_Kpad, post_Npad;
 } YpConvDesc;
 
 int yp_conv2d(const YpConvDesc* d, void* stream);

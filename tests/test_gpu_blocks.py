@@ -206,6 +206,36 @@ def test_fused_bottleneck_kernel(cuda, case, dtype):
     assert torch.equal(outs["fused"], outs["two"]), (case, dtype, float((outs["fused"] - outs["two"]).abs().max()))
 
 
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("c1,c2,n,B,H,W", [(64, 64, 1, 2, 24, 40), (128, 128, 2, 1, 19, 23), (256, 128, 1, 2, 16, 16), (64, 64, 1, 1, 9, 21)])
+def test_c3_tail_fused_into_last_bottleneck(cuda, c1, c2, n, B, H, W, dtype):
+    """C3 with cv3 running inside the last Bottleneck's kernel (hidden widths 32 / 64) against the oracle and against the
+    unfused launch sequence, which it must reproduce exactly (same 16-bit rounding points, same k order); ragged tiles."""
+    m = C3(c1, c2, n).eval()
+    for mod in m.modules():
+        if hasattr(mod, "compute_dtype"):
+            mod.compute_dtype = dtype
+    sd = block_state(m, 5, "blk.")
+    x = net_oracle.synth_image(B, c1, H, W, 2) - 0.5
+    ref = net_oracle.c3(sd, "blk", x, n)
+    outs = {}
+    for fused in (True, False):
+        C3.fuse_tail = fused
+        try:
+            m._plans = {} if hasattr(m, "_plans") else None
+            m.__dict__.pop("_plan_cache", None)
+            mm = C3(c1, c2, n).eval()
+            mm.load_state_dict(m.state_dict())
+            for mod in mm.modules():
+                if hasattr(mod, "compute_dtype"):
+                    mod.compute_dtype = dtype
+            outs[fused] = mm.to(cuda)(x.to(cuda)).float().cpu()
+        finally:
+            C3.fuse_tail = True
+    assert rel_err(outs[True], ref)[0] < TOL[dtype] * 2
+    assert torch.equal(outs[True], outs[False]), float((outs[True] - outs[False]).abs().max())
+
+
 def test_fused_bottleneck_rejects_unsupported(cuda):
     pb = PlanBuilder(1, _hip.YP_F16, cuda)
     pb.autotune = False

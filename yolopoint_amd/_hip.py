@@ -34,7 +34,8 @@ class YpConvDesc(C.Structure):
                 ("dil_h", C.c_int32), ("dil_w", C.c_int32), ("in0_zero_stuffed", C.c_int32), ("ksplit", C.c_int32),
                 ("atomic_accumulate", C.c_int32), ("tail_zero", C.c_int32),
                 ("pre_weight", C.c_void_p), ("pre_bias", C.c_void_p), ("pre_Kpad", C.c_int32), ("pre_Npad", C.c_int32),
-                ("pre_act", C.c_int32), ("reserved_", C.c_int32)]
+                ("pre_act", C.c_int32), ("post_act", C.c_int32),
+                ("post_weight", C.c_void_p), ("post_bias", C.c_void_p), ("post_Kpad", C.c_int32), ("post_Npad", C.c_int32)]
 
 
 class YpDetectDesc(C.Structure):

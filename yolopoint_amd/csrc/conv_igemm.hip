@@ -92,6 +92,10 @@ struct ConvKArgs {
     const char* pre_wgt;           // fused Bottleneck: 1x1 prologue filter / bias
     const float* pre_bias;
     int pre_Kpad, pre_act;
+    const char* post_wgt;          // fused C3 tail: 1x1 conv over cat(bottleneck output, in1) -> out
+    const float* post_bias;
+    int post_Kpad, post_Npad, post_act, post_N;
+    unsigned post_zrow;
     // fused Detect decode (EPI_DETECT instantiations)
     int det_na, det_no, det_invno, det_rows_total, det_row_off;
     float det_stride;
@@ -750,7 +754,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvKArgs a) {
 // HBM traffic: x once (+ the shortcut re-read of the tile centre, an L2 hit) and out once -- the hidden
 // tensor's write + 9-tap read of the two-launch form disappear, as does one launch.
 // ==========================================================================================
-template <int DT, int C, int BN, int WAVES_M>
+template <int DT, int C, int BN, int WAVES_M, bool POST = false>
 __global__ __launch_bounds__(256) void bottleneck_halo_kernel(const ConvKArgs a) {
     using E = Elem<DT>;
     using frag_t = typename E::frag;
@@ -770,11 +774,18 @@ __global__ __launch_bounds__(256) void bottleneck_halo_kernel(const ConvKArgs a)
     constexpr int WSLOTS_TAP = BN / 16, WSLOTS = 3 * WSLOTS_TAP, NW = (WSLOTS + 3) / 4, WBYTES = WSLOTS * 1024;
     constexpr int NLA = NH + NWA;                       // DMA instructions per wave per phase-A chunk
     static_assert(HROWS <= HSLOTS * 16 && BN <= C && FN >= 1 && FM >= 1, "unsupported tile");
+    // POST: the C3 tail.  out = act(W3 . cat(bottleneck output, in1) + b3), N3 = K3 = 2C; the bottleneck output never leaves LDS.
+    constexpr int N3 = 2 * C, FN3 = N3 / 16, LPG3 = 4 * FN3, KCH3 = N3 / BK;      // one wave column: every wave holds all N3 channels
+    constexpr int W3BYTES = KCH3 * N3 * 64, NW3 = KCH3 * (N3 / 16) / 4, NU = NCH * 8 / 4;
+    static_assert(!POST || (BN == C && WAVES_M == 4), "C3 tail: all channels of a pixel in one workgroup");
 
-    extern __shared__ __attribute__((aligned(1024))) char hsm[];      // [hidden: NCH x HBYTES][ring: phase A operands | filter rows]
+    extern __shared__ __attribute__((aligned(1024))) char hsm[];      // [hidden | bottleneck output][ring: phase A operands | filter rows | W3][POST: in1 tile]
     const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)hsm);
     constexpr int RING = NCH * HBYTES;
+    constexpr int OPA = NCH * ASTAGE, OPB = 3 * WBYTES;
+    constexpr int RINGBYTES = POST ? (OPA > OPB ? (OPA > W3BYTES ? OPA : W3BYTES) : (OPB > W3BYTES ? OPB : W3BYTES)) : (OPA > OPB ? OPA : OPB);
     const unsigned ldsR = lds0 + RING;
+    const unsigned ldsU = ldsR + RINGBYTES;
 
     YP_TL(0);
     int bid = yp_xcd_remap(blockIdx.x, gridDim.x);
@@ -851,6 +862,18 @@ __global__ __launch_bounds__(256) void bottleneck_halo_kernel(const ConvKArgs a)
     yp_load_bias<LPG>(a, nb, bias);
 
     YP_TL(1);
+    if constexpr (POST) {
+        // in1 (the C3's cv2 branch) at the tile's 128 centre pixels: issued first, consumed last
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int sl = wave + 4 * i;                 // NCH chunks x 8 slots of 16 pixel rows
+            const int cc = sl >> 3, rho = (sl & 7) * 16 + lrow;
+            const int oy = y0 + (rho >> 4), ox = x0 + (rho & 15);
+            const bool ok = oy < a.Ho && ox < a.Wo;
+            const unsigned off = ok ? (unsigned)((((b * a.Ho + oy) * a.Wo + ox) * a.in1_cs + a.in1_co + cc * BK) * EB) + (unsigned)jl * 16u : a.in1_zoff;
+            yp_glds16_s(a.in1, off, ldsU + sl * 1024);
+        }
+    }
     // ---- phase A: everything in flight at once
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -975,14 +998,113 @@ __global__ __launch_bounds__(256) void bottleneck_halo_kernel(const ConvKArgs a)
     }
 
     YP_TL(40);
+    if constexpr (!POST) {
 #pragma unroll
-    for (int fm = 0; fm < FM; ++fm) {
-        const int oy = y0 + wm * FM + fm, ox = x0 + p;
-        if (oy >= a.Ho || ox >= a.Wo) continue;
-        const int m = (b * a.Ho + oy) * a.Wo + ox;
-        yp_epilogue_pixel<DT, false, LPG>(a, m, nb, bias, [&](int cj) { return acc[cj >> 2][fm][cj & 3]; });
+        for (int fm = 0; fm < FM; ++fm) {
+            const int oy = y0 + wm * FM + fm, ox = x0 + p;
+            if (oy >= a.Ho || ox >= a.Wo) continue;
+            const int m = (b * a.Ho + oy) * a.Wo + ox;
+            yp_epilogue_pixel<DT, false, LPG>(a, m, nb, bias, [&](int cj) { return acc[cj >> 2][fm][cj & 3]; });
+        }
+        YP_TL(41);
+    } else {
+        // ---- C3 tail.  The ring is free: fetch W3 (all of it), meanwhile finish the bottleneck output into LDS (it replaces the
+        // hidden tensor, same swizzled 64-byte-row format, rows = the tile's 128 centre pixels).
+        __builtin_amdgcn_s_barrier();
+        {
+            const char* w3 = a.post_wgt;
+#pragma unroll
+            for (int i = 0; i < NW3; ++i) {
+                const int sl = wave + 4 * i;             // KCH3 chunks x N3/16 slots
+                const int kc = sl / (N3 / 16), rs = sl - kc * (N3 / 16);
+                const int rho = rs * 16 + lrow;          // LDS row -> channel (lanes own LPG3 consecutive channels)
+                const int n = ((rho & 15) >> 2) * LPG3 + (rho >> 4) * 4 + (rho & 3);
+                const unsigned off = (unsigned)n * (unsigned)a.post_Kpad * EB + (unsigned)(kc * BK * EB) + (unsigned)jl * 16u;
+                yp_glds16_s(w3, off, ldsR + sl * 1024);
+            }
+        }
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) {
+            const int ly = wm * FM + fm;
+            const int oy = y0 + ly, ox = x0 + p;
+            const bool inside = oy < a.Ho && ox < a.Wo;
+            const int m = (b * a.Ho + oy) * a.Wo + ox;
+            const int rho = ly * 16 + p;
+#pragma unroll
+            for (int h = 0; h < LPG / 8; ++h) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float x = acc[(h * 8 + j) >> 2][fm][(h * 8 + j) & 3] + bias[h * 8 + j];
+                    if (a.act == YP_ACT_SILU) x = yp_silu(x);
+                    v[j] = x;
+                }
+                const int nc = nb + h * 8;
+                if (a.has_res && inside) {
+                    const u32x4 raw = *reinterpret_cast<const u32x4*>(a.res + ((size_t)m * a.res_cs + a.res_co + nc) * EB);
+                    const sc* e = reinterpret_cast<const sc*>(&raw);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
+                }
+                u32x4 pk;
+                sc* e = reinterpret_cast<sc*>(&pk);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) e[j] = (sc)v[j];
+                *reinterpret_cast<u32x4*>(hsm + (nc >> 5) * 8192 + rho * 64 + ((((nc & 31) >> 3) ^ swr) << 4)) = pk;
+            }
+        }
+        float b3[LPG3];
+#pragma unroll
+        for (int q = 0; q < LPG3 / 4; ++q) {
+            f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (a.post_bias != nullptr) b4 = *reinterpret_cast<const f32x4*>(a.post_bias + g * LPG3 + 4 * q);
+            b3[4 * q] = b4[0]; b3[4 * q + 1] = b4[1]; b3[4 * q + 2] = b4[2]; b3[4 * q + 3] = b4[3];
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        YP_TL(41);
+        f32x4 acc3[FN3][FM];
+#pragma unroll
+        for (int f = 0; f < FN3; ++f)
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) acc3[f][fm] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int rd = p * 64 + ((g ^ swr) << 4);
+#pragma unroll
+        for (int kc = 0; kc < KCH3; ++kc) {
+            const char* xb = kc < NCH ? hsm + kc * 8192 : hsm + RING + RINGBYTES + (kc - NCH) * 8192;
+            const char* wb = hsm + RING + kc * (N3 * 64);
+            frag_t xf[FM];
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) xf[fm] = *reinterpret_cast<const frag_t*>(xb + (wm * FM + fm) * 1024 + rd);
+#pragma unroll
+            for (int f = 0; f < FN3; ++f) {
+                const frag_t wf = *reinterpret_cast<const frag_t*>(wb + f * 1024 + rd);
+#pragma unroll
+                for (int fm = 0; fm < FM; ++fm) acc3[f][fm] = E::mma(wf, xf[fm], acc3[f][fm]);
+            }
+        }
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) {
+            const int oy = y0 + wm * FM + fm, ox = x0 + p;
+            if (oy >= a.Ho || ox >= a.Wo) continue;
+            const size_t m = (size_t)(b * a.Ho + oy) * a.Wo + ox;
+            char* op = a.out + (m * a.out_cs + a.out_co + g * LPG3) * EB;
+#pragma unroll
+            for (int h = 0; h < LPG3 / 8; ++h) {
+                if (g * LPG3 + h * 8 >= a.post_N) continue;
+                u32x4 pk;
+                sc* e = reinterpret_cast<sc*>(&pk);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float x = acc3[(h * 8 + j) >> 2][fm][(h * 8 + j) & 3] + b3[h * 8 + j];
+                    if (a.post_act == YP_ACT_SILU) x = yp_silu(x);
+                    e[j] = (sc)x;
+                }
+                *reinterpret_cast<u32x4*>(op + h * 16) = pk;
+            }
+        }
+        YP_TL(42);
     }
-    YP_TL(41);
 }
 
 
@@ -1193,12 +1315,15 @@ hipError_t dispatch_halo(int stride, int bn, int th, const ConvKArgs& a, int nbl
 #undef YP_HALO
 }
 
-template <int DT, int C, int BN, int WAVES_M>
+template <int DT, int C, int BN, int WAVES_M, bool POST>
 hipError_t launch_bneck(const ConvKArgs& a, int nblk, hipStream_t st) {
     constexpr size_t hid = (size_t)(C / 32) * 12 * 1024;
     constexpr size_t opa = (size_t)(C / 32) * (12 + C / 16) * 1024, opb = (size_t)3 * 3 * (BN / 16) * 1024;
-    constexpr size_t lds = hid + (opa > opb ? opa : opb);
-    auto kern = bottleneck_halo_kernel<DT, C, BN, WAVES_M>;
+    constexpr size_t w3 = POST ? (size_t)(2 * C / 32) * (2 * C) * 64 : 0, ub = POST ? (size_t)(C / 32) * 8192 : 0;
+    constexpr size_t ring = opa > opb ? (opa > w3 ? opa : w3) : (opb > w3 ? opb : w3);
+    constexpr size_t lds = hid + ring + ub;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = bottleneck_halo_kernel<DT, C, BN, WAVES_M, POST>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1210,12 +1335,13 @@ hipError_t launch_bneck(const ConvKArgs& a, int nblk, hipStream_t st) {
 }
 
 template <int DT>
-hipError_t dispatch_bneck(int c, int bn, const ConvKArgs& a, int nblk, hipStream_t st) {
-    if (c == 32) return launch_bneck<DT, 32, 32, 4>(a, nblk, st);
-    if (c == 64) return bn == 32 ? launch_bneck<DT, 64, 32, 4>(a, nblk, st) : launch_bneck<DT, 64, 64, 4>(a, nblk, st);
-    if (bn == 32) return launch_bneck<DT, 128, 32, 4>(a, nblk, st);
-    if (bn == 64) return launch_bneck<DT, 128, 64, 4>(a, nblk, st);
-    return launch_bneck<DT, 128, 128, 2>(a, nblk, st);
+hipError_t dispatch_bneck(int c, int bn, bool post, const ConvKArgs& a, int nblk, hipStream_t st) {
+    if (post) return c == 32 ? launch_bneck<DT, 32, 32, 4, true>(a, nblk, st) : launch_bneck<DT, 64, 64, 4, true>(a, nblk, st);
+    if (c == 32) return launch_bneck<DT, 32, 32, 4, false>(a, nblk, st);
+    if (c == 64) return bn == 32 ? launch_bneck<DT, 64, 32, 4, false>(a, nblk, st) : launch_bneck<DT, 64, 64, 4, false>(a, nblk, st);
+    if (bn == 32) return launch_bneck<DT, 128, 32, 4, false>(a, nblk, st);
+    if (bn == 64) return launch_bneck<DT, 128, 64, 4, false>(a, nblk, st);
+    return launch_bneck<DT, 128, 128, 2, false>(a, nblk, st);
 }
 
 int pick_tile(int M, int N) {
@@ -1238,15 +1364,19 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
     YP_REQUIRE(d != nullptr, "yp_conv2d: null descriptor");
     YP_REQUIRE(d->dtype == YP_F16 || d->dtype == YP_BF16 || d->dtype == YP_F32, "yp_conv2d: bad dtype %d", d->dtype);
     const int ce = d->dtype == YP_F32 ? 4 : 8;
-    const int Cin = d->in0.C + d->in1.C;
-    const int Cout = d->out.C + d->out2.C;
+    // fused C3 tail (post_weight): in1 is the second input of the TAIL convolution and `out` its destination; the 3x3 itself maps
+    // in0.C -> in0.C channels
+    const bool post = d->post_weight != nullptr;
+    const int Cin = post ? d->in0.C : d->in0.C + d->in1.C;
+    const int Cout = post ? d->in0.C : d->out.C + d->out2.C;
     YP_REQUIRE(d->in0.ptr && (d->out.ptr || det) && d->weight, "yp_conv2d: null buffer");
     YP_REQUIRE(d->in0.C > 0 && d->in0.C % ce == 0 && d->in1.C % ce == 0, "yp_conv2d: input channels (%d,%d) must be multiples of %d", d->in0.C, d->in1.C, ce);
     YP_REQUIRE(d->in0.cstride % ce == 0 && d->in0.coff % ce == 0, "yp_conv2d: in0 slice not 16-byte aligned");
     YP_REQUIRE(d->in1.C == 0 || (d->in1.ptr && d->in1.cstride % ce == 0 && d->in1.coff % ce == 0), "yp_conv2d: in1 slice not 16-byte aligned");
     YP_REQUIRE(d->out.C > 0 && d->out.C % 8 == 0 && d->out.cstride % 8 == 0 && d->out.coff % 8 == 0, "yp_conv2d: output slice (C=%d cs=%d co=%d) must be multiples of 8", d->out.C, d->out.cstride, d->out.coff);
+    YP_REQUIRE(!post || (d->pre_weight != nullptr && det == nullptr), "yp_conv2d: the fused C3 tail (post_weight) extends the fused Bottleneck (pre_weight)");
     YP_REQUIRE(d->out2.C == 0 || (d->out2.ptr && d->out2.C % 8 == 0 && d->out2.cstride % 8 == 0 && d->out2.coff % 8 == 0 && d->out2.H == d->Ho && d->out2.W == d->Wo && d->res.C == 0), "yp_conv2d: bad second output view");
-    YP_REQUIRE(d->res.C == 0 || (d->res.ptr && d->res.C == d->out.C && d->res.cstride % 8 == 0 && d->res.coff % 8 == 0 && !d->out_f32), "yp_conv2d: bad residual view");
+    YP_REQUIRE(d->res.C == 0 || (d->res.ptr && d->res.C == Cout && d->res.cstride % 8 == 0 && d->res.coff % 8 == 0 && !d->out_f32), "yp_conv2d: bad residual view");
     YP_REQUIRE(d->B > 0 && d->Ho > 0 && d->Wo > 0 && d->R > 0 && d->S > 0, "yp_conv2d: bad dims");
     YP_REQUIRE(d->in0.ups >= 0 && d->in0.ups <= 1 && d->in1.ups >= 0 && d->in1.ups <= 1, "yp_conv2d: ups must be 0/1");
     YP_REQUIRE((d->in0.H << d->in0.ups) == d->Hi && (d->in0.W << d->in0.ups) == d->Wi, "yp_conv2d: in0 %dx%d<<%d != logical %dx%d", d->in0.H, d->in0.W, d->in0.ups, d->Hi, d->Wi);
@@ -1322,9 +1452,10 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
     }
     // 3x3 / pad 1 / stride 1|2, single un-upsampled source, 16-bit types, Cin % 32 == 0: LDS halo-reuse kernel
     // (tile ids 10..12 force it with BN = 32/64/128; tile 0 picks BN by the channel count; ids 1..5 force the generic kernel)
-    const bool halo_ok = fast && d->dtype != YP_F32 && d->R == 3 && d->S == 3 && d->pad_h == 1 && d->pad_w == 1 &&
-                         d->stride_h == d->stride_w && (d->stride_h == 1 || d->stride_h == 2) && d->in1.C == 0 && d->in0.ups == 0 && ksplit == 1 && !d->atomic_accumulate &&
-                         in0_bytes + (size_t)d->in0.cstride * eb + 64 < (1ull << 31);
+    const bool halo_base = fast && d->dtype != YP_F32 && d->R == 3 && d->S == 3 && d->pad_h == 1 && d->pad_w == 1 &&
+                           d->stride_h == d->stride_w && (d->stride_h == 1 || d->stride_h == 2) && d->in0.ups == 0 && ksplit == 1 && !d->atomic_accumulate &&
+                           in0_bytes + (size_t)d->in0.cstride * eb + 64 < (1ull << 31);
+    const bool halo_ok = halo_base && (d->in1.C == 0 || post);
     if (d->pre_weight != nullptr) {      // fused Bottleneck: 1x1 prologue + 3x3, hidden tensor in LDS
         const int Cc = d->in0.C;
         YP_REQUIRE(halo_ok && d->stride_h == 1 && !of32 && d->out2.C == 0, "yp_conv2d: the pointwise prologue needs a 16-bit 3x3 / stride 1 / pad 1 convolution with tail_zero buffers");
@@ -1335,12 +1466,21 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
         if (d->tile == 10) bn = 32; else if (d->tile == 11) bn = 64; else if (d->tile == 12) bn = 128;
         YP_REQUIRE(bn <= Cc, "yp_conv2d: fused bottleneck tile of %d channels > %d", bn, Cc);
         a.pre_wgt = (const char*)d->pre_weight; a.pre_bias = d->pre_bias; a.pre_Kpad = d->pre_Kpad; a.pre_act = d->pre_act;
+        if (post) {
+            YP_REQUIRE(Cc <= 64 && d->in1.C == Cc && d->in1.ups == 0 && d->in1.H == d->Ho && d->in1.W == d->Wo && d->out.C == 2 * Cc,
+                       "yp_conv2d: fused C3 tail needs hidden channels <= 64, in1 = the other %d-channel branch at the output size, out.C = %d", Cc, 2 * Cc);
+            YP_REQUIRE(d->post_Npad >= 2 * Cc && d->post_Kpad >= 2 * Cc && d->post_Kpad % 32 == 0 && (d->tile == 0 || d->tile == (Cc == 32 ? 10 : 11)),
+                       "yp_conv2d: bad packed C3-tail filter %dx%d / tile %d", d->post_Npad, d->post_Kpad, d->tile);
+            bn = Cc;
+            a.post_wgt = (const char*)d->post_weight; a.post_bias = d->post_bias; a.post_Kpad = d->post_Kpad; a.post_Npad = d->post_Npad;
+            a.post_act = d->post_act; a.post_N = 2 * Cc;
+        }
         a.tiles_n = yp_cdiv(Cout, bn);
         a.tiles_x = yp_cdiv(d->Wo, 16);
         a.tiles_y = yp_cdiv(d->Ho, 8);
         a.Ho = d->Ho;
         const int nb3 = d->B * a.tiles_y * a.tiles_x * a.tiles_n;
-        e = d->dtype == YP_F16 ? dispatch_bneck<YP_F16>(Cc, bn, a, nb3, stream) : dispatch_bneck<YP_BF16>(Cc, bn, a, nb3, stream);
+        e = d->dtype == YP_F16 ? dispatch_bneck<YP_F16>(Cc, bn, post, a, nb3, stream) : dispatch_bneck<YP_BF16>(Cc, bn, post, a, nb3, stream);
         if (e != hipSuccess) {
             yp_set_error("yp_conv2d: fused bottleneck launch failed: %s", hipGetErrorString(e));
             return YP_ERR_HIP;

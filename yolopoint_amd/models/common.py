@@ -171,6 +171,9 @@ class C3(HipModule):
         self.cv3 = Conv(2 * c_, c2, 1)
         self.m = nn.Sequential(*(Bottleneck(c_, c_, shortcut, g, e=1.0) for _ in range(n)))
 
+    # YP_FUSE_C3_TAIL=0 disables the cv3-in-the-last-Bottleneck fusion (A/B measurements)
+    fuse_tail = os.environ.get("YP_FUSE_C3_TAIL", "1") != "0"
+
     def _standalone_out_channels(self):
         return self.cv3.conv.out_channels
 
@@ -186,8 +189,21 @@ class C3(HipModule):
         pb.conv(x, torch.cat((w1, w2), 0), torch.cat((b1, b2), 0), 1, 1, 0, _hip.YP_ACT_SILU, out=t, out2=cat.view(c_, c_))
         pb.scope.pop()
         n = len(self.m)
+        last = self.m[n - 1]
+        # C3 tail fusion: cv3 runs inside the last Bottleneck's kernel (its output never reaches HBM); hidden widths 32 / 64
+        fuse_tail = (self.fuse_tail and c_ in (32, 64) and last.fuse is True and last._fusable(pb, t) and isinstance(self.cv3.act, nn.SiLU)
+                     and self.cv3.conv.out_channels == 2 * c_)
         for i, blk in enumerate(self.m):
             pb.scope.append(f"m.{i}")
+            if i == n - 1 and fuse_tail:
+                (wa, ba), (wb, bb), (w3, b3) = blk.cv1.folded(), blk.cv2.folded(), self.cv3.folded()
+                if out is None:
+                    out = pb.new_buf(x0.LH, x0.LW, 2 * c_).view()
+                pb.scope.append("cv1>cv2>cv3")
+                y = pb.conv(t, wb, bb, 3, 1, 1, _hip.YP_ACT_SILU, out=out, res=t if blk.add else None,
+                            extra={"pre": (wa, ba, _hip.YP_ACT_SILU), "post": (w3, b3, _hip.YP_ACT_SILU, cat.view(c_, c_))})
+                pb.scope.pop(); pb.scope.pop()
+                return y
             t = blk.emit(pb, t, out=cat.view(0, c_) if i == n - 1 else None)
             pb.scope.pop()
         pb.scope.append("cv3"); y = self.cv3.emit(pb, cat.view(), out=out); pb.scope.pop()

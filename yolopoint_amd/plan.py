@@ -280,7 +280,8 @@ class PlanBuilder:
             assert out2 is None
             out = self.new_buf(Ho, Wo, Cout_pad, f32=out_f32).view()
         c2 = out2.C if out2 is not None else 0      # channels [out.C, out.C + c2) are written to out2
-        assert out.C + c2 == Cout_pad and out.H == Ho and out.W == Wo, (self.name(), out.C, c2, Cout_pad, out.H, Ho)
+        post = extra.get("post")                    # fused C3 tail: `out` is the tail's destination (2 * Cout channels)
+        assert out.C + c2 == (2 * Cout_pad if post is not None else Cout_pad) and out.H == Ho and out.W == Wo, (self.name(), out.C, c2, Cout_pad, out.H, Ho)
         if raw_weight is not None:
             wp, Kpad, Npad = raw_weight
             bp = None
@@ -339,6 +340,14 @@ class PlanBuilder:
             self.keep += [wp1, bp1]
             d.pre_weight, d.pre_bias = wp1.data_ptr(), (bp1.data_ptr() if b1 is not None else None)
             d.pre_Kpad, d.pre_Npad, d.pre_act = Kpad1, Npad1, act1
+        if post is not None:
+            w3, b3, act3, u = post
+            assert pre is not None and len(srcs) == 1 and tuple(w3.shape) == (2 * Cout, 2 * Cout, 1, 1) and u.C == Cout, (self.name(), tuple(w3.shape), u.C, Cout)
+            wp3, bp3, Kpad3, Npad3 = pack_conv_weight(w3, b3, self.code, self.device)
+            self.keep += [wp3, bp3]
+            d.in1 = u.c()
+            d.post_weight, d.post_bias = wp3.data_ptr(), (bp3.data_ptr() if b3 is not None else None)
+            d.post_Kpad, d.post_Npad, d.post_act = Kpad3, Npad3, act3
         det = None
         if detect is not None:
             det = YpDetectDesc()
@@ -351,7 +360,7 @@ class PlanBuilder:
         tuned_ms = None
         if tile == 0 and self.autotune and d.ksplit == 1 and not d.atomic_accumulate:
             d.tile, tuned_ms = self._autotune(d, det, (self.code, d.B, Hi, Wi, tuple((v.C, v.ups) for v in srcs), Cout_pad, R, S, sh, sw, dil, zs,
-                                                       int(out_f32), res is not None, c2, act, detect is not None, pre is not None))
+                                                       int(out_f32), res is not None, c2, act, detect is not None, pre is not None, post is not None))
         if extra.get("dry_run"):
             return tuned_ms
         if det is not None:
@@ -361,7 +370,7 @@ class PlanBuilder:
                         ([(detect["z_out"], detect["row_offset"], detect["row_offset"] + rows)] if detect["z_out"] is not None else []))
         else:
             check(lib().yp_plan_add_conv(self.handle, C.byref(d)))
-            self._track(list(srcs) + [res] + ([extra["weight_view"]] if "weight_view" in extra else []), [out, out2])
+            self._track(list(srcs) + [res] + ([extra["weight_view"]] if "weight_view" in extra else []) + ([post[3]] if post is not None else []), [out, out2])
         # algorithmic work: MAC*2 with the REAL channel counts (BASELINE.md section 2 convention)
         Kreal = Cin * R * (S * (2 if pair else 1))
         if thin:
@@ -374,6 +383,9 @@ class PlanBuilder:
         if pre is not None:       # the 1x1 of the fused Bottleneck: its algorithmic work (not the halo recompute) and its filter
             flops += 2 * M * Cin * Cin
             bytes_ += Cin * Cin * eb
+        if post is not None:      # the C3 tail: 1x1 over 2*Cout channels; reads the other branch, writes 2*Cout channels (counted in M * out.C above? no: add)
+            flops += 2 * M * (2 * Cout) * (2 * Cout)
+            bytes_ += (M * Cout + M * Cout + 4 * Cout * Cout) * eb
         self.records.append(OpRecord(self.name(), "conv", flops, bytes_, M, Cout, Kreal))
         return out
 
