@@ -609,6 +609,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvKArgs a) {
     const unsigned ldsW = lds0 + hbufs * HBYTES;
 
     // ---- tile decode (channel tiles fastest: neighbours share the input halo in L2)
+    YP_TL(0);
     int bid = yp_xcd_remap(blockIdx.x, gridDim.x);
     const int tn = bid % a.tiles_n; bid /= a.tiles_n;
     const int tx = bid % a.tiles_x; bid /= a.tiles_x;
@@ -642,6 +643,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvKArgs a) {
         const int iy = y0 * STRIDE - 1 + hy, ix = x0 * STRIDE - 1 + hx;
         valid = valid && (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi;
         hoff[i] = valid ? (unsigned)(((b * Hi + iy) * Wi + ix) * in0_cs * EB) + (unsigned)jl * 16u : in0_zoff;
+        // chunk 0's DMA leaves as soon as its offset exists: the rest of the setup overlaps the first round trip
+        yp_glds16_s(in0 + (size_t)in0_co * EB, hoff[i], lds0 + hslot[i] * 1024);
     }
     unsigned woff[NW];
     int wslot[NW];
@@ -688,8 +691,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvKArgs a) {
 
     const int nchunks = Cin / BK;
     const int nsteps = 3 * nchunks;
-    issueH(0);
-    issueW(0, 0);
+    YP_TL(1);
+    issueW(0, 0);        // (halo chunk 0 is already in flight; filter row 1 stays the youngest DMA, as the counted waits assume)
     issueW(0, 1);
     for (int c = 0; c < nchunks; ++c) {
 #pragma unroll
@@ -703,6 +706,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvKArgs a) {
             else if (moreW) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+            if (st < 30) YP_TL(2 + st);
             if (st + 2 < nsteps) { const int s2 = st + 2; issueW(s2 / 3, s2 % 3); }
             if (r == 0 && c + 1 < nchunks) issueH(c + 1);
             const char* hb = hsm + (c & 1) * HBYTES;
@@ -729,6 +733,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvKArgs a) {
         }
     }
 
+    YP_TL(40);
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm) {
         const int oy = y0 + wm * FM + fm, ox = x0 + p;
@@ -736,6 +741,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvKArgs a) {
         const int m = (b * a.Ho + oy) * a.Wo + ox;
         yp_epilogue_pixel<DT, OUT_F32, LPG>(a, m, nb, bias, [&](int cj) { return acc[cj >> 2][fm][cj & 3]; });
     }
+    YP_TL(41);
 }
 
 
