@@ -200,6 +200,8 @@ size_t yp_maxpool5_bwd_workspace_bytes(int B, int H, int W, int C);
 int yp_maxpool5_bwd(YpView x, YpView dy, YpView dx, int dtype, int B, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 /* backward of the descriptor L2 normalisation (models/YOLOPoint.py:219-220), fp32 views */
 int yp_l2norm_bwd_f32(YpView x, YpView g, YpView dx, int B, int C, void* stream);
+/* backward of MaxPool2d(2,2) (YOLOPointv52 descriptor branch, reference models/YOLOPoint.py:311): dx (+)= dy at the first maximum of each window */
+int yp_maxpool2_bwd(YpView x, YpView dy, YpView dx, int dtype, int B, int accumulate, void* stream);
 /* fp32 gradient of the permuted Detect output [B,na,ny,nx,no] -> NHWC view in `dtype` (inverse of models/yolo.py:53) */
 int yp_detect_bwd_pack(const float* gx, int B, int na, int no, YpView out, int dtype, void* stream);
 /* NHWC view (optionally through its 2x upsample) -> [C][H][W][Bpad] copy, batch zero-padded (wgrad operand layout) */
@@ -245,6 +247,7 @@ enum {
     YP_OP_CAST_F32 = 24,      /* v0=in (fp32) v1=out; i0=dtype i1=B */
     YP_OP_MAXPOOL2 = 25,      /* v0=x v1=y; i0=dtype i1=B */
     YP_OP_WGRAD = 27,         /* v0=x v1=dy; p0=dw; i0=dtype i1=B i2=k i3=stride */
+    YP_OP_MAXPOOL2_BWD = 29,  /* v0=x v1=dy v2=dx; i0=dtype i1=B i2=accumulate */
     YP_OP_WGRAD_UNPACK = 28,  /* p0=dw [Cj][k][k][Cout_pad] fp32 -> g0=grad OIHW [Cout][Cin][k][k] fp32, input-channel slice [c0, c0+creal):
                                * i1=Cout i2=Cin i3=k i4=c0 i5=creal i6=Cout_pad */
     YP_OP_PACK_WEIGHT = 26    /* f0=w f1=bias; g0=bias_dst; p0=dst; i0=dtype i1=Cout i2=Cin i3=R i4=S i5=c0 i6=Cj i7=mode; n0=Kpad n1=Npad | Cout_pad<<32 */

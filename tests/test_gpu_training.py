@@ -127,3 +127,63 @@ def test_train_step_with_precomputed_label_parts(cuda):
     assert grads[True][0].keys() == grads[False][0].keys() and len(grads[True][0]) > 100
     for n, g in grads[False][0].items():
         assert rel_err(grads[True][0][n], g)[1] < 2e-3, n
+
+
+@pytest.mark.parametrize("kp_only", [False, True])
+def test_v52_backward_matches_oracle_autograd(cuda, kp_only):
+    """YOLOPointv52 training path (C2f / Bottleneckv8 blocks, MaxPool2d descriptor branch, the 65-channel BN keypoint head with
+    padded BN parameters, descriptor normalisation differentiated in PyTorch) against CPU autograd through the oracle:
+    train-mode outputs, running statistics of the 65-channel BN, and every parameter gradient."""
+    m, sd = make_model("n", 41, dtype="f32", model_name="YOLOPointv52")
+    m = m.to(cuda).train()
+    x = net_oracle.synth_image(2, 3, 64, 64, 41)
+    g = torch.Generator().manual_seed(8)
+    leaf = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in sd.items()}
+    stats = {}
+    ref = net_oracle.yolopointv52_forward(leaf, x, "n", training=True, stats=stats)
+    proj = {"semi": torch.randn(ref["semi"].shape, generator=g), "desc": torch.randn(ref["desc"].shape, generator=g),
+            "objects": [torch.randn(t.shape, generator=g) for t in ref["objects"]]}
+
+    def loss_of(o, dev):
+        l = (o["semi"] * proj["semi"].to(dev)).sum() * 0.01 + (o["desc"] * proj["desc"].to(dev)).sum()
+        if not kp_only:
+            for t, p in zip(o["objects"], proj["objects"]):
+                l = l + (t * p.to(dev)).sum() * 0.01
+        return l
+    loss_of(ref, "cpu").backward()
+    out = m(x.to(cuda))
+    for k in ("semi", "desc"):
+        assert rel_err(out[k], ref[k])[0] < 1e-3, k
+    for t, r in zip(out["objects"], ref["objects"]):
+        assert rel_err(t, r)[0] < 1e-3
+    loss_of(out, cuda).backward()
+    reached = 0
+    for name, p in m.named_parameters():
+        gref = leaf[name].grad
+        if gref is None:
+            assert p.grad is None, name
+            continue
+        reached += 1
+        assert p.grad is not None, name
+        assert rel_err(p.grad, gref)[1] < 2e-3, name
+    assert reached > (60 if kp_only else 150)
+    sd2 = m.state_dict()
+    key = "model.BottleneckDet.cv2.bn.running_mean"          # the 65-channel BatchNorm (padded to 72 inside the plan)
+    if key in stats:
+        np.testing.assert_allclose(sd2[key].cpu().numpy(), stats[key].numpy(), rtol=2e-4, atol=1e-5)
+
+
+def test_v52_train_step_runs_in_bf16(cuda):
+    """One full optimizer step (both forwards, the three losses, backward, Adam) of YOLOPointv52 in the bf16 compute path."""
+    from yolopoint_amd.engine import TrainStep, synthetic_batch
+    m, _ = make_model("n", 9, dtype="bf16", model_name="YOLOPointv52")
+    m = m.to(cuda).train()
+    step = TrainStep(m, cuda, img_size=128)
+    step.sparse = dict(num_samples_per_image=100, num_masked_non_matches_per_match=20)
+    batch = synthetic_batch(2, 128, cuda, 5)
+    before = m.model.Conv2.conv.weight.detach().clone()
+    l0 = float(step(batch))
+    l1 = float(step(batch))
+    assert np.isfinite(l0) and np.isfinite(l1)
+    assert not torch.equal(before, m.model.Conv2.conv.weight.detach())
+    assert all(torch.isfinite(p).all() for p in m.parameters())

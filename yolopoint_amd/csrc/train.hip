@@ -835,6 +835,63 @@ extern "C" int yp_wgrad_unpack(const float* dw, float* grad, int Cout, int Cin, 
     return YP_OK;
 }
 
+// backward of MaxPool2d(2, 2): the gradient of an output pixel goes to the FIRST maximum of its 2x2 window (row-major scan, as
+// ATen); windows do not overlap, so every input element is written exactly once (dx (+)= dy or 0).
+template <int DT>
+__global__ void maxpool2_bwd_kernel(const char* __restrict__ x, int xcs, int xco, const char* __restrict__ dy, int dcs, int dco, char* __restrict__ dx,
+                                    int gcs, int gco, int B, int Ho, int Wo, int C, int accumulate) {
+    const int chunks = C / 8;
+    const size_t n = (size_t)B * Ho * Wo * chunks;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % chunks);
+        const size_t pix = i / chunks;
+        const int w = (int)(pix % Wo), h = (int)((pix / Wo) % Ho);
+        const size_t b = pix / ((size_t)Wo * Ho);
+        float g[8], v[4][8];
+        load8<DT>(dy, pix * dcs + dco + ch * 8, g);
+        size_t ip[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ip[q] = (b * 2 * Ho + 2 * h + (q >> 1)) * 2 * Wo + 2 * w + (q & 1);
+            load8<DT>(x, ip[q] * xcs + xco + ch * 8, v[q]);
+        }
+        int arg[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int a = 0;
+            float best = v[0][j];
+#pragma unroll
+            for (int q = 1; q < 4; ++q)
+                if (v[q][j] > best) { best = v[q][j]; a = q; }
+            arg[j] = a;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float o[8];
+            if (accumulate) load8<DT>(dx, ip[q] * gcs + gco + ch * 8, o);
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += arg[j] == q ? g[j] : 0.f;
+            store8<DT>(dx, ip[q] * gcs + gco + ch * 8, o);
+        }
+    }
+}
+
+extern "C" int yp_maxpool2_bwd(YpView x, YpView dy, YpView dx, int dtype, int B, int accumulate, void* stream) {
+    if (int rc = check_view8(x, "yp_maxpool2_bwd")) return rc;
+    if (int rc = check_view8(dy, "yp_maxpool2_bwd")) return rc;
+    if (int rc = check_view8(dx, "yp_maxpool2_bwd")) return rc;
+    YP_REQUIRE(x.C == dy.C && x.C == dx.C && x.H == 2 * dy.H && x.W == 2 * dy.W && dx.H == x.H && dx.W == x.W, "yp_maxpool2_bwd: dims mismatch");
+    const size_t n = (size_t)B * dy.H * dy.W * (x.C / 8);
+    YP_DT_SWITCH(dtype, (maxpool2_bwd_kernel<DT><<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>((const char*)x.ptr, x.cstride, x.coff, (const char*)dy.ptr, dy.cstride,
+                                                                                                   dy.coff, (char*)dx.ptr, dx.cstride, dx.coff, B, dy.H, dy.W, x.C, accumulate)));
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
 extern "C" int yp_run_op(const YpOpArgs* a, void* stream) {
     YP_REQUIRE(a != nullptr, "yp_run_op: null args");
     const int dt = a->i[0], B = a->i[1];
@@ -855,6 +912,7 @@ extern "C" int yp_run_op(const YpOpArgs* a, void* stream) {
         case YP_OP_SPPF_POOL: return yp_sppf_pool(a->v[0], a->v[1], a->v[2], a->v[3], B, dt, stream);
         case YP_OP_CAST_F32: return yp_cast_from_f32(a->v[0], a->v[1], dt, B, stream);
         case YP_OP_MAXPOOL2: return yp_maxpool2(a->v[0], a->v[1], B, dt, stream);
+        case YP_OP_MAXPOOL2_BWD: return yp_maxpool2_bwd(a->v[0], a->v[1], a->v[2], dt, B, a->i[2], stream);
         case YP_OP_WGRAD_UNPACK: return yp_wgrad_unpack((const float*)a->p[0], a->g[0], a->i[1], a->i[2], a->i[3], a->i[4], a->i[5], a->i[6], stream);
         case YP_OP_WGRAD: return yp_conv_wgrad(a->v[0], a->v[1], dt, B, a->i[2], a->i[3] > 0 ? a->i[3] : 1, (float*)a->p[0], stream);
         case YP_OP_PACK_WEIGHT:

@@ -99,7 +99,7 @@ class TrainStep:
                 det = m.model.Detect
                 shapes = [(B, det.na, img.shape[-2] // int(st), S // int(st), det.no) for st in det.stride]
                 tgt = self.obj_loss.build_targets(shapes, batch['box_labels'])
-                dch = m.model.ConvDesc.out_channels
+                dch = getattr(m.model, "_desc_channels", None) or m.model.ConvDesc.out_channels
                 nce = infonce_prepare(batch['warped_valid_mask'], batch['inv_homographies'], (B, dch, img.shape[-2] // 8, S // 8), True,
                                       self.sparse['num_samples_per_image'], self.sparse['num_masked_non_matches_per_match'], 8, dev)
                 _record_stream((tgt, nce), main)

@@ -188,8 +188,6 @@ class YOLOPoint(HipModule):
         if not (isinstance(x, torch.Tensor) and x.is_cuda):
             raise _hip.YpError("YOLOPoint.forward needs a cuda (HIP) tensor: the hot path has no CPU fallback")
         if self.training:
-            if isinstance(self, YOLOPointv52):
-                raise _hip.YpError("YOLOPointv52: the training path is built for YOLOPoint only (DESIGN.md section 7)")
             if any(not hasattr(m, "bn") for m in self.modules() if isinstance(m, Conv)):
                 raise _hip.YpError("a fused model (Model.fuse()) cannot run in train mode")
             from ..training import train_forward
@@ -285,8 +283,6 @@ class YOLOPointv52(YOLOPoint):
         pb.scope.pop()
         return {"semi": semi, "desc": desc, "z": z, "xs": xs}
 
-    def _train_graph(self, x):
-        raise _hip.YpError("YOLOPointv52: the training path is built for YOLOPoint only (DESIGN.md section 7)")
 
 
 class Model(nn.Module):

@@ -52,6 +52,7 @@ class TrainGraph:
         self.ws = torch.empty(wsb, dtype=torch.uint8, device=device)
         self.Bpad = round_up(B, 8)
         self._nbt = None
+        self.pre_forward, self.post_forward = [], []      # host callables around every forward (padded BN parameter copies)
         # every per-layer weight-gradient accumulator (fp32 [Cin][k][k][Cout_pad]) lives in one arena that the backward plan
         # clears with a single memset
         self.dw_arena = torch.zeros(2 * sum(p_.numel() for p_ in net.parameters()) + (1 << 20), dtype=torch.float32, device=device)
@@ -107,14 +108,31 @@ class TrainGraph:
         image = len(srcs) == 1 and srcs[0].geom is None and srcs[0].cstride == 4 and srcs[0].C == 4      # the stem keeps the host packer
         wsrc = (lambda: (conv.weight.detach().float(), None)) if image else MasterWeight(conv.weight)
         raw = f.conv(srcs, wsrc, None, k, s, p, _hip.YP_ACT_NONE)
-        Cc = conv.out_channels
-        mean, invstd = f.new_tensor((Cc,)), f.new_tensor((Cc,))
+        Cc, Cp = conv.out_channels, raw.C
+        mean, invstd = f.new_tensor((Cp,)), f.new_tensor((Cp,))
+        gamma, beta, rmean, rvar = bn.weight, bn.bias, bn.running_mean, bn.running_var
+        padded = Cp != Cc
+        if padded:
+            # the kernels walk the padded channel count (65 -> 72 for the v52 keypoint head): give them padded parameter /
+            # statistics tensors, synchronised with the module's around every pass (the padded channels are all-zero activations)
+            gamma, beta, rmean = (f.new_tensor((Cp,)) for _ in range(3))
+            rvar = torch.ones((Cp,), dtype=torch.float32, device=self.device)
+            f.keep.append(rvar)
+
+            def sync_in(gamma=gamma, beta=beta, rmean=rmean, rvar=rvar):
+                gamma[:Cc].copy_(bn.weight.detach()); beta[:Cc].copy_(bn.bias.detach())
+                rmean[:Cc].copy_(bn.running_mean); rvar[:Cc].copy_(bn.running_var)
+
+            def sync_out(rmean=rmean, rvar=rvar):
+                bn.running_mean.copy_(rmean[:Cc]); bn.running_var.copy_(rvar[:Cc])
+            self.pre_forward.append(sync_in)
+            self.post_forward.append(sync_out)
         f.op(_hip.OP_BN_STATS, [raw], [self.T(mean), self.T(invstd)], "bn_stats", v=[raw], i=[code, B], s=[bn.eps, bn.momentum],
-             g=[mean, invstd, bn.running_mean, bn.running_var], p=[self.ws], n=[self.ws.numel()])
+             g=[mean, invstd, rmean, rvar], p=[self.ws], n=[self.ws.numel()])
         if out is None:
             out = f.new_buf(raw.H, raw.W, raw.C).view()
         f.op(_hip.OP_BN_APPLY, [raw, res, self.T(mean), self.T(invstd)], [out], "bn_act", v=[raw, out, res], i=[code, B, act],
-             f=[mean, invstd, bn.weight, bn.bias])
+             f=[mean, invstd, gamma, beta])
 
         def backward():
             b = self.bwd
@@ -123,8 +141,12 @@ class TrainGraph:
                 gr, acc = self.gview(res)
                 b.op(_hip.OP_ADD_VIEWS, [gy, gr], [gr], "res_add", v=[gy, gr], i=[code, B, int(acc)])
             draw = b.new_buf(raw.H, raw.W, raw.C).view()
+            gw_, gb_ = self.pgrad(bn.weight), self.pgrad(bn.bias)
+            dg, db = (b.new_tensor((Cp,)), b.new_tensor((Cp,))) if padded else (gw_, gb_)
             b.op(_hip.OP_BN_BWD, [raw, gy], [draw], "bn_act_bwd", v=[raw, gy, draw], i=[code, B, act, 0],
-                 f=[mean, invstd, bn.weight, bn.bias], g=[self.pgrad(bn.weight), self.pgrad(bn.bias)], p=[self.ws], n=[self.ws.numel()])
+                 f=[mean, invstd, gamma, beta], g=[dg, db], p=[self.ws], n=[self.ws.numel()])
+            if padded:
+                self.collect.append(lambda dg=dg, db=db, gw_=gw_, gb_=gb_: (gw_.copy_(dg[:Cc]), gb_.copy_(db[:Cc])))
             self.conv_backward(srcs, conv.weight, None, draw, k, s, p)
         self.tape.append((self.branch, backward))
         return out
@@ -226,6 +248,31 @@ class TrainGraph:
         self.conv_bn_act(m.cv2, x, out=cat.view(c_, c_))
         return self.conv_bn_act(m.cv3, cat.view(), out=out)
 
+    def c2f(self, m, x, out=None):
+        """C2f (reference models/common.py:151-171): cv1 -> channels [0, 2c) of the concat buffer; Bottleneckv8 i (two 3x3
+        convs, optional shortcut) reads slice 1+i and writes slice 2+i; cv2 over the whole buffer."""
+        c, n = m.c, len(m.m)
+        x0 = x[0] if isinstance(x, (list, tuple)) else x
+        cat = self.fwd.new_buf(x0.LH, x0.LW, (2 + n) * c)
+        self.conv_bn_act(m.cv1, x, out=cat.view(0, 2 * c))
+        for i, blk in enumerate(m.m):
+            src = cat.view((1 + i) * c, c)
+            t = self.conv_bn_act(blk.cv1, src)
+            self.conv_bn_act(blk.cv2, t, out=cat.view((2 + i) * c, c), res=src if blk.add else None)
+        return self.conv_bn_act(m.cv2, cat.view(), out=out)
+
+    def maxpool2(self, x):
+        f, code, B = self.fwd, self.code, self.B
+        y = f.new_buf(x.LH // 2, x.LW // 2, x.C).view()
+        f.op(_hip.OP_MAXPOOL2, [x], [y], "maxpool2", v=[x, y], i=[code, B])
+
+        def backward():
+            gy = self.gread(y)
+            gx, acc = self.gview(x)
+            self.bwd.op(_hip.OP_MAXPOOL2_BWD, [x, gy, gx], [gx], "maxpool2_bwd", v=[x, gy, gx], i=[code, B, int(acc)])
+        self.tape.append((self.branch, backward))
+        return y
+
     def sppf(self, m, x):
         c_ = m.cv1.conv.out_channels
         f, code, B = self.fwd, self.code, self.B
@@ -247,52 +294,77 @@ class TrainGraph:
     def _build(self):
         net, f, b, B, code = self.net, self.fwd, self.bwd, self.B, self.code
         Hc, Wc = self.H // 8, self.W // 8
+        v52 = type(net).__name__ == "YOLOPointv52"
+        blk = self.c2f if v52 else self.c3
         self.img = f.new_buf(self.H, self.W, 4)
         x = self.conv_bn_act(net.Conv1, self.img.view())
         x = self.conv_bn_act(net.Conv2, x)
-        xa = self.c3(net.Bottleneck1, x)
+        xa = blk(net.Bottleneck1, x)
         x8 = self.conv_bn_act(net.Conv3, xa)
-        # keypoint head
-        t = self.c3(net.BottleneckDet, x8)
-        semi = self.conv_plain(net.ConvDet.weight, None, t, 1, 1, 0, "ConvDet")
+        # keypoint head: C3 + plain 1x1 conv (fp32) | v52: a 65-channel C2f whose BN + SiLU output IS semi
+        if v52:
+            semi = self.c2f(net.BottleneckDet, x8)
+        else:
+            t = self.c3(net.BottleneckDet, x8)
+            semi = self.conv_plain(net.ConvDet.weight, None, t, 1, 1, 0, "ConvDet")
         self.g_semi = torch.zeros((B, 65, Hc, Wc), dtype=torch.float32, device=self.device)
+        semi_code = _hip.YP_F32 if semi.buf.t.dtype == torch.float32 else code
 
         def semi_seed():
             gsemi_v, _ = self.gview(semi)
-            self.bwd.op(_hip.OP_PACK_NCHW, [self.T(self.g_semi)], [gsemi_v], "seed_semi", f=[self.g_semi], v=[gsemi_v], i=[_hip.YP_F32, B, 65])
-        xb = self.c3(net.Bottleneck2, x8)
+            self.bwd.op(_hip.OP_PACK_NCHW, [self.T(self.g_semi)], [gsemi_v], "seed_semi", f=[self.g_semi], v=[gsemi_v], i=[semi_code, B, 65])
+        xb = blk(net.Bottleneck2, x8)
         # descriptor head
-        dA = self.conv_bn_act(net.ConvDescA, xa)
-        dB = self.conv_bn_act(net.ConvDescB, xb)
-        d = self.c3(net.BottleneckDesc, [dA, dB.up()])
-        craw = self.conv_plain(net.ConvDesc.weight, None, d, 3, 1, 1, "ConvDesc")
-        c3ch = net.ConvDesc.out_channels
-        dnorm = f.new_buf(Hc, Wc, craw.C, f32=True).view()
-        f.op(_hip.OP_L2NORM, [craw], [dnorm], "l2norm", v=[craw, dnorm], i=[0, B, c3ch])
-        self.g_desc = torch.zeros((B, c3ch, Hc, Wc), dtype=torch.float32, device=self.device)
-        gd = Buf(B, Hc, Wc, craw.C, torch.float32, self.device)
-        self.keep.append(gd.flat)
+        if v52:
+            # MaxPool(xa) ++ up(ConvDescB(xb)) -> C2f; the L2 normalisation is applied (and differentiated) by the caller in PyTorch
+            dA = self.maxpool2(xa)
+            dB = self.conv_bn_act(net.ConvDescB, xb)
+            craw = self.c2f(net.BottleneckDesc, [dA, dB.up()])
+            c3ch = net._desc_channels
+            self.g_desc = torch.zeros((B, c3ch, Hc, Wc), dtype=torch.float32, device=self.device)
+            dnorm = craw
 
-        def desc_seed():
-            b = self.bwd
-            gcraw, _ = self.gview(craw)
-            b.op(_hip.OP_PACK_NCHW, [self.T(self.g_desc)], [gd.view()], "seed_desc", f=[self.g_desc], v=[gd.view()], i=[_hip.YP_F32, B, c3ch])
-            b.op(_hip.OP_L2NORM_BWD, [craw, gd.view()], [gcraw], "l2norm_bwd", v=[craw, gd.view(), gcraw], i=[0, B, c3ch])
+            def desc_seed():
+                gcraw, _ = self.gview(craw)
+                self.bwd.op(_hip.OP_PACK_NCHW, [self.T(self.g_desc)], [gcraw], "seed_desc", f=[self.g_desc], v=[gcraw], i=[code, B, c3ch])
+        else:
+            dA = self.conv_bn_act(net.ConvDescA, xa)
+            dB = self.conv_bn_act(net.ConvDescB, xb)
+            d = self.c3(net.BottleneckDesc, [dA, dB.up()])
+            craw = self.conv_plain(net.ConvDesc.weight, None, d, 3, 1, 1, "ConvDesc")
+            c3ch = net.ConvDesc.out_channels
+            dnorm = f.new_buf(Hc, Wc, craw.C, f32=True).view()
+            f.op(_hip.OP_L2NORM, [craw], [dnorm], "l2norm", v=[craw, dnorm], i=[0, B, c3ch])
+            self.g_desc = torch.zeros((B, c3ch, Hc, Wc), dtype=torch.float32, device=self.device)
+            gd = Buf(B, Hc, Wc, craw.C, torch.float32, self.device)
+            self.keep.append(gd.flat)
+
+            def desc_seed():
+                b = self.bwd
+                gcraw, _ = self.gview(craw)
+                b.op(_hip.OP_PACK_NCHW, [self.T(self.g_desc)], [gd.view()], "seed_desc", f=[self.g_desc], v=[gd.view()], i=[_hip.YP_F32, B, c3ch])
+                b.op(_hip.OP_L2NORM_BWD, [craw, gd.view()], [gcraw], "l2norm_bwd", v=[craw, gd.view(), gcraw], i=[0, B, c3ch])
+        self.desc_channels = c3ch
         # YOLO encoder + PAN: nothing below feeds semi / desc
         self.branch = "yolo"
         x = self.conv_bn_act(net.Conv4, xb)
-        xc = self.c3(net.Bottleneck3, x)
+        xc = blk(net.Bottleneck3, x)
         x = self.conv_bn_act(net.Conv5, xc)
-        x = self.c3(net.Bottleneck4, x)
+        x = blk(net.Bottleneck4, x)
         x = self.sppf(net.SPPooling, x)
-        xd = self.conv_bn_act(net.Conv6, x)
-        x = self.c3(net.Bottleneck5, [xd.up(), xc])
-        xe = self.conv_bn_act(net.Conv7, x)
-        xf = self.c3(net.Bottleneck6, [xe.up(), xb])
+        if v52:
+            xd = x
+            xe = blk(net.Bottleneck5, [xd.up(), xc])
+            xf = blk(net.Bottleneck6, [xe.up(), xb])
+        else:
+            xd = self.conv_bn_act(net.Conv6, x)
+            x = self.c3(net.Bottleneck5, [xd.up(), xc])
+            xe = self.conv_bn_act(net.Conv7, x)
+            xf = self.c3(net.Bottleneck6, [xe.up(), xb])
         x = self.conv_bn_act(net.Conv8, xf)
-        xg = self.c3(net.Bottleneck7, [x, xe])
+        xg = blk(net.Bottleneck7, [x, xe])
         x = self.conv_bn_act(net.Conv9, xg)
-        p5 = self.c3(net.Bottleneck8, [x, xd])
+        p5 = blk(net.Bottleneck8, [x, xd])
         # Detect (train mode: permuted raw logits only)
         det = net.Detect
         self.xs, self.g_xs = [], []
@@ -359,16 +431,24 @@ class TrainGraph:
         if (ver, nops) != self.pack["version"]:                 # device-packed filters shared by all graphs
             check(lib().yp_plan_run(self.pack["pb"].handle, _hip.stream_ptr()))
             self.pack["version"] = (ver, nops)
+        for fn in self.pre_forward:
+            fn()
         pack_input(x, self.img.view(), self.code)
         self.fwd_plan.run()
+        for fn in self.post_forward:
+            fn()
         if self._nbt is None:
             self._nbt = [m.num_batches_tracked for m in self.net.modules()
                          if isinstance(m, torch.nn.BatchNorm2d) and m.num_batches_tracked is not None]
         if self._nbt:
             torch._foreach_add_(self._nbt, 1)          # one launch for all BatchNorm counters
-        c3ch = self.net.ConvDesc.out_channels
-        semi = self.semi_v.buf.t[..., :65].permute(0, 3, 1, 2).clone()
-        desc = self.desc_v.buf.t[..., :c3ch].permute(0, 3, 1, 2).clone()
+        c3ch = self.desc_channels
+        semi = self.semi_v.buf.t[..., :65].permute(0, 3, 1, 2).float()      # (a copy: fp32 heads are cloned, 16-bit ones converted)
+        desc = self.desc_v.buf.t[..., :c3ch].permute(0, 3, 1, 2).float()
+        if semi.data_ptr() == self.semi_v.buf.t.data_ptr():
+            semi = semi.clone()
+        if desc.data_ptr() == self.desc_v.buf.t.data_ptr():
+            desc = desc.clone()
         return semi, desc, [t.clone() for t in self.xs]
 
     def backward(self, g_semi, g_desc, g_xs):
@@ -426,4 +506,7 @@ def train_forward(net, x):
     """Train-mode forward of a YOLOPoint module through the native plans, differentiable w.r.t. its parameters."""
     params = list(net.parameters())
     outs = _YOLOPointTrainFn.apply(net, x, *params)
-    return {'semi': outs[0], 'desc': outs[1], 'objects': list(outs[2:])}
+    desc = outs[1]
+    if type(net).__name__ == "YOLOPointv52":          # reference models/YOLOPoint.py:318-319; YOLOPoint normalises inside the plan
+        desc = desc.div(torch.unsqueeze(torch.norm(desc, p=2, dim=1), 1))
+    return {'semi': outs[0], 'desc': desc, 'objects': list(outs[2:])}
