@@ -10,7 +10,8 @@ Bucketing: parameters are packed in REVERSE registration order (descriptor/keypo
 first, Conv1 last = the order in which the backward plan finishes their gradients) into few large flat
 fp32 buffers (default 32 MB: YOLOPoint-s is one bucket of 30.6 MB, -l seven) so that each collective is
 bandwidth- rather than latency-bound on the 7-link xGMI mesh.  `all_reduce()` launches every bucket
-asynchronously, then waits and scatters the averaged values back into `p.grad`.
+asynchronously, then waits and scales.  With `bind_grads()` (what TrainStep uses) the parameters' .grad ARE views of the
+buckets, so a step moves no gradient bytes other than the collective itself; without it the gradients are copied in and out.
 """
 import torch
 import torch.distributed as dist
@@ -21,6 +22,7 @@ class GradAllReducer:
         self.group = group
         self.params = [p for p in params if p.requires_grad]
         self.buckets = []                       # list of (flat fp32 buffer, [(param, offset, numel)])
+        self._views = None
         cur, size = [], 0
         for p in reversed(self.params):
             n = p.numel()
@@ -47,22 +49,43 @@ class GradAllReducer:
         for p in module.parameters():
             dist.broadcast(p.data, src=src, group=self.group)
 
+    def bind_grads(self):
+        """Zero-copy mode: every p.grad becomes a view into its bucket (all fp32 parameters), the buckets are cleared with one
+        launch each, backward passes ACCUMULATE into them and all_reduce() reduces them in place -- no per-parameter copies.
+        Call instead of optimizer.zero_grad() at the start of a step."""
+        if self._views is None:
+            self._views = [[flat[off:off + n].view_as(p) for p, off, n in entries] for flat, entries in self.buckets]
+        for (flat, entries), views in zip(self.buckets, self._views):
+            flat.zero_()
+            for (p, _, _), v in zip(entries, views):
+                if p.grad is not v:
+                    p.grad = v
+
+    def _bound(self, entries, views):
+        return views is not None and all(p.grad is v for (p, _, _), v in zip(entries, views))
+
     def all_reduce(self):
         """Average p.grad over the ranks (missing gradients count as zeros)."""
         if self.world == 1:
             return
-        works = []
-        for flat, entries in self.buckets:
-            for p, off, n in entries:
-                if p.grad is None:
-                    flat[off:off + n].zero_()
-                else:
-                    flat[off:off + n].copy_(p.grad.reshape(-1))
+        works, bound = [], []
+        for i, (flat, entries) in enumerate(self.buckets):
+            is_bound = self._bound(entries, self._views[i] if self._views else None)
+            bound.append(is_bound)
+            if not is_bound:
+                have = [(p, off, n) for p, off, n in entries if p.grad is not None]
+                for p, off, n in entries:
+                    if p.grad is None:
+                        flat[off:off + n].zero_()
+                if have:
+                    torch._foreach_copy_([flat[off:off + n] for _, off, n in have], [p.grad.reshape(-1) for p, _, _ in have])
             works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         inv = 1.0 / self.world
-        for (flat, entries), w in zip(self.buckets, works):
+        for (flat, entries), w, is_bound in zip(self.buckets, works, bound):
             w.wait()
             flat.mul_(inv)
+            if is_bound:
+                continue
             for p, off, n in entries:
                 g = flat[off:off + n].view_as(p)
                 if p.grad is None:

@@ -83,7 +83,7 @@ class TrainStep:
         object-loss backward is differentiated -- the step is device-bound, the extra autograd entry points cost more than the
         overlap wins: 40-48 ms vs 38 ms per step.)"""
         m, dev = self.model, self.device
-        self.opt.zero_grad(set_to_none=True)
+        self.reducer.bind_grads()          # (instead of optimizer.zero_grad: gradients accumulate straight into the all-reduce buckets)
         img = batch['image']
         B, S = img.shape[0], img.shape[-1]
         # both forwards are launched first ...
