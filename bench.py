@@ -260,6 +260,9 @@ def bench_train(a, rank, world, dev):
     if rank != 0:
         return
     samples = a.batch * world * steps
+    # conv FLOP the reference executes per training sample (pair) = 4 F_fwd + 2 F_kp at 640x640
+    gflop_sample = {"n": 27.77, "s": 103.28, "m": 299.67, "l": 657.56}.get(a.version, 0.0) * (a.size / 640.0) ** 2
+    achieved = gflop_sample * samples / wall / 1e3 / max(world, 1)          # TFLOP/s per GPU
     print(json.dumps({
         "metric": f"images/sec at {a.size}x{a.size} (YOLOPoint-{a.version} training, {a.batch} samples/GPU, {dtype}); an image pair counts as 2 images",
         "value": round(2 * samples / wall, 1), "unit": "images/s", "samples_per_s": round(samples / wall, 1), "n_gpus": world, "steps": steps,
@@ -268,7 +271,10 @@ def bench_train(a, rank, world, dev):
         "config": {"workload": f"BASELINE.json configs[2] shape: YOLOPoint-{a.version} optimizer step as src/train.py:189-259 (2 forwards, detector + object + "
                                f"InfoNCE losses in PyTorch autograd, native backward, gradient all-reduce, Adam), {a.batch} samples/GPU, {a.size}x{a.size}",
                    "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
-                   "grad_allreduce_bytes": step.reducer.payload_bytes()}}), flush=True)
+                   "grad_allreduce_bytes": step.reducer.payload_bytes()},
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS["bf16"], 4),
+                     "traffic": None, "per_gpu": True, "algorithmic_gflop_per_sample": round(gflop_sample, 2),
+                     "note": "whole step (losses, BN / elementwise passes, optimizer included) against the conv FLOP the reference executes per sample"}}), flush=True)
 
 
 def bench_frame(a, dev):
