@@ -227,6 +227,17 @@ int yp_wgrad_unpack(const float* dw, float* grad, int Cout, int Cin, int k, int 
 int yp_pack_weight(const float* w, int Cout, int Cin, int R, int S, int c0, int Cj, int mode, int Cout_pad, void* dst, int Kpad,
                    int Npad, int dtype, const float* bias, float* bias_dst, void* stream);
 
+/* InfoNCE descriptor loss (reference utils/loss_functions.py:484-597) without the gathered-negatives / Gram-matrix tensors.
+ *   da, db [n][D] fp32 (D a multiple of 64, <= 256): sampled descriptors of the image / the warped image
+ *   idx [n][E] int32: column 0 = the row itself (the match), columns 1.. = the sampled negatives (rows of db); E <= 512
+ *   forward:  logits[i][j] = <da[i], db[idx[i][j]]> * inv_tau,  loss_rows[i] = logsumexp_j logits[i][j] - logits[i][0]
+ *   backward: with the upstream gradient of mean(loss_rows) folded into *grad_scale_dev (= g * inv_tau / n, device scalar):
+ *             dda, ddb [n][D]; `order` / `offsets` are the edge list (edge = i*E + j) sorted by idx value and its CSR offsets
+ *             [n+1] (built once with the sampling); w_scratch [n][E] fp32. */
+int yp_infonce_fwd(const float* da, const float* db, const int* idx, int n, int E, int D, float inv_tau, float* logits, float* loss_rows, void* stream);
+int yp_infonce_bwd(const float* da, const float* db, const int* idx, const int* order, const int* offsets, const float* logits, int n, int E, int D,
+                   const float* grad_scale_dev, float* w_scratch, float* dda, float* ddb, void* stream);
+
 /* One generic launch record: `op` selects one of the functions above, the slots carry its arguments in the
  * order documented next to each opcode.  Lets training plans replay any mix of launches (yp_plan_add_op). */
 enum {

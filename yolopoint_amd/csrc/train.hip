@@ -892,6 +892,10 @@ extern "C" int yp_maxpool2_bwd(YpView x, YpView dy, YpView dx, int dtype, int B,
     return YP_OK;
 }
 
+__global__ void zero_fill_kernel(f32x4* __restrict__ p, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
 extern "C" int yp_run_op(const YpOpArgs* a, void* stream) {
     YP_REQUIRE(a != nullptr, "yp_run_op: null args");
     const int dt = a->i[0], B = a->i[1];
@@ -906,7 +910,15 @@ extern "C" int yp_run_op(const YpOpArgs* a, void* stream) {
         case YP_OP_DETECT_BWD_PACK: return yp_detect_bwd_pack(a->f[0], B, a->i[2], a->i[3], a->v[0], dt, stream);
         case YP_OP_TO_CHWB: return yp_to_chwb(a->v[0], dt, B, a->i[2], a->p[0], a->i[3], stream);
         case YP_OP_COL_SUM: return yp_col_sum(a->v[0], dt, B, a->g[0], a->i[2], a->p[0], a->n[0], stream);
-        case YP_OP_MEMSET0: YP_CHECK_HIP(hipMemsetAsync(a->p[0], 0, a->n[0], (hipStream_t)stream)); return YP_OK;
+        case YP_OP_MEMSET0: {
+            // a zero-fill KERNEL, not hipMemsetAsync: captured into a hipGraph, the memset node did not stay ordered with the kernel
+            // nodes around it when backward graphs were replayed back to back (weight gradients came out inf / huge; tools/probe)
+            YP_REQUIRE(a->p[0] != nullptr && a->n[0] % 16 == 0 && ((size_t)a->p[0]) % 16 == 0, "YP_OP_MEMSET0: 16-byte aligned pointer and size");
+            const size_t n16 = a->n[0] / 16;
+            zero_fill_kernel<<<grid_for(n16, 256, 2048), 256, 0, (hipStream_t)stream>>>((f32x4*)a->p[0], n16);
+            YP_CHECK_HIP(hipGetLastError());
+            return YP_OK;
+        }
         case YP_OP_PACK_NCHW: return yp_pack_input(a->f[0], B, a->i[2], a->v[0].H, a->v[0].W, a->v[0], dt, stream);
         case YP_OP_L2NORM: return yp_l2norm_f32(a->v[0], a->v[1], B, a->i[2], stream);
         case YP_OP_SPPF_POOL: return yp_sppf_pool(a->v[0], a->v[1], a->v[2], a->v[3], B, dt, stream);

@@ -7,6 +7,8 @@
 Forward/backward of the network run through the native plans (yolopoint_amd/training.py); the losses are PyTorch
 autograd; Adam is torch.optim.Adam (train.py:88).  Data: SURVEY.md 8(d) synthetic recipe, generated on the device.
 """
+import os
+
 import torch
 
 from .utils.loss_functions import ComputeDetectorLoss, ComputeObjectLoss, infonce, infonce_prepare
@@ -66,7 +68,7 @@ class TrainStep:
         self.opt = torch.optim.Adam(model.parameters(), lr=lr)
         self.reducer = GradAllReducer(model.parameters(), group=group)
         self.sparse = dict(SPARSE)
-        self.side_stream = torch.cuda.Stream(device=device)
+        self.side_stream = torch.cuda.Stream(device=device) if os.environ.get("YP_TRAIN_SIDE_STREAM") == "1" else None
         self.reducer.broadcast_parameters(model)
 
     def __call__(self, batch):
@@ -78,23 +80,25 @@ class TrainStep:
     def loss_and_grads(self, batch, prepare=True):
         """loss = (det + det_warp) + lambda_desc * infonce + lambda_obj * obj and its backward (reference train.py:208-245).
         With `prepare`, the label-only, host-synchronising parts of the losses (YOLO target assignment, InfoNCE sampling)
-        run on a side stream right after both forward passes have been launched: the host never waits for the forwards,
-        and nothing after them synchronises until the optimizer step.  (Measured and dropped: a two-stage backward that launches the warped pass's native backward before the
+        run right after both forward passes have been launched, and nothing after them synchronises until the optimizer step.
+        (Measured and dropped: a two-stage backward that launches the warped pass's native backward before the
         object-loss backward is differentiated -- the step is device-bound, the extra autograd entry points cost more than the
         overlap wins: 40-48 ms vs 38 ms per step.)"""
         m, dev = self.model, self.device
         self.reducer.bind_grads()          # (instead of optimizer.zero_grad: gradients accumulate straight into the all-reduce buckets)
         img = batch['image']
         B, S = img.shape[0], img.shape[-1]
-        # both forwards are launched first ...
+        # both forwards are launched first; the label-only parts then run while the device works through them (their host syncs --
+        # boolean-mask indexing, .item() -- wait for the forwards, which the device has to finish anyway).  YP_TRAIN_SIDE_STREAM=1
+        # runs them on a side stream instead (no host wait for the forwards): measured no faster once the step is device-bound.
         outs = m(img)
         outs_w = m(batch['warped_image'])
-        # ... then the label-only parts run on a side stream: their host syncs (boolean-mask indexing, .item()) wait for that
-        # stream's few small kernels only, while the device works through the forwards
         tgt = nce = None
         if prepare:
             main = torch.cuda.current_stream(dev)
-            side = self.side_stream
+            side = self.side_stream if self.side_stream is not None else main
+            if side is not main:
+                side.wait_stream(main)          # (the forwards are queued ahead of this point; the side stream only overlaps with them)
             with torch.cuda.stream(side):
                 det = m.model.Detect
                 shapes = [(B, det.na, img.shape[-2] // int(st), S // int(st), det.no) for st in det.stride]
@@ -102,8 +106,10 @@ class TrainStep:
                 dch = getattr(m.model, "_desc_channels", None) or m.model.ConvDesc.out_channels
                 nce = infonce_prepare(batch['warped_valid_mask'], batch['inv_homographies'], (B, dch, img.shape[-2] // 8, S // 8), True,
                                       self.sparse['num_samples_per_image'], self.sparse['num_masked_non_matches_per_match'], 8, dev)
-                _record_stream((tgt, nce), main)
-            main.wait_stream(side)
+                if side is not main:
+                    _record_stream((tgt, nce), main)
+            if side is not main:
+                main.wait_stream(side)
         l_obj = self.obj_loss(outs['objects'], batch['box_labels'], prepared=tgt)[0]
         l_det = self.det_loss(outs['semi'], labels2Dto3D(batch['labels_2D']), getMasks(batch['valid_mask'], dev))
         l_det_w = self.det_loss(outs_w['semi'], labels2Dto3D(batch['warped_labels']), getMasks(batch['warped_valid_mask'], dev))

@@ -18,6 +18,7 @@ master parameters before every forward (`refresh`).
 """
 import ctypes as C
 import os
+import weakref
 
 import torch
 
@@ -55,7 +56,7 @@ class TrainGraph:
         self.pre_forward, self.post_forward = [], []      # host callables around every forward (padded BN parameter copies)
         # every per-layer weight-gradient accumulator (fp32 [Cin][k][k][Cout_pad]) lives in one arena that the backward plan
         # clears with a single memset
-        self.dw_arena = torch.zeros(2 * sum(p_.numel() for p_ in net.parameters()) + (1 << 20), dtype=torch.float32, device=device)
+        self.dw_arena = torch.zeros(round_up(2 * sum(p_.numel() for p_ in net.parameters()) + (1 << 20), 64), dtype=torch.float32, device=device)
         self.dw_used = 0
         self._build()
 
@@ -413,9 +414,12 @@ class TrainGraph:
             return plan, self.touched, self.collect
         self.bwd_plan, self.bwd_params, self.bwd_collect = emit(False)
         self.bwd_kp_plan, self.bwd_kp_params, self.bwd_kp_collect = emit(True)
-        if os.environ.get("YP_TRAIN_GRAPH", "1") != "0":      # replay the launch lists as hipGraphs (284 / 455 / 230 launches)
-            for plan in (self.fwd_plan, self.bwd_plan, self.bwd_kp_plan):
-                plan.instantiate_graph()
+        mode = os.environ.get("YP_TRAIN_GRAPH", "1")         # replay the launch lists as hipGraphs (284 / 455 / 230 launches)
+        if mode in ("1", "fwd"):
+            self.fwd_plan.instantiate_graph()
+        if mode in ("1", "bwd"):
+            self.bwd_plan.instantiate_graph()
+            self.bwd_kp_plan.instantiate_graph()
         self.params = [p_ for p_ in net.parameters()]
 
     # ------------------------------------------------------------------ run
@@ -466,6 +470,10 @@ class TrainGraph:
         return [self.pgrads[p_] if p_ in touched else None for p_ in self.params]
 
 
+def _release(g):
+    g.busy = False
+
+
 class _YOLOPointTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, x, *params):
@@ -475,6 +483,8 @@ class _YOLOPointTrainFn(torch.autograd.Function):
         semi, desc, xs = g.forward(x)
         if torch.is_grad_enabled() or any(p.requires_grad for p in params):
             g.busy = True
+            # a forward whose graph is dropped without a backward (e.g. a train-mode evaluation pass) must give its plans back
+            weakref.finalize(ctx, _release, g)
         return (semi, desc, *xs)
 
     @staticmethod
