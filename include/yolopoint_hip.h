@@ -238,6 +238,17 @@ int yp_infonce_fwd(const float* da, const float* db, const int* idx, int n, int 
 int yp_infonce_bwd(const float* da, const float* db, const int* idx, const int* order, const int* offsets, const float* logits, int n, int E, int D,
                    const float* grad_scale_dev, float* w_scratch, float* dda, float* ddb, void* stream);
 
+/* YOLOv5 object loss of ONE Detect level, value and gradient (reference utils/loss_functions.py:90-176 ComputeLoss.__call__ body
+ * of the per-level loop; CIoU: utils/metrics_yolo.py:202-240).  p / dp: [cells, no] fp32 with cells = B*na*ny*nx and no = 5 + nc;
+ * the n (target, cell) entries of the level (reference build_targets, :178-234) arrive flattened: cell[e] = ((b*na+a)*ny+gj)*nx+gi,
+ * tbox[e] = (dx, dy, w, h) in grid units, anch[e] = the anchor (w, h), tcls[e] = class.  w_box / w_obj / w_cls = hyp gain (x level
+ * balance for obj).  Adds the weighted box / obj / cls terms to sums[0..2] (device, caller-zeroed) and writes d(sum)/dp to dp.
+ * tobj follows index_put semantics on duplicates: the entry with the highest index owns the cell.
+ * iou_scratch: n floats; owner_scratch: cells ints. */
+int yp_objloss_level(const float* p, int cells, int no, int nc, const int* cell, const float* tbox, const float* anch, const int* tcls, int n, float cp,
+                     float cn, float cls_pw, float obj_pw, float w_box, float w_obj, float w_cls, float* iou_scratch, int* owner_scratch, float* dp,
+                     float* sums, void* stream);
+
 /* One generic launch record: `op` selects one of the functions above, the slots carry its arguments in the
  * order documented next to each opcode.  Lets training plans replay any mix of launches (yp_plan_add_op). */
 enum {

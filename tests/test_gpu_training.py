@@ -212,6 +212,52 @@ def test_native_infonce_matches_torch_formulation(cuda, n, negs, D):
     assert rel_err(da.grad, ga)[1] < 1e-5 and rel_err(db.grad, gb)[1] < 1e-5
 
 
+class _DetStub:
+    def __init__(self, nc, dev):
+        self.na, self.nc, self.nl, self.no = 3, nc, 3, nc + 5
+        self.stride = torch.tensor([8., 16., 32.])
+        a = torch.tensor([[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]], dtype=torch.float32)
+        self.anchors = (a.view(3, 3, 2) / self.stride.view(-1, 1, 1)).to(dev)
+
+
+class _NetStub(torch.nn.Module):
+    def __init__(self, nc, dev):
+        super().__init__()
+        self.model = type("M", (), {})()
+        self.model.Detect = _DetStub(nc, dev)
+
+
+@pytest.mark.parametrize("nc,B,S,nt", [(1, 4, 256, 40), (3, 2, 128, 25), (80, 2, 64, 9), (1, 2, 96, 0)])
+def test_native_object_loss_matches_torch_formulation(cuda, nc, B, S, nt):
+    """csrc/losses.hip (yp_objloss_level: CIoU + objectness + class BCE, value and gradient) against the PyTorch formulation
+    of ComputeObjectLoss (reference utils/loss_functions.py:90-234) evaluated on the CPU on the same logits and targets --
+    duplicated cell claims included (the CPU index_put is sequential: last entry wins, which the kernel reproduces)."""
+    from yolopoint_amd.utils.loss_functions import ComputeObjectLoss
+    hyp = dict(cls_pw=0.7, obj_pw=1.3, fl_gamma=0.0, label_smoothing=0.1, anchor_t=4.0, box=0.05, obj=1.0, cls=0.5)
+    g = torch.Generator().manual_seed(nc * 100 + nt)
+    tg = torch.rand(nt, 6, generator=g)
+    if nt:
+        tg[:, 0] = torch.randint(0, B, (nt,), generator=g).float()
+        tg[:, 1] = torch.randint(0, nc, (nt,), generator=g).float()
+        tg[:, 2:4] = tg[:, 2:4] * 0.9 + 0.05
+        tg[:, 4:6] = tg[:, 4:6] * 0.3 + 0.02
+        tg[nt // 2:nt // 2 + 3] = tg[0]                      # exact duplicates: the same cells are claimed several times
+        tg[nt // 2, 4:6] *= 1.1
+    ps = [(torch.randn(B, 3, S // s, S // s, nc + 5, generator=g) * 1.5) for s in (8, 16, 32)]
+    res = {}
+    for dev in ("cpu", cuda):
+        crit = ComputeObjectLoss(_NetStub(nc, dev), hyp, dev)
+        p = [t.clone().to(dev).requires_grad_() for t in ps]
+        loss, items = crit(p, tg.to(dev))
+        (loss * 2.5).backward()
+        res[str(dev)] = (loss.detach().cpu(), items.cpu(), [t.grad.cpu() for t in p])
+    (l0, i0, g0), (l1, i1, g1) = res["cpu"], res[str(cuda)]
+    assert l1.shape == l0.shape and i1.shape == i0.shape
+    assert torch.allclose(l1, l0, rtol=2e-5, atol=1e-6) and torch.allclose(i1, i0, rtol=2e-5, atol=1e-6)
+    for a, b in zip(g1, g0):
+        assert rel_err(a, b)[1] < 2e-5
+
+
 def test_train_forward_without_backward_releases_its_plans(cuda):
     """Train-mode forwards whose autograd graph is dropped (no backward) must not exhaust the pool of 4 plan sets."""
     m, _ = make_model("n", 2, dtype="f32")

@@ -154,6 +154,140 @@ __global__ __launch_bounds__(256) void infonce_bwd_b_kernel(const float* __restr
     for (int q = 0; q < VPL; ++q) o[q] = acc[q];
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// YOLOv5 object loss of one Detect level (reference utils/loss_functions.py:90-176, `ComputeObjectLoss.__call__`; CIoU:
+// utils/metrics_yolo.py:202-240), value AND gradient in three launches instead of ~330 tiny PyTorch kernels per level:
+//   objloss_init    dp = 0, owner = -1
+//   objloss_targets one thread per (target, cell) entry: decode the box, CIoU against the target box with forward-mode dual
+//                   numbers (4 inputs), class BCE; gradients are atomically added to dp (a cell can be claimed twice), the
+//                   clamped IoU is kept per entry and the LAST entry of a cell becomes its owner (index_put semantics)
+//   objloss_cells   one thread per cell: objectness BCE against tobj = IoU of the owner (0 without), gradient into channel 4
+// sums[0..2] accumulate the weighted box / obj / cls terms (weights = hyp gain x level balance, folded on the host).
+// ---------------------------------------------------------------------------------------------------------------------------
+struct Dual {
+    float v, d[4];
+};
+__device__ __forceinline__ Dual dconst(float c) { return Dual{c, {0.f, 0.f, 0.f, 0.f}}; }
+__device__ __forceinline__ Dual operator+(const Dual& a, const Dual& b) { return Dual{a.v + b.v, {a.d[0] + b.d[0], a.d[1] + b.d[1], a.d[2] + b.d[2], a.d[3] + b.d[3]}}; }
+__device__ __forceinline__ Dual operator-(const Dual& a, const Dual& b) { return Dual{a.v - b.v, {a.d[0] - b.d[0], a.d[1] - b.d[1], a.d[2] - b.d[2], a.d[3] - b.d[3]}}; }
+__device__ __forceinline__ Dual operator*(const Dual& a, const Dual& b) {
+    return Dual{a.v * b.v, {a.d[0] * b.v + a.v * b.d[0], a.d[1] * b.v + a.v * b.d[1], a.d[2] * b.v + a.v * b.d[2], a.d[3] * b.v + a.v * b.d[3]}};
+}
+__device__ __forceinline__ Dual operator*(const Dual& a, float c) { return Dual{a.v * c, {a.d[0] * c, a.d[1] * c, a.d[2] * c, a.d[3] * c}}; }
+__device__ __forceinline__ Dual operator+(const Dual& a, float c) { return Dual{a.v + c, {a.d[0], a.d[1], a.d[2], a.d[3]}}; }
+__device__ __forceinline__ Dual operator/(const Dual& a, const Dual& b) {
+    const float r = 1.0f / b.v, q = a.v * r;
+    return Dual{q, {(a.d[0] - q * b.d[0]) * r, (a.d[1] - q * b.d[1]) * r, (a.d[2] - q * b.d[2]) * r, (a.d[3] - q * b.d[3]) * r}};
+}
+// torch.minimum / maximum split the gradient at ties; clamp(min=0) passes it at 0
+__device__ __forceinline__ Dual dmin(const Dual& a, const Dual& b) { return a.v < b.v ? a : (b.v < a.v ? b : (a + b) * 0.5f); }
+__device__ __forceinline__ Dual dmax(const Dual& a, const Dual& b) { return a.v > b.v ? a : (b.v > a.v ? b : (a + b) * 0.5f); }
+__device__ __forceinline__ Dual dclamp0(const Dual& a) { return a.v >= 0.f ? a : dconst(0.f); }
+__device__ __forceinline__ Dual datan(const Dual& a) {
+    const float g = 1.0f / (1.0f + a.v * a.v);
+    return Dual{atanf(a.v), {a.d[0] * g, a.d[1] * g, a.d[2] * g, a.d[3] * g}};
+}
+__device__ __forceinline__ Dual dsigmoid_in(float x, int k) {       // sigmoid of input k
+    const float s = 1.0f / (1.0f + expf(-x));
+    Dual r = dconst(s);
+    r.d[k] = s * (1.0f - s);
+    return r;
+}
+__device__ __forceinline__ float softplus(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+// BCEWithLogits(x, t, pos_weight = pw) = pw * t * softplus(-x) + (1 - t) * softplus(x)
+__device__ __forceinline__ void bce_pw(float x, float t, float pw, float& loss, float& grad) {
+    const float s = 1.0f / (1.0f + expf(-x));
+    loss = pw * t * softplus(-x) + (1.0f - t) * softplus(x);
+    grad = (1.0f - t) * s - pw * t * (1.0f - s);
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float r = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(256) void objloss_init_kernel(float* __restrict__ dp, size_t nf, int* __restrict__ owner, int cells) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i * 4 + 3 < nf) *reinterpret_cast<float4*>(dp + i * 4) = float4{0.f, 0.f, 0.f, 0.f};
+    else
+        for (size_t k = i * 4; k < nf; ++k) dp[k] = 0.f;
+    if (i < (size_t)cells) owner[i] = -1;
+}
+
+__global__ __launch_bounds__(256) void objloss_targets_kernel(const float* __restrict__ p, int no, int nc, const int* __restrict__ cell, const float* __restrict__ tbox,
+                                                              const float* __restrict__ anch, const int* __restrict__ tcls, int n, float cp, float cn, float cls_pw,
+                                                              float w_box, float w_cls, float* __restrict__ iou_e, int* __restrict__ owner, float* __restrict__ dp,
+                                                              float* __restrict__ sums) {
+    __shared__ float sh[4];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    float lb = 0.f, lc = 0.f;
+    if (e < n) {
+        const int c = cell[e];
+        const float* row = p + (size_t)c * no;
+        float* drow = dp + (size_t)c * no;
+        const float eps = 1e-7f;
+        const Dual px = dsigmoid_in(row[0], 0) * 2.0f + (-0.5f), py = dsigmoid_in(row[1], 1) * 2.0f + (-0.5f);
+        Dual sw = dsigmoid_in(row[2], 2) * 2.0f, shh = dsigmoid_in(row[3], 3) * 2.0f;
+        const Dual pw = sw * sw * anch[e * 2 + 0], ph = shh * shh * anch[e * 2 + 1];
+        const float tx = tbox[e * 4 + 0], ty = tbox[e * 4 + 1], tw = tbox[e * 4 + 2], th = tbox[e * 4 + 3];
+        const Dual ax1 = px - pw * 0.5f, ax2 = px + pw * 0.5f, ay1 = py - ph * 0.5f, ay2 = py + ph * 0.5f;
+        const Dual bx1 = dconst(tx - tw / 2), bx2 = dconst(tx + tw / 2), by1 = dconst(ty - th / 2), by2 = dconst(ty + th / 2);
+        const Dual inter = dclamp0(dmin(ax2, bx2) - dmax(ax1, bx1)) * dclamp0(dmin(ay2, by2) - dmax(ay1, by1));
+        const Dual uni = pw * ph + tw * th - inter + eps;
+        const Dual iou = inter / uni;
+        const Dual cw = dmax(ax2, bx2) - dmin(ax1, bx1), ch = dmax(ay2, by2) - dmin(ay1, by1);
+        const Dual c2 = cw * cw + ch * ch + eps;
+        const Dual dx = bx1 + bx2 - ax1 - ax2, dy = by1 + by2 - ay1 - ay2;
+        const Dual rho2 = (dx * dx + dy * dy) * 0.25f;
+        const Dual da = dconst(atanf(tw / (th + eps))) - datan(pw / (ph + eps));
+        const Dual v = da * da * 0.40528473456935109f;                     // 4 / pi^2
+        const float alpha = v.v / (v.v - iou.v + (1.0f + eps));              // (no gradient through alpha)
+        const Dual ciou = iou - (rho2 / c2 + v * alpha);
+        lb = (1.0f - ciou.v) * w_box;
+        iou_e[e] = fmaxf(ciou.v, 0.f);
+        atomicMax(owner + c, e);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) atomicAdd(drow + k, -ciou.d[k] * w_box);
+        if (nc > 1) {
+            const int tc = tcls[e];
+            for (int k = 0; k < nc; ++k) {
+                float l, g;
+                bce_pw(row[5 + k], k == tc ? cp : cn, cls_pw, l, g);
+                lc += l * w_cls;
+                atomicAdd(drow + 5 + k, g * w_cls);
+            }
+        }
+    }
+    lb = block_sum_256(lb, sh);
+    lc = block_sum_256(lc, sh);
+    if (threadIdx.x == 0) {
+        atomicAdd(sums + 0, lb);
+        if (nc > 1) atomicAdd(sums + 2, lc);
+    }
+}
+
+__global__ __launch_bounds__(256) void objloss_cells_kernel(const float* __restrict__ p, int no, int cells, const int* __restrict__ owner, const float* __restrict__ iou_e,
+                                                            float obj_pw, float w_obj, float* __restrict__ dp, float* __restrict__ sums) {
+    __shared__ float sh[4];
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    float lo = 0.f;
+    if (c < cells) {
+        const int o = owner[c];
+        const float t = o >= 0 ? iou_e[o] : 0.f;
+        float l, g;
+        bce_pw(p[(size_t)c * no + 4], t, obj_pw, l, g);
+        lo = l * w_obj;
+        dp[(size_t)c * no + 4] = g * w_obj;
+    }
+    lo = block_sum_256(lo, sh);
+    if (threadIdx.x == 0) atomicAdd(sums + 1, lo);
+}
+
 }  // namespace
 
 #define YP_VPL_SWITCH(D, CALL)                                  \
@@ -182,6 +316,23 @@ extern "C" int yp_infonce_bwd(const float* da, const float* db, const int* idx, 
     hipStream_t st = (hipStream_t)stream;
     YP_VPL_SWITCH(D, (infonce_bwd_a_kernel<VPL><<<grid, 256, 0, st>>>(db, idx, logits, n, E, D, grad_scale_dev, w_scratch, dda)));
     YP_VPL_SWITCH(D, (infonce_bwd_b_kernel<VPL><<<grid, 256, 0, st>>>(da, w_scratch, order, offsets, n, E, D, ddb)));
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
+extern "C" int yp_objloss_level(const float* p, int cells, int no, int nc, const int* cell, const float* tbox, const float* anch, const int* tcls, int n, float cp,
+                                float cn, float cls_pw, float obj_pw, float w_box, float w_obj, float w_cls, float* iou_scratch, int* owner_scratch, float* dp,
+                                float* sums, void* stream) {
+    YP_REQUIRE(p && dp && sums && owner_scratch && cells > 0 && no >= 5 && nc == no - 5 && n >= 0, "yp_objloss_level: bad arguments");
+    YP_REQUIRE(n == 0 || (cell && tbox && anch && iou_scratch && (nc <= 1 || tcls)), "yp_objloss_level: target arrays missing");
+    YP_REQUIRE(((uintptr_t)dp & 15) == 0, "yp_objloss_level: dp must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nf = (size_t)cells * no, n4 = (nf + 3) / 4;
+    objloss_init_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, st>>>(dp, nf, owner_scratch, cells);
+    if (n > 0)
+        objloss_targets_kernel<<<(n + 255) / 256, 256, 0, st>>>(p, no, nc, cell, tbox, anch, tcls, n, cp, cn, cls_pw, w_box / n,
+                                                                 nc > 1 ? w_cls / ((float)n * nc) : 0.f, iou_scratch, owner_scratch, dp, sums);
+    objloss_cells_kernel<<<(cells + 255) / 256, 256, 0, st>>>(p, no, cells, owner_scratch, iou_scratch, obj_pw, w_obj / cells, dp, sums);
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
 }

@@ -69,8 +69,11 @@ class ComputeObjectLoss:
         the labels and the level shapes only and synchronises with the device (boolean-mask indexing), so a training step
         runs it BEFORE launching the forward passes to keep the rest of the step free of host syncs."""
         dev = self.device
+        prepared = prepared if prepared is not None else self.build_targets(p, targets)
+        if p[0].is_cuda and not self.autobalance and not self.sort_obj_iou and self.gr == 1 and os.environ.get("YP_NATIVE_OBJLOSS", "1") != "0":
+            return _ObjLossNative.apply(self, prepared, *p)
         lcls, lbox, lobj = (torch.zeros(1, device=dev) for _ in range(3))
-        tcls, tbox, indices, anchors = prepared if prepared is not None else self.build_targets(p, targets)
+        tcls, tbox, indices, anchors = prepared[:4]
         for i, pi in enumerate(p):
             b, a, gj, gi = indices[i]
             tobj = torch.zeros(pi.shape[:4], dtype=pi.dtype, device=dev)
@@ -140,7 +143,53 @@ class ComputeObjectLoss:
             tbox.append(torch.cat((gxy - gij, gwh), 1))
             anch.append(anchors[a])
             tcls.append(c)
-        return tcls, tbox, indices, anch
+        # flattened (image, anchor, gy, gx) cell of every entry + int32 classes: what csrc/losses.hip (yp_objloss_level) reads
+        flat = []
+        for i in range(self.nl):
+            shape = p[i].shape if isinstance(p[i], torch.Tensor) else tuple(p[i])
+            b, a, gj, gi = indices[i]
+            cell = ((b * shape[1] + a) * shape[2] + gj) * shape[3] + gi
+            flat.append((cell.to(torch.int32), tcls[i].to(torch.int32), tbox[i].float().contiguous(), anch[i].float().contiguous()))
+        return tcls, tbox, indices, anch, flat
+
+
+class _ObjLossNative(torch.autograd.Function):
+    """ComputeObjectLoss.__call__ through csrc/losses.hip (yp_objloss_level): three launches per Detect level compute the CIoU /
+    objectness / class terms AND their gradient (forward-mode duals for the CIoU), instead of ~1000 small PyTorch kernels per
+    step forward + backward.  Same value and gradient as the PyTorch formulation above to fp32 rounding
+    (tests/test_gpu_training.py::test_native_object_loss_*); duplicated (cell, anchor) claims resolve like a sequential
+    index_put (last entry wins).  YP_NATIVE_OBJLOSS=0 selects the PyTorch formulation."""
+
+    @staticmethod
+    def forward(ctx, owner, prepared, *p):
+        from .. import _hip
+        flat = prepared[4]
+        dev = p[0].device
+        sums = torch.zeros(3, dtype=torch.float32, device=dev)
+        dps = []
+        hyp = owner.hyp
+        st = _hip.stream_ptr()
+        for i, pi in enumerate(p):
+            pi = pi.contiguous()
+            assert pi.dtype == torch.float32
+            cell, tcls, tbox, anch = flat[i]
+            n, no = cell.shape[0], pi.shape[-1]
+            cells = pi.numel() // no
+            dp = torch.empty_like(pi)
+            iou = torch.empty((max(n, 1),), dtype=torch.float32, device=dev)
+            own = torch.empty((cells,), dtype=torch.int32, device=dev)
+            _hip.check(_hip.lib().yp_objloss_level(pi.data_ptr(), cells, no, owner.nc, cell.data_ptr(), tbox.data_ptr(), anch.data_ptr(), tcls.data_ptr(), n,
+                                                   float(owner.cp), float(owner.cn), float(hyp['cls_pw']), float(hyp['obj_pw']), float(hyp['box']),
+                                                   float(hyp['obj']) * float(owner.balance[i]), float(hyp['cls']), iou.data_ptr(), own.data_ptr(),
+                                                   dp.data_ptr(), sums.data_ptr(), st))
+            dps.append(dp)
+        ctx.dps = dps
+        ctx.mark_non_differentiable(sums)
+        return sums.sum().reshape(1), sums
+
+    @staticmethod
+    def backward(ctx, g, _g_items):
+        return (None, None, *torch._foreach_mul(ctx.dps, g.reshape(()).float()))
 
 
 # ---------------------------------------------------------------------------------------------
