@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", default="", help="write a per-launch table (us, TFLOP/s, GB/s) to this path")
     ap.add_argument("--postproc", action="store_true", help="also time the post-processing kernels on planted head outputs")
-    ap.add_argument("--mode", default="infer", choices=["infer", "train", "frame"],
+    ap.add_argument("--mode", default="infer", choices=["infer", "train", "frame", "export"],
                     help="infer (default, BASELINE.json configs[1]) or train: the reference's optimizer step, data parallel over --gpus")
     return ap.parse_args()
 
@@ -114,6 +114,8 @@ def main():
         return bench_train(a, rank, world, dev)
     if a.mode == "frame":
         return bench_frame(a, dev)
+    if a.mode == "export":
+        return bench_export(a, dev)
     m, _ = build_model(a.version, a.dtype, dev)
     net = m.model
     B, S = a.batch, a.size
@@ -339,6 +341,65 @@ def bench_frame(a, dev):
                       "data": "synthetic", "config": {"workload": "BASELINE.json configs[3] shape: one frame end to end, device-resident, 2 host syncs per frame "
                                                                   "(front-end counters, match count)", "image": [S, S],
                                                       "post_processing_inputs": "planted heat map / predictions (SURVEY.md 8d), model descriptors", **stats}}), flush=True)
+
+
+def bench_export(a, dev):
+    """homography-adaptation export, reference configs/coco_export.yaml (100 views per 640x640 image,
+    threshold 0.085, nms 4, top_k 1000).  One step = one source image: 100 views through the network as one batch, keypoint
+    decode, aggregation of the 100 heat maps in the base frame, threshold + grid NMS, points to the host."""
+    import numpy as np
+    from yolopoint_amd.export_homography import HomographyExporter
+    from oracle import net_oracle
+    N, S = 100, a.size
+    m, _ = build_model(a.version, a.dtype, dev)
+    exp = HomographyExporter(m, dev, dict(nms=4, top_k=1000, detection_threshold=0.085))
+    rng = np.random.default_rng(5)
+    homs = np.zeros((N, 3, 3), dtype=np.float32)
+    for i in range(N):
+        ang, sc = rng.uniform(-0.5, 0.5), 1.0 + rng.uniform(-0.25, 0.25)
+        homs[i] = [[sc * np.cos(ang), -sc * np.sin(ang), rng.uniform(-0.2, 0.2)], [sc * np.sin(ang), sc * np.cos(ang), rng.uniform(-0.2, 0.2)],
+                   [rng.uniform(-0.15, 0.15), rng.uniform(-0.15, 0.15), 1.0]]
+    homs[0] = np.eye(3)
+    inv = torch.from_numpy(np.linalg.inv(homs.astype(np.float64)).astype(np.float32)).to(dev)
+    from yolopoint_amd.utils.loss_functions import warp_image_batch
+    base = net_oracle.synth_image(1, 3, S, S, 9).to(dev)
+    views = warp_image_batch(base.repeat(N, 1, 1, 1), torch.from_numpy(homs).to(dev), device=dev).contiguous()
+    mask = warp_image_batch(torch.ones(N, 1, S, S, device=dev), torch.from_numpy(homs).to(dev), device=dev, mode="nearest").contiguous()
+    sample = {"image": views[None], "valid_mask": mask.view(1, N, S, S), "inv_homographies": inv[None]}
+    # random-weight heads give a flat heat map (no point reaches 0.085): the network runs in full, the aggregation / decode is fed
+    # planted keypoint logits (1000 x (S/640)^2 peaks, SURVEY.md 8d), the same for every view, as in --mode frame
+    from helpers import planted_heatmap
+    heat = planted_heatmap(S, S, int(1000 * (S / 640) ** 2), 10).astype(np.float64)
+    cells = heat.reshape(S // 8, 8, S // 8, 8).transpose(1, 3, 0, 2).reshape(64, S // 8, S // 8)
+    cells = cells / np.maximum(cells.sum(0, keepdims=True), 1.0) * np.minimum(cells.sum(0, keepdims=True), 0.98)
+    semi = torch.from_numpy(np.log(np.concatenate((cells, 1.0 - cells.sum(0, keepdims=True)), 0) + 1e-12).astype(np.float32)).to(dev)
+    semi = semi[None].repeat(N, 1, 1, 1).contiguous()
+
+    class PlantedSemi(torch.nn.Module):
+        def __init__(self, model):
+            super().__init__()
+            self.model = model
+
+        def forward(self, x):
+            self.model(x)
+            return {"semi": semi}
+    exp.model = PlantedSemi(m)
+    npts = 0
+    for _ in range(max(1, a.warmup // 5)):
+        npts = exp.export_sample(sample).shape[0]
+    torch.cuda.synchronize()
+    steps = max(1, a.steps // 5)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        npts = exp.export_sample(sample).shape[0]
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    print(json.dumps({"metric": f"source images/sec, homography-adaptation export ({N} views of {S}x{S} per image, YOLOPoint-{a.version}, {a.dtype})",
+                      "value": round(steps / wall, 2), "unit": "images/s", "views_per_s": round(steps * N / wall, 1), "n_gpus": 1, "steps": steps,
+                      "warmup": max(1, a.warmup // 5), "ms_per_step": round(wall / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                      "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+                      "config": {"workload": "reference configs/coco_export.yaml: 100 views, detection_threshold 0.085, nms 4, top_k 1000", "points": npts}}),
+          flush=True)
 
 
 def bench_postproc(dev):

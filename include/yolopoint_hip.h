@@ -317,6 +317,13 @@ int yp_box_nms(const float* pred, int B, int N, int nc, float conf_thres, float 
                int multi_label, int agnostic, int max_det, int max_nms, float max_wh,
                float* out_det, int32_t* out_count, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Homography adaptation aggregate (reference export_homography.py:94-96,143-145 with warp_image_batch utils/utils.py:333-376):
+ * heat / mask: [N,H,W] fp32 per-view heat maps (flattenDetection output) and valid masks; inv_homographies [N,9] row-major in
+ * normalised [-1,1] coordinates.  out[H,W] = sum_v warp(heat_v*mask_v) / sum_v warp(mask_v) (bilinear, align_corners, zero pad;
+ * NaN where no view covers a pixel, as in the reference); out_cover (optional) = the denominator. */
+int yp_homo_combine(const float* heat, const float* mask, const float* inv_homographies, int N, int H, int W, float* out, float* out_cover,
+                    void* stream);
+
 /* Drop the keypoints that fall inside a detected box: pts_xyc [n,3] (x, y, conf; order kept) against boxes [n_boxes, box_stride]
  * (x1,y1,x2,y2,...), bounds = rint(xyxy) with numpy slice semantics on an H x W mask.  Counts may live on the device
  * (n_pts_dev / n_boxes_dev non-NULL override the host values, which then only bound the launch) so that the whole frame

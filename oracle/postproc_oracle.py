@@ -250,3 +250,66 @@ def frontend_postprocess(semi, coarse_desc, pred, det_thresh=0.015, nms=4, borde
         pts = filter_points(boxes, pts, H, W)
     desc = sample_desc_from_points(coarse_desc, pts) if pts.shape[1] else np.zeros((coarse_desc.shape[0], 0))
     return pts, desc, boxes
+
+
+# ------------------------------------------------------------------------------------------
+# homography adaptation (export_homography.py:88-150)
+# ------------------------------------------------------------------------------------------
+def _linspace_m1_p1(n):
+    """torch.linspace(-1, 1, n) in float32: filled symmetrically from both ends."""
+    i = np.arange(n)
+    step = np.float32(2.0) / np.float32(max(n - 1, 1))
+    lo = np.float32(-1.0) + step * i.astype(np.float32)
+    hi = np.float32(1.0) - step * (n - 1 - i).astype(np.float32)
+    return np.where(i < n // 2, lo, hi).astype(np.float32)
+
+
+def warp_image_batch(img, mat_homo_inv, mode="bilinear"):
+    """utils/utils.py:333-376 for img [B,C,H,W]: every output pixel's normalised coordinate goes through mat_homo_inv[b]
+    (warp_points :274-295), then F.grid_sample(align_corners=True, padding_mode='zeros').  float32 throughout."""
+    img = np.asarray(img, dtype=np.float32)
+    Hm = np.asarray(mat_homo_inv, dtype=np.float32).reshape(-1, 3, 3)
+    B, C, H, W = img.shape
+    gx, gy = np.meshgrid(_linspace_m1_p1(W), _linspace_m1_p1(H))                   # [H,W] each
+    out = np.zeros_like(img)
+    for b in range(B):
+        h = Hm[b]
+        X = h[0, 0] * gx + h[0, 1] * gy + h[0, 2]
+        Y = h[1, 0] * gx + h[1, 1] * gy + h[1, 2]
+        Z = h[2, 0] * gx + h[2, 1] * gy + h[2, 2]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ix = ((X / Z + np.float32(1)) / np.float32(2)) * np.float32(W - 1)
+            iy = ((Y / Z + np.float32(1)) / np.float32(2)) * np.float32(H - 1)
+        if mode == "nearest":
+            xn, yn = np.rint(ix), np.rint(iy)
+            ok = (xn >= 0) & (xn < W) & (yn >= 0) & (yn < H)
+            xi, yi = np.where(ok, xn, 0).astype(np.int64), np.where(ok, yn, 0).astype(np.int64)
+            out[b] = np.where(ok[None], img[b][:, yi, xi], 0)
+            continue
+        x0, y0 = np.floor(ix), np.floor(iy)
+        acc = np.zeros((C, H, W), dtype=np.float32)
+        for dy in (0, 1):
+            for dx in (0, 1):
+                xt, yt = x0 + dx, y0 + dy
+                wx = (x0 + 1 - ix) if dx == 0 else (ix - x0)
+                wy = (y0 + 1 - iy) if dy == 0 else (iy - y0)
+                ok = (xt >= 0) & (xt < W) & (yt >= 0) & (yt < H)
+                xi, yi = np.where(ok, xt, 0).astype(np.int64), np.where(ok, yt, 0).astype(np.int64)
+                acc += np.where(ok[None], img[b][:, yi, xi] * (wx * wy).astype(np.float32)[None], np.float32(0))
+        out[b] = acc
+    return out
+
+
+def homography_adaptation(semi, valid_mask, inv_homographies, conf_thresh=0.015, nms_dist=4, top_k=None):
+    """export_homography.py:88-150 for one image: semi [N,65,Hc,Wc] of its N views, valid_mask [N,1,H,W], inv_homographies
+    [N,3,3] -> (aggregated heat map [H,W], pts [n,3] (x, y, prob))."""
+    heat = flatten_detection(semi) * np.asarray(valid_mask, dtype=np.float32)
+    heat = warp_image_batch(heat, inv_homographies)
+    mask = warp_image_batch(valid_mask, inv_homographies)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        agg = heat.sum(axis=0, dtype=np.float32) / mask.sum(axis=0, dtype=np.float32)
+    agg = agg[0]
+    pts = get_pts_from_heatmap(agg, conf_thresh, nms_dist).transpose()
+    if top_k and pts.shape[0] > top_k:
+        pts = pts[:top_k, :]
+    return agg, pts

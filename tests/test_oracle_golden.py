@@ -163,3 +163,27 @@ def test_descriptors(post):
 def test_labels(post):
     np.testing.assert_allclose(po.labels2d_to_3d(post["l2d.labels"]), post["l2d.out"])
     np.testing.assert_allclose(po.get_masks(post["l2d.mask"]), post["l2d.maskout"])
+
+
+# ------------------------------------------------------------------ homography adaptation (export)
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_homography_adaptation_oracle(i):
+    """oracle/postproc_oracle.homography_adaptation against the imported reference's export flow (export_homography.py:88-150)."""
+    g = np.load(os.path.join(G, "export.npz"))
+    N, Hc, Wc, thr, r, top_k = g[f"ha{i}.cfg"]
+    N, Hc, Wc, r, top_k = int(N), int(Hc), int(Wc), int(r), int(top_k)
+    mask = g[f"ha{i}.valid_mask"].astype(np.float32)
+    # the valid masks themselves: compute_valid_mask (utils/utils.py:297-331) = nearest warp of ones + a 1-px frame
+    m2 = po.warp_image_batch(np.ones((N, 1, Hc * 8, Wc * 8), np.float32), g[f"ha{i}.homographies"], mode="nearest")
+    m2[:, :, :1, :] = 0; m2[:, :, -1:, :] = 0; m2[:, :, :, :1] = 0; m2[:, :, :, -1:] = 0
+    assert np.array_equal(m2, mask)
+    agg, pts = po.homography_adaptation(g[f"ha{i}.semi"], mask, g[f"ha{i}.inv_homographies"], thr, r, top_k)
+    ref = g[f"ha{i}.agg"]
+    assert np.array_equal(np.isnan(agg), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    # fp32 source coordinates carry ~1e-5 px of rounding x a heat gradient of O(0.5 / px): absolute 1e-5 on a [0,1] map
+    np.testing.assert_allclose(agg[ok], ref[ok], rtol=1e-5, atol=1e-5)
+    rp = g[f"ha{i}.pts"]
+    assert pts.shape == rp.shape
+    assert np.array_equal(pts[:, :2], rp[:, :2])
+    np.testing.assert_allclose(pts[:, 2], rp[:, 2], rtol=1e-5, atol=1e-5)

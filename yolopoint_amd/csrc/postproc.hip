@@ -697,6 +697,59 @@ extern "C" int yp_pts_box_filter(const float* pts_xyc, const int* n_pts_dev, int
     return YP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Homography adaptation, the aggregation step (reference export_homography.py:94-96,143-145): N views of one image were pushed
+// through the network; view v's heat map (times its valid mask) and the mask itself are warped back to the base frame with
+// warp_image_batch (utils/utils.py:333-376: normalised [-1,1] grid through inv_homographies[v], bilinear grid_sample,
+// align_corners=True, zero padding), summed over the views and divided.  The reference materialises 2 x N warped full-resolution
+// maps; here one thread owns one base-frame pixel and walks the N views (8 gathered taps per view), nothing is written but the
+// aggregated map.  0 / 0 (a pixel no view covers) stays NaN as in the reference; the >= threshold of the decode rejects it.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float linspace_m1_p1(int i, int n) {      // torch.linspace(-1, 1, n)[i] (symmetric fill)
+    if (n == 1) return -1.0f;
+    const float step = 2.0f / (float)(n - 1);
+    return i < n / 2 ? -1.0f + step * (float)i : 1.0f - step * (float)(n - 1 - i);
+}
+
+__global__ __launch_bounds__(256) void homo_combine_kernel(const float* __restrict__ heat, const float* __restrict__ mask, const float* __restrict__ invh, int N,
+                                                           int H, int W, float* __restrict__ out, float* __restrict__ out_cover) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const float gx = linspace_m1_p1(x, W), gy = linspace_m1_p1(y, H);
+    const size_t plane = (size_t)H * W;
+    float sh = 0.f, sm = 0.f;
+    for (int v = 0; v < N; ++v) {
+        const float* h = invh + v * 9;
+        const float X = h[0] * gx + h[1] * gy + h[2], Y = h[3] * gx + h[4] * gy + h[5], Z = h[6] * gx + h[7] * gy + h[8];
+        const float ix = ((X / Z + 1.0f) / 2.0f) * (float)(W - 1), iy = ((Y / Z + 1.0f) / 2.0f) * (float)(H - 1);
+        const float fx0 = floorf(ix), fy0 = floorf(iy);
+        if (!(fx0 >= -1.0f && fx0 <= (float)W && fy0 >= -1.0f && fy0 <= (float)H)) continue;     // all four taps outside (or NaN)
+        const int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
+        const float wx1 = ix - fx0, wx0 = (fx0 + 1.0f) - ix, wy1 = iy - fy0, wy0 = (fy0 + 1.0f) - iy;
+        const float* hp = heat + v * plane;
+        const float* mp = mask + v * plane;
+        float ah = 0.f, am = 0.f;
+        const bool okx0 = x0 >= 0 && x0 < W, okx1 = x1 >= 0 && x1 < W, oky0 = y0 >= 0 && y0 < H, oky1 = y1 >= 0 && y1 < H;
+        if (oky0 && okx0) { const float m = mp[(size_t)y0 * W + x0], w = wx0 * wy0; ah += hp[(size_t)y0 * W + x0] * m * w; am += m * w; }
+        if (oky0 && okx1) { const float m = mp[(size_t)y0 * W + x1], w = wx1 * wy0; ah += hp[(size_t)y0 * W + x1] * m * w; am += m * w; }
+        if (oky1 && okx0) { const float m = mp[(size_t)y1 * W + x0], w = wx0 * wy1; ah += hp[(size_t)y1 * W + x0] * m * w; am += m * w; }
+        if (oky1 && okx1) { const float m = mp[(size_t)y1 * W + x1], w = wx1 * wy1; ah += hp[(size_t)y1 * W + x1] * m * w; am += m * w; }
+        sh += ah;
+        sm += am;
+    }
+    out[(size_t)y * W + x] = sh / sm;
+    if (out_cover) out_cover[(size_t)y * W + x] = sm;
+}
+
+extern "C" int yp_homo_combine(const float* heat, const float* mask, const float* inv_homographies, int N, int H, int W, float* out, float* out_cover,
+                               void* stream) {
+    YP_REQUIRE(heat && mask && inv_homographies && out && N > 0 && H > 0 && W > 0, "yp_homo_combine: bad arguments");
+    dim3 grid((W + 63) / 64, (H + 3) / 4);
+    homo_combine_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(heat, mask, inv_homographies, N, H, W, out, out_cover);
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
 extern "C" int yp_desc_sample(const float* desc, int D, int Hc, int Wc, int64_t sc, int64_t sy, int64_t sx, const float* pts_xy, int N,
                               int cell, float* out, void* stream) {
     YP_REQUIRE(desc && out && D > 0 && Hc > 0 && Wc > 0 && cell > 0 && N >= 0, "yp_desc_sample: bad arguments");
