@@ -367,13 +367,14 @@ def bench_export(a, dev):
     mask = warp_image_batch(torch.ones(N, 1, S, S, device=dev), torch.from_numpy(homs).to(dev), device=dev, mode="nearest").contiguous()
     sample = {"image": views[None], "valid_mask": mask.view(1, N, S, S), "inv_homographies": inv[None]}
     # random-weight heads give a flat heat map (no point reaches 0.085): the network runs in full, the aggregation / decode is fed
-    # planted keypoint logits (1000 x (S/640)^2 peaks), the same for every view, as in --mode frame
+    # planted keypoint logits (1000 x (S/640)^2 peaks in the base frame, SURVEY.md 8d, warped into every view), as in --mode frame
     from helpers import planted_heatmap
-    heat = planted_heatmap(S, S, int(1000 * (S / 640) ** 2), 10).astype(np.float64)
-    cells = heat.reshape(S // 8, 8, S // 8, 8).transpose(1, 3, 0, 2).reshape(64, S // 8, S // 8)
-    cells = cells / np.maximum(cells.sum(0, keepdims=True), 1.0) * np.minimum(cells.sum(0, keepdims=True), 0.98)
-    semi = torch.from_numpy(np.log(np.concatenate((cells, 1.0 - cells.sum(0, keepdims=True)), 0) + 1e-12).astype(np.float32)).to(dev)
-    semi = semi[None].repeat(N, 1, 1, 1).contiguous()
+    heat = torch.from_numpy(planted_heatmap(S, S, int(1000 * (S / 640) ** 2), 10).astype(np.float32)).to(dev)
+    hv = warp_image_batch(heat[None, None].repeat(N, 1, 1, 1), torch.from_numpy(homs).to(dev), device=dev)          # the peaks as each view sees them
+    cells = torch.nn.functional.pixel_unshuffle(hv, 8).double()                                                       # [N,64,S/8,S/8]
+    tot = cells.sum(1, keepdim=True)
+    cells = cells / tot.clamp_min(1.0) * tot.clamp_max(0.98)
+    semi = torch.log(torch.cat((cells, 1.0 - cells.sum(1, keepdim=True)), 1) + 1e-12).float().contiguous()
 
     class PlantedSemi(torch.nn.Module):
         def __init__(self, model):

@@ -313,3 +313,65 @@ def homography_adaptation(semi, valid_mask, inv_homographies, conf_thresh=0.015,
     if top_k and pts.shape[0] > top_k:
         pts = pts[:top_k, :]
     return agg, pts
+
+
+# ------------------------------------------------------------------------------------------
+# PointTracker bookkeeping (models/model_wrap.py:410-606)
+# ------------------------------------------------------------------------------------------
+class PointTrackerOracle:
+    """Sequential restatement of the reference tracker: one match at a time, as the reference loops."""
+
+    def __init__(self, max_length=2, nn_thresh=0.7):
+        assert max_length >= 2
+        self.maxl, self.nn_thresh = max_length, nn_thresh
+        self.all_pts = [np.zeros((2, 0)) for _ in range(max_length)]
+        self.last_desc, self.last_pts, self.matches = None, None, None
+        self.tracks = np.zeros((0, max_length + 2))
+        self.track_count, self.max_score = 0, 9999
+
+    def get_offsets(self):                                    # :477-491
+        sizes = [0] + [self.all_pts[i].shape[1] for i in range(len(self.all_pts) - 1)]
+        return np.cumsum(np.array(sizes))
+
+    def update(self, pts, desc):                              # :503-577
+        if self.last_desc is None:
+            self.last_desc = np.zeros((desc.shape[0], 0))
+        gone = self.all_pts.pop(0).shape[1]
+        self.all_pts.append(pts)
+        self.tracks = np.delete(self.tracks, 2, axis=1)
+        for col in range(2, self.tracks.shape[1]):
+            self.tracks[:, col] -= gone
+        self.tracks[:, 2:][self.tracks[:, 2:] < -1] = -1
+        offsets = self.get_offsets()
+        self.tracks = np.hstack((self.tracks, -1 * np.ones((self.tracks.shape[0], 1))))
+        taken = np.zeros(pts.shape[1], dtype=bool)
+        matches = nn_match_two_way(self.last_desc, desc, self.nn_thresh)
+        self.matches = matches
+        if self.last_pts is not None:
+            self.matches = np.concatenate((self.last_pts[:, matches[0, :].astype(int)], pts[:2, matches[1, :].astype(int)]), axis=0)
+        for m in matches.T:
+            a, b = int(m[0]) + offsets[-2], int(m[1]) + offsets[-1]
+            rows = np.argwhere(self.tracks[:, -2] == a)
+            if rows.shape[0] == 0:
+                continue
+            taken[int(m[1])] = True
+            r = int(rows[0, 0])
+            self.tracks[r, -1] = b
+            if self.tracks[r, 1] == self.max_score:
+                self.tracks[r, 1] = m[2]
+            else:
+                n_obs = (self.tracks[r, 2:] != -1).sum() - 1.0
+                self.tracks[r, 1] = (1.0 - 1.0 / n_obs) * self.tracks[r, 1] + (1.0 / n_obs) * m[2]
+        ids = (np.arange(pts.shape[1]) + offsets[-1])[~taken]
+        fresh = -1 * np.ones((ids.shape[0], self.maxl + 2))
+        fresh[:, -1] = ids
+        fresh[:, 0] = self.track_count + np.arange(ids.shape[0])
+        fresh[:, 1] = self.max_score
+        self.tracks = np.vstack((self.tracks, fresh))
+        self.track_count += ids.shape[0]
+        self.tracks = self.tracks[np.any(self.tracks[:, 2:] >= 0, axis=1), :]
+        self.last_desc, self.last_pts = desc.copy(), pts[:2, :].copy()
+
+    def get_tracks(self, min_length):                         # :579-596
+        long_enough = np.sum(self.tracks[:, 2:] != -1, axis=1) >= min_length
+        return self.tracks[long_enough & (self.tracks[:, -1] != -1), :].copy()

@@ -104,3 +104,26 @@ def planted_descriptors(D, N1, N2, frac, seed, noise=0.2):
     d2[:, dst] = d1[:, src] + noise * rng.normal(size=(D, nmatch)).astype(np.float32) / np.sqrt(D)
     d2 /= np.linalg.norm(d2, axis=0, keepdims=True)
     return d1.astype(np.float32), d2.astype(np.float32)
+
+
+def tracking_sequence(D, frames, N, seed, keep=0.7, noise=0.15):
+    """A sequence of (pts [3,n] float64, desc [D,n] float32 unit columns): each frame carries `keep` of the previous frame's
+    points over (descriptor + noise, position + 1 px, shuffled) and adds new ones; n varies per frame."""
+    rng = np.random.default_rng(seed)
+    out, prev = [], None
+    for f in range(frames):
+        n = int(N * rng.uniform(0.8, 1.2))
+        d = rng.normal(size=(D, n)).astype(np.float32)
+        xy = rng.uniform(8, 300, size=(2, n)).round()
+        if prev is not None:
+            pd, pxy = prev
+            k = min(int(pd.shape[1] * keep), n)
+            src = rng.choice(pd.shape[1], k, replace=False)
+            dst = rng.choice(n, k, replace=False)
+            d[:, dst] = pd[:, src] + noise * rng.normal(size=(D, k)).astype(np.float32) / np.sqrt(D)
+            xy[:, dst] = pxy[:, src] + 1.0
+        d /= np.linalg.norm(d, axis=0, keepdims=True)
+        pts = np.vstack((xy, rng.uniform(0.02, 1.0, size=(1, n))))
+        out.append((pts.astype(np.float64), d.astype(np.float32)))
+        prev = (d, xy)
+    return out

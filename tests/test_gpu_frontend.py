@@ -7,6 +7,7 @@ import torch
 
 from helpers import make_model
 from oracle import net_oracle, postproc_oracle
+from oracle import postproc_oracle as po
 from yolopoint_amd import _hip
 from yolopoint_amd.frontend import YoloPointFrontend
 
@@ -70,3 +71,37 @@ def test_frontend_process_img_reference_formats(cuda):
     np.testing.assert_allclose(np.linalg.norm(desc, axis=0), 1.0, atol=1e-4)
     with pytest.raises(_hip.YpError):
         YoloPointFrontend(m, cuda, crop_resize=[0, 1, 0, 1, 2])
+
+
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_point_tracker_bookkeeping(cuda, i):
+    """PointTracker.update / get_tracks (HIP matcher + vectorised bookkeeping, descriptors kept on the device) against the
+    reference's tracks captured in tests/golden/tracker.npz and the sequential oracle, frame by frame."""
+    import os
+    from helpers import tracking_sequence
+    from yolopoint_amd.models.model_wrap import PointTracker
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "tracker.npz"))
+    D, frames, N, maxl, seed = (int(v) for v in g[f"tr{i}.cfg"])
+    tr, orc = PointTracker(maxl, nn_thresh=0.7), po.PointTrackerOracle(maxl, nn_thresh=0.7)
+    ids = [0] + list(range(2, maxl + 2))
+    for f, (pts, desc) in enumerate(tracking_sequence(D, frames, N, seed)):
+        tr.update(pts, torch.from_numpy(desc).to(cuda))
+        orc.update(pts, desc)
+        ref = g[f"tr{i}.f{f}.tracks"]
+        assert tr.tracks.shape == ref.shape
+        assert np.array_equal(tr.tracks[:, ids], ref[:, ids]) and np.array_equal(tr.tracks[:, ids], orc.tracks[:, ids])
+        np.testing.assert_allclose(tr.tracks[:, 1], ref[:, 1], rtol=1e-5, atol=1e-6)          # fp32 match distances
+        assert np.array_equal(tr.get_tracks(2)[:, ids], g[f"tr{i}.f{f}.long"][:, ids])
+        assert np.array_equal(tr.get_matches(), g[f"tr{i}.f{f}.matches"])
+        assert np.array_equal(tr.get_offsets(), orc.get_offsets())
+
+
+def test_keypoint_array_from_device(cuda):
+    from yolopoint_amd.frontend import to_keypoint_array
+    rng = np.random.default_rng(1)
+    pts = np.vstack((rng.integers(0, 1280, (2, 300)).astype(np.float64), rng.random((1, 300))))
+    desc = rng.normal(size=(256, 300)).astype(np.float32)
+    a = to_keypoint_array(pts, desc)
+    b = to_keypoint_array(torch.from_numpy(pts).float().to(cuda), torch.from_numpy(desc).to(cuda))
+    for k in a:
+        assert np.array_equal(a[k], b[k]) and np.asarray(a[k]).dtype == np.asarray(b[k]).dtype, k

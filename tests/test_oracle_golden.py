@@ -187,3 +187,35 @@ def test_homography_adaptation_oracle(i):
     assert pts.shape == rp.shape
     assert np.array_equal(pts[:, :2], rp[:, :2])
     np.testing.assert_allclose(pts[:, 2], rp[:, 2], rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------ PointTracker bookkeeping
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_point_tracker_oracle(i):
+    """oracle PointTrackerOracle against the imported reference tracker (models/model_wrap.py:410-606) frame by frame."""
+    g = np.load(os.path.join(G, "tracker.npz"))
+    D, frames, N, maxl, seed = (int(v) for v in g[f"tr{i}.cfg"])
+    tr = po.PointTrackerOracle(maxl, nn_thresh=0.7)
+    for f, (pts, desc) in enumerate(helpers.tracking_sequence(D, frames, N, seed)):
+        tr.update(pts, desc)
+        ref = g[f"tr{i}.f{f}.tracks"]
+        ids = [0] + list(range(2, maxl + 2))
+        assert np.array_equal(tr.tracks[:, ids], ref[:, ids])
+        np.testing.assert_allclose(tr.tracks[:, 1], ref[:, 1], rtol=1e-9)
+        assert np.array_equal(tr.get_tracks(2)[:, ids], g[f"tr{i}.f{f}.long"][:, ids])
+        assert np.array_equal(tr.matches, g[f"tr{i}.f{f}.matches"])
+
+
+def test_keypoint_array_wire_format():
+    """KeypointArray.msg fields as yolopoint_ros.py:109-117 fills them (host path of the packer)."""
+    from yolopoint_amd.frontend import to_keypoint_array
+    rng = np.random.default_rng(0)
+    pts = np.vstack((rng.integers(0, 640, (2, 17)).astype(np.float64), rng.random((1, 17))))
+    desc = rng.normal(size=(128, 17)).astype(np.float32)
+    m = to_keypoint_array(pts, desc)
+    assert m["x"].dtype == np.uint16 and m["y"].dtype == np.uint16 and m["score"].dtype == np.float32 and m["desc_flat"].dtype == np.float32
+    assert np.array_equal(m["x"], pts[1].astype(np.uint16)) and np.array_equal(m["y"], pts[0].astype(np.uint16))
+    assert np.array_equal(m["score"], pts[2].astype(np.float32))
+    assert m["desc_len"] == 128 and m["desc_len"].dtype == np.uint8
+    assert np.array_equal(m["desc_flat"], desc.flatten())
+    assert to_keypoint_array(pts, np.zeros((256, 17), np.float32))["desc_len"] == 0

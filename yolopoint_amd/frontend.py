@@ -108,3 +108,21 @@ class YoloPointFrontend:
         boxes = r["boxes"].clone()
         boxes[:, :4] = (boxes[:, :4] + torch.tensor([ctw, cth, ctw, cth], device=boxes.device)) / fac
         return pts, desc, [boxes]
+
+
+def to_keypoint_array(pts, desc):
+    """(pts [3,N] (x, y, conf), desc [D,N]) -> the fields of the reference's `KeypointArray` ROS message
+    (src/ros_messages/keypoint_msg/msg/KeypointArray.msg; filled by yolopoint_ros.py:109-117): uint16[] x, uint16[] y,
+    float32[] score, uint8 desc_len, float32[] desc_flat (the [D,N] matrix flattened row-major, i.e. dimension-major).
+    Kept as the reference writes it: `x` carries pts[1] and `y` carries pts[0]; desc_len is D modulo 256 (the field is a uint8,
+    so D = 256 reads 0).  Device tensors are converted on the device and cross to the host once."""
+    if isinstance(pts, torch.Tensor) and isinstance(desc, torch.Tensor) and pts.is_cuda:
+        n, D = pts.shape[1], desc.shape[0]
+        blob = torch.cat((pts[1].to(torch.int32).to(torch.float32), pts[0].to(torch.int32).to(torch.float32), pts[2].float(), desc.float().flatten())).cpu().numpy()
+        x, y, score, flat = blob[:n], blob[n:2 * n], blob[2 * n:3 * n], blob[3 * n:]
+    else:
+        pts, desc = np.asarray(pts), np.asarray(desc)
+        D = desc.shape[0]
+        x, y, score, flat = pts[1, :], pts[0, :], pts[2, :], desc.flatten()
+    return {"x": x.astype(np.uint16), "y": y.astype(np.uint16), "score": score.astype(np.float32), "desc_len": np.uint8(D % 256),
+            "desc_flat": np.ascontiguousarray(flat, dtype=np.float32)}
