@@ -37,6 +37,7 @@ struct WgradArgs {
     int Cj, Cout_pad;
     int n_co_blk;
     int tiles_x, tiles_y, ntiles, M;
+    int skip_store;                        // probe only (YP_WG_NOSTORE): time the reduction without the final atomics
 };
 
 __device__ __forceinline__ void wg_glds16(const void* gsrc, unsigned lds_dst) {
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     const int ci = ci0 + (wci * 2 + fa) * 16 + 4 * g + jj;
-                    if (ci < a.Cj) atomicAdd(a.dw + ((size_t)ci * TAPS + tp) * a.Cout_pad + co, acc[tp][fa][fb][jj]);
+                    if (ci < a.Cj && !a.skip_store) atomicAdd(a.dw + ((size_t)ci * TAPS + tp) * a.Cout_pad + co, acc[tp][fa][fb][jj]);
                 }
             }
 }
@@ -255,12 +256,19 @@ extern "C" int yp_conv_wgrad(YpView x, YpView dy, int dtype, int B, int k, int s
     a.dy_cs = dy.cstride; a.dy_co = dy.coff;
     a.B = B; a.H = dy.H; a.W = dy.W; a.Cj = x.C; a.Cout_pad = dy.C; a.M = (int)M;
     a.n_co_blk = yp_cdiv(dy.C, 64);
+    a.skip_store = getenv("YP_WG_NOSTORE") != nullptr;
     const int nblk = yp_cdiv(x.C, 64) * a.n_co_blk;
     if (k == 3) { a.tiles_x = yp_cdiv(dy.W, 16); a.tiles_y = yp_cdiv(dy.H, stride == 2 ? 4 : 8); a.ntiles = B * a.tiles_x * a.tiles_y; }
     else a.ntiles = yp_cdiv((int)M, 128);
-    // pixel split: enough workgroups to fill the chip, but every workgroup ends in 64*64*taps atomics -> bound the split
-    int split = yp_cdiv(768, nblk);
-    const int cap = k == 3 ? 96 : 256;
+    // pixel split: one workgroup per CU.  Every workgroup ends in 64*64*taps fp32 atomics and the chip retires only ~250 G of them
+    // per second (tools/probe/wgrad_bench.py: YP_WG_NOSTORE halves the total), so more, smaller workgroups lose: 768 -> 256
+    // workgroups took the 23 distinct YOLOPoint-s shapes from 863 to 612 us.  A single 64x64 block of a 3x3 filter (nblk = 1)
+    // is best at ~96 when it has few tiles per workgroup anyway.
+    int target = 256;
+    if (const char* e = getenv("YP_WG_TARGET")) target = atoi(e);
+    int split = yp_cdiv(target, nblk);
+    int cap = (k == 3 && nblk == 1 && a.ntiles <= 800) ? 96 : 256;
+    if (const char* e = getenv("YP_WG_CAP")) cap = atoi(e);          // (tools/probe/wgrad_bench.py)
     if (split > cap) split = cap;
     if (split > a.ntiles) split = a.ntiles;
     if (split < 1) split = 1;
