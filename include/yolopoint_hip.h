@@ -218,6 +218,17 @@ int yp_conv_wgrad(YpView x, YpView dy, int dtype, int B, int k, int stride, floa
 /* dw[ci][r][s][co] (fp32, Cout_pad channels per tap: the layout yp_conv_wgrad / the wgrad-as-convolution path produce)
  * -> grad[co][c0+ci][r][s] for ci < creal, co < Cout: the reference layout of conv.weight.grad */
 int yp_wgrad_unpack(const float* dw, float* grad, int Cout, int Cin, int k, int c0, int creal, int Cout_pad, void* stream);
+
+/* Every weight gradient of a backward pass in ONE launch (tiled LDS transposes, optional sum over `split` partial copies).
+ * Entry: dw [rows = creal*k*k][cout_pad] fp32 (+ p*pstride floats for partial p) -> grad[co*out_stride + out_off + row] for
+ * co < cout; out_stride = Cin*k*k, out_off = c0*k*k; tiles of 32 x 32 are numbered across the table: tile0 = the entry's first,
+ * it owns ceil(rows/32)*ceil(cout/32) of them.  The table lives in device memory, sorted by tile0. */
+typedef struct YpUnpackEntry {
+    const float* dw;
+    float* grad;
+    int64_t rows, cout, cout_pad, out_stride, out_off, tile0, split, pstride;
+} YpUnpackEntry;
+int yp_wgrad_unpack_batch(const YpUnpackEntry* table_dev, int n_entries, int total_tiles, void* stream);
 /* fp32 OIHW master filter w[Cout][Cin][R][S] -> the packed [Npad + 1][Kpad] `dtype` filter yp_conv2d reads (zero padded,
  * zero row last), so a training step re-derives its 16-bit filters on the device without host work:
  *   mode 0  forward filter of input-channel slice [c0, c0+Cj):  dst[n][(r*S+s)*Cj + c]       = w[n][c0+c][r][s]
@@ -272,6 +283,7 @@ enum {
     YP_OP_MAXPOOL2_BWD = 29,  /* v0=x v1=dy v2=dx; i0=dtype i1=B i2=accumulate */
     YP_OP_WGRAD_UNPACK = 28,  /* p0=dw [Cj][k][k][Cout_pad] fp32 -> g0=grad OIHW [Cout][Cin][k][k] fp32, input-channel slice [c0, c0+creal):
                                * i1=Cout i2=Cin i3=k i4=c0 i5=creal i6=Cout_pad */
+    YP_OP_WGRAD_UNPACK_BATCH = 30, /* p0=device table of YpUnpackEntry; i1=entries i2=total tiles */
     YP_OP_PACK_WEIGHT = 26    /* f0=w f1=bias; g0=bias_dst; p0=dst; i0=dtype i1=Cout i2=Cin i3=R i4=S i5=c0 i6=Cj i7=mode; n0=Kpad n1=Npad | Cout_pad<<32 */
 };
 typedef struct YpOpArgs {

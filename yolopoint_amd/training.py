@@ -214,8 +214,9 @@ class TrainGraph:
                        extra=dict(raw_weight=(dyp, K, Cout_pad), cout=Cout_pad, kernel_hw=(Ho, Wo), dil=s, out_hw=(k, k), ksplit=ksplit,
                                   atomic=1, batch=Cj, weight_view=self.T(dyp)))
             creal = weight.shape[1] - c0 if image else Cj
-            b.op(_hip.OP_WGRAD_UNPACK, [dwb.view()], [self.T(gw)], "dw_unpack", p=[dwb.flat], g=[gw],
-                 i=[0, Cout, weight.shape[1], k, c0, creal, Cout_pad])
+            # (dw -> OIHW gradient: all of a backward pass's transposes run as ONE launch at the end of the plan, see emit())
+            self.unpack.append(dict(dw=dwb, grad=gw, rows=creal * k * k, cout=Cout, cout_pad=Cout_pad, out_stride=weight.shape[1] * k * k,
+                                    out_off=c0 * k * k, split=1, pstride=0))
             # ---- dgrad (no gradient flows into the image)
             if not image:
                 cs, ce_ = c0, c0 + Cj
@@ -400,7 +401,7 @@ class TrainGraph:
             bb.pack_target = self.fwd.pack_target
             for key in self.gwritten:
                 self.gwritten[key] = []
-            self.touched, self.collect = set(), []
+            self.touched, self.collect, self.unpack = set(), [], []
             bb.op(_hip.OP_MEMSET0, [], [self.T(self.dw_arena)], "zero_dw", p=[self.dw_arena], n=[self.dw_arena.numel() * 4])
             semi_seed()
             desc_seed()
@@ -410,6 +411,15 @@ class TrainGraph:
             for branch, fn in reversed(self.tape):
                 if not kp_only or branch == "kp":
                     fn()
+            rows, tile0 = [], 0
+            for u in self.unpack:
+                rows.append([u["dw"].flat.data_ptr(), u["grad"].data_ptr(), u["rows"], u["cout"], u["cout_pad"], u["out_stride"], u["out_off"], tile0,
+                             u["split"], u["pstride"]])
+                tile0 += -(-u["rows"] // 32) * -(-u["cout"] // 32)
+            table = torch.tensor(rows, dtype=torch.int64).to(self.device)
+            self.keep.append(table)
+            bb.op(_hip.OP_WGRAD_UNPACK_BATCH, [u["dw"].view() for u in self.unpack], [self.T(u["grad"]) for u in self.unpack], "dw_unpack",
+                  p=[table], i=[0, len(rows), tile0])
             plan = bb.finish(parallel=False)
             return plan, self.touched, self.collect
         self.bwd_plan, self.bwd_params, self.bwd_collect = emit(False)
