@@ -191,6 +191,7 @@ int yp_bn_act_apply(YpView raw, YpView out, YpView res, int dtype, int B, const 
 int yp_bn_act_bwd(YpView raw, YpView dy, YpView dx, int dtype, int B, const float* mean, const float* invstd,
                   const float* gamma, const float* beta, int act, float* dgamma, float* dbeta, int accumulate_param_grads,
                   void* workspace, size_t workspace_bytes, void* stream);
+
 /* out (+)= 2x2 block sums of `in` (backward of nn.Upsample(2,'nearest'), models/YOLOPoint.py:192) */
 int yp_ups2_bwd(YpView in, YpView out, int dtype, int B, int accumulate, void* stream);
 /* dst (+)= src (gradient fan-in) */
@@ -382,6 +383,11 @@ int yp_plan_num_ops(const YpPlan* plan);
  * independent branches run concurrently.  Eager yp_plan_run ignores them (single stream order). */
 int yp_plan_set_deps(YpPlan* plan, int op, const int* deps, int ndeps);
 int yp_plan_graph_is_parallel(const YpPlan* plan);
+/* Two-lane schedule: an op on YP_LANE_SIDE starts after everything added before it but runs BESIDE the ops added after it (second
+ * stream; a parallel branch once the plan is a hipGraph); an op on YP_LANE_JOIN first waits for every side op.  The end of the
+ * plan always joins.  The caller guarantees that no later main-lane op touches what a side op reads or writes. */
+enum { YP_LANE_MAIN = 0, YP_LANE_SIDE = 1, YP_LANE_JOIN = 2 };
+int yp_plan_set_lane(YpPlan* plan, int op, int lane);
 /* capture the op list into a hipGraph on `stream` (call once, after the last add) */
 int yp_plan_instantiate_graph(YpPlan* plan, void* stream);
 /* enqueue all ops (graph launch when instantiated) */

@@ -258,6 +258,24 @@ def test_native_object_loss_matches_torch_formulation(cuda, nc, B, S, nt):
         assert rel_err(a, b)[1] < 2e-5
 
 
+def test_two_lane_backward_matches_single_lane(cuda, monkeypatch):
+    """yp_plan_set_lane: the backward with its weight-gradient kernels on the side lane (a parallel branch of the hipGraph)
+    produces the gradients of the single-lane schedule."""
+    grads = {}
+    for lanes in ("0", "1"):
+        monkeypatch.setenv("YP_TRAIN_LANES", lanes)
+        m, _ = make_model("n", 3, dtype="bf16")
+        m = m.to(cuda).train()
+        x = net_oracle.synth_image(2, 3, 64, 64, 4).to(cuda)
+        for _ in range(2):                      # second pass replays the instantiated graphs
+            m.zero_grad(set_to_none=True)
+            o = m(x)
+            (o["semi"].square().mean() + o["desc"].mean() + sum(t.tanh().mean() for t in o["objects"])).backward()
+        grads[lanes] = [p.grad.clone() for p in m.parameters()]
+    for a, b in zip(grads["1"], grads["0"]):
+        assert rel_err(a, b)[1] < 1e-4          # fp32 atomics: the accumulation order differs run to run
+
+
 def test_train_forward_without_backward_releases_its_plans(cuda):
     """Train-mode forwards whose autograd graph is dropped (no backward) must not exhaust the pool of 4 plan sets."""
     m, _ = make_model("n", 2, dtype="f32")

@@ -41,6 +41,7 @@ struct PlanOp {
     float* z_out;
     bool has_deps = false;
     std::vector<int> deps;      // earlier op indices this op must wait for (true data dependencies)
+    int lane = YP_LANE_MAIN;    // YP_LANE_SIDE: runs beside the ops that follow it; YP_LANE_JOIN: waits for every side op first
 };
 
 struct YpPlan {
@@ -48,6 +49,8 @@ struct YpPlan {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     bool parallel = false;              // graph edges rewired to the data dependencies
+    hipStream_t side = nullptr;         // second lane (yp_plan_set_lane): stream + fork / join events, created on first use
+    hipEvent_t fork = nullptr, join = nullptr;
 };
 
 static int run_op(const PlanOp& op, hipStream_t st) {
@@ -75,6 +78,9 @@ extern "C" int yp_plan_destroy(YpPlan* plan) {
     if (!plan) return YP_OK;
     if (plan->exec) (void)hipGraphExecDestroy(plan->exec);
     if (plan->graph) (void)hipGraphDestroy(plan->graph);
+    if (plan->fork) (void)hipEventDestroy(plan->fork);
+    if (plan->join) (void)hipEventDestroy(plan->join);
+    if (plan->side) (void)hipStreamDestroy(plan->side);
     delete plan;
     return YP_OK;
 }
@@ -152,11 +158,49 @@ extern "C" int yp_plan_add_op(YpPlan* plan, const YpOpArgs* a) {
 
 extern "C" int yp_plan_num_ops(const YpPlan* plan) { return plan ? (int)plan->ops.size() : 0; }
 
+static int ensure_side(YpPlan* plan) {
+    if (plan->side) return YP_OK;
+    YP_CHECK_HIP(hipStreamCreateWithFlags(&plan->side, hipStreamNonBlocking));
+    YP_CHECK_HIP(hipEventCreateWithFlags(&plan->fork, hipEventDisableTiming));
+    YP_CHECK_HIP(hipEventCreateWithFlags(&plan->join, hipEventDisableTiming));
+    return YP_OK;
+}
+
+// Ops on YP_LANE_SIDE are issued on the plan's second stream: they wait for everything issued before them (fork event) and
+// nothing after them waits for them until an op on YP_LANE_JOIN (or the end of the plan).  Under stream capture the events become
+// graph edges, so the side ops form a parallel branch of the hipGraph.  Used by the training backward: the weight-gradient
+// kernels (one workgroup per CU, atomics-bound) run beside the dgrad / BatchNorm-backward chain, which never reads their output.
 static int run_eager(YpPlan* plan, hipStream_t st) {
+    bool pending = false;
     for (const PlanOp& op : plan->ops) {
+        if (op.lane == YP_LANE_SIDE) {
+            if (int rc = ensure_side(plan)) return rc;
+            YP_CHECK_HIP(hipEventRecord(plan->fork, st));
+            YP_CHECK_HIP(hipStreamWaitEvent(plan->side, plan->fork, 0));
+            const int rc = run_op(op, plan->side);
+            if (rc != YP_OK) return rc;
+            pending = true;
+            continue;
+        }
+        if (op.lane == YP_LANE_JOIN && pending) {
+            YP_CHECK_HIP(hipEventRecord(plan->join, plan->side));
+            YP_CHECK_HIP(hipStreamWaitEvent(st, plan->join, 0));
+            pending = false;
+        }
         const int rc = run_op(op, st);
         if (rc != YP_OK) return rc;
     }
+    if (pending) {
+        YP_CHECK_HIP(hipEventRecord(plan->join, plan->side));
+        YP_CHECK_HIP(hipStreamWaitEvent(st, plan->join, 0));
+    }
+    return YP_OK;
+}
+
+extern "C" int yp_plan_set_lane(YpPlan* plan, int op, int lane) {
+    YP_PLAN_MUTABLE(plan);
+    YP_REQUIRE(op >= 0 && op < (int)plan->ops.size() && lane >= YP_LANE_MAIN && lane <= YP_LANE_JOIN, "yp_plan_set_lane: bad argument");
+    plan->ops[op].lane = lane;
     return YP_OK;
 }
 
@@ -184,6 +228,8 @@ extern "C" int yp_plan_instantiate_graph(YpPlan* plan, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     YP_REQUIRE(st != nullptr, "yp_plan_instantiate_graph: capture needs a non-default stream");
     const size_t n = plan->ops.size();
+    for (const PlanOp& op : plan->ops)
+        if (op.lane == YP_LANE_SIDE) { if (int rc = ensure_side(plan)) return rc; break; }     // (no stream creation inside a capture)
     YP_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     const int rc = run_eager(plan, st);
     hipGraph_t g = nullptr;

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const char* __restrict_
     }
 }
 
-// fold partials -> mean / invstd (+ running statistics), or -> dgamma / dbeta.  One wavefront per channel: lanes
+// fold partials -> mean / invstd (+ running statistics), or -> dgamma / dbeta.  One workgroup per channel: threads
 // stride over the workgroup partials, then a butterfly reduction in double precision.
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
@@ -137,14 +137,21 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     }
     return v;
 }
+// (256 threads per channel: with one wavefront the 2048 partial rows of a large layer were 32 dependent round trips)
 __device__ __forceinline__ void fold_partials(const float* __restrict__ part, int nblk, int C, int c, double& s, double& ss) {
-    const int lane = threadIdx.x & 63;
+    __shared__ double fold_sh[8];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     double a = 0.0, b = 0.0;
-    for (int q = lane; q < nblk; q += 64) { a += part[((size_t)q * 2) * C + c]; b += part[((size_t)q * 2 + 1) * C + c]; }
-    s = wave_sum_d(a);
-    ss = wave_sum_d(b);
+#pragma unroll 4
+    for (int q = t; q < nblk; q += 256) { a += part[((size_t)q * 2) * C + c]; b += part[((size_t)q * 2 + 1) * C + c]; }
+    a = wave_sum_d(a);
+    b = wave_sum_d(b);
+    if (lane == 0) { fold_sh[2 * w] = a; fold_sh[2 * w + 1] = b; }
+    __syncthreads();
+    s = fold_sh[0] + fold_sh[2] + fold_sh[4] + fold_sh[6];
+    ss = fold_sh[1] + fold_sh[3] + fold_sh[5] + fold_sh[7];
 }
-__global__ __launch_bounds__(64) void bn_stats_finalize_kernel(const float* __restrict__ part, int nblk, int C, double M, float eps, float momentum,
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ part, int nblk, int C, double M, float eps, float momentum,
                                                                float* __restrict__ mean, float* __restrict__ invstd, float* running_mean,
                                                                float* running_var) {
     const int c = blockIdx.x;
@@ -163,7 +170,7 @@ __global__ __launch_bounds__(64) void bn_stats_finalize_kernel(const float* __re
     }
 }
 // o0 / o1 get the two column sums; when p0 / p1 are given they receive (or accumulate) them as well
-__global__ __launch_bounds__(64) void pair_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ o0, float* __restrict__ o1,
+__global__ __launch_bounds__(256) void pair_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ o0, float* __restrict__ o1,
                                                            float* p0, float* p1, int accumulate) {
     const int c = blockIdx.x;
     double s, ss;
@@ -623,7 +630,7 @@ extern "C" int yp_bn_stats(YpView raw, int dtype, int B, float eps, float moment
         YP_DT_SWITCH(dtype, (col_reduce_kernel<DT, 0><<<nblk, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, nullptr, 0, 0, M, raw.C,
                                                                             nullptr, nullptr, nullptr, nullptr, 0, (float*)ws)));
     }
-    bn_stats_finalize_kernel<<<raw.C, 64, 0, st>>>((const float*)ws, nblk, raw.C, (double)M, eps, momentum, mean, invstd,
+    bn_stats_finalize_kernel<<<raw.C, 256, 0, st>>>((const float*)ws, nblk, raw.C, (double)M, eps, momentum, mean, invstd,
                                                                running_mean, running_var);
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
@@ -678,7 +685,7 @@ extern "C" int yp_bn_act_bwd(YpView raw, YpView dy, YpView dx, int dtype, int B,
                                                                             dy.coff, M, raw.C, mean, invstd, gamma, beta, act, (float*)ws)));
     }
     // (sum dz, sum dz*xhat) -> this call's dbeta / dgamma, and (accumulated) into the parameter gradients
-    pair_finalize_kernel<<<raw.C, 64, 0, st>>>((const float*)ws, nblk, raw.C, db, dg, dbeta, dgamma, accumulate_param_grads);
+    pair_finalize_kernel<<<raw.C, 256, 0, st>>>((const float*)ws, nblk, raw.C, db, dg, dbeta, dgamma, accumulate_param_grads);
     const int g = grid_for(M * (raw.C / 8), 256);
     if (fastp) {
         const int gf = grid_for((M * (raw.C / 8) + 1) / 2, 256);
@@ -767,7 +774,7 @@ extern "C" int yp_col_sum(YpView v, int dtype, int B, float* out, int accumulate
     YP_DT_SWITCH(dtype, (col_reduce_kernel<DT, 0><<<nblk, 256, 0, st>>>((const char*)v.ptr, v.cstride, v.coff, nullptr, 0, 0, M, v.C, nullptr, nullptr,
                                                                         nullptr, nullptr, 0, (float*)ws)));
     (void)scratch;
-    pair_finalize_kernel<<<v.C, 64, 0, st>>>((const float*)ws, nblk, v.C, nullptr, nullptr, out, nullptr, accumulate);
+    pair_finalize_kernel<<<v.C, 256, 0, st>>>((const float*)ws, nblk, v.C, nullptr, nullptr, out, nullptr, accumulate);
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
 }

@@ -427,6 +427,10 @@ class PlanBuilder:
         self._track(reads, writes)
         self.records.append(OpRecord(self.name(name), "aux"))
 
+    def set_lane(self, lane):
+        """Put the op added last on a schedule lane (_hip.LANE_SIDE: beside the following ops; _hip.LANE_JOIN: after all side ops)."""
+        check(lib().yp_plan_set_lane(self.handle, lib().yp_plan_num_ops(self.handle) - 1, lane))
+
     def refresh(self):
         """Re-derive every packed weight from its source (call before each training step)."""
         for fn in self.refreshers:
