@@ -250,6 +250,13 @@ int yp_infonce_fwd(const float* da, const float* db, const int* idx, int n, int 
 int yp_infonce_bwd(const float* da, const float* db, const int* idx, const int* order, const int* offsets, const float* logits, int n, int E, int D,
                    const float* grad_scale_dev, float* w_scratch, float* dda, float* ddb, void* stream);
 
+/* The descriptor lookup in front of the InfoNCE loss: F.grid_sample(desc, uv, bilinear, align_corners=True, zero padding) at P
+ * points per image (reference utils/loss_functions.py:553-560).  map / gmap: [B,H,W,D] fp32, channels innermost (the layout the
+ * network emits; D % 64 == 0, D <= 256); uv [B*P,2] normalised (x, y); out / g [B*P, D].  gmap must be ZEROED by the caller; the
+ * backward accumulates with atomics. */
+int yp_points_sample_fwd(const float* map_nhwc, int B, int H, int W, int D, const float* uv, int P, float* out, void* stream);
+int yp_points_sample_bwd(const float* g, int B, int H, int W, int D, const float* uv, int P, float* gmap_nhwc, void* stream);
+
 /* YOLOv5 object loss of ONE Detect level, value and gradient (reference utils/loss_functions.py:90-176 ComputeLoss.__call__ body
  * of the per-level loop; CIoU: utils/metrics_yolo.py:202-240).  p / dp: [cells, no] fp32 with cells = B*na*ny*nx and no = 5 + nc;
  * the n (target, cell) entries of the level (reference build_targets, :178-234) arrive flattened: cell[e] = ((b*na+a)*ny+gj)*nx+gi,

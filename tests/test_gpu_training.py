@@ -212,6 +212,28 @@ def test_native_infonce_matches_torch_formulation(cuda, n, negs, D):
     assert rel_err(da.grad, ga)[1] < 1e-5 and rel_err(db.grad, gb)[1] < 1e-5
 
 
+@pytest.mark.parametrize("B,D,H,W,P", [(8, 256, 80, 80, 1500), (2, 64, 8, 12, 37), (1, 128, 16, 16, 300)])
+def test_native_point_sample_matches_grid_sample(cuda, B, D, H, W, P):
+    """csrc/losses.hip yp_points_sample_fwd / _bwd against F.grid_sample(bilinear, align_corners=True) + autograd (the descriptor
+    lookup of reference utils/loss_functions.py:553-560), points outside the map included."""
+    from yolopoint_amd.utils.loss_functions import _PointSampleNative
+    torch.manual_seed(B * D + P)
+    nhwc = torch.randn(B, H, W, D, device=cuda)
+    desc = nhwc.permute(0, 3, 1, 2).requires_grad_()                # NCHW view of channels-innermost memory, as the network emits
+    uv = torch.rand(B, P, 2, device=cuda) * 2.3 - 1.15              # some points fall outside [-1, 1]: zero padding
+    uv[0, 0] = torch.tensor([-1.0, 1.0]); uv[0, 1] = torch.tensor([1.0, -1.0])
+    proj = torch.randn(B, P, D, device=cuda)
+    ref = torch.nn.functional.grid_sample(desc, uv.unsqueeze(1), mode="bilinear", align_corners=True).squeeze(2).transpose(1, 2)
+    (ref * proj).sum().backward()
+    gref = desc.grad.clone()
+    desc.grad = None
+    got = _PointSampleNative.apply(desc, uv)
+    (got * proj).sum().backward()
+    assert got.shape == ref.shape
+    assert rel_err(got, ref)[0] < 1e-5
+    assert rel_err(desc.grad, gref)[0] < 1e-5
+
+
 class _DetStub:
     def __init__(self, nc, dev):
         self.na, self.nc, self.nl, self.no = 3, nc, 3, nc + 5
