@@ -1,0 +1,17 @@
+#!/bin/bash
+# Copy the distilled evidence of tools/profile_round.sh <round> from gpurun_out/prof_<round>/ into profiles/ (tracked).
+set -eu
+R=${1:-r01}
+S=gpurun_out/prof_$R
+cp $S/bench_default.json profiles/${R}_bench_infer.json
+cp $S/${R}_infer_kernel_trace.txt profiles/${R}_infer_kernel_trace.txt
+cp $S/${R}_collect.json profiles/${R}_pmc_collect.json
+cp $S/conv_traffic.json profiles/conv_traffic.json
+cp $S/layers.txt profiles/${R}_layers_infer.txt
+cp $S/bench_train.json profiles/${R}_bench_train.json
+cp $S/${R}_train_kernel_trace.txt profiles/${R}_train_kernel_trace.txt
+cp $S/train_fwd_ops.txt profiles/${R}_train_fwd_ops.txt
+cp $S/train_bwd_ops.txt profiles/${R}_train_bwd_ops.txt
+cp $S/bench_frame.json profiles/${R}_bench_frame.json
+cp $S/bench_export.json profiles/${R}_bench_export.json
+ls -la profiles/

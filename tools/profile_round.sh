@@ -22,6 +22,10 @@ python bench.py --mode train --steps 20 --warmup 3 > $OUT/bench_train.json 2> $O
 cd /tmp
 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_train -o t -- python $ROOT/bench.py --mode train --steps 5 --warmup 2 > $OUT/trace_train.log 2>&1
 cd $ROOT
+python tools/train_bench.py > $OUT/train_bench.log 2>&1
+cp gpurun_out/train_fwd_ops.txt gpurun_out/train_bwd_ops.txt $OUT/ 2>/dev/null
+python bench.py --mode frame --version l --size 1280 > $OUT/bench_frame.json 2> $OUT/bench_frame.err
+python bench.py --mode export > $OUT/bench_export.json 2> $OUT/bench_export.err
 python tools/profile_collect.py $R
 # raw traces are large: keep only what profile_collect distilled
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/trace_train
