@@ -85,6 +85,22 @@ def main():
     if tt:
         d, tl = trace_table(tt, 7, "rocprofv3 --kernel-trace of: python bench.py --mode train --steps 5 --warmup 2 (7 optimizer steps + plan build/autotune)", steady=False)
         open(os.path.join(OUT, f"{R}_train_kernel_trace.txt"), "w").write("\n".join(tl[:80]) + "\n")
+        # one steady-state optimizer step: the dispatches between the last two Adam kernels
+        rows = sorted(csv.DictReader(open(tt)), key=lambda r: int(r["Start_Timestamp"]))
+        adam = [i for i, r in enumerate(rows) if "FusedAdam" in r["Kernel_Name"] or "fused_adam" in r["Kernel_Name"].lower()]
+        ends = [i for i in adam if i + 1 >= len(rows) or (i + 1) not in set(adam)]       # last kernel of each step's optimizer run
+        if len(ends) >= 2:
+            win = rows[ends[-2] + 1:ends[-1] + 1]
+            agg = collections.defaultdict(list)
+            for r in win:
+                agg[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            tot = sum(sum(v) for v in agg.values())
+            span = int(win[-1]["End_Timestamp"]) - int(win[0]["Start_Timestamp"])
+            sl = [f"# ONE steady-state training step (dispatches between the last two Adam kernels): {len(win)} kernels, busy {tot / 1e3:.0f} us, "
+                  f"span {span / 1e3:.0f} us", f"{'kernel':102s} {'calls':>7s} {'total_us':>11s} {'avg_us':>9s} {'%':>6s}"]
+            for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+                sl.append(f"{k:102s} {len(v):7d} {sum(v) / 1e3:11.1f} {sum(v) / len(v) / 1e3:9.2f} {100 * sum(v) / tot:6.2f}")
+            open(os.path.join(OUT, f"{R}_train_step_kernels.txt"), "w").write("\n".join(sl[:70]) + "\n")
     json.dump(res, open(os.path.join(OUT, f"{R}_collect.json"), "w"), indent=1)
     print(json.dumps(res, indent=1))
 

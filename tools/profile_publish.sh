@@ -10,6 +10,7 @@ cp $S/conv_traffic.json profiles/conv_traffic.json
 cp $S/layers.txt profiles/${R}_layers_infer.txt
 cp $S/bench_train.json profiles/${R}_bench_train.json
 cp $S/${R}_train_kernel_trace.txt profiles/${R}_train_kernel_trace.txt
+cp $S/${R}_train_step_kernels.txt profiles/${R}_train_step_kernels.txt
 cp $S/train_fwd_ops.txt profiles/${R}_train_fwd_ops.txt
 cp $S/train_bwd_ops.txt profiles/${R}_train_bwd_ops.txt
 cp $S/bench_frame.json profiles/${R}_bench_frame.json

@@ -227,8 +227,9 @@ __global__ __launch_bounds__(256) void points_sample_bwd_kernel(const float* __r
 // utils/metrics_yolo.py:202-240), value AND gradient in three launches instead of ~330 tiny PyTorch kernels per level:
 //   objloss_init    dp = 0, owner = -1
 //   objloss_targets one thread per (target, cell) entry: decode the box, CIoU against the target box with forward-mode dual
-//                   numbers (4 inputs), class BCE; gradients are atomically added to dp (a cell can be claimed twice), the
+//                   numbers (4 inputs); gradients are atomically added to dp (a cell can be claimed twice), the
 //                   clamped IoU is kept per entry and the LAST entry of a cell becomes its owner (index_put semantics)
+//   objloss_cls     one thread per (entry, class): class BCE of the claimed cells (nc > 1)
 //   objloss_cells   one thread per cell: objectness BCE against tobj = IoU of the owner (0 without), gradient into channel 4
 // sums[0..2] accumulate the weighted box / obj / cls terms (weights = hyp gain x level balance, folded on the host).
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -286,13 +287,12 @@ __global__ __launch_bounds__(256) void objloss_init_kernel(float* __restrict__ d
     if (i < (size_t)cells) owner[i] = -1;
 }
 
-__global__ __launch_bounds__(256) void objloss_targets_kernel(const float* __restrict__ p, int no, int nc, const int* __restrict__ cell, const float* __restrict__ tbox,
-                                                              const float* __restrict__ anch, const int* __restrict__ tcls, int n, float cp, float cn, float cls_pw,
-                                                              float w_box, float w_cls, float* __restrict__ iou_e, int* __restrict__ owner, float* __restrict__ dp,
-                                                              float* __restrict__ sums) {
+__global__ __launch_bounds__(256) void objloss_targets_kernel(const float* __restrict__ p, int no, const int* __restrict__ cell, const float* __restrict__ tbox,
+                                                              const float* __restrict__ anch, int n, float w_box, float* __restrict__ iou_e,
+                                                              int* __restrict__ owner, float* __restrict__ dp, float* __restrict__ sums) {
     __shared__ float sh[4];
     const int e = blockIdx.x * 256 + threadIdx.x;
-    float lb = 0.f, lc = 0.f;
+    float lb = 0.f;
     if (e < n) {
         const int c = cell[e];
         const float* row = p + (size_t)c * no;
@@ -320,22 +320,27 @@ __global__ __launch_bounds__(256) void objloss_targets_kernel(const float* __res
         atomicMax(owner + c, e);
 #pragma unroll
         for (int k = 0; k < 4; ++k) atomicAdd(drow + k, -ciou.d[k] * w_box);
-        if (nc > 1) {
-            const int tc = tcls[e];
-            for (int k = 0; k < nc; ++k) {
-                float l, g;
-                bce_pw(row[5 + k], k == tc ? cp : cn, cls_pw, l, g);
-                lc += l * w_cls;
-                atomicAdd(drow + 5 + k, g * w_cls);
-            }
-        }
     }
     lb = block_sum_256(lb, sh);
-    lc = block_sum_256(lc, sh);
-    if (threadIdx.x == 0) {
-        atomicAdd(sums + 0, lb);
-        if (nc > 1) atomicAdd(sums + 2, lc);
+    if (threadIdx.x == 0) atomicAdd(sums + 0, lb);
+}
+
+// class BCE of the claimed cells, one thread per (entry, class): a per-entry loop over 80 classes is 80 dependent global loads
+__global__ __launch_bounds__(256) void objloss_cls_kernel(const float* __restrict__ p, int no, int nc, const int* __restrict__ cell, const int* __restrict__ tcls, int n,
+                                                          float cp, float cn, float cls_pw, float w_cls, float* __restrict__ dp, float* __restrict__ sums) {
+    __shared__ float sh[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float lc = 0.f;
+    if (i < n * nc) {
+        const int e = i / nc, k = i - e * nc;
+        const size_t at = (size_t)cell[e] * no + 5 + k;
+        float l, g;
+        bce_pw(p[at], k == tcls[e] ? cp : cn, cls_pw, l, g);
+        lc = l * w_cls;
+        atomicAdd(dp + at, g * w_cls);
     }
+    lc = block_sum_256(lc, sh);
+    if (threadIdx.x == 0) atomicAdd(sums + 2, lc);
 }
 
 __global__ __launch_bounds__(256) void objloss_cells_kernel(const float* __restrict__ p, int no, int cells, const int* __restrict__ owner, const float* __restrict__ iou_e,
@@ -396,9 +401,11 @@ extern "C" int yp_objloss_level(const float* p, int cells, int no, int nc, const
     hipStream_t st = (hipStream_t)stream;
     const size_t nf = (size_t)cells * no, n4 = (nf + 3) / 4;
     objloss_init_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, st>>>(dp, nf, owner_scratch, cells);
-    if (n > 0)
-        objloss_targets_kernel<<<(n + 255) / 256, 256, 0, st>>>(p, no, nc, cell, tbox, anch, tcls, n, cp, cn, cls_pw, w_box / n,
-                                                                 nc > 1 ? w_cls / ((float)n * nc) : 0.f, iou_scratch, owner_scratch, dp, sums);
+    if (n > 0) {
+        objloss_targets_kernel<<<(n + 255) / 256, 256, 0, st>>>(p, no, cell, tbox, anch, n, w_box / n, iou_scratch, owner_scratch, dp, sums);
+        if (nc > 1)
+            objloss_cls_kernel<<<(n * nc + 255) / 256, 256, 0, st>>>(p, no, nc, cell, tcls, n, cp, cn, cls_pw, w_cls / ((float)n * nc), dp, sums);
+    }
     objloss_cells_kernel<<<(cells + 255) / 256, 256, 0, st>>>(p, no, cells, owner_scratch, iou_scratch, obj_pw, w_obj / cells, dp, sums);
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;

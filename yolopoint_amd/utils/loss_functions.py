@@ -321,10 +321,12 @@ def infonce_edges(rnd):
     column, CSR offsets [n+1]): the backward of the native kernel walks the transposed edge list instead of scattering."""
     n = rnd.shape[0]
     idx = torch.cat((torch.arange(n, device=rnd.device).unsqueeze(1), rnd), 1).to(torch.int32).contiguous()
-    flat = idx.flatten().long()
-    order = torch.sort(idx.flatten(), stable=True).indices.to(torch.int32)        # (int32 keys: half the radix passes of int64)
-    offsets = torch.zeros(n + 1, dtype=torch.int32, device=rnd.device)
-    offsets[1:] = torch.cumsum(torch.bincount(flat, minlength=n), 0).to(torch.int32)
+    # stable sort of the column ids; int16 keys when they fit (2 radix passes instead of the 8 of int64), CSR offsets by binary
+    # search in the sorted keys (bincount's atomics histogram was 0.2 ms)
+    keys = idx.flatten().to(torch.int16) if n < 32768 else idx.flatten()
+    skeys, order = torch.sort(keys, stable=True)
+    order = order.to(torch.int32)
+    offsets = torch.searchsorted(skeys, torch.arange(n + 1, device=rnd.device, dtype=skeys.dtype)).to(torch.int32)
     return idx, order, offsets
 
 
