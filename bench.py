@@ -270,8 +270,9 @@ def bench_train(a, rank, world, dev):
         "value": round(2 * samples / wall, 1), "unit": "images/s", "samples_per_s": round(samples / wall, 1), "n_gpus": world, "steps": steps,
         "warmup": warmup, "ms_per_step": round(wall / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": dtype, "data": "synthetic",
-        "config": {"workload": f"BASELINE.json configs[2] shape: YOLOPoint-{a.version} optimizer step as src/train.py:189-259 (2 forwards, detector + object + "
-                               f"InfoNCE losses in PyTorch autograd, native backward, gradient all-reduce, Adam), {a.batch} samples/GPU, {a.size}x{a.size}",
+        "config": {"workload": f"BASELINE.json configs[{4 if a.version == 'l' else 2}] shape{' in bf16 (fp8 not built)' if a.version == 'l' else ''}: "
+                               f"YOLOPoint-{a.version} optimizer step as src/train.py:189-259 (2 forwards, detector + object + InfoNCE losses through "
+                               f"csrc/losses.hip, native backward, gradient all-reduce, fused Adam), {a.batch} samples/GPU, {a.size}x{a.size}",
                    "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
                    "grad_allreduce_bytes": step.reducer.payload_bytes()},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS["bf16"], 4),
