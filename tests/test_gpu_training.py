@@ -298,6 +298,31 @@ def test_two_lane_backward_matches_single_lane(cuda, monkeypatch):
         assert rel_err(a, b)[1] < 1e-4          # fp32 atomics: the accumulation order differs run to run
 
 
+@pytest.mark.parametrize("fused", [False, True])
+def test_forward_sees_optimizer_updates(cuda, fused):
+    """torch.optim.Adam(fused=True) updates parameters without bumping Tensor._version: the packed filters of the training plans and
+    the cached inference plan must still be re-derived after every optimizer step (they key on the optimizer-step count too)."""
+    m, _ = make_model("n", 9, dtype="f32")
+    m = m.to(cuda).train()
+    opt = torch.optim.Adam(m.parameters(), lr=0.05, fused=fused)
+    x = net_oracle.synth_image(2, 3, 64, 64, 6).to(cuda)
+    o0 = m(x)
+    (o0["semi"].square().mean() + o0["desc"].square().mean() + sum(t.square().mean() for t in o0["objects"])).backward()
+    semi0 = o0["semi"].detach().clone()
+    opt.step()
+    with torch.no_grad():
+        semi1 = m(x)["semi"]
+        sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+        ref = net_oracle.yolopoint_forward(sd, x.cpu(), "n", training=True)["semi"]
+    assert rel_err(semi1, semi0)[1] > 1e-3                       # a step of lr 0.05 moves the output
+    m.eval()
+    with torch.no_grad():
+        ev = m(x)["semi"]
+        ref_ev = net_oracle.yolopoint_forward(sd, x.cpu(), "n")["semi"]
+    assert rel_err(ev, ref_ev)[1] < 1e-3                         # eval plan rebuilt from the UPDATED parameters
+    assert rel_err(semi1, ref)[1] < 1e-3                         # train-mode forward ran on the UPDATED filters
+
+
 def test_train_forward_without_backward_releases_its_plans(cuda):
     """Train-mode forwards whose autograd graph is dropped (no backward) must not exhaust the pool of 4 plan sets."""
     m, _ = make_model("n", 2, dtype="f32")

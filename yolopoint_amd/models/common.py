@@ -37,13 +37,33 @@ def fold_bn(conv, bn):
     return wf, bf
 
 
+_GENERATION = [0]
+
+
+def weights_generation():
+    """Number of optimizer steps taken in this process (any optimizer): see HipModule._weights_version."""
+    return _GENERATION[0]
+
+
+def _count_optimizer_step(*_args, **_kwargs):
+    _GENERATION[0] += 1
+
+
+from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook  # noqa: E402
+
+_register_step_hook(_count_optimizer_step)
+
+
 class HipModule(nn.Module):
     """Base class: standalone forward through a cached native plan."""
 
     compute_dtype = "f16"
 
     def _weights_version(self):
-        v = 0
+        """Changes whenever the parameters / buffers may have changed: tensor version counters and storage addresses, plus the
+        process-wide optimizer-step count -- fused optimizers (torch.optim.Adam(fused=True)) update parameters WITHOUT bumping
+        Tensor._version, so a key built on the counters alone keeps replaying plans packed from the old filters."""
+        v = weights_generation() * 1000003
         for t in list(self.parameters()) + list(self.buffers()):
             v += t._version + (t.data_ptr() % 1000003)
         return v

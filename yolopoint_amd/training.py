@@ -25,6 +25,7 @@ import torch
 from . import _hip
 from ._hip import lib, check
 from .plan import PlanBuilder, Buf, View, MasterWeight, round_up, pack_input
+from .models.common import weights_generation
 
 
 class TrainGraph:
@@ -442,7 +443,8 @@ class TrainGraph:
     # ------------------------------------------------------------------ run
     def forward(self, x):
         # packed weights (forward + dgrad) are re-derived only when an optimizer step (or a load) changed the masters
-        ver = sum(p_._version for p_ in self.params)
+        # (the optimizer-step count is part of the key: fused optimizers do not bump Tensor._version)
+        ver = sum(p_._version for p_ in self.params) + weights_generation() * 1000003
         if ver != getattr(self, "_packed_version", None):      # host-packed filters of this graph (stem, Detect)
             self.fwd_plan.refresh()
             self.bwd_plan.refresh()
