@@ -25,7 +25,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import torch  # noqa: E402
 
@@ -52,7 +51,7 @@ def parse():
 
 
 def build_model(version, dtype, dev):
-    from helpers import make_model
+    from yolopoint_amd.utils.synthetic import make_model
     m, sd = make_model(version, 1234, dtype=dtype)
     m = m.to(dev)
     m.fuse()                          # inference path: BN folded (reference demo.py:48-49)
@@ -64,8 +63,8 @@ def cpu_baseline(version, B, S, budget_s=14.0):
     """Oracle forward on the host cores (PyTorch-CPU fp32, eval).  Bounded sample: the thread count is picked by a
     short probe (oversubscribing a 256-thread host makes ATen's small convolutions crawl), then up to 10 timed
     iterations or `budget_s` seconds of the same workload."""
-    from oracle import net_oracle
-    from helpers import NAMES80, layout_of
+    from oracle import net_oracle                     # the CPU baseline IS the oracle's forward; nothing else in this file touches oracle/
+    from yolopoint_amd.utils.synthetic import NAMES80, layout_of
     from yolopoint_amd import models
     cores = os.cpu_count() or 1
     layout = layout_of(models.Model(names=NAMES80, version=version))
@@ -119,8 +118,8 @@ def main():
     m, _ = build_model(a.version, a.dtype, dev)
     net = m.model
     B, S = a.batch, a.size
-    from oracle import net_oracle  # synthetic image generator only (data, not compute)
-    x = net_oracle.synth_image(B, 3, S, S, 1234 + rank).to(dev)
+    from yolopoint_amd.utils.synthetic import synth_image
+    x = synth_image(B, 3, S, S, 1234 + rank).to(dev)
     from yolopoint_amd.plan import pack_input
 
     stream = torch.cuda.Stream(device=dev)
@@ -242,7 +241,7 @@ def bench_train(a, rank, world, dev):
     """BASELINE.json configs[2] shape: YOLOPoint-s training, per-GPU batch a.batch (8 -> global 64 on 8 GPUs), 640x640,
     bf16 compute: two forwards + detector/object/InfoNCE losses + backward + bucketed gradient all-reduce + Adam per step."""
     import torch.distributed as dist
-    from helpers import make_model
+    from yolopoint_amd.utils.synthetic import make_model
     from yolopoint_amd.engine import TrainStep, synthetic_batch
     from yolopoint_amd.dp import timed_region
     dtype = a.dtype if a.dtype != "f16" else "bf16"
@@ -286,16 +285,16 @@ def bench_frame(a, dev):
     Random-weight heads: the keypoint / box counts are whatever the seed gives (reported), thresholds are the reference's."""
     from yolopoint_amd.frontend import YoloPointFrontend
     from yolopoint_amd.models.model_wrap import PointTracker
-    from oracle import net_oracle
+    from yolopoint_amd.utils.synthetic import synth_image
     m, _ = build_model(a.version, a.dtype, dev)
     S = a.size
     fe = YoloPointFrontend(m, dev, yolo_config=dict(conf_thres_box=0.25, iou_thres_box=0.45, max_det=300), filter_pts=True)
-    frames = [net_oracle.synth_image(1, 3, S, S, 100 + i).to(dev) for i in range(4)]
+    frames = [synth_image(1, 3, S, S, 100 + i).to(dev) for i in range(4)]
     # Seeded random heads saturate (every pixel a keypoint, every anchor a box), which is not the load of a trained model: the
     # network runs in full, but the post-processing is fed PLANTED head outputs (SURVEY.md 8(d)): a heat map with
     # 1000 x (S/640)^2 Gaussian peaks over U(0, 0.01) noise (as logits of the 65-channel cell softmax) and 2000 box candidates.
     import numpy as np
-    from helpers import planted_heatmap, planted_predictions
+    from yolopoint_amd.utils.synthetic import planted_heatmap, planted_predictions
     nrows = sum(3 * (S // st) ** 2 for st in (8, 16, 32))
     semis, preds = [], []
     for i in range(len(frames)):
@@ -350,7 +349,7 @@ def bench_export(a, dev):
     decode, aggregation of the 100 heat maps in the base frame, threshold + grid NMS, points to the host."""
     import numpy as np
     from yolopoint_amd.export_homography import HomographyExporter
-    from oracle import net_oracle
+    from yolopoint_amd.utils.synthetic import synth_image
     N, S = 100, a.size
     m, _ = build_model(a.version, a.dtype, dev)
     exp = HomographyExporter(m, dev, dict(nms=4, top_k=1000, detection_threshold=0.085))
@@ -363,13 +362,13 @@ def bench_export(a, dev):
     homs[0] = np.eye(3)
     inv = torch.from_numpy(np.linalg.inv(homs.astype(np.float64)).astype(np.float32)).to(dev)
     from yolopoint_amd.utils.loss_functions import warp_image_batch
-    base = net_oracle.synth_image(1, 3, S, S, 9).to(dev)
+    base = synth_image(1, 3, S, S, 9).to(dev)
     views = warp_image_batch(base.repeat(N, 1, 1, 1), torch.from_numpy(homs).to(dev), device=dev).contiguous()
     mask = warp_image_batch(torch.ones(N, 1, S, S, device=dev), torch.from_numpy(homs).to(dev), device=dev, mode="nearest").contiguous()
     sample = {"image": views[None], "valid_mask": mask.view(1, N, S, S), "inv_homographies": inv[None]}
     # random-weight heads give a flat heat map (no point reaches 0.085): the network runs in full, the aggregation / decode is fed
     # planted keypoint logits (1000 x (S/640)^2 peaks in the base frame, SURVEY.md 8d, warped into every view), as in --mode frame
-    from helpers import planted_heatmap
+    from yolopoint_amd.utils.synthetic import planted_heatmap
     heat = torch.from_numpy(planted_heatmap(S, S, int(1000 * (S / 640) ** 2), 10).astype(np.float32)).to(dev)
     hv = warp_image_batch(heat[None, None].repeat(N, 1, 1, 1), torch.from_numpy(homs).to(dev), device=dev)          # the peaks as each view sees them
     cells = torch.nn.functional.pixel_unshuffle(hv, 8).double()                                                       # [N,64,S/8,S/8]
@@ -407,7 +406,7 @@ def bench_export(a, dev):
 def bench_postproc(dev):
     """Post-processing kernels on planted head outputs; microseconds per call, GPU events."""
     import numpy as np
-    from helpers import planted_heatmap, planted_predictions, planted_descriptors
+    from yolopoint_amd.utils.synthetic import planted_heatmap, planted_predictions, planted_descriptors
     from yolopoint_amd.utils import utils as U
     from yolopoint_amd.utils.general_yolo import non_max_suppression
     from yolopoint_amd.models.model_wrap import PointTracker

@@ -169,38 +169,6 @@ def fuse_conv_bn(w, gamma, beta, mean, var, eps=BN_EPS):
 
 
 # ---------------------------------------------------------------------------------------------
-# deterministic synthetic weights (numpy PCG64 streams: identical here and on the GPU box)
+# deterministic synthetic weights / images: data generators shared with the benchmarks (yolopoint_amd/utils/synthetic.py)
 # ---------------------------------------------------------------------------------------------
-def synth_state_dict(layout, seed):
-    """layout: list of (key, shape) in reference state_dict order -> fp32 tensors.  BN affine /
-    running statistics are randomised so that BN folding is exercised."""
-    import numpy as np
-    sd = {}
-    for idx, (key, shape) in enumerate(layout):
-        rng = np.random.default_rng([seed, idx])
-        shape = tuple(shape)
-        if key.endswith("num_batches_tracked"):
-            sd[key] = torch.tensor(0, dtype=torch.int64)
-            continue
-        if key.endswith("anchors"):
-            a = torch.tensor(ANCHORS, dtype=torch.float32).view(3, 3, 2)
-            sd[key] = a / torch.tensor(STRIDES).view(3, 1, 1)
-            continue
-        if key.endswith("running_var"):
-            v = rng.uniform(0.5, 1.5, shape)
-        elif key.endswith("running_mean"):
-            v = rng.normal(0.0, 0.1, shape)
-        elif key.endswith("bn.weight"):
-            v = rng.uniform(0.7, 1.3, shape)
-        elif key.endswith("bn.bias") or key.endswith(".bias"):
-            v = rng.normal(0.0, 0.1, shape)
-        else:   # conv weight OIHW: He-style scale keeps activations O(1) through ~30 layers
-            fan_in = shape[1] * shape[2] * shape[3]
-            v = rng.normal(0.0, 1.0, shape) * (1.6 / math.sqrt(fan_in))
-        sd[key] = torch.from_numpy(np.asarray(v, dtype=np.float32).reshape(shape))
-    return sd
-
-
-def synth_image(B, C, H, W, seed):
-    import numpy as np
-    return torch.from_numpy(np.random.default_rng([seed, 777]).random((B, C, H, W), dtype=np.float32))
+from yolopoint_amd.utils.synthetic import synth_state_dict, synth_image  # noqa: E402,F401

@@ -5,20 +5,8 @@ import torch
 from oracle import net_oracle
 from yolopoint_amd import models
 
-NAMES80 = [str(i) for i in range(80)]
-
-
-def layout_of(model):
-    return [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
-
-
-def make_model(version, seed, names=NAMES80, dtype="f32", model_name="YOLOPoint"):
-    """Product model + the synthetic reference-layout state_dict loaded into it."""
-    m = models.Model(names=names, model_name=model_name, version=version)
-    sd = net_oracle.synth_state_dict(layout_of(m), seed)
-    m.load_state_dict(sd, strict=True)
-    m.set_compute_dtype(dtype)
-    return m.eval(), sd
+from yolopoint_amd.utils.synthetic import (NAMES80, layout_of, make_model, planted_heatmap, planted_predictions,  # noqa: F401
+                                           planted_descriptors, tracking_sequence)
 
 
 def block_state(module, seed, prefix=""):
@@ -45,85 +33,3 @@ TOL = {"f32": 1e-4, "f16": 4e-3, "bf16": 3e-2}
 # ---------------------------------------------------------------------------------------------
 # planted post-processing inputs (random-init heads give degenerate workloads)
 # ---------------------------------------------------------------------------------------------
-def planted_heatmap(H, W, npeaks, seed, noise=0.01, sigma=1.5):
-    """Gaussian peaks of distinct heights over U(0, noise) background; every pixel value distinct."""
-    rng = np.random.default_rng(seed)
-    heat = rng.random((H, W)).astype(np.float64) * noise
-    ys, xs = rng.integers(0, H, npeaks), rng.integers(0, W, npeaks)
-    amp = rng.uniform(0.1, 0.9, npeaks)
-    r = int(3 * sigma) + 1
-    for y, x, a in zip(ys, xs, amp):
-        y0, y1, x0, x1 = max(0, y - r), min(H, y + r + 1), max(0, x - r), min(W, x + r + 1)
-        yy, xx = np.mgrid[y0:y1, x0:x1]
-        heat[y0:y1, x0:x1] += a * np.exp(-((yy - y) ** 2 + (xx - x) ** 2) / (2 * sigma ** 2))
-    heat = (heat / heat.max() * 0.95).astype(np.float32)
-    # make all fp32 values distinct so that sort order is total (parity is defined on distinct scores)
-    flat = heat.ravel()
-    order = np.argsort(flat, kind="stable")
-    u = flat[order].copy()
-    for i in range(1, len(u)):
-        if u[i] <= u[i - 1]:
-            u[i] = np.nextafter(u[i - 1], np.float32(2), dtype=np.float32)
-    flat[order] = u
-    return flat.reshape(H, W)
-
-
-def planted_predictions(B, N, nc, ncand, seed, img=640):
-    """[B,N,5+nc] decoded predictions: `ncand` rows per image with high objectness in overlapping clusters."""
-    rng = np.random.default_rng(seed)
-    p = np.zeros((B, N, 5 + nc), dtype=np.float32)
-    p[..., 4] = rng.uniform(0.0, 0.2, (B, N))
-    p[..., 5:] = rng.uniform(0.0, 0.3, (B, N, nc))
-    p[..., 0:2] = rng.uniform(0, img, (B, N, 2))
-    p[..., 2:4] = rng.uniform(8, 64, (B, N, 2))
-    for b in range(B):
-        rows = rng.choice(N, ncand, replace=False)
-        nclust = max(1, ncand // 6)
-        centres = rng.uniform(0.1 * img, 0.9 * img, (nclust, 2))
-        sizes = np.exp(rng.uniform(np.log(0.03 * img), np.log(0.4 * img), (nclust, 2)))
-        cl = rng.integers(0, nclust, ncand)
-        p[b, rows, 0:2] = centres[cl] + rng.normal(0, 0.08, (ncand, 2)) * sizes[cl]
-        p[b, rows, 2:4] = sizes[cl] * np.exp(rng.normal(0, 0.15, (ncand, 2)))
-        p[b, rows, 4] = rng.uniform(0.3, 1.0, ncand)
-        cls_main = rng.integers(0, nc, nclust)[cl]
-        p[b, rows, 5 + cls_main] = rng.uniform(0.5, 1.0, ncand)
-        second = (cls_main + 1 + rng.integers(0, max(nc - 1, 1), ncand)) % nc
-        p[b, rows, 5 + second] = np.maximum(p[b, rows, 5 + second], rng.uniform(0.2, 0.9, ncand))
-    return p
-
-
-def planted_descriptors(D, N1, N2, frac, seed, noise=0.2):
-    """Unit descriptors with `frac` planted correspondences (d2 = normalise(d1 + noise*g), permuted)."""
-    rng = np.random.default_rng(seed)
-    d1 = rng.normal(size=(D, N1)).astype(np.float32)
-    d1 /= np.linalg.norm(d1, axis=0, keepdims=True)
-    d2 = rng.normal(size=(D, N2)).astype(np.float32)
-    nmatch = int(min(N1, N2) * frac)
-    src = rng.choice(N1, nmatch, replace=False)
-    dst = rng.choice(N2, nmatch, replace=False)
-    d2[:, dst] = d1[:, src] + noise * rng.normal(size=(D, nmatch)).astype(np.float32) / np.sqrt(D)
-    d2 /= np.linalg.norm(d2, axis=0, keepdims=True)
-    return d1.astype(np.float32), d2.astype(np.float32)
-
-
-def tracking_sequence(D, frames, N, seed, keep=0.7, noise=0.15):
-    """A sequence of (pts [3,n] float64, desc [D,n] float32 unit columns): each frame carries `keep` of the previous frame's
-    points over (descriptor + noise, position + 1 px, shuffled) and adds new ones; n varies per frame."""
-    rng = np.random.default_rng(seed)
-    out, prev = [], None
-    for f in range(frames):
-        n = int(N * rng.uniform(0.8, 1.2))
-        d = rng.normal(size=(D, n)).astype(np.float32)
-        xy = rng.uniform(8, 300, size=(2, n)).round()
-        if prev is not None:
-            pd, pxy = prev
-            k = min(int(pd.shape[1] * keep), n)
-            src = rng.choice(pd.shape[1], k, replace=False)
-            dst = rng.choice(n, k, replace=False)
-            d[:, dst] = pd[:, src] + noise * rng.normal(size=(D, k)).astype(np.float32) / np.sqrt(D)
-            xy[:, dst] = pxy[:, src] + 1.0
-        d /= np.linalg.norm(d, axis=0, keepdims=True)
-        pts = np.vstack((xy, rng.uniform(0.02, 1.0, size=(1, n))))
-        out.append((pts.astype(np.float64), d.astype(np.float32)))
-        prev = (d, xy)
-    return out

@@ -92,21 +92,28 @@ def train(version, S, steps, B, device, seed=0, lr=2e-3, log=None):
     return m
 
 
-def evaluate(m, version, S, n_images, device, conf=0.001, iou=0.6, seed=50_000, chunk=16):
-    """-> dict(map50_cpu, map_cpu, map50_hip, map_hip, n_cpu, n_hip): mAP of the CPU oracle and of the HIP path on the same images."""
+def evaluate(m, version, S, n_images, device, conf=0.001, iou=0.6, seed=50_000, chunk=16, kp_thresh=0.015, kp_nms=4):
+    """mAP (IoU .5 and .5:.95, 101-point, reference metric definitions) and keypoint repeatability (k = 300, 3 px) of the CPU oracle and
+    of the HIP path on the same fresh images against the same ground truth -> dict(map50_*, map_*, rep_*, n_*)."""
     from oracle import net_oracle, postproc_oracle as po, eval_oracle as eo
+    from yolopoint_amd.utils import utils as U
     from yolopoint_amd.utils.general_yolo import non_max_suppression
+    from yolopoint_amd.utils.loss_functions import warp_image_batch
     sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
     m.set_compute_dtype("f16")
     m = m.to(device).eval()
     iouv = np.linspace(0.5, 0.95, 10).astype(np.float32)
-    stats = {"cpu": [], "hip": []}
+    th = 0.05
+    Hn = torch.tensor([[np.cos(th), -np.sin(th), 0.04], [np.sin(th), np.cos(th), -0.03], [0.02, 0.01, 1.0]], dtype=torch.float32)
+    Hinv = torch.linalg.inv(Hn)
+    stats, reps, npts = {"cpu": [], "hip": []}, {"cpu": [], "hip": []}, {"cpu": 0, "hip": 0}
     for c in range(0, n_images, chunk):
         batch = shapes_batch(chunk, S, device, seed + c)
         img, lab = batch["image"].cpu(), batch["box_labels"].cpu().numpy()
+        wimg = warp_image_batch(img, Hinv.repeat(chunk, 1, 1), mode="bilinear").contiguous()
         with torch.no_grad():
-            ref = net_oracle.yolopoint_forward(sd, img, version)
-            got = m(img.to(device))
+            ref, refw = net_oracle.yolopoint_forward(sd, img, version), net_oracle.yolopoint_forward(sd, wimg, version)
+            got, gotw = m(img.to(device)), m(wimg.to(device))
         det_cpu = po.non_max_suppression(ref["objects"][0].numpy(), conf, iou, agnostic=False, multi_label=True, max_det=300)
         det_hip = [d.cpu().numpy() for d in non_max_suppression(got["objects"][0], conf, iou, labels=[], multi_label=True, agnostic=False, max_det=300)]
         for b in range(chunk):
@@ -116,11 +123,20 @@ def evaluate(m, version, S, n_images, device, conf=0.001, iou=0.6, seed=50_000, 
             for name, dets in (("cpu", det_cpu[b]), ("hip", det_hip[b])):
                 tp = eo.process_batch(dets, labels, iouv) if len(dets) else np.zeros((0, 10), bool)
                 stats[name].append((tp, dets[:, 4], dets[:, 5], labels[:, 0]))
+            data = dict(image=np.zeros((3, S, S), np.float32), homography=Hn.numpy(), inv_homography=Hinv.numpy())
+            p1 = po.get_pts_from_semi(ref["semi"][b].numpy(), kp_thresh, kp_nms).T
+            p2 = po.get_pts_from_semi(refw["semi"][b].numpy(), kp_thresh, kp_nms).T
+            q1 = U.getPtsFromSemi(got["semi"][b], kp_thresh, kp_nms).T
+            q2 = U.getPtsFromSemi(gotw["semi"][b], kp_thresh, kp_nms).T
+            reps["cpu"].append(eo.compute_repeatability(dict(data, prob=p1, warped_prob=p2))[0])
+            reps["hip"].append(eo.compute_repeatability(dict(data, prob=q1, warped_prob=q2))[0])
+            npts["cpu"] += len(p1); npts["hip"] += len(q1)
     out = {}
     for name, st in stats.items():
         tp, cf, pc, tc = (np.concatenate(x) for x in zip(*st))
         ap, _ = eo.ap_per_class(tp, cf, pc, tc)
         out[f"map50_{name}"], out[f"map_{name}"], out[f"n_{name}"] = 100 * float(ap[:, 0].mean()), 100 * float(ap.mean()), int(len(cf))
+        out[f"rep_{name}"], out[f"kpts_{name}"] = 100 * float(np.mean(reps[name])), npts[name]
     return out
 
 

@@ -101,3 +101,20 @@ def test_repeatability_and_map_parity(cuda, dtype, twin_iou, twin_conf, twin_fra
     print(f"{dtype}: {matched}/{total} oracle detections have a HIP twin")
     assert matched / total >= twin_frac, (matched, total)
     assert abs(sum(len(d) for d in det_cpu) - sum(len(d) for d in det_hip)) <= 0.02 * total
+
+
+def test_trained_checkpoint_map_and_repeatability_parity(cuda):
+    """BASELINE.json "det mAP / kp repeatability parity within 0.2 pt on the same synthetic eval", on a checkpoint the build TRAINED
+    itself: YOLOPoint-s, 500 bf16 optimizer steps of yolopoint_amd.engine.TrainStep on the synthetic shapes task
+    (tests/synth_task.py: coloured rectangles = boxes of 3 classes, their corners = keypoints), then the same 64 fresh images go
+    through (a) the CPU oracle in fp32 and (b) the HIP path in f16 with the HIP NMS / keypoint kernels; both are scored with the
+    reference's metric definitions against the same ground truth."""
+    import synth_task
+    m = synth_task.train("s", 256, 500, 16, cuda, lr=2e-3)
+    r = synth_task.evaluate(m, "s", 256, 64, cuda)
+    print(r)
+    assert r["map50_cpu"] > 60 and r["n_cpu"] > 200, r                 # the checkpoint detects: the comparison is not vacuous
+    assert r["kpts_cpu"] > 200, r
+    assert abs(r["map50_cpu"] - r["map50_hip"]) <= 0.2, r
+    assert abs(r["map_cpu"] - r["map_hip"]) <= 0.2, r
+    assert abs(r["rep_cpu"] - r["rep_hip"]) <= 0.2, r

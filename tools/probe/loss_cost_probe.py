@@ -2,7 +2,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
-from helpers import make_model
+from yolopoint_amd.utils.synthetic import make_model
 from yolopoint_amd.engine import TrainStep, synthetic_batch
 dev = torch.device("cuda:0")
 m, _ = make_model("s", 1, dtype="bf16"); m = m.to(dev).train()

@@ -4,7 +4,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
-from helpers import make_model
+from yolopoint_amd.utils.synthetic import make_model
 from yolopoint_amd.engine import TrainStep, synthetic_batch, LAMBDA_DESC, LAMBDA_OBJ
 from yolopoint_amd.utils.loss_functions import infonce, infonce_prepare
 from yolopoint_amd.utils.utils import labels2Dto3D, getMasks
