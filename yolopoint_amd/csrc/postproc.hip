@@ -249,22 +249,28 @@ __device__ __forceinline__ u64 box_key(float conf, unsigned id) {
     return ((u64)(0xFFFFFFFFu - __float_as_uint(conf)) << 32) | id;
 }
 
-__global__ void box_candidates_kernel(const float* __restrict__ pred, int B, int N, int nc, float conf_thres, int multi_label,
-                                      u64* __restrict__ keys, int cap, int* __restrict__ count) {
+// (block-aggregated like kp_threshold_kernel: a workgroup counts the candidates of its row span, reserves its slice of the key list
+// with one atomic and writes it in a second walk over the rows that passed the objectness test.)  grid = (BOX_SPANS, B)
+constexpr int BOX_SPANS = 128;
+__global__ __launch_bounds__(256) void box_candidates_kernel(const float* __restrict__ pred, int B, int N, int nc, float conf_thres, int multi_label,
+                                                             u64* __restrict__ keys, int cap, int* __restrict__ count) {
+    __shared__ int wave_cnt[4];
+    __shared__ int base_s;
     const int no = nc + 5;
-    const long n = (long)B * N;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const int b = (int)(i / N);
-        const int row = (int)(i - (long)b * N);
-        const float* r = pred + i * no;
+    const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int span = (N + BOX_SPANS - 1) / BOX_SPANS;
+    const int r0 = blockIdx.x * span, r1 = min(r0 + span, N);
+    const float* pb = pred + (long)b * N * no;
+    auto visit = [&](int row, int& pos, bool write) {
+        const float* r = pb + (long)row * no;
         const float obj = r[4];
-        if (!(obj > conf_thres)) continue;
+        if (!(obj > conf_thres)) return;
         if (multi_label) {
             for (int j = 0; j < nc; ++j) {
                 const float conf = r[5 + j] * obj;
                 if (conf > conf_thres) {
-                    const int pos = atomicAdd(&count[b], 1);
-                    if (pos < cap) keys[(long)b * cap + pos] = box_key(conf, (unsigned)(row * nc + j));
+                    if (write && pos < cap) keys[(long)b * cap + pos] = box_key(conf, (unsigned)(row * nc + j));
+                    ++pos;
                 }
             }
         } else {
@@ -275,11 +281,31 @@ __global__ void box_candidates_kernel(const float* __restrict__ pred, int B, int
                 if (conf > best) { best = conf; bj = j; }
             }
             if (best > conf_thres) {
-                const int pos = atomicAdd(&count[b], 1);
-                if (pos < cap) keys[(long)b * cap + pos] = box_key(best, (unsigned)(row * nc + bj));
+                if (write && pos < cap) keys[(long)b * cap + pos] = box_key(best, (unsigned)(row * nc + bj));
+                ++pos;
             }
         }
+    };
+    int mine = 0;
+    for (int row = r0 + t; row < r1; row += 256) visit(row, mine, false);
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
     }
+    if (lane == 63) wave_cnt[wave] = incl;
+    __syncthreads();
+    int before = incl - mine;
+    for (int w = 0; w < wave; ++w) before += wave_cnt[w];
+    if (t == 0) {
+        const int total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        base_s = total ? atomicAdd(&count[b], total) : 0;
+    }
+    __syncthreads();
+    if (mine == 0) return;
+    int pos = base_s + before;
+    for (int row = r0 + t; row < r1; row += 256) visit(row, pos, true);
 }
 
 struct BoxF { float x1, y1, x2, y2; };
@@ -303,7 +329,8 @@ __global__ __launch_bounds__(BOX_THREADS) void box_sort_nms_kernel(const float* 
                                                                     u64* __restrict__ keys_all, int cap, int cap_pow2,
                                                                     int* __restrict__ count, float* __restrict__ out_det,
                                                                     int* __restrict__ out_count) {
-    __shared__ BoxF kbox[BOX_MAX_DET];
+    __shared__ __attribute__((aligned(16))) char kraw[BOX_MAX_DET * sizeof(BoxF)];       // sort tile first (4096 keys), kept boxes afterwards
+    BoxF* kbox = reinterpret_cast<BoxF*>(kraw);
     __shared__ float karea[BOX_MAX_DET];
     __shared__ unsigned kid[BOX_MAX_DET];
     __shared__ float kconf[BOX_MAX_DET];
@@ -318,10 +345,38 @@ __global__ __launch_bounds__(BOX_THREADS) void box_sort_nms_kernel(const float* 
     // ---- bitonic sort (ascending u64), padded with ~0
     int P = 1;
     while (P < n) P <<= 1;
+    // Bitonic network; every compare-exchange step whose partner distance j is < 4096 stays inside a 4096-key tile, so those steps run
+    // on tiles held in LDS (all stages k <= 4096 in one visit per tile, then the tail j = 2048..1 of each later stage); only the
+    // j >= 4096 steps go through global memory.  30 000 multi-label candidates (P = 32768): 120 global passes before, 6 now.
+    constexpr int TILE = (int)(BOX_MAX_DET * sizeof(BoxF) / sizeof(u64));     // 4096
+    u64* sk = reinterpret_cast<u64*>(kraw);
     for (int i = n + t; i < P; i += BOX_THREADS) keys[i] = ~0ull;
     __syncthreads();
-    for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
+    auto tile_pass = [&](int kfirst, int klast) {      // stages kfirst..klast (powers of two), steps j = min(k/2, TILE/2) .. 1, per tile
+        for (int t0 = 0; t0 < P; t0 += TILE) {
+            const int tn = min(TILE, P - t0);
+            for (int i = t; i < tn; i += BOX_THREADS) sk[i] = keys[t0 + i];
+            __syncthreads();
+            for (int k = kfirst; k <= klast; k <<= 1) {
+                for (int j = min(k >> 1, TILE >> 1); j > 0; j >>= 1) {
+                    for (int i = t; i < tn; i += BOX_THREADS) {
+                        const int ixj = i ^ j;
+                        if (ixj > i) {
+                            const u64 a = sk[i], c = sk[ixj];
+                            const bool up = ((t0 + i) & k) == 0;
+                            if ((a > c) == up) { sk[i] = c; sk[ixj] = a; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            for (int i = t; i < tn; i += BOX_THREADS) keys[t0 + i] = sk[i];
+            __syncthreads();
+        }
+    };
+    tile_pass(2, min(P, TILE));
+    for (int k = TILE << 1; k <= P; k <<= 1) {
+        for (int j = k >> 1; j >= TILE; j >>= 1) {
             for (int i = t; i < P; i += BOX_THREADS) {
                 const int ixj = i ^ j;
                 if (ixj > i) {
@@ -332,6 +387,7 @@ __global__ __launch_bounds__(BOX_THREADS) void box_sort_nms_kernel(const float* 
             }
             __syncthreads();
         }
+        tile_pass(k, k);
     }
     n = min(n, max_nms);
 
@@ -687,7 +743,7 @@ extern "C" int yp_box_nms(const float* pred, int B, int N, int nc, float conf_th
     int* count = (int*)workspace;
     u64* keys = (u64*)((char*)workspace + align_up((size_t)B * 4, 256));
     YP_CHECK_HIP(hipMemsetAsync(count, 0, (size_t)B * 4, st));
-    box_candidates_kernel<<<grid_for((size_t)B * N, 256), 256, 0, st>>>(pred, B, N, nc, conf_thres, multi_label, keys, cap2, count);
+    box_candidates_kernel<<<dim3(BOX_SPANS, B), 256, 0, st>>>(pred, B, N, nc, conf_thres, multi_label, keys, cap2, count);
     box_sort_nms_kernel<<<B, BOX_THREADS, 0, st>>>(pred, N, nc, iou_thres, agnostic, max_det, max_nms, max_wh, keys, cap, cap2, count,
                                                    out_det, out_count);
     YP_CHECK_HIP(hipGetLastError());
