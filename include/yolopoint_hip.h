@@ -327,6 +327,11 @@ size_t yp_kp_nms_workspace_bytes(int B, int H, int W);
 int yp_kp_nms(const float* heat, int B, int H, int W, float conf_thresh, int radius, int border,
               float* out_xyc, int32_t* out_count, int max_out, void* workspace, size_t workspace_bytes,
               void* stream);
+/* The same without a host synchronisation: exactly `rounds` fix-point rounds are enqueued (rounds after convergence exit at once) and
+ * the number of candidates still undecided after the last one is written to *undecided_out (device memory).  The result is the
+ * reference's iff that counter is 0: the caller checks it at its own synchronisation point and falls back to yp_kp_nms otherwise. */
+int yp_kp_nms_async(const float* heat, int B, int H, int W, float conf_thresh, int radius, int border, float* out_xyc, int32_t* out_count,
+                    int max_out, void* workspace, size_t workspace_bytes, int rounds, int32_t* undecided_out, void* stream);
 
 /* Batched box NMS on decoded predictions.
  *   pred [B,N,5+nc] fp32 (xywh, obj, cls...).  Output rows (x1,y1,x2,y2,conf,cls) sorted by conf desc.

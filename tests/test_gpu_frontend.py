@@ -59,6 +59,41 @@ def test_frontend_matches_oracle_postprocessing(cuda, filter_pts):
                                                      #  planted-box test above exercises the removal itself)
 
 
+def test_async_keypoint_nms_and_frontend_fallback(cuda):
+    """yp_kp_nms_async enqueues a fixed number of fix-point rounds without a host sync and reports the candidates left undecided:
+    with enough rounds it equals yp_kp_nms (and the oracle); with too few the counter is non-zero and the front end falls back."""
+    from helpers import planted_heatmap
+    from yolopoint_amd.utils._ws import workspace
+    H, W, r = 160, 192, 4
+    heat_np = planted_heatmap(H, W, 120, 5)
+    ref = postproc_oracle.get_pts_from_heatmap(heat_np, 0.015, r)                     # [3,n]
+    heat = torch.from_numpy(heat_np).to(cuda).contiguous()
+    l, st = _hip.lib(), _hip.stream_ptr()
+    max_out = (H // (r + 1) + 1) * (W // (r + 1) + 1)
+    ws = workspace(cuda, l.yp_kp_nms_workspace_bytes(1, H, W), "kp_nms_test")
+    res = {}
+    for rounds in (1, 32):
+        out = torch.zeros(max_out, 3, device=cuda)
+        cnt = torch.zeros(2, dtype=torch.int32, device=cuda)
+        _hip.check(l.yp_kp_nms_async(heat.data_ptr(), 1, H, W, 0.015, r, 4, out.data_ptr(), cnt.data_ptr(), max_out, ws.data_ptr(), ws.numel(), rounds,
+                                     cnt[1:2].data_ptr(), st))
+        n, undecided = cnt.cpu().tolist()
+        res[rounds] = (out[:n].cpu().numpy().T, undecided)
+    assert res[1][1] > 0                                   # one round cannot resolve clusters: reported, not silently wrong
+    assert res[32][1] == 0
+    np.testing.assert_array_equal(res[32][0].astype(np.float64)[:2], ref[:2])
+    np.testing.assert_allclose(res[32][0][2], ref[2], rtol=1e-6)
+    # front end: too few rounds -> the synchronising variant takes over, results identical
+    m, _ = make_model("n", 17, dtype="f32")
+    m = m.to(cuda).eval()
+    x = net_oracle.synth_image(1, 3, 96, 128, 4).to(cuda)
+    fe = YoloPointFrontend(m, cuda, yolo_config=dict(conf_thres_box=0.5, iou_thres_box=0.45, max_det=10))
+    a = fe.process_tensor(x)
+    fe.NMS_ROUNDS = 1
+    b = fe.process_tensor(x)
+    assert torch.equal(a["pts"], b["pts"]) and torch.equal(a["desc"], b["desc"]) and torch.equal(a["boxes"], b["boxes"])
+
+
 def test_frontend_process_img_reference_formats(cuda):
     m, _ = make_model("n", 17, dtype="f16")
     m = m.to(cuda).eval()

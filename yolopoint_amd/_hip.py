@@ -98,6 +98,7 @@ SIGNATURES = {
     "yp_kp_decode": (_i, [_p, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _p, _p]),
     "yp_kp_nms_workspace_bytes": (_sz, [_i, _i, _i]),
     "yp_kp_nms": (_i, [_p, _i, _i, _i, _f, _i, _i, _p, _p, _i, _p, _sz, _p]),
+    "yp_kp_nms_async": (_i, [_p, _i, _i, _i, _f, _i, _i, _p, _p, _i, _p, _sz, _i, _p, _p]),
     "yp_box_nms_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "yp_box_nms": (_i, [_p, _i, _i, _i, _f, _f, _i, _i, _i, _i, _f, _p, _p, _p, _sz, _p]),
     "yp_pts_box_filter": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p]),

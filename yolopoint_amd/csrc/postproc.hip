@@ -208,35 +208,49 @@ __global__ void kp_collect_kernel(const float* __restrict__ heat, int B, int H, 
 }
 
 // rank-by-counting sort (score desc, index asc) of the kept list; writes (x, y, conf) rows.
-__global__ __launch_bounds__(256) void kp_rank_kernel(int B, int HW, int W, const int* __restrict__ kept, const float* __restrict__ kscore,
-                                                      const int* __restrict__ nkept, float* __restrict__ out, int* __restrict__ out_count, int max_out) {
+// rank of kept point i = number of kept points of higher priority, counted against tiles of the list staged in LDS; the j range is
+// split KP_RANK_SPLIT ways across blockIdx.y (partial counts, summed by kp_rank_write_kernel) so that 20 000 points use the whole chip.
+constexpr int KP_RANK_SPLIT = 8;
+__global__ __launch_bounds__(256) void kp_rank_kernel(int b, int HW, const int* __restrict__ kept, const float* __restrict__ kscore,
+                                                      const int* __restrict__ nkept, int* __restrict__ partial) {
     __shared__ int tp[1024];
     __shared__ float ts[1024];
-    for (int b = 0; b < B; ++b) {
-        const int n = nkept[b];
-        const int* kb = kept + (long)b * HW;
-        const float* sb = kscore + (long)b * HW;
-        if (blockIdx.x == 0 && threadIdx.x == 0) out_count[b] = min(n, max_out);
-        for (int i0 = blockIdx.x * 256; i0 < n; i0 += gridDim.x * 256) {     // (uniform per workgroup: barriers inside)
-            const int i = i0 + threadIdx.x;
-            const bool live = i < n;
-            const int p = live ? kb[i] : 0;
-            const float sp = live ? sb[i] : 0.f;
-            int rank = 0;
-            for (int j0 = 0; j0 < n; j0 += 1024) {
-                __syncthreads();
-                for (int j = threadIdx.x; j < 1024 && j0 + j < n; j += 256) { tp[j] = kb[j0 + j]; ts[j] = sb[j0 + j]; }
-                __syncthreads();
-                const int m = min(1024, n - j0);
-                for (int j = 0; j < m; ++j) rank += kp_higher(ts[j], tp[j], sp, p) ? 1 : 0;
-            }
-            if (live && rank < max_out) {
-                float* o = out + ((long)b * max_out + rank) * 3;
-                const int y = p / W;
-                o[0] = (float)(p - y * W);
-                o[1] = (float)y;
-                o[2] = sp;
-            }
+    const int n = nkept[b];
+    const int* kb = kept + (long)b * HW;
+    const float* sb = kscore + (long)b * HW;
+    const int jspan = ((n + (int)gridDim.y - 1) / (int)gridDim.y + 1023) & ~1023;
+    const int ja = blockIdx.y * jspan, jb = min(ja + jspan, n);
+    for (int i0 = blockIdx.x * 256; i0 < n; i0 += gridDim.x * 256) {     // (uniform per workgroup: barriers inside)
+        const int i = i0 + threadIdx.x;
+        const bool live = i < n;
+        const int p = live ? kb[i] : 0;
+        const float sp = live ? sb[i] : 0.f;
+        int rank = 0;
+        for (int j0 = ja; j0 < jb; j0 += 1024) {
+            __syncthreads();
+            for (int j = threadIdx.x; j < 1024 && j0 + j < jb; j += 256) { tp[j] = kb[j0 + j]; ts[j] = sb[j0 + j]; }
+            __syncthreads();
+            const int m = min(1024, jb - j0);
+            for (int j = 0; j < m; ++j) rank += kp_higher(ts[j], tp[j], sp, p) ? 1 : 0;
+        }
+        if (live) partial[(long)blockIdx.y * n + i] = rank;
+    }
+}
+
+__global__ void kp_rank_write_kernel(int b, int HW, int W, const int* __restrict__ kept, const float* __restrict__ kscore, const int* __restrict__ nkept,
+                                     const int* __restrict__ partial, int split, float* __restrict__ out, int* __restrict__ out_count, int max_out) {
+    const int n = nkept[b];
+    if (blockIdx.x == 0 && threadIdx.x == 0) out_count[b] = min(n, max_out);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        int rank = 0;
+        for (int y = 0; y < split; ++y) rank += partial[(long)y * n + i];
+        if (rank < max_out) {
+            const int p = kept[(long)b * HW + i];
+            float* o = out + ((long)b * max_out + rank) * 3;
+            const int yy = p / W;
+            o[0] = (float)(p - yy * W);
+            o[1] = (float)yy;
+            o[2] = kscore[(long)b * HW + i];
         }
     }
 }
@@ -672,8 +686,11 @@ extern "C" size_t yp_kp_nms_workspace_bytes(int B, int H, int W) {
     return align_up(hw, 256) + 3 * align_up(hw * 4, 256) + 2 * align_up((size_t)B * 4, 256) + align_up((size_t)KP_MAX_ROUNDS * 4, 256);
 }
 
-extern "C" int yp_kp_nms(const float* heat, int B, int H, int W, float conf_thresh, int radius, int border, float* out_xyc,
-                         int32_t* out_count, int max_out, void* workspace, size_t workspace_bytes, void* stream) {
+// fixed_rounds == 0: rounds in batches of KP_ROUND_BATCH until the undecided counter read back by the host is 0 (one stream
+// synchronisation per batch).  fixed_rounds > 0: exactly that many rounds, no host synchronisation; the last round's undecided counter
+// goes to *undecided_out (device) for the caller to check at its own synchronisation point.
+static int kp_nms_run(const float* heat, int B, int H, int W, float conf_thresh, int radius, int border, float* out_xyc, int32_t* out_count, int max_out,
+                      void* workspace, size_t workspace_bytes, int fixed_rounds, int32_t* undecided_out, void* stream) {
     YP_REQUIRE(heat && out_xyc && out_count && workspace, "yp_kp_nms: null pointer");
     YP_REQUIRE(B > 0 && H > 0 && W > 0 && radius >= 0 && border >= 0 && max_out > 0, "yp_kp_nms: bad dims");
     if (workspace_bytes < yp_kp_nms_workspace_bytes(B, H, W)) {
@@ -695,22 +712,50 @@ extern "C" int yp_kp_nms(const float* heat, int B, int H, int W, float conf_thre
     kp_threshold_kernel<<<dim3(KP_SPANS, B), 256, 0, st>>>(heat, B, H * W, conf_thresh, state, cand, ncand);
     YP_CHECK_HIP(hipGetLastError());
     int round = 0;
-    for (;;) {
-        for (int k = 0; k < KP_ROUND_BATCH; ++k, ++round) {
-            kp_round_kernel<<<512, 256, 0, st>>>(heat, B, H, W, radius, state, cand, ncand, round ? left + round - 1 : nullptr,
-                                                 left + round);
-        }
+    if (fixed_rounds > 0) {
+        YP_REQUIRE(fixed_rounds <= KP_MAX_ROUNDS && undecided_out != nullptr, "yp_kp_nms_async: 1..%d rounds and a device counter", KP_MAX_ROUNDS);
+        for (; round < fixed_rounds; ++round)
+            kp_round_kernel<<<512, 256, 0, st>>>(heat, B, H, W, radius, state, cand, ncand, round ? left + round - 1 : nullptr, left + round);
         YP_CHECK_HIP(hipGetLastError());
-        int h_left = 0;
-        YP_CHECK_HIP(hipMemcpyAsync(&h_left, left + round - 1, sizeof(int), hipMemcpyDeviceToHost, st));
-        YP_CHECK_HIP(hipStreamSynchronize(st));
-        if (h_left == 0) break;
-        YP_REQUIRE(round + KP_ROUND_BATCH <= KP_MAX_ROUNDS, "yp_kp_nms: no fix-point after %d rounds", round);
+        YP_CHECK_HIP(hipMemcpyAsync(undecided_out, left + round - 1, sizeof(int), hipMemcpyDeviceToDevice, st));
+    } else {
+        for (;;) {
+            for (int k = 0; k < KP_ROUND_BATCH; ++k, ++round) {
+                kp_round_kernel<<<512, 256, 0, st>>>(heat, B, H, W, radius, state, cand, ncand, round ? left + round - 1 : nullptr,
+                                                     left + round);
+            }
+            YP_CHECK_HIP(hipGetLastError());
+            int h_left = 0;
+            YP_CHECK_HIP(hipMemcpyAsync(&h_left, left + round - 1, sizeof(int), hipMemcpyDeviceToHost, st));
+            YP_CHECK_HIP(hipStreamSynchronize(st));
+            if (h_left == 0) break;
+            YP_REQUIRE(round + KP_ROUND_BATCH <= KP_MAX_ROUNDS, "yp_kp_nms: no fix-point after %d rounds", round);
+        }
     }
     kp_collect_kernel<<<256, 256, 0, st>>>(heat, B, H, W, border, state, cand, ncand, kept, kscore, nkept);
-    kp_rank_kernel<<<256, 256, 0, st>>>(B, H * W, W, kept, kscore, nkept, out_xyc, out_count, max_out);
+    // the candidate list is dead after the collect: its storage (HW ints per image) takes the partial ranks, split * kept of them --
+    // kept points are pairwise > radius apart, so kept <= ceil(H/(r+1)) * ceil(W/(r+1))
+    const long max_kept = (long)((H + radius) / (radius + 1)) * ((W + radius) / (radius + 1));
+    int split = (int)((long)H * W / (max_kept > 0 ? max_kept : 1));
+    split = split < 1 ? 1 : (split > KP_RANK_SPLIT ? KP_RANK_SPLIT : split);
+    for (int b = 0; b < B; ++b) {
+        int* partial = cand + (size_t)b * H * W;
+        kp_rank_kernel<<<dim3(64, split), 256, 0, st>>>(b, H * W, kept, kscore, nkept, partial);
+        kp_rank_write_kernel<<<64, 256, 0, st>>>(b, H * W, W, kept, kscore, nkept, partial, split, out_xyc, out_count, max_out);
+    }
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
+}
+
+extern "C" int yp_kp_nms(const float* heat, int B, int H, int W, float conf_thresh, int radius, int border, float* out_xyc,
+                         int32_t* out_count, int max_out, void* workspace, size_t workspace_bytes, void* stream) {
+    return kp_nms_run(heat, B, H, W, conf_thresh, radius, border, out_xyc, out_count, max_out, workspace, workspace_bytes, 0, nullptr, stream);
+}
+
+extern "C" int yp_kp_nms_async(const float* heat, int B, int H, int W, float conf_thresh, int radius, int border, float* out_xyc,
+                               int32_t* out_count, int max_out, void* workspace, size_t workspace_bytes, int rounds, int32_t* undecided_out,
+                               void* stream) {
+    return kp_nms_run(heat, B, H, W, conf_thresh, radius, border, out_xyc, out_count, max_out, workspace, workspace_bytes, rounds, undecided_out, stream);
 }
 
 // workspace layout: count[B] i32 | keys[B*cap_pow2] u64
@@ -778,36 +823,44 @@ __global__ __launch_bounds__(1024) void pts_box_filter_kernel(const float* __res
     }
     if (t == 0) base = 0;
     __syncthreads();
-    for (int i0 = 0; i0 < n; i0 += 1024) {
-        const int i = i0 + t;
-        bool keep = false;
-        float x = 0.f, y = 0.f, c = 0.f;
-        if (i < n) {
-            x = pts[3 * i]; y = pts[3 * i + 1]; c = pts[3 * i + 2];
-            const int xi = (int)x, yi = (int)y;
-            bool inside = false;
-#pragma unroll 8
-            for (int k = 0; k < nb; ++k) {
-                const int4 q = sb[k];
-                inside |= xi >= q.x && xi < q.z && yi >= q.y && yi < q.w;
+    for (int i0 = 0; i0 < n; i0 += 4096) {                     // four points per thread share every box read
+        float x[4], y[4], c[4];
+        int xi[4], yi[4];
+        bool inside[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * 1024 + t;
+            x[u] = y[u] = c[u] = 0.f;
+            if (i < n) { x[u] = pts[3 * i]; y[u] = pts[3 * i + 1]; c[u] = pts[3 * i + 2]; }
+            xi[u] = (int)x[u]; yi[u] = (int)y[u];
+            inside[u] = false;
+        }
+#pragma unroll 4
+        for (int k = 0; k < nb; ++k) {
+            const int4 q = sb[k];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) inside[u] |= xi[u] >= q.x && xi[u] < q.z && yi[u] >= q.y && yi[u] < q.w;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * 1024 + t;
+            const bool keep = i < n && !inside[u];
+            const unsigned long long m = __ballot(keep);
+            if (lane == 0) wave_cnt[wave] = __popcll(m);
+            __syncthreads();
+            int off = base, total = 0;
+            for (int w = 0; w < 16; ++w) {
+                if (w < wave) off += wave_cnt[w];
+                total += wave_cnt[w];
             }
-            keep = !inside;
+            if (keep) {
+                const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
+                out[3 * slot] = x[u]; out[3 * slot + 1] = y[u]; out[3 * slot + 2] = c[u];
+            }
+            __syncthreads();
+            if (t == 0) base += total;
+            __syncthreads();
         }
-        const unsigned long long m = __ballot(keep);
-        if (lane == 0) wave_cnt[wave] = __popcll(m);
-        __syncthreads();
-        int off = base, total = 0;
-        for (int w = 0; w < 16; ++w) {
-            if (w < wave) off += wave_cnt[w];
-            total += wave_cnt[w];
-        }
-        if (keep) {
-            const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
-            out[3 * slot] = x; out[3 * slot + 1] = y; out[3 * slot + 2] = c;
-        }
-        __syncthreads();
-        if (t == 0) base += total;
-        __syncthreads();
     }
     if (t == 0) *out_count = base;
 }

@@ -39,8 +39,10 @@ class YoloPointFrontend:
         cut_w0, cut_w1 = int(np.ceil(cut_w)), int(np.floor(cut_w))
         return img[cut_h0:h0 - cut_h1, cut_w0:w0 - cut_w1], cut_h0, cut_w0, 1.0
 
+    NMS_ROUNDS = 24       # fix-point rounds enqueued per frame by the non-synchronising keypoint NMS
+
     @torch.no_grad()
-    def process_tensor(self, inp):
+    def process_tensor(self, inp, sync_nms=False):
         """inp: float [1,3,H,W] on the device, values in [0,1].  Returns dict(pts [N,3] (x, y, conf; conf descending),
         desc [D,N] L2-normalised columns, boxes [n,6] (xyxy, conf, cls)) -- all device tensors."""
         if inp.dim() != 4 or inp.shape[0] != 1:
@@ -58,10 +60,14 @@ class YoloPointFrontend:
         step = radius + 1
         max_pts = max(1, -(-H // step) * -(-W // step))
         pts = torch.empty((max_pts, 3), dtype=torch.float32, device=dev)
-        counts = torch.zeros((3,), dtype=torch.int32, device=dev)            # [points after NMS, boxes, points after filtering]
+        counts = torch.zeros((4,), dtype=torch.int32, device=dev)   # [points after NMS, boxes, points after filtering, NMS candidates left undecided]
         ws = workspace(dev, l.yp_kp_nms_workspace_bytes(1, H, W), "kp_nms")
-        _hip.check(l.yp_kp_nms(heat.data_ptr(), 1, H, W, float(self.sp_config["detection_threshold"]), radius, int(self.border_remove),
-                               pts.data_ptr(), counts.data_ptr(), max_pts, ws.data_ptr(), ws.numel(), st))
+        kp_args = (heat.data_ptr(), 1, H, W, float(self.sp_config["detection_threshold"]), radius, int(self.border_remove), pts.data_ptr(),
+                   counts.data_ptr(), max_pts, ws.data_ptr(), ws.numel())
+        if sync_nms:
+            _hip.check(l.yp_kp_nms(*kp_args, st))
+        else:       # a fixed number of fix-point rounds, no host synchronisation inside; convergence is checked with the frame's counters
+            _hip.check(l.yp_kp_nms_async(*kp_args, self.NMS_ROUNDS, counts[3:4].data_ptr(), st))
         # boxes: multi-label, class-agnostic NMS as the demo calls it (demo.py:168-174)
         p = pred if (pred.dtype == torch.float32 and pred.is_contiguous()) else pred.float().contiguous()
         N, no = p.shape[1], p.shape[2]
@@ -80,7 +86,9 @@ class YoloPointFrontend:
         else:
             kept = pts
             counts[2:3].copy_(counts[0:1])
-        n_nms, n_box, n_pts = counts.cpu().tolist()                               # the frame's only host sync
+        n_nms, n_box, n_pts, undecided = counts.cpu().tolist()                    # the frame's only host sync
+        if undecided:                                                              # the greedy NMS needed more rounds than enqueued: redo with the
+            return self.process_tensor(inp, sync_nms=True)                         # converging variant (not seen on real or planted heat maps)
         if n_box < 0:
             raise _hip.YpError("YoloPointFrontend: box NMS candidate list overflowed its workspace")
         kept, boxes = kept[:n_pts], boxes[0, :n_box]
