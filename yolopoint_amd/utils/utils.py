@@ -63,6 +63,9 @@ def flattenDetection_demo(semi):
 
 
 # ---------------------------------------------------------------------------------------------
+KP_NMS_ROUNDS = 16
+
+
 def _kp_nms_device(heat3, conf_thresh, radius, border):
     """heat3: fp32 cuda [B,H,W] -> list of B float32 cuda tensors [n,3] (x,y,conf), conf descending."""
     heat3 = heat3.contiguous()
@@ -71,12 +74,16 @@ def _kp_nms_device(heat3, conf_thresh, radius, border):
     step = radius + 1
     max_out = max(1, -(-H // step) * -(-W // step))   # kept points are pairwise > radius apart
     out = torch.empty((B, max_out, 3), dtype=torch.float32, device=heat3.device)
-    cnt = torch.empty((B,), dtype=torch.int32, device=heat3.device)
+    cnt = torch.empty((B + 1,), dtype=torch.int32, device=heat3.device)     # [counts..., candidates left undecided]
     nbytes = l.yp_kp_nms_workspace_bytes(B, H, W)
     ws = workspace(heat3.device, nbytes, "kp_nms")
-    _hip.check(l.yp_kp_nms(heat3.data_ptr(), B, H, W, float(conf_thresh), int(radius), int(border), out.data_ptr(),
-                           cnt.data_ptr(), max_out, ws.data_ptr(), ws.numel(), _hip.stream_ptr()))
+    args = (heat3.data_ptr(), B, H, W, float(conf_thresh), int(radius), int(border), out.data_ptr(), cnt.data_ptr(), max_out, ws.data_ptr(), ws.numel())
+    # a fixed number of fix-point rounds without a host synchronisation; whether they sufficed is read back with the counts
+    _hip.check(l.yp_kp_nms_async(*args, KP_NMS_ROUNDS, cnt[B:].data_ptr(), _hip.stream_ptr()))
     counts = cnt.cpu().tolist()
+    if counts[B]:                                                          # not converged: the synchronising variant iterates to the fix-point
+        _hip.check(l.yp_kp_nms(*args, _hip.stream_ptr()))
+        counts = cnt.cpu().tolist()
     return [out[b, :counts[b]] for b in range(B)]
 
 
