@@ -231,7 +231,12 @@ __global__ __launch_bounds__(256) void kp_rank_kernel(int b, int HW, const int* 
             for (int j = threadIdx.x; j < 1024 && j0 + j < jb; j += 256) { tp[j] = kb[j0 + j]; ts[j] = sb[j0 + j]; }
             __syncthreads();
             const int m = min(1024, jb - j0);
-            for (int j = 0; j < m; ++j) rank += kp_higher(ts[j], tp[j], sp, p) ? 1 : 0;
+            int j = 0;
+            for (; j + 8 <= m; j += 8) {                      // eight independent LDS reads in flight
+#pragma unroll
+                for (int u = 0; u < 8; ++u) rank += kp_higher(ts[j + u], tp[j + u], sp, p) ? 1 : 0;
+            }
+            for (; j < m; ++j) rank += kp_higher(ts[j], tp[j], sp, p) ? 1 : 0;
         }
         if (live) partial[(long)blockIdx.y * n + i] = rank;
     }
@@ -404,6 +409,7 @@ __global__ __launch_bounds__(BOX_THREADS) void box_sort_nms_kernel(const float* 
         tile_pass(k, k);
     }
     n = min(n, max_nms);
+    if (max_wh < 0.f) n = 0;          // (probe: negative max_wh = sort only)
 
     // ---- greedy NMS over sorted candidates, 64 at a time
     const int no = nc + 5;
@@ -826,23 +832,31 @@ __global__ __launch_bounds__(1024) void pts_box_filter_kernel(const float* __res
     for (int i0 = 0; i0 < n; i0 += 4096) {                     // four points per thread share every box read
         float x[4], y[4], c[4];
         int xi[4], yi[4];
-        bool inside[4];
+        int inside[4];
+        const int U = min(4, (n - i0 + 1023) / 1024);          // slots of this pass that hold points (uniform over the workgroup)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = i0 + u * 1024 + t;
             x[u] = y[u] = c[u] = 0.f;
             if (i < n) { x[u] = pts[3 * i]; y[u] = pts[3 * i + 1]; c[u] = pts[3 * i + 2]; }
             xi[u] = (int)x[u]; yi[u] = (int)y[u];
-            inside[u] = false;
+            inside[u] = 0;
         }
+        if (U == 1) {
 #pragma unroll 4
-        for (int k = 0; k < nb; ++k) {
-            const int4 q = sb[k];
+            for (int k = 0; k < nb; ++k) {                    // branch-free: bitwise combination of the four comparisons
+                const int4 q = sb[k];
+                inside[0] |= (int)(xi[0] >= q.x) & (int)(xi[0] < q.z) & (int)(yi[0] >= q.y) & (int)(yi[0] < q.w);
+            }
+        } else {
+#pragma unroll 4
+            for (int k = 0; k < nb; ++k) {
+                const int4 q = sb[k];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) inside[u] |= xi[u] >= q.x && xi[u] < q.z && yi[u] >= q.y && yi[u] < q.w;
+                for (int u = 0; u < 4; ++u) inside[u] |= (int)(xi[u] >= q.x) & (int)(xi[u] < q.z) & (int)(yi[u] >= q.y) & (int)(yi[u] < q.w);
+            }
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int i = i0 + u * 1024 + t;
             const bool keep = i < n && !inside[u];
             const unsigned long long m = __ballot(keep);
