@@ -129,6 +129,40 @@ def test_nms_all_suppressed_and_truncation(cuda):
     assert got[0].shape == (1, 6) and np.array_equal(got[0].cpu().numpy(), ref[0])
 
 
+@pytest.mark.parametrize("case", ["prefix_suffices", "prefix_runs_out", "equal_confidences"])
+def test_nms_many_candidates_selection_shortcut(cuda, case):
+    """> 4096 candidates: the kernel selects the best <= 4096 (whole confidence bins), sorts them in LDS and runs the greedy NMS on
+    that prefix; when the prefix is exhausted before max_det boxes are kept it sorts everything and starts over.  Both ways the
+    kept rows must be the sequential oracle's, exactly."""
+    rng = np.random.default_rng(11)
+    N, nc = 9000, 3
+    pred = np.zeros((2, N, 5 + nc), np.float32)
+    for b in range(2):
+        if case == "prefix_runs_out":
+            # 7000 jittered copies of 6 boxes take the 7000 best confidences (6 survivors), 2000 distinct boxes follow at low confidence
+            base = rng.uniform(100, 500, (6, 2))
+            which = rng.integers(0, 6, 7000)
+            pred[b, :7000, 0:2] = base[which] + rng.normal(0, 0.5, (7000, 2))
+            pred[b, :7000, 2:4] = 80.0
+            pred[b, :7000, 4] = rng.permutation(np.linspace(0.60, 0.99, 7000))
+            gx, gy = np.meshgrid(np.arange(50), np.arange(40))
+            pred[b, 7000:, 0] = 700 + gx.ravel() * 12.0; pred[b, 7000:, 1] = 20 + gy.ravel() * 12.0
+            pred[b, 7000:, 2:4] = 10.0
+            pred[b, 7000:, 4] = rng.permutation(np.linspace(0.30, 0.55, 2000))
+        else:
+            pred[b, :, 0:2] = rng.uniform(50, 1200, (N, 2))
+            pred[b, :, 2:4] = rng.uniform(8, 60, (N, 2))
+            pred[b, :, 4] = rng.permutation(np.linspace(0.3, 0.99, N)) if case == "prefix_suffices" else np.repeat(np.linspace(0.3, 0.9, 9), 1000)
+        pred[b, :, 5] = 1.0
+    ref = po.non_max_suppression(pred, 0.25, 0.45, agnostic=True, multi_label=False, max_det=300)
+    got = non_max_suppression(torch.from_numpy(pred).to(cuda), 0.25, 0.45, agnostic=True, multi_label=False, labels=[], max_det=300)
+    for b in range(2):
+        assert got[b].shape == ref[b].shape, (case, got[b].shape, ref[b].shape)
+        np.testing.assert_array_equal(got[b].cpu().numpy(), ref[b])
+    if case == "prefix_runs_out":
+        assert 6 < ref[0].shape[0] <= 300
+
+
 # ------------------------------------------------------------------ descriptors
 @pytest.mark.parametrize("D,Hc,Wc,N", [(64, 8, 8, 17), (128, 30, 40, 500), (256, 20, 20, 1)])
 def test_sample_desc_from_points(cuda, D, Hc, Wc, N):

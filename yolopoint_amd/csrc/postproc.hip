@@ -343,18 +343,19 @@ constexpr int BOX_THREADS = 1024;
 constexpr int BOX_MAX_DET = 2048;
 
 // one workgroup per image: bitonic sort of the candidate keys, then chunked greedy NMS.
-__global__ __launch_bounds__(BOX_THREADS) void box_sort_nms_kernel(const float* __restrict__ pred, int N, int nc, float iou_thres,
+__global__ __launch_bounds__(BOX_THREADS) void box_sort_nms_kernel(const float* __restrict__ pred, int N, int nc, float iou_thres, float conf_lo,
                                                                     int agnostic, int max_det, int max_nms, float max_wh,
                                                                     u64* __restrict__ keys_all, int cap, int cap_pow2,
                                                                     int* __restrict__ count, float* __restrict__ out_det,
                                                                     int* __restrict__ out_count) {
     __shared__ __attribute__((aligned(16))) char kraw[BOX_MAX_DET * sizeof(BoxF)];       // sort tile first (4096 keys), kept boxes afterwards
     BoxF* kbox = reinterpret_cast<BoxF*>(kraw);
-    __shared__ float karea[BOX_MAX_DET];
-    __shared__ unsigned kid[BOX_MAX_DET];
-    __shared__ float kconf[BOX_MAX_DET];
+    __shared__ __attribute__((aligned(16))) char kaux[3 * BOX_MAX_DET * 4];              // selection histogram first (4096 bins), then:
+    float* karea = reinterpret_cast<float*>(kaux);
+    unsigned* kid = reinterpret_cast<unsigned*>(kaux + BOX_MAX_DET * 4);
+    float* kconf = reinterpret_cast<float*>(kaux + 2 * BOX_MAX_DET * 4);
     __shared__ u64 supmask[BOX_THREADS / 64];
-    __shared__ int s_nkept;
+    __shared__ int s_nkept, s_bsel, s_cnt;
 
     const int b = blockIdx.x;
     const int t = threadIdx.x;
@@ -364,70 +365,170 @@ __global__ __launch_bounds__(BOX_THREADS) void box_sort_nms_kernel(const float* 
     // ---- bitonic sort (ascending u64), padded with ~0
     int P = 1;
     while (P < n) P <<= 1;
-    // Bitonic network; every compare-exchange step whose partner distance j is < 4096 stays inside a 4096-key tile, so those steps run
-    // on tiles held in LDS (all stages k <= 4096 in one visit per tile, then the tail j = 2048..1 of each later stage); only the
-    // j >= 4096 steps go through global memory.  30 000 multi-label candidates (P = 32768): 120 global passes before, 6 now.
     constexpr int TILE = (int)(BOX_MAX_DET * sizeof(BoxF) / sizeof(u64));     // 4096
     u64* sk = reinterpret_cast<u64*>(kraw);
+    const int lane = t & 63, wave = t >> 6;
     for (int i = n + t; i < P; i += BOX_THREADS) keys[i] = ~0ull;
     __syncthreads();
-    auto tile_pass = [&](int kfirst, int klast) {      // stages kfirst..klast (powers of two), steps j = min(k/2, TILE/2) .. 1, per tile
-        for (int t0 = 0; t0 < P; t0 += TILE) {
-            const int tn = min(TILE, P - t0);
-            for (int i = t; i < tn; i += BOX_THREADS) sk[i] = keys[t0 + i];
-            __syncthreads();
-            for (int k = kfirst; k <= klast; k <<= 1) {
-                for (int j = min(k >> 1, TILE >> 1); j > 0; j >>= 1) {
-                    for (int i = t; i < tn; i += BOX_THREADS) {
-                        const int ixj = i ^ j;
-                        if (ixj > i) {
-                            const u64 a = sk[i], c = sk[ixj];
-                            const bool up = ((t0 + i) & k) == 0;
-                            if ((a > c) == up) { sk[i] = c; sk[ixj] = a; }
-                        }
+    auto lds_sort = [&](int cntp2) {                 // sk[0..cntp2), cntp2 a power of two <= TILE
+        for (int k = 2; k <= cntp2; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = t; i < cntp2; i += BOX_THREADS) {
+                    const int ixj = i ^ j;
+                    if (ixj > i) {
+                        const u64 a = sk[i], c = sk[ixj];
+                        const bool up = (i & k) == 0;
+                        if ((a > c) == up) { sk[i] = c; sk[ixj] = a; }
                     }
-                    __syncthreads();
                 }
+                __syncthreads();
             }
-            for (int i = t; i < tn; i += BOX_THREADS) keys[t0 + i] = sk[i];
-            __syncthreads();
         }
     };
-    tile_pass(2, min(P, TILE));
-    for (int k = TILE << 1; k <= P; k <<= 1) {
-        for (int j = k >> 1; j >= TILE; j >>= 1) {
-            for (int i = t; i < P; i += BOX_THREADS) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const u64 a = keys[i], c = keys[ixj];
-                    const bool up = (i & k) == 0;
-                    if ((a > c) == up) { keys[i] = c; keys[ixj] = a; }
+    // Full sort: bitonic network; every compare-exchange step whose partner distance j is < 4096 stays inside a 4096-key tile, so those
+    // steps run on tiles held in LDS (all stages k <= 4096 in one visit per tile, then the tail j = 2048..1 of each later stage); only
+    // the j >= 4096 steps go through global memory.  30 000 multi-label candidates (P = 32768): 120 global passes before, 6 now.
+    auto full_sort = [&]() {
+        auto tile_pass = [&](int kfirst, int klast) {      // stages kfirst..klast (powers of two), steps j = min(k/2, TILE/2) .. 1, per tile
+            for (int t0 = 0; t0 < P; t0 += TILE) {
+                const int tn = min(TILE, P - t0);
+                for (int i = t; i < tn; i += BOX_THREADS) sk[i] = keys[t0 + i];
+                __syncthreads();
+                for (int k = kfirst; k <= klast; k <<= 1) {
+                    for (int j = min(k >> 1, TILE >> 1); j > 0; j >>= 1) {
+                        for (int i = t; i < tn; i += BOX_THREADS) {
+                            const int ixj = i ^ j;
+                            if (ixj > i) {
+                                const u64 a = sk[i], c = sk[ixj];
+                                const bool up = ((t0 + i) & k) == 0;
+                                if ((a > c) == up) { sk[i] = c; sk[ixj] = a; }
+                            }
+                        }
+                        __syncthreads();
+                    }
                 }
+                for (int i = t; i < tn; i += BOX_THREADS) keys[t0 + i] = sk[i];
+                __syncthreads();
+            }
+        };
+        tile_pass(2, min(P, TILE));
+        for (int k = TILE << 1; k <= P; k <<= 1) {
+            for (int j = k >> 1; j >= TILE; j >>= 1) {
+                for (int i = t; i < P; i += BOX_THREADS) {
+                    const int ixj = i ^ j;
+                    if (ixj > i) {
+                        const u64 a = keys[i], c = keys[ixj];
+                        const bool up = (i & k) == 0;
+                        if ((a > c) == up) { keys[i] = c; keys[ixj] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+            tile_pass(k, k);
+        }
+    };
+    // Top-of-the-list shortcut: the greedy NMS stops at max_det boxes, usually long before it has seen 30 000 candidates.  When there
+    // are more than 4096, the best <= 4096 are SELECTED exactly (4096-bin histogram over the confidence word of the keys, whole bins
+    // only, so equal confidences stay together), sorted in LDS and copied behind the list; the NMS runs on that prefix of the
+    // fully sorted order.  Only if it runs out of them before max_det boxes are kept is the whole list sorted and the NMS redone.
+    const int n_all = min(n, max_nms);
+    const u64* src = keys;
+    int src_n = n_all;
+    bool shortcut = n > TILE && (long)P + TILE <= (long)cap_pow2;
+    if (shortcut) {
+        int* hist = reinterpret_cast<int*>(kaux);
+        if (t == 0) { s_bsel = -1; s_cnt = 0; }
+        for (int i = t; i < TILE; i += BOX_THREADS) hist[i] = 0;
+        __syncthreads();
+        // confidences lie in (conf_thres, 1]: the key's confidence word (0xFFFFFFFF - float bits) in [~bits(1), ~bits(conf_thres)]
+        const unsigned base_h = 0xFFFFFFFFu - __float_as_uint(1.0f);
+        const unsigned span_h = (0xFFFFFFFFu - __float_as_uint(conf_lo)) - base_h;
+        int shift = 0;
+        while ((span_h >> shift) >= (unsigned)TILE) ++shift;
+#pragma unroll 4
+        for (int i = t; i < n; i += BOX_THREADS) {
+            const unsigned h = (unsigned)(keys[i] >> 32);
+            const unsigned bin = h <= base_h ? 0u : min((h - base_h) >> shift, (unsigned)TILE - 1u);
+            atomicAdd(&hist[bin], 1);
+        }
+        __syncthreads();
+        // inclusive prefix over the bins (4 per thread), largest bin whose prefix still fits the tile
+        int v[4], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v[q] = hist[4 * t + q]; sum += v[q]; }
+        int incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+        __syncthreads();
+        int* wsum = reinterpret_cast<int*>(supmask);                // 16 wave totals (32 ints fit)
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int before = incl - sum;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        int run = before;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            run += v[q];
+            if (run <= TILE && v[q] > 0) atomicMax(&s_bsel, 4 * t + q);
+        }
+        __syncthreads();
+        const int bsel = s_bsel;
+        if (bsel < 0) shortcut = false;                              // the best bin alone overflows the tile: full sort
+        else {
+            __syncthreads();
+            const int n_up = (n + BOX_THREADS - 1) / BOX_THREADS * BOX_THREADS;          // whole waves stay in the loop (ballots)
+            for (int i = t; i < n_up; i += BOX_THREADS) {
+                const u64 key = i < n ? keys[i] : ~0ull;
+                const unsigned h = (unsigned)(key >> 32);
+                const unsigned bin = h <= base_h ? 0u : min((h - base_h) >> shift, (unsigned)TILE - 1u);
+                const bool sel = i < n && (int)bin <= bsel;
+                const u64 mk = __ballot(sel);                    // one LDS atomic per wave (64 returning atomics on one address serialise)
+                if (mk == 0) continue;
+                const int leader = __ffsll((long long)mk) - 1;
+                int wbase = 0;
+                if (lane == leader) wbase = atomicAdd(&s_cnt, __popcll(mk));
+                wbase = __shfl(wbase, leader, 64);
+                if (sel) sk[wbase + __popcll(mk & ((1ull << lane) - 1ull))] = key;
             }
             __syncthreads();
+            const int m = s_cnt;
+            int p2 = 1;
+            while (p2 < m) p2 <<= 1;
+            for (int i = m + t; i < p2; i += BOX_THREADS) sk[i] = ~0ull;
+            __syncthreads();
+            lds_sort(p2);
+            u64* top = keys + P;
+            for (int i = t; i < m; i += BOX_THREADS) top[i] = sk[i];
+            __syncthreads();
+            src = top;
+            src_n = min(m, n_all);
         }
-        tile_pass(k, k);
     }
-    n = min(n, max_nms);
-    if (max_wh < 0.f) n = 0;          // (probe: negative max_wh = sort only)
+    if (!shortcut) {
+        full_sort();
+        src = keys;
+        src_n = n_all;
+    }
+    if (max_wh < 0.f) src_n = 0;          // (probe: negative max_wh = sort only)
+
 
     // ---- greedy NMS over sorted candidates, 64 at a time
     const int no = nc + 5;
     const float* pb = pred + (long)b * N * no;
-    const int lane = t & 63, wave = t >> 6;
     constexpr int NW = BOX_THREADS / 64;
+    auto run_nms = [&](const u64* list, int cnt) {
     if (t == 0) s_nkept = 0;
     __syncthreads();
-    for (int base = 0; base < n; base += 64) {
+    for (int base = 0; base < cnt; base += 64) {
         const int nk0 = s_nkept;
         if (nk0 >= max_det) break;
         const int ci = base + lane;
-        const bool valid = ci < n;
+        const bool valid = ci < cnt;
         BoxF bx{0.f, 0.f, 0.f, 0.f};
         float area = 0.f, conf = 0.f;
         unsigned id = 0;
         if (valid) {
-            const u64 key = keys[ci];
+            const u64 key = list[ci];
             id = (unsigned)(key & 0xFFFFFFFFu);
             conf = __uint_as_float(0xFFFFFFFFu - (unsigned)(key >> 32));
             const unsigned row = id / (unsigned)nc, cls = id - row * (unsigned)nc;
@@ -452,11 +553,13 @@ __global__ __launch_bounds__(BOX_THREADS) void box_sort_nms_kernel(const float* 
             u64 alive = __ballot(valid) & ~dead;
             int nk = nk0;
             while (alive != 0 && nk < max_det) {
-                const int i = __ffsll((long long)alive) - 1;
-                BoxF bi;
-                bi.x1 = __shfl(bx.x1, i, 64); bi.y1 = __shfl(bx.y1, i, 64);
-                bi.x2 = __shfl(bx.x2, i, 64); bi.y2 = __shfl(bx.y2, i, 64);
-                const float ai = __shfl(area, i, 64);
+                const int i = __builtin_amdgcn_readfirstlane(__ffsll((long long)alive) - 1);     // (uniform: a scalar lane index)
+                BoxF bi;                                                                            // v_readlane instead of ds_bpermute
+                bi.x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx.x1), i));
+                bi.y1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx.y1), i));
+                bi.x2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx.x2), i));
+                bi.y2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx.y2), i));
+                const float ai = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(area), i));
                 if (lane == i) { kbox[nk] = bx; karea[nk] = area; kid[nk] = id; kconf[nk] = conf; }
                 ++nk;
                 const bool mine = ((alive >> lane) & 1ull) && lane > i;
@@ -467,6 +570,13 @@ __global__ __launch_bounds__(BOX_THREADS) void box_sort_nms_kernel(const float* 
             if (lane == 0) s_nkept = nk;
         }
         __syncthreads();
+    }
+    };
+    run_nms(src, src_n);
+    if (shortcut && s_nkept < max_det && src_n < n_all && !(max_wh < 0.f)) {      // the selected prefix ran out: sort everything, redo
+        __syncthreads();
+        full_sort();
+        run_nms(keys, n_all);
     }
     // ---- emit (x1,y1,x2,y2,conf,cls) without the class offset
     const int nk = min(s_nkept, max_det);
@@ -795,7 +905,7 @@ extern "C" int yp_box_nms(const float* pred, int B, int N, int nc, float conf_th
     u64* keys = (u64*)((char*)workspace + align_up((size_t)B * 4, 256));
     YP_CHECK_HIP(hipMemsetAsync(count, 0, (size_t)B * 4, st));
     box_candidates_kernel<<<dim3(BOX_SPANS, B), 256, 0, st>>>(pred, B, N, nc, conf_thres, multi_label, keys, cap2, count);
-    box_sort_nms_kernel<<<B, BOX_THREADS, 0, st>>>(pred, N, nc, iou_thres, agnostic, max_det, max_nms, max_wh, keys, cap, cap2, count,
+    box_sort_nms_kernel<<<B, BOX_THREADS, 0, st>>>(pred, N, nc, iou_thres, conf_thres, agnostic, max_det, max_nms, max_wh, keys, cap, cap2, count,
                                                    out_det, out_count);
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
