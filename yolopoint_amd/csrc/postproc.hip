@@ -434,7 +434,8 @@ __global__ __launch_bounds__(BOX_THREADS) void box_sort_nms_kernel(const float* 
     const int n_all = min(n, max_nms);
     const u64* src = keys;
     int src_n = n_all;
-    bool shortcut = n > TILE && (long)P + TILE <= (long)cap_pow2;
+    // (worth trying only when the prefix is likely to suffice: max_det well below the tile; otherwise it is paid on top of the full sort)
+    bool shortcut = n > TILE && (long)P + TILE <= (long)cap_pow2 && max_det * 8 <= TILE;
     if (shortcut) {
         int* hist = reinterpret_cast<int*>(kaux);
         if (t == 0) { s_bsel = -1; s_cnt = 0; }
