@@ -39,6 +39,24 @@ def test_forward_f32(cuda, version, B, S):
         assert rel_err(a, b)[0] < 1e-3
 
 
+@pytest.mark.parametrize("version,B,H,W", [("n", 3, 96, 160), ("s", 5, 64, 224), ("n", 1, 32, 32), ("s", 7, 160, 96), ("n", 9, 64, 64)])
+def test_forward_non_square_and_odd_batches(cuda, version, B, H, W):
+    """Ragged shapes: non-square inputs (multiples of 32), batch sizes that are not powers of two, the minimum 32 x 32 input."""
+    for dtype, bar in (("f32", 1e-4), ("f16", 3e-3)):
+        m, sd = make_model(version, 31, dtype=dtype)
+        x = net_oracle.synth_image(B, 3, H, W, 5)
+        with torch.no_grad():
+            ref = net_oracle.yolopoint_forward(sd, x, version)
+            got = m.to(cuda)(x.to(cuda))
+        for name in ("semi", "desc"):
+            assert got[name].shape == ref[name].shape
+            assert rel_err(got[name], ref[name])[1] < bar, (dtype, name)
+        assert got["objects"][0].shape == ref["objects"][0].shape
+        assert rel_err(got["objects"][0], ref["objects"][0])[1] < (1e-4 if dtype == "f32" else 2e-2)
+        if dtype == "f32":
+            assert torch.equal(got["semi"].argmax(1).cpu(), ref["semi"].argmax(1))
+
+
 # 16-bit perf paths: measured error grows with depth (fp16 rounding of weights and of every
 # layer's activations, fp32 accumulation): raw head logits are the quantities held to a bar; the
 # decoded boxes ((2*sigmoid)^2 * anchor amplifies logit error) get a looser L2 bar.

@@ -32,11 +32,12 @@ def test_train_forward_matches_reference_golden(cuda):
     assert int(sd2["model.Conv1.bn.num_batches_tracked"]) == 1
 
 
-@pytest.mark.parametrize("version,B,S", [("n", 2, 64), ("s", 2, 128)])
-def test_backward_matches_oracle_autograd(cuda, version, B, S):
+@pytest.mark.parametrize("version,B,H,W", [("n", 2, 64, 64), ("s", 2, 128, 128), ("n", 3, 128, 192), ("s", 5, 64, 192)])
+def test_backward_matches_oracle_autograd(cuda, version, B, H, W):
+    """(square and non-square inputs, odd batch sizes)"""
     m, sd = make_model(version, 31, dtype="f32")
     m = m.to(cuda).train()
-    x = net_oracle.synth_image(B, 3, S, S, 31)
+    x = net_oracle.synth_image(B, 3, H, W, 31)
     # random projections of the three outputs as the loss (SURVEY.md 8c item 3)
     g = torch.Generator().manual_seed(5)
     leaf = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in sd.items()}
