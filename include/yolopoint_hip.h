@@ -120,6 +120,11 @@ typedef struct YpConvDesc {
     const void* post_weight;         /* packed [post_Npad][post_Kpad] 1x1 filter over 2 * in0.C input channels */
     const float* post_bias;
     int32_t post_Kpad, post_Npad;
+    /* BatchNorm statistics in the epilogue (training forward of Conv = conv -> BN -> SiLU, reference models/common.py:22-34): when
+     * non-NULL the generic kernel also writes, per block of 64 output pixels rb, the column sums of the raw output and of its square:
+     * bn_partial[(rb*2 + 0)*C + c] and [(rb*2 + 1)*C + c], C = out.C, ceil(B*Ho*Wo / 64) row blocks; yp_bn_finalize folds them.
+     * Needs tail_zero, a 16-bit or fp32 store of the same dtype, no bias / activation / residual / out2 / ksplit, tile 0..5. */
+    float* bn_partial;
 } YpConvDesc;
 
 int yp_conv2d(const YpConvDesc* d, void* stream);
@@ -184,6 +189,11 @@ size_t yp_bn_workspace_bytes(int B, int H, int W, int C);
  * (momentum, unbiased variance) in place when the pointers are non-NULL */
 int yp_bn_stats(YpView raw, int dtype, int B, float eps, float momentum, float* mean, float* invstd,
                 float* running_mean, float* running_var, void* workspace, size_t workspace_bytes, void* stream);
+
+/* mean / invstd (+ running statistics) from the per-row-block partial sums a convolution wrote (YpConvDesc.bn_partial): the second half
+ * of yp_bn_stats without its reduction pass.  partial [rows][2][C]; M = the number of pixels the sums cover. */
+int yp_bn_finalize(const float* partial, int rows, int C, double M, float eps, float momentum, float* mean, float* invstd, float* running_mean,
+                   float* running_var, void* stream);
 /* out = act(gamma*(raw-mean)*invstd + beta) [+ res] */
 int yp_bn_act_apply(YpView raw, YpView out, YpView res, int dtype, int B, const float* mean, const float* invstd,
                     const float* gamma, const float* beta, int act, void* stream);
@@ -271,7 +281,8 @@ int yp_objloss_level(const float* p, int cells, int no, int nc, const int* cell,
 /* One generic launch record: `op` selects one of the functions above, the slots carry its arguments in the
  * order documented next to each opcode.  Lets training plans replay any mix of launches (yp_plan_add_op). */
 enum {
-    YP_OP_BN_STATS = 10,      /* v0=raw; i0=dtype i1=B; s0=eps s1=momentum; g0=mean g1=invstd g2=running_mean g3=running_var; p0=ws n0=ws_bytes */
+    YP_OP_BN_STATS = 10,      /* v0=raw; i0=dtype i1=B; s0=eps s1=momentum; g0=mean g1=invstd g2=running_mean g3=running_var; p0=ws n0=ws_bytes;
+                                 i2=rows > 0: finalize only (yp_bn_finalize) from p1 = the partial sums a convolution wrote */
     YP_OP_BN_APPLY = 11,      /* v0=raw v1=out v2=res; i0=dtype i1=B i2=act; f0=mean f1=invstd f2=gamma f3=beta */
     YP_OP_BN_BWD = 12,        /* v0=raw v1=dy v2=dx; i0=dtype i1=B i2=act i3=accumulate; f0..f3 as above; g0=dgamma g1=dbeta; p0=ws n0=ws_bytes */
     YP_OP_UPS2_BWD = 13,      /* v0=in v1=out; i0=dtype i1=B i2=accumulate */

@@ -35,7 +35,8 @@ class YpConvDesc(C.Structure):
                 ("atomic_accumulate", C.c_int32), ("tail_zero", C.c_int32),
                 ("pre_weight", C.c_void_p), ("pre_bias", C.c_void_p), ("pre_Kpad", C.c_int32), ("pre_Npad", C.c_int32),
                 ("pre_act", C.c_int32), ("post_act", C.c_int32),
-                ("post_weight", C.c_void_p), ("post_bias", C.c_void_p), ("post_Kpad", C.c_int32), ("post_Npad", C.c_int32)]
+                ("post_weight", C.c_void_p), ("post_bias", C.c_void_p), ("post_Kpad", C.c_int32), ("post_Npad", C.c_int32),
+                ("bn_partial", C.c_void_p)]
 
 
 class YpDetectDesc(C.Structure):
@@ -82,6 +83,7 @@ SIGNATURES = {
     "yp_cast_from_f32": (_i, [YpView, YpView, _i, _i, _p]),
     "yp_conv_wgrad": (_i, [YpView, YpView, _i, _i, _i, _i, _p, _p]),
     "yp_plan_set_lane": (_i, [_p, _i, _i]),
+    "yp_bn_finalize": (_i, [_p, _i, _i, C.c_double, _f, _f, _p, _p, _p, _p, _p]),
     "yp_wgrad_unpack_batch": (_i, [_p, _i, _i, _p]),
     "yp_infonce_fwd": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _p, _p]),
     "yp_infonce_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p]),

@@ -102,6 +102,7 @@ struct ConvKArgs {
     float det_anchor[16];
     float* det_x;
     float* det_z;
+    float* stats;                  // STATS instantiations: per-64-pixel-row-block column sums [row block][2][Cout] (BatchNorm statistics)
 };
 
 // sigmoid as v_mul, v_exp_f32, v_add, v_rcp_f32 (rel. error ~1e-7); a plain 1/(1+expf(-x)) is ~25 instructions
@@ -261,7 +262,7 @@ __device__ __forceinline__ void yp_glds16_s(const void* sbase, unsigned voff, un
 // places lanes linearly).  Bank conflicts of the 16-byte fragment reads are removed by an XOR
 // swizzle applied on the SOURCE side: physical chunk j of row r holds logical chunk j ^ swz(r),
 // swz(r) = {0,0,3,3}[(r/4)%4]; readers apply the same involution.
-template <int DT, bool OUT_F32, bool FAST, bool DETECT, int BM, int BN, int WAVES_M, int WAVES_N, int NS>
+template <int DT, bool OUT_F32, bool FAST, bool DETECT, int BM, int BN, int WAVES_M, int WAVES_N, int NS, bool STATS = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     using E = Elem<DT>;
     using frag_t = typename E::frag;
@@ -506,6 +507,48 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
             } else {
                 yp_epilogue_pixel<DT, OUT_F32, LPG>(a, m, nb, bias, [&](int cj) { return acc[cj >> 2][fm][cj & 3]; });
             }
+        }
+    }
+    if constexpr (STATS) {
+        // BatchNorm statistics of the raw output straight from the accumulators (training forward of a 1x1 Conv: the separate reduction
+        // pass re-read the tensor, 5.8 us per layer): per lane sum / sum of squares over its pixels, 16-lane butterfly over the pixel
+        // lanes, LDS atomics across the waves of a 64-pixel row block, one partial row per row block: stats[(rb*2 + {0,1})*Cout + c].
+        float sv[LPG], sq[LPG];
+#pragma unroll
+        for (int j = 0; j < LPG; ++j) sv[j] = sq[j] = 0.f;
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) {
+            const int m = m0 + wm * TM + fm * 16 + p;
+            if (m < a.M) {
+#pragma unroll
+                for (int j = 0; j < LPG; ++j) { const float v = acc[j >> 2][fm][j & 3]; sv[j] += v; sq[j] += v * v; }
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+#pragma unroll
+            for (int j = 0; j < LPG; ++j) { sv[j] += __shfl_xor(sv[j], o, 64); sq[j] += __shfl_xor(sq[j], o, 64); }
+        }
+        constexpr int HALVES = BM / 64;
+        float* red = reinterpret_cast<float*>(smem);           // [HALVES][2][BN], in the now idle pipeline LDS
+        __syncthreads();
+        for (int i = t; i < HALVES * 2 * BN; i += 256) red[i] = 0.f;
+        __syncthreads();
+        const int half = (wm * TM) / 64;
+        if (p == 0) {
+#pragma unroll
+            for (int j = 0; j < LPG; ++j) {
+                const int cl = wn * TN + g * LPG + j;
+                atomicAdd(red + (half * 2 + 0) * BN + cl, sv[j]);
+                atomicAdd(red + (half * 2 + 1) * BN + cl, sq[j]);
+            }
+        }
+        __syncthreads();
+        for (int i = t; i < HALVES * 2 * BN; i += 256) {
+            const int h = i / (2 * BN), w2 = (i / BN) & 1, cl = i % BN;
+            const int c = n0 + cl;
+            const int rb = m0 / 64 + h;
+            if (c < a.Cout && rb * 64 < a.M) a.stats[((size_t)rb * 2 + w2) * a.Cout + c] = red[i];
         }
     }
     YP_TL(41);
@@ -1263,10 +1306,10 @@ struct TileCfg { int id, bm, bn; };
 // tiles on the 80 x 80 level and was dropped.)
 constexpr TileCfg kTiles[] = {{1, 128, 32}, {2, 128, 64}, {3, 128, 128}, {4, 64, 64}, {5, 64, 32}};
 
-template <int DT, bool OUT_F32, bool FAST, bool DETECT, int BM, int BN, int WAVES_M, int WAVES_N, int NS>
+template <int DT, bool OUT_F32, bool FAST, bool DETECT, int BM, int BN, int WAVES_M, int WAVES_N, int NS, bool STATS = false>
 hipError_t launch_tile(const ConvKArgs& a, int nblk, hipStream_t st) {
     constexpr size_t lds = (size_t)NS * (BM / 16 + BN / 16) * 1024;
-    auto kern = conv_igemm_kernel<DT, OUT_F32, FAST, DETECT, BM, BN, WAVES_M, WAVES_N, NS>;
+    auto kern = conv_igemm_kernel<DT, OUT_F32, FAST, DETECT, BM, BN, WAVES_M, WAVES_N, NS, STATS>;
     if constexpr (lds > 65536) {
         static bool attr_set = false;        // per instantiation
         if (!attr_set) {
@@ -1279,14 +1322,14 @@ hipError_t launch_tile(const ConvKArgs& a, int nblk, hipStream_t st) {
     return hipGetLastError();
 }
 
-template <int DT, bool OUT_F32, bool FAST, bool DETECT = false>
+template <int DT, bool OUT_F32, bool FAST, bool DETECT = false, bool STATS = false>
 hipError_t launch_cfg(int tile, const ConvKArgs& a, int nblk, hipStream_t st) {
     switch (tile) {
-        case 1: return launch_tile<DT, OUT_F32, FAST, DETECT, 128, 32, 4, 1, 4>(a, nblk, st);
-        case 2: return launch_tile<DT, OUT_F32, FAST, DETECT, 128, 64, 4, 1, 4>(a, nblk, st);
-        case 3: return launch_tile<DT, OUT_F32, FAST, DETECT, 128, 128, 2, 2, 4>(a, nblk, st);
-        case 4: return launch_tile<DT, OUT_F32, FAST, DETECT, 64, 64, 2, 2, 4>(a, nblk, st);
-        case 5: return launch_tile<DT, OUT_F32, FAST, DETECT, 64, 32, 4, 1, 4>(a, nblk, st);
+        case 1: return launch_tile<DT, OUT_F32, FAST, DETECT, 128, 32, 4, 1, 4, STATS>(a, nblk, st);
+        case 2: return launch_tile<DT, OUT_F32, FAST, DETECT, 128, 64, 4, 1, 4, STATS>(a, nblk, st);
+        case 3: return launch_tile<DT, OUT_F32, FAST, DETECT, 128, 128, 2, 2, 4, STATS>(a, nblk, st);
+        case 4: return launch_tile<DT, OUT_F32, FAST, DETECT, 64, 64, 2, 2, 4, STATS>(a, nblk, st);
+        case 5: return launch_tile<DT, OUT_F32, FAST, DETECT, 64, 32, 4, 1, 4, STATS>(a, nblk, st);
         default: return hipErrorInvalidValue;
     }
 }
@@ -1513,6 +1556,21 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
         return YP_OK;
     }
     YP_REQUIRE(d->tile < 10, "yp_conv2d: tile %d (3x3 halo kernel) does not apply to this convolution", d->tile);
+    if (d->bn_partial != nullptr) {          // BatchNorm statistics in the epilogue (generic kernel, fast addressing, 16-bit or fp32 store)
+        YP_REQUIRE(fast && !of32 && ksplit <= 1 && !a.atomic_out && d->bias == nullptr && d->act == YP_ACT_NONE && d->res.C == 0 && d->out2.C == 0,
+                   "yp_conv2d: bn_partial needs the plain fast path (tail_zero, no bias / activation / residual / split / second output)");
+        a.stats = d->bn_partial;
+        switch (d->dtype) {
+            case YP_F16: e = launch_cfg<YP_F16, false, true, false, true>(tile, a, nblk, stream); break;
+            case YP_BF16: e = launch_cfg<YP_BF16, false, true, false, true>(tile, a, nblk, stream); break;
+            default: e = launch_cfg<YP_F32, false, true, false, true>(tile, a, nblk, stream); break;
+        }
+        if (e != hipSuccess) {
+            yp_set_error("yp_conv2d: launch failed: %s", hipGetErrorString(e));
+            return YP_ERR_HIP;
+        }
+        return YP_OK;
+    }
 #define YP_DISPATCH(DT)                                                                                             \
     (of32 ? (fast ? launch_cfg<DT, true, true>(tile, a, nblk, stream) : launch_cfg<DT, true, false>(tile, a, nblk, stream)) \
           : (fast ? launch_cfg<DT, false, true>(tile, a, nblk, stream) : launch_cfg<DT, false, false>(tile, a, nblk, stream)))

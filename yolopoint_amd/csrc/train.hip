@@ -636,6 +636,14 @@ extern "C" int yp_bn_stats(YpView raw, int dtype, int B, float eps, float moment
     return YP_OK;
 }
 
+extern "C" int yp_bn_finalize(const float* partial, int rows, int C, double M, float eps, float momentum, float* mean, float* invstd, float* running_mean,
+                              float* running_var, void* stream) {
+    YP_REQUIRE(partial && mean && invstd && rows > 0 && C > 0 && M > 0, "yp_bn_finalize: bad arguments");
+    bn_stats_finalize_kernel<<<C, 256, 0, (hipStream_t)stream>>>(partial, rows, C, M, eps, momentum, mean, invstd, running_mean, running_var);
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
 extern "C" int yp_bn_act_apply(YpView raw, YpView out, YpView res, int dtype, int B, const float* mean, const float* invstd,
                                const float* gamma, const float* beta, int act, void* stream) {
     if (int rc = check_view8(raw, "yp_bn_act_apply")) return rc;
@@ -949,7 +957,11 @@ extern "C" int yp_run_op(const YpOpArgs* a, void* stream) {
     YP_REQUIRE(a != nullptr, "yp_run_op: null args");
     const int dt = a->i[0], B = a->i[1];
     switch (a->op) {
-        case YP_OP_BN_STATS: return yp_bn_stats(a->v[0], dt, B, a->s[0], a->s[1], a->g[0], a->g[1], a->g[2], a->g[3], a->p[0], a->n[0], stream);
+        case YP_OP_BN_STATS:
+            if (a->i[2] > 0)
+                return yp_bn_finalize((const float*)a->p[1], a->i[2], a->v[0].C, (double)B * a->v[0].H * a->v[0].W, a->s[0], a->s[1], a->g[0], a->g[1], a->g[2], a->g[3],
+                                      stream);
+            return yp_bn_stats(a->v[0], dt, B, a->s[0], a->s[1], a->g[0], a->g[1], a->g[2], a->g[3], a->p[0], a->n[0], stream);
         case YP_OP_BN_APPLY: return yp_bn_act_apply(a->v[0], a->v[1], a->v[2], dt, B, a->f[0], a->f[1], a->f[2], a->f[3], a->i[2], stream);
         case YP_OP_BN_BWD: return yp_bn_act_bwd(a->v[0], a->v[1], a->v[2], dt, B, a->f[0], a->f[1], a->f[2], a->f[3], a->i[2], a->g[0], a->g[1], a->i[3], a->p[0], a->n[0], stream);
         case YP_OP_UPS2_BWD: return yp_ups2_bwd(a->v[0], a->v[1], dt, B, a->i[2], stream);

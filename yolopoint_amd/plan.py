@@ -216,6 +216,7 @@ class PlanBuilder:
           out_hw=(Ho,Wo), dil=int, zero_stuffed=bool (in0 read as a zero-stuffed 2x tensor), ksplit=int,
           kernel_hw=(R,S) for non-square "filters", raw_weight=(tensor [Npad+1][Kpad], Kpad, Npad) to bypass packing,
           pre=(w1, b1, act1): fused Bottleneck — this 3x3 reads act1(conv1x1(src, w1) + b1), the hidden tensor stays in LDS,
+          bn_partial=tensor: the generic kernel's epilogue also writes the per-64-pixel-block column sums (yp_bn_finalize),
           dry_run=True: build + autotune the launch but do not add it; returns the measured ms per launch (None if untimed)."""
         if isinstance(srcs, View):
             srcs = [srcs]
@@ -332,6 +333,10 @@ class PlanBuilder:
         d.ksplit = int(extra.get("ksplit", 1))
         d.atomic_accumulate = int(extra.get("atomic", 0))
         d.Kpad, d.Npad, d.act, d.tile, d.tail_zero = Kpad, Npad, act, tile, 1
+        bn_partial = extra.get("bn_partial")        # fp32 [ceil(M/64)][2][Cout_pad]: BatchNorm column sums written by the epilogue
+        if bn_partial is not None:
+            d.bn_partial = bn_partial.data_ptr()
+            self.keep.append(bn_partial)
         pre = extra.get("pre")
         if pre is not None:
             w1, b1, act1 = pre
@@ -360,7 +365,8 @@ class PlanBuilder:
         tuned_ms = None
         if tile == 0 and self.autotune and d.ksplit == 1 and not d.atomic_accumulate:
             d.tile, tuned_ms = self._autotune(d, det, (self.code, d.B, Hi, Wi, tuple((v.C, v.ups) for v in srcs), Cout_pad, R, S, sh, sw, dil, zs,
-                                                       int(out_f32), res is not None, c2, act, detect is not None, pre is not None, post is not None))
+                                                       int(out_f32), res is not None, c2, act, detect is not None, pre is not None, post is not None,
+                                                       bn_partial is not None))
         if extra.get("dry_run"):
             return tuned_ms
         if det is not None:

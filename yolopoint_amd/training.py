@@ -113,7 +113,16 @@ class TrainGraph:
         f, B, code = self.fwd, self.B, self.code
         image = len(srcs) == 1 and srcs[0].geom is None and srcs[0].cstride == 4 and srcs[0].C == 4      # the stem keeps the host packer
         wsrc = (lambda: (conv.weight.detach().float(), None)) if image else MasterWeight(conv.weight)
-        raw = f.conv(srcs, wsrc, None, k, s, p, _hip.YP_ACT_NONE)
+        # 1x1 convolutions (always the generic kernel): the BatchNorm column sums come out of the conv epilogue, per block of 64 pixels
+        # (YpConvDesc.bn_partial) -- no separate reduction pass over the raw output.  YP_BN_EPILOGUE=0: the reduction kernel everywhere.
+        chunk = 16 if code == _hip.YP_F32 else 32          # (the epilogue variant exists for the kernel's fast addressing mode: 64-byte k chunks)
+        fuse_stats = (k == 1 and s == 1 and not image and all(v.C % chunk == 0 for v in srcs) and os.environ.get("YP_BN_EPILOGUE", "1") != "0")
+        partial = None
+        if fuse_stats:
+            Ho_, Wo_ = srcs[0].LH, srcs[0].LW
+            rows = -(-(B * Ho_ * Wo_) // 64)
+            partial = torch.zeros((rows, 2, round_up(conv.out_channels, 8)), dtype=torch.float32, device=self.device)
+        raw = f.conv(srcs, wsrc, None, k, s, p, _hip.YP_ACT_NONE, extra=dict(bn_partial=partial) if fuse_stats else None)
         Cc, Cp = conv.out_channels, raw.C
         mean, invstd = f.new_tensor((Cp,)), f.new_tensor((Cp,))
         gamma, beta, rmean, rvar = bn.weight, bn.bias, bn.running_mean, bn.running_var
@@ -133,8 +142,13 @@ class TrainGraph:
                 bn.running_mean.copy_(rmean[:Cc]); bn.running_var.copy_(rvar[:Cc])
             self.pre_forward.append(sync_in)
             self.post_forward.append(sync_out)
-        f.op(_hip.OP_BN_STATS, [raw], [self.T(mean), self.T(invstd)], "bn_stats", v=[raw], i=[code, B], s=[bn.eps, bn.momentum],
-             g=[mean, invstd, rmean, rvar], p=[self.ws], n=[self.ws.numel()])
+        if fuse_stats:
+            assert partial.shape[2] == Cp
+            f.op(_hip.OP_BN_STATS, [raw, self.T(partial)], [self.T(mean), self.T(invstd)], "bn_stats", v=[raw], i=[code, B, partial.shape[0]],
+                 s=[bn.eps, bn.momentum], g=[mean, invstd, rmean, rvar], p=[self.ws, partial], n=[self.ws.numel()])
+        else:
+            f.op(_hip.OP_BN_STATS, [raw], [self.T(mean), self.T(invstd)], "bn_stats", v=[raw], i=[code, B], s=[bn.eps, bn.momentum],
+                 g=[mean, invstd, rmean, rvar], p=[self.ws], n=[self.ws.numel()])
         if out is None:
             out = f.new_buf(raw.H, raw.W, raw.C).view()
         f.op(_hip.OP_BN_APPLY, [raw, res, self.T(mean), self.T(invstd)], [out], "bn_act", v=[raw, out, res], i=[code, B, act],
