@@ -209,7 +209,7 @@ def test_native_infonce_matches_torch_formulation(cuda, n, negs, D):
     da.grad = db.grad = None
     got = _InfoNCENative.apply(da, db, *infonce_edges(rnd), tau)
     (got * 3.0).backward()
-    assert abs(float(got) - float(ref)) <= 1e-5 * abs(float(ref))
+    assert abs(float(got) - float(ref)) <= 1e-5 * abs(float(ref)), (float(got), float(ref))
     assert rel_err(da.grad, ga)[1] < 1e-5 and rel_err(db.grad, gb)[1] < 1e-5
 
 
@@ -296,7 +296,7 @@ def test_two_lane_backward_matches_single_lane(cuda, monkeypatch):
             (o["semi"].square().mean() + o["desc"].mean() + sum(t.tanh().mean() for t in o["objects"])).backward()
         grads[lanes] = [p.grad.clone() for p in m.parameters()]
     for a, b in zip(grads["1"], grads["0"]):
-        assert rel_err(a, b)[1] < 1e-4          # fp32 atomics: the accumulation order differs run to run
+        assert rel_err(a, b)[1] < 1e-4          # fp32 atomics of the weight-gradient flush: the accumulation order differs run to run
 
 
 @pytest.mark.parametrize("fused", [False, True])

@@ -524,31 +524,51 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
                 for (int j = 0; j < LPG; ++j) { const float v = acc[j >> 2][fm][j & 3]; sv[j] += v; sq[j] += v * v; }
             }
         }
+        // reduce over the 16 pixel lanes by recursive halving: at offset o a lane keeps one half of its channels and hands the other half
+        // to lane ^ o (LPG/2 + LPG/4 + ... exchanges instead of 4 * LPG); once a single channel is left the remaining offsets are plain
+        // butterfly adds.  Lane p ends up with the total of channel `mych` of its group's LPG channels.
+        int n = LPG, mych = 0;
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) {
+            const bool up = (p & o) != 0;
+            if (n > 1) {
+                const int hn = n / 2;
 #pragma unroll
-            for (int j = 0; j < LPG; ++j) { sv[j] += __shfl_xor(sv[j], o, 64); sq[j] += __shfl_xor(sq[j], o, 64); }
+                for (int j = 0; j < LPG / 2; ++j) {
+                    if (j < hn) {
+                        const float keep_s = up ? sv[hn + j] : sv[j], give_s = up ? sv[j] : sv[hn + j];
+                        const float keep_q = up ? sq[hn + j] : sq[j], give_q = up ? sq[j] : sq[hn + j];
+                        sv[j] = keep_s + __shfl_xor(give_s, o, 64);
+                        sq[j] = keep_q + __shfl_xor(give_q, o, 64);
+                    }
+                }
+                mych += up ? hn : 0;
+                n = hn;
+            } else {
+                sv[0] += __shfl_xor(sv[0], o, 64);
+                sq[0] += __shfl_xor(sq[0], o, 64);
+            }
         }
         constexpr int HALVES = BM / 64;
-        float* red = reinterpret_cast<float*>(smem);           // [HALVES][2][BN], in the now idle pipeline LDS
-        __syncthreads();
-        for (int i = t; i < HALVES * 2 * BN; i += 256) red[i] = 0.f;
-        __syncthreads();
-        const int half = (wm * TM) / 64;
-        if (p == 0) {
-#pragma unroll
-            for (int j = 0; j < LPG; ++j) {
-                const int cl = wn * TN + g * LPG + j;
-                atomicAdd(red + (half * 2 + 0) * BN + cl, sv[j]);
-                atomicAdd(red + (half * 2 + 1) * BN + cl, sq[j]);
-            }
+        constexpr int WPH = WAVES_M / HALVES > 0 ? WAVES_M / HALVES : 1;       // waves sharing a 64-pixel row block (per channel range)
+        constexpr int OWNERS = LPG < 16 ? LPG : 16;           // lanes p < OWNERS of a 16-lane group each own one channel total
+        float* red = reinterpret_cast<float*>(smem);           // [HALVES][WPH][2][BN] in the now idle pipeline LDS; plain stores and a
+        __syncthreads();                                       // fixed summation order: the statistics are bit-reproducible
+        const int half = (wm * TM) / 64, wih = wm % WPH;
+        if (p < OWNERS) {
+            const int cl = wn * TN + g * LPG + mych;
+            red[((half * WPH + wih) * 2 + 0) * BN + cl] = sv[0];
+            red[((half * WPH + wih) * 2 + 1) * BN + cl] = sq[0];
         }
         __syncthreads();
         for (int i = t; i < HALVES * 2 * BN; i += 256) {
             const int h = i / (2 * BN), w2 = (i / BN) & 1, cl = i % BN;
             const int c = n0 + cl;
             const int rb = m0 / 64 + h;
-            if (c < a.Cout && rb * 64 < a.M) a.stats[((size_t)rb * 2 + w2) * a.Cout + c] = red[i];
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < WPH; ++w) v += red[((h * WPH + w) * 2 + w2) * BN + cl];
+            if (c < a.Cout && rb * 64 < a.M) a.stats[((size_t)rb * 2 + w2) * a.Cout + c] = v;
         }
     }
     YP_TL(41);
