@@ -226,6 +226,14 @@ int yp_col_sum(YpView v, int dtype, int B, float* out, int accumulate, void* wor
  * `dw` [x.C][k][k][dy.C] must be zero-initialised).  x may be read through its 2x nearest upsample (x.ups = 1).
  * 16-bit dtypes.  replaces: autograd's conv2d weight gradient (reference train.py:245 loss.backward()). */
 int yp_conv_wgrad(YpView x, YpView dy, int dtype, int B, int k, int stride, float* dw, void* stream);
+
+/* Every weight gradient of ONE filter class (k, stride as yp_conv_wgrad) of a backward pass in a single launch.  yp_wgrad_group_pack
+ * fills a host table of n entries of yp_wgrad_group_entry_bytes() bytes each (argument checks as yp_conv_wgrad) and returns the
+ * launch size; the caller copies the table to device memory and replays yp_wgrad_group_run(table_dev, n, total_blocks, ...). */
+size_t yp_wgrad_group_entry_bytes(void);
+int yp_wgrad_group_pack(const YpView* xs, const YpView* dys, float* const* dws, int n, int dtype, int B, int k, int stride, void* table_host,
+                        int* total_blocks);
+int yp_wgrad_group_run(const void* table_dev, int n, int total_blocks, int dtype, int k, int stride, void* stream);
 /* dw[ci][r][s][co] (fp32, Cout_pad channels per tap: the layout yp_conv_wgrad / the wgrad-as-convolution path produce)
  * -> grad[co][c0+ci][r][s] for ci < creal, co < Cout: the reference layout of conv.weight.grad */
 int yp_wgrad_unpack(const float* dw, float* grad, int Cout, int Cin, int k, int c0, int creal, int Cout_pad, void* stream);
@@ -303,6 +311,7 @@ enum {
     YP_OP_WGRAD_UNPACK = 28,  /* p0=dw [Cj][k][k][Cout_pad] fp32 -> g0=grad OIHW [Cout][Cin][k][k] fp32, input-channel slice [c0, c0+creal):
                                * i1=Cout i2=Cin i3=k i4=c0 i5=creal i6=Cout_pad */
     YP_OP_WGRAD_UNPACK_BATCH = 30, /* p0=device table of YpUnpackEntry; i1=entries i2=total tiles */
+    YP_OP_WGRAD_GROUP = 31,   /* p0=device table (yp_wgrad_group_pack); i0=dtype i1=entries i2=total blocks i3=k i4=stride */
     YP_OP_PACK_WEIGHT = 26    /* f0=w f1=bias; g0=bias_dst; p0=dst; i0=dtype i1=Cout i2=Cin i3=R i4=S i5=c0 i6=Cj i7=mode; n0=Kpad n1=Npad | Cout_pad<<32 */
 };
 typedef struct YpOpArgs {

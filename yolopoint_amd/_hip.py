@@ -50,7 +50,7 @@ class YpOpArgs(C.Structure):
 
 
 (OP_BN_STATS, OP_BN_APPLY, OP_BN_BWD, OP_UPS2_BWD, OP_ADD_VIEWS, OP_MAXPOOL5_BWD, OP_L2NORM_BWD, OP_DETECT_BWD_PACK, OP_TO_CHWB,
- OP_COL_SUM, OP_MEMSET0, OP_PACK_NCHW, OP_L2NORM, OP_SPPF_POOL, OP_CAST_F32, OP_MAXPOOL2, OP_PACK_WEIGHT, OP_WGRAD, OP_WGRAD_UNPACK, OP_MAXPOOL2_BWD, OP_WGRAD_UNPACK_BATCH) = range(10, 31)
+ OP_COL_SUM, OP_MEMSET0, OP_PACK_NCHW, OP_L2NORM, OP_SPPF_POOL, OP_CAST_F32, OP_MAXPOOL2, OP_PACK_WEIGHT, OP_WGRAD, OP_WGRAD_UNPACK, OP_MAXPOOL2_BWD, OP_WGRAD_UNPACK_BATCH, OP_WGRAD_GROUP) = range(10, 32)
 LANE_MAIN, LANE_SIDE, LANE_JOIN = 0, 1, 2
 
 _i, _f, _p, _sz, _i64 = C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_int64
@@ -84,6 +84,9 @@ SIGNATURES = {
     "yp_conv_wgrad": (_i, [YpView, YpView, _i, _i, _i, _i, _p, _p]),
     "yp_plan_set_lane": (_i, [_p, _i, _i]),
     "yp_bn_finalize": (_i, [_p, _i, _i, C.c_double, _f, _f, _p, _p, _p, _p, _p]),
+    "yp_wgrad_group_entry_bytes": (_sz, []),
+    "yp_wgrad_group_pack": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "yp_wgrad_group_run": (_i, [_p, _i, _i, _i, _i, _i, _p]),
     "yp_wgrad_unpack_batch": (_i, [_p, _i, _i, _p]),
     "yp_infonce_fwd": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _p, _p]),
     "yp_infonce_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p]),

@@ -38,6 +38,7 @@ struct WgradArgs {
     int n_co_blk;
     int tiles_x, tiles_y, ntiles, M;
     int skip_store;                        // probe only (YP_WG_NOSTORE): time the reduction without the final atomics
+    int g_blk0, g_nblk, g_split;           // grouped launch: first flat workgroup of this entry, its (ci x co) blocks and pixel split
 };
 
 __device__ __forceinline__ void wg_glds16(const void* gsrc, unsigned lds_dst) {
@@ -60,7 +61,7 @@ __device__ __forceinline__ s16x8 wg_tr8(const char* lds_lo, const char* lds_hi) 
 }
 
 template <int DT, int TAPS, int ST>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
+__device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bx, const int first, const int step) {
     constexpr int KS = TAPS == 9 ? 3 : 1;
     constexpr int TH = (TAPS == 9 && ST == 2) ? 4 : 8;     // output rows of a 3x3 tile (16 columns)
     constexpr int HP = 16 * ST + (ST == 1 ? 2 : 1);        // halo pitch: 18 | 33 pixels
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char wsm[];      // 2 stages of [x: 4 cb][XR][32 B] [dy: 4 cb][NPIX][32 B]
     const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)wsm);
 
-    const int ci0 = (blockIdx.x / a.n_co_blk) * 64, co0 = (blockIdx.x % a.n_co_blk) * 64;
+    const int ci0 = (bx / a.n_co_blk) * 64, co0 = (bx % a.n_co_blk) * 64;
     const int t = threadIdx.x, l = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int half = l & 1, prow = l >> 1;                 // DMA: this lane moves channels [half*8, +8) of row prow of its 32-row slab
@@ -159,7 +160,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
             for (int fb = 0; fb < 2; ++fb) acc[tp][fa][fb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int first = blockIdx.y, step = gridDim.y;
     if (first < a.ntiles) issue(first, 0);
     int it = 0;
     for (int tile = first; tile < a.ntiles; tile += step, ++it) {
@@ -214,6 +214,27 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 }
 
 template <int DT, int TAPS, int ST>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
+    wgrad_body<DT, TAPS, ST>(a, blockIdx.x, blockIdx.y, gridDim.y);
+}
+
+// All weight gradients of one filter class (1x1 | 3x3 stride 1 | 3x3 stride 2) of a backward pass in ONE launch: a device table of
+// argument sets, flat workgroup ids mapped to (entry, channel block, pixel-split slice).  81 + 20 + 12 launches per training step
+// become 3 per backward pass; the small 1x1 gradients no longer leave most of the chip idle between launches.
+template <int DT, int TAPS, int ST>
+__global__ __launch_bounds__(256) void wgrad_group_kernel(const WgradArgs* __restrict__ table, int n_entries) {
+    const int bid = blockIdx.x;                                   // (everything below depends on blockIdx only: scalar loads, SGPR arguments)
+    int e = 0;
+    for (int lo = 0, hi = n_entries - 1; lo <= hi;) {             // last entry with g_blk0 <= bid
+        const int mid = (lo + hi) >> 1;
+        if (table[mid].g_blk0 <= bid) { e = mid; lo = mid + 1; } else hi = mid - 1;
+    }
+    const WgradArgs a = table[e];
+    const int local = bid - a.g_blk0;
+    wgrad_body<DT, TAPS, ST>(a, local % a.g_nblk, local / a.g_nblk, a.g_split);
+}
+
+template <int DT, int TAPS, int ST>
 hipError_t launch_wgrad(const WgradArgs& a, dim3 grid, hipStream_t st) {
     constexpr int TH = (TAPS == 9 && ST == 2) ? 4 : 8;
     constexpr int HP = 16 * ST + (ST == 1 ? 2 : 1);
@@ -239,7 +260,8 @@ hipError_t dispatch_wgrad(int k, int stride, const WgradArgs& a, dim3 grid, hipS
 
 }  // namespace
 
-extern "C" int yp_conv_wgrad(YpView x, YpView dy, int dtype, int B, int k, int stride, float* dw, void* stream) {
+// argument set + launch geometry of one weight gradient (shared by the single and the grouped entry points)
+static int wgrad_make_args(YpView x, YpView dy, int dtype, int B, int k, int stride, float* dw, WgradArgs* out, int* nblk_out, int* split_out) {
     YP_REQUIRE(dtype == YP_F16 || dtype == YP_BF16, "yp_conv_wgrad: 16-bit element types only");
     YP_REQUIRE((k == 1 && stride == 1) || (k == 3 && (stride == 1 || stride == 2)), "yp_conv_wgrad: 1x1 (stride 1) or 3x3 (pad 1, stride 1 | 2) filters only");
     YP_REQUIRE(x.ptr && dy.ptr && dw && B > 0, "yp_conv_wgrad: null buffer");
@@ -272,8 +294,65 @@ extern "C" int yp_conv_wgrad(YpView x, YpView dy, int dtype, int B, int k, int s
     if (split > cap) split = cap;
     if (split > a.ntiles) split = a.ntiles;
     if (split < 1) split = 1;
+    a.g_nblk = nblk; a.g_split = split;
+    *out = a; *nblk_out = nblk; *split_out = split;
+    return YP_OK;
+}
+
+extern "C" int yp_conv_wgrad(YpView x, YpView dy, int dtype, int B, int k, int stride, float* dw, void* stream) {
+    WgradArgs a;
+    int nblk, split;
+    if (int rc = wgrad_make_args(x, dy, dtype, B, k, stride, dw, &a, &nblk, &split)) return rc;
     const dim3 grid(nblk, split);
     const hipError_t e = dtype == YP_F16 ? dispatch_wgrad<YP_F16>(k, stride, a, grid, (hipStream_t)stream) : dispatch_wgrad<YP_BF16>(k, stride, a, grid, (hipStream_t)stream);
     if (e != hipSuccess) { yp_set_error("yp_conv_wgrad: launch failed: %s", hipGetErrorString(e)); return YP_ERR_HIP; }
+    return YP_OK;
+}
+
+extern "C" size_t yp_wgrad_group_entry_bytes(void) { return sizeof(WgradArgs); }
+
+extern "C" int yp_wgrad_group_pack(const YpView* xs, const YpView* dys, float* const* dws, int n, int dtype, int B, int k, int stride, void* table_host,
+                                   int* total_blocks) {
+    YP_REQUIRE(xs && dys && dws && table_host && total_blocks && n > 0, "yp_wgrad_group_pack: bad arguments");
+    WgradArgs* t = (WgradArgs*)table_host;
+    int blk0 = 0;
+    for (int i = 0; i < n; ++i) {
+        int nblk, split;
+        if (int rc = wgrad_make_args(xs[i], dys[i], dtype, B, k, stride, dws[i], &t[i], &nblk, &split)) return rc;
+        t[i].g_blk0 = blk0;
+        blk0 += nblk * split;
+    }
+    *total_blocks = blk0;
+    return YP_OK;
+}
+
+template <int DT, int TAPS, int ST>
+static hipError_t launch_wgrad_group(const WgradArgs* table, int n, int blocks, hipStream_t st) {
+    constexpr int TH = (TAPS == 9 && ST == 2) ? 4 : 8;
+    constexpr int HP = 16 * ST + (ST == 1 ? 2 : 1);
+    constexpr int HROWS = (TH * ST + (ST == 1 ? 2 : 1)) * HP;
+    constexpr int XR = TAPS == 9 ? (HROWS + 31) / 32 * 32 : 128;
+    constexpr size_t lds = (size_t)2 * (4 * XR * 32 + 4 * TH * 16 * 32);
+    auto kern = wgrad_group_kernel<DT, TAPS, ST>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    kern<<<blocks, 256, lds, st>>>(table, n);
+    return hipGetLastError();
+}
+
+extern "C" int yp_wgrad_group_run(const void* table_dev, int n, int total_blocks, int dtype, int k, int stride, void* stream) {
+    YP_REQUIRE(table_dev && n > 0 && total_blocks > 0 && (dtype == YP_F16 || dtype == YP_BF16), "yp_wgrad_group_run: bad arguments");
+    YP_REQUIRE((k == 1 && stride == 1) || (k == 3 && (stride == 1 || stride == 2)), "yp_wgrad_group_run: 1x1 (stride 1) or 3x3 (stride 1 | 2)");
+    const WgradArgs* t = (const WgradArgs*)table_dev;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e;
+#define YP_G(DT) (k == 1 ? launch_wgrad_group<DT, 1, 1>(t, n, total_blocks, st) : (stride == 2 ? launch_wgrad_group<DT, 9, 2>(t, n, total_blocks, st) : launch_wgrad_group<DT, 9, 1>(t, n, total_blocks, st)))
+    e = dtype == YP_F16 ? YP_G(YP_F16) : YP_G(YP_BF16);
+#undef YP_G
+    if (e != hipSuccess) { yp_set_error("yp_wgrad_group_run: launch failed: %s", hipGetErrorString(e)); return YP_ERR_HIP; }
     return YP_OK;
 }

@@ -61,6 +61,8 @@ class TrainGraph:
         # BatchNorm chain that never reads them.  Measured: 20.5 ms per step against 19.2 ms on one lane -- the concurrent kernels
         # fight over CUs / LDS / L2 (as the sub-batch stream experiment of the forward did) -- so it stays off.
         self.lanes = os.environ.get("YP_TRAIN_LANES", "0") == "1"
+        # YP_WGRAD_GROUP=0: one launch per weight gradient instead of one per filter class and backward pass
+        self.group_wgrad = not self.lanes and os.environ.get("YP_WGRAD_GROUP", "1") != "0"
         self.dw_arena = torch.zeros(round_up(2 * sum(p_.numel() for p_ in net.parameters()) + (1 << 20), 64), dtype=torch.float32, device=device)
         self.dw_used = 0
         self._build()
@@ -215,10 +217,14 @@ class TrainGraph:
             assert self.dw_used + ndw <= self.dw_arena.numel()
             dwb = Buf(Cj, k, k, Cout_pad, torch.float32, self.device, storage=self.dw_arena[self.dw_used:self.dw_used + ndw])
             self.dw_used += round_up(ndw, 64)
-            if direct and not image:
+            if direct and not image and self.group_wgrad:
+                # nothing in the rest of the backward reads dW or overwrites x / dy: the weight gradients of a filter class are
+                # collected and run as ONE grouped launch at the end of the pass (emit())
+                self.wgroups.setdefault((k, s), []).append((src, draw, dwb, 2 * B * Ho * Wo * Cj * k * k * Cout))
+            elif direct and not image:
                 b.op(_hip.OP_WGRAD, [src, draw], [dwb.view()], "wgrad", v=[src, draw], i=[code, B, k, s], p=[dwb.flat])
                 b.records[-1].kind, b.records[-1].flops = "conv", 2 * B * Ho * Wo * Cj * k * k * Cout
-                if self.lanes:       # nothing in the rest of the backward reads dW or overwrites x / dy: runs beside the dgrad chain
+                if self.lanes:       # runs beside the dgrad chain (second lane of the graph)
                     b.set_lane(_hip.LANE_SIDE)
             else:
                 if dyp is None:
@@ -422,7 +428,7 @@ class TrainGraph:
             bb.pack_target = self.fwd.pack_target
             for key in self.gwritten:
                 self.gwritten[key] = []
-            self.touched, self.collect, self.unpack = set(), [], []
+            self.touched, self.collect, self.unpack, self.wgroups = set(), [], [], {}
             bb.op(_hip.OP_MEMSET0, [], [self.T(self.dw_arena)], "zero_dw", p=[self.dw_arena], n=[self.dw_arena.numel() * 4])
             semi_seed()
             desc_seed()
@@ -432,6 +438,18 @@ class TrainGraph:
             for branch, fn in reversed(self.tape):
                 if not kp_only or branch == "kp":
                     fn()
+            for (gk, gs), ents in sorted(self.wgroups.items()):
+                n = len(ents)
+                xs, dys = (_hip.YpView * n)(*[e[0].c() for e in ents]), (_hip.YpView * n)(*[e[1].c() for e in ents])
+                dws = (C.c_void_p * n)(*[e[2].flat.data_ptr() for e in ents])
+                host = (C.c_char * (n * lib().yp_wgrad_group_entry_bytes()))()
+                blocks = C.c_int(0)
+                check(lib().yp_wgrad_group_pack(xs, dys, dws, n, code, B, gk, gs, host, C.byref(blocks)))
+                wtab = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(self.device)
+                self.keep.append(wtab)
+                bb.op(_hip.OP_WGRAD_GROUP, [v for e in ents for v in e[:2]], [e[2].view() for e in ents], f"wgrad_k{gk}s{gs}", p=[wtab],
+                      i=[code, n, blocks.value, gk, gs])
+                bb.records[-1].kind, bb.records[-1].flops = "conv", sum(e[3] for e in ents)
             rows, tile0 = [], 0
             for u in self.unpack:
                 rows.append([u["dw"].flat.data_ptr(), u["grad"].data_ptr(), u["rows"], u["cout"], u["cout_pad"], u["out_stride"], u["out_off"], tile0,
