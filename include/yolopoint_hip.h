@@ -257,6 +257,18 @@ int yp_wgrad_unpack_batch(const YpUnpackEntry* table_dev, int n_entries, int tot
 int yp_pack_weight(const float* w, int Cout, int Cin, int R, int S, int c0, int Cj, int mode, int Cout_pad, void* dst, int Kpad,
                    int Npad, int dtype, const float* bias, float* bias_dst, void* stream);
 
+/* yp_pack_weight for a whole parameter set in ONE launch: a device table of argument sets (same meaning as yp_pack_weight's);
+ * blocks of 1024 packed elements are numbered across the table, blk0 = an entry's first block, it owns
+ * ceil((Npad + 1) * Kpad / 1024) of them; sorted by blk0. */
+typedef struct YpPackEntry {
+    const float* w;
+    void* dst;
+    const float* bias;
+    float* bias_dst;
+    int64_t Cout, Cin, R, S, c0, Cj, mode, Cout_pad, Kpad, Npad, blk0;
+} YpPackEntry;
+int yp_pack_weight_batch(const YpPackEntry* table_dev, int n_entries, int total_blocks, int dtype, void* stream);
+
 /* InfoNCE descriptor loss (reference utils/loss_functions.py:484-597) without the gathered-negatives / Gram-matrix tensors.
  *   da, db [n][D] fp32 (D a multiple of 64, <= 256): sampled descriptors of the image / the warped image
  *   idx [n][E] int32: column 0 = the row itself (the match), columns 1.. = the sampled negatives (rows of db); E <= 512

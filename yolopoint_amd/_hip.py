@@ -87,6 +87,7 @@ SIGNATURES = {
     "yp_wgrad_group_entry_bytes": (_sz, []),
     "yp_wgrad_group_pack": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "yp_wgrad_group_run": (_i, [_p, _i, _i, _i, _i, _i, _p]),
+    "yp_pack_weight_batch": (_i, [_p, _i, _i, _i, _p]),
     "yp_wgrad_unpack_batch": (_i, [_p, _i, _i, _p]),
     "yp_infonce_fwd": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _p, _p]),
     "yp_infonce_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p]),

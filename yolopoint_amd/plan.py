@@ -303,6 +303,10 @@ class PlanBuilder:
                 tgt.keep += [wp, bp, master.param] + ([master.bias] if master.bias is not None else [])
                 tgt.op(_hip.OP_PACK_WEIGHT, [], [(wp, 0, 1 << 30)], "pack_w", f=[master.param, master.bias], g=[bp], p=[wp],
                        i=[self.code, mo, mi, mr, ms, master.c0, master.cj, master.mode], n=[Kpad, Npad | (master.cout_pad << 32)])
+                # (the same arguments as a row of the batched packer's table: yp_pack_weight_batch, TrainGraph.forward)
+                tgt.__dict__.setdefault("pack_entries", []).append(
+                    [master.param.data_ptr(), wp.data_ptr(), master.bias.data_ptr() if master.bias is not None else 0, bp.data_ptr(), mo, mi, mr, ms,
+                     master.c0, master.cj, master.mode, master.cout_pad, Kpad, Npad])
                 if cache is not None:
                     cache[key] = (wp, bp)
             self.keep += [wp, bp]

@@ -483,8 +483,18 @@ class TrainGraph:
             self.bwd_kp_plan.refresh()
             self._packed_version = ver
         nops = lib().yp_plan_num_ops(self.pack["pb"].handle)
-        if (ver, nops) != self.pack["version"]:                 # device-packed filters shared by all graphs
-            check(lib().yp_plan_run(self.pack["pb"].handle, _hip.stream_ptr()))
+        if (ver, nops) != self.pack["version"]:                 # device-packed filters shared by all graphs: one batched launch
+            ents = getattr(self.pack["pb"], "pack_entries", [])
+            if len(ents) == nops and os.environ.get("YP_PACK_BATCH", "1") != "0":
+                if self.pack.get("table_n") != nops:
+                    rows, blk0 = [], 0
+                    for e in ents:
+                        rows.append(e + [blk0])
+                        blk0 += -(-((e[13] + 1) * e[12]) // 1024)
+                    self.pack["table"], self.pack["table_n"], self.pack["blocks"] = torch.tensor(rows, dtype=torch.int64).to(self.device), nops, blk0
+                check(lib().yp_pack_weight_batch(self.pack["table"].data_ptr(), nops, self.pack["blocks"], self.code, _hip.stream_ptr()))
+            else:
+                check(lib().yp_plan_run(self.pack["pb"].handle, _hip.stream_ptr()))
             self.pack["version"] = (ver, nops)
         for fn in self.pre_forward:
             fn()
