@@ -298,6 +298,14 @@ int yp_objloss_level(const float* p, int cells, int no, int nc, const int* cell,
                      float cn, float cls_pw, float obj_pw, float w_box, float w_obj, float w_cls, float* iou_scratch, int* owner_scratch, float* dp,
                      float* sums, void* stream);
 
+/* Keypoint-detector loss (reference utils/loss_functions.py:600-619 ComputeDetectorLoss): sums[0] = sum over cells of
+ * mask * sum_c BCE(softmax(semi)_c, target_c) (PyTorch's BCE: logs clamped at -100), sums[1] = sum of mask; dsemi (same strides as
+ * semi) = d sums[0] / d semi.  semi / target: fp32 [B,65,Hc,Wc] with element strides (b, c, y, x); mask: contiguous [B,Hc,Wc].
+ * loss = sums[0] / (sums[1] + 1e-10), so its gradient is dsemi / (sums[1] + 1e-10). */
+size_t yp_detloss_workspace_bytes(int B, int Hc, int Wc);
+int yp_detloss(const float* semi, const int64_t* semi_strides, const float* target, const int64_t* target_strides, const float* mask, int B, int Hc, int Wc,
+               float* dsemi, float* sums, void* workspace, size_t workspace_bytes, void* stream);
+
 /* One generic launch record: `op` selects one of the functions above, the slots carry its arguments in the
  * order documented next to each opcode.  Lets training plans replay any mix of launches (yp_plan_add_op). */
 enum {

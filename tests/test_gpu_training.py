@@ -235,6 +235,32 @@ def test_native_point_sample_matches_grid_sample(cuda, B, D, H, W, P):
     assert rel_err(desc.grad, gref)[0] < 1e-5
 
 
+@pytest.mark.parametrize("B,Hc,Wc,layout", [(8, 80, 80, "nhwc"), (2, 8, 12, "nchw"), (3, 5, 7, "nhwc")])
+def test_native_detector_loss_matches_torch_formulation(cuda, monkeypatch, B, Hc, Wc, layout):
+    """csrc/losses.hip yp_detloss (softmax + clamped BCE + mask + reductions + gradient) against the PyTorch formulation of
+    ComputeDetectorLoss (reference utils/loss_functions.py:600-619) on the labels labels2Dto3D / getMasks produce."""
+    from yolopoint_amd.utils.loss_functions import ComputeDetectorLoss
+    from yolopoint_amd.utils.utils import labels2Dto3D, getMasks
+    torch.manual_seed(B + Hc)
+    base = torch.randn(B, Hc, Wc, 65, device=cuda) * 3.0
+    semi = (base.permute(0, 3, 1, 2) if layout == "nhwc" else base.permute(0, 3, 1, 2).contiguous()).requires_grad_()
+    lab2d = (torch.rand(B, 1, Hc * 8, Wc * 8, device=cuda) < 0.003).float()
+    valid = torch.ones(B, 1, Hc * 8, Wc * 8, device=cuda)
+    valid[:, :, :8, :] = 0; valid[:, :, :, -16:] = 0
+    target, mask = labels2Dto3D(lab2d), getMasks(valid, cuda)
+    crit = ComputeDetectorLoss(cuda)
+    monkeypatch.setenv("YP_NATIVE_DETLOSS", "0")
+    ref = crit(semi, target, mask)
+    (ref * 1.7).backward()
+    gref = semi.grad.clone()
+    semi.grad = None
+    monkeypatch.setenv("YP_NATIVE_DETLOSS", "1")
+    got = crit(semi, target, mask)
+    (got * 1.7).backward()
+    assert abs(float(got) - float(ref)) <= 2e-6 * abs(float(ref)), (float(got), float(ref))
+    assert rel_err(semi.grad, gref)[1] < 1e-5
+
+
 class _DetStub:
     def __init__(self, nc, dev):
         self.na, self.nc, self.nl, self.no = 3, nc, 3, nc + 5

@@ -94,6 +94,8 @@ SIGNATURES = {
     "yp_homo_combine": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p]),
     "yp_points_sample_fwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p]),
     "yp_points_sample_bwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p]),
+    "yp_detloss_workspace_bytes": (_sz, [_i, _i, _i]),
+    "yp_detloss": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _sz, _p]),
     "yp_objloss_level": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _i, _f, _f, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p]),
     "yp_maxpool2_bwd": (_i, [YpView, YpView, YpView, _i, _i, _i, _p]),
     "yp_wgrad_unpack": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),

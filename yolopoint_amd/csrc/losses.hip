@@ -223,6 +223,70 @@ __global__ __launch_bounds__(256) void points_sample_bwd_kernel(const float* __r
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// Keypoint-detector loss (reference utils/loss_functions.py:600-619): BCE between softmax(semi) over the 65 cell channels and the cell
+// labels, summed over channels, masked, averaged over the valid cells.  One wavefront per cell (lane = channel, lane 0 also carries the
+// dustbin): softmax, the BCE with PyTorch's log clamp (-100) and its gradient w.r.t. the logits in one pass; per-workgroup partial
+// sums (no same-address atomics), folded by a second tiny launch.  Replaces softmax / BCE / mask / sum kernels forward and backward.
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void detloss_kernel(const float* __restrict__ z, long zb, long zc, long zy, long zx, const float* __restrict__ y, long yb, long yc,
+                                                      long yy, long yx, const float* __restrict__ mask, int B, int Hc, int Wc, float* __restrict__ dz,
+                                                      float* __restrict__ partial) {
+    __shared__ float sh[4][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long cell = (long)blockIdx.x * 4 + wave, ncell = (long)B * Hc * Wc;
+    float lsum = 0.f, m = 0.f;
+    if (cell < ncell) {
+        const int b = (int)(cell / (Hc * Wc)), rem = (int)(cell - (long)b * Hc * Wc), cy = rem / Wc, cx = rem - cy * Wc;
+        const float* zp = z + b * zb + cy * zy + cx * zx;
+        const float* yp = y + b * yb + cy * yy + cx * yx;
+        m = mask[cell];
+        const float z0 = zp[lane * zc], z1 = lane == 0 ? zp[64 * zc] : -3.0e38f;       // lane 0: channels 0 and 64
+        const float t0 = yp[lane * yc], t1 = lane == 0 ? yp[64 * yc] : 0.f;
+        const float mx = wave_max(fmaxf(z0, z1));
+        const float e0 = expf(z0 - mx), e1 = lane == 0 ? expf(z1 - mx) : 0.f;
+        const float inv = 1.0f / wave_sum(e0 + e1);
+        const float p0 = e0 * inv, p1 = e1 * inv;
+        auto bce = [](float p, float t, float& g) {
+            const float l = -(t * fmaxf(logf(p), -100.0f) + (1.0f - t) * fmaxf(logf(1.0f - p), -100.0f));
+            g = (p - t) / fmaxf((1.0f - p) * p, 1e-12f);
+            return l;
+        };
+        float g0, g1 = 0.f;
+        float l = bce(p0, t0, g0);
+        if (lane == 0) l += bce(p1, t1, g1);
+        lsum = wave_sum(l) * m;
+        g0 *= m; g1 *= m;
+        const float dot = wave_sum(p0 * g0 + (lane == 0 ? p1 * g1 : 0.f));
+        float* dp = dz + b * zb + cy * zy + cx * zx;
+        dp[lane * zc] = p0 * (g0 - dot);
+        if (lane == 0) dp[64 * zc] = p1 * (g1 - dot);
+    }
+    if (lane == 0) { sh[wave][0] = lsum; sh[wave][1] = cell < ncell ? m : 0.f; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = sh[0][0] + sh[1][0] + sh[2][0] + sh[3][0];
+        partial[2 * blockIdx.x + 1] = sh[0][1] + sh[1][1] + sh[2][1] + sh[3][1];
+    }
+}
+
+__global__ __launch_bounds__(256) void detloss_fold_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ sums) {
+    __shared__ double sh[4][2];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) { a += partial[2 * i]; b += partial[2 * i + 1]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __longlong_as_double(((long long)__shfl_xor((int)(__double_as_longlong(a) >> 32), o, 64) << 32) | (unsigned)__shfl_xor((int)(__double_as_longlong(a) & 0xffffffffll), o, 64));
+        b += __longlong_as_double(((long long)__shfl_xor((int)(__double_as_longlong(b) >> 32), o, 64) << 32) | (unsigned)__shfl_xor((int)(__double_as_longlong(b) & 0xffffffffll), o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6][0] = a; sh[threadIdx.x >> 6][1] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        sums[0] = (float)(sh[0][0] + sh[1][0] + sh[2][0] + sh[3][0]);
+        sums[1] = (float)(sh[0][1] + sh[1][1] + sh[2][1] + sh[3][1]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // YOLOv5 object loss of one Detect level (reference utils/loss_functions.py:90-176, `ComputeObjectLoss.__call__`; CIoU:
 // utils/metrics_yolo.py:202-240), value AND gradient in three launches instead of ~330 tiny PyTorch kernels per level:
 //   objloss_init    dp = 0, owner = -1
@@ -423,6 +487,21 @@ extern "C" int yp_points_sample_bwd(const float* g, int B, int H, int W, int D, 
     YP_REQUIRE(g && uv && gmap_nhwc && B > 0 && H > 0 && W > 0 && P > 0 && D > 0 && D % 64 == 0, "yp_points_sample_bwd: bad arguments (D %% 64 == 0)");
     const int n = B * P, grid = (n + 3) / 4;
     YP_VPL_SWITCH(D, (points_sample_bwd_kernel<VPL><<<grid, 256, 0, (hipStream_t)stream>>>(g, H, W, D, uv, P, n, gmap_nhwc)));
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
+extern "C" size_t yp_detloss_workspace_bytes(int B, int Hc, int Wc) { return ((size_t)B * Hc * Wc + 3) / 4 * 2 * sizeof(float); }
+
+extern "C" int yp_detloss(const float* semi, const int64_t* semi_strides, const float* target, const int64_t* target_strides, const float* mask, int B, int Hc,
+                          int Wc, float* dsemi, float* sums, void* workspace, size_t workspace_bytes, void* stream) {
+    YP_REQUIRE(semi && semi_strides && target && target_strides && mask && dsemi && sums && workspace && B > 0 && Hc > 0 && Wc > 0, "yp_detloss: bad arguments");
+    YP_REQUIRE(workspace_bytes >= yp_detloss_workspace_bytes(B, Hc, Wc), "yp_detloss: workspace too small");
+    const int nblk = (int)(((size_t)B * Hc * Wc + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+    detloss_kernel<<<nblk, 256, 0, st>>>(semi, semi_strides[0], semi_strides[1], semi_strides[2], semi_strides[3], target, target_strides[0], target_strides[1],
+                                         target_strides[2], target_strides[3], mask, B, Hc, Wc, dsemi, (float*)workspace);
+    detloss_fold_kernel<<<1, 256, 0, st>>>((const float*)workspace, nblk, sums);
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
 }
