@@ -151,13 +151,32 @@ __device__ __forceinline__ void fold_partials(const float* __restrict__ part, in
     s = fold_sh[0] + fold_sh[2] + fold_sh[4] + fold_sh[6];
     ss = fold_sh[1] + fold_sh[3] + fold_sh[5] + fold_sh[7];
 }
+// WAVE variants (few partial rows, <= 256): one wavefront per channel, four channels per workgroup, no LDS / barrier -- these kernels
+// are pure launch latency (237 of them per training step), so the lighter they are the better.
+template <bool WAVE>
+__device__ __forceinline__ bool fold_dispatch(const float* __restrict__ part, int nblk, int C, int& c, double& s, double& ss) {
+    if constexpr (WAVE) {
+        c = blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (c >= C) return false;
+        const int lane = threadIdx.x & 63;
+        double a = 0.0, b = 0.0;
+        for (int q = lane; q < nblk; q += 64) { a += part[((size_t)q * 2) * C + c]; b += part[((size_t)q * 2 + 1) * C + c]; }
+        s = wave_sum_d(a);
+        ss = wave_sum_d(b);
+        return lane == 0;
+    } else {
+        c = blockIdx.x;
+        fold_partials(part, nblk, C, c, s, ss);
+        return threadIdx.x == 0;
+    }
+}
+template <bool WAVE>
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ part, int nblk, int C, double M, float eps, float momentum,
                                                                float* __restrict__ mean, float* __restrict__ invstd, float* running_mean,
                                                                float* running_var) {
-    const int c = blockIdx.x;
+    int c;
     double s, ss;
-    fold_partials(part, nblk, C, c, s, ss);
-    if (threadIdx.x != 0) return;
+    if (!fold_dispatch<WAVE>(part, nblk, C, c, s, ss)) return;
     const double mu = s / M;
     double var = ss / M - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -170,12 +189,12 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
     }
 }
 // o0 / o1 get the two column sums; when p0 / p1 are given they receive (or accumulate) them as well
+template <bool WAVE>
 __global__ __launch_bounds__(256) void pair_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ o0, float* __restrict__ o1,
                                                            float* p0, float* p1, int accumulate) {
-    const int c = blockIdx.x;
+    int c;
     double s, ss;
-    fold_partials(part, nblk, C, c, s, ss);
-    if (threadIdx.x != 0) return;
+    if (!fold_dispatch<WAVE>(part, nblk, C, c, s, ss)) return;
     if (o0) o0[c] = (float)s;
     if (o1) o1[c] = (float)ss;
     if (p0) p0[c] = (accumulate ? p0[c] : 0.f) + (float)s;
@@ -630,8 +649,8 @@ extern "C" int yp_bn_stats(YpView raw, int dtype, int B, float eps, float moment
         YP_DT_SWITCH(dtype, (col_reduce_kernel<DT, 0><<<nblk, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, nullptr, 0, 0, M, raw.C,
                                                                             nullptr, nullptr, nullptr, nullptr, 0, (float*)ws)));
     }
-    bn_stats_finalize_kernel<<<raw.C, 256, 0, st>>>((const float*)ws, nblk, raw.C, (double)M, eps, momentum, mean, invstd,
-                                                               running_mean, running_var);
+    if (nblk <= 256) bn_stats_finalize_kernel<true><<<(raw.C + 3) / 4, 256, 0, st>>>((const float*)ws, nblk, raw.C, (double)M, eps, momentum, mean, invstd, running_mean, running_var);
+    else bn_stats_finalize_kernel<false><<<raw.C, 256, 0, st>>>((const float*)ws, nblk, raw.C, (double)M, eps, momentum, mean, invstd, running_mean, running_var);
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
 }
@@ -639,7 +658,8 @@ extern "C" int yp_bn_stats(YpView raw, int dtype, int B, float eps, float moment
 extern "C" int yp_bn_finalize(const float* partial, int rows, int C, double M, float eps, float momentum, float* mean, float* invstd, float* running_mean,
                               float* running_var, void* stream) {
     YP_REQUIRE(partial && mean && invstd && rows > 0 && C > 0 && M > 0, "yp_bn_finalize: bad arguments");
-    bn_stats_finalize_kernel<<<C, 256, 0, (hipStream_t)stream>>>(partial, rows, C, M, eps, momentum, mean, invstd, running_mean, running_var);
+    if (rows <= 256) bn_stats_finalize_kernel<true><<<(C + 3) / 4, 256, 0, (hipStream_t)stream>>>(partial, rows, C, M, eps, momentum, mean, invstd, running_mean, running_var);
+    else bn_stats_finalize_kernel<false><<<C, 256, 0, (hipStream_t)stream>>>(partial, rows, C, M, eps, momentum, mean, invstd, running_mean, running_var);
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
 }
@@ -693,7 +713,8 @@ extern "C" int yp_bn_act_bwd(YpView raw, YpView dy, YpView dx, int dtype, int B,
                                                                             dy.coff, M, raw.C, mean, invstd, gamma, beta, act, (float*)ws)));
     }
     // (sum dz, sum dz*xhat) -> this call's dbeta / dgamma, and (accumulated) into the parameter gradients
-    pair_finalize_kernel<<<raw.C, 256, 0, st>>>((const float*)ws, nblk, raw.C, db, dg, dbeta, dgamma, accumulate_param_grads);
+    if (nblk <= 256) pair_finalize_kernel<true><<<(raw.C + 3) / 4, 256, 0, st>>>((const float*)ws, nblk, raw.C, db, dg, dbeta, dgamma, accumulate_param_grads);
+    else pair_finalize_kernel<false><<<raw.C, 256, 0, st>>>((const float*)ws, nblk, raw.C, db, dg, dbeta, dgamma, accumulate_param_grads);
     const int g = grid_for(M * (raw.C / 8), 256);
     if (fastp) {
         const int gf = grid_for((M * (raw.C / 8) + 1) / 2, 256);
@@ -782,7 +803,8 @@ extern "C" int yp_col_sum(YpView v, int dtype, int B, float* out, int accumulate
     YP_DT_SWITCH(dtype, (col_reduce_kernel<DT, 0><<<nblk, 256, 0, st>>>((const char*)v.ptr, v.cstride, v.coff, nullptr, 0, 0, M, v.C, nullptr, nullptr,
                                                                         nullptr, nullptr, 0, (float*)ws)));
     (void)scratch;
-    pair_finalize_kernel<<<v.C, 256, 0, st>>>((const float*)ws, nblk, v.C, nullptr, nullptr, out, nullptr, accumulate);
+    if (nblk <= 256) pair_finalize_kernel<true><<<(v.C + 3) / 4, 256, 0, st>>>((const float*)ws, nblk, v.C, nullptr, nullptr, out, nullptr, accumulate);
+    else pair_finalize_kernel<false><<<v.C, 256, 0, st>>>((const float*)ws, nblk, v.C, nullptr, nullptr, out, nullptr, accumulate);
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
 }
