@@ -2,7 +2,7 @@
 each phase), then the final wait for the device."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
 import torch
 from yolopoint_amd.utils.synthetic import make_model
 from yolopoint_amd.engine import TrainStep, synthetic_batch, LAMBDA_DESC, LAMBDA_OBJ
