@@ -297,6 +297,19 @@ int yp_points_sample_bwd(const float* g, int B, int H, int W, int D, const float
 int yp_objloss_level(const float* p, int cells, int no, int nc, const int* cell, const float* tbox, const float* anch, const int* tcls, int n, float cp,
                      float cn, float cls_pw, float obj_pw, float w_box, float w_obj, float w_cls, float* iou_scratch, int* owner_scratch, float* dp,
                      float* sums, void* stream);
+/* The same with the entry count read on the device (n_dev != NULL: `n` is then the capacity of the entry arrays): what follows
+ * yp_build_targets without a host synchronisation. */
+int yp_objloss_level_dev(const float* p, int cells, int no, int nc, const int* cell, const float* tbox, const float* anch, const int* tcls, int n,
+                         const int* n_dev, float cp, float cn, float cls_pw, float obj_pw, float w_box, float w_obj, float w_cls, float* iou_scratch,
+                         int* owner_scratch, float* dp, float* sums, void* stream);
+
+/* YOLOv5 target assignment on the device (reference utils/loss_functions.py:177-234 ComputeLoss.build_targets): labels [nt,6]
+ * (image, class, xc, yc, w, h normalised) x anchors [nl][na][2] (grid units) x shapes_dev [nl][2] (ny, nx; device ints) -> per level
+ * the entry list in the reference's order (offset-major, anchor, label): cell [nl][cap], tcls [nl][cap], tbox [nl][cap][4],
+ * anch [nl][cap][2], count [nl]; cap >= 5 * na * nt.  No host synchronisation (the reference's boolean-mask indexing has one per level). */
+int yp_build_targets(const float* targets, int nt, const float* anchors, int nl, int na, const int* shapes_dev, float anchor_t, int cap, int* cell,
+                     int* tcls, float* tbox, float* anch, int* count, void* stream);
+
 
 /* Keypoint-detector loss (reference utils/loss_functions.py:600-619 ComputeDetectorLoss): sums[0] = sum over cells of
  * mask * sum_c BCE(softmax(semi)_c, target_c) (PyTorch's BCE: logs clamped at -100), sums[1] = sum of mask; dsemi (same strides as
@@ -381,6 +394,12 @@ size_t yp_box_nms_workspace_bytes(int B, int N, int nc, int multi_label, int max
 int yp_box_nms(const float* pred, int B, int N, int nc, float conf_thres, float iou_thres,
                int multi_label, int agnostic, int max_det, int max_nms, float max_wh,
                float* out_det, int32_t* out_count, void* workspace, size_t workspace_bytes, void* stream);
+/* The same with the reference's `classes` argument (utils/general_yolo.py:128,199-200): class_mask = device bit mask, bit j of word
+ * j/32 set when class j is kept (NULL: every class). */
+int yp_box_nms_classes(const float* pred, int B, int N, int nc, float conf_thres, float iou_thres,
+                       int multi_label, int agnostic, int max_det, int max_nms, float max_wh, const uint32_t* class_mask,
+                       float* out_det, int32_t* out_count, void* workspace, size_t workspace_bytes, void* stream);
+
 
 /* Homography adaptation aggregate (reference export_homography.py:94-96,143-145 with warp_image_batch utils/utils.py:333-376):
  * heat / mask: [N,H,W] fp32 per-view heat maps (flattenDetection output) and valid masks; inv_homographies [N,9] row-major in

@@ -172,3 +172,30 @@ def fuse_conv_bn(w, gamma, beta, mean, var, eps=BN_EPS):
 # deterministic synthetic weights / images: data generators shared with the benchmarks (yolopoint_amd/utils/synthetic.py)
 # ---------------------------------------------------------------------------------------------
 from yolopoint_amd.utils.synthetic import synth_state_dict, synth_image  # noqa: E402,F401
+
+
+# ---------------------------------------------------------------------------------------------
+# backward golden vectors: seeded output projections as the loss, gradient sketches
+# ---------------------------------------------------------------------------------------------
+def output_projections(o, seed):
+    """Seeded N(0,1) projections with the shapes of the three train-mode outputs ({'semi','desc','objects': list[3]})."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    return {"semi": torch.randn(o["semi"].shape, generator=g), "desc": torch.randn(o["desc"].shape, generator=g),
+            "objects": [torch.randn(t.shape, generator=g) for t in o["objects"]]}
+
+
+def projected_loss(o, proj, device="cpu"):
+    """loss = 0.01 <semi, P_semi> + <desc, P_desc> + 0.01 sum_i <objects_i, P_i>  (the scalar whose backward is the golden vector)."""
+    l = (o["semi"] * proj["semi"].to(device)).sum() * 0.01 + (o["desc"] * proj["desc"].to(device)).sum()
+    for t, p in zip(o["objects"], proj["objects"]):
+        l = l + (t * p.to(device)).sum() * 0.01
+    return l
+
+
+def sign_projections(name, size, n):
+    """n seeded +-1 vectors of length `size` (float64 [n, size]); the stream is keyed on the tensor's name so that the generator of
+    the golden file and the tests agree without storing the vectors."""
+    import zlib
+    import numpy as np
+    rng = np.random.Generator(np.random.PCG64(zlib.crc32(name.encode()) + 77))
+    return rng.integers(0, 2, (n, size), dtype=np.int8).astype(np.float64) * 2.0 - 1.0

@@ -150,8 +150,8 @@ def nms_greedy(boxes, scores, iou_thres):
     return np.asarray(keep, dtype=np.int64)
 
 
-def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, agnostic=False, multi_label=False, max_det=300):
-    """utils/general_yolo.py:124-235 for classes=None, labels=(), nm=0.
+def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, agnostic=False, multi_label=False, max_det=300, classes=None, labels=()):
+    """utils/general_yolo.py:124-235 for nm=0 (`classes`: :199-200; a-priori `labels`: :171-178).
     prediction [B,N,5+nc] fp32 -> list of B arrays [n,6] (x1,y1,x2,y2,conf,cls)."""
     prediction = np.asarray(prediction, dtype=np.float32)
     nc = prediction.shape[2] - 5
@@ -159,8 +159,14 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, agnostic=Fa
     multi_label = multi_label and nc > 1
     ct = np.float32(conf_thres)
     out = []
-    for x in prediction:
+    for xi, x in enumerate(prediction):
         x = x[x[:, 4] > ct].copy()
+        if labels and len(labels[xi]):
+            lb = np.asarray(labels[xi], dtype=np.float32)
+            v = np.zeros((len(lb), nc + 5), dtype=np.float32)
+            v[:, :4], v[:, 4] = lb[:, 1:5], 1.0
+            v[np.arange(len(lb)), lb[:, 0].astype(np.int64) + 5] = 1.0
+            x = np.concatenate((x, v), 0)
         if not x.shape[0]:
             out.append(np.zeros((0, 6), dtype=np.float32))
             continue
@@ -173,6 +179,8 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, agnostic=Fa
             j = x[:, 5:].argmax(1)
             conf = x[np.arange(len(x)), 5 + j]
             x = np.concatenate((box, conf[:, None], j[:, None].astype(np.float32)), 1)[conf > ct]
+        if classes is not None:
+            x = x[np.isin(x[:, 5], np.asarray(classes, dtype=np.float32))]
         if not x.shape[0]:
             out.append(np.zeros((0, 6), dtype=np.float32))
             continue

@@ -33,3 +33,24 @@ TOL = {"f32": 1e-4, "f16": 4e-3, "bf16": 3e-2}
 # ---------------------------------------------------------------------------------------------
 # planted post-processing inputs (random-init heads give degenerate workloads)
 # ---------------------------------------------------------------------------------------------
+
+
+def check_grad_sketch(G, tag, name, grad, rel):
+    """Compare a gradient tensor with its committed sketch (tests/golden/backward.npz, make_golden.grad_sketch): L2 norm and 8 seeded
+    +-1 projections (a projection of an error vector e is ~|e|_2, so the bar on each is 4 * rel * |g_ref|_2), plus the whole tensor
+    where the file holds it.  Returns the worst normalised deviation."""
+    g = np.asarray(grad.detach().double().cpu()).ravel()
+    nref = float(G[f"{tag}.norm.{name}"])
+    den = max(nref, 1e-30)
+    worst = abs(np.sqrt((g * g).sum()) - nref) / den
+    assert worst < rel, (tag, name, "norm", worst)
+    proj = net_oracle.sign_projections(name, g.size, 8) @ g
+    dev = np.abs(proj - G[f"{tag}.proj.{name}"]).max() / den
+    assert dev < 4 * rel, (tag, name, "projection", dev)
+    worst = max(worst, dev / 4)
+    key = f"{tag}.full.{name}"
+    if key in G:
+        e = np.sqrt(((g - G[key].astype(np.float64).ravel()) ** 2).sum()) / den
+        assert e < rel, (tag, name, "full", e)
+        worst = max(worst, e)
+    return worst

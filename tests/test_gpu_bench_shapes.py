@@ -1,0 +1,154 @@
+"""Parity at the shapes that are benchmarked (BASELINE.json configs[1..3]), not only at small ones: the plan-time autotuner
+picks other kernel variants / tiles at these sizes, so they are checked against the oracle here.
+
+  configs[1]  YOLOPoint-s, batch 8, 640x640: f32 compute path (north_star bar: 1e-3 of max|ref|, keypoint-cell argmax exact) and the
+              f16 path that `python bench.py` times, replayed through the hipGraph as the benchmark does (bars below)
+  configs[3]  YOLOPoint-l, batch 1, 1280x1280 f16; keypoint NMS of a 1280x1280 heat map with 4000 planted peaks; box NMS of
+              [1, 100800, 85] with 30 000 multi-label candidates; both index selections exact
+  configs[2]  all-parameter gradients in bf16 (the dtype of the training configs) against fp32 CPU autograd, with an explicit bar
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_model, rel_err, planted_heatmap, planted_predictions
+from oracle import net_oracle, postproc_oracle as po
+from yolopoint_amd.utils import utils as U
+from yolopoint_amd.utils.general_yolo import non_max_suppression
+
+pytestmark = pytest.mark.gpu
+
+# bars of the 16-bit inference path at the benchmarked shapes: relative L2 of the head outputs / max-abs relative to max|ref| /
+# fraction of keypoint cells whose argmax agrees (ties within the 16-bit error may flip)
+F16_BARS = dict(head_l2=3e-3, head_max=1.5e-2, raw_l2=1e-2, pred_l2=2e-2, argmax=0.97)
+
+
+def _oracle(version, sd, x):
+    torch.set_num_threads(min(32, torch.get_num_threads() or 8))
+    with torch.no_grad():
+        return net_oracle.yolopoint_forward(sd, x, version)
+
+
+def test_config1_s_bs8_640_f32(cuda):
+    m, sd = make_model("s", 1234, dtype="f32")
+    x = net_oracle.synth_image(8, 3, 640, 640, 1234)
+    ref = _oracle("s", sd, x)
+    with torch.no_grad():
+        got = m.to(cuda)(x.to(cuda))
+    for name in ("semi", "desc"):
+        e_max, e_l2 = rel_err(got[name], ref[name])
+        assert e_max < 1e-3, (name, e_max, e_l2)
+    assert torch.equal(got["semi"].argmax(1).cpu(), ref["semi"].argmax(1))          # keypoint cell argmax: bit-exact
+    assert rel_err(got["objects"][0], ref["objects"][0])[0] < 1e-3
+    for a, b in zip(got["objects"][1], ref["objects"][1]):
+        assert rel_err(a, b)[0] < 1e-3
+
+
+def test_config1_s_bs8_640_f16_graph_as_benchmarked(cuda):
+    """The exact configuration `python bench.py` times: fused BN, f16, static outputs, hipGraph replay."""
+    m, sd = make_model("s", 1234, dtype="f16")
+    x = net_oracle.synth_image(8, 3, 640, 640, 1234)
+    ref = _oracle("s", sd, x)
+    m = m.to(cuda)
+    m.fuse()
+    m.model.use_graph = True
+    with torch.no_grad():
+        m(x.to(cuda))
+        got = m(x.to(cuda))                        # second call = graph replay
+    t = F16_BARS
+    for name in ("semi", "desc"):
+        e_max, e_l2 = rel_err(got[name], ref[name])
+        print(name, f"max {e_max:.2e} l2 {e_l2:.2e}")
+        assert e_l2 < t["head_l2"] and e_max < t["head_max"], (name, e_max, e_l2)
+    for a, b in zip(got["objects"][1], ref["objects"][1]):
+        assert rel_err(a, b)[1] < t["raw_l2"]
+    assert rel_err(got["objects"][0], ref["objects"][0])[1] < t["pred_l2"]
+    same = (got["semi"].argmax(1).cpu() == ref["semi"].argmax(1)).float().mean()
+    assert same > t["argmax"], float(same)
+
+
+def test_config3_l_bs1_1280_f16(cuda):
+    m, sd = make_model("l", 77, dtype="f16")
+    x = net_oracle.synth_image(1, 3, 1280, 1280, 77)
+    ref = _oracle("l", sd, x)
+    m = m.to(cuda)
+    m.fuse()
+    with torch.no_grad():
+        got = m(x.to(cuda))
+    assert got["objects"][0].shape == (1, 100800, 85) and got["desc"].shape == (1, 256, 160, 160)
+    t = F16_BARS
+    for name in ("semi", "desc"):
+        e_max, e_l2 = rel_err(got[name], ref[name])
+        print(name, f"max {e_max:.2e} l2 {e_l2:.2e}")
+        assert e_l2 < 2 * t["head_l2"] and e_max < 2 * t["head_max"], (name, e_max, e_l2)      # -l is three times as deep as -s
+    assert rel_err(got["objects"][0], ref["objects"][0])[1] < 2 * t["pred_l2"]
+    same = (got["semi"].argmax(1).cpu() == ref["semi"].argmax(1)).float().mean()
+    assert same > 0.95, float(same)
+
+
+def test_config3_keypoint_nms_1280_4000_peaks(cuda):
+    heat = planted_heatmap(1280, 1280, 4000, seed=4000)
+    ref = po.get_pts_from_heatmap(heat, 0.015, 4)
+    got = U.getPtsFromHeatmap(heat, 0.015, 4)
+    assert got.shape == ref.shape and ref.shape[1] > 2000
+    assert np.array_equal(got[:2], ref[:2])
+    assert np.array_equal(got[2].astype(np.float32), ref[2].astype(np.float32))
+
+
+def test_config3_box_nms_100800_rows_30000_candidates(cuda):
+    """[1, 100800, 85] (the 1280x1280 prediction tensor): 12 000 planted rows above the confidence threshold expand to > 30 000
+    multi-label candidates (max_nms = 30000 truncation of general_yolo.py:154-155,207 is exercised)."""
+    pred = planted_predictions(1, 100800, 80, 12000, seed=5, img=1280)
+    pred[0, :, 5:] = np.where(pred[0, :, 4:5] > 0.25, np.maximum(pred[0, :, 5:], np.random.default_rng(6).uniform(0.0, 1.0, (100800, 80)) ** 0.5), pred[0, :, 5:])
+    ncand = int(((pred[0, :, 5:] * pred[0, :, 4:5] > 0.25) & (pred[0, :, 4:5] > 0.25)).sum())
+    assert ncand > 30000, ncand
+    for ag in (True, False):
+        ref = po.non_max_suppression(pred, 0.25, 0.45, agnostic=ag, multi_label=True, max_det=300)
+        got = non_max_suppression(torch.from_numpy(pred).to(cuda), 0.25, 0.45, agnostic=ag, multi_label=True, labels=[], max_det=300)
+        assert got[0].shape == ref[0].shape and ref[0].shape[0] > 50
+        np.testing.assert_array_equal(got[0].cpu().numpy(), ref[0])
+
+
+# bf16 operands (8 mantissa bits) through ~70 layers forward and backward against fp32 autograd: measured 1e-2 .. 4e-2 relative L2
+# per parameter tensor on YOLOPoint-s; the bar is per tensor, the median is asserted tighter
+BF16_GRAD_BAR, BF16_GRAD_MEDIAN_BAR = 1e-1, 4e-2
+
+
+@pytest.mark.parametrize("version,B,S", [("s", 4, 128), ("n", 2, 256)])
+def test_all_parameter_gradients_bf16(cuda, version, B, S):
+    m, sd = make_model(version, 35, dtype="bf16")
+    m = m.to(cuda).train()
+    x = net_oracle.synth_image(B, 3, S, S, 35)
+    leaf = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in sd.items()}
+    ref = net_oracle.yolopoint_forward(leaf, x, version, training=True, stats={})
+    proj = net_oracle.output_projections(ref, 35)
+    net_oracle.projected_loss(ref, proj).backward()
+    out = m(x.to(cuda))
+    for k in ("semi", "desc"):
+        assert rel_err(out[k], ref[k])[1] < 2.5e-2, k
+    net_oracle.projected_loss(out, proj, cuda).backward()
+    errs = []
+    for name, p in m.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        e = rel_err(p.grad, leaf[name].grad)[1]
+        errs.append((e, name))
+        assert e < BF16_GRAD_BAR, (name, e)
+    errs.sort()
+    print(f"bf16 gradient rel-L2: median {errs[len(errs) // 2][0]:.2e}, worst {errs[-3:]}")
+    assert errs[len(errs) // 2][0] < BF16_GRAD_MEDIAN_BAR
+
+
+def test_bf16_gradients_are_deterministic(cuda):
+    """Two identical bf16 forward/backward passes give bit-identical parameter gradients (the weight-gradient reduction has a fixed
+    order: per-workgroup partials folded by a second pass, no floating-point atomics)."""
+    m, _ = make_model("n", 36, dtype="bf16")
+    m = m.to(cuda).train()
+    x = net_oracle.synth_image(2, 3, 128, 128, 36).to(cuda)
+    grads = []
+    for _ in range(3):
+        m.zero_grad(set_to_none=True)
+        o = m(x)
+        (o["semi"].square().mean() + o["desc"][:, :8].mean() + sum(t.tanh().mean() for t in o["objects"])).backward()
+        grads.append([p.grad.clone() for p in m.parameters()])
+    for a, b in zip(grads[1], grads[2]):
+        assert torch.equal(a, b)

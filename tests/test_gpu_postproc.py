@@ -119,6 +119,30 @@ def test_non_max_suppression(cuda, B, N, nc, ncand, ml, ag, max_det):
         assert sum(len(r) for r in ref) > 0
 
 
+@pytest.mark.parametrize("ml", [False, True])
+def test_non_max_suppression_classes_and_labels(cuda, ml):
+    """The `classes` filter and a-priori `labels` rows of the reference signature (general_yolo.py:124-135,171-178,199-200): exact rows
+    against the oracle AND the reference's golden output."""
+    import os
+    P = np.load(os.path.join(os.path.dirname(__file__), "golden", "postproc.npz"))
+    pred = planted_predictions(2, 1000, 80, 120, seed=77)
+    classes = [int(c) for c in P["boxc.classes"]]
+    labels = [torch.from_numpy(P["boxc.labels0"]).to(cuda), torch.zeros((0, 5), device=cuda)]
+    got = non_max_suppression(torch.from_numpy(pred).to(cuda), 0.25, 0.45, classes=classes, labels=labels, multi_label=ml, agnostic=False, max_det=300)
+    ref = po.non_max_suppression(pred, 0.25, 0.45, agnostic=False, multi_label=ml, max_det=300, classes=classes, labels=[P["boxc.labels0"], np.zeros((0, 5), np.float32)])
+    for b in range(2):
+        np.testing.assert_array_equal(got[b].cpu().numpy(), ref[b])
+        np.testing.assert_array_equal(got[b].cpu().numpy(), P[f"boxc.ml{int(ml)}.det{b}"])
+    # classes only, on another planted set; class ids >= 32 exercise the second mask word
+    pred2 = planted_predictions(1, 2520, 80, 300, seed=9)
+    for cl in ([0], [33, 64, 79], list(range(80))):
+        g2 = non_max_suppression(torch.from_numpy(pred2).to(cuda), 0.25, 0.45, classes=cl, labels=[], multi_label=ml, agnostic=True)
+        r2 = po.non_max_suppression(pred2, 0.25, 0.45, agnostic=True, multi_label=ml, classes=cl)
+        np.testing.assert_array_equal(g2[0].cpu().numpy(), r2[0])
+    with pytest.raises(Exception):
+        non_max_suppression(torch.from_numpy(pred2).to(cuda), 0.25, 0.45, nm=32)
+
+
 def test_nms_all_suppressed_and_truncation(cuda):
     nc = 4
     pred = np.zeros((1, 64, 5 + nc), np.float32)

@@ -277,10 +277,11 @@ class _NetStub(torch.nn.Module):
 
 
 @pytest.mark.parametrize("nc,B,S,nt", [(1, 4, 256, 40), (3, 2, 128, 25), (80, 2, 64, 9), (1, 2, 96, 0)])
-def test_native_object_loss_matches_torch_formulation(cuda, nc, B, S, nt):
-    """csrc/losses.hip (yp_objloss_level: CIoU + objectness + class BCE, value and gradient) against the PyTorch formulation
-    of ComputeObjectLoss (reference utils/loss_functions.py:90-234) evaluated on the CPU on the same logits and targets --
-    duplicated cell claims included (the CPU index_put is sequential: last entry wins, which the kernel reproduces)."""
+def test_native_object_loss_matches_cpu_statement(cuda, nc, B, S, nt):
+    """csrc/losses.hip (yp_build_targets + yp_objloss_level_dev: target assignment, CIoU + objectness + class BCE, value and gradient)
+    against the CPU statement of the same loss (oracle/loss_oracle.py, itself pinned to the reference by tests/test_losses_golden.py) on
+    the same logits and labels -- duplicated cell claims included (the sequential index_put lets the last entry win, as the kernel does)."""
+    from oracle import loss_oracle
     from yolopoint_amd.utils.loss_functions import ComputeObjectLoss
     hyp = dict(cls_pw=0.7, obj_pw=1.3, fl_gamma=0.0, label_smoothing=0.1, anchor_t=4.0, box=0.05, obj=1.0, cls=0.5)
     g = torch.Generator().manual_seed(nc * 100 + nt)
@@ -293,18 +294,26 @@ def test_native_object_loss_matches_torch_formulation(cuda, nc, B, S, nt):
         tg[nt // 2:nt // 2 + 3] = tg[0]                      # exact duplicates: the same cells are claimed several times
         tg[nt // 2, 4:6] *= 1.1
     ps = [(torch.randn(B, 3, S // s, S // s, nc + 5, generator=g) * 1.5) for s in (8, 16, 32)]
-    res = {}
-    for dev in ("cpu", cuda):
-        crit = ComputeObjectLoss(_NetStub(nc, dev), hyp, dev)
-        p = [t.clone().to(dev).requires_grad_() for t in ps]
-        loss, items = crit(p, tg.to(dev))
-        (loss * 2.5).backward()
-        res[str(dev)] = (loss.detach().cpu(), items.cpu(), [t.grad.cpu() for t in p])
-    (l0, i0, g0), (l1, i1, g1) = res["cpu"], res[str(cuda)]
+    stub = _NetStub(nc, "cpu")
+    p0 = [t.clone().requires_grad_() for t in ps]
+    l0, i0 = loss_oracle.object_loss(p0, tg, stub.model.Detect.anchors, nc, hyp)
+    (l0 * 2.5).backward()
+    crit = ComputeObjectLoss(_NetStub(nc, cuda), hyp, cuda)
+    p1 = [t.clone().to(cuda).requires_grad_() for t in ps]
+    l1, i1 = crit(p1, tg.to(cuda))
+    (l1 * 2.5).backward()
     assert l1.shape == l0.shape and i1.shape == i0.shape
-    assert torch.allclose(l1, l0, rtol=2e-5, atol=1e-6) and torch.allclose(i1, i0, rtol=2e-5, atol=1e-6)
-    for a, b in zip(g1, g0):
-        assert rel_err(a, b)[1] < 2e-5
+    assert torch.allclose(l1.detach().cpu(), l0.detach(), rtol=2e-5, atol=1e-6) and torch.allclose(i1.cpu(), i0, rtol=2e-5, atol=1e-6)
+    for a, b in zip(p1, p0):
+        assert rel_err(a.grad, b.grad)[1] < 2e-5
+    # the entry lists themselves, in the reference's return format and order
+    tcls, tbox, indices, anch = crit.build_targets(p1, tg.to(cuda))
+    ref = loss_oracle.assign_targets(tg, stub.model.Detect.anchors, [(t.shape[2], t.shape[3]) for t in ps], hyp["anchor_t"])
+    for l, e in enumerate(ref):
+        b_, a_, gj_, gi_ = (t.cpu() for t in indices[l])
+        assert torch.equal(b_, e["b"]) and torch.equal(a_, e["a"]) and torch.equal(gj_, e["gj"]) and torch.equal(gi_, e["gi"]), l
+        assert torch.equal(tcls[l].cpu(), e["cls"])
+        assert torch.allclose(tbox[l].cpu(), e["box"], rtol=1e-6, atol=1e-6) and torch.allclose(anch[l].cpu(), e["anchor"])
 
 
 def test_two_lane_backward_matches_single_lane(cuda, monkeypatch):
@@ -358,3 +367,20 @@ def test_train_forward_without_backward_releases_its_plans(cuda):
     for _ in range(12):
         o = m(x)
         del o
+
+
+@pytest.mark.parametrize("tag,version,B,S,seed", [("s64", "s", 2, 64, 31), ("n96", "n", 3, 96, 32)])
+def test_backward_matches_reference_golden(cuda, tag, version, B, S, seed):
+    """The f32 HIP path against the REFERENCE's loss.backward() (train.py:245): all 215 parameter gradients and the train-mode loss
+    of seeded output projections, tests/golden/backward.npz (sketches: norm + 8 projections + small tensors whole)."""
+    from helpers import check_grad_sketch
+    Gb = np.load(os.path.join(G, "backward.npz"))
+    m, sd = make_model(version, seed, dtype="f32")
+    m = m.to(cuda).train()
+    x = net_oracle.synth_image(B, 3, S, S, seed).to(cuda)
+    o = m(x)
+    loss = net_oracle.projected_loss(o, net_oracle.output_projections(o, seed), cuda)
+    assert abs(float(loss) - float(Gb[f"{tag}.loss"])) <= 1e-3 * abs(float(Gb[f"{tag}.loss"])) + 1e-2
+    loss.backward()
+    worst = max(check_grad_sketch(Gb, tag, n, p.grad, 2e-3) for n, p in m.named_parameters())
+    print(tag, "worst normalised deviation from the reference gradients:", worst)

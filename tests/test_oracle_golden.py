@@ -219,3 +219,15 @@ def test_keypoint_array_wire_format():
     assert m["desc_len"] == 128 and m["desc_len"].dtype == np.uint8
     assert np.array_equal(m["desc_flat"], desc.flatten())
     assert to_keypoint_array(pts, np.zeros((256, 17), np.float32))["desc_len"] == 0
+
+
+def test_box_nms_classes_and_labels():
+    """non_max_suppression(classes=..., labels=...) (general_yolo.py:171-178,199-200): oracle vs the imported reference's kept rows."""
+    P = np.load(os.path.join(os.path.dirname(__file__), "golden", "postproc.npz"))
+    from helpers import planted_predictions
+    pred = planted_predictions(2, 1000, 80, 120, seed=77)
+    labels = [P["boxc.labels0"], np.zeros((0, 5), np.float32)]
+    for ml in (0, 1):
+        mine = po.non_max_suppression(pred, 0.25, 0.45, agnostic=False, multi_label=bool(ml), max_det=300, classes=list(P["boxc.classes"]), labels=labels)
+        for b, mm in enumerate(mine):
+            assert np.array_equal(mm, P[f"boxc.ml{ml}.det{b}"]), (ml, b)

@@ -97,6 +97,9 @@ SIGNATURES = {
     "yp_detloss_workspace_bytes": (_sz, [_i, _i, _i]),
     "yp_detloss": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _sz, _p]),
     "yp_objloss_level": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _i, _f, _f, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p]),
+    "yp_objloss_level_dev": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _f, _f, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p]),
+    "yp_build_targets": (_i, [_p, _i, _p, _i, _i, _p, _f, _i, _p, _p, _p, _p, _p, _p]),
+    "yp_box_nms_classes": (_i, [_p, _i, _i, _i, _f, _f, _i, _i, _i, _i, _f, _p, _p, _p, _p, _sz, _p]),
     "yp_maxpool2_bwd": (_i, [YpView, YpView, YpView, _i, _i, _i, _p]),
     "yp_wgrad_unpack": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "yp_pack_weight": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _p, _p]),
@@ -162,9 +165,58 @@ def require_gpu():
 
 
 def stream_ptr(stream=None):
+    """The HIP stream a native launch goes to: torch's current stream of the CURRENT device.  Kernels run on the current device,
+    so a launch whose stream belongs to another device is refused (the public entry points are wrapped in `guarded`, which makes the
+    device of their tensors current for the duration of the call)."""
     import torch
     s = stream if stream is not None else torch.cuda.current_stream()
+    if s.device.index != torch.cuda.current_device():
+        raise YpError(f"native launch on stream of cuda:{s.device.index} while cuda:{torch.cuda.current_device()} is current")
     return C.c_void_p(s.cuda_stream)
+
+
+def _cuda_device_of(obj, depth=0):
+    import torch
+    if isinstance(obj, torch.Tensor):
+        return obj.device if obj.is_cuda else None
+    if isinstance(obj, torch.device):
+        return obj if obj.type == "cuda" and obj.index is not None else None
+    if depth < 2 and isinstance(obj, (list, tuple)):
+        for o in obj:
+            d = _cuda_device_of(o, depth + 1)
+            if d is not None:
+                return d
+    if depth < 2 and isinstance(obj, dict):
+        for o in obj.values():
+            d = _cuda_device_of(o, depth + 1)
+            if d is not None:
+                return d
+    if depth == 0 and not isinstance(obj, (str, bytes, int, float)) and hasattr(obj, "device"):
+        try:
+            return _cuda_device_of(torch.device(obj.device) if isinstance(obj.device, str) else obj.device, 2)
+        except Exception:
+            return None
+    return None
+
+
+def guarded(fn):
+    """Decorator of the public entry points: run `fn` with the device of its first cuda tensor (or of `self.device`) current, as
+    PyTorch's own operators do per call -- a model on cuda:1 works while cuda:0 is the current device."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrap(*a, **k):
+        import torch
+        dev = None
+        for o in list(a) + list(k.values()):
+            dev = _cuda_device_of(o)
+            if dev is not None:
+                break
+        if dev is None or not torch.cuda.is_available() or dev.index == torch.cuda.current_device():
+            return fn(*a, **k)
+        with torch.cuda.device(dev):
+            return fn(*a, **k)
+    return wrap
 
 
 def dtype_code(dt):

@@ -58,11 +58,15 @@ template <> struct Elem<YP_F32> {
 // Probe builds (-DYP_TIMELINE, tools/probe/timeline.py): workgroup 0 / lane 0 records the shader clock at phase boundaries.
 #ifdef YP_TIMELINE
 __device__ long long yp_timeline[64];
+__device__ int yp_tl_block = 0;                            // the workgroup whose phase clocks are recorded (yp_debug_timeline_block)
+__device__ unsigned long long yp_wg_times[3 * 16384];      // per workgroup: {entry, epilogue-stores-issued} on the 100 MHz wall clock, HW_ID | XCC_ID << 32
 extern "C" int yp_debug_timeline(long long* out_host) { return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(yp_timeline), sizeof(long long) * 64); }
-#define YP_TL(i) do { if (blockIdx.x == YP_TL_BLOCK && threadIdx.x == 0) yp_timeline[i] = __builtin_readcyclecounter(); } while (0)
-#ifndef YP_TL_BLOCK
-#define YP_TL_BLOCK 0
-#endif
+extern "C" int yp_debug_timeline_block(int b) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(yp_tl_block), &b, sizeof(int)); }
+extern "C" int yp_debug_wg_times(unsigned long long* out_host, int nwg) { return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(yp_wg_times), sizeof(unsigned long long) * 3 * nwg); }
+#define YP_TL(i) do { if (threadIdx.x == 0) { if ((int)blockIdx.x == yp_tl_block) yp_timeline[i] = __builtin_readcyclecounter();                       \
+        if (((i) == 0 || (i) >= 41) && blockIdx.x < 16384) { yp_wg_times[blockIdx.x * 3 + ((i) == 0 ? 0 : 1)] = wall_clock64();                          \
+            if ((i) == 0) yp_wg_times[blockIdx.x * 3 + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |             \
+                                                               ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32); } } } while (0)
 #else
 #define YP_TL(i) do {} while (0)
 #endif
@@ -1324,7 +1328,11 @@ struct TileCfg { int id, bm, bn; };
 // (A 64 x 256 tile for the fused Detect convolution -- every channel of a pixel in one workgroup, so that an anchor's rows form
 // one contiguous 16-byte-aligned run per tile, written with 16-byte stores -- measured 62-87 us vs 43-47 us for the 64 x 32 / 64 x 64
 // tiles on the 80 x 80 level and was dropped.)
-constexpr TileCfg kTiles[] = {{1, 128, 32}, {2, 128, 64}, {3, 128, 128}, {4, 64, 64}, {5, 64, 32}};
+constexpr TileCfg kTiles[] = {{1, 128, 32}, {2, 128, 64}, {3, 128, 128}, {4, 64, 64}, {5, 64, 32}
+#ifdef YP_TIMELINE
+    , {6, 64, 64}, {7, 128, 128}, {8, 128, 64}      // probe build only: the same tiles with 8-stage rings
+#endif
+};
 
 template <int DT, bool OUT_F32, bool FAST, bool DETECT, int BM, int BN, int WAVES_M, int WAVES_N, int NS, bool STATS = false>
 hipError_t launch_tile(const ConvKArgs& a, int nblk, hipStream_t st) {
@@ -1350,6 +1358,11 @@ hipError_t launch_cfg(int tile, const ConvKArgs& a, int nblk, hipStream_t st) {
         case 3: return launch_tile<DT, OUT_F32, FAST, DETECT, 128, 128, 2, 2, 4, STATS>(a, nblk, st);
         case 4: return launch_tile<DT, OUT_F32, FAST, DETECT, 64, 64, 2, 2, 4, STATS>(a, nblk, st);
         case 5: return launch_tile<DT, OUT_F32, FAST, DETECT, 64, 32, 4, 1, 4, STATS>(a, nblk, st);
+#ifdef YP_TIMELINE
+        case 6: if constexpr (!DETECT && !STATS && FAST) return launch_tile<DT, OUT_F32, FAST, DETECT, 64, 64, 2, 2, 8, STATS>(a, nblk, st); else return hipErrorInvalidValue;
+        case 7: if constexpr (!DETECT && !STATS && FAST) return launch_tile<DT, OUT_F32, FAST, DETECT, 128, 128, 2, 2, 8, STATS>(a, nblk, st); else return hipErrorInvalidValue;
+        case 8: if constexpr (!DETECT && !STATS && FAST) return launch_tile<DT, OUT_F32, FAST, DETECT, 128, 64, 4, 1, 8, STATS>(a, nblk, st); else return hipErrorInvalidValue;
+#endif
         default: return hipErrorInvalidValue;
     }
 }
@@ -1483,7 +1496,11 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
     a.act = d->act; a.M = (int)Ml;
     a.dil_h = dil_h; a.dil_w = dil_w; a.in0_zs = d->in0_zero_stuffed ? 1 : 0; a.ksplit = ksplit; a.atomic_out = ksplit > 1 || d->atomic_accumulate;
 
+#ifdef YP_TIMELINE
+    int tile = (d->tile >= 1 && d->tile <= 8) ? d->tile : pick_tile(a.M, Cout);
+#else
     int tile = (d->tile >= 1 && d->tile <= 5) ? d->tile : pick_tile(a.M, Cout);
+#endif
     const TileCfg* tc = nullptr;
     for (const auto& c : kTiles) if (c.id == tile) tc = &c;
     YP_REQUIRE(tc != nullptr, "yp_conv2d: unknown tile id %d", tile);

@@ -351,10 +351,15 @@ __global__ __launch_bounds__(256) void objloss_init_kernel(float* __restrict__ d
     if (i < (size_t)cells) owner[i] = -1;
 }
 
+// (entry counts: `n` from the host, or -- n_dev != nullptr -- read from the device, where yp_build_targets left it: no host sync between
+// the target assignment and the loss; the grids are then sized for the capacity and surplus workgroups leave at once)
 __global__ __launch_bounds__(256) void objloss_targets_kernel(const float* __restrict__ p, int no, const int* __restrict__ cell, const float* __restrict__ tbox,
-                                                              const float* __restrict__ anch, int n, float w_box, float* __restrict__ iou_e,
+                                                              const float* __restrict__ anch, int n, const int* __restrict__ n_dev, float w_box, float* __restrict__ iou_e,
                                                               int* __restrict__ owner, float* __restrict__ dp, float* __restrict__ sums) {
     __shared__ float sh[4];
+    if (n_dev != nullptr) n = *n_dev;
+    if (blockIdx.x * 256 >= n) return;
+    w_box /= (float)n;
     const int e = blockIdx.x * 256 + threadIdx.x;
     float lb = 0.f;
     if (e < n) {
@@ -391,8 +396,12 @@ __global__ __launch_bounds__(256) void objloss_targets_kernel(const float* __res
 
 // class BCE of the claimed cells, one thread per (entry, class): a per-entry loop over 80 classes is 80 dependent global loads
 __global__ __launch_bounds__(256) void objloss_cls_kernel(const float* __restrict__ p, int no, int nc, const int* __restrict__ cell, const int* __restrict__ tcls, int n,
-                                                          float cp, float cn, float cls_pw, float w_cls, float* __restrict__ dp, float* __restrict__ sums) {
+                                                          const int* __restrict__ n_dev, float cp, float cn, float cls_pw, float w_cls, float* __restrict__ dp,
+                                                          float* __restrict__ sums) {
     __shared__ float sh[4];
+    if (n_dev != nullptr) n = *n_dev;
+    if ((long)blockIdx.x * 256 >= (long)n * nc) return;
+    w_cls /= ((float)n * nc);
     const int i = blockIdx.x * 256 + threadIdx.x;
     float lc = 0.f;
     if (i < n * nc) {
@@ -422,6 +431,77 @@ __global__ __launch_bounds__(256) void objloss_cells_kernel(const float* __restr
     }
     lo = block_sum_256(lo, sh);
     if (threadIdx.x == 0) atomicAdd(sums + 1, lo);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// YOLOv5 target assignment on the device (reference utils/loss_functions.py:177-234 `build_targets`): every label [img, cls, x, y, w, h]
+// (normalised) is tried against the na anchors of a level (kept when max(w/aw, aw/w, h/ah, ah/h) < anchor_t) and claims its own grid cell
+// plus the up-to-two neighbour cells its centre is closest to (the four half-cell tests of :211-217).  The reference builds the entry
+// list with boolean-mask indexing (a host synchronisation per level); here one workgroup per level evaluates the 5 * na * nt candidate
+// entries, and an ordered block scan gives every live entry the position it has in the reference's list: offset-major, then anchor,
+// then label -- the order matters where two entries claim one cell (the later one owns it, index_put semantics).
+// Outputs per level l (arrays of capacity cap = 5 * na * nt): cell = ((img*na + a)*ny + gj)*nx + gi, tcls, tbox = (gx - gi, gy - gj, gw, gh),
+// anch = the anchor, count[l].
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void build_targets_kernel(const float* __restrict__ targets, int nt, const float* __restrict__ anchors, int na,
+                                                            const int* __restrict__ shapes, float anchor_t, int cap, int* __restrict__ cell_out,
+                                                            int* __restrict__ cls_out, float* __restrict__ box_out, float* __restrict__ anch_out,
+                                                            int* __restrict__ count) {
+    __shared__ int wsum[4];
+    __shared__ int running;
+    const int l = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int ny = shapes[l * 2], nx = shapes[l * 2 + 1];
+    const float* an = anchors + (size_t)l * na * 2;
+    int* cell = cell_out + (size_t)l * cap;
+    int* cls = cls_out + (size_t)l * cap;
+    float* box = box_out + (size_t)l * cap * 4;
+    float* anch = anch_out + (size_t)l * cap * 2;
+    const int total = 5 * na * nt;
+    if (t == 0) running = 0;
+    __syncthreads();
+    for (int base = 0; base < total; base += 256) {
+        const int id = base + t;
+        bool live = false;
+        int o = 0, a = 0, k = 0;
+        float gx = 0.f, gy = 0.f, gw = 0.f, gh = 0.f;
+        if (id < total) {
+            o = id / (na * nt);
+            a = (id / nt) % na;
+            k = id % nt;
+            const float* tg = targets + (size_t)k * 6;
+            gx = tg[2] * (float)nx; gy = tg[3] * (float)ny; gw = tg[4] * (float)nx; gh = tg[5] * (float)ny;
+            const float rw = gw / an[a * 2], rh = gh / an[a * 2 + 1];
+            live = fmaxf(fmaxf(rw, 1.0f / rw), fmaxf(rh, 1.0f / rh)) < anchor_t;
+            // neighbour claims: the centre lies in the lower / upper half of its cell and is not in the border cell
+            const float ix = (float)nx - gx, iy = (float)ny - gy;
+            if (o == 1) live = live && (fmodf(gx, 1.0f) < 0.5f) && gx > 1.0f;
+            else if (o == 2) live = live && (fmodf(gy, 1.0f) < 0.5f) && gy > 1.0f;
+            else if (o == 3) live = live && (fmodf(ix, 1.0f) < 0.5f) && ix > 1.0f;
+            else if (o == 4) live = live && (fmodf(iy, 1.0f) < 0.5f) && iy > 1.0f;
+        }
+        // ordered compaction: exclusive prefix count of the live flags over this chunk
+        const unsigned long long bal = __ballot(live);
+        const int before_lane = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int before = running + before_lane;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        if (live) {
+            const float ox = o == 1 ? 0.5f : (o == 3 ? -0.5f : 0.f), oy = o == 2 ? 0.5f : (o == 4 ? -0.5f : 0.f);
+            int gi = (int)(gx - ox), gj = (int)(gy - oy);              // .long(): truncation
+            gi = min(max(gi, 0), nx - 1); gj = min(max(gj, 0), ny - 1);   // clamp_ acts on the view the box offsets are taken from too
+            const float* tg = targets + (size_t)k * 6;
+            const int b = (int)tg[0];
+            cell[before] = ((b * na + a) * ny + gj) * nx + gi;
+            cls[before] = (int)tg[1];
+            box[before * 4 + 0] = gx - (float)gi; box[before * 4 + 1] = gy - (float)gj; box[before * 4 + 2] = gw; box[before * 4 + 3] = gh;
+            anch[before * 2 + 0] = an[a * 2]; anch[before * 2 + 1] = an[a * 2 + 1];
+        }
+        __syncthreads();
+        if (t == 0) running += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    if (t == 0) count[l] = running;
 }
 
 }  // namespace
@@ -459,16 +539,23 @@ extern "C" int yp_infonce_bwd(const float* da, const float* db, const int* idx, 
 extern "C" int yp_objloss_level(const float* p, int cells, int no, int nc, const int* cell, const float* tbox, const float* anch, const int* tcls, int n, float cp,
                                 float cn, float cls_pw, float obj_pw, float w_box, float w_obj, float w_cls, float* iou_scratch, int* owner_scratch, float* dp,
                                 float* sums, void* stream) {
+    return yp_objloss_level_dev(p, cells, no, nc, cell, tbox, anch, tcls, n, nullptr, cp, cn, cls_pw, obj_pw, w_box, w_obj, w_cls, iou_scratch, owner_scratch, dp,
+                                sums, stream);
+}
+
+extern "C" int yp_objloss_level_dev(const float* p, int cells, int no, int nc, const int* cell, const float* tbox, const float* anch, const int* tcls, int n,
+                                    const int* n_dev, float cp, float cn, float cls_pw, float obj_pw, float w_box, float w_obj, float w_cls, float* iou_scratch,
+                                    int* owner_scratch, float* dp, float* sums, void* stream) {
     YP_REQUIRE(p && dp && sums && owner_scratch && cells > 0 && no >= 5 && nc == no - 5 && n >= 0, "yp_objloss_level: bad arguments");
     YP_REQUIRE(n == 0 || (cell && tbox && anch && iou_scratch && (nc <= 1 || tcls)), "yp_objloss_level: target arrays missing");
     YP_REQUIRE(((uintptr_t)dp & 15) == 0, "yp_objloss_level: dp must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const size_t nf = (size_t)cells * no, n4 = (nf + 3) / 4;
     objloss_init_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, st>>>(dp, nf, owner_scratch, cells);
-    if (n > 0) {
-        objloss_targets_kernel<<<(n + 255) / 256, 256, 0, st>>>(p, no, cell, tbox, anch, n, w_box / n, iou_scratch, owner_scratch, dp, sums);
+    if (n > 0) {      // (with n_dev: n is the CAPACITY of the entry arrays, the live count is read on the device)
+        objloss_targets_kernel<<<(n + 255) / 256, 256, 0, st>>>(p, no, cell, tbox, anch, n, n_dev, w_box, iou_scratch, owner_scratch, dp, sums);
         if (nc > 1)
-            objloss_cls_kernel<<<(n * nc + 255) / 256, 256, 0, st>>>(p, no, nc, cell, tcls, n, cp, cn, cls_pw, w_cls / ((float)n * nc), dp, sums);
+            objloss_cls_kernel<<<(unsigned)(((long)n * nc + 255) / 256), 256, 0, st>>>(p, no, nc, cell, tcls, n, n_dev, cp, cn, cls_pw, w_cls, dp, sums);
     }
     objloss_cells_kernel<<<(cells + 255) / 256, 256, 0, st>>>(p, no, cells, owner_scratch, iou_scratch, obj_pw, w_obj / cells, dp, sums);
     YP_CHECK_HIP(hipGetLastError());
@@ -502,6 +589,21 @@ extern "C" int yp_detloss(const float* semi, const int64_t* semi_strides, const 
     detloss_kernel<<<nblk, 256, 0, st>>>(semi, semi_strides[0], semi_strides[1], semi_strides[2], semi_strides[3], target, target_strides[0], target_strides[1],
                                          target_strides[2], target_strides[3], mask, B, Hc, Wc, dsemi, (float*)workspace);
     detloss_fold_kernel<<<1, 256, 0, st>>>((const float*)workspace, nblk, sums);
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
+
+extern "C" int yp_build_targets(const float* targets, int nt, const float* anchors, int nl, int na, const int* shapes_dev, float anchor_t, int cap, int* cell,
+                                int* tcls, float* tbox, float* anch, int* count, void* stream) {
+    YP_REQUIRE(anchors && shapes_dev && count && nl > 0 && nl <= 8 && na > 0 && na <= 8 && nt >= 0 && cap >= 5 * na * nt && anchor_t > 0.f, "yp_build_targets: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (nt == 0) {
+        YP_CHECK_HIP(hipMemsetAsync(count, 0, sizeof(int) * nl, st));
+        return YP_OK;
+    }
+    YP_REQUIRE(targets && cell && tcls && tbox && anch, "yp_build_targets: null output");
+    build_targets_kernel<<<nl, 256, 0, st>>>(targets, nt, anchors, na, shapes_dev, anchor_t, cap, cell, tcls, tbox, anch, count);
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
 }

@@ -272,7 +272,7 @@ __device__ __forceinline__ u64 box_key(float conf, unsigned id) {
 // with one atomic and writes it in a second walk over the rows that passed the objectness test.)  grid = (BOX_SPANS, B)
 constexpr int BOX_SPANS = 128;
 __global__ __launch_bounds__(256) void box_candidates_kernel(const float* __restrict__ pred, int B, int N, int nc, float conf_thres, int multi_label,
-                                                             u64* __restrict__ keys, int cap, int* __restrict__ count) {
+                                                             const unsigned* __restrict__ class_mask, u64* __restrict__ keys, int cap, int* __restrict__ count) {
     __shared__ int wave_cnt[4];
     __shared__ int base_s;
     const int no = nc + 5;
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void box_candidates_kernel(const float* __rest
         if (multi_label) {
             for (int j = 0; j < nc; ++j) {
                 const float conf = r[5 + j] * obj;
-                if (conf > conf_thres) {
+                if (conf > conf_thres && (class_mask == nullptr || ((class_mask[j >> 5] >> (j & 31)) & 1u))) {     // `classes` filter (general_yolo.py:199-200)
                     if (write && pos < cap) keys[(long)b * cap + pos] = box_key(conf, (unsigned)(row * nc + j));
                     ++pos;
                 }
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void box_candidates_kernel(const float* __rest
                 const float conf = r[5 + j] * obj;
                 if (conf > best) { best = conf; bj = j; }
             }
-            if (best > conf_thres) {
+            if (best > conf_thres && (class_mask == nullptr || ((class_mask[bj >> 5] >> (bj & 31)) & 1u))) {
                 if (write && pos < cap) keys[(long)b * cap + pos] = box_key(best, (unsigned)(row * nc + bj));
                 ++pos;
             }
@@ -890,6 +890,13 @@ extern "C" size_t yp_box_nms_workspace_bytes(int B, int N, int nc, int multi_lab
 extern "C" int yp_box_nms(const float* pred, int B, int N, int nc, float conf_thres, float iou_thres, int multi_label, int agnostic,
                           int max_det, int max_nms, float max_wh, float* out_det, int32_t* out_count, void* workspace,
                           size_t workspace_bytes, void* stream) {
+    return yp_box_nms_classes(pred, B, N, nc, conf_thres, iou_thres, multi_label, agnostic, max_det, max_nms, max_wh, nullptr, out_det, out_count, workspace,
+                              workspace_bytes, stream);
+}
+
+extern "C" int yp_box_nms_classes(const float* pred, int B, int N, int nc, float conf_thres, float iou_thres, int multi_label, int agnostic,
+                                  int max_det, int max_nms, float max_wh, const uint32_t* class_mask, float* out_det, int32_t* out_count, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
     YP_REQUIRE(pred && out_det && out_count && workspace, "yp_box_nms: null pointer");
     YP_REQUIRE(B > 0 && N > 0 && nc > 0 && max_det > 0 && max_det <= BOX_MAX_DET && max_nms > 0, "yp_box_nms: bad dims (max_det <= %d)", BOX_MAX_DET);
     YP_REQUIRE(conf_thres >= 0.f && conf_thres <= 1.f && iou_thres >= 0.f && iou_thres <= 1.f, "yp_box_nms: thresholds must be in [0,1]");
@@ -905,7 +912,7 @@ extern "C" int yp_box_nms(const float* pred, int B, int N, int nc, float conf_th
     int* count = (int*)workspace;
     u64* keys = (u64*)((char*)workspace + align_up((size_t)B * 4, 256));
     YP_CHECK_HIP(hipMemsetAsync(count, 0, (size_t)B * 4, st));
-    box_candidates_kernel<<<dim3(BOX_SPANS, B), 256, 0, st>>>(pred, B, N, nc, conf_thres, multi_label, keys, cap2, count);
+    box_candidates_kernel<<<dim3(BOX_SPANS, B), 256, 0, st>>>(pred, B, N, nc, conf_thres, multi_label, class_mask, keys, cap2, count);
     box_sort_nms_kernel<<<B, BOX_THREADS, 0, st>>>(pred, N, nc, iou_thres, conf_thres, agnostic, max_det, max_nms, max_wh, keys, cap, cap2, count,
                                                    out_det, out_count);
     YP_CHECK_HIP(hipGetLastError());

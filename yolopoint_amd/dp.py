@@ -48,6 +48,9 @@ class GradAllReducer:
             return
         for p in module.parameters():
             dist.broadcast(p.data, src=src, group=self.group)
+        # a write through .data bumps neither Tensor._version nor the optimizer-step count: tell the plans their packed filters are stale
+        from .models.common import invalidate_packed_weights
+        invalidate_packed_weights()
 
     def bind_grads(self):
         """Zero-copy mode: every p.grad becomes a view into its bucket (all fp32 parameters), the buckets are cleared with one

@@ -53,6 +53,9 @@ def _record_stream(obj, stream):
     elif isinstance(obj, (list, tuple)):
         for o in obj:
             _record_stream(o, stream)
+    elif isinstance(obj, dict):
+        for o in obj.values():
+            _record_stream(o, stream)
 
 
 class TrainStep:
@@ -74,6 +77,10 @@ class TrainStep:
         self.reducer.broadcast_parameters(model)
 
     def __call__(self, batch):
+        with torch.cuda.device(self.device):
+            return self._step(batch)
+
+    def _step(self, batch):
         loss = self.loss_and_grads(batch)
         self.reducer.all_reduce()
         self.opt.step()
@@ -104,7 +111,7 @@ class TrainStep:
             with torch.cuda.stream(side):
                 det = m.model.Detect
                 shapes = [(B, det.na, img.shape[-2] // int(st), S // int(st), det.no) for st in det.stride]
-                tgt = self.obj_loss.build_targets(shapes, batch['box_labels'])
+                tgt = self.obj_loss.assign(shapes, batch['box_labels'])
                 dch = getattr(m.model, "_desc_channels", None) or m.model.ConvDesc.out_channels
                 nce = infonce_prepare(batch['warped_valid_mask'], batch['inv_homographies'], (B, dch, img.shape[-2] // 8, S // 8), True,
                                       self.sparse['num_samples_per_image'], self.sparse['num_masked_non_matches_per_match'], 8, dev)

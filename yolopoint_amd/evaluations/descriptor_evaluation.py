@@ -6,6 +6,7 @@ from .. import _hip
 from ..utils._ws import as_cuda_f32
 
 
+@_hip.guarded
 def sample_desc_from_points(coarse_desc, pts, device=None, cell_size=8):
     """Bilinear-sample the coarse descriptor map [D,Hc,Wc] (or [1,D,Hc,Wc]) at pts [3,N] / [2,N]
     (x, y in full-resolution pixels) and L2-normalise each column -> float32 numpy [D, N]."""

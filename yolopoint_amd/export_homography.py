@@ -22,6 +22,7 @@ from .utils import utils as U
 HA_DEFAULT = dict(nms=4, top_k=600, detection_threshold=0.015)           # reference configs/*_export.yaml: homography_adaptation
 
 
+@_hip.guarded
 def combine_heatmaps(heat, mask, inv_homographies, want_cover=False):
     """heat, mask: cuda fp32 [N,H,W] (or [N,1,H,W]); inv_homographies [N,3,3] (normalised coordinates)
     -> sum_v warp(heat_v * mask_v) / sum_v warp(mask_v), cuda [H,W]  (export_homography.py:94-96,143-145)."""
@@ -46,6 +47,7 @@ class HomographyExporter:
         self.normalize_points = normalize_points
 
     @torch.no_grad()
+    @_hip.guarded
     def aggregate(self, views, valid_mask, inv_homographies, pad=None):
         """views [N,C,H,W]; valid_mask [N,1,H,W] or [N,H,W]; inv_homographies [N,3,3] -> aggregated heat map, cuda [H',W']."""
         views = views.to(self.device)
@@ -62,6 +64,7 @@ class HomographyExporter:
         return out
 
     @torch.no_grad()
+    @_hip.guarded
     def export_sample(self, sample):
         """One dataset sample (reference layout, batch dimension of 1 in front) -> numpy [n,3] (x, y, prob)."""
         img = sample["image"]

@@ -41,6 +41,7 @@ class YoloPointFrontend:
 
     NMS_ROUNDS = 12       # fix-point rounds enqueued per frame by the non-synchronising keypoint NMS (planted 1280x1280 maps need ~6)
 
+    @_hip.guarded
     @torch.no_grad()
     def process_tensor(self, inp, sync_nms=False):
         """inp: float [1,3,H,W] on the device, values in [0,1].  Returns dict(pts [N,3] (x, y, conf; conf descending),
@@ -60,7 +61,7 @@ class YoloPointFrontend:
         step = radius + 1
         max_pts = max(1, -(-H // step) * -(-W // step))
         pts = torch.empty((max_pts, 3), dtype=torch.float32, device=dev)
-        counts = torch.zeros((4,), dtype=torch.int32, device=dev)   # [points after NMS, boxes, points after filtering, NMS candidates left undecided]
+        counts = torch.zeros((5,), dtype=torch.int32, device=dev)   # [points after NMS, boxes, points after filtering, NMS candidates left undecided, pixels >= threshold]
         ws = workspace(dev, l.yp_kp_nms_workspace_bytes(1, H, W), "kp_nms")
         kp_args = (heat.data_ptr(), 1, H, W, float(self.sp_config["detection_threshold"]), radius, int(self.border_remove), pts.data_ptr(),
                    counts.data_ptr(), max_pts, ws.data_ptr(), ws.numel())
@@ -86,7 +87,11 @@ class YoloPointFrontend:
         else:
             kept = pts
             counts[2:3].copy_(counts[0:1])
-        n_nms, n_box, n_pts, undecided = counts.cpu().tolist()                    # the frame's only host sync
+        # pixels that passed the threshold: the NMS kernels' candidate counter (workspace layout of yp_kp_nms_workspace_bytes)
+        al = lambda v: -(-v // 256) * 256
+        off = al(H * W) + 3 * al(H * W * 4)
+        counts[4:5].copy_(ws[off:off + 4].view(torch.int32))
+        n_nms, n_box, n_pts, undecided, n_cand = counts.cpu().tolist()            # the frame's only host sync
         if undecided:                                                              # the greedy NMS needed more rounds than enqueued: redo with the
             return self.process_tensor(inp, sync_nms=True)                         # converging variant (not seen on real or planted heat maps)
         if n_box < 0:
@@ -98,16 +103,17 @@ class YoloPointFrontend:
             xy = kept[:, :2].contiguous()
             _, dc, dy, dx = coarse.stride()
             _hip.check(l.yp_desc_sample(coarse.data_ptr(), D, Hc, Wc, dc, dy, dx, xy.data_ptr(), n_pts, 8, desc.data_ptr(), st))
-        return {"pts": kept, "desc": desc, "boxes": boxes, "n_before_filter": n_nms, "heat": heat[0]}
+        return {"pts": kept, "desc": desc, "boxes": boxes, "n_before_filter": n_nms, "n_candidates": n_cand, "heat": heat[0]}
 
     @torch.no_grad()
     def process_img(self, img):
         """img: HxWx3 uint8 (numpy).  Returns (pts [3,N] float64, desc [D,N] float32, [boxes tensor]) in the coordinates of the
-        original image, or (zeros((3,0)), None, None) when no keypoint survives -- the reference's return convention."""
+        original image, or (zeros((3,0)), None, None) when no pixel reaches the detection threshold -- the reference's return
+        convention (demo.py:151-153; a frame whose candidates are all removed later returns empty arrays and the boxes)."""
         img, cth, ctw, fac = self.preprocess(img)
         x = torch.from_numpy(np.ascontiguousarray(img.transpose(2, 0, 1))).to(self.device).float().div_(255.).unsqueeze(0)
         r = self.process_tensor(x)
-        if r["n_before_filter"] == 0:
+        if r["n_candidates"] == 0:
             return np.zeros((3, 0)), None, None
         pts = r["pts"].cpu().numpy().astype(np.float64).T.copy()
         desc = r["desc"].cpu().numpy()

@@ -184,6 +184,7 @@ class YOLOPoint(HipModule):
         graphs.append(g)
         return g
 
+    @_hip.guarded
     def forward(self, x):
         if not (isinstance(x, torch.Tensor) and x.is_cuda):
             raise _hip.YpError("YOLOPoint.forward needs a cuda (HIP) tensor: the hot path has no CPU fallback")
@@ -313,25 +314,27 @@ class Model(nn.Module):
 
     @staticmethod
     def _check_anchor_order(m):
-        a = m.anchors.prod(-1).view(-1)
-        da = a[-1] - a[0]
-        ds = m.stride[-1] - m.stride[0]
-        if da.sign() != ds.sign():
+        """Anchor areas must grow with the strides (reference YOLOPoint.py:20-28): a list given large-to-small is turned around."""
+        areas = m.anchors.prod(-1).view(-1)
+        direction = lambda first, last: (float(last) > float(first)) - (float(last) < float(first))      # -1 / 0 / +1
+        if direction(areas[0], areas[-1]) != direction(m.stride[0], m.stride[-1]):
             LOGGER.info('Reversing anchor order')
-            m.anchors[:] = m.anchors.flip(0)
+            m.anchors.copy_(torch.flip(m.anchors, dims=(0,)))
 
     def forward(self, x):
         return self.model(x)
 
     def _apply(self, fn):
-        self = super()._apply(fn)
-        if hasattr(self.model, 'Detect'):
-            m = self.model.Detect
-            m.stride = fn(m.stride)
-            m.grid = list(map(fn, m.grid))
-            if isinstance(m.anchor_grid, list):
-                m.anchor_grid = list(map(fn, m.anchor_grid))
-        return self
+        """.to() / .cuda() / .float() also move the Detect head's plain-tensor attributes (stride and the cached decode grids, which
+        are not registered buffers; reference YOLOPoint.py:73-82)."""
+        moved = super()._apply(fn)
+        head = getattr(moved.model, 'Detect', None)
+        if head is not None:
+            head.stride = fn(head.stride)
+            head.grid = [fn(g) for g in head.grid]
+            if isinstance(head.anchor_grid, list):
+                head.anchor_grid = [fn(g) for g in head.anchor_grid]
+        return moved
 
     # -- compute precision ----------------------------------------------------------------
     def set_compute_dtype(self, dt):
@@ -360,47 +363,57 @@ class Model(nn.Module):
         return self
 
     def _initialize_biases(self, cf=None):
-        m = self.model.Detect
-        for mi, s in zip(m.m, m.stride):
-            b = mi.bias.view(m.na, -1)
-            b.data[:, 4] += math.log(8 / (640 / s) ** 2)
-            b.data[:, 5:] += math.log(0.6 / (m.nc - 0.999999)) if cf is None else torch.log(cf / cf.sum())
-            mi.bias = torch.nn.Parameter(b.view(-1), requires_grad=True)
+        """Detect bias prior (reference YOLOPoint.py:92-100): objectness as if 8 objects fell on a 640-px image at the level's
+        stride, classes as if each had prior 0.6 / nc (or the given class frequencies)."""
+        head = self.model.Detect
+        class_prior = math.log(0.6 / (head.nc - 0.999999)) if cf is None else torch.log(cf / cf.sum())
+        for conv, stride in zip(head.m, head.stride):
+            with torch.no_grad():
+                per_anchor = conv.bias.detach().clone().view(head.na, -1)
+                per_anchor[:, 4] += math.log(8 / (640 / float(stride)) ** 2)
+                per_anchor[:, 5:] += class_prior
+            conv.bias = torch.nn.Parameter(per_anchor.reshape(-1), requires_grad=True)
 
     def load_state_dict(self, target_state_dict, strict=True, verbose=False):
-        """Tolerant loading (reference: YOLOPoint.py:102-120): a changed class count re-initialises Detect."""
-        key = 'model.Detect.m.0.bias' if 'model.Detect.m.0.bias' in target_state_dict else 'Detect.m.0.bias'
-        if key in target_state_dict:
-            if target_state_dict[key].shape == self.state_dict()[key].shape:
-                super().load_state_dict(target_state_dict, strict)
-            else:
-                if verbose:
-                    LOGGER.info("Number of classes have changed. Reinitializing Detect layer.\n")
-                self.load_partial_state_dict(target_state_dict, strict, verbose)
-        else:
+        """Checkpoints of either prefix style ('model.Conv1...' or 'Conv1...') load; one whose Detect head was built for another
+        class count keeps everything that still fits and leaves the head freshly initialised (reference YOLOPoint.py:102-120)."""
+        from .common import invalidate_packed_weights
+        probe = next((k for k in ('model.Detect.m.0.bias', 'Detect.m.0.bias') if k in target_state_dict), None)
+        if probe is None:                       # a checkpoint of the bare network, or of a model without a Detect head
             try:
                 self.model.load_state_dict(target_state_dict, strict=strict)
             except RuntimeError:
                 super().load_state_dict(target_state_dict, strict=strict)
+        elif tuple(target_state_dict[probe].shape) == tuple(self.state_dict()[probe].shape):
+            super().load_state_dict(target_state_dict, strict)
+        else:
+            if verbose:
+                LOGGER.info("Number of classes have changed. Reinitializing Detect layer.\n")
+            self.load_partial_state_dict(target_state_dict, strict, verbose)
+        invalidate_packed_weights()
 
     def load_partial_state_dict(self, target_state_dict, strict=True, verbose=False):
-        """Copy every tensor whose last-two name components and shape match (reference: YOLOPoint.py:122-135)."""
-        current = self.state_dict()
-        new = deepcopy(current)
-        for k_this, k_new in zip(current, target_state_dict):
-            if '.'.join(k_this.split('.')[-2:]) == '.'.join(k_new.split('.')[-2:]) \
-                    and current[k_this].shape == target_state_dict[k_new].shape:
-                if verbose:
-                    LOGGER.info(f"{k_this} {' ' * (50 - len(k_this))} {k_new}")
-                new[k_new] = target_state_dict[k_this]
-        super().load_state_dict(new, strict)
+        """Walk both key lists in step; where the trailing '<module>.<tensor>' name and the shape agree, take the checkpoint's tensor
+        (reference YOLOPoint.py:122-135, including its pairing of the two key lists by position)."""
+        own = self.state_dict()
+        merged = deepcopy(own)
+        tail = lambda key: key.rsplit('.', 2)[-2:]
+        for mine, theirs in zip(list(own), list(target_state_dict)):
+            if tail(mine) != tail(theirs) or own[mine].shape != target_state_dict[theirs].shape:
+                continue
+            if verbose:
+                LOGGER.info(f"{mine} {' ' * (50 - len(mine))} {theirs}")
+            merged[theirs] = target_state_dict[mine]
+        super().load_state_dict(merged, strict)
 
     def freeze_layers(self, to_freeze, verbose=True):
+        """requires_grad = False for the parameters whose position in named_parameters() is listed (reference YOLOPoint.py:137-145)."""
+        wanted = set(int(i) for i in to_freeze)
         if verbose:
             LOGGER.info("Freezing weights...")
-        for i, (name, param) in enumerate(self.named_parameters()):
-            freeze = i in to_freeze and hasattr(param, 'requires_grad')
+        for pos, (name, param) in enumerate(self.named_parameters()):
+            hit = pos in wanted
             if verbose:
-                LOGGER.info(f"{i} {name} {' ' * (45 - len(name) - len(str(i)))} {'--> freeze' if freeze else ''}")
-            if freeze:
-                param.requires_grad = False
+                LOGGER.info(f"{pos} {name} {' ' * (45 - len(name) - len(str(pos)))} {'--> freeze' if hit else ''}")
+            if hit:
+                param.requires_grad_(False)

@@ -41,8 +41,16 @@ _GENERATION = [0]
 
 
 def weights_generation():
-    """Number of optimizer steps taken in this process (any optimizer): see HipModule._weights_version."""
+    """Number of optimizer steps taken in this process (any optimizer) + explicit invalidations: see HipModule._weights_version."""
     return _GENERATION[0]
+
+
+def invalidate_packed_weights():
+    """Tell every plan that the fp32 master parameters may have changed behind PyTorch's version counters: updates made through
+    `.data` (p.data.copy_ / add_, dist.broadcast(p.data), hand-written SGD or EMA) bump neither Tensor._version nor the
+    optimizer-step count.  Cheap (a counter); the next forward re-derives the packed 16-bit filters.  Called by
+    dp.GradAllReducer.broadcast_parameters, Model.load_state_dict and ModelEMA; call it after any other `.data` write."""
+    _GENERATION[0] += 1
 
 
 def _count_optimizer_step(*_args, **_kwargs):
@@ -63,10 +71,7 @@ class HipModule(nn.Module):
         """Changes whenever the parameters / buffers may have changed: tensor version counters and storage addresses, plus the
         process-wide optimizer-step count -- fused optimizers (torch.optim.Adam(fused=True)) update parameters WITHOUT bumping
         Tensor._version, so a key built on the counters alone keeps replaying plans packed from the old filters."""
-        v = weights_generation() * 1000003
-        for t in list(self.parameters()) + list(self.buffers()):
-            v += t._version + (t.data_ptr() % 1000003)
-        return v
+        return (weights_generation(),) + tuple((t._version, t.data_ptr()) for t in list(self.parameters()) + list(self.buffers()))
 
     def _plan_key(self, x):
         return (tuple(x.shape), _hip.dtype_code(self.compute_dtype), self.training, self._weights_version(), x.device.index)
@@ -74,6 +79,7 @@ class HipModule(nn.Module):
     def _standalone_out_channels(self):
         raise NotImplementedError
 
+    @_hip.guarded
     def forward(self, x):
         if not (isinstance(x, torch.Tensor) and x.is_cuda):
             raise _hip.YpError(f"{type(self).__name__}.forward needs a cuda (HIP) tensor: the hot path has no CPU fallback")

@@ -94,6 +94,7 @@ class PointTracker(object):
         keep = ((self.tracks[:, 2:] != -1).sum(axis=1) >= min_length) & (self.tracks[:, -1] != -1)
         return self.tracks[keep].copy()
 
+    @_hip.guarded
     def nn_match_two_way(self, desc1, desc2, nn_thresh):
         """Mutual nearest-neighbour matching of unit descriptors desc1 [D,N1], desc2 [D,N2]
         -> float64 numpy [3, L] rows (idx1, idx2, L2 distance), idx1 ascending."""

@@ -476,7 +476,7 @@ class TrainGraph:
     def forward(self, x):
         # packed weights (forward + dgrad) are re-derived only when an optimizer step (or a load) changed the masters
         # (the optimizer-step count is part of the key: fused optimizers do not bump Tensor._version)
-        ver = sum(p_._version for p_ in self.params) + weights_generation() * 1000003
+        ver = (weights_generation(),) + tuple(p_._version for p_ in self.params)      # (a tuple: a sum of counters can collide)
         if ver != getattr(self, "_packed_version", None):      # host-packed filters of this graph (stem, Detect)
             self.fwd_plan.refresh()
             self.bwd_plan.refresh()
@@ -537,6 +537,7 @@ def _release(g):
 
 class _YOLOPointTrainFn(torch.autograd.Function):
     @staticmethod
+    @_hip.guarded
     def forward(ctx, net, x, *params):
         g = net._train_graph(x)
         ctx.graph = g
@@ -551,6 +552,11 @@ class _YOLOPointTrainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_semi, g_desc, *g_xs):
         g = ctx.graph
+        with torch.cuda.device(g.device):
+            return _YOLOPointTrainFn._backward(ctx, g, g_semi, g_desc, g_xs)
+
+    @staticmethod
+    def _backward(ctx, g, g_semi, g_desc, g_xs):
         grads = g.backward(g_semi, g_desc, list(g_xs))
         g.busy = False
         # Parameter gradients are delivered with multi-tensor ops instead of ~215 per-parameter autograd returns (each of

@@ -36,6 +36,7 @@ def xywh2xyxy(x):
     return y
 
 
+@_hip.guarded
 def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
                         labels=(), max_det=300, nm=0):
     """Batched NMS on decoded predictions [B, N, 5+nc]; returns a list of B tensors [n, 6]
@@ -48,11 +49,36 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
         prediction = prediction[0]
     assert 0 <= conf_thres <= 1, f'Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0'
     assert 0 <= iou_thres <= 1, f'Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0'
-    if classes is not None or nm != 0 or (labels and any(len(l) for l in labels)):
-        raise _hip.YpError("non_max_suppression: classes / labels / nm are not used on the YOLOPoint path and are unsupported")
+    if nm != 0:
+        raise _hip.YpError("non_max_suppression: mask outputs (nm > 0) do not exist on the YOLOPoint path (Detect has no mask head)")
     pred = as_cuda_f32(prediction, what="prediction")
     B, N, no = pred.shape
     nc = no - 5
+    if labels and any(len(lb) for lb in labels):
+        # a-priori labels (autolabelling, general_yolo.py:171-178): rows [class, x, y, w, h] become predictions with objectness 1 and a
+        # one-hot class, appended behind the image's own rows (rows padded with objectness 0 never become candidates)
+        extra = max(len(lb) for lb in labels)
+        grown = torch.zeros((B, N + extra, no), dtype=torch.float32, device=pred.device)
+        grown[:, :N] = pred
+        for b, lb in enumerate(labels):
+            if len(lb):
+                lb = torch.as_tensor(lb, dtype=torch.float32, device=pred.device)
+                rows = torch.arange(N, N + lb.shape[0], device=pred.device)
+                grown[b, rows, 0:4] = lb[:, 1:5]
+                grown[b, rows, 4] = 1.0
+                grown[b, rows, 5 + lb[:, 0].long()] = 1.0
+        pred, N = grown, N + extra
+    mask = None
+    if classes is not None:
+        # keep only the listed classes (general_yolo.py:199-200): a bit mask tested where the candidates are collected
+        words = [0] * ((nc + 31) // 32)
+        for c in classes:
+            c = int(c)
+            if 0 <= c < nc:
+                words[c >> 5] |= 1 << (c & 31)
+        mask = torch.tensor(words, dtype=torch.int64, device=pred.device).to(torch.int32) if words else None
+        if mask is not None:
+            mask = torch.tensor([w - (1 << 32) if w >= (1 << 31) else w for w in words], dtype=torch.int32, device=pred.device)
     max_wh, max_nms = 7680.0, 30000     # reference constants (general_yolo.py:154-155)
     l = _hip.lib()
     out = torch.empty((B, max_det, 6), dtype=torch.float32, device=pred.device)
@@ -60,9 +86,9 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     ml = int(bool(multi_label) and nc > 1)
     nbytes = l.yp_box_nms_workspace_bytes(B, N, nc, ml, max_nms)
     ws = workspace(pred.device, nbytes, "box_nms")
-    _hip.check(l.yp_box_nms(pred.data_ptr(), B, N, nc, float(conf_thres), float(iou_thres), ml, int(bool(agnostic)),
-                            int(max_det), max_nms, max_wh, out.data_ptr(), cnt.data_ptr(), ws.data_ptr(), ws.numel(),
-                            _hip.stream_ptr()))
+    _hip.check(l.yp_box_nms_classes(pred.data_ptr(), B, N, nc, float(conf_thres), float(iou_thres), ml, int(bool(agnostic)),
+                                    int(max_det), max_nms, max_wh, mask.data_ptr() if mask is not None else None, out.data_ptr(), cnt.data_ptr(),
+                                    ws.data_ptr(), ws.numel(), _hip.stream_ptr()))
     counts = cnt.cpu().tolist()
     if any(c < 0 for c in counts):
         raise _hip.YpError("non_max_suppression: candidate list overflowed the workspace (more than 2^21 candidates per image)")

@@ -28,6 +28,7 @@ def toNumpy(tensor):
 
 
 # ---------------------------------------------------------------------------------------------
+@_hip.guarded
 def _kp_decode(semi4, mode):
     """semi4: fp32 cuda tensor [B,65,Hc,Wc] with arbitrary strides -> heat [B, 8Hc, 8Wc]."""
     B, ch, Hc, Wc = semi4.shape
@@ -66,6 +67,7 @@ def flattenDetection_demo(semi):
 KP_NMS_ROUNDS = 16
 
 
+@_hip.guarded
 def _kp_nms_device(heat3, conf_thresh, radius, border):
     """heat3: fp32 cuda [B,H,W] -> list of B float32 cuda tensors [n,3] (x,y,conf), conf descending."""
     heat3 = heat3.contiguous()
