@@ -54,3 +54,17 @@ def check_grad_sketch(G, tag, name, grad, rel):
         assert e < rel, (tag, name, "full", e)
         worst = max(worst, e)
     return worst
+
+
+def argmax_mismatches(got, ref, tie_tol):
+    """Cells whose channel argmax differs between `got` and `ref` ([B,C,H,W]).  Every such cell must be a TIE of the reference within
+    `tie_tol` (absolute margin between the reference's value at its own argmax and at the other candidate): fp32 sums evaluated in
+    a different order can only flip an argmax where the two logits are equal to rounding.  Returns (mismatching cells, largest margin)."""
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    ia, ib = got.argmax(1, keepdim=True), ref.argmax(1, keepdim=True)
+    bad = ia != ib
+    if not bool(bad.any()):
+        return 0, 0.0
+    margin = (ref.gather(1, ib) - ref.gather(1, ia))[bad]
+    assert float(margin.max()) <= tie_tol, f"argmax differs on a non-tie: margin {float(margin.max()):.3e} > {tie_tol:.1e}"
+    return int(bad.sum()), float(margin.max())

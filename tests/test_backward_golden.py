@@ -12,7 +12,7 @@ from oracle import net_oracle
 from yolopoint_amd import models
 
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "backward.npz"))
-CASES = {"s64": ("s", 2, 64, 31), "n96": ("n", 3, 96, 32)}
+CASES = {"s64": ("s", 2, 64, 31), "n128": ("n", 3, 128, 32)}
 
 
 @pytest.mark.parametrize("tag", list(CASES))

@@ -369,7 +369,7 @@ def test_train_forward_without_backward_releases_its_plans(cuda):
         del o
 
 
-@pytest.mark.parametrize("tag,version,B,S,seed", [("s64", "s", 2, 64, 31), ("n96", "n", 3, 96, 32)])
+@pytest.mark.parametrize("tag,version,B,S,seed", [("s64", "s", 2, 64, 31), ("n128", "n", 3, 128, 32)])
 def test_backward_matches_reference_golden(cuda, tag, version, B, S, seed):
     """The f32 HIP path against the REFERENCE's loss.backward() (train.py:245): all 215 parameter gradients and the train-mode loss
     of seeded output projections, tests/golden/backward.npz (sketches: norm + 8 projections + small tensors whole)."""

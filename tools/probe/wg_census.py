@@ -77,11 +77,20 @@ def census(name, c1, c2, k, s, Ho, tile):
           f"life p10/p50/p90/max {pct(life,10):5.2f}/{pct(life,50):5.2f}/{pct(life,90):5.2f}/{life.max():5.2f}  last end {e_us.max():5.2f} us")
 
 
+l.yp_debug_probe_mode.argtypes = [C.c_int]
+MODES = [int(v) for v in os.environ.get("YP_PROBE_MODES", "0").split(",")]
+if os.environ.get("YP_PROBE_CASES"):
+    CASES = [c for c in CASES if any(k in c[0] for k in os.environ["YP_PROBE_CASES"].split(","))]
 for name, c1, c2, k, s, Ho, tiles in CASES:
     M = 8 * Ho * Ho
     Hi = Ho * s
     bin_, bout = 8 * Hi * Hi * c1 * 2, M * c2 * 2
     cf, nb = copy_floor(bin_, bout)
     print(f"{name}: M={M} in {bin_/1e6:.1f} MB out {bout/1e6:.1f} MB w {c1*c2*k*k*2/1e6:.2f} MB; device copy of {nb/1e6:.1f} MB: {cf:.1f} us")
-    for tile in tiles:
-        census(name, c1, c2, k, s, Ho, tile)
+    for mode in MODES:
+        l.yp_debug_probe_mode(mode)
+        if len(MODES) > 1:
+            print(f" probe mode {mode} (1 = no MFMA, 2 = pixel DMA from the zero page, 4 = filter DMA from the zero row)")
+        for tile in tiles:
+            census(name, c1, c2, k, s, Ho, tile)
+    l.yp_debug_probe_mode(0)

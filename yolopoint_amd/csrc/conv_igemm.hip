@@ -59,16 +59,27 @@ template <> struct Elem<YP_F32> {
 #ifdef YP_TIMELINE
 __device__ long long yp_timeline[64];
 __device__ int yp_tl_block = 0;                            // the workgroup whose phase clocks are recorded (yp_debug_timeline_block)
+__device__ int yp_probe_mode = 0;                          // elimination experiments on the generic kernel: 1 = no MFMA / fragment reads, 2 = pixel DMA
+                                                           // reads the zero page, 4 = filter DMA reads the zero row
+extern "C" int yp_debug_probe_mode(int m) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(yp_probe_mode), &m, sizeof(int)); }
+#define YP_PROBE_MODE() __builtin_amdgcn_readfirstlane(yp_probe_mode)
 __device__ unsigned long long yp_wg_times[3 * 16384];      // per workgroup: {entry, epilogue-stores-issued} on the 100 MHz wall clock, HW_ID | XCC_ID << 32
 extern "C" int yp_debug_timeline(long long* out_host) { return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(yp_timeline), sizeof(long long) * 64); }
 extern "C" int yp_debug_timeline_block(int b) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(yp_tl_block), &b, sizeof(int)); }
 extern "C" int yp_debug_wg_times(unsigned long long* out_host, int nwg) { return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(yp_wg_times), sizeof(unsigned long long) * 3 * nwg); }
-#define YP_TL(i) do { if (threadIdx.x == 0) { if ((int)blockIdx.x == yp_tl_block) yp_timeline[i] = __builtin_readcyclecounter();                       \
-        if (((i) == 0 || (i) >= 41) && blockIdx.x < 16384) { yp_wg_times[blockIdx.x * 3 + ((i) == 0 ? 0 : 1)] = wall_clock64();                          \
-            if ((i) == 0) yp_wg_times[blockIdx.x * 3 + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |             \
-                                                               ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32); } } } while (0)
+// (the selected block is read ONCE, at YP_TL(0) = kernel entry: a load of the __device__ variable inside the k loop is a VMEM operation
+// that the compiler waits for with vmcnt(0) -- it drained the hand-counted DMA pipeline every iteration and made the probe build
+// 1.5x slower than the production one)
+#define YP_TL(i) do { if ((i) == 0) yp_tl_hit = (threadIdx.x == 0 && (int)blockIdx.x == __builtin_amdgcn_readfirstlane(yp_tl_block));                    \
+        if (yp_tl_hit) yp_timeline[i] = __builtin_readcyclecounter();                                                                                        \
+        if (((i) == 0 || (i) >= 41) && threadIdx.x == 0 && blockIdx.x < 16384) { yp_wg_times[blockIdx.x * 3 + ((i) == 0 ? 0 : 1)] = wall_clock64();        \
+            if ((i) == 0) yp_wg_times[blockIdx.x * 3 + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |               \
+                                                               ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32); } } while (0)
+#define YP_TL_DECL bool yp_tl_hit = false
 #else
 #define YP_TL(i) do {} while (0)
+#define YP_TL_DECL do {} while (0)
+#define YP_PROBE_MODE() 0
 #endif
 
 struct ConvKArgs {
@@ -250,10 +261,16 @@ __device__ __forceinline__ void yp_glds16(const void* gsrc, unsigned lds_dst) {
 
 // Same, with the source given as a wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset.
 __device__ __forceinline__ void yp_glds16_s(const void* sbase, unsigned voff, unsigned lds_dst) {
+    // (the scalar operands go through readfirstlane: a no-op where the compiler already holds them in SGPRs, and the guarantee the "s"
+    // constraints need where register pressure made it keep a uniform value in a VGPR -- "illegal VGPR to SGPR copy" otherwise)
+    const unsigned long long b = (unsigned long long)sbase;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    const void* sb = (const void*)(((unsigned long long)hi << 32) | lo);
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
-                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "v"(voff), "s"(sb), "s"(dst)
                  : "memory");
 }
 
@@ -266,7 +283,19 @@ __device__ __forceinline__ void yp_glds16_s(const void* sbase, unsigned voff, un
 // places lanes linearly).  Bank conflicts of the 16-byte fragment reads are removed by an XOR
 // swizzle applied on the SOURCE side: physical chunk j of row r holds logical chunk j ^ swz(r),
 // swz(r) = {0,0,3,3}[(r/4)%4]; readers apply the same involution.
-template <int DT, bool OUT_F32, bool FAST, bool DETECT, int BM, int BN, int WAVES_M, int WAVES_N, int NS, bool STATS = false>
+//
+// KPB > 0 selects the second-generation main loop (16-bit element types, FAST addressing): a ring stage holds KPB consecutive k tiles,
+// so there is ONE barrier per KPB tiles instead of one per tile, the MFMA fragments are double-buffered in registers (the LDS reads of
+// sub-tile q+1 are in flight while the MFMAs of sub-tile q issue) and the refill of a ring slot is issued right behind the barrier
+// that frees it.  Measured on the first-generation loop (tools/probe/wg_census.py): one k tile of a 128 x 128 workgroup took 0.56 us
+// whatever the ring depth -- 1340 clocks for 256 clocks of MFMA work, a serial barrier -> DMA issue -> LDS read -> MFMA chain per tile.
+//
+// WSK ("waves split k", with KPB = 4): the four waves of the workgroup each take ONE of the four k tiles of a stage and multiply it
+// against the WHOLE BM x BN tile (16 MFMAs per wave and barrier for 64 x 64 instead of 4: short-M / deep-K layers keep small tiles for
+// the sake of enough workgroups, and were issue-bound on ~50 instructions per 4 MFMAs); the four partial tiles are summed through LDS
+// before the unchanged epilogue.  The k order of the fp32 sums changes (4 interleaved partial sums), so results differ from the
+// sequential loop in the last bits.
+template <int DT, bool OUT_F32, bool FAST, bool DETECT, int BM, int BN, int WAVES_M, int WAVES_N, int NS, bool STATS = false, int KPB = 0, bool WSK = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     using E = Elem<DT>;
     using frag_t = typename E::frag;
@@ -278,15 +307,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     constexpr int NLA = SLOTS_A / 4;                 // DMA instructions per wave per tile (pixels)
     constexpr int NLB = (SLOTS_B + 3) / 4;           //                                   (filter rows)
     constexpr int NL = NLA + NLB;
-    constexpr int STAGE = SLOTS * 1024;
+    constexpr int KP = KPB > 0 ? KPB : 1;            // k tiles per ring stage (= per barrier)
+    constexpr int SUB = SLOTS * 1024;                // LDS image of one k tile
+    constexpr int STAGE = KP * SUB;
+    static_assert(KPB == 0 || (FAST && DT != YP_F32 && KPB % 2 == 0), "the second-generation loop serves the 16-bit FAST path; KPB even");
+    static_assert(!WSK || (KPB == 4 && !STATS), "waves-split-k: one k tile of a 4-tile stage per wave");
     constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N;
     constexpr int FM = TM / 16, FN = TN / 16;
     constexpr int LPG = 4 * FN;          // consecutive channels owned by one lane
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
     static_assert(BM % 64 == 0 && FM >= 1 && FN >= 1 && NS >= 2 && NS <= 8, "unsupported tile");
-    static_assert(NL * (NS - 2) <= 60, "vmcnt immediate range");
+    static_assert(KP * NL * (NS - 1) <= 60, "vmcnt immediate range");
 
     extern __shared__ __attribute__((aligned(1024))) char smem[];      // NS * STAGE bytes (dynamic: deep rings exceed 64 KiB)
+    YP_TL_DECL;
     YP_TL(0);
 
     // ---- XCD-aware tile mapping: workgroup b runs on XCD b%8; give each XCD a contiguous run of
@@ -367,7 +401,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     YP_PIN(const char*, in0); YP_PIN(const char*, in1);
     YP_PIN(int, in0_cs); YP_PIN(int, in1_cs); YP_PIN(int, in0_co); YP_PIN(int, in1_co); YP_PIN(int, in0_C);
     YP_PIN(int, in0_ups); YP_PIN(int, in1_ups); YP_PIN(int, in0_H); YP_PIN(int, in1_H); YP_PIN(int, in0_W); YP_PIN(int, in1_W);
-    YP_PIN(int, Hi); YP_PIN(int, Wi); YP_PIN(int, Cin); YP_PIN(int, S); YP_PIN(int, RS); YP_PIN(int, invS); YP_PIN(int, dt); YP_PIN(int, dc);
+    YP_PIN(int, Hi); YP_PIN(int, Wi); YP_PIN(int, Cin); YP_PIN(int, S); YP_PIN(int, invS); YP_PIN(int, dt); YP_PIN(int, dc);
 #undef YP_PIN
     const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -376,35 +410,69 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     int s_tap = 0, s_c0 = 0;
     if (kt0 > 0) { s_tap = (kt0 * BK) / a.Cin; s_c0 = kt0 * BK - s_tap * a.Cin; }
     YP_PIN2(unsigned, in0_zoff); YP_PIN2(unsigned, in1_zoff); YP_PIN2(const char*, wgt);
-    auto issue_tile = [&](int kt, int stage) {
-        const unsigned sbase = lds0 + stage * STAGE;
+    YP_PIN2(int, RS);
+    const int probe_mode = YP_PROBE_MODE();
+    unsigned seg_voff[NLA];            // FAST path issue state: per-lane pixel offsets of the current segment,
+    const char* seg_base = in0;        // its scalar base (advances 64 bytes per k tile), the tiles left in it, its zero-page offset
+    int seg_left = 0;
+    unsigned seg_zoff = 0;
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) seg_voff[i] = 0;
+    auto issue_tile = [&](int kt, unsigned lds_off) {
+        const unsigned sbase = lds0 + lds_off;
         if constexpr (FAST) {
-            const int kr = (s_tap * invS) >> 16;
-            const int ks = s_tap - kr * S;
-            const bool s0 = s_c0 < in0_C;
-            const char* base = s0 ? in0 : in1;
-            const int cs = s0 ? in0_cs : in1_cs;
-            const int ups = s0 ? in0_ups : in1_ups;
-            const int Hp = s0 ? in0_H : in1_H;
-            const int Wp = s0 ? in0_W : in1_W;
-            const unsigned zoff = s0 ? in0_zoff : in1_zoff;
-            const bool zs = s0 && a.in0_zs;
-            const int cbyte = ((s0 ? in0_co + s_c0 : in1_co + s_c0 - in0_C)) * EB;     // scalar
-            const int csb = cs * EB;
-            const unsigned lanec = (unsigned)jl * 16u;
+            // A SEGMENT = the run of k tiles inside one (filter tap, source tensor): there the per-lane pixel offsets are constant and
+            // only the channel position moves, which rides in the scalar base pointer.  The per-lane work (tap decode, bounds test,
+            // pixel offset: ~35 instructions per slot) is done once per segment, a k tile inside a segment costs two scalar adds per
+            // DMA instruction -- a 1x1 convolution is ONE segment per source.  (Before: ~95 instructions per k tile around 4 MFMAs; with
+            // every load redirected to the zero page and the MFMAs removed the kernel took as long as with them: it was issue-bound.)
+            const bool past = KPB > 0 && kt >= kt1;        // a k tile behind this workgroup's k range (stage padding): all-zero operands
+            if (seg_left == 0) {
+                const int kr = (s_tap * invS) >> 16;
+                const int ks = s_tap - kr * S;
+                const bool s0 = s_c0 < in0_C;
+                const char* base = s0 ? in0 : in1;
+                const int cs = s0 ? in0_cs : in1_cs;
+                const int ups = s0 ? in0_ups : in1_ups;
+                const int Hp = s0 ? in0_H : in1_H;
+                const int Wp = s0 ? in0_W : in1_W;
+                const bool zs = s0 && a.in0_zs;
+                const int c_in_src = s0 ? s_c0 : s_c0 - in0_C;
+                seg_zoff = s0 ? in0_zoff : in1_zoff;
+                seg_left = ((s0 ? in0_C : Cin - in0_C) - c_in_src) / BK;
+                seg_base = base + (size_t)((s0 ? in0_co : in1_co) + c_in_src) * EB;
+                const int csb = cs * EB;
+                const unsigned lanec = (unsigned)jl * 16u;
 #pragma unroll
-            for (int i = 0; i < NLA; ++i) {
-                const int hi = hi0[i] + kr, wi = wi0[i] + ks;
-                const bool ok = (unsigned)hi < (unsigned)Hi && (unsigned)wi < (unsigned)Wi && !(zs && ((hi | wi) & 1));
-                const int pix = (bb[i] * Hp + (hi >> ups)) * Wp + (wi >> ups);
-                const unsigned off = (unsigned)(pix * csb + cbyte) + lanec;
-                yp_glds16_s(base, ok ? off : zoff, sbase + (wave_u + 4 * i) * 1024);
+                for (int i = 0; i < NLA; ++i) {
+                    const int hi = hi0[i] + kr, wi = wi0[i] + ks;
+                    const bool ok = (unsigned)hi < (unsigned)Hi && (unsigned)wi < (unsigned)Wi && !(zs && ((hi | wi) & 1));
+                    const int pix = (bb[i] * Hp + (hi >> ups)) * Wp + (wi >> ups);
+                    // (an out-of-image lane reads seg_base + zoff: the channel position moves it at most one pixel of channels into the
+                    // buffer's zero tail, which is one pixel + 64 elements long)
+                    seg_voff[i] = ok ? (unsigned)(pix * csb) + lanec : seg_zoff;
+                }
             }
-            const char* wk = wgt + (size_t)kt * (BK * EB);
+            const bool zero_pix = past;
+#ifndef YP_PROBE_NODMA
+            {
 #pragma unroll
-            for (int i = 0; i < NLB; ++i) yp_glds16_s(wk, b_off[i], sbase + b_slot[i] * 1024);
-            s_c0 += BK;
-            if (s_c0 >= Cin) { s_c0 -= Cin; ++s_tap; }
+            for (int i = 0; i < NLA; ++i) yp_glds16_s(seg_base, zero_pix ? seg_zoff : seg_voff[i], sbase + (wave_u + 4 * i) * 1024);
+            }
+#endif
+            const char* wk = past ? wgt : wgt + (size_t)kt * (BK * EB);
+#ifndef YP_PROBE_NODMA
+            {
+#pragma unroll
+            for (int i = 0; i < NLB; ++i) yp_glds16_s(wk, past ? a.wgt_zrow + (unsigned)jl * 16u : b_off[i], sbase + b_slot[i] * 1024);
+            }
+#endif
+            if (!past) {
+                seg_base += BK * EB;
+                --seg_left;
+                s_c0 += BK;
+                if (s_c0 >= Cin) { s_c0 -= Cin; ++s_tap; }
+            }
             return;
         }
         const int kr = tap / S;                       // generic path: any filter size (wgrad "filters" are Ho x Wo)
@@ -462,9 +530,136 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
 
     const int nk = kt1 - kt0;              // tiles are numbered relative to kt0 below; the filter offset uses kt0 + kt
     YP_TL(1);
+    if constexpr (WSK) {
+        constexpr int FNT = BN / 16, FMT = BM / 16;                // every wave multiplies the whole tile
+        constexpr int NLS = KP * NL;
+        static_assert(4 * FNT * FMT * 1024 <= NS * STAGE, "the partial tiles are summed through the pipeline LDS");
+        const int nks = (nk + KP - 1) / KP;
+        f32x4 pacc[FNT][FMT];
+#pragma unroll
+        for (int fa = 0; fa < FNT; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < FMT; ++fb) pacc[fa][fb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto issue_stage = [&](int ks) {
+            const unsigned base = (unsigned)(ks % NS) * STAGE;
+#pragma unroll
+            for (int j = 0; j < KP; ++j) issue_tile(kt0 + ks * KP + j, base + j * SUB);
+        };
+        const int ko = koff(0);
+        const int rd_p = p * ROWB + ko;
+#pragma unroll
+        for (int sidx = 0; sidx < NS - 1; ++sidx)
+            if (sidx < nks) issue_stage(sidx);
+        for (int ks = 0; ks < nks; ++ks) {
+            int younger = nks - 1 - ks;
+            if (younger > NS - 2) younger = NS - 2;
+            if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS > 3 ? 2 * NLS : NLS) : "memory");
+            static_assert(NS <= 4, "waves-split-k: rings of up to 4 stages");
+            __builtin_amdgcn_s_barrier();
+            if (ks < 20) YP_TL(2 + ks);
+            if (ks + NS - 1 < nks) issue_stage(ks + NS - 1);          // into the slot every wave finished reading before this barrier
+            const char* sub = smem + (ks % NS) * STAGE + wave_u * SUB + rd_p;
+            frag_t wf[FNT], xf[FMT];
+#pragma unroll
+            for (int fa = 0; fa < FNT; ++fa) wf[fa] = *reinterpret_cast<const frag_t*>(sub + (BM + fa * 16) * ROWB);
+#pragma unroll
+            for (int fb = 0; fb < FMT; ++fb) xf[fb] = *reinterpret_cast<const frag_t*>(sub + fb * 16 * ROWB);
+#pragma unroll
+            for (int fa = 0; fa < FNT; ++fa)
+#pragma unroll
+                for (int fb = 0; fb < FMT; ++fb) pacc[fa][fb] = E::mma(wf[fa], xf[fb], pacc[fa][fb]);
+        }
+        // ---- sum the four partial tiles: every wave parks its tile in LDS, wave (wm, wn) collects the fragments its epilogue owns
+        __syncthreads();
+        f32x4* red = reinterpret_cast<f32x4*>(smem);
+#pragma unroll
+        for (int fa = 0; fa < FNT; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < FMT; ++fb) red[((wave_u * FNT + fa) * FMT + fb) * 64 + lane] = pacc[fa][fb];
+        __syncthreads();
+#pragma unroll
+        for (int f = 0; f < FN; ++f)
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) {
+                const int fa = wn * FN + f, fb = wm * FM + fm;
+                f32x4 v = red[((0 * FNT + fa) * FMT + fb) * 64 + lane];
+#pragma unroll
+                for (int w = 1; w < 4; ++w) {
+                    const f32x4 u = red[((w * FNT + fa) * FMT + fb) * 64 + lane];
+                    v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
+                }
+                acc[f][fm] = v;
+            }
+        if constexpr (DETECT) __syncthreads();        // the Detect epilogue stages its tile in the same LDS
+    } else if constexpr (KPB > 0) {
+        // ---- second-generation loop.  Stage ks = k tiles [ks*KP, (ks+1)*KP) (zero tiles behind the end), ring slot ks % NS.
+        constexpr int NLS = KP * NL;                              // DMA instructions per wave per stage
+        const int nks = (nk + KP - 1) / KP;
+        auto issue_stage = [&](int ks) {
+            const unsigned base = (unsigned)(ks % NS) * STAGE;
+#pragma unroll
+            for (int j = 0; j < KP; ++j) issue_tile(kt0 + ks * KP + j, base + j * SUB);
+        };
+        auto wait_stages = [&](int younger) {                     // all but the `younger` most recent stages have landed
+            if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLS) : "memory");
+            else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS > 2 ? 2 * NLS : 0) : "memory");
+            else if (younger == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS > 3 ? 3 * NLS : 0) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS > 4 ? 4 * NLS : 0) : "memory");
+        };
+        static_assert(NS <= 6, "wait_stages covers rings of up to 6 stages");
+        const int ko = koff(0);
+        auto load_frags = [&](const char* sub, frag_t (&wf)[FN], frag_t (&xf)[FM]) {
+#pragma unroll
+            for (int f = 0; f < FN; ++f) wf[f] = *reinterpret_cast<const frag_t*>(sub + b_rd + f * 16 * ROWB + ko);
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) xf[fm] = *reinterpret_cast<const frag_t*>(sub + a_rd + fm * 16 * ROWB + ko);
+        };
+        auto mma_all = [&](const frag_t (&wf)[FN], const frag_t (&xf)[FM]) {
+#pragma unroll
+            for (int f = 0; f < FN; ++f)
+#pragma unroll
+                for (int fm = 0; fm < FM; ++fm) acc[f][fm] = E::mma(wf[f], xf[fm], acc[f][fm]);
+        };
+#pragma unroll
+        for (int sidx = 0; sidx < NS; ++sidx)
+            if (sidx < nks) issue_stage(sidx);
+        wait_stages((nks < NS ? nks : NS) - 1);
+        __builtin_amdgcn_s_barrier();
+        frag_t wfA[FN], xfA[FM], wfB[FN], xfB[FM];
+        load_frags(smem, wfA, xfA);
+        for (int ks = 0; ks < nks; ++ks) {
+            const char* st = smem + (ks % NS) * STAGE;
+            // the KP sub-tiles of this stage, fragments ping-ponging between the A and B register sets (KP is even or 1)
+#pragma unroll
+            for (int j = 0; j < KP; ++j) {
+                const bool cur_is_a = (j & 1) == 0;
+                auto step = [&](frag_t (&wc)[FN], frag_t (&xc)[FM], frag_t (&wn)[FN], frag_t (&xn)[FM]) {
+                    if (j + 1 < KP) {
+                        load_frags(st + (j + 1) * SUB, wn, xn);                 // same stage: landed and published at the last barrier
+                    } else if (ks + 1 < nks) {
+                        // stage boundary: stage ks+1 must have landed for every wave, and every wave must be done READING stage ks
+                        // (its last fragments are in registers: lgkmcnt(0)) before the slot is refilled
+                        int younger = nks - 2 - ks;
+                        if (younger > NS - 2) younger = NS - 2;
+                        wait_stages(younger);
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        if (ks < 20) YP_TL(2 + ks);
+                        load_frags(smem + ((ks + 1) % NS) * STAGE, wn, xn);
+                        if (ks + NS < nks) issue_stage(ks + NS);                 // into the slot of stage ks
+                    }
+                    mma_all(wc, xc);
+                };
+                if (cur_is_a) step(wfA, xfA, wfB, xfB); else step(wfB, xfB, wfA, xfA);
+            }
+        }
+    } else {
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
-        if (s < nk) issue_tile(kt0 + s, s);
+        if (s < nk) issue_tile(kt0 + s, s * STAGE);
 
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt must have landed; up to NS-2 younger tiles may stay in flight
@@ -477,11 +672,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
         else if (younger == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS > 5 ? 4 * NL : 0) : "memory");
         else if (younger == 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS > 6 ? 5 * NL : 0) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS > 7 ? 6 * NL : 0) : "memory");
+#ifndef YP_PROBE_NOBAR
         __builtin_amdgcn_s_barrier();
+#endif
         if (kt < 24) YP_TL(2 + kt);
         // every wave has finished reading tile kt-1: its stage can be refilled
-        if (kt + NS - 1 < nk) issue_tile(kt0 + kt + NS - 1, (kt + NS - 1) % NS);
+        if (kt + NS - 1 < nk) issue_tile(kt0 + kt + NS - 1, ((kt + NS - 1) % NS) * STAGE);
         const char* s = smem + (kt % NS) * STAGE;
+        if (probe_mode & 1) continue;
 #pragma unroll
         for (int kk = 0; kk < BK / E::KM; ++kk) {
             frag_t wf[FN], xf[FM];
@@ -495,6 +693,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
 #pragma unroll
                 for (int fm = 0; fm < FM; ++fm) acc[f][fm] = E::mma(wf[f], xf[fm], acc[f][fm]);
         }
+    }
     }
 
     YP_TL(40);
@@ -676,6 +875,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvKArgs a) {
     const unsigned ldsW = lds0 + hbufs * HBYTES;
 
     // ---- tile decode (channel tiles fastest: neighbours share the input halo in L2)
+    YP_TL_DECL;
     YP_TL(0);
     int bid = yp_xcd_remap(blockIdx.x, gridDim.x);
     const int tn = bid % a.tiles_n; bid /= a.tiles_n;
@@ -860,6 +1060,7 @@ __global__ __launch_bounds__(256) void bottleneck_halo_kernel(const ConvKArgs a)
     const unsigned ldsR = lds0 + RING;
     const unsigned ldsU = ldsR + RINGBYTES;
 
+    YP_TL_DECL;
     YP_TL(0);
     int bid = yp_xcd_remap(blockIdx.x, gridDim.x);
     const int tn = bid % a.tiles_n; bid /= a.tiles_n;
@@ -1328,16 +1529,18 @@ struct TileCfg { int id, bm, bn; };
 // (A 64 x 256 tile for the fused Detect convolution -- every channel of a pixel in one workgroup, so that an anchor's rows form
 // one contiguous 16-byte-aligned run per tile, written with 16-byte stores -- measured 62-87 us vs 43-47 us for the 64 x 32 / 64 x 64
 // tiles on the 80 x 80 level and was dropped.)
-constexpr TileCfg kTiles[] = {{1, 128, 32}, {2, 128, 64}, {3, 128, 128}, {4, 64, 64}, {5, 64, 32}
+constexpr TileCfg kTiles[] = {{1, 128, 32}, {2, 128, 64}, {3, 128, 128}, {4, 64, 64}, {5, 64, 32},
+                              {21, 128, 32}, {22, 128, 64}, {23, 128, 128}, {24, 64, 64}, {25, 64, 32}, {26, 64, 64}, {27, 128, 128},
+                              {31, 64, 64}, {33, 64, 32}
 #ifdef YP_TIMELINE
     , {6, 64, 64}, {7, 128, 128}, {8, 128, 64}      // probe build only: the same tiles with 8-stage rings
 #endif
 };
 
-template <int DT, bool OUT_F32, bool FAST, bool DETECT, int BM, int BN, int WAVES_M, int WAVES_N, int NS, bool STATS = false>
+template <int DT, bool OUT_F32, bool FAST, bool DETECT, int BM, int BN, int WAVES_M, int WAVES_N, int NS, bool STATS = false, int KPB = 0, bool WSK = false>
 hipError_t launch_tile(const ConvKArgs& a, int nblk, hipStream_t st) {
-    constexpr size_t lds = (size_t)NS * (BM / 16 + BN / 16) * 1024;
-    auto kern = conv_igemm_kernel<DT, OUT_F32, FAST, DETECT, BM, BN, WAVES_M, WAVES_N, NS, STATS>;
+    constexpr size_t lds = (size_t)NS * (KPB > 0 ? KPB : 1) * (BM / 16 + BN / 16) * 1024;
+    auto kern = conv_igemm_kernel<DT, OUT_F32, FAST, DETECT, BM, BN, WAVES_M, WAVES_N, NS, STATS, KPB, WSK>;
     if constexpr (lds > 65536) {
         static bool attr_set = false;        // per instantiation
         if (!attr_set) {
@@ -1352,12 +1555,25 @@ hipError_t launch_tile(const ConvKArgs& a, int nblk, hipStream_t st) {
 
 template <int DT, bool OUT_F32, bool FAST, bool DETECT = false, bool STATS = false>
 hipError_t launch_cfg(int tile, const ConvKArgs& a, int nblk, hipStream_t st) {
+    constexpr bool V2OK = FAST && DT != YP_F32 && !STATS;
     switch (tile) {
         case 1: return launch_tile<DT, OUT_F32, FAST, DETECT, 128, 32, 4, 1, 4, STATS>(a, nblk, st);
         case 2: return launch_tile<DT, OUT_F32, FAST, DETECT, 128, 64, 4, 1, 4, STATS>(a, nblk, st);
         case 3: return launch_tile<DT, OUT_F32, FAST, DETECT, 128, 128, 2, 2, 4, STATS>(a, nblk, st);
         case 4: return launch_tile<DT, OUT_F32, FAST, DETECT, 64, 64, 2, 2, 4, STATS>(a, nblk, st);
         case 5: return launch_tile<DT, OUT_F32, FAST, DETECT, 64, 32, 4, 1, 4, STATS>(a, nblk, st);
+        // second-generation main loop (ids 21..27: tiles as 1..5, KPB k tiles per barrier, register double-buffered fragments)
+        case 21: if constexpr (V2OK) return launch_tile<DT, OUT_F32, FAST, DETECT, 128, 32, 4, 1, 3, STATS, 2>(a, nblk, st); else return hipErrorInvalidValue;
+        case 22: if constexpr (V2OK) return launch_tile<DT, OUT_F32, FAST, DETECT, 128, 64, 4, 1, 3, STATS, 2>(a, nblk, st); else return hipErrorInvalidValue;
+        case 23: if constexpr (V2OK) return launch_tile<DT, OUT_F32, FAST, DETECT, 128, 128, 2, 2, 3, STATS, 2>(a, nblk, st); else return hipErrorInvalidValue;
+        case 24: if constexpr (V2OK) return launch_tile<DT, OUT_F32, FAST, DETECT, 64, 64, 2, 2, 3, STATS, 2>(a, nblk, st); else return hipErrorInvalidValue;
+        case 25: if constexpr (V2OK) return launch_tile<DT, OUT_F32, FAST, DETECT, 64, 32, 4, 1, 3, STATS, 2>(a, nblk, st); else return hipErrorInvalidValue;
+        case 26: if constexpr (V2OK) return launch_tile<DT, OUT_F32, FAST, DETECT, 64, 64, 2, 2, 3, STATS, 4>(a, nblk, st); else return hipErrorInvalidValue;
+        case 27: if constexpr (V2OK) return launch_tile<DT, OUT_F32, FAST, DETECT, 128, 128, 2, 2, 2, STATS, 4>(a, nblk, st); else return hipErrorInvalidValue;
+        // waves-split-k (ids 31..33): 64 x 64 / 128 x 64 / 64 x 32 tiles, each wave one k tile of a 4-tile stage against the whole tile
+        case 31: if constexpr (V2OK) return launch_tile<DT, OUT_F32, FAST, DETECT, 64, 64, 2, 2, 3, STATS, 4, true>(a, nblk, st); else return hipErrorInvalidValue;
+        // (a 128 x 64 tile -- 32 accumulator fragments per wave -- does not fit: the compiler runs out of scalar registers for the DMA operands)
+        case 33: if constexpr (V2OK) return launch_tile<DT, OUT_F32, FAST, DETECT, 64, 32, 4, 1, 4, STATS, 4, true>(a, nblk, st); else return hipErrorInvalidValue;
 #ifdef YP_TIMELINE
         case 6: if constexpr (!DETECT && !STATS && FAST) return launch_tile<DT, OUT_F32, FAST, DETECT, 64, 64, 2, 2, 8, STATS>(a, nblk, st); else return hipErrorInvalidValue;
         case 7: if constexpr (!DETECT && !STATS && FAST) return launch_tile<DT, OUT_F32, FAST, DETECT, 128, 128, 2, 2, 8, STATS>(a, nblk, st); else return hipErrorInvalidValue;
@@ -1496,11 +1712,7 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
     a.act = d->act; a.M = (int)Ml;
     a.dil_h = dil_h; a.dil_w = dil_w; a.in0_zs = d->in0_zero_stuffed ? 1 : 0; a.ksplit = ksplit; a.atomic_out = ksplit > 1 || d->atomic_accumulate;
 
-#ifdef YP_TIMELINE
-    int tile = (d->tile >= 1 && d->tile <= 8) ? d->tile : pick_tile(a.M, Cout);
-#else
-    int tile = (d->tile >= 1 && d->tile <= 5) ? d->tile : pick_tile(a.M, Cout);
-#endif
+    int tile = ((d->tile >= 1 && d->tile <= 8) || (d->tile >= 21 && d->tile <= 27) || (d->tile == 31 || d->tile == 33)) ? d->tile : pick_tile(a.M, Cout);
     const TileCfg* tc = nullptr;
     for (const auto& c : kTiles) if (c.id == tile) tc = &c;
     YP_REQUIRE(tc != nullptr, "yp_conv2d: unknown tile id %d", tile);
@@ -1573,8 +1785,7 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
         }
         return YP_OK;
     }
-    if (halo_ok && (d->tile == 0 || d->tile >= 10)) {
-        YP_REQUIRE(d->tile == 0 || d->tile <= 15, "yp_conv2d: unknown tile id %d", d->tile);
+    if (halo_ok && (d->tile == 0 || (d->tile >= 10 && d->tile <= 15))) {
         int bn = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128);
         const int tsel = d->tile >= 13 ? d->tile - 3 : d->tile;
         if (tsel == 10) bn = 32; else if (tsel == 11) bn = 64; else if (tsel == 12) bn = 128;
@@ -1592,7 +1803,7 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
         }
         return YP_OK;
     }
-    YP_REQUIRE(d->tile < 10, "yp_conv2d: tile %d (3x3 halo kernel) does not apply to this convolution", d->tile);
+    YP_REQUIRE(d->tile < 10 || d->tile > 15, "yp_conv2d: tile %d (3x3 halo kernel) does not apply to this convolution", d->tile);
     if (d->bn_partial != nullptr) {          // BatchNorm statistics in the epilogue (generic kernel, fast addressing, 16-bit or fp32 store)
         YP_REQUIRE(fast && !of32 && ksplit <= 1 && !a.atomic_out && d->bias == nullptr && d->act == YP_ACT_NONE && d->res.C == 0 && d->out2.C == 0,
                    "yp_conv2d: bn_partial needs the plain fast path (tail_zero, no bias / activation / residual / split / second output)");

@@ -141,10 +141,11 @@ class OpRecord:
 
 # conv signature -> fastest kernel/tile id, measured once per process (see PlanBuilder._autotune)
 _TUNE_CACHE = {}
-# candidate ids: 1..5 generic implicit-GEMM tiles (128x32, 128x64, 128x128, 64x64, 64x32); 10..12 the 3x3 halo kernel
+# candidate ids: 1..5 generic implicit-GEMM tiles (128x32, 128x64, 128x128, 64x64, 64x32), 21..27 the same tiles with the
+# second-generation main loop (several k tiles per barrier, register double-buffered fragments); 10..12 the 3x3 halo kernel
 # with 32/64/128 output channels per workgroup on 8x16 pixel tiles, 13..15 the same on 4x16 tiles (rejected by the library
 # when it does not apply)
-_TUNE_CANDIDATES = (1, 2, 3, 4, 5, 10, 11, 12, 13, 14, 15)
+_TUNE_CANDIDATES = (1, 2, 3, 4, 5, 21, 22, 23, 24, 25, 26, 27, 10, 11, 12, 13, 14, 15)
 
 
 class PlanBuilder:
@@ -459,7 +460,7 @@ class PlanBuilder:
             run = lambda: lib().yp_conv2d(C.byref(d), st)
         best, best_ms = 0, None
         for cand in _TUNE_CANDIDATES:
-            if det is not None and cand >= 10:
+            if det is not None and 10 <= cand <= 15:
                 continue
             d.tile = cand
             if run() != 0:
