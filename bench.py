@@ -68,7 +68,8 @@ def cpu_baseline(version, B, S, budget_s=14.0):
     from yolopoint_amd import models
     cores = os.cpu_count() or 1
     layout = layout_of(models.Model(names=NAMES80, version=version))
-    sd = net_oracle.synth_state_dict(layout, 1234)
+    from yolopoint_amd.utils.synthetic import GAIN
+    sd = net_oracle.synth_state_dict(layout, 1234, gain=GAIN.get(version, 1.6))
     Bc = min(B, 8)
     x = net_oracle.synth_image(Bc, 3, S, S, 1234)
     best_t, best_n = None, None

@@ -125,7 +125,15 @@ typedef struct YpConvDesc {
      * bn_partial[(rb*2 + 0)*C + c] and [(rb*2 + 1)*C + c], C = out.C, ceil(B*Ho*Wo / 64) row blocks; yp_bn_finalize folds them.
      * Needs tail_zero, a 16-bit or fp32 store of the same dtype, no bias / activation / residual / out2 / ksplit, tile 0..5. */
     float* bn_partial;
+    /* Deterministic split-K (ksplit > 1): when non-NULL, k slice y writes its partial output -- laid out like `out` -- to
+     * split_slabs + y * split_stride floats with plain stores, and the caller sums the slices in order (yp_sum_slabs); NULL: fp32 atomics
+     * into the zero-initialised `out` (order of arrival). */
+    float* split_slabs;
+    int64_t split_stride;
 } YpConvDesc;
+
+/* dst[i] = slabs[0][i] + slabs[1][i] + ... + slabs[n_slabs-1][i], summed in that order (the fold of a deterministic split-K). */
+int yp_sum_slabs(const float* slabs, float* dst, size_t elems, int n_slabs, void* stream);
 
 int yp_conv2d(const YpConvDesc* d, void* stream);
 
@@ -234,6 +242,14 @@ size_t yp_wgrad_group_entry_bytes(void);
 int yp_wgrad_group_pack(const YpView* xs, const YpView* dys, float* const* dws, int n, int dtype, int B, int k, int stride, void* table_host,
                         int* total_blocks);
 int yp_wgrad_group_run(const void* table_dev, int n, int total_blocks, int dtype, int k, int stride, void* stream);
+/* Deterministic variant: every pixel slice of an entry writes its own partial slab (plain stores, parts[i] = device buffer of
+ * yp_wgrad_partial_elems(...) floats, 16-byte aligned) and a second launch sums the slabs in slice order into dW -- bit-reproducible
+ * gradients, no floating-point atomics, dW needs no clearing.  pack_det also returns the fold launch size for run_det. */
+size_t yp_wgrad_partial_elems(YpView x, YpView dy, int dtype, int B, int k, int stride);
+int yp_wgrad_group_pack_det(const YpView* xs, const YpView* dys, float* const* dws, float* const* parts, int n, int dtype, int B, int k, int stride,
+                            void* table_host, int* total_blocks, int* fold_chunks);
+int yp_wgrad_group_run_det(const void* table_dev, int n, int total_blocks, int fold_chunks, int dtype, int k, int stride, void* stream);
+
 /* dw[ci][r][s][co] (fp32, Cout_pad channels per tap: the layout yp_conv_wgrad / the wgrad-as-convolution path produce)
  * -> grad[co][c0+ci][r][s] for ci < creal, co < Cout: the reference layout of conv.weight.grad */
 int yp_wgrad_unpack(const float* dw, float* grad, int Cout, int Cin, int k, int c0, int creal, int Cout_pad, void* stream);
@@ -344,7 +360,8 @@ enum {
     YP_OP_WGRAD_UNPACK = 28,  /* p0=dw [Cj][k][k][Cout_pad] fp32 -> g0=grad OIHW [Cout][Cin][k][k] fp32, input-channel slice [c0, c0+creal):
                                * i1=Cout i2=Cin i3=k i4=c0 i5=creal i6=Cout_pad */
     YP_OP_WGRAD_UNPACK_BATCH = 30, /* p0=device table of YpUnpackEntry; i1=entries i2=total tiles */
-    YP_OP_WGRAD_GROUP = 31,   /* p0=device table (yp_wgrad_group_pack); i0=dtype i1=entries i2=total blocks i3=k i4=stride */
+    YP_OP_SUM_SLABS = 32,     /* p0=slabs p1=dst; n0=elements per slab (multiple of 4) n1=slabs: dst = slab0 + slab1 + ... in order */
+    YP_OP_WGRAD_GROUP = 31,   /* p0=device table (yp_wgrad_group_pack[_det]); i0=dtype i1=entries i2=total blocks i3=k i4=stride i5=fold chunks (0: atomics) */
     YP_OP_PACK_WEIGHT = 26    /* f0=w f1=bias; g0=bias_dst; p0=dst; i0=dtype i1=Cout i2=Cin i3=R i4=S i5=c0 i6=Cj i7=mode; n0=Kpad n1=Npad | Cout_pad<<32 */
 };
 typedef struct YpOpArgs {

@@ -36,7 +36,7 @@ class YpConvDesc(C.Structure):
                 ("pre_weight", C.c_void_p), ("pre_bias", C.c_void_p), ("pre_Kpad", C.c_int32), ("pre_Npad", C.c_int32),
                 ("pre_act", C.c_int32), ("post_act", C.c_int32),
                 ("post_weight", C.c_void_p), ("post_bias", C.c_void_p), ("post_Kpad", C.c_int32), ("post_Npad", C.c_int32),
-                ("bn_partial", C.c_void_p)]
+                ("bn_partial", C.c_void_p), ("split_slabs", C.c_void_p), ("split_stride", C.c_int64)]
 
 
 class YpDetectDesc(C.Structure):
@@ -50,7 +50,8 @@ class YpOpArgs(C.Structure):
 
 
 (OP_BN_STATS, OP_BN_APPLY, OP_BN_BWD, OP_UPS2_BWD, OP_ADD_VIEWS, OP_MAXPOOL5_BWD, OP_L2NORM_BWD, OP_DETECT_BWD_PACK, OP_TO_CHWB,
- OP_COL_SUM, OP_MEMSET0, OP_PACK_NCHW, OP_L2NORM, OP_SPPF_POOL, OP_CAST_F32, OP_MAXPOOL2, OP_PACK_WEIGHT, OP_WGRAD, OP_WGRAD_UNPACK, OP_MAXPOOL2_BWD, OP_WGRAD_UNPACK_BATCH, OP_WGRAD_GROUP) = range(10, 32)
+ OP_COL_SUM, OP_MEMSET0, OP_PACK_NCHW, OP_L2NORM, OP_SPPF_POOL, OP_CAST_F32, OP_MAXPOOL2, OP_PACK_WEIGHT, OP_WGRAD, OP_WGRAD_UNPACK, OP_MAXPOOL2_BWD, OP_WGRAD_UNPACK_BATCH, OP_WGRAD_GROUP,
+ OP_SUM_SLABS) = range(10, 33)
 LANE_MAIN, LANE_SIDE, LANE_JOIN = 0, 1, 2
 
 _i, _f, _p, _sz, _i64 = C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_int64
@@ -62,6 +63,7 @@ SIGNATURES = {
     "yp_conv2d": (_i, [C.POINTER(YpConvDesc), _p]),
     "yp_conv2d_detect": (_i, [C.POINTER(YpConvDesc), C.POINTER(YpDetectDesc), _p]),
     "yp_conv_kpad": (_i, [_i, _i]),
+    "yp_sum_slabs": (_i, [_p, _p, _sz, _i, _p]),
     "yp_stem_conv": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _i, YpView, _i, _p]),
     "yp_pack_input": (_i, [_p, _i, _i, _i, _i, YpView, _i, _p]),
     "yp_unpack_nchw": (_i, [YpView, _i, _i, _i, _p, _p]),
@@ -87,6 +89,9 @@ SIGNATURES = {
     "yp_wgrad_group_entry_bytes": (_sz, []),
     "yp_wgrad_group_pack": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "yp_wgrad_group_run": (_i, [_p, _i, _i, _i, _i, _i, _p]),
+    "yp_wgrad_partial_elems": (_sz, [YpView, YpView, _i, _i, _i, _i]),
+    "yp_wgrad_group_pack_det": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "yp_wgrad_group_run_det": (_i, [_p, _i, _i, _i, _i, _i, _i, _p]),
     "yp_pack_weight_batch": (_i, [_p, _i, _i, _i, _p]),
     "yp_wgrad_unpack_batch": (_i, [_p, _i, _i, _p]),
     "yp_infonce_fwd": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _p, _p]),

@@ -100,6 +100,8 @@ struct ConvKArgs {
     int dil_h, dil_w;              // filter dilation (wgrad-as-convolution of a strided conv)
     int in0_zs;                    // in0 is a zero-stuffed view: logical (2H x 2W), odd rows/cols are zero (dgrad of stride 2)
     int ksplit, atomic_out;        // split-K over blockIdx.y with fp32 atomicAdd epilogue
+    float* split_slabs;            // ... or (non-null) a plain fp32 store of slice y's partial tile to split_slabs + y * split_stride
+    long split_stride;
     unsigned in0_zoff, in1_zoff, wgt_zrow;   // FAST path: byte offsets of the 16 zero bytes behind each input / the zero filter row
     int act;
     int M, tiles_n;
@@ -703,7 +705,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
         const int m = m0 + wm * TM + fm * 16 + p;
         if (m >= a.M) continue;
         if constexpr (!DETECT) {
-            if (a.atomic_out) {          // split-K partial sums (wgrad): fp32 atomics into a zero-initialised buffer
+            if (a.split_slabs != nullptr) {   // deterministic split-K: this k slice's own slab, summed in slice order by yp_sum_slabs
+                float* slab = a.split_slabs + (size_t)blockIdx.y * a.split_stride;
+#pragma unroll
+                for (int j = 0; j < LPG; ++j)
+                    if (nb + j < a.Cout) slab[(size_t)m * a.out_cs + a.out_co + nb + j] = acc[j >> 2][fm][j & 3];
+            } else if (a.atomic_out) {   // split-K partial sums (wgrad): fp32 atomics into a zero-initialised buffer
 #pragma unroll
                 for (int j = 0; j < LPG; ++j)
                     if (nb + j < a.Cout) atomicAdd(reinterpret_cast<float*>(a.out) + (size_t)m * a.out_cs + a.out_co + nb + j, acc[j >> 2][fm][j & 3]);
@@ -1711,6 +1718,8 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
     a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w;
     a.act = d->act; a.M = (int)Ml;
     a.dil_h = dil_h; a.dil_w = dil_w; a.in0_zs = d->in0_zero_stuffed ? 1 : 0; a.ksplit = ksplit; a.atomic_out = ksplit > 1 || d->atomic_accumulate;
+    a.split_slabs = ksplit > 1 ? d->split_slabs : nullptr; a.split_stride = d->split_stride;
+    YP_REQUIRE(a.split_slabs == nullptr || (d->split_stride >= (int64_t)Ml * d->out.cstride && !d->atomic_accumulate), "yp_conv2d: split_stride must cover one partial output");
 
     int tile = ((d->tile >= 1 && d->tile <= 8) || (d->tile >= 21 && d->tile <= 27) || (d->tile == 31 || d->tile == 33)) ? d->tile : pick_tile(a.M, Cout);
     const TileCfg* tc = nullptr;

@@ -1017,6 +1017,26 @@ __global__ void zero_fill_kernel(f32x4* __restrict__ p, size_t n16) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
+namespace {
+__global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ dst, size_t elems, int n) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= elems) return;
+    float4 v = *reinterpret_cast<const float4*>(slabs + i);
+    for (int s = 1; s < n; ++s) {
+        const float4 u = *reinterpret_cast<const float4*>(slabs + (size_t)s * elems + i);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    *reinterpret_cast<float4*>(dst + i) = v;
+}
+}  // namespace
+
+extern "C" int yp_sum_slabs(const float* slabs, float* dst, size_t elems, int n_slabs, void* stream) {
+    YP_REQUIRE(slabs && dst && elems > 0 && elems % 4 == 0 && n_slabs > 0 && ((uintptr_t)slabs & 15) == 0 && ((uintptr_t)dst & 15) == 0, "yp_sum_slabs: bad arguments");
+    sum_slabs_kernel<<<(unsigned)((elems / 4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(slabs, dst, elems, n_slabs);
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
 extern "C" int yp_run_op(const YpOpArgs* a, void* stream) {
     YP_REQUIRE(a != nullptr, "yp_run_op: null args");
     const int dt = a->i[0], B = a->i[1];
@@ -1052,7 +1072,8 @@ extern "C" int yp_run_op(const YpOpArgs* a, void* stream) {
         case YP_OP_MAXPOOL2_BWD: return yp_maxpool2_bwd(a->v[0], a->v[1], a->v[2], dt, B, a->i[2], stream);
         case YP_OP_WGRAD_UNPACK: return yp_wgrad_unpack((const float*)a->p[0], a->g[0], a->i[1], a->i[2], a->i[3], a->i[4], a->i[5], a->i[6], stream);
         case YP_OP_WGRAD_UNPACK_BATCH: return yp_wgrad_unpack_batch((const YpUnpackEntry*)a->p[0], a->i[1], a->i[2], stream);
-        case YP_OP_WGRAD_GROUP: return yp_wgrad_group_run(a->p[0], a->i[1], a->i[2], dt, a->i[3], a->i[4], stream);
+        case YP_OP_SUM_SLABS: return yp_sum_slabs((const float*)a->p[0], (float*)a->p[1], a->n[0], (int)a->n[1], stream);
+        case YP_OP_WGRAD_GROUP: return yp_wgrad_group_run_det(a->p[0], a->i[1], a->i[2], a->i[5], dt, a->i[3], a->i[4], stream);
         case YP_OP_WGRAD: return yp_conv_wgrad(a->v[0], a->v[1], dt, B, a->i[2], a->i[3] > 0 ? a->i[3] : 1, (float*)a->p[0], stream);
         case YP_OP_PACK_WEIGHT:
             return yp_pack_weight(a->f[0], a->i[1], a->i[2], a->i[3], a->i[4], a->i[5], a->i[6], a->i[7], (int)(a->n[1] >> 32), a->p[0], (int)a->n[0],

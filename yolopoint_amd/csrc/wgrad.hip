@@ -39,6 +39,8 @@ struct WgradArgs {
     int tiles_x, tiles_y, ntiles, M;
     int skip_store;                        // probe only (YP_WG_NOSTORE): time the reduction without the final atomics
     int g_blk0, g_nblk, g_split;           // grouped launch: first flat workgroup of this entry, its (ci x co) blocks and pixel split
+    float* part;                           // deterministic mode: partial slabs [g_split][Cj][taps][Cout_pad] (plain stores, folded in order by
+    int f_chunk0, f_chunks;                // wgrad_fold_kernel: this entry's first 1024-element chunk and chunk count); nullptr: fp32 atomics into dw
 };
 
 __device__ __forceinline__ void wg_glds16(const void* gsrc, unsigned lds_dst) {
@@ -196,7 +198,28 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bx, con
         __builtin_amdgcn_s_barrier();                      // everyone is done reading this stage before it is refilled
     }
 
-    // ---- partial sums -> dW[ci][r][s][co] (fp32 atomics); accumulator lane (p, g): rows (ci) 4g..4g+3, column (co) p
+    // ---- partial sums -> dW[ci][r][s][co]; accumulator lane (p, g): rows (ci) 4g..4g+3, column (co) p.
+    // Deterministic mode: this pixel slice's own slab, plain stores (every element of a slab has exactly one writer); the slabs are summed
+    // in slice order by wgrad_fold_kernel.  Otherwise fp32 atomics into the zero-initialised dW (order of arrival: run-to-run differences
+    // at the 1e-4 level in 16-bit training).
+    if (a.part != nullptr) {
+        float* slab = a.part + (size_t)first * a.Cj * TAPS * a.Cout_pad;
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+            for (int fa = 0; fa < 2; ++fa)
+#pragma unroll
+                for (int fb = 0; fb < 2; ++fb) {
+                    const int co = co0 + (wco * 2 + fb) * 16 + li;
+                    if (co >= a.Cout_pad) continue;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int ci = ci0 + (wci * 2 + fa) * 16 + 4 * g + jj;
+                        if (ci < a.Cj) slab[((size_t)ci * TAPS + tp) * a.Cout_pad + co] = acc[tp][fa][fb][jj];
+                    }
+                }
+        return;
+    }
 #pragma unroll
     for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
@@ -232,6 +255,26 @@ __global__ __launch_bounds__(256) void wgrad_group_kernel(const WgradArgs* __res
     const WgradArgs a = table[e];
     const int local = bid - a.g_blk0;
     wgrad_body<DT, TAPS, ST>(a, local % a.g_nblk, local / a.g_nblk, a.g_split);
+}
+
+// dW = slab[0] + slab[1] + ... + slab[split-1], in that order, for every entry of a grouped launch (1024 elements per workgroup).
+__global__ __launch_bounds__(256) void wgrad_fold_kernel(const WgradArgs* __restrict__ table, int n_entries, int taps) {
+    const int bid = blockIdx.x;
+    int e = 0;
+    for (int lo = 0, hi = n_entries - 1; lo <= hi;) {
+        const int mid = (lo + hi) >> 1;
+        if (table[mid].f_chunk0 <= bid) { e = mid; lo = mid + 1; } else hi = mid - 1;
+    }
+    const WgradArgs a = table[e];
+    const size_t n = (size_t)a.Cj * taps * a.Cout_pad;            // (a multiple of 8: Cout_pad is)
+    const size_t i = ((size_t)(bid - a.f_chunk0) * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    f32x4 v = *reinterpret_cast<const f32x4*>(a.part + i);
+    for (int s = 1; s < a.g_split; ++s) {
+        const f32x4 u = *reinterpret_cast<const f32x4*>(a.part + (size_t)s * n + i);
+        v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
+    }
+    *reinterpret_cast<f32x4*>(a.dw + i) = v;
 }
 
 template <int DT, int TAPS, int ST>
@@ -313,16 +356,37 @@ extern "C" size_t yp_wgrad_group_entry_bytes(void) { return sizeof(WgradArgs); }
 
 extern "C" int yp_wgrad_group_pack(const YpView* xs, const YpView* dys, float* const* dws, int n, int dtype, int B, int k, int stride, void* table_host,
                                    int* total_blocks) {
-    YP_REQUIRE(xs && dys && dws && table_host && total_blocks && n > 0, "yp_wgrad_group_pack: bad arguments");
+    return yp_wgrad_group_pack_det(xs, dys, dws, nullptr, n, dtype, B, k, stride, table_host, total_blocks, nullptr);
+}
+
+extern "C" size_t yp_wgrad_partial_elems(YpView x, YpView dy, int dtype, int B, int k, int stride) {
+    WgradArgs a;
+    int nblk, split;
+    float dummy;
+    if (wgrad_make_args(x, dy, dtype, B, k, stride, &dummy, &a, &nblk, &split) != YP_OK) return 0;
+    return (size_t)split * a.Cj * (k * k) * a.Cout_pad;
+}
+
+extern "C" int yp_wgrad_group_pack_det(const YpView* xs, const YpView* dys, float* const* dws, float* const* parts, int n, int dtype, int B, int k, int stride,
+                                       void* table_host, int* total_blocks, int* fold_chunks) {
+    YP_REQUIRE(xs && dys && dws && table_host && total_blocks && n > 0 && (parts == nullptr || fold_chunks != nullptr), "yp_wgrad_group_pack: bad arguments");
     WgradArgs* t = (WgradArgs*)table_host;
-    int blk0 = 0;
+    int blk0 = 0, chunk0 = 0;
     for (int i = 0; i < n; ++i) {
         int nblk, split;
         if (int rc = wgrad_make_args(xs[i], dys[i], dtype, B, k, stride, dws[i], &t[i], &nblk, &split)) return rc;
         t[i].g_blk0 = blk0;
         blk0 += nblk * split;
+        if (parts != nullptr) {
+            YP_REQUIRE(parts[i] != nullptr && ((uintptr_t)parts[i] & 15) == 0 && ((uintptr_t)dws[i] & 15) == 0, "yp_wgrad_group_pack_det: slabs / dW must be 16-byte aligned");
+            t[i].part = parts[i];
+            t[i].f_chunk0 = chunk0;
+            t[i].f_chunks = yp_cdiv(t[i].Cj * k * k * t[i].Cout_pad, 1024);
+            chunk0 += t[i].f_chunks;
+        }
     }
     *total_blocks = blk0;
+    if (fold_chunks) *fold_chunks = chunk0;
     return YP_OK;
 }
 
@@ -345,7 +409,11 @@ static hipError_t launch_wgrad_group(const WgradArgs* table, int n, int blocks, 
 }
 
 extern "C" int yp_wgrad_group_run(const void* table_dev, int n, int total_blocks, int dtype, int k, int stride, void* stream) {
-    YP_REQUIRE(table_dev && n > 0 && total_blocks > 0 && (dtype == YP_F16 || dtype == YP_BF16), "yp_wgrad_group_run: bad arguments");
+    return yp_wgrad_group_run_det(table_dev, n, total_blocks, 0, dtype, k, stride, stream);
+}
+
+extern "C" int yp_wgrad_group_run_det(const void* table_dev, int n, int total_blocks, int fold_chunks, int dtype, int k, int stride, void* stream) {
+    YP_REQUIRE(table_dev && n > 0 && total_blocks > 0 && fold_chunks >= 0 && (dtype == YP_F16 || dtype == YP_BF16), "yp_wgrad_group_run: bad arguments");
     YP_REQUIRE((k == 1 && stride == 1) || (k == 3 && (stride == 1 || stride == 2)), "yp_wgrad_group_run: 1x1 (stride 1) or 3x3 (stride 1 | 2)");
     const WgradArgs* t = (const WgradArgs*)table_dev;
     hipStream_t st = (hipStream_t)stream;
@@ -354,5 +422,9 @@ extern "C" int yp_wgrad_group_run(const void* table_dev, int n, int total_blocks
     e = dtype == YP_F16 ? YP_G(YP_F16) : YP_G(YP_BF16);
 #undef YP_G
     if (e != hipSuccess) { yp_set_error("yp_wgrad_group_run: launch failed: %s", hipGetErrorString(e)); return YP_ERR_HIP; }
+    if (fold_chunks > 0) {           // deterministic mode: sum the slices' slabs in order
+        wgrad_fold_kernel<<<fold_chunks, 256, 0, st>>>(t, n, k * k);
+        YP_CHECK_HIP(hipGetLastError());
+    }
     return YP_OK;
 }

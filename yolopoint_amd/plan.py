@@ -336,6 +336,10 @@ class PlanBuilder:
         d.dil_h = d.dil_w = dil
         d.in0_zero_stuffed = int(zs)
         d.ksplit = int(extra.get("ksplit", 1))
+        slabs = extra.get("split_slabs")            # deterministic split-K: (tensor, stride in floats)
+        if slabs is not None:
+            d.split_slabs, d.split_stride = slabs[0].data_ptr(), int(slabs[1])
+            self.keep.append(slabs[0])
         d.atomic_accumulate = int(extra.get("atomic", 0))
         d.Kpad, d.Npad, d.act, d.tile, d.tail_zero = Kpad, Npad, act, tile, 1
         bn_partial = extra.get("bn_partial")        # fp32 [ceil(M/64)][2][Cout_pad]: BatchNorm column sums written by the epilogue

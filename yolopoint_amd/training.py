@@ -65,6 +65,9 @@ class TrainGraph:
         self.group_wgrad = not self.lanes and os.environ.get("YP_WGRAD_GROUP", "1") != "0"
         self.dw_arena = torch.zeros(round_up(2 * sum(p_.numel() for p_ in net.parameters()) + (1 << 20), 64), dtype=torch.float32, device=device)
         self.dw_used = 0
+        # YP_WGRAD_DET=0: fp32 atomics instead of per-slice slabs + ordered fold (not bit-reproducible)
+        self.det_wgrad = self.group_wgrad and os.environ.get("YP_WGRAD_DET", "1") != "0"
+        self.wpart = None
         self._build()
 
     # ------------------------------------------------------------------ helpers
@@ -237,9 +240,18 @@ class TrainGraph:
                 blocks = -(-(Cj * k * k) // 64) * -(-Cout_pad // 64)
                 nk = K // (16 if code == _hip.YP_F32 else 32)
                 ksplit = max(1, min(-(-1024 // blocks), max(1, nk // 8), 2048))
-                b.conv([xp.view()], None, None, 0, 1, p, _hip.YP_ACT_NONE, out=dwb.view(), out_f32=True,
-                       extra=dict(raw_weight=(dyp, K, Cout_pad), cout=Cout_pad, kernel_hw=(Ho, Wo), dil=s, out_hw=(k, k), ksplit=ksplit,
-                                  atomic=1, batch=Cj, weight_view=self.T(dyp)))
+                if self.det_wgrad and ksplit > 1:
+                    # deterministic split-K: one slab per k slice (plain stores), summed in slice order (the atomics of the default
+                    # epilogue made the stem's weight gradient the one tensor that differed between two identical passes)
+                    slabs = torch.empty((ksplit, ndw), dtype=torch.float32, device=self.device)
+                    b.conv([xp.view()], None, None, 0, 1, p, _hip.YP_ACT_NONE, out=dwb.view(), out_f32=True,
+                           extra=dict(raw_weight=(dyp, K, Cout_pad), cout=Cout_pad, kernel_hw=(Ho, Wo), dil=s, out_hw=(k, k), ksplit=ksplit,
+                                      batch=Cj, weight_view=self.T(dyp), split_slabs=(slabs, ndw)))
+                    b.op(_hip.OP_SUM_SLABS, [dwb.view()], [dwb.view()], "dw_fold", p=[slabs, dwb.flat], n=[ndw, ksplit])
+                else:
+                    b.conv([xp.view()], None, None, 0, 1, p, _hip.YP_ACT_NONE, out=dwb.view(), out_f32=True,
+                           extra=dict(raw_weight=(dyp, K, Cout_pad), cout=Cout_pad, kernel_hw=(Ho, Wo), dil=s, out_hw=(k, k), ksplit=ksplit,
+                                      atomic=1, batch=Cj, weight_view=self.T(dyp)))
             creal = weight.shape[1] - c0 if image else Cj
             # (dw -> OIHW gradient: all of a backward pass's transposes run as ONE launch at the end of the plan, see emit())
             self.unpack.append(dict(dw=dwb, grad=gw, rows=creal * k * k, cout=Cout, cout_pad=Cout_pad, out_stride=weight.shape[1] * k * k,
@@ -443,12 +455,24 @@ class TrainGraph:
                 xs, dys = (_hip.YpView * n)(*[e[0].c() for e in ents]), (_hip.YpView * n)(*[e[1].c() for e in ents])
                 dws = (C.c_void_p * n)(*[e[2].flat.data_ptr() for e in ents])
                 host = (C.c_char * (n * lib().yp_wgrad_group_entry_bytes()))()
-                blocks = C.c_int(0)
-                check(lib().yp_wgrad_group_pack(xs, dys, dws, n, code, B, gk, gs, host, C.byref(blocks)))
+                blocks, fold = C.c_int(0), C.c_int(0)
+                if self.det_wgrad:
+                    # deterministic reduction: every pixel slice of an entry writes its own slab, a second launch sums them in order.
+                    # The slab arena is shared by the filter classes of all backward plans of this graph (they run one after another).
+                    sizes = [round_up(lib().yp_wgrad_partial_elems(e[0].c(), e[1].c(), code, B, gk, gs), 64) for e in ents]
+                    if self.wpart is None:      # sized by the largest filter class of the FULL backward (emitted first; the keypoint-only plan is a subset)
+                        self.wpart = torch.empty(max(sum(round_up(lib().yp_wgrad_partial_elems(e[0].c(), e[1].c(), code, B, k_, s_), 64) for e in es)
+                                                     for (k_, s_), es in self.wgroups.items()), dtype=torch.float32, device=self.device)
+                    assert sum(sizes) <= self.wpart.numel()
+                    offs = [sum(sizes[:i]) for i in range(n)]
+                    parts = (C.c_void_p * n)(*[self.wpart.data_ptr() + 4 * o for o in offs])
+                    check(lib().yp_wgrad_group_pack_det(xs, dys, dws, parts, n, code, B, gk, gs, host, C.byref(blocks), C.byref(fold)))
+                else:
+                    check(lib().yp_wgrad_group_pack(xs, dys, dws, n, code, B, gk, gs, host, C.byref(blocks)))
                 wtab = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(self.device)
                 self.keep.append(wtab)
                 bb.op(_hip.OP_WGRAD_GROUP, [v for e in ents for v in e[:2]], [e[2].view() for e in ents], f"wgrad_k{gk}s{gs}", p=[wtab],
-                      i=[code, n, blocks.value, gk, gs])
+                      i=[code, n, blocks.value, gk, gs, fold.value])
                 bb.records[-1].kind, bb.records[-1].flops = "conv", sum(e[3] for e in ents)
             rows, tile0 = [], 0
             for u in self.unpack:

@@ -18,7 +18,13 @@ def layout_of(model):
 # ---------------------------------------------------------------------------------------------
 # deterministic synthetic weights (numpy PCG64 streams: identical here and on the GPU box)
 # ---------------------------------------------------------------------------------------------
-def synth_state_dict(layout, seed):
+# He-style gain of the synthetic conv weights per model size: 1.6 keeps the activations of the 25-layer-deep -n / -s O(1..40); the same
+# gain compounds to 1e6 (-m) and 3e10 (-l) through their deeper C3 stacks -- beyond f16 -- so the deeper members get a smaller one
+# (head logits O(1..500) at 640x640).  The golden vectors (-n / -s) use the default.
+GAIN = {"n": 1.6, "s": 1.6, "m": 1.42, "l": 1.35, "x": 1.3}
+
+
+def synth_state_dict(layout, seed, gain=1.6):
     """layout: list of (key, shape) in reference state_dict order -> fp32 tensors.  BN affine /
     running statistics are randomised so that BN folding is exercised."""
     sd = {}
@@ -42,7 +48,7 @@ def synth_state_dict(layout, seed):
             v = rng.normal(0.0, 0.1, shape)
         else:   # conv weight OIHW: He-style scale keeps activations O(1) through ~30 layers
             fan_in = shape[1] * shape[2] * shape[3]
-            v = rng.normal(0.0, 1.0, shape) * (1.6 / math.sqrt(fan_in))
+            v = rng.normal(0.0, 1.0, shape) * (gain / math.sqrt(fan_in))
         sd[key] = torch.from_numpy(np.asarray(v, dtype=np.float32).reshape(shape))
     return sd
 
@@ -55,7 +61,7 @@ def make_model(version, seed, names=NAMES80, dtype="f32", model_name="YOLOPoint"
     """Product model + the synthetic reference-layout state_dict loaded into it."""
     from .. import models
     m = models.Model(names=names, model_name=model_name, version=version)
-    sd = synth_state_dict(layout_of(m), seed)
+    sd = synth_state_dict(layout_of(m), seed, gain=GAIN.get(version, 1.6))
     m.load_state_dict(sd, strict=True)
     m.set_compute_dtype(dtype)
     return m.eval(), sd
