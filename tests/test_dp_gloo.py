@@ -83,3 +83,112 @@ def test_gradient_allreduce_two_ranks():
     assert a["rm"][0] == 0.0 and b["rm"][0] == 1.0                             # per-rank BN statistics
     assert a["shard"] == (0, 32) and b["shard"] == (32, 64)
     assert abs(a["dt"] - b["dt"]) < 1e-9 and a["dt"] >= 0.06 - 1e-3            # max over ranks: rank 1's 3 x 20 ms
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The overlapped schedule on the REAL model's parameters (world 2 and 4): which buckets are launched when, accumulation / no_sync,
+# and data-parallel step == single-process step on the concatenated batch with per-rank BatchNorm statistics.
+# The network itself has no CPU path, so the per-rank compute is the oracle's forward + PyTorch autograd (test infrastructure)
+# -- what is under test is the product's bucket plan (training.grad_ready_groups) and reducer (dp.GradAllReducer).
+# ---------------------------------------------------------------------------------------------------------------------------
+def _schedule_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import NAMES80, layout_of
+    from oracle import net_oracle
+    from yolopoint_amd import models
+    from yolopoint_amd.dp import GradAllReducer, shard_batch
+    from yolopoint_amd.training import grad_ready_groups, KP_BRANCH_MODULES
+    torch.set_num_threads(2)
+    model = models.Model(names=NAMES80, version="n")
+    sd = net_oracle.synth_state_dict(layout_of(model), 5)
+    model.load_state_dict(sd)
+    net = model.model
+    groups = grad_ready_groups(net)
+    red = GradAllReducer(None, groups=groups)
+    kp = set(id(p) for p in groups[1][1])
+    red.set_expected({p: (2 if id(p) in kp else 1) for p in red.params})
+    names = {id(p): n for n, p in net.named_parameters()}
+    out = {"nbuckets": len(red.buckets), "groups": red.bucket_group,
+           "kp_ok": all(names[id(p)].split(".")[0] in KP_BRANCH_MODULES for p in groups[1][1]) and
+                    not any(names[id(p)].split(".")[0] in KP_BRANCH_MODULES for p in groups[0][1]),
+           "covers_all": sorted(id(p) for p in red.params) == sorted(id(p) for p in net.parameters())}
+
+    # ---- real gradients: this rank's shard of a global batch through the oracle (per-rank batch statistics)
+    Bg, S = 2 * world, 64
+    x = net_oracle.synth_image(Bg, 3, S, S, 11)
+
+    def grads_of(xs):
+        leaf = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in sd.items()}
+        o = net_oracle.yolopoint_forward(leaf, xs, "n", training=True, stats={})
+        ow = net_oracle.yolopoint_forward(leaf, xs.flip(-1), "n", training=True, stats={})
+        full = torch.autograd.grad(o["semi"].square().mean() + o["desc"][:, :4].sum() + sum(t.tanh().mean() for t in o["objects"]),
+                                   [leaf["model." + names[id(p)]] for p in red.params], allow_unused=True, retain_graph=False)
+        kpar = [p for p in red.params if id(p) in kp]
+        part = torch.autograd.grad(ow["semi"].square().mean() + ow["desc"][:, :4].sum(), [leaf["model." + names[id(p)]] for p in kpar])
+        return full, dict(zip((id(p) for p in kpar), part))
+    lo, hi = shard_batch(Bg, rank, world)
+    full, part = grads_of(x[lo:hi])
+
+    # ---- one optimizer step = 2 micro-batches (gradient accumulation): no collective on the first, overlapped launch on the second
+    log = []
+    for micro in range(2):
+        red.bind_grads(zero=(micro == 0))
+        ctx = red.no_sync() if micro == 0 else __import__("contextlib").nullcontext()
+        with ctx:
+            red.begin()
+            for p, g in zip(red.params, full):                     # "full backward": every parameter
+                p.grad += g * 0.5
+            red.notify(red.params)
+            after_full = list(red.launch_log)
+            for p in red.params:                                   # "keypoint-only backward": the trunk and the keypoint / descriptor heads
+                if id(p) in kp:
+                    p.grad += part[id(p)] * 0.5
+            red.notify([p for p in red.params if id(p) in kp])
+            log.append((after_full, list(red.launch_log)))
+    red.finish()
+    out["log"] = log
+    # expected: the mean over ranks of (full + part) -- every rank recomputes all shards (single-process reference, per-shard BN)
+    worst = 0.0
+    acc = None
+    for r in range(world):
+        a, b = shard_batch(Bg, r, world)
+        f, pt = grads_of(x[a:b])
+        tot = [fg + (pt[id(p)] if id(p) in pt else 0) for p, fg in zip(red.params, f)]
+        acc = tot if acc is None else [u + v for u, v in zip(acc, tot)]
+    for p, e in zip(red.params, acc):
+        e = e / world
+        worst = max(worst, float((p.grad - e).norm() / e.norm().clamp_min(1e-20)))
+    out["worst_rel"] = worst
+    out["grad0"] = float(red.params[0].grad.flatten()[0])
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_overlapped_bucket_schedule_and_dp_equivalence(world):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_schedule_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    r0 = res[0]
+    assert r0["nbuckets"] >= 3 and r0["kp_ok"] and r0["covers_all"]
+    det = [i for i, g in enumerate(r0["groups"]) if g == "detector"]
+    kpb = [i for i, g in enumerate(r0["groups"]) if g == "keypoint"]
+    assert det and kpb and max(det) < min(kpb)                         # detector buckets first: they are final after the full backward
+    for r in res.values():
+        (f0, a0), (f1, a1) = r["log"]
+        assert f0 == [] and a0 == []                                    # first micro-batch: inside no_sync, nothing is launched
+        assert f1 == det                                                # after the full backward: exactly the detector buckets, in order
+        assert a1 == det + kpb                                          # the keypoint buckets follow the second pass
+        assert r["worst_rel"] < 1e-5, r["worst_rel"]                    # == single-process gradients of the concatenated batch (per-shard BN)
+    assert len({round(r["grad0"], 9) for r in res.values()}) == 1       # every rank ends with the same gradients

@@ -384,3 +384,62 @@ def test_backward_matches_reference_golden(cuda, tag, version, B, S, seed):
     loss.backward()
     worst = max(check_grad_sketch(Gb, tag, n, p.grad, 2e-3) for n, p in m.named_parameters())
     print(tag, "worst normalised deviation from the reference gradients:", worst)
+
+
+def test_bucket_plan_matches_the_backward_plans(cuda):
+    """training.grad_ready_groups (a pure walk over the module names, what the CPU gloo tests use) names exactly the parameters the
+    keypoint-only backward plan of a real TrainGraph reaches."""
+    from yolopoint_amd.training import grad_ready_groups
+    for name in ("YOLOPoint", "YOLOPointv52"):
+        m, _ = make_model("n", 3, dtype="bf16", model_name=name)
+        m = m.to(cuda).train()
+        x = net_oracle.synth_image(2, 3, 64, 64, 3).to(cuda)
+        _, _, graph = m.model.forward_with_graph(x)
+        groups = dict(grad_ready_groups(m.model))
+        assert set(id(p) for p in groups["keypoint"]) == set(id(p) for p in graph.bwd_kp_params), name
+        assert set(id(p) for p in groups["keypoint"] + groups["detector"]) == set(id(p) for p in graph.bwd_params), name
+        graph.busy = False
+
+
+def test_gradient_accumulation_and_overlapped_reducer_on_one_gpu(cuda):
+    """TrainStep(gas=2): two micro-batches accumulate (loss / 2 each) into the bound buckets, one optimizer step; the gradients equal
+    the mean of the two single-batch gradients.  The collectives run through RCCL on this one GPU (world 1, ReduceOp.AVG, async work
+    handles on ProcessGroupNCCL's stream): detector buckets are launched after the full backward, the keypoint buckets after the second."""
+    import torch.distributed as dist
+    from yolopoint_amd.engine import TrainStep, synthetic_batch
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        m, _ = make_model("n", 3, dtype="f32")
+        m = m.to(cuda).train()
+        b1, b2 = synthetic_batch(2, 128, cuda, 5), synthetic_batch(2, 128, cuda, 6)
+        single = []
+        step1 = TrainStep(m, cuda, img_size=128)
+        step1.sparse = dict(num_samples_per_image=100, num_masked_non_matches_per_match=20)
+        step1.loss_and_grads(b1)                       # (plan construction)
+        for b in (b1, b2):
+            torch.manual_seed(3)
+            step1.loss_and_grads(b)
+            single.append([p.grad.clone() for p in m.parameters()])
+        step = TrainStep(m, cuda, img_size=128, gas=2, lr=0.0)
+        step.sparse = dict(step1.sparse)
+        step.reducer.force_collectives = True
+        seeds = iter((3, 3))
+        orig = step.loss_and_grads
+
+        def seeded(*a, **k):
+            torch.manual_seed(next(seeds))
+            return orig(*a, **k)
+        step.loss_and_grads = seeded
+        step([b1, b2])
+        torch.cuda.synchronize()
+        for p, g1, g2 in zip(m.parameters(), *single):
+            assert rel_err(p.grad, (g1 + g2) / 2)[1] < 1e-4
+        det = [i for i, g in enumerate(step.reducer.bucket_group) if g == "detector"]
+        kpb = [i for i, g in enumerate(step.reducer.bucket_group) if g == "keypoint"]
+        assert len(det) >= 2 and kpb and step.reducer.launch_log == det + kpb
+        with pytest.raises(ValueError):
+            step(b1)                                   # gas = 2 takes two micro-batches
+    finally:
+        dist.destroy_process_group()

@@ -1,42 +1,70 @@
-"""Data parallelism for the training path: one process per GPU, replicated weights, per-rank BatchNorm
-statistics, ONE bucketed gradient all-reduce per optimizer step.
+"""Data parallelism for the training path: one process per GPU, replicated weights, per-rank BatchNorm statistics, bucketed
+gradient all-reduce OVERLAPPED with the backward, gradient accumulation.
 
-Reference: accelerate -> DistributedDataParallel(broadcast_buffers=False) (src/train.py:44-46,174,245):
-gradients are averaged over ranks, BN buffers are never synchronised, rank 0's buffers are what a
-checkpoint holds.  `torch.distributed` with backend "nccl" is RCCL over xGMI on MI355X; the helper is
-backend-agnostic, so the same code runs under gloo in the CPU tests.
+Reference: accelerate -> DistributedDataParallel(broadcast_buffers=False) (src/train.py:44-46,174,245): gradients are averaged
+over ranks while `accelerator.backward(loss)` runs (DDP's reducer fires one all-reduce per bucket as the bucket's gradients
+become final), BN buffers are never synchronised, `accelerator.accumulate` / `gas` (train.py:38-43,190) skips the all-reduce on
+all but the last micro-batch of an optimizer step.  `torch.distributed` with backend "nccl" is RCCL over xGMI on MI355X; the
+helper is backend-agnostic, so the same code runs under gloo in the CPU tests.
 
-Bucketing: parameters are packed in REVERSE registration order (descriptor/keypoint heads and Detect
-first, Conv1 last = the order in which the backward plan finishes their gradients) into few large flat
-fp32 buffers (default 32 MB: YOLOPoint-s is one bucket of 30.6 MB, -l seven) so that each collective is
-bandwidth- rather than latency-bound on the 7-link xGMI mesh.  `all_reduce()` launches every bucket
-asynchronously, then waits and scales.  With `bind_grads()` (what TrainStep uses) the parameters' .grad ARE views of the
-buckets, so a step moves no gradient bytes other than the collective itself; without it the gradients are copied in and out.
+Schedule.  A training step back-propagates two forwards (train.py:208-245): the image pass through the whole network and the
+warped pass through the keypoint / descriptor sub-graph only.  engine.TrainStep runs the FULL backward first: when it returns,
+every parameter the second pass does not reach (Detect, PAN, YOLO encoder: ~87 % of YOLOPoint-s's gradient bytes) is final, and
+`notify()` launches the all-reduce of those buckets -- asynchronously: ProcessGroupNCCL enqueues the collective on its own stream
+behind an event recorded on the compute stream at that point -- while the keypoint-only backward keeps the compute stream busy.
+The trunk / keypoint-head buckets follow when that pass returns; `finish()` makes the compute stream wait for the collectives
+right before the optimizer reads the gradients.  The division by the world size is part of the collective (ReduceOp.AVG on RCCL;
+gloo has no AVG: SUM and one scale per bucket).
+
+Buckets hold parameters in gradient-ready order (training.grad_ready_groups), a few per group (default: 3 detector + 1 keypoint
+bucket for YOLOPoint-s, 6-8 MB each: large enough to be bandwidth- rather than latency-bound on the 7-link xGMI mesh, small enough
+to start early).  With `bind_grads()` (what TrainStep uses) the parameters' .grad ARE views of the buckets, so a step moves no
+gradient bytes other than the collectives themselves; without it the gradients are copied in and out.
 """
+import contextlib
+
 import torch
 import torch.distributed as dist
 
 
 class GradAllReducer:
-    def __init__(self, params, group=None, bucket_bytes=32 << 20):
+    def __init__(self, params, group=None, bucket_bytes=None, groups=None, buckets_per_group=(3, 1)):
+        """params: iterable of parameters (buckets in REVERSE registration order: the order a backward finishes them), or
+        groups: [(name, [params in gradient-ready order]), ...] (training.grad_ready_groups): buckets never straddle a group."""
         self.group = group
-        self.params = [p for p in params if p.requires_grad]
+        if groups is None:
+            ps = [p for p in params if p.requires_grad]
+            groups = [("all", list(reversed(ps)))]
+            buckets_per_group = (max(1, sum(p.numel() for p in ps) * 4 // (bucket_bytes or (32 << 20)) + 1),) if bucket_bytes else (1,)
+        self.params = [p for _, g in groups for p in g]
         self.buckets = []                       # list of (flat fp32 buffer, [(param, offset, numel)])
+        self.bucket_group = []                  # group name per bucket
         self._views = None
-        cur, size = [], 0
-        for p in reversed(self.params):
-            n = p.numel()
-            if cur and (size + n) * 4 > bucket_bytes:
-                self._close(cur, size)
-                cur, size = [], 0
-            cur.append((p, size, n))
-            size += n
-        if cur:
-            self._close(cur, size)
+        for gi, (gname, gparams) in enumerate(groups):
+            total = sum(p.numel() for p in gparams)
+            want = buckets_per_group[min(gi, len(buckets_per_group) - 1)]
+            limit = bucket_bytes // 4 if bucket_bytes else -(-total // max(want, 1))
+            cur, size = [], 0
+            for p in gparams:
+                n = p.numel()
+                if cur and size + n > limit:
+                    self._close(cur, size, gname)
+                    cur, size = [], 0
+                cur.append((p, size, n))
+                size += n
+            if cur:
+                self._close(cur, size, gname)
+        self._bucket_of = {id(p): bi for bi, (_, entries) in enumerate(self.buckets) for p, _, _ in entries}
+        self.expected = {id(p): 1 for p in self.params}     # gradient contributions per micro-batch (set_expected)
+        self.sync = True
+        self.force_collectives = False          # run the collectives even for a single rank (exercises the RCCL path on one GPU)
+        self.launch_log = []                    # bucket indices in launch order (tests, bench reporting)
+        self._pending, self._works, self._launched = None, {}, set()
 
-    def _close(self, entries, size):
+    def _close(self, entries, size, gname):
         dev = entries[0][0].device
         self.buckets.append((torch.zeros(size, dtype=torch.float32, device=dev), entries))
+        self.bucket_group.append(gname)
 
     @property
     def world(self):
@@ -52,42 +80,95 @@ class GradAllReducer:
         from .models.common import invalidate_packed_weights
         invalidate_packed_weights()
 
-    def bind_grads(self):
-        """Zero-copy mode: every p.grad becomes a view into its bucket (all fp32 parameters), the buckets are cleared with one
-        launch each, backward passes ACCUMULATE into them and all_reduce() reduces them in place -- no per-parameter copies.
-        Call instead of optimizer.zero_grad() at the start of a step."""
+    # -- zero-copy gradients ---------------------------------------------------------------------------------------------
+    def bind_grads(self, zero=True):
+        """Every p.grad becomes a view into its bucket (all fp32 parameters); with `zero` the buckets are cleared (one launch
+        each).  Backward passes ACCUMULATE into them and the all-reduce runs in place -- no per-parameter copies.  Call instead of
+        optimizer.zero_grad() at the start of an optimizer step (zero=False on the later micro-batches of an accumulation)."""
         if self._views is None:
             self._views = [[flat[off:off + n].view_as(p) for p, off, n in entries] for flat, entries in self.buckets]
         for (flat, entries), views in zip(self.buckets, self._views):
-            flat.zero_()
+            if zero:
+                flat.zero_()
             for (p, _, _), v in zip(entries, views):
                 if p.grad is not v:
                     p.grad = v
 
-    def _bound(self, entries, views):
-        return views is not None and all(p.grad is v for (p, _, _), v in zip(entries, views))
+    def _bound(self, bi):
+        views = self._views[bi] if self._views else None
+        return views is not None and all(p.grad is v for (p, _, _), v in zip(self.buckets[bi][1], views))
 
-    def all_reduce(self):
-        """Average p.grad over the ranks (missing gradients count as zeros)."""
-        if self.world == 1:
+    # -- overlapped reduction --------------------------------------------------------------------------------------------
+    def set_expected(self, counts):
+        """counts: {parameter: number of backward passes that contribute to it per micro-batch} (default 1 each)."""
+        for p, c in counts.items():
+            if id(p) in self.expected:
+                self.expected[id(p)] = int(c)
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Micro-batches of a gradient accumulation whose gradients are NOT reduced yet (DDP.no_sync / accelerator.accumulate)."""
+        prev, self.sync = self.sync, False
+        try:
+            yield
+        finally:
+            self.sync = prev
+
+    def begin(self):
+        """Start of a micro-batch's backward: every bucket waits for `expected` contributions to each of its parameters."""
+        self._pending = [sum(self.expected[id(p)] for p, _, _ in entries) for _, entries in self.buckets]
+        self._works, self._launched = {}, set()
+        self.launch_log = []
+
+    def notify(self, params):
+        """A backward pass has accumulated its contribution to `params`.  Buckets whose parameters are all final are all-reduced
+        NOW (asynchronously, behind the work queued on the current stream so far) unless inside no_sync()."""
+        if self._pending is None:
+            self.begin()
+        hit = set()
+        for p in params:
+            bi = self._bucket_of.get(id(p))
+            if bi is not None:
+                self._pending[bi] -= 1
+                hit.add(bi)
+        for bi in sorted(hit):
+            if self._pending[bi] <= 0:
+                self._launch(bi)
+
+    def _launch(self, bi):
+        if bi in self._launched or not self.sync or (self.world == 1 and not self.force_collectives):
             return
-        works, bound = [], []
-        for i, (flat, entries) in enumerate(self.buckets):
-            is_bound = self._bound(entries, self._views[i] if self._views else None)
-            bound.append(is_bound)
-            if not is_bound:
-                have = [(p, off, n) for p, off, n in entries if p.grad is not None]
-                for p, off, n in entries:
-                    if p.grad is None:
-                        flat[off:off + n].zero_()
-                if have:
-                    torch._foreach_copy_([flat[off:off + n] for _, off, n in have], [p.grad.reshape(-1) for p, _, _ in have])
-            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._launched.add(bi)
+        self.launch_log.append(bi)
+        flat, entries = self.buckets[bi]
+        if not self._bound(bi):                # copy mode: gather the gradients into the bucket first
+            have = [(p, off, n) for p, off, n in entries if p.grad is not None]
+            for p, off, n in entries:
+                if p.grad is None:
+                    flat[off:off + n].zero_()
+            if have:
+                torch._foreach_copy_([flat[off:off + n] for _, off, n in have], [p.grad.reshape(-1) for p, _, _ in have])
+        avg = dist.get_backend(self.group) == "nccl"
+        op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+        self._works[bi] = (dist.all_reduce(flat, op=op, group=self.group, async_op=True), avg)
+
+    def finish(self):
+        """Launch whatever has not been launched (parameters without a gradient count as zeros), then make the current stream wait
+        for every collective; the gradients are the rank average afterwards.  No-op inside no_sync() / for a single rank."""
+        if not self.sync or (self.world == 1 and not self.force_collectives):
+            self._pending = None
+            return
+        if self._pending is None:
+            self.begin()
+        for bi in range(len(self.buckets)):
+            self._launch(bi)
         inv = 1.0 / self.world
-        for (flat, entries), w, is_bound in zip(self.buckets, works, bound):
-            w.wait()
-            flat.mul_(inv)
-            if is_bound:
+        for bi, (work, avg) in sorted(self._works.items()):
+            work.wait()
+            flat, entries = self.buckets[bi]
+            if not avg:
+                flat.mul_(inv)
+            if self._bound(bi):
                 continue
             for p, off, n in entries:
                 g = flat[off:off + n].view_as(p)
@@ -95,9 +176,18 @@ class GradAllReducer:
                     p.grad = g.clone().to(p.dtype)
                 else:
                     p.grad.copy_(g)
+        self._pending = None
+
+    def all_reduce(self):
+        """Average p.grad over the ranks in one go (no overlap): begin + finish."""
+        self.begin()
+        self.finish()
 
     def payload_bytes(self):
         return sum(f.numel() * 4 for f, _ in self.buckets)
+
+    def describe(self):
+        return [{"group": g, "mbytes": round(f.numel() * 4 / 1e6, 2), "params": len(e)} for g, (f, e) in zip(self.bucket_group, self.buckets)]
 
 
 def shard_batch(n_global, rank, world):
@@ -106,6 +196,11 @@ def shard_batch(n_global, rank, world):
         raise ValueError(f"global batch {n_global} is not divisible by world size {world}")
     per = n_global // world
     return rank * per, (rank + 1) * per
+
+
+def accumulation_steps(batch_per_device, n_devices, nominal=64):
+    """gas of the reference (train.py:38-43): micro-batches per optimizer step so that the global batch is about `nominal`."""
+    return max(round(nominal / (batch_per_device * n_devices)), 1)
 
 
 def timed_region(step, steps, warmup, sync, barrier, reduce_max):

@@ -7,6 +7,7 @@
 Forward/backward of the network run through the native plans (yolopoint_amd/training.py); the losses are PyTorch
 autograd; Adam is torch.optim.Adam (train.py:88).  Data: SURVEY.md 8(d) synthetic recipe, generated on the device.
 """
+import contextlib
 import os
 
 import torch
@@ -59,7 +60,12 @@ def _record_stream(obj, stream):
 
 
 class TrainStep:
-    def __init__(self, model, device, img_size=640, lr=1e-3, group=None):
+    """One optimizer step of the reference loop (train.py:189-259) with its data-parallel and accumulation semantics:
+    `gas` micro-batches per optimizer step (accelerator.accumulate: the loss of each is divided by gas, the gradient all-reduce runs
+    on the last one only), optional gradient clipping (train.py:249-250) and LambdaLR schedule (train.py:91-93, stepped by the caller
+    once per epoch: `step.scheduler`)."""
+
+    def __init__(self, model, device, img_size=640, lr=1e-3, group=None, gas=1, max_grad_norm=None, lr_lambda=None):
         self.model, self.device = model, device
         det = model.model.Detect
         hyp = dict(HYP)
@@ -71,7 +77,15 @@ class TrainStep:
         # the reference's optimizer (train.py:88) in its single-kernel implementation: the default multi-tensor one re-reads the 7.6 M
         # parameters / moments in ~10 passes (2.5-3 ms of the step); same update rule, fp32
         self.opt = torch.optim.Adam(model.parameters(), lr=lr, fused=torch.device(device).type == "cuda" and os.environ.get("YP_ADAM_FUSED", "1") != "0")
-        self.reducer = GradAllReducer(model.parameters(), group=group)
+        self.scheduler = torch.optim.lr_scheduler.LambdaLR(self.opt, lr_lambda=lr_lambda) if lr_lambda is not None else None
+        self.gas, self.max_grad_norm = int(gas), max_grad_norm
+        # gradient buckets in the order the gradients become final: the parameters only the full backward reaches first (all-reduced
+        # while the keypoint-only backward of the warped pass runs), the shared trunk + keypoint / descriptor heads last
+        from .training import grad_ready_groups
+        groups = grad_ready_groups(model.model)
+        self.reducer = GradAllReducer(None, group=group, groups=groups)
+        kp = set(id(p) for p in groups[1][1])
+        self.reducer.set_expected({p: (2 if id(p) in kp else 1) for p in self.reducer.params})
         self.sparse = dict(SPARSE)
         self.side_stream = torch.cuda.Stream(device=device) if os.environ.get("YP_TRAIN_SIDE_STREAM") == "1" else None
         self.reducer.broadcast_parameters(model)
@@ -81,27 +95,40 @@ class TrainStep:
             return self._step(batch)
 
     def _step(self, batch):
-        loss = self.loss_and_grads(batch)
-        self.reducer.all_reduce()
+        """batch: one micro-batch (gas == 1) or a sequence of `gas` micro-batches."""
+        micro = list(batch) if isinstance(batch, (list, tuple)) else [batch]
+        if len(micro) != self.gas:
+            raise ValueError(f"TrainStep(gas={self.gas}) takes {self.gas} micro-batch(es) per optimizer step, got {len(micro)}")
+        total = None
+        for i, mb in enumerate(micro):
+            last = i == len(micro) - 1
+            with (contextlib.nullcontext() if last else self.reducer.no_sync()):
+                loss = self.loss_and_grads(mb, first_micro=(i == 0), scale=1.0 / len(micro))
+            total = loss if total is None else total + loss
+        self.reducer.finish()                       # the compute stream waits for the collectives here, right before the optimizer reads
+        if self.max_grad_norm:
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=self.max_grad_norm)
         self.opt.step()
-        return loss
+        return total
 
-    def loss_and_grads(self, batch, prepare=True):
+    def loss_and_grads(self, batch, prepare=True, first_micro=True, scale=1.0):
         """loss = (det + det_warp) + lambda_desc * infonce + lambda_obj * obj and its backward (reference train.py:208-245).
-        With `prepare`, the label-only, host-synchronising parts of the losses (YOLO target assignment, InfoNCE sampling)
-        run right after both forward passes have been launched, and nothing after them synchronises until the optimizer step.
+        With `prepare`, the label-only parts of the losses (YOLO target assignment: a device kernel; InfoNCE sampling: one host sync)
+        run right after both forward passes have been launched.  The backward is driven explicitly: the loss kernels are
+        differentiated down to the network's head outputs (torch.autograd.grad), then the FULL native backward of the image pass
+        runs, the gradient buckets it completes are handed to the all-reduce, and the keypoint-only backward of the warped pass runs
+        while those collectives are in flight (dp.GradAllReducer).
         (Measured and dropped: a two-stage backward that launches the warped pass's native backward before the
         object-loss backward is differentiated -- the step is device-bound, the extra autograd entry points cost more than the
         overlap wins: 40-48 ms vs 38 ms per step.)"""
+        from .training import run_native_backward
         m, dev = self.model, self.device
-        self.reducer.bind_grads()          # (instead of optimizer.zero_grad: gradients accumulate straight into the all-reduce buckets)
+        self.reducer.bind_grads(zero=first_micro)   # (instead of optimizer.zero_grad: gradients accumulate straight into the all-reduce buckets)
         img = batch['image']
         B, S = img.shape[0], img.shape[-1]
-        # both forwards are launched first; the label-only parts then run while the device works through them (their host syncs --
-        # boolean-mask indexing, .item() -- wait for the forwards, which the device has to finish anyway).  YP_TRAIN_SIDE_STREAM=1
-        # runs them on a side stream instead (no host wait for the forwards): measured no faster once the step is device-bound.
-        outs = m(img)
-        outs_w = m(batch['warped_image'])
+        # both forwards are launched first; the label-only parts then run while the device works through them
+        outs, raw, graph = m.model.forward_with_graph(img)
+        outs_w, raw_w, graph_w = m.model.forward_with_graph(batch['warped_image'])
         tgt = nce = None
         if prepare:
             main = torch.cuda.current_stream(dev)
@@ -124,5 +151,11 @@ class TrainStep:
         l_det_w = self.det_loss(outs_w['semi'], labels2Dto3D(batch['warped_labels']), getMasks(batch['warped_valid_mask'], dev))
         l_desc = infonce(outs['desc'], outs_w['desc'], batch['warped_valid_mask'], batch['inv_homographies'], device=dev, prepared=nce, **self.sparse)
         loss = (l_det + l_det_w) + LAMBDA_DESC * l_desc + LAMBDA_OBJ * l_obj
-        loss.backward()
+        if scale != 1.0:
+            loss = loss * scale                     # accelerator.backward divides by the accumulation steps
+        heads = list(raw) + list(raw_w[:2])
+        g = torch.autograd.grad(loss, heads, allow_unused=True)
+        self.reducer.begin()
+        self.reducer.notify(run_native_backward(graph, g[0], g[1], list(g[2:len(raw)])))           # image pass: the whole network
+        self.reducer.notify(run_native_backward(graph_w, g[len(raw)], g[len(raw) + 1], [None] * (len(raw_w) - 2)))   # warped pass: keypoint sub-graph
         return loss.detach()

@@ -185,6 +185,14 @@ class YOLOPoint(HipModule):
         return g
 
     @_hip.guarded
+    def forward_with_graph(self, x):
+        """Train-mode forward that also hands back the raw head tensors and the native graph (see training.train_forward)."""
+        if not self.training:
+            raise _hip.YpError("forward_with_graph is a train-mode entry point")
+        from ..training import train_forward
+        return train_forward(self, x.contiguous().float(), with_graph=True)
+
+    @_hip.guarded
     def forward(self, x):
         if not (isinstance(x, torch.Tensor) and x.is_cuda):
             raise _hip.YpError("YOLOPoint.forward needs a cuda (HIP) tensor: the hot path has no CPU fallback")

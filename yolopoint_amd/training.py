@@ -581,33 +581,68 @@ class _YOLOPointTrainFn(torch.autograd.Function):
 
     @staticmethod
     def _backward(ctx, g, g_semi, g_desc, g_xs):
-        grads = g.backward(g_semi, g_desc, list(g_xs))
-        g.busy = False
-        # Parameter gradients are delivered with multi-tensor ops instead of ~215 per-parameter autograd returns (each of
-        # which AccumulateGrad would clone): a fresh copy for parameters without a gradient yet, an in-place add otherwise.
-        new_p, new_g, acc_p, acc_g = [], [], [], []
-        for p_, gr in zip(g.params, grads):
-            if gr is None or not p_.requires_grad:
-                continue
-            if p_.grad is None:
-                new_p.append(p_); new_g.append(gr)
-            else:
-                acc_p.append(p_.grad); acc_g.append(gr)
-        if new_p:
-            fresh = [torch.empty_like(p_, dtype=p_.dtype) for p_ in new_p]
-            torch._foreach_copy_(fresh, new_g)
-            for p_, f_ in zip(new_p, fresh):
-                p_.grad = f_
-        if acc_p:
-            torch._foreach_add_(acc_p, acc_g)
+        run_native_backward(g, g_semi, g_desc, list(g_xs))
         return (None, None, *([None] * len(g.params)))
 
 
-def train_forward(net, x):
-    """Train-mode forward of a YOLOPoint module through the native plans, differentiable w.r.t. its parameters."""
+def run_native_backward(g, g_semi, g_desc, g_xs):
+    """One native backward pass of TrainGraph `g` (head gradients; None = that head took no part in the loss), its parameter
+    gradients accumulated into p.grad.  Parameter gradients are delivered with multi-tensor ops instead of ~215 per-parameter
+    autograd returns (each of which AccumulateGrad would clone): a fresh copy for parameters without a gradient yet, an in-place
+    add otherwise (p.grad may be a view of a gradient all-reduce bucket: dp.GradAllReducer.bind_grads).  Returns the parameters
+    that received a contribution."""
+    grads = g.backward(g_semi, g_desc, list(g_xs))
+    g.busy = False
+    new_p, new_g, acc_p, acc_g, touched = [], [], [], [], []
+    for p_, gr in zip(g.params, grads):
+        if gr is None or not p_.requires_grad:
+            continue
+        touched.append(p_)
+        if p_.grad is None:
+            new_p.append(p_); new_g.append(gr)
+        else:
+            acc_p.append(p_.grad); acc_g.append(gr)
+    if new_p:
+        fresh = [torch.empty_like(p_, dtype=p_.dtype) for p_ in new_p]
+        torch._foreach_copy_(fresh, new_g)
+        for p_, f_ in zip(new_p, fresh):
+            p_.grad = f_
+    if acc_p:
+        torch._foreach_add_(acc_p, acc_g)
+    return touched
+
+
+# modules whose parameters the keypoint / descriptor heads depend on (everything a forward whose Detect outputs take no part in the loss
+# back-propagates through -- the warped pass of a training step, reference train.py:220-241); every other parameter only receives
+# gradient from the full backward of the first pass.  TrainGraph._build marks the same split on its tape (checked by a GPU test).
+KP_BRANCH_MODULES = ("Conv1", "Conv2", "Bottleneck1", "Conv3", "BottleneckDet", "ConvDet", "Bottleneck2", "ConvDescA", "ConvDescB", "BottleneckDesc",
+                     "ConvDesc")
+
+
+def grad_ready_groups(net):
+    """Parameters of a YOLOPoint / YOLOPointv52 module in the order their gradients become FINAL in a training step that runs the
+    full backward (image pass) before the keypoint-only backward (warped pass): first the parameters only the full pass reaches
+    (Detect, PAN, YOLO encoder -- in reverse registration order, heads first), then the shared trunk and the keypoint / descriptor
+    heads, which both passes contribute to.  Returns [("detector", [...]), ("keypoint", [...])]: the bucket plan of dp.GradAllReducer
+    -- the detector buckets are all-reduced while the second backward pass is still running."""
+    kp, det = [], []
+    for name, p in reversed(list(net.named_parameters())):
+        if not p.requires_grad:
+            continue
+        (kp if name.split(".")[0] in KP_BRANCH_MODULES else det).append(p)
+    return [("detector", det), ("keypoint", kp)]
+
+
+def train_forward(net, x, with_graph=False):
+    """Train-mode forward of a YOLOPoint module through the native plans, differentiable w.r.t. its parameters.
+    with_graph: also return the raw head tensors of the native forward (semi, desc, the Detect levels) and the TrainGraph that
+    produced them, for callers that drive the native backward themselves (engine.TrainStep: run_native_backward)."""
     params = list(net.parameters())
     outs = _YOLOPointTrainFn.apply(net, x, *params)
     desc = outs[1]
     if type(net).__name__ == "YOLOPointv52":          # reference models/YOLOPoint.py:318-319; YOLOPoint normalises inside the plan
         desc = desc.div(torch.unsqueeze(torch.norm(desc, p=2, dim=1), 1))
-    return {'semi': outs[0], 'desc': desc, 'objects': list(outs[2:])}
+    res = {'semi': outs[0], 'desc': desc, 'objects': list(outs[2:])}
+    if with_graph:
+        return res, tuple(outs), outs[0].grad_fn.graph
+    return res
