@@ -1,21 +1,29 @@
 #!/usr/bin/env python3
-"""bench.py — images/sec of the YOLOPoint hot path on MI355X.
+"""bench.py -- images/sec of the YOLOPoint hot path on MI355X.
 
-Workload at N=1 (BASELINE.json configs[1]): YOLOPoint-s inference, batch 8, 640x640, fp16 compute
-(fp32 accumulate, fp32 head outputs), BN folded, synthetic seeded weights + synthetic images that
-are already resident in HBM when the timed region starts.  One "step" = one forward of the
-batch through the native plan: input pack (NCHW fp32 -> NHWC f16), 74 fused implicit-GEMM convs,
-SPPF pooling, descriptor L2 norm, Detect decode to [8, 25200, 85].
+`python bench.py [--gpus N --steps K --warmup W]` prints ONE JSON line.
 
-N>1 (launched by torch.distributed.run): inference shards by independent images — every rank
-runs its own replica on its own batch ("replicas only", weak scaling, no data-path collective);
-the barrier + max-over-ranks timing is the only communication.
+Top level (BASELINE.json configs[1], the configuration `metric` is quoted on that fits one GPU): YOLOPoint-s inference, batch 8 per GPU,
+640x640, fp16 compute (fp32 accumulate, fp32 head outputs), BN folded, seeded synthetic weights, synthetic images resident in HBM when
+the timed region starts.  One step = one forward of the batch through the native plan (fused stem reading the NCHW fp32 batch, 47
+convolution launches, SPPF pooling, descriptor L2 norm, Detect decode to [8, 25200, 85]) replayed as a hipGraph.  N > 1 (launched by
+torch.distributed.run): inference shards by independent images -- one replica per rank, no data-path collective, `scaling: weak`.
 
-The JSON line also carries
-  roofline      achieved MFMA TFLOP/s of the implicit-GEMM conv kernel = algorithmic conv FLOPs per
-                forward (21.023 GFLOP/img for -s) / sum of the conv launches'
-                durations, measured with HIP events on the launch stream in this process
-  cpu_baseline  the oracle's PyTorch-CPU fp32 forward timed on this host's cores (rank 0, N=1)
+Sub-records of the same line (each measured in this process, after the top-level timing):
+  parity        head outputs of the timed plan against the oracle's fp32 CPU forward on the same weights and input (the oracle forward
+                is what `cpu_baseline` times anyway): relative errors of semi / desc / raw Detect levels / decoded rows, argmax agreement
+  roofline      the convolution kernels of the timed plan: algorithmic conv FLOP per forward / the sum of the conv
+                launches' durations, HIP events on the launch stream; `backbone` = the same for Conv1..SPPooling (F_bb)
+  cpu_baseline  the oracle's PyTorch-CPU fp32 forward timed on this host's cores (rank 0, N = 1), >= 3 warm-ups
+  train         BASELINE configs[2]: the reference's optimizer step (train.py:189-259: two train-mode forwards, detector + object + InfoNCE
+                losses, native backward, bucketed gradient all-reduce overlapped with the second backward pass, fused Adam), 8 samples per
+                GPU, 640x640, bf16 -- DATA PARALLEL over all N ranks (weak scaling: 8 samples per GPU); reports the bucket plan, payload
+                and the time the compute stream waits for the collectives (exposed communication)
+  train_bs64    (N = 1) the metric's "train bs=64" on one GPU the way the reference reaches its nominal batch (train.py:38-43):
+                gas = 8 micro-batches of 8 per optimizer step
+  frame         (N = 1) BASELINE configs[3]: YOLOPoint-l, one 1280x1280 frame end to end (forward + keypoint decode / NMS + box NMS on 100 800
+                rows + box-mask filter + descriptor sampling + MNN matching against the previous frame)
+`--only infer|train|frame` restricts the run; `--mode train|frame|export` prints that workload as the top-level record (round-1 CLI).
 """
 import argparse
 import json
@@ -46,7 +54,12 @@ def parse():
     ap.add_argument("--layers", default="", help="write a per-launch table (us, TFLOP/s, GB/s) to this path")
     ap.add_argument("--postproc", action="store_true", help="also time the post-processing kernels on planted head outputs")
     ap.add_argument("--mode", default="infer", choices=["infer", "train", "frame", "export"],
-                    help="infer (default, BASELINE.json configs[1]) or train: the reference's optimizer step, data parallel over --gpus")
+                    help="infer (default, BASELINE.json configs[1] + sub-records) or one workload as the top-level record")
+    ap.add_argument("--only", default="", help="comma list of sub-records to run beside the top level: train,train64,frame (default: all)")
+    ap.add_argument("--train-steps", type=int, default=20)
+    ap.add_argument("--train-warmup", type=int, default=3)
+    ap.add_argument("--frame-steps", type=int, default=60)
+    ap.add_argument("--gas", type=int, default=1, help="--mode train: micro-batches per optimizer step")
     return ap.parse_args()
 
 
@@ -59,19 +72,19 @@ def build_model(version, dtype, dev):
     return m, sd
 
 
-def cpu_baseline(version, B, S, budget_s=14.0):
-    """Oracle forward on the host cores (PyTorch-CPU fp32, eval).  Bounded sample: the thread count is picked by a
-    short probe (oversubscribing a 256-thread host makes ATen's small convolutions crawl), then up to 10 timed
-    iterations or `budget_s` seconds of the same workload."""
+def cpu_baseline(version, B, S, budget_s=14.0, gpu_outs=None):
+    """Oracle forward on the host cores (PyTorch-CPU fp32, eval).  Bounded sample: the thread count is picked by a short probe
+    (oversubscribing a 256-thread host makes ATen's small convolutions crawl), then 3 warm-ups and up to 10 timed iterations or
+    `budget_s` seconds of the same workload.  With `gpu_outs` (the timed plan's head outputs for the same weights and input) the
+    oracle's outputs are also the reference of the `parity` record."""
     from oracle import net_oracle                     # the CPU baseline IS the oracle's forward; nothing else in this file touches oracle/
-    from yolopoint_amd.utils.synthetic import NAMES80, layout_of
+    from yolopoint_amd.utils.synthetic import NAMES80, layout_of, GAIN
     from yolopoint_amd import models
     cores = os.cpu_count() or 1
     layout = layout_of(models.Model(names=NAMES80, version=version))
-    from yolopoint_amd.utils.synthetic import GAIN
     sd = net_oracle.synth_state_dict(layout, 1234, gain=GAIN.get(version, 1.6))
     Bc = min(B, 8)
-    x = net_oracle.synth_image(Bc, 3, S, S, 1234)
+    x = net_oracle.synth_image(B, 3, S, S, 1234)[:Bc]
     best_t, best_n = None, None
     with torch.no_grad():
         for n in sorted({min(cores, c) for c in (16, 32, 64)}):
@@ -83,17 +96,31 @@ def cpu_baseline(version, B, S, budget_s=14.0):
             if best_t is None or dt < best_t:
                 best_t, best_n = dt, n
         torch.set_num_threads(best_n)
-        net_oracle.yolopoint_forward(sd, x, version)                              # warm-up at full batch
+        for _ in range(3):                                                        # warm-ups at full batch (>= 3)
+            ref = net_oracle.yolopoint_forward(sd, x, version)
         times = []
         t_start = time.perf_counter()
-        while len(times) < 10 and (time.perf_counter() - t_start) < budget_s:
+        while len(times) < 10 and (len(times) < 3 or (time.perf_counter() - t_start) < budget_s):
             t0 = time.perf_counter()
             net_oracle.yolopoint_forward(sd, x, version)
             times.append(time.perf_counter() - t0)
     med = sorted(times)[len(times) // 2]
-    return {"value": round(Bc / med, 2), "unit": "images/s", "cores": best_n, "kind": "port",
+    base = {"value": round(Bc / med, 2), "unit": "images/s", "cores": best_n, "kind": "port",
             "sample": f"oracle (PyTorch-CPU fp32, eval) forward of YOLOPoint-{version} batch {Bc} {S}x{S}: {best_n} threads "
-                      f"(best of 16/32/64 on a {cores}-thread host), 1 warm-up + {len(times)} timed iterations, median"}
+                      f"(best of 16/32/64 on a {cores}-thread host), 3 warm-ups + {len(times)} timed iterations, median"}
+    parity = None
+    if gpu_outs is not None and Bc == B:
+        def rel(a, b):
+            a, b = a.detach().double().cpu(), b.detach().double()
+            return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)), float((a - b).norm() / b.norm().clamp_min(1e-30))
+        parity = {"against": "oracle fp32 CPU forward, same weights and input as the timed plan", "dtype": gpu_outs["dtype"]}
+        for k in ("semi", "desc"):
+            parity[k + "_max_rel"], parity[k + "_rel_l2"] = (round(v, 6) for v in rel(gpu_outs[k], ref[k]))
+        parity["pred_rel_l2"] = round(rel(gpu_outs["pred"], ref["objects"][0])[1], 6)
+        parity["raw_levels_rel_l2"] = [round(rel(a, b)[1], 6) for a, b in zip(gpu_outs["xs"], ref["objects"][1])]
+        parity["keypoint_cell_argmax_agreement"] = round(float((gpu_outs["semi"].argmax(1).cpu() == ref["semi"].argmax(1)).float().mean()), 6)
+        parity["bars"] = "tests/test_gpu_bench_shapes.py: f16 semi/desc rel-L2 < 3e-3, max < 1.5e-2, argmax > 0.97; the f32 path meets 1e-3 of max|ref|"
+    return base, parity
 
 
 def main():
@@ -198,59 +225,110 @@ def main():
             f.write(f"# conv: {n_conv} launches {conv_ms * 1e3:.1f} us, {conv_flops / 1e9:.2f} GFLOP -> {achieved:.1f} TFLOP/s; "
                     f"other ops {other_ms * 1e3:.1f} us; graph step {gpu_ms / a.steps * 1e3:.1f} us\n")
 
+    # backbone conv stack (Conv1 .. SPPooling, SURVEY 8d F_bb) separately
+    bb_names = ("Conv1", "Conv2", "Bottleneck1", "Conv3", "Bottleneck2", "Conv4", "Bottleneck3", "Conv5", "Bottleneck4", "SPPooling")
+    bb = [(ms, r) for ms, r in zip(per_op, recs) if r.kind == "conv" and r.name.split(".")[0] in bb_names]
+    bb_ms, bb_flops = sum(ms for ms, _ in bb), sum(r.flops for _, r in bb)
+    gpu_outs = None
+    if world == 1 and not a.no_cpu_baseline:
+        net.run_plan(plan, img, x)
+        torch.cuda.synchronize()
+        dch = net.ConvDesc.out_channels if hasattr(net, "ConvDesc") else net._desc_channels
+        gpu_outs = {"dtype": a.dtype, "semi": outs["semi"].buf.t[..., :65].permute(0, 3, 1, 2).float().cpu(),
+                    "desc": outs["desc"].buf.t[..., :dch].permute(0, 3, 1, 2).float().cpu(), "pred": outs["z"].float().cpu(),
+                    "xs": [t.float().cpu() for t in outs["xs"]]}
+    imgs = B * a.steps * world
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "images/sec at 640x640 (YOLOPoint-s inference, bs=8, fp16)" if (a.version, B, S, a.dtype) == ("s", 8, 640, "f16")
+            else f"images/sec at {S}x{S} (YOLOPoint-{a.version} inference, bs={B}, {a.dtype})",
+            "value": round(imgs / wall, 1),
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": round(wall / a.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": a.dtype,
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[1]: YOLOPoint-{a.version} inference forward (backbone + detect/keypoint/descriptor "
+                                   f"heads + Detect decode), batch {B}/GPU, {S}x{S}, {a.dtype} compute / fp32 accumulate, BN folded, "
+                                   f"seeded synthetic weights, inputs resident in HBM",
+                       "per_gpu_batch": B, "global_batch": B * world, "image": [S, S],
+                       "parallelism": "replicas" if world > 1 else "single",
+                       "launch": "eager" if a.no_graph else "hipGraph", "ops_per_step": len(per_op) + (0 if plan.stem_launch else 1),
+                       "scaling_records": "value = inference replicas (weak); train.value = data-parallel training over the same N ranks (weak, 8 samples/GPU)"},
+            "gpu_ms_per_step_events": round(gpu_ms / a.steps, 4),
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": round(conv_bytes / max(n_conv, 1)),
+                         "kernel": "the convolution kernels: conv_igemm / conv3x3_halo / bottleneck_halo / stem_conv (all instantiations)",
+                         "launches_per_step": n_conv, "conv_us_per_step": round(conv_ms * 1e3, 1),
+                         "algorithmic_gflop_per_step": round(conv_flops / 1e9, 3),
+                         "algorithmic_hbm_frac": round(conv_bytes / (conv_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if conv_ms > 0 else None,
+                         "whole_step_tflops": round(conv_flops / (gpu_ms / a.steps * 1e-3) / 1e12, 2),
+                         "whole_step_frac": round(conv_flops / (gpu_ms / a.steps * 1e-3) / 1e12 / peak, 4),
+                         "backbone": {"layers": "Conv1..SPPooling", "gflop_per_step": round(bb_flops / 1e9, 3), "us_per_step": round(bb_ms * 1e3, 1),
+                                      "achieved": round(bb_flops / (bb_ms * 1e-3) / 1e12, 2) if bb_ms > 0 else None,
+                                      "frac": round(bb_flops / (bb_ms * 1e-3) / 1e12 / peak, 4) if bb_ms > 0 else None},
+                         "mfma_busy": mfma_busy_record()},
+        }
+        if a.postproc:
+            out["postproc"] = bench_postproc(dev)
+    # ---- sub-records (every rank takes part in the data-parallel training; the rest is rank 0, N = 1)
+    only = set(k for k in a.only.split(",") if k) or {"train", "train64", "frame"}
+    del plan, img, outs
+    net.__dict__.pop("_plans", None)
+    torch.cuda.empty_cache()
+    if "train" in only:
+        rec = run_train(a, rank, world, dev, a.version, 8, a.train_steps, a.train_warmup, gas=1)
+        if rank == 0:
+            out["train"] = rec
+    if world == 1 and "train64" in only:
+        out["train_bs64"] = run_train(a, rank, world, dev, a.version, 8, max(3, a.train_steps // 4), 1, gas=8)
+    if world == 1 and "frame" in only:
+        torch.cuda.empty_cache()
+        out["frame"] = run_frame(dev, "l", 1280, a.dtype, a.frame_steps, max(3, a.frame_steps // 6))
     if rank != 0:
         return
-    imgs = B * a.steps * world
-    out = {
-        "metric": "images/sec at 640x640 (YOLOPoint-s inference, bs=8, fp16)" if (a.version, B, S, a.dtype) == ("s", 8, 640, "f16")
-        else f"images/sec at {S}x{S} (YOLOPoint-{a.version} inference, bs={B}, {a.dtype})",
-        "value": round(imgs / wall, 1),
-        "unit": "images/s",
-        "n_gpus": world,
-        "steps": a.steps,
-        "warmup": a.warmup,
-        "ms_per_step": round(wall / a.steps * 1e3, 4),
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": a.dtype,
-        "data": "synthetic",
-        "config": {"workload": f"BASELINE.json configs[1]: YOLOPoint-{a.version} inference forward (backbone + detect/keypoint/descriptor "
-                               f"heads + Detect decode), batch {B}/GPU, {S}x{S}, {a.dtype} compute / fp32 accumulate, BN folded, "
-                               f"seeded synthetic weights, inputs resident in HBM",
-                   "per_gpu_batch": B, "global_batch": B * world, "image": [S, S],
-                   "parallelism": "replicas" if world > 1 else "single",
-                   "launch": "eager" if a.no_graph else "hipGraph", "ops_per_step": len(per_op) + (0 if plan.stem_launch else 1)},
-        "gpu_ms_per_step_events": round(gpu_ms / a.steps, 4),
-        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                     "frac": round(achieved / peak, 4), "traffic": traffic,
-                     "algorithmic_bytes_per_launch": round(conv_bytes / max(n_conv, 1)),
-                     "kernel": "the convolution kernels: conv_igemm / conv3x3_halo / bottleneck_halo / stem_conv (all instantiations)",
-                     "launches_per_step": n_conv, "conv_us_per_step": round(conv_ms * 1e3, 1),
-                     "algorithmic_gflop_per_step": round(conv_flops / 1e9, 3),
-                     "algorithmic_hbm_frac": round(conv_bytes / (conv_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if conv_ms > 0 else None,
-                     "whole_step_tflops": round(conv_flops / (gpu_ms / a.steps * 1e-3) / 1e12, 2)},
-    }
-    if a.postproc:
-        out["postproc"] = bench_postproc(dev)
     if world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(a.version, B, S)
+        out["cpu_baseline"], parity = cpu_baseline(a.version, B, S, gpu_outs=gpu_outs)
+        if parity is not None:
+            out["parity"] = parity
     print(json.dumps(out), flush=True)
 
 
-def bench_train(a, rank, world, dev):
-    """BASELINE.json configs[2] shape: YOLOPoint-s training, per-GPU batch a.batch (8 -> global 64 on 8 GPUs), 640x640,
-    bf16 compute: two forwards + detector/object/InfoNCE losses + backward + bucketed gradient all-reduce + Adam per step."""
+def mfma_busy_record():
+    """MFMA utilisation of the timed plan from the PMC counters (cannot be read in-process): the latest committed measurement,
+    profiles/mfma_busy.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE of this command, tools/profile_collect.py)."""
+    path = os.path.join(ROOT, "profiles", "mfma_busy.json")
+    if os.path.exists(path):
+        try:
+            return json.load(open(path))
+        except Exception:
+            return None
+    return None
+
+
+TRAIN_GFLOP_PER_SAMPLE = {"n": 27.77, "s": 103.28, "m": 299.67, "l": 657.56}      # SURVEY.md 8(d): 4 F_fwd + 2 F_kp at 640x640
+
+
+def run_train(a, rank, world, dev, version, batch, steps, warmup, gas=1, size=640, dtype="bf16"):
+    """The reference's optimizer step (src/train.py:189-259) on synthetic batches, data parallel over `world` ranks: `batch` samples per
+    GPU and micro-batch, `gas` micro-batches per optimizer step.  Returns the sub-record (rank 0) -- every rank must call it."""
     import torch.distributed as dist
     from yolopoint_amd.utils.synthetic import make_model
     from yolopoint_amd.engine import TrainStep, synthetic_batch
     from yolopoint_amd.dp import timed_region
-    dtype = a.dtype if a.dtype != "f16" else "bf16"
-    m, _ = make_model(a.version, 1234, dtype=dtype)
+    m, _ = make_model(version, 1234, dtype=dtype)
     m = m.to(dev).train()
-    step = TrainStep(m, dev, img_size=a.size)
-    batch = synthetic_batch(a.batch, a.size, dev, 1234 + rank)
-    steps, warmup = min(a.steps, 20), min(a.warmup, 3)
+    step = TrainStep(m, dev, img_size=size, gas=gas)
+    step.comm_events = [] if world > 1 else None
+    micro = [synthetic_batch(batch, size, dev, 1234 + rank * 97 + i) for i in range(gas)]
+    arg = micro if gas > 1 else micro[0]
 
     def reduce_max(t):
         if world == 1:
@@ -258,37 +336,65 @@ def bench_train(a, rank, world, dev):
         x = torch.tensor([t], device=dev)
         dist.all_reduce(x, op=dist.ReduceOp.MAX)
         return float(x.item())
-    wall = timed_region(lambda: step(batch), steps, warmup, torch.cuda.synchronize, (dist.barrier if world > 1 else (lambda: None)), reduce_max)
+    wall = timed_region(lambda: step(arg), steps, warmup, torch.cuda.synchronize, (dist.barrier if world > 1 else (lambda: None)), reduce_max)
+    exposed = None
+    if step.comm_events:
+        ev = step.comm_events[-steps:]
+        exposed = round(sum(e0.elapsed_time(e1) for e0, e1 in ev) / len(ev), 4)
+    samples = batch * gas * world * steps
+    gflop_sample = TRAIN_GFLOP_PER_SAMPLE.get(version, 0.0) * (size / 640.0) ** 2
+    achieved = gflop_sample * samples / wall / 1e3 / max(world, 1)          # TFLOP/s per GPU
+    rec = {"workload": f"BASELINE.json configs[{2 if version == 's' else 4}] shape: YOLOPoint-{version} optimizer step as src/train.py:189-259 (2 train-mode "
+                       f"forwards, detector + object + InfoNCE losses through csrc/losses.hip, native backward, bucketed gradient all-reduce overlapped with "
+                       f"the keypoint-only backward, fused Adam), {batch} samples/GPU/micro-batch x gas {gas}, {size}x{size}, {dtype}",
+           "value": round(2 * samples / wall, 1), "unit": "images/s (an image pair counts as 2 images)", "samples_per_s": round(samples / wall, 1),
+           "ms_per_step": round(wall / steps * 1e3, 3), "steps": steps, "warmup": warmup, "n_gpus": world, "dtype": dtype, "scaling": "weak",
+           "per_gpu_batch": batch, "gas": gas, "global_batch": batch * gas * world, "parallelism": f"dp{world}",
+           "grad_allreduce_bytes": step.reducer.payload_bytes(), "buckets": step.reducer.describe(),
+           "bucket_launch_order": list(step.reducer.launch_log), "exposed_comm_ms_per_step": exposed,
+           "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS["bf16"], 4),
+                        "traffic": None, "per_gpu": True, "algorithmic_gflop_per_sample": round(gflop_sample, 2),
+                        "note": "whole step (losses, BN / elementwise passes, optimizer included) against the conv FLOP the reference executes per sample"}}
+    del step, m, micro
+    torch.cuda.empty_cache()
+    return rec if rank == 0 else None
+
+
+def bench_train(a, rank, world, dev):
+    """--mode train: the training step as the top-level record (per-GPU batch a.batch, a.gas micro-batches per step)."""
+    dtype = a.dtype if a.dtype != "f16" else "bf16"
+    rec = run_train(a, rank, world, dev, a.version, a.batch, a.steps, a.warmup, gas=a.gas, size=a.size, dtype=dtype)
     if rank != 0:
         return
-    samples = a.batch * world * steps
-    # conv FLOP the reference executes per training sample (pair) = 4 F_fwd + 2 F_kp at 640x640
-    gflop_sample = {"n": 27.77, "s": 103.28, "m": 299.67, "l": 657.56}.get(a.version, 0.0) * (a.size / 640.0) ** 2
-    achieved = gflop_sample * samples / wall / 1e3 / max(world, 1)          # TFLOP/s per GPU
-    print(json.dumps({
-        "metric": f"images/sec at {a.size}x{a.size} (YOLOPoint-{a.version} training, {a.batch} samples/GPU, {dtype}); an image pair counts as 2 images",
-        "value": round(2 * samples / wall, 1), "unit": "images/s", "samples_per_s": round(samples / wall, 1), "n_gpus": world, "steps": steps,
-        "warmup": warmup, "ms_per_step": round(wall / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": dtype, "data": "synthetic",
-        "config": {"workload": f"BASELINE.json configs[{4 if a.version == 'l' else 2}] shape{' in bf16 (fp8 not built)' if a.version == 'l' else ''}: "
-                               f"YOLOPoint-{a.version} optimizer step as src/train.py:189-259 (2 forwards, detector + object + InfoNCE losses through "
-                               f"csrc/losses.hip, native backward, gradient all-reduce, fused Adam), {a.batch} samples/GPU, {a.size}x{a.size}",
-                   "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
-                   "grad_allreduce_bytes": step.reducer.payload_bytes()},
-        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS["bf16"], 4),
-                     "traffic": None, "per_gpu": True, "algorithmic_gflop_per_sample": round(gflop_sample, 2),
-                     "note": "whole step (losses, BN / elementwise passes, optimizer included) against the conv FLOP the reference executes per sample"}}), flush=True)
+    top = {"metric": f"images/sec at {a.size}x{a.size} (YOLOPoint-{a.version} training, {a.batch} samples/GPU x gas {a.gas}, {dtype}); an image pair counts as 2 images",
+           "value": rec["value"], "unit": "images/s", "samples_per_s": rec["samples_per_s"], "n_gpus": world, "steps": rec["steps"], "warmup": rec["warmup"],
+           "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+           "config": {"workload": rec["workload"], "per_gpu_batch": a.batch, "gas": a.gas, "global_batch": rec["global_batch"], "parallelism": rec["parallelism"],
+                      "grad_allreduce_bytes": rec["grad_allreduce_bytes"], "buckets": rec["buckets"], "bucket_launch_order": rec["bucket_launch_order"],
+                      "exposed_comm_ms_per_step": rec["exposed_comm_ms_per_step"]},
+           "roofline": rec["roofline"]}
+    print(json.dumps(top), flush=True)
 
 
 def bench_frame(a, dev):
+    """--mode frame: the frame pipeline as the top-level record."""
+    rec = run_frame(dev, a.version, a.size, a.dtype, a.steps, a.warmup)
+    top = {"metric": rec["metric"], "value": rec["value"], "unit": "frames/s", "n_gpus": 1, "steps": rec["steps"], "warmup": rec["warmup"],
+           "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+           "config": rec["config"], "roofline": rec["roofline"]}
+    print(json.dumps(top), flush=True)
+
+
+FWD_GFLOP_PER_IMAGE = {"n": 5.642, "s": 21.023, "m": 61.477, "l": 135.526}       # SURVEY.md 8(d) F_fwd at 640x640
+
+
+def run_frame(dev, version, S, dtype, steps, warmup):
     """SURVEY.md 8(f) row 2 / BASELINE.json configs[3]: one frame through the GPU-resident front end (forward, keypoint decode +
-    NMS, box NMS, box-mask keypoint filter, descriptor sampling) + mutual-NN matching against the previous frame's descriptors.
-    Random-weight heads: the keypoint / box counts are whatever the seed gives (reported), thresholds are the reference's."""
+    NMS, box NMS, box-mask keypoint filter, descriptor sampling) + mutual-NN matching against the previous frame's descriptors."""
     from yolopoint_amd.frontend import YoloPointFrontend
     from yolopoint_amd.models.model_wrap import PointTracker
     from yolopoint_amd.utils.synthetic import synth_image
-    m, _ = build_model(a.version, a.dtype, dev)
-    S = a.size
+    m, _ = build_model(version, dtype, dev)
     fe = YoloPointFrontend(m, dev, yolo_config=dict(conf_thres_box=0.25, iou_thres_box=0.45, max_det=300), filter_pts=True)
     frames = [synth_image(1, 3, S, S, 100 + i).to(dev) for i in range(4)]
     # Seeded random heads saturate (every pixel a keypoint, every anchor a box), which is not the load of a trained model: the
@@ -327,21 +433,27 @@ def bench_frame(a, dev):
             stats["matches"] = tr.nn_match_two_way(r["desc"], prev[0], 0.7).shape[1]
         prev[0] = r["desc"]
         stats["keypoints"], stats["boxes"] = int(r["pts"].shape[0]), int(r["boxes"].shape[0])
-    for i in range(a.warmup):
+    for i in range(warmup):
         step(i)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(a.steps):
+    for i in range(steps):
         step(i)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    print(json.dumps({"metric": f"frames/sec at {S}x{S} (YOLOPoint-{a.version} frame pipeline: forward + keypoint decode/NMS + box NMS + "
-                                f"box-mask filter + descriptor sampling + MNN matching, bs=1, {a.dtype})",
-                      "value": round(a.steps / wall, 1), "unit": "frames/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
-                      "ms_per_step": round(wall / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype,
-                      "data": "synthetic", "config": {"workload": "BASELINE.json configs[3] shape: one frame end to end, device-resident, 2 host syncs per frame "
-                                                                  "(front-end counters, match count)", "image": [S, S],
-                                                      "post_processing_inputs": "planted heat map / predictions (SURVEY.md 8d), model descriptors", **stats}}), flush=True)
+    gflop = FWD_GFLOP_PER_IMAGE.get(version, 0.0) * (S / 640.0) ** 2
+    achieved = gflop * steps / wall / 1e3
+    rec = {"metric": f"frames/sec at {S}x{S} (YOLOPoint-{version} frame pipeline: forward + keypoint decode/NMS + box NMS + box-mask filter + descriptor "
+                     f"sampling + MNN matching, bs=1, {dtype})",
+           "value": round(steps / wall, 1), "unit": "frames/s", "steps": steps, "warmup": warmup, "ms_per_step": round(wall / steps * 1e3, 4), "dtype": dtype,
+           "config": {"workload": "BASELINE.json configs[3] shape: one frame end to end, device-resident, 2 host syncs per frame (front-end counters, match count)",
+                      "image": [S, S], "post_processing_inputs": "planted heat map / predictions (SURVEY.md 8d), model descriptors", **stats},
+           "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS.get(dtype, 2500.0), "unit": "TFLOP/s",
+                        "frac": round(achieved / PEAK_TFLOPS.get(dtype, 2500.0), 4), "traffic": None, "algorithmic_gflop_per_frame": round(gflop, 2),
+                        "note": "whole frame (post-processing and host syncs included) against the forward's algorithmic conv FLOP"}}
+    del fe, m
+    torch.cuda.empty_cache()
+    return rec
 
 
 def bench_export(a, dev):

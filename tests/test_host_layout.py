@@ -185,3 +185,35 @@ def test_graph_schedule_respects_dependencies():
     pb.accesses.append(([(Cc, 0, 64)], [(Cc, 0, 64)]))           # 4: in-place on the result
     pb.accesses.append(([(A, 0, 64)], [(D, 0, 8)]))              # 5: another reader of x
     assert pb.dependencies() == [[], [0], [0], [1, 2], [3], [0]]
+
+
+def test_model_ema_matches_reference_formula():
+    """utils/torch_utils_yolo.py:315-349: ema <- d ema + (1 - d) model, d = decay (1 - exp(-updates / 2000)), every floating-point state_dict
+    tensor (parameters and BN statistics), integer buffers untouched; deepcopy of a model leaves its native plan caches behind."""
+    import math
+    from copy import deepcopy
+    from yolopoint_amd.utils.torch_utils_yolo import ModelEMA
+    m, _ = make_model("n", 4)
+    m.model.__dict__["_plans"] = {"sentinel": object()}
+    ema = ModelEMA(m, decay=0.99)
+    assert "_plans" not in ema.ema.model.__dict__ and not any(p.requires_grad for p in ema.ema.parameters())
+    before = {k: v.clone() for k, v in ema.ema.state_dict().items()}
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(torch.randn_like(p) * 0.1)
+        for b in m.buffers():
+            if b.dtype.is_floating_point:
+                b.add_(0.05)
+    for upd in (1, 2):
+        ema.update(m)
+        d = 0.99 * (1 - math.exp(-upd / 2000))
+        now = m.state_dict()
+        for k, v in ema.ema.state_dict().items():
+            if v.dtype.is_floating_point:
+                want = before[k] * d + (1 - d) * now[k]
+                assert torch.allclose(v, want, rtol=1e-5, atol=1e-7), k
+                before[k] = want
+            else:
+                assert torch.equal(v, before[k])
+    assert ema.updates == 2
+    deepcopy(m)

@@ -80,6 +80,35 @@ def main():
                    "conv_us_per_step_trace": res.get("conv_us_per_step_trace")}
         json.dump(traffic, open(os.path.join(OUT, "conv_traffic.json"), "w"), indent=1)
         res["traffic"] = traffic
+    mf = find("pmc_mfma", "*counter_collection.csv")
+    if mf:
+        # per dispatch: MFMA-busy cycles summed over the chip's SIMDs / (GPU-active cycles x 4 SIMDs x 256 CUs).  Eager replay: the k-th
+        # kernel of a plan execution is the k-th op of the plan (stem first), so the backbone (Conv1..SPPooling) can be separated.
+        d0 = first_step_dispatch(find("pmc_mfma", "*kernel_trace.csv"))
+        rows = collections.defaultdict(dict)
+        for r in csv.DictReader(open(mf)):
+            if int(r["Dispatch_Id"]) >= d0:
+                rows[int(r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
+                rows[int(r["Dispatch_Id"])]["name"] = r["Kernel_Name"]
+        order = [rows[k] for k in sorted(rows)]
+        layers = [l.split()[0] for l in open(os.path.join(OUT, "layers.txt")) if l.strip() and not l.startswith("#") and not l.startswith("op ")] if os.path.exists(os.path.join(OUT, "layers.txt")) else []
+        bbn = ("Conv1", "Conv2", "Bottleneck1", "Conv3", "Bottleneck2", "Conv4", "Bottleneck3", "Conv5", "Bottleneck4", "SPPooling")
+        per = len(layers)
+        tot = {"all": [0.0, 0.0], "conv": [0.0, 0.0], "backbone": [0.0, 0.0]}
+        for i, r in enumerate(order):
+            busy, act = r.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), r.get("GRBM_GUI_ACTIVE", 0.0)
+            tot["all"][0] += busy; tot["all"][1] += act
+            if CONV.search(r["name"]):
+                tot["conv"][0] += busy; tot["conv"][1] += act
+                if per and layers[i % per].split(".")[0] in bbn:
+                    tot["backbone"][0] += busy; tot["backbone"][1] += act
+        util = {k: (v[0] / (v[1] * 4 * 256) if v[1] else None) for k, v in tot.items()}
+        rec = {"source": f"gpurun_out/prof_{R}: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (own pass, --kernel-trace only) of `{res['command']} --no-graph`",
+               "formula": "sum(SQ_VALU_MFMA_BUSY_CYCLES) / (sum(GRBM_GUI_ACTIVE) x 4 SIMDs x 256 CUs) over the dispatches of the plan replays",
+               "workload": "YOLOPoint-s bs8 640x640 f16", "dispatches": len(order),
+               "mfma_busy_all_kernels": util["all"], "mfma_busy_conv_kernels": util["conv"], "mfma_busy_backbone_convs": util["backbone"]}
+        json.dump(rec, open(os.path.join(OUT, "mfma_busy.json"), "w"), indent=1)
+        res["mfma_busy"] = rec
     open(os.path.join(OUT, f"{R}_infer_kernel_trace.txt"), "w").write("\n".join(lines) + "\n")
     tt = find("trace_train", "*kernel_trace.csv")
     if tt:

@@ -10,13 +10,15 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$R
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --no-cpu-baseline --steps 50 --warmup 10"
+BENCH="python $ROOT/bench.py --no-cpu-baseline --only none --steps 50 --warmup 10"
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
-python bench.py --no-cpu-baseline --steps 300 --warmup 30 --layers $OUT/layers.txt > $OUT/bench_long.json 2>> $OUT/bench_default.err
+python bench.py --no-cpu-baseline --only none --steps 300 --warmup 30 --layers $OUT/layers.txt > $OUT/bench_long.json 2>> $OUT/bench_default.err
 cd /tmp
 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o t -- $BENCH > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o f -- $BENCH > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o w -- $BENCH > $OUT/pmc_write.log 2>&1
+# MFMA utilisation: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 4 SIMDs x 256 CUs); eager replay so that the dispatch order is the plan order
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma -o m -- $BENCH --no-graph > $OUT/pmc_mfma.log 2>&1
 cd $ROOT
 python bench.py --mode train --steps 20 --warmup 3 > $OUT/bench_train.json 2> $OUT/bench_train.err
 cd /tmp
@@ -28,5 +30,5 @@ python bench.py --mode frame --version l --size 1280 > $OUT/bench_frame.json 2> 
 python bench.py --mode export > $OUT/bench_export.json 2> $OUT/bench_export.err
 python tools/profile_collect.py $R
 # raw traces are large: keep only what profile_collect distilled
-rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/trace_train
+rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma $OUT/trace_train
 ls -la $OUT

@@ -47,11 +47,14 @@ class GradAllReducer:
             cur, size = [], 0
             for p in gparams:
                 n = p.numel()
-                if cur and size + n > limit:
+                if cur and bucket_bytes and size + n > limit:      # byte budget: never exceed it
                     self._close(cur, size, gname)
                     cur, size = [], 0
                 cur.append((p, size, n))
                 size += n
+                if not bucket_bytes and size >= limit:              # bucket count: close once the share is reached (no dangling remainder)
+                    self._close(cur, size, gname)
+                    cur, size = [], 0
             if cur:
                 self._close(cur, size, gname)
         self._bucket_of = {id(p): bi for bi, (_, entries) in enumerate(self.buckets) for p, _, _ in entries}

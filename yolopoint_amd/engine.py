@@ -87,6 +87,7 @@ class TrainStep:
         kp = set(id(p) for p in groups[1][1])
         self.reducer.set_expected({p: (2 if id(p) in kp else 1) for p in self.reducer.params})
         self.sparse = dict(SPARSE)
+        self.comm_events = None
         self.side_stream = torch.cuda.Stream(device=device) if os.environ.get("YP_TRAIN_SIDE_STREAM") == "1" else None
         self.reducer.broadcast_parameters(model)
 
@@ -105,7 +106,14 @@ class TrainStep:
             with (contextlib.nullcontext() if last else self.reducer.no_sync()):
                 loss = self.loss_and_grads(mb, first_micro=(i == 0), scale=1.0 / len(micro))
             total = loss if total is None else total + loss
-        self.reducer.finish()                       # the compute stream waits for the collectives here, right before the optimizer reads
+        if self.comm_events is not None:            # (bench: how long the compute stream waits for the collectives = exposed communication)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.reducer.finish()
+            e1.record()
+            self.comm_events.append((e0, e1))
+        else:
+            self.reducer.finish()                   # the compute stream waits for the collectives here, right before the optimizer reads
         if self.max_grad_norm:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=self.max_grad_norm)
         self.opt.step()

@@ -66,6 +66,19 @@ class HipModule(nn.Module):
     """Base class: standalone forward through a cached native plan."""
 
     compute_dtype = "f16"
+    _NATIVE_CACHES = ("_plans", "_train_graphs", "_pack_states")      # per-object native plans / graphs: never copied or pickled
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k not in self._NATIVE_CACHES:
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
+
+    def __getstate__(self):
+        return {k: v for k, v in self.__dict__.items() if k not in self._NATIVE_CACHES}
 
     def _weights_version(self):
         """Changes whenever the parameters / buffers may have changed: tensor version counters and storage addresses, plus the
