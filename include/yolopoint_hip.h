@@ -123,7 +123,9 @@ typedef struct YpConvDesc {
     /* BatchNorm statistics in the epilogue (training forward of Conv = conv -> BN -> SiLU, reference models/common.py:22-34): when
      * non-NULL the generic kernel also writes, per block of 64 output pixels rb, the column sums of the raw output and of its square:
      * bn_partial[(rb*2 + 0)*C + c] and [(rb*2 + 1)*C + c], C = out.C, ceil(B*Ho*Wo / 64) row blocks; yp_bn_finalize folds them.
-     * Needs tail_zero, a 16-bit or fp32 store of the same dtype, no bias / activation / residual / out2 / ksplit, tile 0..5. */
+     * Needs tail_zero, a 16-bit or fp32 store of the same dtype, no bias / activation / residual / out2 / ksplit.  The 3x3 halo kernels
+     * (tile ids 10..15) write one row per pixel tile instead: B * ceil(Ho/8 | Ho/4) * ceil(Wo/16) rows; size the buffer for
+     * B * ceil(Ho/4) * ceil(Wo/16) rows (>= every variant's count), zero it once after the kernel variant is fixed and fold all rows. */
     float* bn_partial;
     /* Deterministic split-K (ksplit > 1): when non-NULL, k slice y writes its partial output -- laid out like `out` -- to
      * split_slabs + y * split_stride floats with plain stores, and the caller sums the slices in order (yp_sum_slabs); NULL: fp32 atomics

@@ -73,6 +73,27 @@ def test_config1_s_bs8_640_f16_graph_as_benchmarked(cuda):
     assert same > t["argmax"], float(same)
 
 
+def test_config1_forward_is_deterministic(cuda):
+    """Six replays of the benchmarked plan (three eager, three through the hipGraph) are bit-identical.  Regression test: the fused
+    Bottleneck kernel refilled a filter-ring stage one barrier after its last read WITHOUT retiring the reads first -- the compiler had
+    sunk the last MFMAs (and the lgkmcnt wait for their operands) below that barrier, so at 4 workgroups per CU a DMA occasionally landed
+    under an in-flight ds_read: a handful of wrong 8x16 tiles per forward, different ones every run (only at this size)."""
+    m, _ = make_model("s", 1234, dtype="f16")
+    x = net_oracle.synth_image(8, 3, 640, 640, 1234).to(cuda)
+    m = m.to(cuda)
+    m.fuse()
+    outs = []
+    with torch.no_grad():
+        for i in range(6):
+            if i == 3:
+                m.model.use_graph = True
+            o = m(x)
+            outs.append((o["semi"].clone(), o["desc"].clone(), o["objects"][0].clone()))
+    for o in outs[1:]:
+        for a, b in zip(o, outs[0]):
+            assert torch.equal(a, b)
+
+
 def test_config3_l_bs1_1280_f16(cuda):
     m, sd = make_model("l", 77, dtype="f16")
     x = net_oracle.synth_image(1, 3, 1280, 1280, 77)

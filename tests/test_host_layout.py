@@ -177,14 +177,24 @@ def test_graph_schedule_respects_dependencies():
     from yolopoint_amd.plan import PlanBuilder
     pb = PlanBuilder.__new__(PlanBuilder)
     pb.accesses = []
+    # an access = (allocation, buffer base, lo, hi, first byte, last byte): same buffer -> channel ranges, slices of one arena -> byte ranges
     A, B_, Cc, D = 0x1000, 0x2000, 0x3000, 0x4000
-    pb.accesses.append(([], [(A, 0, 64)]))                       # 0: produce x
-    pb.accesses.append(([(A, 0, 64)], [(B_, 0, 32)]))            # 1: cv1(x)  -> cat[0:32]
-    pb.accesses.append(([(A, 0, 64)], [(B_, 32, 64)]))           # 2: cv2(x)  -> cat[32:64]  (independent of 1)
-    pb.accesses.append(([(B_, 0, 64)], [(Cc, 0, 64)]))           # 3: cv3(cat) needs both
-    pb.accesses.append(([(Cc, 0, 64)], [(Cc, 0, 64)]))           # 4: in-place on the result
-    pb.accesses.append(([(A, 0, 64)], [(D, 0, 8)]))              # 5: another reader of x
+    acc = lambda base, lo, hi, alloc=None, nbytes=0x800: (alloc or base, base, lo, hi, base, base + nbytes)
+    pb.accesses.append(([], [acc(A, 0, 64)]))                           # 0: produce x
+    pb.accesses.append(([acc(A, 0, 64)], [acc(B_, 0, 32)]))             # 1: cv1(x)  -> cat[0:32]
+    pb.accesses.append(([acc(A, 0, 64)], [acc(B_, 32, 64)]))            # 2: cv2(x)  -> cat[32:64]  (independent of 1)
+    pb.accesses.append(([acc(B_, 0, 64)], [acc(Cc, 0, 64)]))            # 3: cv3(cat) needs both
+    pb.accesses.append(([acc(Cc, 0, 64)], [acc(Cc, 0, 64)]))            # 4: in-place on the result
+    pb.accesses.append(([acc(A, 0, 64)], [acc(D, 0, 8)]))               # 5: another reader of x
     assert pb.dependencies() == [[], [0], [0], [1, 2], [3], [0]]
+    # slices of one arena (weight-gradient accumulators) against a whole-arena clear: byte ranges decide; redundant edges are dropped
+    pb.accesses = []
+    ARENA = 0x9000
+    pb.accesses.append(([], [acc(ARENA, 0, 1 << 30, ARENA, 0x1000)]))                   # 0: clear the arena
+    pb.accesses.append(([], [acc(ARENA + 0x100, 0, 8, ARENA, 0x100)]))                  # 1: writes slice [0x100, 0x200)
+    pb.accesses.append(([], [acc(ARENA + 0x200, 0, 8, ARENA, 0x100)]))                  # 2: writes slice [0x200, 0x300): independent of 1
+    pb.accesses.append(([acc(ARENA + 0x100, 0, 8, ARENA, 0x100), acc(ARENA + 0x200, 0, 8, ARENA, 0x100)], [acc(D, 0, 8)]))   # 3: reads both
+    assert pb.dependencies() == [[], [0], [0], [1, 2]]                 # (3 -> 0 is implied by 1 and 2)
 
 
 def test_model_ema_matches_reference_formula():

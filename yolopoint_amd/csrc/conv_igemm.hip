@@ -559,6 +559,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
             else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLS) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS > 3 ? 2 * NLS : NLS) : "memory");
             static_assert(NS <= 4, "waves-split-k: rings of up to 4 stages");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (reads of stage ks-1 retired: its slot is refilled behind the barrier)
             __builtin_amdgcn_s_barrier();
             if (ks < 20) YP_TL(2 + ks);
             if (ks + NS - 1 < nks) issue_stage(ks + NS - 1);          // into the slot every wave finished reading before this barrier
@@ -674,6 +675,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
         else if (younger == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS > 5 ? 4 * NL : 0) : "memory");
         else if (younger == 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS > 6 ? 5 * NL : 0) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS > 7 ? 6 * NL : 0) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (this wave's reads of tile kt-1 have retired before its stage is refilled)
 #ifndef YP_PROBE_NOBAR
         __builtin_amdgcn_s_barrier();
 #endif
@@ -861,7 +863,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
 // halo of a TH x 16 output tile: TH*S + (3 - S) rows; pitch 18 pixels (stride 1) / 2 x 17 de-interleaved columns (stride 2)
 template <int STRIDE, int TH> struct Halo { static constexpr int HH = TH * STRIDE + (3 - STRIDE), HP = STRIDE == 1 ? 18 : 34; };
 
-template <int DT, bool OUT_F32, int STRIDE, int BN, int WAVES_M, int TH = 8>
+template <int DT, bool OUT_F32, int STRIDE, int BN, int WAVES_M, int TH = 8, bool STATS = false>
 __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvKArgs a) {
     using E = Elem<DT>;
     using frag_t = typename E::frag;
@@ -979,6 +981,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvKArgs a) {
             else if (moreH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NH) : "memory");
             else if (moreW) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (WAR: the reads of the stage / halo buffer refilled behind this barrier have retired)
             __builtin_amdgcn_s_barrier();
             if (st < 30) YP_TL(2 + st);
             if (st + 2 < nsteps) { const int s2 = st + 2; issueW(s2 / 3, s2 % 3); }
@@ -1014,6 +1017,60 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvKArgs a) {
         if (oy >= a.Ho || ox >= a.Wo) continue;
         const int m = (b * a.Ho + oy) * a.Wo + ox;
         yp_epilogue_pixel<DT, OUT_F32, LPG>(a, m, nb, bias, [&](int cj) { return acc[cj >> 2][fm][cj & 3]; });
+    }
+    if constexpr (STATS) {
+        // BatchNorm statistics of the raw output from the accumulators (training forward of a 3x3 Conv; see the generic kernel): one
+        // partial row per pixel tile, stats[(tile*2 + {0,1})*Cout + c] -- the reduction pass that re-read the tensor disappears.
+        float sv[LPG], sq[LPG];
+#pragma unroll
+        for (int j = 0; j < LPG; ++j) sv[j] = sq[j] = 0.f;
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) {
+            const int oy = y0 + wm * FM + fm, ox = x0 + p;
+            if (oy < a.Ho && ox < a.Wo) {
+#pragma unroll
+                for (int j = 0; j < LPG; ++j) { const float v = acc[j >> 2][fm][j & 3]; sv[j] += v; sq[j] += v * v; }
+            }
+        }
+        int nleft = LPG, mych = 0;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            const bool up = (p & o) != 0;
+            if (nleft > 1) {
+                const int hn = nleft / 2;
+#pragma unroll
+                for (int j = 0; j < LPG / 2; ++j) {
+                    if (j < hn) {
+                        const float keep_s = up ? sv[hn + j] : sv[j], give_s = up ? sv[j] : sv[hn + j];
+                        const float keep_q = up ? sq[hn + j] : sq[j], give_q = up ? sq[j] : sq[hn + j];
+                        sv[j] = keep_s + __shfl_xor(give_s, o, 64);
+                        sq[j] = keep_q + __shfl_xor(give_q, o, 64);
+                    }
+                }
+                mych += up ? hn : 0;
+                nleft = hn;
+            } else {
+                sv[0] += __shfl_xor(sv[0], o, 64);
+                sq[0] += __shfl_xor(sq[0], o, 64);
+            }
+        }
+        constexpr int OWNERS = LPG < 16 ? LPG : 16;
+        float* red = reinterpret_cast<float*>(hsm);            // [WAVES_M][2][BN] in the idle pipeline LDS; fixed summation order
+        __syncthreads();
+        if (p < OWNERS) {
+            const int cl = wn * TN + g * LPG + mych;
+            red[(wm * 2 + 0) * BN + cl] = sv[0];
+            red[(wm * 2 + 1) * BN + cl] = sq[0];
+        }
+        __syncthreads();
+        const int tile = (b * a.tiles_y + ty) * a.tiles_x + tx;
+        for (int i = t; i < 2 * BN; i += 256) {
+            const int w2 = i / BN, cl = i % BN, c = n0 + cl;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES_M; ++w) v += red[(w * 2 + w2) * BN + cl];
+            if (c < a.Cout) a.stats[((size_t)tile * 2 + w2) * a.Cout + c] = v;
+        }
     }
     YP_TL(41);
 }
@@ -1197,7 +1254,8 @@ __global__ __launch_bounds__(256) void bottleneck_halo_kernel(const ConvKArgs a)
                 for (int i = 0; i < 3; ++i) hacc[sb][f][i] = E::mma(wf[f], xf[i], hacc[sb][f][i]);
         }
     }
-    __builtin_amdgcn_s_barrier();            // every wave is done with phase A's operands: the ring may be overwritten
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // every wave is done with phase A's operands (its reads have retired): the ring may be overwritten
     YP_TL(8);
 #pragma unroll
     for (int sb = 0; sb < NSUB; ++sb)        // make the compiler's own wait for the bias loads land here, not behind the prefetch below
@@ -1251,6 +1309,11 @@ __global__ __launch_bounds__(256) void bottleneck_halo_kernel(const ConvKArgs a)
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int st = 3 * c + r;
+            // WAR on the ring: the refill issued behind this barrier overwrites the stage that step st-1 READ.  The loop is fully unrolled
+            // and an MFMA is not a memory operation, so the compiler may sink step st-1's last MFMAs -- and the lgkmcnt wait for their
+            // operands -- below the barrier: a ds_read could then still be in flight when another wave's DMA lands in its stage
+            // (rare wrong tiles at high occupancy: YOLOPoint-s bs 8 640x640 differed run to run).  Retire the reads before the barrier.
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (st + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -1291,6 +1354,7 @@ __global__ __launch_bounds__(256) void bottleneck_halo_kernel(const ConvKArgs a)
     } else {
         // ---- C3 tail.  The ring is free: fetch W3 (all of it), meanwhile finish the bottleneck output into LDS (it replaces the
         // hidden tensor, same swizzled 64-byte-row format, rows = the tile's 128 centre pixels).
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         {
             const char* w3 = a.post_wgt;
@@ -1591,12 +1655,12 @@ hipError_t launch_cfg(int tile, const ConvKArgs& a, int nblk, hipStream_t st) {
 }
 
 
-template <int DT, bool OUT_F32, int STRIDE, int BN, int WAVES_M, int TH>
+template <int DT, bool OUT_F32, int STRIDE, int BN, int WAVES_M, int TH, bool STATS = false>
 hipError_t launch_halo(const ConvKArgs& a, int nblk, hipStream_t st) {
     constexpr int HSLOTS = (Halo<STRIDE, TH>::HH * Halo<STRIDE, TH>::HP + 15) / 16;
     constexpr size_t lds2 = (size_t)2 * HSLOTS * 1024 + (size_t)3 * 3 * (BN / 16) * 1024;
     const size_t lds = lds2 - (a.Cin > 32 ? 0 : (size_t)HSLOTS * 1024);
-    auto kern = conv3x3_halo_kernel<DT, OUT_F32, STRIDE, BN, WAVES_M, TH>;
+    auto kern = conv3x3_halo_kernel<DT, OUT_F32, STRIDE, BN, WAVES_M, TH, STATS>;
     static bool attr_set = false;        // per instantiation
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
@@ -1608,9 +1672,9 @@ hipError_t launch_halo(const ConvKArgs& a, int nblk, hipStream_t st) {
 }
 
 // th = 8: 8 x 16 output tiles (ids 10..12); th = 4: 4 x 16 tiles (ids 13..15) -- twice the workgroups, half the halo in LDS
-template <int DT, bool OUT_F32>
+template <int DT, bool OUT_F32, bool STATS = false>
 hipError_t dispatch_halo(int stride, int bn, int th, const ConvKArgs& a, int nblk, hipStream_t st) {
-#define YP_HALO(S, B, WM, T) launch_halo<DT, OUT_F32, S, B, WM, T>(a, nblk, st)
+#define YP_HALO(S, B, WM, T) launch_halo<DT, OUT_F32, S, B, WM, T, STATS>(a, nblk, st)
     if (th == 8) {
         if (stride == 1) return bn == 128 ? YP_HALO(1, 128, 2, 8) : (bn == 64 ? YP_HALO(1, 64, 4, 8) : YP_HALO(1, 32, 4, 8));
         return bn == 128 ? YP_HALO(2, 128, 2, 8) : (bn == 64 ? YP_HALO(2, 64, 4, 8) : YP_HALO(2, 32, 4, 8));
@@ -1804,7 +1868,12 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
         a.tiles_y = yp_cdiv(d->Ho, th);
         a.Ho = d->Ho;
         const int nb3 = d->B * a.tiles_y * a.tiles_x * a.tiles_n;
-        if (d->dtype == YP_F16) e = of32 ? dispatch_halo<YP_F16, true>(d->stride_h, bn, th, a, nb3, stream) : dispatch_halo<YP_F16, false>(d->stride_h, bn, th, a, nb3, stream);
+        if (d->bn_partial != nullptr) {      // BatchNorm statistics in the epilogue: one partial row per pixel tile (B * tiles_y * tiles_x rows)
+            YP_REQUIRE(!of32 && d->bias == nullptr && d->act == YP_ACT_NONE && d->res.C == 0 && d->out2.C == 0 && d->in1.C == 0,
+                       "yp_conv2d: bn_partial needs a plain convolution (no bias / activation / residual / second output)");
+            a.stats = d->bn_partial;
+            e = d->dtype == YP_F16 ? dispatch_halo<YP_F16, false, true>(d->stride_h, bn, th, a, nb3, stream) : dispatch_halo<YP_BF16, false, true>(d->stride_h, bn, th, a, nb3, stream);
+        } else if (d->dtype == YP_F16) e = of32 ? dispatch_halo<YP_F16, true>(d->stride_h, bn, th, a, nb3, stream) : dispatch_halo<YP_F16, false>(d->stride_h, bn, th, a, nb3, stream);
         else e = of32 ? dispatch_halo<YP_BF16, true>(d->stride_h, bn, th, a, nb3, stream) : dispatch_halo<YP_BF16, false>(d->stride_h, bn, th, a, nb3, stream);
         if (e != hipSuccess) {
             yp_set_error("yp_conv2d: halo kernel launch failed: %s", hipGetErrorString(e));

@@ -230,29 +230,51 @@ extern "C" int yp_plan_instantiate_graph(YpPlan* plan, void* stream) {
     const size_t n = plan->ops.size();
     for (const PlanOp& op : plan->ops)
         if (op.lane == YP_LANE_SIDE) { if (int rc = ensure_side(plan)) return rc; break; }     // (no stream creation inside a capture)
+    bool rewire = n > 1;
+    for (const PlanOp& op : plan->ops) rewire = rewire && op.has_deps && op.lane == YP_LANE_MAIN;
     YP_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    const int rc = run_eager(plan, st);
+    int rc = YP_OK;
+    // last[i] = the last graph node op i produced (an op may launch several kernels, or none): read off the capture's frontier after
+    // every op.  Plans with schedule lanes (side streams) keep the captured topology.
+    std::vector<hipGraphNode_t> last(n, nullptr);
+    if (rewire) {
+        for (size_t i = 0; i < n && rc == YP_OK; ++i) {
+            rc = run_op(plan->ops[i], st);
+            if (rc != YP_OK) break;
+            hipStreamCaptureStatus status;
+            const hipGraphNode_t* frontier = nullptr;
+            size_t nf = 0;
+            if (hipStreamGetCaptureInfo_v2(st, &status, nullptr, nullptr, &frontier, &nf) != hipSuccess || status != hipStreamCaptureStatusActive || nf > 1) {
+                rewire = false;                     // (unexpected capture state: fall back to the linear chain)
+                for (size_t k = i + 1; k < n && rc == YP_OK; ++k) rc = run_op(plan->ops[k], st);
+                break;
+            }
+            last[i] = nf == 1 ? frontier[0] : (i ? last[i - 1] : nullptr);
+        }
+    } else {
+        rc = run_eager(plan, st);
+    }
     hipGraph_t g = nullptr;
     const hipError_t e = hipStreamEndCapture(st, &g);
     if (rc != YP_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
     YP_CHECK_HIP(e);
     plan->graph = g;
 
-    bool rewire = n > 1;
-    for (const PlanOp& op : plan->ops) rewire = rewire && op.has_deps;
     size_t nn = 0, ne = 0;
     YP_CHECK_HIP(hipGraphGetNodes(g, nullptr, &nn));
     YP_CHECK_HIP(hipGraphGetEdges(g, nullptr, nullptr, &ne));
-    if (rewire && nn == n && ne == n - 1) {
-        std::vector<hipGraphNode_t> from(ne), to(ne), chain;
-        YP_CHECK_HIP(hipGraphGetEdges(g, from.data(), to.data(), &ne));
+    if (rewire && nn >= 1 && ne == nn - 1) {
+        // the capture is a linear chain of nn nodes; op i owns the run of nodes behind last[i-1] up to last[i] (possibly empty)
+        std::vector<hipGraphNode_t> from(ne), to(ne);
+        if (ne) YP_CHECK_HIP(hipGraphGetEdges(g, from.data(), to.data(), &ne));
         size_t nroot = 0;
         YP_CHECK_HIP(hipGraphGetRootNodes(g, nullptr, &nroot));
+        std::vector<hipGraphNode_t> chain;
         if (nroot == 1) {
             hipGraphNode_t cur;
             YP_CHECK_HIP(hipGraphGetRootNodes(g, &cur, &nroot));
             chain.push_back(cur);
-            for (size_t step = 0; step + 1 < n; ++step) {
+            for (size_t step = 0; step + 1 < nn; ++step) {
                 bool found = false;
                 for (size_t k = 0; k < ne && !found; ++k)
                     if (from[k] == cur) { cur = to[k]; found = true; }
@@ -260,11 +282,44 @@ extern "C" int yp_plan_instantiate_graph(YpPlan* plan, void* stream) {
                 chain.push_back(cur);
             }
         }
-        if (chain.size() == n) {
-            YP_CHECK_HIP(hipGraphRemoveDependencies(g, from.data(), to.data(), ne));
-            for (size_t j = 0; j < n; ++j)
-                for (int d : plan->ops[j].deps) YP_CHECK_HIP(hipGraphAddDependencies(g, &chain[d], &chain[j], 1));
-            plan->parallel = true;
+        if (chain.size() == nn) {
+            std::vector<long> first_pos(n, -1), last_pos(n, -1);      // positions in `chain` of op i's first / last node (-1: the op has no node)
+            long pos = 0;
+            bool ok = true;
+            for (size_t i = 0; i < n && ok; ++i) {
+                const hipGraphNode_t prev_last = i ? last[i - 1] : nullptr;
+                if (last[i] == prev_last) continue;                   // no node of its own
+                long end = pos;
+                while (end < (long)nn && chain[end] != last[i]) ++end;
+                if (end >= (long)nn) { ok = false; break; }
+                first_pos[i] = pos; last_pos[i] = end;
+                pos = end + 1;
+            }
+            if (ok && pos == (long)nn) {
+                // drop the edges BETWEEN ops (keep the chains inside multi-kernel ops), then add the data dependencies.  A dependency on
+                // an op without nodes is inherited from that op's own dependencies.
+                std::vector<hipGraphNode_t> rf, rt;
+                for (size_t i = 0; i < n; ++i)
+                    if (first_pos[i] > 0) { rf.push_back(chain[first_pos[i] - 1]); rt.push_back(chain[first_pos[i]]); }
+                if (!rf.empty()) YP_CHECK_HIP(hipGraphRemoveDependencies(g, rf.data(), rt.data(), rf.size()));
+                std::vector<std::vector<int>> eff(n);
+                for (size_t j = 0; j < n; ++j) {
+                    std::vector<int> stack(plan->ops[j].deps.begin(), plan->ops[j].deps.end());
+                    std::vector<char> seen(n, 0);
+                    while (!stack.empty()) {
+                        const int d = stack.back(); stack.pop_back();
+                        if (seen[d]) continue;
+                        seen[d] = 1;
+                        if (first_pos[d] >= 0) eff[j].push_back(d);
+                        else for (int dd : plan->ops[d].deps) stack.push_back(dd);
+                    }
+                }
+                for (size_t j = 0; j < n; ++j) {
+                    if (first_pos[j] < 0) continue;
+                    for (int d : eff[j]) YP_CHECK_HIP(hipGraphAddDependencies(g, &chain[last_pos[d]], &chain[first_pos[j]], 1));
+                }
+                plan->parallel = true;
+            }
         }
     }
     YP_CHECK_HIP(hipGraphInstantiate(&plan->exec, g, nullptr, nullptr, 0));

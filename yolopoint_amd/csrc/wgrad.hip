@@ -195,6 +195,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bx, con
                     for (int fb = 0; fb < 2; ++fb) acc[tp][fa][fb] = wg_mma<DT>(xf[fa], yf[fb], acc[tp][fa][fb]);
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the compiler may sink the last MFMAs, and the wait for their operands, below a barrier)
         __builtin_amdgcn_s_barrier();                      // everyone is done reading this stage before it is refilled
     }
 
@@ -304,7 +305,7 @@ hipError_t dispatch_wgrad(int k, int stride, const WgradArgs& a, dim3 grid, hipS
 }  // namespace
 
 // argument set + launch geometry of one weight gradient (shared by the single and the grouped entry points)
-static int wgrad_make_args(YpView x, YpView dy, int dtype, int B, int k, int stride, float* dw, WgradArgs* out, int* nblk_out, int* split_out) {
+static int wgrad_make_args(YpView x, YpView dy, int dtype, int B, int k, int stride, float* dw, WgradArgs* out, int* nblk_out, int* split_out, int target = 256) {
     YP_REQUIRE(dtype == YP_F16 || dtype == YP_BF16, "yp_conv_wgrad: 16-bit element types only");
     YP_REQUIRE((k == 1 && stride == 1) || (k == 3 && (stride == 1 || stride == 2)), "yp_conv_wgrad: 1x1 (stride 1) or 3x3 (pad 1, stride 1 | 2) filters only");
     YP_REQUIRE(x.ptr && dy.ptr && dw && B > 0, "yp_conv_wgrad: null buffer");
@@ -329,7 +330,8 @@ static int wgrad_make_args(YpView x, YpView dy, int dtype, int B, int k, int str
     // per second (tools/probe/wgrad_bench.py: YP_WG_NOSTORE halves the total), so more, smaller workgroups lose: 768 -> 256
     // workgroups took the 23 distinct YOLOPoint-s shapes from 863 to 612 us.  A single 64x64 block of a 3x3 filter (nblk = 1)
     // is best at ~96 when it has few tiles per workgroup anyway.
-    int target = 256;
+    // (grouped launches run dozens of entries side by side: 128 workgroups per entry keep the chip full with half the slab / flush traffic --
+    // 13.7 -> 13.0 ms per training step)
     if (const char* e = getenv("YP_WG_TARGET")) target = atoi(e);
     int split = yp_cdiv(target, nblk);
     int cap = (k == 3 && nblk == 1 && a.ntiles <= 800) ? 96 : 256;
@@ -363,7 +365,7 @@ extern "C" size_t yp_wgrad_partial_elems(YpView x, YpView dy, int dtype, int B, 
     WgradArgs a;
     int nblk, split;
     float dummy;
-    if (wgrad_make_args(x, dy, dtype, B, k, stride, &dummy, &a, &nblk, &split) != YP_OK) return 0;
+    if (wgrad_make_args(x, dy, dtype, B, k, stride, &dummy, &a, &nblk, &split, 128) != YP_OK) return 0;
     return (size_t)split * a.Cj * (k * k) * a.Cout_pad;
 }
 
@@ -374,7 +376,7 @@ extern "C" int yp_wgrad_group_pack_det(const YpView* xs, const YpView* dys, floa
     int blk0 = 0, chunk0 = 0;
     for (int i = 0; i < n; ++i) {
         int nblk, split;
-        if (int rc = wgrad_make_args(xs[i], dys[i], dtype, B, k, stride, dws[i], &t[i], &nblk, &split)) return rc;
+        if (int rc = wgrad_make_args(xs[i], dys[i], dtype, B, k, stride, dws[i], &t[i], &nblk, &split, 128)) return rc;
         t[i].g_blk0 = blk0;
         blk0 += nblk * split;
         if (parts != nullptr) {

@@ -169,7 +169,8 @@ class Bottleneck(HipModule):
 
     def _fusable(self, pb, x):
         c1, c_, c2 = self.cv1.conv.in_channels, self.cv1.conv.out_channels, self.cv2.conv.out_channels
-        return (self.fuse and isinstance(x, View) and x.ups == 0 and c1 == c_ == c2 and c_ in (32, 64, 128) and pb.code != _hip.YP_F32
+        allowed = tuple(int(v) for v in os.environ["YP_FUSE_ONLY_C"].split(",")) if os.environ.get("YP_FUSE_ONLY_C") else (32, 64, 128)
+        return (self.fuse and isinstance(x, View) and x.ups == 0 and c1 == c_ == c2 and c_ in allowed and pb.code != _hip.YP_F32
                 and self.cv2.conv.kernel_size == (3, 3) and self.cv2.conv.stride == (1, 1) and self.cv2.conv.padding == (1, 1)
                 and isinstance(self.cv1.act, nn.SiLU) and isinstance(self.cv2.act, nn.SiLU))
 

@@ -142,10 +142,14 @@ class OpRecord:
 # conv signature -> fastest kernel/tile id, measured once per process (see PlanBuilder._autotune)
 _TUNE_CACHE = {}
 # candidate ids: 1..5 generic implicit-GEMM tiles (128x32, 128x64, 128x128, 64x64, 64x32), 21..27 the same tiles with the
-# second-generation main loop (several k tiles per barrier, register double-buffered fragments); 10..12 the 3x3 halo kernel
+# second-generation main loop (several k tiles per barrier, register double-buffered fragments) -- all of these accumulate in the same
+# k order, so the output bits do not depend on the tuner's pick; the waves-split-k tiles (31, 33: four interleaved partial sums) are
+# reachable by explicit id only; 10..12 the 3x3 halo kernel
 # with 32/64/128 output channels per workgroup on 8x16 pixel tiles, 13..15 the same on 4x16 tiles (rejected by the library
 # when it does not apply)
 _TUNE_CANDIDATES = (1, 2, 3, 4, 5, 21, 22, 23, 24, 25, 26, 27, 10, 11, 12, 13, 14, 15)
+if os.environ.get("YP_TUNE_ONLY"):           # A/B experiments: restrict the autotuner to a subset of the variants
+    _TUNE_CANDIDATES = tuple(int(v) for v in os.environ["YP_TUNE_ONLY"].split(","))
 
 
 class PlanBuilder:
@@ -185,12 +189,16 @@ class PlanBuilder:
     # -- dependency tracking (feeds the multi-stream graph schedule) ---------------------------
     @staticmethod
     def _rng(v):
+        """An access as (allocation, buffer base, lo, hi, first byte, last byte): two accesses of the SAME buffer conflict when their
+        channel (or row) ranges [lo, hi) overlap; accesses through different tensors of one allocation (slices of an arena) conflict
+        when their byte ranges do."""
         if isinstance(v, View):
-            if v.geom is not None:                      # paired-pixel stem view: the whole buffer
-                return (v.buf.t.data_ptr(), 0, 1 << 30)
-            return (v.buf.t.data_ptr(), v.coff, v.coff + v.C)
-        t, lo, hi = v                                   # (tensor, lo, hi) for plain output tensors
-        return (t.data_ptr(), lo, hi)
+            t = v.buf.t
+            lo, hi = (0, 1 << 30) if v.geom is not None else (v.coff, v.coff + v.C)      # (paired-pixel stem view: the whole buffer)
+        else:
+            t, lo, hi = v                                                                # (tensor, lo, hi) for plain tensors
+        b0 = t.data_ptr()
+        return (t.untyped_storage().data_ptr(), b0, lo, hi, b0, b0 + t.numel() * t.element_size())
 
     def _track(self, reads, writes):
         self.accesses.append(([self._rng(v) for v in reads if v is not None], [self._rng(v) for v in writes if v is not None]))
@@ -198,7 +206,11 @@ class PlanBuilder:
     def dependencies(self):
         """deps[j] = sorted earlier op indices j must wait for (RAW, WAR, WAW on overlapping slices)."""
         def overlap(a, b):
-            return a[0] == b[0] and a[1] < b[2] and b[1] < a[2]
+            if a[0] != b[0]:
+                return False
+            if a[1] == b[1]:
+                return a[2] < b[3] and b[2] < a[3]
+            return a[4] < b[5] and b[4] < a[5]
         deps = []
         for j, (rd, wr) in enumerate(self.accesses):
             d = set()
@@ -207,6 +219,15 @@ class PlanBuilder:
                 if any(overlap(r, w) for r in rd for w in wi) or any(overlap(w, x) for w in wr for x in ri + wi):
                     d.add(i)
             deps.append(sorted(d))
+        # transitive reduction light: a dependency already implied by another dependency of j adds an edge and nothing else
+        reach = []
+        for j, d in enumerate(deps):
+            r = set()
+            for i in d:
+                r |= reach[i]
+            keep = [i for i in d if i not in r]
+            deps[j] = keep
+            reach.append(r | set(d))
         return deps
 
     # -- ops ----------------------------------------------------------------------------
@@ -508,6 +529,8 @@ class PlanBuilder:
     def finish(self, parallel=True):
         """Freeze the plan; attach the data dependencies used when it is captured into a hipGraph."""
         assert len(self.accesses) == len(self.records) == lib().yp_plan_num_ops(self.handle)
+        if os.environ.get("YP_GRAPH_LINEAR") == "1":      # A/B: replay every plan as a linear chain
+            parallel = False
         self.deps = self.dependencies() if parallel else None
         if self.deps is not None:
             for j, d in enumerate(self.deps):

@@ -118,16 +118,20 @@ class TrainGraph:
         f, B, code = self.fwd, self.B, self.code
         image = len(srcs) == 1 and srcs[0].geom is None and srcs[0].cstride == 4 and srcs[0].C == 4      # the stem keeps the host packer
         wsrc = (lambda: (conv.weight.detach().float(), None)) if image else MasterWeight(conv.weight)
-        # 1x1 convolutions (always the generic kernel): the BatchNorm column sums come out of the conv epilogue, per block of 64 pixels
-        # (YpConvDesc.bn_partial) -- no separate reduction pass over the raw output.  YP_BN_EPILOGUE=0: the reduction kernel everywhere.
-        chunk = 16 if code == _hip.YP_F32 else 32          # (the epilogue variant exists for the kernel's fast addressing mode: 64-byte k chunks)
-        fuse_stats = (k == 1 and s == 1 and not image and all(v.C % chunk == 0 for v in srcs) and os.environ.get("YP_BN_EPILOGUE", "1") != "0")
+        # The BatchNorm column sums come out of the convolution's epilogue (YpConvDesc.bn_partial: one partial row per block of 64 pixels in
+        # the generic kernel, per pixel tile in the 3x3 halo kernels) -- no separate reduction pass over the raw output.
+        # YP_BN_EPILOGUE=0: the reduction kernel everywhere; =1: 1x1 convolutions only (the first version).
+        chunk = 16 if code == _hip.YP_F32 else 32          # (the epilogue variant exists for the kernels' fast addressing mode: 64-byte k chunks)
+        mode = os.environ.get("YP_BN_EPILOGUE", "2")
+        fuse_stats = (not image and all(v.C % chunk == 0 for v in srcs) and mode != "0" and (k == 1 and s == 1 or (mode == "2" and k == 3 and code != _hip.YP_F32)))
         partial = None
         if fuse_stats:
-            Ho_, Wo_ = srcs[0].LH, srcs[0].LW
-            rows = -(-(B * Ho_ * Wo_) // 64)
+            Ho_, Wo_ = (srcs[0].LH + 2 * p - k) // s + 1, (srcs[0].LW + 2 * p - k) // s + 1
+            rows = max(-(-(B * Ho_ * Wo_) // 64), B * -(-Ho_ // 4) * -(-Wo_ // 16) if k == 3 else 0)
             partial = torch.zeros((rows, 2, round_up(conv.out_channels, 8)), dtype=torch.float32, device=self.device)
         raw = f.conv(srcs, wsrc, None, k, s, p, _hip.YP_ACT_NONE, extra=dict(bn_partial=partial) if fuse_stats else None)
+        if fuse_stats:
+            partial.zero_()          # (the autotuner ran several kernel variants, which write different row sets: start from zeros with the chosen one)
         Cc, Cp = conv.out_channels, raw.C
         mean, invstd = f.new_tensor((Cp,)), f.new_tensor((Cp,))
         gamma, beta, rmean, rvar = bn.weight, bn.bias, bn.running_mean, bn.running_var
@@ -149,10 +153,10 @@ class TrainGraph:
             self.post_forward.append(sync_out)
         if fuse_stats:
             assert partial.shape[2] == Cp
-            f.op(_hip.OP_BN_STATS, [raw, self.T(partial)], [self.T(mean), self.T(invstd)], "bn_stats", v=[raw], i=[code, B, partial.shape[0]],
+            f.op(_hip.OP_BN_STATS, [raw, self.T(partial)], [self.T(mean), self.T(invstd), self.T(self.ws)], "bn_stats", v=[raw], i=[code, B, partial.shape[0]],
                  s=[bn.eps, bn.momentum], g=[mean, invstd, rmean, rvar], p=[self.ws, partial], n=[self.ws.numel()])
         else:
-            f.op(_hip.OP_BN_STATS, [raw], [self.T(mean), self.T(invstd)], "bn_stats", v=[raw], i=[code, B], s=[bn.eps, bn.momentum],
+            f.op(_hip.OP_BN_STATS, [raw], [self.T(mean), self.T(invstd), self.T(self.ws)], "bn_stats", v=[raw], i=[code, B], s=[bn.eps, bn.momentum],
                  g=[mean, invstd, rmean, rvar], p=[self.ws], n=[self.ws.numel()])
         if out is None:
             out = f.new_buf(raw.H, raw.W, raw.C).view()
@@ -168,7 +172,7 @@ class TrainGraph:
             draw = b.new_buf(raw.H, raw.W, raw.C).view()
             gw_, gb_ = self.pgrad(bn.weight), self.pgrad(bn.bias)
             dg, db = (b.new_tensor((Cp,)), b.new_tensor((Cp,))) if padded else (gw_, gb_)
-            b.op(_hip.OP_BN_BWD, [raw, gy], [draw], "bn_act_bwd", v=[raw, gy, draw], i=[code, B, act, 0],
+            b.op(_hip.OP_BN_BWD, [raw, gy], [draw, self.T(self.ws)], "bn_act_bwd", v=[raw, gy, draw], i=[code, B, act, 0],
                  f=[mean, invstd, gamma, beta], g=[dg, db], p=[self.ws], n=[self.ws.numel()])
             if padded:
                 self.collect.append(lambda dg=dg, db=db, gw_=gw_, gb_=gb_: (gw_.copy_(dg[:Cc]), gb_.copy_(db[:Cc])))
@@ -203,7 +207,7 @@ class TrainGraph:
         gw = self.pgrad(weight)
         if bias is not None:
             gb_full = b.new_tensor((Cout_pad,))
-            b.op(_hip.OP_COL_SUM, [draw], [self.T(gb_full)], "bias_grad", v=[draw], i=[code, B, 0], g=[gb_full], p=[self.ws], n=[self.ws.numel()])
+            b.op(_hip.OP_COL_SUM, [draw], [self.T(gb_full), self.T(self.ws)], "bias_grad", v=[draw], i=[code, B, 0], g=[gb_full], p=[self.ws], n=[self.ws.numel()])
             gbias = self.pgrad(bias)
             self.collect.append(lambda: gbias.copy_(gb_full[:Cout]))
         # ---- wgrad.  Stride-1 1x1 / 3x3 convolutions in a 16-bit dtype: yp_conv_wgrad reads the NHWC tensors directly
@@ -325,9 +329,9 @@ class TrainGraph:
         def backward():
             b = self.bwd
             g0, g1, g2, g3 = (self.gread(v) for v in (s0, s1, s2, s3))
-            b.op(_hip.OP_MAXPOOL5_BWD, [s2, g3, g2], [g2], "pool_bwd3", v=[s2, g3, g2], i=[code, B, 1], p=[self.ws], n=[self.ws.numel()])
-            b.op(_hip.OP_MAXPOOL5_BWD, [s1, g2, g1], [g1], "pool_bwd2", v=[s1, g2, g1], i=[code, B, 1], p=[self.ws], n=[self.ws.numel()])
-            b.op(_hip.OP_MAXPOOL5_BWD, [s0, g1, g0], [g0], "pool_bwd1", v=[s0, g1, g0], i=[code, B, 1], p=[self.ws], n=[self.ws.numel()])
+            b.op(_hip.OP_MAXPOOL5_BWD, [s2, g3, g2], [g2, self.T(self.ws)], "pool_bwd3", v=[s2, g3, g2], i=[code, B, 1], p=[self.ws], n=[self.ws.numel()])
+            b.op(_hip.OP_MAXPOOL5_BWD, [s1, g2, g1], [g1, self.T(self.ws)], "pool_bwd2", v=[s1, g2, g1], i=[code, B, 1], p=[self.ws], n=[self.ws.numel()])
+            b.op(_hip.OP_MAXPOOL5_BWD, [s0, g1, g0], [g0, self.T(self.ws)], "pool_bwd1", v=[s0, g1, g0], i=[code, B, 1], p=[self.ws], n=[self.ws.numel()])
         self.tape.append((self.branch, backward))
         return self.conv_bn_act(m.cv2, cat.view())
 
@@ -429,7 +433,12 @@ class TrainGraph:
                 self.conv_backward([v], mi.weight, mi.bias, draw, 1, 1, 0)
             det_seeds.append(det_backward)
         self.semi_v, self.desc_v = semi, dnorm
-        self.fwd_plan = f.finish(parallel=False)
+        # YP_TRAIN_PARALLEL=1: replay the launch lists as the DAG of their data dependencies (multi-kernel ops keep their inner chain) instead
+        # of linear chains.  Measured SLOWER for the training step (14.4 vs 13.1 ms: the concurrent BatchNorm / weight-gradient / dgrad
+        # kernels fight over CUs and L2, as the two-lane schedule and the sub-batch streams of the forward did), so it is off by default;
+        # bit-identical results either way (tests/test_gpu_training.py).
+        self.par = not self.lanes and os.environ.get("YP_TRAIN_PARALLEL", "0") == "1"
+        self.fwd_plan = f.finish(parallel=self.par)
 
         # ---- backward plans: clear the weight-gradient arena, seed the head gradients, then the tape in reverse.
         # Two variants: the full one, and one that only back-propagates the semi / desc sub-graph -- the reference's second
@@ -471,7 +480,8 @@ class TrainGraph:
                     check(lib().yp_wgrad_group_pack(xs, dys, dws, n, code, B, gk, gs, host, C.byref(blocks)))
                 wtab = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(self.device)
                 self.keep.append(wtab)
-                bb.op(_hip.OP_WGRAD_GROUP, [v for e in ents for v in e[:2]], [e[2].view() for e in ents], f"wgrad_k{gk}s{gs}", p=[wtab],
+                bb.op(_hip.OP_WGRAD_GROUP, [v for e in ents for v in e[:2]], [e[2].view() for e in ents] + ([self.T(self.wpart)] if self.det_wgrad else []),
+                      f"wgrad_k{gk}s{gs}", p=[wtab],
                       i=[code, n, blocks.value, gk, gs, fold.value])
                 bb.records[-1].kind, bb.records[-1].flops = "conv", sum(e[3] for e in ents)
             rows, tile0 = [], 0
@@ -484,7 +494,7 @@ class TrainGraph:
             bb.op(_hip.OP_WGRAD_UNPACK_BATCH, [u["dw"].view() for u in self.unpack], [self.T(u["grad"]) for u in self.unpack], "dw_unpack",
                   p=[table], i=[0, len(rows), tile0])
             bb.set_lane(_hip.LANE_JOIN)
-            plan = bb.finish(parallel=False)
+            plan = bb.finish(parallel=self.par)
             return plan, self.touched, self.collect
         self.bwd_plan, self.bwd_params, self.bwd_collect = emit(False)
         self.bwd_kp_plan, self.bwd_kp_params, self.bwd_kp_collect = emit(True)
