@@ -102,9 +102,15 @@ def main():
                 tot["conv"][0] += busy; tot["conv"][1] += act
                 if per and layers[i % per].split(".")[0] in bbn:
                     tot["backbone"][0] += busy; tot["backbone"][1] += act
-        util = {k: (v[0] / (v[1] * 4 * 256) if v[1] else None) for k, v in tot.items()}
+        # Calibration (tools/probe/pmc_calib.sh, same pass = counters + kernel trace): SQ_VALU_MFMA_BUSY_CYCLES is the sum over all SIMDs of
+        # their MFMA-busy cycles -- exactly 16 cycles x the number of v_mfma_f32_16x16x32 instructions (102 400 MFMAs of a 256->256 1x1
+        # layer at M = 12 800 -> 1 638 400) -- and GRBM_GUI_ACTIVE is reported summed over 16 counter instances on this stack (value /
+        # dispatch duration = 30-35 per ns at a ~2.1 GHz clock).  Utilisation = busy SIMD-cycles / (GPU-active cycles x 1024 SIMDs).
+        GUI_INSTANCES = 16
+        util = {k: (v[0] / (v[1] / GUI_INSTANCES * 4 * 256) if v[1] else None) for k, v in tot.items()}
         rec = {"source": f"gpurun_out/prof_{R}: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (own pass, --kernel-trace only) of `{res['command']} --no-graph`",
-               "formula": "sum(SQ_VALU_MFMA_BUSY_CYCLES) / (sum(GRBM_GUI_ACTIVE) x 4 SIMDs x 256 CUs) over the dispatches of the plan replays",
+               "formula": "sum(SQ_VALU_MFMA_BUSY_CYCLES) / (sum(GRBM_GUI_ACTIVE) / 16 instances x 4 SIMDs x 256 CUs) over the dispatches of the plan replays; "
+                          "calibrated: MFMA_BUSY = 16 cycles x (number of 16x16x32 MFMAs), GUI_ACTIVE / duration = 16 x clock",
                "workload": "YOLOPoint-s bs8 640x640 f16", "dispatches": len(order),
                "mfma_busy_all_kernels": util["all"], "mfma_busy_conv_kernels": util["conv"], "mfma_busy_backbone_convs": util["backbone"]}
         json.dump(rec, open(os.path.join(OUT, "mfma_busy.json"), "w"), indent=1)
