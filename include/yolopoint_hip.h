@@ -134,6 +134,10 @@ typedef struct YpConvDesc {
     int64_t split_stride;
 } YpConvDesc;
 
+/* Number of bn_partial rows the launch described by `d` (its tile id included) writes; rows are batch-major, so with `groups` statistics
+ * groups the rows of group g are [g*rows/groups, (g+1)*rows/groups) -- for the generic kernel only when B/groups*Ho*Wo is a multiple of 64. */
+int yp_conv_bn_partial_rows(const YpConvDesc* d, int* rows);
+
 /* dst[i] = slabs[0][i] + slabs[1][i] + ... + slabs[n_slabs-1][i], summed in that order (the fold of a deterministic split-K). */
 int yp_sum_slabs(const float* slabs, float* dst, size_t elems, int n_slabs, void* stream);
 
@@ -211,6 +215,21 @@ int yp_bn_act_apply(YpView raw, YpView out, YpView res, int dtype, int B, const 
 int yp_bn_act_bwd(YpView raw, YpView dy, YpView dx, int dtype, int B, const float* mean, const float* invstd,
                   const float* gamma, const float* beta, int act, float* dgamma, float* dbeta, int accumulate_param_grads,
                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same four passes with `groups` statistics groups: the B samples are `groups` consecutive sets of B/groups samples, each normalised with
+ * its own batch statistics -- what the reference computes when it calls the module once per set (src/train.py:208,220: model(img), then
+ * model(img_warp)), in ONE launch per pass.  mean / invstd: [groups][C]; the running statistics take one momentum update per group, in group
+ * order; dgamma / dbeta sum over the groups; yp_bn_act_bwd_grouped needs workspace >= yp_bn_workspace_bytes + 8*groups*C bytes.
+ * yp_bn_finalize_grouped: `rows` partial rows and M pixels in total, rows/groups and M/groups per group.  groups <= 8, B % groups == 0. */
+int yp_bn_stats_grouped(YpView raw, int dtype, int B, int groups, float eps, float momentum, float* mean, float* invstd, float* running_mean,
+                        float* running_var, void* workspace, size_t workspace_bytes, void* stream);
+int yp_bn_finalize_grouped(const float* partial, int rows, int groups, int C, double M, float eps, float momentum, float* mean, float* invstd,
+                           float* running_mean, float* running_var, void* stream);
+int yp_bn_act_apply_grouped(YpView raw, YpView out, YpView res, int dtype, int B, int groups, const float* mean, const float* invstd,
+                            const float* gamma, const float* beta, int act, void* stream);
+int yp_bn_act_bwd_grouped(YpView raw, YpView dy, YpView dx, int dtype, int B, int groups, const float* mean, const float* invstd,
+                          const float* gamma, const float* beta, int act, float* dgamma, float* dbeta, int accumulate_param_grads,
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* out (+)= 2x2 block sums of `in` (backward of nn.Upsample(2,'nearest'), models/YOLOPoint.py:192) */
 int yp_ups2_bwd(YpView in, YpView out, int dtype, int B, int accumulate, void* stream);
@@ -341,9 +360,9 @@ int yp_detloss(const float* semi, const int64_t* semi_strides, const float* targ
  * order documented next to each opcode.  Lets training plans replay any mix of launches (yp_plan_add_op). */
 enum {
     YP_OP_BN_STATS = 10,      /* v0=raw; i0=dtype i1=B; s0=eps s1=momentum; g0=mean g1=invstd g2=running_mean g3=running_var; p0=ws n0=ws_bytes;
-                                 i2=rows > 0: finalize only (yp_bn_finalize) from p1 = the partial sums a convolution wrote */
-    YP_OP_BN_APPLY = 11,      /* v0=raw v1=out v2=res; i0=dtype i1=B i2=act; f0=mean f1=invstd f2=gamma f3=beta */
-    YP_OP_BN_BWD = 12,        /* v0=raw v1=dy v2=dx; i0=dtype i1=B i2=act i3=accumulate; f0..f3 as above; g0=dgamma g1=dbeta; p0=ws n0=ws_bytes */
+                                 i2=rows > 0: finalize only (yp_bn_finalize) from p1 = the partial sums a convolution wrote; i3=groups (0 = 1) */
+    YP_OP_BN_APPLY = 11,      /* v0=raw v1=out v2=res; i0=dtype i1=B i2=act i3=groups; f0=mean f1=invstd f2=gamma f3=beta */
+    YP_OP_BN_BWD = 12,        /* v0=raw v1=dy v2=dx; i0=dtype i1=B i2=act i3=accumulate i4=groups; f0..f3 as above; g0=dgamma g1=dbeta; p0=ws n0=ws_bytes */
     YP_OP_UPS2_BWD = 13,      /* v0=in v1=out; i0=dtype i1=B i2=accumulate */
     YP_OP_ADD_VIEWS = 14,     /* v0=src v1=dst; i0=dtype i1=B i2=accumulate */
     YP_OP_MAXPOOL5_BWD = 15,  /* v0=x v1=dy v2=dx; i0=dtype i1=B i2=accumulate; p0=ws n0=ws_bytes */

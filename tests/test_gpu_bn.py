@@ -63,3 +63,55 @@ def test_bn_forward_backward(cuda, C, B, H, W, act, with_res):
     assert float((got_dx - x.grad).norm() / x.grad.norm()) < 1e-2
     assert torch.allclose(dgamma, g_.grad, rtol=2e-3, atol=2e-4 * float(g_.grad.abs().max()))
     assert torch.allclose(dbeta, b_.grad, rtol=2e-3, atol=2e-4 * float(b_.grad.abs().max()))
+
+
+@pytest.mark.parametrize("C,B,H,W,act,with_res,groups", [(32, 8, 40, 40, 1, False, 2), (64, 4, 20, 24, 1, True, 2), (72, 6, 16, 16, 1, False, 2),
+                                                          (256, 16, 20, 20, 1, False, 2), (128, 6, 9, 11, 0, True, 3), (512, 16, 80, 80, 1, False, 2)])
+def test_bn_statistics_groups(cuda, C, B, H, W, act, with_res, groups):
+    """`groups` consecutive sample sets, each normalised with its own batch statistics in one launch per pass == the module called once per
+    set, in order (reference train.py:208,220: model(img), model(img_warp)): outputs, running statistics after BOTH updates, input
+    gradients per set, parameter gradients summed over the sets.  C = 72 takes the general kernels (C/8 not a power of two), (512, 16, 80,
+    80) the 256-thread fold."""
+    torch.manual_seed(C + H + groups)
+    l, st = lib(), _hip.stream_ptr()
+    code = _hip.YP_BF16
+    raw = (torch.randn(B, H, W, C + 8, device=cuda) * 1.7 + 0.3)
+    raw[B // groups:] = raw[B // groups:] * 0.5 - 1.0            # (the sets have visibly different statistics)
+    raw = raw.to(torch.bfloat16)
+    res = torch.randn(B, H, W, C, device=cuda).to(torch.bfloat16)
+    dy = (torch.randn(B, H, W, C, device=cuda) * 0.1).to(torch.bfloat16)
+    gamma, beta = torch.rand(C, device=cuda) + 0.5, torch.randn(C, device=cuda) * 0.2
+    rmean, rvar = torch.randn(C, device=cuda) * 0.1, torch.rand(C, device=cuda) + 0.5
+    rm_ref, rv_ref = rmean.clone(), rvar.clone()
+    eps, mom = 1e-3, 0.03
+    mean, invstd = torch.zeros(groups, C, device=cuda), torch.zeros(groups, C, device=cuda)
+    out = torch.zeros(B, H, W, C, device=cuda, dtype=torch.bfloat16)
+    dx = torch.zeros_like(out)
+    dgamma, dbeta = torch.full((C,), 7.0, device=cuda), torch.full((C,), -3.0, device=cuda)
+    vr, vo, vres, vdy, vdx = view(raw, 8, C), view(out, 0, C), view(res, 0, C) if with_res else NULLV, view(dy, 0, C), view(dx, 0, C)
+    nb = l.yp_bn_workspace_bytes(B, H, W, C) + 8 * groups * C + 4096
+    ws = torch.empty(nb, dtype=torch.uint8, device=cuda)
+    check(l.yp_bn_stats_grouped(vr, code, B, groups, eps, mom, mean.data_ptr(), invstd.data_ptr(), rmean.data_ptr(), rvar.data_ptr(), ws.data_ptr(), nb, st))
+    check(l.yp_bn_act_apply_grouped(vr, vo, vres, code, B, groups, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), act, st))
+    check(l.yp_bn_act_bwd_grouped(vr, vdy, vdx, code, B, groups, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), act,
+                                  dgamma.data_ptr(), dbeta.data_ptr(), 0, ws.data_ptr(), nb, st))
+    torch.cuda.synchronize()
+    g_, b_ = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    Bg = B // groups
+    for g in range(groups):
+        sl = slice(g * Bg, (g + 1) * Bg)
+        x = raw[sl, ..., 8:8 + C].float().permute(0, 3, 1, 2).contiguous().requires_grad_()
+        y = torch.nn.functional.batch_norm(x, rm_ref, rv_ref, g_, b_, True, mom, eps)          # (updates rm_ref / rv_ref in place, set after set)
+        y = torch.nn.functional.silu(y) if act else y
+        ref_out = y + (res[sl].float().permute(0, 3, 1, 2) if with_res else 0)
+        y.backward(dy[sl].float().permute(0, 3, 1, 2))
+        assert torch.allclose(mean[g], x.detach().mean((0, 2, 3)), rtol=1e-4, atol=1e-5)
+        assert torch.allclose(invstd[g], 1.0 / torch.sqrt(x.detach().var((0, 2, 3), unbiased=False) + eps), rtol=1e-4)
+        got_out = out[sl].float().permute(0, 3, 1, 2)
+        assert float((got_out - ref_out.detach()).abs().max() / ref_out.detach().abs().max()) < 1e-2
+        got_dx = dx[sl].float().permute(0, 3, 1, 2)
+        assert float((got_dx - x.grad).norm() / x.grad.norm()) < 1e-2
+    assert torch.allclose(rmean, rm_ref, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(rvar, rv_ref, rtol=1e-4)
+    assert torch.allclose(dgamma, g_.grad, rtol=2e-3, atol=2e-4 * float(g_.grad.abs().max()))
+    assert torch.allclose(dbeta, b_.grad, rtol=2e-3, atol=2e-4 * float(b_.grad.abs().max()))

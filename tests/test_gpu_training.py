@@ -386,6 +386,84 @@ def test_backward_matches_reference_golden(cuda, tag, version, B, S, seed):
     print(tag, "worst normalised deviation from the reference gradients:", worst)
 
 
+@pytest.mark.parametrize("name,version,B,H,W", [("YOLOPoint", "n", 2, 64, 64), ("YOLOPoint", "s", 3, 128, 64), ("YOLOPointv52", "n", 2, 64, 128)])
+def test_pair_pass_matches_two_oracle_passes(cuda, name, version, B, H, W):
+    """forward_pair(img, img_warp) == model(img); model(img_warp) of the reference step (train.py:208,220) run through the oracle one
+    after the other: outputs of both passes, BatchNorm running statistics after both updates, and every parameter gradient of a loss
+    over the image pass's three heads and the warped pass's semi / desc (fp32 compute path: the two-call bars)."""
+    m, sd = make_model(version, 41, dtype="f32", model_name=name)
+    m = m.to(cuda).train()
+    x, xw = net_oracle.synth_image(B, 3, H, W, 41), net_oracle.synth_image(B, 3, H, W, 42)
+    fwd = net_oracle.yolopointv52_forward if name == "YOLOPointv52" else net_oracle.yolopoint_forward
+    leaf = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in sd.items()}
+    st1, st2 = {}, {}
+    ref = fwd(leaf, x, version, training=True, stats=st1)
+    ref_w = fwd({**leaf, **st1}, xw, version, training=True, stats=st2)
+    g = torch.Generator().manual_seed(7)
+    proj = {k: torch.randn(ref[k].shape, generator=g) for k in ("semi", "desc")}
+    proj_w = {k: torch.randn(ref[k].shape, generator=g) for k in ("semi", "desc")}
+    proj_o = [torch.randn(t.shape, generator=g) for t in ref["objects"]]
+
+    def loss_of(o, ow, dev):
+        l = (o["semi"] * proj["semi"].to(dev)).sum() * 0.01 + (o["desc"] * proj["desc"].to(dev)).sum()
+        l = l + (ow["semi"] * proj_w["semi"].to(dev)).sum() * 0.01 + (ow["desc"] * proj_w["desc"].to(dev)).sum()
+        for t, p in zip(o["objects"], proj_o):
+            l = l + (t * p.to(dev)).sum() * 0.01
+        return l
+    loss_of(ref, ref_w, "cpu").backward()
+    out, out_w, heads, graph = m.model.forward_pair(x.to(cuda), xw.to(cuda))
+    assert out_w["objects"] is None and graph.G == 2
+    for k in ("semi", "desc"):
+        assert rel_err(out[k], ref[k].detach())[0] < 1e-3 and rel_err(out_w[k], ref_w[k].detach())[0] < 1e-3, k
+    for t, r in zip(out["objects"], ref["objects"]):
+        assert rel_err(t, r.detach())[0] < 1e-3
+    sd2 = m.state_dict()
+    for k, v in st2.items():                        # running statistics after the image pass's AND the warped pass's update
+        np.testing.assert_allclose(sd2[k].cpu().numpy(), v.numpy(), rtol=3e-4, atol=2e-5, err_msg=k)
+    assert int(sd2["model.Conv1.bn.num_batches_tracked"]) == 2
+    loss_of(out, out_w, cuda).backward()
+    worst = []
+    for pname, p in m.named_parameters():
+        gref = leaf[pname].grad
+        assert p.grad is not None and gref is not None, pname
+        e_max, e_l2 = rel_err(p.grad, gref)
+        worst.append((e_l2, pname))
+        assert e_l2 < 2e-3, (pname, e_max, e_l2)
+    print("pair pass: largest gradient rel-L2 errors:", sorted(worst)[-3:])
+
+
+def test_pair_pass_matches_two_graph_schedule_bf16(cuda):
+    """bf16 (the benchmarked dtype), YOLOPoint-s at 2 x 4 x 256 x 256: the one-pass schedule against the two-graph schedule of the same
+    build on the same weights -- heads within bf16 rounding, gradients within the bf16 noise between two valid schedules."""
+    import copy
+    from yolopoint_amd.training import run_native_backward, run_native_backward_pair
+    m, _ = make_model("s", 43, dtype="bf16")
+    m = m.to(cuda).train()
+    m2 = copy.deepcopy(m)
+    x, xw = net_oracle.synth_image(4, 3, 256, 256, 43).to(cuda), net_oracle.synth_image(4, 3, 256, 256, 44).to(cuda)
+    o1, raw1, g1 = m.model.forward_with_graph(x)
+    o1w, raw1w, g1w = m.model.forward_with_graph(xw)
+    o2, o2w, heads, g2 = m2.model.forward_pair(x, xw)
+    for k in ("semi", "desc"):
+        assert rel_err(o2[k], o1[k])[1] < 1e-2 and rel_err(o2w[k], o1w[k])[1] < 1e-2, k
+    for a, b in zip(o2["objects"], o1["objects"]):
+        assert rel_err(a, b)[1] < 5e-2          # (the deepest tensors: ~60 bf16 layers with batch-statistics BN between two tile schedules)
+    for (k, a), b in zip(m.state_dict().items(), m2.state_dict().values()):
+        if "running" in k:
+            assert rel_err(b, a)[1] < 2e-3, k
+    gen = torch.Generator(device=cuda).manual_seed(9)
+    gs = [torch.randn(t.shape, device=cuda, generator=gen) * 1e-2 for t in raw1] + [torch.randn(t.shape, device=cuda, generator=gen) * 1e-2 for t in raw1w[:2]]
+    n = len(raw1)
+    run_native_backward(g1, gs[0], gs[1], gs[2:n])
+    run_native_backward(g1w, gs[n], gs[n + 1], [None] * (n - 2))
+    order = []
+    run_native_backward_pair(g2, torch.cat((gs[0], gs[n])), torch.cat((gs[1], gs[n + 1])), gs[2:n], notify=lambda ps: order.append(len(ps)))
+    assert len(order) == 2 and order[0] > 0 and order[1] > 0
+    errs = sorted((rel_err(p2.grad, p1.grad)[1], k) for (k, p1), p2 in zip(m.named_parameters(), m2.parameters()))
+    print("pair vs two-graph bf16: median / worst gradient rel-L2:", errs[len(errs) // 2], errs[-1])
+    assert errs[len(errs) // 2][0] < 0.1 and errs[-1][0] < 0.6
+
+
 def test_bucket_plan_matches_the_backward_plans(cuda):
     """training.grad_ready_groups (a pure walk over the module names, what the CPU gloo tests use) names exactly the parameters the
     keypoint-only backward plan of a real TrainGraph reaches."""
@@ -399,6 +477,11 @@ def test_bucket_plan_matches_the_backward_plans(cuda):
         assert set(id(p) for p in groups["keypoint"]) == set(id(p) for p in graph.bwd_kp_params), name
         assert set(id(p) for p in groups["keypoint"] + groups["detector"]) == set(id(p) for p in graph.bwd_params), name
         graph.busy = False
+        # pair mode: the YOLO-branch plan reaches exactly the detector group, the trunk plan exactly the keypoint group
+        _, _, _, pg = m.model.forward_pair(x, x.flip(0))
+        assert set(id(p) for p in groups["detector"]) == set(id(p) for p in pg.bwd_params), name
+        assert set(id(p) for p in groups["keypoint"]) == set(id(p) for p in pg.bwd_kp_params), name
+        pg.busy = False
 
 
 def test_gradient_accumulation_and_overlapped_reducer_on_one_gpu(cuda):

@@ -86,6 +86,11 @@ SIGNATURES = {
     "yp_conv_wgrad": (_i, [YpView, YpView, _i, _i, _i, _i, _p, _p]),
     "yp_plan_set_lane": (_i, [_p, _i, _i]),
     "yp_bn_finalize": (_i, [_p, _i, _i, C.c_double, _f, _f, _p, _p, _p, _p, _p]),
+    "yp_bn_stats_grouped": (_i, [YpView, _i, _i, _i, _f, _f, _p, _p, _p, _p, _p, _sz, _p]),
+    "yp_bn_finalize_grouped": (_i, [_p, _i, _i, _i, C.c_double, _f, _f, _p, _p, _p, _p, _p]),
+    "yp_bn_act_apply_grouped": (_i, [YpView, YpView, YpView, _i, _i, _i, _p, _p, _p, _p, _i, _p]),
+    "yp_bn_act_bwd_grouped": (_i, [YpView, YpView, YpView, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _i, _p, _sz, _p]),
+    "yp_conv_bn_partial_rows": (_i, [_p, _p]),
     "yp_wgrad_group_entry_bytes": (_sz, []),
     "yp_wgrad_group_pack": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "yp_wgrad_group_run": (_i, [_p, _i, _i, _i, _i, _i, _p]),

@@ -1729,6 +1729,9 @@ extern "C" int yp_conv_kpad(int K, int dtype) {
     return yp_cdiv(K, g) * g;
 }
 
+// (yp_conv_bn_partial_rows: walk the dispatch decisions of a launch and report the number of bn_partial rows instead of launching)
+static thread_local int* g_bn_rows_query = nullptr;
+
 int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t stream) {
     YP_REQUIRE(d != nullptr, "yp_conv2d: null descriptor");
     YP_REQUIRE(d->dtype == YP_F16 || d->dtype == YP_BF16 || d->dtype == YP_F32, "yp_conv2d: bad dtype %d", d->dtype);
@@ -1872,6 +1875,7 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
             YP_REQUIRE(!of32 && d->bias == nullptr && d->act == YP_ACT_NONE && d->res.C == 0 && d->out2.C == 0 && d->in1.C == 0,
                        "yp_conv2d: bn_partial needs a plain convolution (no bias / activation / residual / second output)");
             a.stats = d->bn_partial;
+            if (g_bn_rows_query != nullptr) { *g_bn_rows_query = d->B * a.tiles_y * a.tiles_x; return YP_OK; }
             e = d->dtype == YP_F16 ? dispatch_halo<YP_F16, false, true>(d->stride_h, bn, th, a, nb3, stream) : dispatch_halo<YP_BF16, false, true>(d->stride_h, bn, th, a, nb3, stream);
         } else if (d->dtype == YP_F16) e = of32 ? dispatch_halo<YP_F16, true>(d->stride_h, bn, th, a, nb3, stream) : dispatch_halo<YP_F16, false>(d->stride_h, bn, th, a, nb3, stream);
         else e = of32 ? dispatch_halo<YP_BF16, true>(d->stride_h, bn, th, a, nb3, stream) : dispatch_halo<YP_BF16, false>(d->stride_h, bn, th, a, nb3, stream);
@@ -1886,6 +1890,7 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
         YP_REQUIRE(fast && !of32 && ksplit <= 1 && !a.atomic_out && d->bias == nullptr && d->act == YP_ACT_NONE && d->res.C == 0 && d->out2.C == 0,
                    "yp_conv2d: bn_partial needs the plain fast path (tail_zero, no bias / activation / residual / split / second output)");
         a.stats = d->bn_partial;
+        if (g_bn_rows_query != nullptr) { *g_bn_rows_query = (int)(((size_t)a.M + 63) / 64); return YP_OK; }
         switch (d->dtype) {
             case YP_F16: e = launch_cfg<YP_F16, false, true, false, true>(tile, a, nblk, stream); break;
             case YP_BF16: e = launch_cfg<YP_BF16, false, true, false, true>(tile, a, nblk, stream); break;
@@ -1914,6 +1919,15 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
 }
 
 extern "C" int yp_conv2d(const YpConvDesc* d, void* stream) { return yp_conv2d_launch(d, nullptr, (hipStream_t)stream); }
+extern "C" int yp_conv_bn_partial_rows(const YpConvDesc* d, int* rows) {
+    YP_REQUIRE(d != nullptr && rows != nullptr && d->bn_partial != nullptr, "yp_conv_bn_partial_rows: a descriptor with bn_partial is required");
+    *rows = -1;
+    g_bn_rows_query = rows;
+    const int rc = yp_conv2d_launch(d, nullptr, nullptr);
+    g_bn_rows_query = nullptr;
+    if (rc == YP_OK && *rows < 0) { yp_set_error("yp_conv_bn_partial_rows: this convolution does not write bn_partial"); return YP_ERR_INVALID; }
+    return rc;
+}
 extern "C" int yp_conv2d_detect(const YpConvDesc* d, const YpDetectDesc* det, void* stream) {
     YP_REQUIRE(det != nullptr, "yp_conv2d_detect: null detect descriptor");
     return yp_conv2d_launch(d, det, (hipStream_t)stream);

@@ -25,6 +25,7 @@ inline int grid_for(size_t n, int block, size_t cap = 256 * 16) {
 }
 
 constexpr int BN_ROWS = 512;     // rows reduced by one workgroup
+template <int DT> __device__ __forceinline__ constexpr size_t esize() { return DT == YP_F32 ? 4 : 2; }
 
 // load 8 consecutive channels of a row as floats (CE8: two 16-byte loads for f32)
 template <int DT>
@@ -67,10 +68,12 @@ __device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + expf
 // ---------------------------------------------------------------------------------------------
 template <int DT, int MODE>
 __global__ __launch_bounds__(256) void col_reduce_kernel(const char* __restrict__ raw, int rcs, int rco, const char* __restrict__ dy,
-                                                         int dcs, int dco, size_t M, int C, const float* __restrict__ mean,
+                                                         int dcs, int dco, size_t Mg, int nbg, int C, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, int act, float* __restrict__ part) {
+    // statistics groups (Mg rows each, nbg workgroups each): a workgroup never straddles two groups; MODE 1 reads the group's mean / invstd
     __shared__ float red[2][256][8];
+    const int grp = blockIdx.x / nbg, gblk = blockIdx.x - grp * nbg;
     const int chunks = C / 8;
     const int rlanes = 256 / chunks;            // row lanes per workgroup (chunks <= 256)
     const int t = threadIdx.x;
@@ -83,12 +86,12 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const char* __restrict_
         if constexpr (MODE == 1) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                mu[j] = mean[ch * 8 + j]; is[j] = invstd[ch * 8 + j];
+                mu[j] = mean[grp * C + ch * 8 + j]; is[j] = invstd[grp * C + ch * 8 + j];
                 ga[j] = gamma[ch * 8 + j]; be[j] = beta[ch * 8 + j];
             }
         }
-        const size_t r0 = (size_t)blockIdx.x * BN_ROWS;
-        const size_t r1 = r0 + BN_ROWS < M ? r0 + BN_ROWS : M;
+        const size_t r0 = (size_t)grp * Mg + (size_t)gblk * BN_ROWS;
+        const size_t r1 = ((size_t)gblk + 1) * BN_ROWS < Mg ? r0 + BN_ROWS : ((size_t)grp + 1) * Mg;
         for (size_t r = r0 + rl; r < r1; r += rlanes) {
             float x[8];
             load8<DT>(raw, r * rcs + rco + ch * 8, x);
@@ -173,32 +176,48 @@ __device__ __forceinline__ bool fold_dispatch(const float* __restrict__ part, in
 template <bool WAVE>
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ part, int nblk, int C, double M, float eps, float momentum,
                                                                float* __restrict__ mean, float* __restrict__ invstd, float* running_mean,
-                                                               float* running_var) {
-    int c;
-    double s, ss;
-    if (!fold_dispatch<WAVE>(part, nblk, C, c, s, ss)) return;
-    const double mu = s / M;
-    double var = ss / M - mu * mu;
-    if (var < 0.0) var = 0.0;
-    mean[c] = (float)mu;
-    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (running_mean != nullptr) {
-        const double unbiased = M > 1.0 ? var * M / (M - 1.0) : var;
-        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
-        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+                                                               float* running_var, int groups) {
+    // `groups` statistics groups of nblk partial rows / M pixels each: mean / invstd [groups][C]; the running statistics take one momentum
+    // update per group, in group order (= consecutive forward passes of the module over the groups' samples)
+    for (int g = 0; g < groups; ++g) {
+        int c;
+        double s, ss;
+        if (fold_dispatch<WAVE>(part + (size_t)g * nblk * 2 * C, nblk, C, c, s, ss)) {
+            const double mu = s / M;
+            double var = ss / M - mu * mu;
+            if (var < 0.0) var = 0.0;
+            mean[g * C + c] = (float)mu;
+            invstd[g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+            if (running_mean != nullptr) {
+                const double unbiased = M > 1.0 ? var * M / (M - 1.0) : var;
+                running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+                running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+            }
+        }
+        if constexpr (!WAVE) __syncthreads();
     }
 }
 // o0 / o1 get the two column sums; when p0 / p1 are given they receive (or accumulate) them as well
 template <bool WAVE>
 __global__ __launch_bounds__(256) void pair_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ o0, float* __restrict__ o1,
-                                                           float* p0, float* p1, int accumulate) {
-    int c;
-    double s, ss;
-    if (!fold_dispatch<WAVE>(part, nblk, C, c, s, ss)) return;
-    if (o0) o0[c] = (float)s;
-    if (o1) o1[c] = (float)ss;
-    if (p0) p0[c] = (accumulate ? p0[c] : 0.f) + (float)s;
-    if (p1) p1[c] = (accumulate ? p1[c] : 0.f) + (float)ss;
+                                                           float* p0, float* p1, int accumulate, int groups) {
+    // per-group sums -> o0 / o1 [groups][C]; p0 / p1 get the sums over all groups
+    double ts = 0.0, tss = 0.0;
+    int c = 0;
+    bool lead = false;
+    for (int g = 0; g < groups; ++g) {
+        double s, ss;
+        if (fold_dispatch<WAVE>(part + (size_t)g * nblk * 2 * C, nblk, C, c, s, ss)) {
+            lead = true;
+            if (o0) o0[g * C + c] = (float)s;
+            if (o1) o1[g * C + c] = (float)ss;
+            ts += s; tss += ss;
+        }
+        if constexpr (!WAVE) __syncthreads();
+    }
+    if (!lead) return;
+    if (p0) p0[c] = (accumulate ? p0[c] : 0.f) + (float)ts;
+    if (p1) p1[c] = (accumulate ? p1[c] : 0.f) + (float)tss;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -206,7 +225,7 @@ __global__ __launch_bounds__(256) void pair_finalize_kernel(const float* __restr
 // ---------------------------------------------------------------------------------------------
 template <int DT>
 __global__ void bn_apply_kernel(const char* __restrict__ raw, int rcs, int rco, char* __restrict__ out, int ocs, int oco,
-                                const char* __restrict__ res, int scs, int sco, size_t M, int C, const float* __restrict__ mean,
+                                const char* __restrict__ res, int scs, int sco, size_t M, size_t Mg, int C, const float* __restrict__ mean,
                                 const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
                                 int act) {
     const int chunks = C / 8;
@@ -214,12 +233,13 @@ __global__ void bn_apply_kernel(const char* __restrict__ raw, int rcs, int rco, 
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int ch = (int)(i % chunks);
         const size_t r = i / chunks;
+        const int gc = (int)(r / Mg) * C;
         float x[8], y[8];
         load8<DT>(raw, r * rcs + rco + ch * 8, x);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = ch * 8 + j;
-            float z = (x[j] - mean[c]) * invstd[c] * gamma[c] + beta[c];
+            float z = (x[j] - mean[gc + c]) * invstd[gc + c] * gamma[c] + beta[c];
             if (act == YP_ACT_SILU) z = z * sigmoidf_(z);
             y[j] = z;
         }
@@ -236,29 +256,30 @@ __global__ void bn_apply_kernel(const char* __restrict__ raw, int rcs, int rco, 
 // dx = gamma*invstd*(dz - dbeta/M - xhat*dgamma/M), dz = dy*act'(z)
 template <int DT>
 __global__ void bn_bwd_apply_kernel(const char* __restrict__ raw, int rcs, int rco, const char* __restrict__ dy, int dcs, int dco,
-                                    char* __restrict__ dx, int xcs, int xco, size_t M, int C, const float* __restrict__ mean,
+                                    char* __restrict__ dx, int xcs, int xco, size_t M, size_t Mg, int C, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
                                     int act, const float* __restrict__ dgamma, const float* __restrict__ dbeta) {
     const int chunks = C / 8;
     const size_t n = M * chunks;
-    const float invM = 1.0f / (float)M;
+    const float invM = 1.0f / (float)Mg;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int ch = (int)(i % chunks);
         const size_t r = i / chunks;
         float x[8], g[8], o[8];
+        const int gc = (int)(r / Mg) * C;
         load8<DT>(raw, r * rcs + rco + ch * 8, x);
         load8<DT>(dy, r * dcs + dco + ch * 8, g);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = ch * 8 + j;
-            const float xh = (x[j] - mean[c]) * invstd[c];
+            const float xh = (x[j] - mean[gc + c]) * invstd[gc + c];
             float dz = g[j];
             if (act == YP_ACT_SILU) {
                 const float z = xh * gamma[c] + beta[c];
                 const float sg = sigmoidf_(z);
                 dz *= sg * (1.0f + z * (1.0f - sg));
             }
-            o[j] = gamma[c] * invstd[c] * (dz - dbeta[c] * invM - xh * dgamma[c] * invM);
+            o[j] = gamma[c] * invstd[gc + c] * (dz - dbeta[gc + c] * invM - xh * dgamma[gc + c] * invM);
         }
         store8<DT>(dx, r * xcs + xco + ch * 8, o);
     }
@@ -273,7 +294,7 @@ __device__ __forceinline__ float fast_sigmoid(float z) { return __builtin_amdgcn
 
 template <int DT, int MODE>
 __global__ __launch_bounds__(256) void col_reduce_fast_kernel(const char* __restrict__ raw, int rcs, int rco, const char* __restrict__ dy,
-                                                              int dcs, int dco, unsigned M, int C, int lg, unsigned rows_per_blk,
+                                                              int dcs, int dco, unsigned Mg, int nbg, int C, int lg, unsigned rows_per_blk,
                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta, int act,
                                                               float* __restrict__ part) {
@@ -284,15 +305,16 @@ __global__ __launch_bounds__(256) void col_reduce_fast_kernel(const char* __rest
 #pragma unroll
     for (int j = 0; j < 8; ++j) s0[j] = s1[j] = 0.f;
     float mu[8], is[8], ga[8], be[8];
+    const int grp = blockIdx.x / nbg, gblk = blockIdx.x - grp * nbg;      // statistics group: Mg rows, nbg workgroups
     if constexpr (MODE == 1) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            mu[j] = mean[ch * 8 + j]; is[j] = invstd[ch * 8 + j];
+            mu[j] = mean[grp * C + ch * 8 + j]; is[j] = invstd[grp * C + ch * 8 + j];
             ga[j] = gamma[ch * 8 + j]; be[j] = beta[ch * 8 + j];
         }
     }
-    const unsigned r0 = blockIdx.x * rows_per_blk;
-    const unsigned r1 = (r0 + rows_per_blk < M) ? r0 + rows_per_blk : M;
+    const unsigned r0 = grp * Mg + gblk * rows_per_blk;
+    const unsigned r1 = ((gblk + 1) * rows_per_blk < Mg) ? r0 + rows_per_blk : (grp + 1) * Mg;
     auto body = [&](const float (&x)[8], const float (&g)[8]) {
         if constexpr (MODE == 0) {
 #pragma unroll
@@ -350,18 +372,27 @@ __global__ __launch_bounds__(256) void col_reduce_fast_kernel(const char* __rest
 template <int DT, bool BWD>
 __global__ __launch_bounds__(256) void bn_rows_fast_kernel(const char* __restrict__ raw, int rcs, int rco, const char* __restrict__ dy, int dcs, int dco,
                                                            char* __restrict__ out, int ocs, int oco, const char* __restrict__ res, int scs, int sco,
-                                                           unsigned M, int lg, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           unsigned M, int C, int lg, const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta, int act,
                                                            const float* __restrict__ dgamma, const float* __restrict__ dbeta) {
+    // blockIdx.y = statistics group: M rows each, mean / invstd / dgamma / dbeta [groups][C]
     const int t = threadIdx.x;
     const int ch = t & ((1 << lg) - 1), rl = t >> lg, rlanes = 256 >> lg;
     float mu[8], is[8], ga[8], be[8], k0[8], k1[8];
     const float invM = 1.0f / (float)M;
+    const int gc = blockIdx.y * C;
+    {
+        const size_t roff = (size_t)blockIdx.y * M;
+        raw += roff * rcs * esize<DT>();
+        out += roff * ocs * esize<DT>();
+        if (dy != nullptr) dy += roff * dcs * esize<DT>();
+        if (res != nullptr) res += roff * scs * esize<DT>();
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int c = ch * 8 + j;
-        mu[j] = mean[c]; is[j] = invstd[c]; ga[j] = gamma[c]; be[j] = beta[c];
-        if constexpr (BWD) { k0[j] = dbeta[c] * invM; k1[j] = dgamma[c] * invM; }
+        mu[j] = mean[gc + c]; is[j] = invstd[gc + c]; ga[j] = gamma[c]; be[j] = beta[c];
+        if constexpr (BWD) { k0[j] = dbeta[gc + c] * invM; k1[j] = dgamma[gc + c] * invM; }
     }
     const unsigned stride = gridDim.x * rlanes;
     auto body = [&](size_t r, const float (&x)[8], const float (&g)[8]) {
@@ -613,10 +644,10 @@ static int fast_lg(int C) {
     while ((1 << lg) < chunks) ++lg;
     return lg;
 }
-static int fast_reduce_blocks(size_t M, int lg, unsigned* rows_per_blk) {
+static int fast_reduce_blocks(size_t M, int lg, unsigned* rows_per_blk, size_t cap = 2048) {
     const unsigned rlanes = 256u >> lg;
     size_t nblk = (M + 4 * rlanes - 1) / (4 * rlanes);       // >= 4 rows per thread
-    if (nblk > 2048) nblk = 2048;
+    if (nblk > cap) nblk = cap;
     if (nblk < 1) nblk = 1;
     unsigned rpb = (unsigned)((M + nblk - 1) / nblk);
     rpb = (rpb + rlanes - 1) / rlanes * rlanes;
@@ -631,102 +662,121 @@ extern "C" size_t yp_bn_workspace_bytes(int B, int H, int W, int C) {
     return align_up(nblk * 2 * (size_t)C * sizeof(float), 256);
 }
 
-extern "C" int yp_bn_stats(YpView raw, int dtype, int B, float eps, float momentum, float* mean, float* invstd, float* running_mean,
-                           float* running_var, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int yp_bn_stats_grouped(YpView raw, int dtype, int B, int groups, float eps, float momentum, float* mean, float* invstd, float* running_mean,
+                                   float* running_var, void* ws, size_t ws_bytes, void* stream) {
     if (int rc = check_view8(raw, "yp_bn_stats")) return rc;
-    YP_REQUIRE(mean && invstd && ws && B > 0 && raw.C <= 2048, "yp_bn_stats: bad arguments");
+    YP_REQUIRE(mean && invstd && ws && B > 0 && raw.C <= 2048 && groups >= 1 && groups <= 8 && B % groups == 0, "yp_bn_stats: bad arguments");
     YP_REQUIRE(ws_bytes >= yp_bn_workspace_bytes(B, raw.H, raw.W, raw.C), "yp_bn_stats: workspace too small");
-    const size_t M = (size_t)B * raw.H * raw.W;
-    int nblk = (int)((M + BN_ROWS - 1) / BN_ROWS);
+    const size_t M = (size_t)B * raw.H * raw.W, Mg = M / groups;
+    int nbg = (int)((Mg + BN_ROWS - 1) / BN_ROWS);                // workgroups per statistics group
     hipStream_t st = (hipStream_t)stream;
     const int lg = fast_lg(raw.C);
     if (lg >= 0 && M < (1ull << 31)) {
         unsigned rpb;
-        nblk = fast_reduce_blocks(M, lg, &rpb);
-        YP_DT_SWITCH(dtype, (col_reduce_fast_kernel<DT, 0><<<nblk, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, nullptr, 0, 0, (unsigned)M, raw.C, lg,
-                                                                                 rpb, nullptr, nullptr, nullptr, nullptr, 0, (float*)ws)));
+        nbg = fast_reduce_blocks(Mg, lg, &rpb, 2048 / groups);
+        YP_DT_SWITCH(dtype, (col_reduce_fast_kernel<DT, 0><<<nbg * groups, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, nullptr, 0, 0, (unsigned)Mg, nbg,
+                                                                                          raw.C, lg, rpb, nullptr, nullptr, nullptr, nullptr, 0, (float*)ws)));
     } else {
-        YP_DT_SWITCH(dtype, (col_reduce_kernel<DT, 0><<<nblk, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, nullptr, 0, 0, M, raw.C,
-                                                                            nullptr, nullptr, nullptr, nullptr, 0, (float*)ws)));
+        YP_DT_SWITCH(dtype, (col_reduce_kernel<DT, 0><<<nbg * groups, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, nullptr, 0, 0, Mg, nbg, raw.C,
+                                                                                     nullptr, nullptr, nullptr, nullptr, 0, (float*)ws)));
     }
-    if (nblk <= 256) bn_stats_finalize_kernel<true><<<(raw.C + 3) / 4, 256, 0, st>>>((const float*)ws, nblk, raw.C, (double)M, eps, momentum, mean, invstd, running_mean, running_var);
-    else bn_stats_finalize_kernel<false><<<raw.C, 256, 0, st>>>((const float*)ws, nblk, raw.C, (double)M, eps, momentum, mean, invstd, running_mean, running_var);
+    if (nbg <= 256) bn_stats_finalize_kernel<true><<<(raw.C + 3) / 4, 256, 0, st>>>((const float*)ws, nbg, raw.C, (double)Mg, eps, momentum, mean, invstd, running_mean, running_var, groups);
+    else bn_stats_finalize_kernel<false><<<raw.C, 256, 0, st>>>((const float*)ws, nbg, raw.C, (double)Mg, eps, momentum, mean, invstd, running_mean, running_var, groups);
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
 }
+extern "C" int yp_bn_stats(YpView raw, int dtype, int B, float eps, float momentum, float* mean, float* invstd, float* running_mean,
+                           float* running_var, void* ws, size_t ws_bytes, void* stream) {
+    return yp_bn_stats_grouped(raw, dtype, B, 1, eps, momentum, mean, invstd, running_mean, running_var, ws, ws_bytes, stream);
+}
 
+extern "C" int yp_bn_finalize_grouped(const float* partial, int rows, int groups, int C, double M, float eps, float momentum, float* mean, float* invstd,
+                                      float* running_mean, float* running_var, void* stream) {
+    YP_REQUIRE(partial && mean && invstd && rows > 0 && C > 0 && M > 0 && groups >= 1 && rows % groups == 0, "yp_bn_finalize: bad arguments");
+    const int rg = rows / groups;
+    if (rg <= 256) bn_stats_finalize_kernel<true><<<(C + 3) / 4, 256, 0, (hipStream_t)stream>>>(partial, rg, C, M / groups, eps, momentum, mean, invstd, running_mean, running_var, groups);
+    else bn_stats_finalize_kernel<false><<<C, 256, 0, (hipStream_t)stream>>>(partial, rg, C, M / groups, eps, momentum, mean, invstd, running_mean, running_var, groups);
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
 extern "C" int yp_bn_finalize(const float* partial, int rows, int C, double M, float eps, float momentum, float* mean, float* invstd, float* running_mean,
                               float* running_var, void* stream) {
-    YP_REQUIRE(partial && mean && invstd && rows > 0 && C > 0 && M > 0, "yp_bn_finalize: bad arguments");
-    if (rows <= 256) bn_stats_finalize_kernel<true><<<(C + 3) / 4, 256, 0, (hipStream_t)stream>>>(partial, rows, C, M, eps, momentum, mean, invstd, running_mean, running_var);
-    else bn_stats_finalize_kernel<false><<<C, 256, 0, (hipStream_t)stream>>>(partial, rows, C, M, eps, momentum, mean, invstd, running_mean, running_var);
-    YP_CHECK_HIP(hipGetLastError());
-    return YP_OK;
+    return yp_bn_finalize_grouped(partial, rows, 1, C, M, eps, momentum, mean, invstd, running_mean, running_var, stream);
 }
 
-extern "C" int yp_bn_act_apply(YpView raw, YpView out, YpView res, int dtype, int B, const float* mean, const float* invstd,
-                               const float* gamma, const float* beta, int act, void* stream) {
+extern "C" int yp_bn_act_apply_grouped(YpView raw, YpView out, YpView res, int dtype, int B, int groups, const float* mean, const float* invstd,
+                                       const float* gamma, const float* beta, int act, void* stream) {
     if (int rc = check_view8(raw, "yp_bn_act_apply")) return rc;
     if (int rc = check_view8(out, "yp_bn_act_apply")) return rc;
-    YP_REQUIRE(out.C == raw.C && (res.C == 0 || res.C == raw.C) && mean && invstd && gamma && beta, "yp_bn_act_apply: bad arguments");
-    const size_t M = (size_t)B * raw.H * raw.W;
+    YP_REQUIRE(out.C == raw.C && (res.C == 0 || res.C == raw.C) && mean && invstd && gamma && beta && groups >= 1 && B % groups == 0, "yp_bn_act_apply: bad arguments");
+    const size_t M = (size_t)B * raw.H * raw.W, Mg = M / groups;
     hipStream_t st = (hipStream_t)stream;
     const int g = grid_for(M * (raw.C / 8), 256);
     const int lg = fast_lg(raw.C);
     if (lg >= 0 && M < (1ull << 31)) {
-        const int gf = grid_for((M * (raw.C / 8) + 1) / 2, 256);      // ~2 rows per thread
-        YP_DT_SWITCH(dtype, (bn_rows_fast_kernel<DT, false><<<gf, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, nullptr, 0, 0, (char*)out.ptr, out.cstride,
-                                                                               out.coff, res.C ? (const char*)res.ptr : nullptr, res.cstride, res.coff, (unsigned)M, lg,
+        const int gf = grid_for((Mg * (raw.C / 8) + 1) / 2, 256, (size_t)(256 * 16) / groups);      // ~2 rows per thread
+        YP_DT_SWITCH(dtype, (bn_rows_fast_kernel<DT, false><<<dim3(gf, groups), 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, nullptr, 0, 0, (char*)out.ptr, out.cstride,
+                                                                               out.coff, res.C ? (const char*)res.ptr : nullptr, res.cstride, res.coff, (unsigned)Mg, raw.C, lg,
                                                                                mean, invstd, gamma, beta, act, nullptr, nullptr)));
     } else {
         YP_DT_SWITCH(dtype, (bn_apply_kernel<DT><<<g, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, (char*)out.ptr, out.cstride, out.coff,
-                                                                    res.C ? (const char*)res.ptr : nullptr, res.cstride, res.coff, M, raw.C, mean,
+                                                                    res.C ? (const char*)res.ptr : nullptr, res.cstride, res.coff, M, Mg, raw.C, mean,
                                                                     invstd, gamma, beta, act)));
     }
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
 }
+extern "C" int yp_bn_act_apply(YpView raw, YpView out, YpView res, int dtype, int B, const float* mean, const float* invstd,
+                               const float* gamma, const float* beta, int act, void* stream) {
+    return yp_bn_act_apply_grouped(raw, out, res, dtype, B, 1, mean, invstd, gamma, beta, act, stream);
+}
 
-extern "C" int yp_bn_act_bwd(YpView raw, YpView dy, YpView dx, int dtype, int B, const float* mean, const float* invstd,
-                             const float* gamma, const float* beta, int act, float* dgamma, float* dbeta, int accumulate_param_grads,
-                             void* ws, size_t ws_bytes, void* stream) {
+extern "C" int yp_bn_act_bwd_grouped(YpView raw, YpView dy, YpView dx, int dtype, int B, int groups, const float* mean, const float* invstd,
+                                     const float* gamma, const float* beta, int act, float* dgamma, float* dbeta, int accumulate_param_grads,
+                                     void* ws, size_t ws_bytes, void* stream) {
     if (int rc = check_view8(raw, "yp_bn_act_bwd")) return rc;
     if (int rc = check_view8(dy, "yp_bn_act_bwd")) return rc;
     if (int rc = check_view8(dx, "yp_bn_act_bwd")) return rc;
-    YP_REQUIRE(dy.C == raw.C && dx.C == raw.C && mean && invstd && gamma && beta && dgamma && dbeta && ws && raw.C <= 2048, "yp_bn_act_bwd: bad arguments");
-    YP_REQUIRE(ws_bytes >= yp_bn_workspace_bytes(B, raw.H, raw.W, raw.C) + 2 * (size_t)raw.C * 4, "yp_bn_act_bwd: workspace too small");
-    const size_t M = (size_t)B * raw.H * raw.W;
-    int nblk = (int)((M + BN_ROWS - 1) / BN_ROWS);
+    YP_REQUIRE(dy.C == raw.C && dx.C == raw.C && mean && invstd && gamma && beta && dgamma && dbeta && ws && raw.C <= 2048 && groups >= 1 && groups <= 8 && B % groups == 0,
+               "yp_bn_act_bwd: bad arguments");
+    YP_REQUIRE(ws_bytes >= yp_bn_workspace_bytes(B, raw.H, raw.W, raw.C) + 2 * (size_t)groups * raw.C * 4, "yp_bn_act_bwd: workspace too small");
+    const size_t M = (size_t)B * raw.H * raw.W, Mg = M / groups;
+    int nbg = (int)((Mg + BN_ROWS - 1) / BN_ROWS);
     hipStream_t st = (hipStream_t)stream;
-    // this call's own sums live at the end of the workspace (the parameter gradients may be accumulated)
+    // this call's own per-group sums live at the end of the workspace (the parameter gradients may be accumulated)
     float* dg = (float*)((char*)ws + yp_bn_workspace_bytes(B, raw.H, raw.W, raw.C));
-    float* db = dg + raw.C;
+    float* db = dg + (size_t)groups * raw.C;
     const int lg = fast_lg(raw.C);
     const bool fastp = lg >= 0 && M < (1ull << 31);
     if (fastp) {
         unsigned rpb;
-        nblk = fast_reduce_blocks(M, lg, &rpb);
-        YP_DT_SWITCH(dtype, (col_reduce_fast_kernel<DT, 1><<<nblk, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, (const char*)dy.ptr, dy.cstride, dy.coff,
-                                                                                 (unsigned)M, raw.C, lg, rpb, mean, invstd, gamma, beta, act, (float*)ws)));
+        nbg = fast_reduce_blocks(Mg, lg, &rpb, 2048 / groups);
+        YP_DT_SWITCH(dtype, (col_reduce_fast_kernel<DT, 1><<<nbg * groups, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, (const char*)dy.ptr, dy.cstride, dy.coff,
+                                                                                          (unsigned)Mg, nbg, raw.C, lg, rpb, mean, invstd, gamma, beta, act, (float*)ws)));
     } else {
-        YP_DT_SWITCH(dtype, (col_reduce_kernel<DT, 1><<<nblk, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, (const char*)dy.ptr, dy.cstride,
-                                                                            dy.coff, M, raw.C, mean, invstd, gamma, beta, act, (float*)ws)));
+        YP_DT_SWITCH(dtype, (col_reduce_kernel<DT, 1><<<nbg * groups, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, (const char*)dy.ptr, dy.cstride,
+                                                                                     dy.coff, Mg, nbg, raw.C, mean, invstd, gamma, beta, act, (float*)ws)));
     }
-    // (sum dz, sum dz*xhat) -> this call's dbeta / dgamma, and (accumulated) into the parameter gradients
-    if (nblk <= 256) pair_finalize_kernel<true><<<(raw.C + 3) / 4, 256, 0, st>>>((const float*)ws, nblk, raw.C, db, dg, dbeta, dgamma, accumulate_param_grads);
-    else pair_finalize_kernel<false><<<raw.C, 256, 0, st>>>((const float*)ws, nblk, raw.C, db, dg, dbeta, dgamma, accumulate_param_grads);
+    // per group (sum dz, sum dz*xhat) -> this call's dbeta / dgamma; their sums over the groups are (accumulated) into the parameter gradients
+    if (nbg <= 256) pair_finalize_kernel<true><<<(raw.C + 3) / 4, 256, 0, st>>>((const float*)ws, nbg, raw.C, db, dg, dbeta, dgamma, accumulate_param_grads, groups);
+    else pair_finalize_kernel<false><<<raw.C, 256, 0, st>>>((const float*)ws, nbg, raw.C, db, dg, dbeta, dgamma, accumulate_param_grads, groups);
     const int g = grid_for(M * (raw.C / 8), 256);
     if (fastp) {
-        const int gf = grid_for((M * (raw.C / 8) + 1) / 2, 256);
-        YP_DT_SWITCH(dtype, (bn_rows_fast_kernel<DT, true><<<gf, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, (const char*)dy.ptr, dy.cstride, dy.coff,
-                                                                              (char*)dx.ptr, dx.cstride, dx.coff, nullptr, 0, 0, (unsigned)M, lg, mean, invstd, gamma, beta,
+        const int gf = grid_for((Mg * (raw.C / 8) + 1) / 2, 256, (size_t)(256 * 16) / groups);
+        YP_DT_SWITCH(dtype, (bn_rows_fast_kernel<DT, true><<<dim3(gf, groups), 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, (const char*)dy.ptr, dy.cstride, dy.coff,
+                                                                              (char*)dx.ptr, dx.cstride, dx.coff, nullptr, 0, 0, (unsigned)Mg, raw.C, lg, mean, invstd, gamma, beta,
                                                                               act, dg, db)));
     } else {
         YP_DT_SWITCH(dtype, (bn_bwd_apply_kernel<DT><<<g, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, (const char*)dy.ptr, dy.cstride, dy.coff,
-                                                                        (char*)dx.ptr, dx.cstride, dx.coff, M, raw.C, mean, invstd, gamma, beta, act, dg, db)));
+                                                                        (char*)dx.ptr, dx.cstride, dx.coff, M, Mg, raw.C, mean, invstd, gamma, beta, act, dg, db)));
     }
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
+}
+extern "C" int yp_bn_act_bwd(YpView raw, YpView dy, YpView dx, int dtype, int B, const float* mean, const float* invstd,
+                             const float* gamma, const float* beta, int act, float* dgamma, float* dbeta, int accumulate_param_grads,
+                             void* ws, size_t ws_bytes, void* stream) {
+    return yp_bn_act_bwd_grouped(raw, dy, dx, dtype, B, 1, mean, invstd, gamma, beta, act, dgamma, dbeta, accumulate_param_grads, ws, ws_bytes, stream);
 }
 
 extern "C" int yp_ups2_bwd(YpView in, YpView out, int dtype, int B, int accumulate, void* stream) {
@@ -800,11 +850,11 @@ extern "C" int yp_col_sum(YpView v, int dtype, int B, float* out, int accumulate
     const int nblk = (int)((M + BN_ROWS - 1) / BN_ROWS);
     hipStream_t st = (hipStream_t)stream;
     float* scratch = (float*)((char*)ws + yp_bn_workspace_bytes(B, v.H, v.W, v.C));      // receives the sum of squares (unused)
-    YP_DT_SWITCH(dtype, (col_reduce_kernel<DT, 0><<<nblk, 256, 0, st>>>((const char*)v.ptr, v.cstride, v.coff, nullptr, 0, 0, M, v.C, nullptr, nullptr,
+    YP_DT_SWITCH(dtype, (col_reduce_kernel<DT, 0><<<nblk, 256, 0, st>>>((const char*)v.ptr, v.cstride, v.coff, nullptr, 0, 0, M, nblk, v.C, nullptr, nullptr,
                                                                         nullptr, nullptr, 0, (float*)ws)));
     (void)scratch;
-    if (nblk <= 256) pair_finalize_kernel<true><<<(v.C + 3) / 4, 256, 0, st>>>((const float*)ws, nblk, v.C, nullptr, nullptr, out, nullptr, accumulate);
-    else pair_finalize_kernel<false><<<v.C, 256, 0, st>>>((const float*)ws, nblk, v.C, nullptr, nullptr, out, nullptr, accumulate);
+    if (nblk <= 256) pair_finalize_kernel<true><<<(v.C + 3) / 4, 256, 0, st>>>((const float*)ws, nblk, v.C, nullptr, nullptr, out, nullptr, accumulate, 1);
+    else pair_finalize_kernel<false><<<v.C, 256, 0, st>>>((const float*)ws, nblk, v.C, nullptr, nullptr, out, nullptr, accumulate, 1);
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
 }
@@ -1043,11 +1093,14 @@ extern "C" int yp_run_op(const YpOpArgs* a, void* stream) {
     switch (a->op) {
         case YP_OP_BN_STATS:
             if (a->i[2] > 0)
-                return yp_bn_finalize((const float*)a->p[1], a->i[2], a->v[0].C, (double)B * a->v[0].H * a->v[0].W, a->s[0], a->s[1], a->g[0], a->g[1], a->g[2], a->g[3],
-                                      stream);
-            return yp_bn_stats(a->v[0], dt, B, a->s[0], a->s[1], a->g[0], a->g[1], a->g[2], a->g[3], a->p[0], a->n[0], stream);
-        case YP_OP_BN_APPLY: return yp_bn_act_apply(a->v[0], a->v[1], a->v[2], dt, B, a->f[0], a->f[1], a->f[2], a->f[3], a->i[2], stream);
-        case YP_OP_BN_BWD: return yp_bn_act_bwd(a->v[0], a->v[1], a->v[2], dt, B, a->f[0], a->f[1], a->f[2], a->f[3], a->i[2], a->g[0], a->g[1], a->i[3], a->p[0], a->n[0], stream);
+                return yp_bn_finalize_grouped((const float*)a->p[1], a->i[2], a->i[3] > 0 ? a->i[3] : 1, a->v[0].C, (double)B * a->v[0].H * a->v[0].W, a->s[0], a->s[1],
+                                              a->g[0], a->g[1], a->g[2], a->g[3], stream);
+            return yp_bn_stats_grouped(a->v[0], dt, B, a->i[3] > 0 ? a->i[3] : 1, a->s[0], a->s[1], a->g[0], a->g[1], a->g[2], a->g[3], a->p[0], a->n[0], stream);
+        case YP_OP_BN_APPLY:
+            return yp_bn_act_apply_grouped(a->v[0], a->v[1], a->v[2], dt, B, a->i[3] > 0 ? a->i[3] : 1, a->f[0], a->f[1], a->f[2], a->f[3], a->i[2], stream);
+        case YP_OP_BN_BWD:
+            return yp_bn_act_bwd_grouped(a->v[0], a->v[1], a->v[2], dt, B, a->i[4] > 0 ? a->i[4] : 1, a->f[0], a->f[1], a->f[2], a->f[3], a->i[2], a->g[0], a->g[1], a->i[3],
+                                         a->p[0], a->n[0], stream);
         case YP_OP_UPS2_BWD: return yp_ups2_bwd(a->v[0], a->v[1], dt, B, a->i[2], stream);
         case YP_OP_ADD_VIEWS: return yp_add_views(a->v[0], a->v[1], dt, B, a->i[2], stream);
         case YP_OP_MAXPOOL5_BWD: return yp_maxpool5_bwd(a->v[0], a->v[1], a->v[2], dt, B, a->i[2], a->p[0], a->n[0], stream);

@@ -85,7 +85,11 @@ class TrainStep:
         groups = grad_ready_groups(model.model)
         self.reducer = GradAllReducer(None, group=group, groups=groups)
         kp = set(id(p) for p in groups[1][1])
-        self.reducer.set_expected({p: (2 if id(p) in kp else 1) for p in self.reducer.params})
+        # YP_TRAIN_PAIR=0: the two forwards of a step as two native passes (two graphs, the schedule of round 1) instead of one 2B-sample pass
+        self.pair = os.environ.get("YP_TRAIN_PAIR", "1") != "0"
+        # contributions a gradient receives per micro-batch: pair mode -- one backward plan reaches each parameter; two-graph mode -- the
+        # trunk / keypoint-head parameters are reached by both passes' backward
+        self.reducer.set_expected({p: (2 if (id(p) in kp and not self.pair) else 1) for p in self.reducer.params})
         self.sparse = dict(SPARSE)
         self.comm_events = None
         self.side_stream = torch.cuda.Stream(device=device) if os.environ.get("YP_TRAIN_SIDE_STREAM") == "1" else None
@@ -129,14 +133,17 @@ class TrainStep:
         (Measured and dropped: a two-stage backward that launches the warped pass's native backward before the
         object-loss backward is differentiated -- the step is device-bound, the extra autograd entry points cost more than the
         overlap wins: 40-48 ms vs 38 ms per step.)"""
-        from .training import run_native_backward
+        from .training import run_native_backward, run_native_backward_pair
         m, dev = self.model, self.device
         self.reducer.bind_grads(zero=first_micro)   # (instead of optimizer.zero_grad: gradients accumulate straight into the all-reduce buckets)
         img = batch['image']
         B, S = img.shape[0], img.shape[-1]
         # both forwards are launched first; the label-only parts then run while the device works through them
-        outs, raw, graph = m.model.forward_with_graph(img)
-        outs_w, raw_w, graph_w = m.model.forward_with_graph(batch['warped_image'])
+        if self.pair:
+            outs, outs_w, raw, graph = m.model.forward_pair(img, batch['warped_image'])
+        else:
+            outs, raw, graph = m.model.forward_with_graph(img)
+            outs_w, raw_w, graph_w = m.model.forward_with_graph(batch['warped_image'])
         tgt = nce = None
         if prepare:
             main = torch.cuda.current_stream(dev)
@@ -161,6 +168,12 @@ class TrainStep:
         loss = (l_det + l_det_w) + LAMBDA_DESC * l_desc + LAMBDA_OBJ * l_obj
         if scale != 1.0:
             loss = loss * scale                     # accelerator.backward divides by the accumulation steps
+        if self.pair:
+            g = torch.autograd.grad(loss, list(raw), allow_unused=True)
+            self.reducer.begin()
+            # YOLO-branch plan over the image pass -> its (detector-group) buckets go out -> trunk plan over both passes
+            run_native_backward_pair(graph, g[0], g[1], list(g[2:]), notify=self.reducer.notify)
+            return loss.detach()
         heads = list(raw) + list(raw_w[:2])
         g = torch.autograd.grad(loss, heads, allow_unused=True)
         self.reducer.begin()

@@ -167,12 +167,12 @@ class YOLOPoint(HipModule):
             pack_input(x, img.view(), plan.code)
         plan.run()
 
-    def _train_graph(self, x):
+    def _train_graph(self, x, pair=False):
         """A free TrainGraph (static forward + backward plans and all their buffers) for this input shape.  The two
         forwards of one training step (image, warped image: reference train.py:208,220) get two graphs."""
         from ..training import TrainGraph
         code = _hip.dtype_code(self.compute_dtype)
-        key = (tuple(x.shape), code, x.device.index, tuple(p.data_ptr() for p in self.parameters()))
+        key = (tuple(x.shape), code, x.device.index, tuple(p.data_ptr() for p in self.parameters()), bool(pair))
         pool = self.__dict__.setdefault("_train_graphs", {})
         graphs = pool.setdefault(key, [])
         for g in graphs:
@@ -180,7 +180,7 @@ class YOLOPoint(HipModule):
                 return g
         if len(graphs) >= 4:
             raise _hip.YpError("more than 4 un-backpropagated train-mode forwards in flight for one input shape")
-        g = TrainGraph(self, x.shape[0], x.shape[2], x.shape[3], code, x.device)
+        g = TrainGraph(self, x.shape[0], x.shape[2], x.shape[3], code, x.device, pair=pair)
         graphs.append(g)
         return g
 
@@ -191,6 +191,17 @@ class YOLOPoint(HipModule):
             raise _hip.YpError("forward_with_graph is a train-mode entry point")
         from ..training import train_forward
         return train_forward(self, x.contiguous().float(), with_graph=True)
+
+    @_hip.guarded
+    def forward_pair(self, x, x_w):
+        """model(img) and model(img_warp) of one training step (reference train.py:208,220) as ONE native pass over 2B samples with
+        per-pass BatchNorm statistics (training.train_forward_pair)."""
+        if not self.training:
+            raise _hip.YpError("forward_pair is a train-mode entry point")
+        if tuple(x.shape) != tuple(x_w.shape):
+            raise _hip.YpError("forward_pair: the image and the warped image batch must have the same shape")
+        from ..training import train_forward_pair
+        return train_forward_pair(self, x.contiguous().float(), x_w.contiguous().float())
 
     @_hip.guarded
     def forward(self, x):

@@ -397,6 +397,11 @@ class PlanBuilder:
             d.tile, tuned_ms = self._autotune(d, det, (self.code, d.B, Hi, Wi, tuple((v.C, v.ups) for v in srcs), Cout_pad, R, S, sh, sw, dil, zs,
                                                        int(out_f32), res is not None, c2, act, detect is not None, pre is not None, post is not None,
                                                        bn_partial is not None))
+        if bn_partial is not None:                  # how many partial rows the chosen kernel variant writes (they are batch-major)
+            rows = C.c_int(0)
+            check(lib().yp_conv_bn_partial_rows(C.byref(d), C.byref(rows)))
+            self.last_bn_rows = rows.value
+            assert rows.value <= bn_partial.shape[0], (self.name(), rows.value, tuple(bn_partial.shape))
         if extra.get("dry_run"):
             return tuned_ms
         if det is not None:

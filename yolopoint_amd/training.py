@@ -15,6 +15,13 @@ image and the three head outputs runs here:
 A TrainGraph owns every buffer of one forward/backward pair; two forwards of the same step (image
 + warped image) use two graphs from a small pool.  Packed weights are re-derived from the fp32
 master parameters before every forward (`refresh`).
+
+Pair mode (TrainGraph(pair=True), YOLOPoint.forward_pair): the two forwards of a training step run as ONE launch list over 2B samples
+-- every convolution sees twice the pixels, every BatchNorm pass normalises the two sample sets with their own batch statistics
+("statistics groups": yp_bn_*_grouped; the running statistics take the image pass's update first, then the warped pass's, as two module
+calls do).  The backward is two plans: the Detect / PAN / YOLO-encoder layers over the image pass's B samples (the warped pass has no
+object loss: reference train.py:220-241), then the shared trunk + keypoint / descriptor heads over all 2B samples.  Half the launches of
+the two-graph schedule for the same arithmetic.
 """
 import ctypes as C
 import os
@@ -29,9 +36,13 @@ from .models.common import weights_generation
 
 
 class TrainGraph:
-    def __init__(self, net, B, H, W, code, device):
+    def __init__(self, net, B, H, W, code, device, pair=False):
+        """B: samples per forward pass.  pair: this graph runs two passes (image, warped image) as one launch list over 2B samples."""
         if H % 64 or W % 64:
             raise _hip.YpError("training needs image sizes that are multiples of 64")
+        self.G, self.Bs = (2 if pair else 1), B          # statistics groups (= passes per launch list), samples per pass
+        B = B * self.G                                   # samples per launch
+        self.bG = self.G                                 # statistics groups of the backward plan being emitted
         self.net, self.B, self.H, self.W, self.code, self.device = net, B, H, W, code, device
         self.tdtype = _hip.torch_dtype(code)
         self.fwd = PlanBuilder(B, code, device)
@@ -50,7 +61,7 @@ class TrainGraph:
         self.pgrads = {}           # parameter -> fp32 gradient tensor (reference layout)
         self.keep = []
         self.busy = False
-        wsb = lib().yp_bn_workspace_bytes(B, H // 2, W // 2, 1024) + 8 * 2048 + 4096
+        wsb = lib().yp_bn_workspace_bytes(B, H // 2, W // 2, 1024) + 8 * self.G * 2048 + 4096
         self.ws = torch.empty(wsb, dtype=torch.uint8, device=device)
         self.Bpad = round_up(B, 8)
         self._nbt = None
@@ -85,6 +96,13 @@ class TrainGraph:
             self.gbufs[key] = gb
             self.keep.append(gb.flat)
             self.gwritten[key] = []
+        if self.G > 1 and self.bG == 1 and key in self.kp_ptrs and not self.gwritten[key]:
+            # pair mode, first write by the image-pass-only backward plan into the gradient of a trunk tensor (the backbone output the YOLO
+            # encoder and the PAN read): the warped pass's half receives nothing from this plan -- zero it; the 2B-sample plan accumulates
+            gb = self.gbufs[key]
+            half = self.Bs * gb.H * gb.W * gb.C
+            esz = gb.t.element_size()
+            self.bwd.op(_hip.OP_MEMSET0, [], [self.T(gb.flat)], "zero_warp_half", p=[gb.flat.data_ptr() + half * esz], n=[half * esz])
         lo, hi = v.coff, v.coff + v.C
         acc = any(a < hi and lo < b for a, b in self.gwritten[key])
         self.gwritten[key].append((lo, hi))
@@ -115,7 +133,7 @@ class TrainGraph:
         conv, bn = m.conv, m.bn
         k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
         act = _hip.YP_ACT_SILU if isinstance(m.act, torch.nn.SiLU) else _hip.YP_ACT_NONE
-        f, B, code = self.fwd, self.B, self.code
+        f, B, code, G = self.fwd, self.B, self.code, self.G
         image = len(srcs) == 1 and srcs[0].geom is None and srcs[0].cstride == 4 and srcs[0].C == 4      # the stem keeps the host packer
         wsrc = (lambda: (conv.weight.detach().float(), None)) if image else MasterWeight(conv.weight)
         # The BatchNorm column sums come out of the convolution's epilogue (YpConvDesc.bn_partial: one partial row per block of 64 pixels in
@@ -125,15 +143,17 @@ class TrainGraph:
         mode = os.environ.get("YP_BN_EPILOGUE", "2")
         fuse_stats = (not image and all(v.C % chunk == 0 for v in srcs) and mode != "0" and (k == 1 and s == 1 or (mode == "2" and k == 3 and code != _hip.YP_F32)))
         partial = None
+        Ho_, Wo_ = (srcs[0].LH + 2 * p - k) // s + 1, (srcs[0].LW + 2 * p - k) // s + 1
+        if G > 1 and (self.Bs * Ho_ * Wo_) % 64:
+            fuse_stats = False       # (a 64-pixel row block of the generic kernel would straddle the two statistics groups)
         if fuse_stats:
-            Ho_, Wo_ = (srcs[0].LH + 2 * p - k) // s + 1, (srcs[0].LW + 2 * p - k) // s + 1
             rows = max(-(-(B * Ho_ * Wo_) // 64), B * -(-Ho_ // 4) * -(-Wo_ // 16) if k == 3 else 0)
             partial = torch.zeros((rows, 2, round_up(conv.out_channels, 8)), dtype=torch.float32, device=self.device)
         raw = f.conv(srcs, wsrc, None, k, s, p, _hip.YP_ACT_NONE, extra=dict(bn_partial=partial) if fuse_stats else None)
         if fuse_stats:
             partial.zero_()          # (the autotuner ran several kernel variants, which write different row sets: start from zeros with the chosen one)
         Cc, Cp = conv.out_channels, raw.C
-        mean, invstd = f.new_tensor((Cp,)), f.new_tensor((Cp,))
+        mean, invstd = f.new_tensor((G * Cp,)), f.new_tensor((G * Cp,))          # [statistics group][channel]
         gamma, beta, rmean, rvar = bn.weight, bn.bias, bn.running_mean, bn.running_var
         padded = Cp != Cc
         if padded:
@@ -153,18 +173,20 @@ class TrainGraph:
             self.post_forward.append(sync_out)
         if fuse_stats:
             assert partial.shape[2] == Cp
-            f.op(_hip.OP_BN_STATS, [raw, self.T(partial)], [self.T(mean), self.T(invstd), self.T(self.ws)], "bn_stats", v=[raw], i=[code, B, partial.shape[0]],
+            assert f.last_bn_rows % G == 0
+            f.op(_hip.OP_BN_STATS, [raw, self.T(partial)], [self.T(mean), self.T(invstd), self.T(self.ws)], "bn_stats", v=[raw], i=[code, B, f.last_bn_rows, G],
                  s=[bn.eps, bn.momentum], g=[mean, invstd, rmean, rvar], p=[self.ws, partial], n=[self.ws.numel()])
         else:
-            f.op(_hip.OP_BN_STATS, [raw], [self.T(mean), self.T(invstd), self.T(self.ws)], "bn_stats", v=[raw], i=[code, B], s=[bn.eps, bn.momentum],
+            f.op(_hip.OP_BN_STATS, [raw], [self.T(mean), self.T(invstd), self.T(self.ws)], "bn_stats", v=[raw], i=[code, B, 0, G], s=[bn.eps, bn.momentum],
                  g=[mean, invstd, rmean, rvar], p=[self.ws], n=[self.ws.numel()])
         if out is None:
             out = f.new_buf(raw.H, raw.W, raw.C).view()
-        f.op(_hip.OP_BN_APPLY, [raw, res, self.T(mean), self.T(invstd)], [out], "bn_act", v=[raw, out, res], i=[code, B, act],
+        f.op(_hip.OP_BN_APPLY, [raw, res, self.T(mean), self.T(invstd)], [out], "bn_act", v=[raw, out, res], i=[code, B, act, G],
              f=[mean, invstd, gamma, beta])
 
         def backward():
             b = self.bwd
+            B = b.B                  # (the plan's samples: in pair mode the image pass's B for the YOLO-branch plan -- statistics group 0)
             gy = self.gread(out)
             if res is not None:
                 gr, acc = self.gview(res)
@@ -172,7 +194,7 @@ class TrainGraph:
             draw = b.new_buf(raw.H, raw.W, raw.C).view()
             gw_, gb_ = self.pgrad(bn.weight), self.pgrad(bn.bias)
             dg, db = (b.new_tensor((Cp,)), b.new_tensor((Cp,))) if padded else (gw_, gb_)
-            b.op(_hip.OP_BN_BWD, [raw, gy], [draw, self.T(self.ws)], "bn_act_bwd", v=[raw, gy, draw], i=[code, B, act, 0],
+            b.op(_hip.OP_BN_BWD, [raw, gy], [draw, self.T(self.ws)], "bn_act_bwd", v=[raw, gy, draw], i=[code, B, act, 0, self.bG],
                  f=[mean, invstd, gamma, beta], g=[dg, db], p=[self.ws], n=[self.ws.numel()])
             if padded:
                 self.collect.append(lambda dg=dg, db=db, gw_=gw_, gb_=gb_: (gw_.copy_(dg[:Cc]), gb_.copy_(db[:Cc])))
@@ -192,14 +214,16 @@ class TrainGraph:
                 draw = g32
             else:
                 draw = b.new_buf(out.H, out.W, out.C).view()
-                b.op(_hip.OP_CAST_F32, [g32], [draw], "cast", v=[g32, draw], i=[self.code, self.B])
+                b.op(_hip.OP_CAST_F32, [g32], [draw], "cast", v=[g32, draw], i=[self.code, b.B])
             self.conv_backward([x], weight, bias, draw, k, s, p)
         self.tape.append((self.branch, backward))
         return out
 
     def conv_backward(self, srcs, weight, bias, draw, k, s, p):
         """Emit wgrad (+ bias grad) and dgrad of a convolution whose output gradient is `draw` [B,Ho,Wo,Cout_pad]."""
-        b, B, code, Bpad = self.bwd, self.B, self.code, self.Bpad
+        b, code = self.bwd, self.code
+        B = b.B
+        Bpad = round_up(B, 8)
         Cout, Cout_pad = weight.shape[0], draw.C
         Ho, Wo = draw.H, draw.W
         K = Ho * Wo * Bpad
@@ -314,7 +338,7 @@ class TrainGraph:
         def backward():
             gy = self.gread(y)
             gx, acc = self.gview(x)
-            self.bwd.op(_hip.OP_MAXPOOL2_BWD, [x, gy, gx], [gx], "maxpool2_bwd", v=[x, gy, gx], i=[code, B, int(acc)])
+            self.bwd.op(_hip.OP_MAXPOOL2_BWD, [x, gy, gx], [gx], "maxpool2_bwd", v=[x, gy, gx], i=[code, self.bwd.B, int(acc)])
         self.tape.append((self.branch, backward))
         return y
 
@@ -328,6 +352,7 @@ class TrainGraph:
 
         def backward():
             b = self.bwd
+            B = b.B
             g0, g1, g2, g3 = (self.gread(v) for v in (s0, s1, s2, s3))
             b.op(_hip.OP_MAXPOOL5_BWD, [s2, g3, g2], [g2, self.T(self.ws)], "pool_bwd3", v=[s2, g3, g2], i=[code, B, 1], p=[self.ws], n=[self.ws.numel()])
             b.op(_hip.OP_MAXPOOL5_BWD, [s1, g2, g1], [g1, self.T(self.ws)], "pool_bwd2", v=[s1, g2, g1], i=[code, B, 1], p=[self.ws], n=[self.ws.numel()])
@@ -357,7 +382,7 @@ class TrainGraph:
 
         def semi_seed():
             gsemi_v, _ = self.gview(semi)
-            self.bwd.op(_hip.OP_PACK_NCHW, [self.T(self.g_semi)], [gsemi_v], "seed_semi", f=[self.g_semi], v=[gsemi_v], i=[semi_code, B, 65])
+            self.bwd.op(_hip.OP_PACK_NCHW, [self.T(self.g_semi)], [gsemi_v], "seed_semi", f=[self.g_semi], v=[gsemi_v], i=[semi_code, self.bwd.B, 65])
         xb = blk(net.Bottleneck2, x8)
         # descriptor head
         if v52:
@@ -371,7 +396,7 @@ class TrainGraph:
 
             def desc_seed():
                 gcraw, _ = self.gview(craw)
-                self.bwd.op(_hip.OP_PACK_NCHW, [self.T(self.g_desc)], [gcraw], "seed_desc", f=[self.g_desc], v=[gcraw], i=[code, B, c3ch])
+                self.bwd.op(_hip.OP_PACK_NCHW, [self.T(self.g_desc)], [gcraw], "seed_desc", f=[self.g_desc], v=[gcraw], i=[code, self.bwd.B, c3ch])
         else:
             dA = self.conv_bn_act(net.ConvDescA, xa)
             dB = self.conv_bn_act(net.ConvDescB, xb)
@@ -387,11 +412,12 @@ class TrainGraph:
             def desc_seed():
                 b = self.bwd
                 gcraw, _ = self.gview(craw)
-                b.op(_hip.OP_PACK_NCHW, [self.T(self.g_desc)], [gd.view()], "seed_desc", f=[self.g_desc], v=[gd.view()], i=[_hip.YP_F32, B, c3ch])
-                b.op(_hip.OP_L2NORM_BWD, [craw, gd.view()], [gcraw], "l2norm_bwd", v=[craw, gd.view(), gcraw], i=[0, B, c3ch])
+                b.op(_hip.OP_PACK_NCHW, [self.T(self.g_desc)], [gd.view()], "seed_desc", f=[self.g_desc], v=[gd.view()], i=[_hip.YP_F32, b.B, c3ch])
+                b.op(_hip.OP_L2NORM_BWD, [craw, gd.view()], [gcraw], "l2norm_bwd", v=[craw, gd.view(), gcraw], i=[0, b.B, c3ch])
         self.desc_channels = c3ch
         # YOLO encoder + PAN: nothing below feeds semi / desc
         self.branch = "yolo"
+        self.kp_ptrs = set(t_.data_ptr() for t_ in f.keep)        # the trunk / keypoint-branch buffers (gview: pair mode)
         x = self.conv_bn_act(net.Conv4, xb)
         xc = blk(net.Bottleneck3, x)
         x = self.conv_bn_act(net.Conv5, xc)
@@ -429,7 +455,7 @@ class TrainGraph:
             def det_backward(v=v, mi=mi, gx=gx, ny=ny, nx=nx):
                 b = self.bwd
                 draw = b.new_buf(ny, nx, round_up(det.na * det.no, 8)).view()
-                b.op(_hip.OP_DETECT_BWD_PACK, [self.T(gx)], [draw], "seed_det", f=[gx], v=[draw], i=[code, B, det.na, det.no])
+                b.op(_hip.OP_DETECT_BWD_PACK, [self.T(gx)], [draw], "seed_det", f=[gx], v=[draw], i=[code, b.B, det.na, det.no])
                 self.conv_backward([v], mi.weight, mi.bias, draw, 1, 1, 0)
             det_seeds.append(det_backward)
         self.semi_v, self.desc_v = semi, dnorm
@@ -444,20 +470,29 @@ class TrainGraph:
         # Two variants: the full one, and one that only back-propagates the semi / desc sub-graph -- the reference's second
         # forward of a step (warped image) has no object loss, so autograd never visits its Detect / PAN / YOLO-encoder
         # layers (4 F_fwd + 2 F_kp per sample, not 6 F_fwd).
-        def emit(kp_only):
+        def emit(branches, B, groups, fresh=True):
+            """One backward plan over the tape entries of `branches` ('kp': trunk + keypoint / descriptor heads, 'yolo': YOLO encoder + PAN +
+            Detect), B samples, `groups` statistics groups.  fresh=False: the activation gradients an earlier plan of the same pass wrote
+            stay valid (pair mode: the trunk plan accumulates onto what the YOLO-branch plan left in the backbone output's gradient)."""
             self.bwd = bb = PlanBuilder(B, code, self.device)
+            self.bG = groups
             bb.pack_target = self.fwd.pack_target
-            for key in self.gwritten:
-                self.gwritten[key] = []
+            if fresh:
+                for key in self.gwritten:
+                    self.gwritten[key] = []
             self.touched, self.collect, self.unpack, self.wgroups = set(), [], [], {}
+            if self.G > 1:
+                self.wpart = None         # (pair mode: one slab arena per plan -- the two plans differ in batch)
+            self.dw_used = 0              # (the plans of a graph run one after another and unpack their accumulators at their end)
             bb.op(_hip.OP_MEMSET0, [], [self.T(self.dw_arena)], "zero_dw", p=[self.dw_arena], n=[self.dw_arena.numel() * 4])
-            semi_seed()
-            desc_seed()
-            if not kp_only:
+            if "kp" in branches:
+                semi_seed()
+                desc_seed()
+            if "yolo" in branches:
                 for fn in det_seeds:      # Detect backward runs before the PAN blocks' backward (it writes their output gradients)
                     fn()
             for branch, fn in reversed(self.tape):
-                if not kp_only or branch == "kp":
+                if branch in branches:
                     fn()
             for (gk, gs), ents in sorted(self.wgroups.items()):
                 n = len(ents)
@@ -472,6 +507,7 @@ class TrainGraph:
                     if self.wpart is None:      # sized by the largest filter class of the FULL backward (emitted first; the keypoint-only plan is a subset)
                         self.wpart = torch.empty(max(sum(round_up(lib().yp_wgrad_partial_elems(e[0].c(), e[1].c(), code, B, k_, s_), 64) for e in es)
                                                      for (k_, s_), es in self.wgroups.items()), dtype=torch.float32, device=self.device)
+                        self.keep.append(self.wpart)
                     assert sum(sizes) <= self.wpart.numel()
                     offs = [sum(sizes[:i]) for i in range(n)]
                     parts = (C.c_void_p * n)(*[self.wpart.data_ptr() + 4 * o for o in offs])
@@ -496,8 +532,14 @@ class TrainGraph:
             bb.set_lane(_hip.LANE_JOIN)
             plan = bb.finish(parallel=self.par)
             return plan, self.touched, self.collect
-        self.bwd_plan, self.bwd_params, self.bwd_collect = emit(False)
-        self.bwd_kp_plan, self.bwd_kp_params, self.bwd_kp_collect = emit(True)
+        if self.G == 1:
+            self.bwd_plan, self.bwd_params, self.bwd_collect = emit(("kp", "yolo"), B, 1)
+            self.bwd_kp_plan, self.bwd_kp_params, self.bwd_kp_collect = emit(("kp",), B, 1)
+        else:
+            # pair mode: the YOLO-branch layers over the image pass's samples (statistics group 0 = the first Bs samples of every buffer),
+            # then the trunk + keypoint / descriptor heads over both passes
+            self.bwd_plan, self.bwd_params, self.bwd_collect = emit(("yolo",), self.Bs, 1)
+            self.bwd_kp_plan, self.bwd_kp_params, self.bwd_kp_collect = emit(("kp",), B, self.G, fresh=False)
         mode = os.environ.get("YP_TRAIN_GRAPH", "1")         # replay the launch lists as hipGraphs (284 / 455 / 230 launches)
         if mode in ("1", "fwd"):
             self.fwd_plan.instantiate_graph()
@@ -507,7 +549,10 @@ class TrainGraph:
         self.params = [p_ for p_ in net.parameters()]
 
     # ------------------------------------------------------------------ run
-    def forward(self, x):
+    def forward(self, x, x_w=None):
+        """x: [B,3,H,W] fp32 (pair mode: x = the image batch, x_w = the warped image batch; the heads come back for all 2B samples, image
+        pass first; the Detect levels for the image pass only)."""
+        assert (x_w is not None) == (self.G > 1)
         # packed weights (forward + dgrad) are re-derived only when an optimizer step (or a load) changed the masters
         # (the optimizer-step count is part of the key: fused optimizers do not bump Tensor._version)
         ver = (weights_generation(),) + tuple(p_._version for p_ in self.params)      # (a tuple: a sum of counters can collide)
@@ -532,7 +577,14 @@ class TrainGraph:
             self.pack["version"] = (ver, nops)
         for fn in self.pre_forward:
             fn()
-        pack_input(x, self.img.view(), self.code)
+        if self.G == 1:
+            pack_input(x, self.img.view(), self.code)
+        else:
+            for j, xx in enumerate((x, x_w)):
+                vc = self.img.view().c()
+                vc.ptr += j * self.Bs * self.H * self.W * 4 * self.img.t.element_size()
+                assert xx.is_cuda and xx.dtype == torch.float32 and xx.is_contiguous() and xx.shape[0] == self.Bs
+                check(lib().yp_pack_input(xx.data_ptr(), self.Bs, xx.shape[1], self.H, self.W, vc, self.code, _hip.stream_ptr()))
         self.fwd_plan.run()
         for fn in self.post_forward:
             fn()
@@ -540,7 +592,7 @@ class TrainGraph:
             self._nbt = [m.num_batches_tracked for m in self.net.modules()
                          if isinstance(m, torch.nn.BatchNorm2d) and m.num_batches_tracked is not None]
         if self._nbt:
-            torch._foreach_add_(self._nbt, 1)          # one launch for all BatchNorm counters
+            torch._foreach_add_(self._nbt, self.G)     # one launch for all BatchNorm counters
         c3ch = self.desc_channels
         semi = self.semi_v.buf.t[..., :65].permute(0, 3, 1, 2).float()      # (a copy: fp32 heads are cloned, 16-bit ones converted)
         desc = self.desc_v.buf.t[..., :c3ch].permute(0, 3, 1, 2).float()
@@ -548,10 +600,42 @@ class TrainGraph:
             semi = semi.clone()
         if desc.data_ptr() == self.desc_v.buf.t.data_ptr():
             desc = desc.clone()
-        return semi, desc, [t.clone() for t in self.xs]
+        return semi, desc, [t[:self.Bs].clone() for t in self.xs]
+
+    def backward_pair(self, g_semi, g_desc, g_xs, between=None):
+        """Pair mode: head gradients (semi / desc over the 2B samples, the Detect levels over the image pass's B; None = zero) ->
+        parameter gradients.  Runs the YOLO-branch plan, calls between(parameter -> gradient of the parameters it reached) -- they are
+        final: a data-parallel step starts their all-reduce here --, then the trunk plan; returns its dict."""
+        assert self.G > 1
+        for dst, src in zip(self.g_xs, g_xs):
+            if src is None:
+                dst[:self.Bs].zero_()
+            else:
+                dst[:self.Bs].copy_(src)
+        self.bwd_plan.run()
+        for fn in self.bwd_collect:
+            fn()
+        first = {p_: self.pgrads[p_] for p_ in self.params if p_ in self.bwd_params}
+        if between is not None:
+            between(first)
+        for dst, src in ((self.g_semi, g_semi), (self.g_desc, g_desc)):
+            if src is None:
+                dst.zero_()
+            else:
+                dst.copy_(src)
+        self.bwd_kp_plan.run()
+        for fn in self.bwd_kp_collect:
+            fn()
+        second = {p_: self.pgrads[p_] for p_ in self.params if p_ in self.bwd_kp_params}
+        if between is None:
+            second.update(first)
+        return second
 
     def backward(self, g_semi, g_desc, g_xs):
         """Head gradients (None = that head took no part in the loss) -> parameter gradients (None = not reached)."""
+        if self.G > 1:
+            got = self.backward_pair(g_semi, g_desc, g_xs)
+            return [got.get(p_) for p_ in self.params]
         kp_only = all(g is None for g in g_xs)
         for dst, src in [(self.g_semi, g_semi), (self.g_desc, g_desc)] + ([] if kp_only else list(zip(self.g_xs, g_xs))):
             if src is None:
@@ -595,6 +679,28 @@ class _YOLOPointTrainFn(torch.autograd.Function):
         return (None, None, *([None] * len(g.params)))
 
 
+class _YOLOPointPairFn(torch.autograd.Function):
+    """Both forwards of a training step in one launch list (TrainGraph pair mode)."""
+    @staticmethod
+    @_hip.guarded
+    def forward(ctx, net, x, x_w, *params):
+        g = net._train_graph(x, pair=True)
+        ctx.graph = g
+        ctx.set_materialize_grads(False)
+        semi, desc, xs = g.forward(x, x_w)
+        if torch.is_grad_enabled() or any(p.requires_grad for p in params):
+            g.busy = True
+            weakref.finalize(ctx, _release, g)
+        return (semi, desc, *xs)
+
+    @staticmethod
+    def backward(ctx, g_semi, g_desc, *g_xs):
+        g = ctx.graph
+        with torch.cuda.device(g.device):
+            run_native_backward_pair(g, g_semi, g_desc, list(g_xs))
+        return (None, None, None, *([None] * len(g.params)))
+
+
 def run_native_backward(g, g_semi, g_desc, g_xs):
     """One native backward pass of TrainGraph `g` (head gradients; None = that head took no part in the loss), its parameter
     gradients accumulated into p.grad.  Parameter gradients are delivered with multi-tensor ops instead of ~215 per-parameter
@@ -603,8 +709,30 @@ def run_native_backward(g, g_semi, g_desc, g_xs):
     that received a contribution."""
     grads = g.backward(g_semi, g_desc, list(g_xs))
     g.busy = False
+    return _deliver(g.params, grads)
+
+
+def run_native_backward_pair(g, g_semi, g_desc, g_xs, notify=None):
+    """The backward of a pair-mode TrainGraph (both passes of a training step), parameter gradients accumulated into p.grad as
+    run_native_backward does.  notify(parameters) is called twice: after the YOLO-branch plan (the detector-group parameters are final
+    while the trunk plan is still to run -- dp.GradAllReducer launches their buckets there) and after the trunk plan."""
+    def between(first):
+        ps = list(first)
+        done = _deliver(ps, [first[p_] for p_ in ps])
+        if notify is not None:
+            notify(done)
+    rest = g.backward_pair(g_semi, g_desc, list(g_xs), between=between)
+    g.busy = False
+    ps = list(rest)
+    done = _deliver(ps, [rest[p_] for p_ in ps])
+    if notify is not None:
+        notify(done)
+    return done
+
+
+def _deliver(params, grads):
     new_p, new_g, acc_p, acc_g, touched = [], [], [], [], []
-    for p_, gr in zip(g.params, grads):
+    for p_, gr in zip(params, grads):
         if gr is None or not p_.requires_grad:
             continue
         touched.append(p_)
@@ -641,6 +769,23 @@ def grad_ready_groups(net):
             continue
         (kp if name.split(".")[0] in KP_BRANCH_MODULES else det).append(p)
     return [("detector", det), ("keypoint", kp)]
+
+
+def train_forward_pair(net, x, x_w):
+    """Both train-mode forwards of a step (reference train.py:208,220: model(img), model(img_warp)) as one native pass.  Returns
+    (outs, outs_w, heads, graph): the two output dicts of the reference's two calls (the warped pass's 'objects' are not produced: no loss
+    reads them), the raw head tensors they are views of (semi / desc over 2B samples, the Detect levels) for torch.autograd.grad, and the
+    TrainGraph for run_native_backward_pair.  BatchNorm batch statistics are per pass and the running statistics take the image pass's
+    update first, exactly as two calls do."""
+    params = list(net.parameters())
+    heads = _YOLOPointPairFn.apply(net, x, x_w, *params)
+    B = x.shape[0]
+    semi, desc = heads[0], heads[1]
+    if type(net).__name__ == "YOLOPointv52":
+        desc = desc.div(torch.unsqueeze(torch.norm(desc, p=2, dim=1), 1))
+    outs = {'semi': semi[:B], 'desc': desc[:B], 'objects': list(heads[2:])}
+    outs_w = {'semi': semi[B:], 'desc': desc[B:], 'objects': None}
+    return outs, outs_w, tuple(heads), heads[0].grad_fn.graph
 
 
 def train_forward(net, x, with_graph=False):
