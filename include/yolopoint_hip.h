@@ -138,8 +138,18 @@ typedef struct YpConvDesc {
  * groups the rows of group g are [g*rows/groups, (g+1)*rows/groups) -- for the generic kernel only when B/groups*Ho*Wo is a multiple of 64. */
 int yp_conv_bn_partial_rows(const YpConvDesc* d, int* rows);
 
+/* Weight gradient of the stem Conv(3, c1, k=6, s=2, p=2) (reference models/YOLOPoint.py:156; autograd's conv2d weight gradient in
+ * loss.backward(), train.py:245) from the packed image x [B][H][W][4] (16-bit, channel 3 zero) and dy [B][H/2][W/2][C <= 80]:
+ * dw[ci][r][s][co] fp32, ci < 4, C = dy.C columns.  slabs: yp_stem_wgrad_slabs(B, H, W) * 144 * dy.C floats of scratch (one partial
+ * sum per workgroup, folded in order: bit-reproducible). */
+int yp_stem_wgrad_slabs(int B, int H, int W);
+int yp_stem_wgrad(YpView x, YpView dy, int dtype, int B, float* slabs, float* dw, void* stream);
+
 /* dst[i] = slabs[0][i] + slabs[1][i] + ... + slabs[n_slabs-1][i], summed in that order (the fold of a deterministic split-K). */
 int yp_sum_slabs(const float* slabs, float* dst, size_t elems, int n_slabs, void* stream);
+/* The same total as a fixed two-level tree (for hundreds of small slabs): every `group` consecutive slabs are summed in order INTO the
+ * group's first slab (the slabs are scratch and are overwritten), then the group sums in order into dst.  n_slabs % group == 0. */
+int yp_sum_slabs_tree(float* slabs, float* dst, size_t elems, int n_slabs, int group, void* stream);
 
 int yp_conv2d(const YpConvDesc* d, void* stream);
 
@@ -230,6 +240,12 @@ int yp_bn_act_apply_grouped(YpView raw, YpView out, YpView res, int dtype, int B
 int yp_bn_act_bwd_grouped(YpView raw, YpView dy, YpView dx, int dtype, int B, int groups, const float* mean, const float* invstd,
                           const float* gamma, const float* beta, int act, float* dgamma, float* dbeta, int accumulate_param_grads,
                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* One Adam step over a flat fp32 range (all parameters of the model laid out back to back, their gradients / moments likewise):
+ * torch.optim.Adam's update rule -- the reference's optimizer (src/train.py:88 Adam(lr), :252 optimizer.step()) -- amsgrad / maximize off;
+ * step = 1 for the first update (bias corrections 1 - beta^step, computed in double on the host).  n % 4 == 0, 16-byte aligned arrays. */
+int yp_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                 void* stream);
 
 /* out (+)= 2x2 block sums of `in` (backward of nn.Upsample(2,'nearest'), models/YOLOPoint.py:192) */
 int yp_ups2_bwd(YpView in, YpView out, int dtype, int B, int accumulate, void* stream);
@@ -382,6 +398,7 @@ enum {
                                * i1=Cout i2=Cin i3=k i4=c0 i5=creal i6=Cout_pad */
     YP_OP_WGRAD_UNPACK_BATCH = 30, /* p0=device table of YpUnpackEntry; i1=entries i2=total tiles */
     YP_OP_SUM_SLABS = 32,     /* p0=slabs p1=dst; n0=elements per slab (multiple of 4) n1=slabs: dst = slab0 + slab1 + ... in order */
+    YP_OP_STEM_WGRAD = 33,    /* v0=image v1=dy; i0=dtype i1=B; p0=slabs p1=dw */
     YP_OP_WGRAD_GROUP = 31,   /* p0=device table (yp_wgrad_group_pack[_det]); i0=dtype i1=entries i2=total blocks i3=k i4=stride i5=fold chunks (0: atomics) */
     YP_OP_PACK_WEIGHT = 26    /* f0=w f1=bias; g0=bias_dst; p0=dst; i0=dtype i1=Cout i2=Cin i3=R i4=S i5=c0 i6=Cj i7=mode; n0=Kpad n1=Npad | Cout_pad<<32 */
 };

@@ -446,8 +446,15 @@ def test_pair_pass_matches_two_graph_schedule_bf16(cuda):
     o2, o2w, heads, g2 = m2.model.forward_pair(x, xw)
     for k in ("semi", "desc"):
         assert rel_err(o2[k], o1[k])[1] < 1e-2 and rel_err(o2w[k], o1w[k])[1] < 1e-2, k
-    for a, b in zip(o2["objects"], o1["objects"]):
-        assert rel_err(a, b)[1] < 5e-2          # (the deepest tensors: ~60 bf16 layers with batch-statistics BN between two tile schedules)
+    # the Detect levels sit behind ~60 bf16 layers with batch-statistics BN: two valid bf16 schedules differ there by the bf16 noise itself
+    # (2-6 % rel-L2) -- judge the one-pass schedule by its distance to the fp32 compute path, against the two-graph schedule's distance
+    m32, _ = make_model("s", 43, dtype="f32")
+    m32 = m32.to(cuda).train()
+    with torch.no_grad():
+        o32 = m32(x)
+    for a, b, r in zip(o2["objects"], o1["objects"], o32["objects"]):
+        e_pair, e_two = rel_err(a, r)[1], rel_err(b, r)[1]
+        assert e_pair < 1.5 * e_two + 1e-2, (e_pair, e_two)
     for (k, a), b in zip(m.state_dict().items(), m2.state_dict().values()):
         if "running" in k:
             assert rel_err(b, a)[1] < 2e-3, k
@@ -551,3 +558,43 @@ def test_parallel_training_graphs_equal_the_eager_launch_order(cuda, monkeypatch
         assert torch.equal(a, b)
     for a, b in zip(grads["1"][1], grads["0"][1]):          # BatchNorm running statistics
         assert torch.equal(a, b)
+
+
+def test_flat_adam_matches_torch_adam(cuda):
+    """optim.FlatAdam (one launch over the flat parameter / gradient / moment arrays) against torch.optim.Adam on the same gradients, five
+    steps with a changing learning rate; state_dict round trip into torch.optim.Adam."""
+    import copy
+    from yolopoint_amd.dp import GradAllReducer
+    from yolopoint_amd.optim import FlatAdam
+    from yolopoint_amd.training import grad_ready_groups
+    m, _ = make_model("n", 5, dtype="bf16")
+    m = m.to(cuda).train()
+    ref = copy.deepcopy(m)
+    red = GradAllReducer(None, groups=grad_ready_groups(m.model))
+    opt = FlatAdam(red, params=m.parameters(), lr=1e-2)
+    ropt = torch.optim.Adam(ref.parameters(), lr=1e-2)
+    assert all(p.data.untyped_storage().data_ptr() == red.param_arena.untyped_storage().data_ptr() for p in m.parameters())
+    for (k, a), b in zip(m.state_dict().items(), ref.state_dict().values()):
+        assert torch.equal(a, b), k                           # flattening keeps the values
+    gen = torch.Generator(device=cuda).manual_seed(1)
+    for it in range(5):
+        red.bind_grads(zero=True)
+        for p, q in zip(m.parameters(), ref.parameters()):
+            g = torch.randn(p.shape, device=cuda, generator=gen) * (0.1 if it % 2 else 1e-3)
+            p.grad.copy_(g)
+            q.grad = g.clone()
+        for o in (opt, ropt):
+            o.param_groups[0]["lr"] = 1e-2 / (1 + it)
+            o.step()
+    for (k, p), q in zip(m.named_parameters(), ref.parameters()):
+        assert rel_err(p, q)[0] < 2e-6, k
+    sd = opt.state_dict()
+    t2 = torch.optim.Adam(m.parameters(), lr=1.0)
+    t2.load_state_dict(sd)
+    assert t2.param_groups[0]["lr"] == opt.param_groups[0]["lr"]
+    i = len(sd["state"]) - 1
+    assert rel_err(t2.state[list(m.parameters())[i]]["exp_avg_sq"], ropt.state[list(ref.parameters())[i]]["exp_avg_sq"])[0] < 2e-6
+    with pytest.raises(Exception):
+        for p in m.parameters():
+            p.grad = None
+        opt.step()

@@ -61,3 +61,46 @@ def test_wgrad_rejects_bad_arguments(cuda):
     assert b"filters only" in lib().yp_last_error()
     assert lib().yp_conv_wgrad(view(x, 0, 16), view(x, 0, 16), _hip.YP_F32, 1, 1, 1, dw.data_ptr(), None) != 0
     assert lib().yp_conv_wgrad(view(x, 0, 16), view(x, 0, 16), _hip.YP_BF16, 1, 1, 2, dw.data_ptr(), None) != 0
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("B,H,W,Cout", [(2, 64, 64, 32), (3, 48, 80, 16), (1, 36, 44, 48), (2, 128, 96, 64), (1, 64, 192, 80), (16, 160, 160, 32)])
+def test_stem_wgrad_matches_autograd(cuda, B, H, W, Cout, dtype):
+    """yp_stem_wgrad (6x6 / stride 2 / pad 2 over the packed 4-channel image; reference models/YOLOPoint.py:156) against torch autograd's
+    conv2d weight gradient on the same 16-bit operands; sizes with partial 8 x 16 output patches, every dy block count (Cout 16..80), more
+    patches than workgroups (16 x 160 x 160); twice: bit-identical."""
+    torch.manual_seed(H + W + Cout)
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    code = _hip.dtype_code(dtype)
+    img = torch.zeros(B, H, W, 4, device=cuda)
+    img[..., :3] = torch.rand(B, H, W, 3, device=cuda)
+    img = img.to(td)
+    dybuf = (torch.randn(B, H // 2, W // 2, Cout + 8, device=cuda) * 0.1).to(td)          # view = channels [8, 8+Cout)
+    nsl = lib().yp_stem_wgrad_slabs(B, H, W)
+    assert nsl > 0
+    slabs = torch.full((nsl, 144 * Cout), float("nan"), device=cuda)
+    outs = []
+    for _ in range(2):
+        dw = torch.full((4, 6, 6, Cout), float("nan"), device=cuda)
+        check(lib().yp_stem_wgrad(view(img, 0, 4), view(dybuf, 8, Cout), code, B, slabs.data_ptr(), dw.data_ptr(), _hip.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append(dw)
+    assert torch.equal(outs[0], outs[1])
+    x = img[..., :3].float().permute(0, 3, 1, 2)
+    dy = dybuf[..., 8:8 + Cout].float().permute(0, 3, 1, 2)
+    w = torch.zeros(Cout, 3, 6, 6, device=cuda, requires_grad=True)
+    torch.nn.functional.conv2d(x, w, None, 2, 2).backward(dy)
+    ref = w.grad.permute(1, 2, 3, 0)
+    err = float((outs[0][:3] - ref).abs().max() / ref.abs().max())
+    assert err < 2e-5, err
+    assert float(outs[0][3].abs().max()) == 0.0           # the zero channel
+
+
+def test_stem_wgrad_rejects_bad_arguments(cuda):
+    img = torch.zeros(1, 16, 16, 4, device=cuda, dtype=torch.bfloat16)
+    dy = torch.zeros(1, 8, 8, 16, device=cuda, dtype=torch.bfloat16)
+    s, dw = torch.zeros(64, 144 * 16, device=cuda), torch.zeros(4, 6, 6, 16, device=cuda)
+    assert lib().yp_stem_wgrad(view(img, 0, 4), view(dy, 0, 16), _hip.YP_F32, 1, s.data_ptr(), dw.data_ptr(), None) != 0
+    assert lib().yp_stem_wgrad(view(dy, 0, 16), view(dy, 0, 16), _hip.YP_BF16, 1, s.data_ptr(), dw.data_ptr(), None) != 0
+    assert b"packed 4-channel image" in lib().yp_last_error()
+    assert lib().yp_stem_wgrad(view(img, 0, 4), view(img, 0, 4), _hip.YP_BF16, 1, s.data_ptr(), dw.data_ptr(), None) != 0

@@ -1068,12 +1068,16 @@ __global__ void zero_fill_kernel(f32x4* __restrict__ p, size_t n16) {
 }
 
 namespace {
-__global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ dst, size_t elems, int n) {
+__global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ dst, size_t elems, int n, size_t stride,
+                                                        size_t group_stride) {
+    // blockIdx.y = slab group: sums its n slabs (`stride` floats apart) in order into dst + blockIdx.y * group_stride
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= elems) return;
+    slabs += blockIdx.y * group_stride;
+    dst += blockIdx.y * group_stride;
     float4 v = *reinterpret_cast<const float4*>(slabs + i);
     for (int s = 1; s < n; ++s) {
-        const float4 u = *reinterpret_cast<const float4*>(slabs + (size_t)s * elems + i);
+        const float4 u = *reinterpret_cast<const float4*>(slabs + (size_t)s * stride + i);
         v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
     }
     *reinterpret_cast<float4*>(dst + i) = v;
@@ -1082,7 +1086,61 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict_
 
 extern "C" int yp_sum_slabs(const float* slabs, float* dst, size_t elems, int n_slabs, void* stream) {
     YP_REQUIRE(slabs && dst && elems > 0 && elems % 4 == 0 && n_slabs > 0 && ((uintptr_t)slabs & 15) == 0 && ((uintptr_t)dst & 15) == 0, "yp_sum_slabs: bad arguments");
-    sum_slabs_kernel<<<(unsigned)((elems / 4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(slabs, dst, elems, n_slabs);
+    const unsigned gx = (unsigned)((elems / 4 + 255) / 256);
+    sum_slabs_kernel<<<gx, 256, 0, (hipStream_t)stream>>>(slabs, dst, elems, n_slabs, elems, 0);
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
+/* The same sum as a fixed two-level tree for many small slabs (few elements, hundreds of slabs: one level leaves the chip to a handful of
+ * workgroups): groups of `group` consecutive slabs are summed in order INTO the group's first slab (the slabs are scratch), then the group
+ * sums in order into dst.  n_slabs % group == 0.  Bit-reproducible: the tree is fixed. */
+extern "C" int yp_sum_slabs_tree(float* slabs, float* dst, size_t elems, int n_slabs, int group, void* stream) {
+    YP_REQUIRE(slabs && dst && elems > 0 && elems % 4 == 0 && n_slabs > 0 && group > 0 && n_slabs % group == 0 && ((uintptr_t)slabs & 15) == 0 && ((uintptr_t)dst & 15) == 0,
+               "yp_sum_slabs_tree: bad arguments");
+    const unsigned gx = (unsigned)((elems / 4 + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    sum_slabs_kernel<<<dim3(gx, n_slabs / group), 256, 0, st>>>(slabs, slabs, elems, group, elems, (size_t)group * elems);
+    sum_slabs_kernel<<<gx, 256, 0, st>>>(slabs, dst, elems, n_slabs / group, (size_t)group * elems, 0);
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
+// Adam over one flat fp32 range: torch.optim.Adam's update (reference train.py:88,252: Adam(lr), amsgrad off, maximize off) --
+//   g' = g + wd*p;  m = b1*m + (1-b1)*g';  v = b2*v + (1-b2)*g'^2;  p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+// one pass over the four arrays instead of a multi-tensor launch per 30-odd parameters (6 launches, 380 us for 7.6 M parameters).
+namespace {
+__global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n4,
+                                                        float b1, float b2, float eps, float wd, float step_size, float bc2_sqrt) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 pp = reinterpret_cast<float4*>(p)[i], mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float* pa = reinterpret_cast<float*>(&pp);
+        float* ma = reinterpret_cast<float*>(&mm);
+        float* va = reinterpret_cast<float*>(&vv);
+        const float* ga = reinterpret_cast<const float*>(&gg);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gr = wd != 0.f ? ga[k] + wd * pa[k] : ga[k];
+            ma[k] = ma[k] + (1.0f - b1) * (gr - ma[k]);                  // (torch: exp_avg.lerp_(grad, 1 - beta1))
+            va[k] = b2 * va[k] + (1.0f - b2) * gr * gr;
+            const float denom = sqrtf(va[k]) / bc2_sqrt + eps;
+            pa[k] -= step_size * (ma[k] / denom);
+        }
+        reinterpret_cast<float4*>(p)[i] = pp; reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv;
+    }
+}
+}  // namespace
+
+extern "C" int yp_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                            void* stream) {
+    YP_REQUIRE(p && g && m && v && n > 0 && n % 4 == 0 && step >= 1, "yp_adam_step: bad arguments (n must be a multiple of 4)");
+    YP_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "yp_adam_step: arrays must be 16-byte aligned");
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const size_t n4 = n / 4;
+    size_t grid = (n4 + 255) / 256;
+    if (grid > 256 * 16) grid = 256 * 16;
+    adam_flat_kernel<<<(unsigned)grid, 256, 0, (hipStream_t)stream>>>(p, g, m, v, n4, beta1, beta2, eps, weight_decay, (float)(lr / bc1), (float)sqrt(bc2));
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
 }
@@ -1125,6 +1183,7 @@ extern "C" int yp_run_op(const YpOpArgs* a, void* stream) {
         case YP_OP_MAXPOOL2_BWD: return yp_maxpool2_bwd(a->v[0], a->v[1], a->v[2], dt, B, a->i[2], stream);
         case YP_OP_WGRAD_UNPACK: return yp_wgrad_unpack((const float*)a->p[0], a->g[0], a->i[1], a->i[2], a->i[3], a->i[4], a->i[5], a->i[6], stream);
         case YP_OP_WGRAD_UNPACK_BATCH: return yp_wgrad_unpack_batch((const YpUnpackEntry*)a->p[0], a->i[1], a->i[2], stream);
+        case YP_OP_STEM_WGRAD: return yp_stem_wgrad(a->v[0], a->v[1], dt, B, (float*)a->p[0], (float*)a->p[1], stream);
         case YP_OP_SUM_SLABS: return yp_sum_slabs((const float*)a->p[0], (float*)a->p[1], a->n[0], (int)a->n[1], stream);
         case YP_OP_WGRAD_GROUP: return yp_wgrad_group_run_det(a->p[0], a->i[1], a->i[2], a->i[5], dt, a->i[3], a->i[4], stream);
         case YP_OP_WGRAD: return yp_conv_wgrad(a->v[0], a->v[1], dt, B, a->i[2], a->i[3] > 0 ? a->i[3] : 1, (float*)a->p[0], stream);

@@ -302,7 +302,179 @@ hipError_t dispatch_wgrad(int k, int stride, const WgradArgs& a, dim3 grid, hipS
     return stride == 2 ? launch_wgrad<DT, 9, 2>(a, grid, st) : launch_wgrad<DT, 9, 1>(a, grid, st);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the STEM (reference models/YOLOPoint.py:156: Conv(3, c1, k=6, s=2, p=2)) straight from the packed image
+// [B][H][W][4] (three channels + a zero one, 8 bytes per pixel) and dy [B][H/2][W/2][Cout_pad]:
+//
+//   dW[ci][r][s][co] = sum over (b, y, x) of  img[b, 2y+r-2, 2x+s-2, ci] * dy[b, y, x, co]
+//
+// Same transposing-LDS-read scheme as above with the image as the 16-wide operand: for one output pixel and one filter row r, the four
+// pixels 2x+4h-2 .. 2x+4h+1 (h = 0 | 1) are 32 contiguous bytes = 16 "channels" (tap column 4h + 0..3, image channel 0..3) of one
+// transposing read row.  12 operand rows (6 filter rows x 2 halves; the half h = 1 carries two tap columns that do not exist, 6 and 7,
+// which are computed and dropped) x Cout_pad/16 dy blocks per 32-pixel k step; wave w owns operand rows 3w..3w+2.  A workgroup walks
+// 8 x 16 output patches (20 x 36 image pixels, DMA'd as they lie) and leaves its sums as one slab, plain stores; the slabs are summed
+// in order by yp_sum_slabs (bit-reproducible).  Replaces the pixel-major copies of both tensors + a split-K convolution over them:
+// 670 us -> ~70 us per training step of YOLOPoint-s at 16 x 640 x 640.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct StemWgradArgs {
+    const char* x;
+    const char* dy;
+    float* slabs;
+    int H, W, Ho, Wo;                      // image / output map
+    int dy_cs, dy_co, Cout_pad;
+    int tiles_x, tiles_y, ntiles;
+};
+
+template <int DT, int NCB>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemWgradArgs a) {
+    constexpr int TH = 8, PW = 36, PROWS = 20, UNITS = PROWS * (PW / 2);       // image patch: 20 rows x 36 pixels = 360 16-byte units
+    constexpr int XBYTES = 8192, NPIX = TH * 16, KK = NPIX / 32, DYBYTES = NCB * NPIX * 32, STAGE = XBYTES + DYBYTES, NDMA = 2 + NCB;
+    extern __shared__ __attribute__((aligned(1024))) char wsm[];
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)wsm);
+    const int t = threadIdx.x, l = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int half = l & 1, prow = l >> 1;
+
+    auto issue = [&](int tile, int stage) {
+        const unsigned sb = lds0 + stage * STAGE;
+        int r_ = tile;
+        const int tx = r_ % a.tiles_x; r_ /= a.tiles_x;
+        const int ty = r_ % a.tiles_y;
+        const int b = r_ / a.tiles_y, y0 = ty * TH, x0 = tx * 16;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {                       // image patch: unit u = row * 18 + pixel pair, laid out densely (pitch 288 bytes)
+            const int slab = i * 4 + wave;
+            const int u = slab * 64 + l;
+            const int row = u / (PW / 2), cu = u - row * (PW / 2);
+            const int iy = 2 * y0 - 2 + row, ix = 2 * x0 - 2 + 2 * cu;
+            const bool ok = u < UNITS && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const char* src = a.x + (((long)b * a.H + iy) * a.W + ix) * 8;
+            wg_glds16(ok ? (const void*)src : (const void*)wg_zero16, sb + slab * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < NCB; ++i) {                     // dy: [16-channel block][128 pixels][32 bytes]
+            const int q = wave + 4 * i;
+            const int cb = q >> 2, rb = q & 3;
+            const int row = rb * 32 + prow;
+            const int ch = cb * 16 + half * 8;
+            const int oy = y0 + (row >> 4), ox = x0 + (row & 15);
+            const bool ok = ch < a.Cout_pad && oy < a.Ho && ox < a.Wo;
+            const long pix = ((long)b * a.Ho + oy) * a.Wo + ox;
+            const char* src = a.dy + (pix * a.dy_cs + a.dy_co + ch) * 2;
+            wg_glds16(ok ? (const void*)src : (const void*)wg_zero16, sb + XBYTES + (cb * NPIX + rb * 32) * 32);
+        }
+    };
+
+    // fragment read addressing as in wgrad_body: lane i of group g addresses row j = i/4 of its 4-row block, 8-byte quarter i%4
+    const int li = l & 15, g = l >> 4, j = li >> 2, q4 = li & 3;
+    int xoff[2], yoff[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int k32 = g * 8 + ((h ^ (g & 1)) * 4) + j;
+        xoff[h] = ((2 * (k32 >> 4)) * PW + 2 * (k32 & 15)) * 8 + q4 * 8;
+        yoff[h] = k32 * 32 + q4 * 8;
+    }
+    f32x4 acc[3][NCB];
+#pragma unroll
+    for (int fi = 0; fi < 3; ++fi)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) acc[fi][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int first = blockIdx.x, step = gridDim.x;
+    if (first < a.ntiles) issue(first, 0);
+    int it = 0;
+    for (int tile = first; tile < a.ntiles; tile += step, ++it) {
+        const bool more = tile + step < a.ntiles;
+        if (more) issue(tile + step, (it + 1) & 1);
+        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const char* xs = wsm + (it & 1) * STAGE;
+        const char* ys = xs + XBYTES;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            s16x8 yf[NCB];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const char* base = ys + (cb * NPIX + kk * 32) * 32;
+                yf[cb] = wg_tr8(base + yoff[0], base + yoff[1]);
+            }
+#pragma unroll
+            for (int fi = 0; fi < 3; ++fi) {
+                const int f = wave * 3 + fi, r = f >> 1, hh = f & 1;
+                const char* base = xs + ((4 * kk + r) * PW + 4 * hh) * 8;
+                const s16x8 xf = wg_tr8(base + xoff[0], base + xoff[1]);
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) acc[fi][cb] = wg_mma<DT>(xf, yf[cb], acc[fi][cb]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    // accumulator lane (li, g): image-side row 4g + jj = (tap column 4hh + g, image channel jj), dy channel cb*16 + li.
+    // slab [ci][6][6][Cout_pad]: every element has exactly one writer
+    float* slab = a.slabs + (size_t)blockIdx.x * (4 * 36 * a.Cout_pad);
+#pragma unroll
+    for (int fi = 0; fi < 3; ++fi) {
+        const int f = wave * 3 + fi, r = f >> 1, sc = 4 * (f & 1) + g;
+        if (sc >= 6) continue;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            const int co = cb * 16 + li;
+            if (co >= a.Cout_pad) continue;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) slab[((size_t)(jj * 6 + r) * 6 + sc) * a.Cout_pad + co] = acc[fi][cb][jj];
+        }
+    }
+}
+
+template <int DT, int NCB>
+static hipError_t launch_stem_wgrad(const StemWgradArgs& a, int grid, hipStream_t st) {
+    constexpr size_t lds = (size_t)2 * (8192 + NCB * 128 * 32);
+    auto kern = stem_wgrad_kernel<DT, NCB>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    kern<<<grid, 256, lds, st>>>(a);
+    return hipGetLastError();
+}
+
 }  // namespace
+
+static int stem_wgrad_grid(int B, int Ho, int Wo) {
+    const int ntiles = B * yp_cdiv(Ho, 8) * yp_cdiv(Wo, 16);
+    return ntiles < 512 ? ntiles : 512;
+}
+
+extern "C" int yp_stem_wgrad_slabs(int B, int H, int W) { return (B > 0 && H > 0 && W > 0) ? stem_wgrad_grid(B, H / 2, W / 2) : 0; }
+
+extern "C" int yp_stem_wgrad(YpView x, YpView dy, int dtype, int B, float* slabs, float* dw, void* stream) {
+    YP_REQUIRE(dtype == YP_F16 || dtype == YP_BF16, "yp_stem_wgrad: 16-bit element types only");
+    YP_REQUIRE(x.ptr && dy.ptr && slabs && dw && B > 0 && ((uintptr_t)slabs & 15) == 0 && ((uintptr_t)dw & 15) == 0, "yp_stem_wgrad: null / unaligned buffer");
+    YP_REQUIRE(x.C == 4 && x.cstride == 4 && x.coff == 0 && x.ups == 0 && x.H % 2 == 0 && x.W % 2 == 0, "yp_stem_wgrad: x must be the packed 4-channel image");
+    YP_REQUIRE(dy.H == x.H / 2 && dy.W == x.W / 2 && dy.C % 8 == 0 && dy.C > 0 && dy.C <= 80 && dy.cstride % 8 == 0 && dy.coff % 8 == 0 && dy.ups == 0,
+               "yp_stem_wgrad: dy %dx%dx%d does not match a 6x6 / stride 2 / pad 2 convolution of a %dx%d image", dy.H, dy.W, dy.C, x.H, x.W);
+    StemWgradArgs a{};
+    a.x = (const char*)x.ptr; a.dy = (const char*)dy.ptr; a.slabs = slabs;
+    a.H = x.H; a.W = x.W; a.Ho = dy.H; a.Wo = dy.W;
+    a.dy_cs = dy.cstride; a.dy_co = dy.coff; a.Cout_pad = dy.C;
+    a.tiles_x = yp_cdiv(dy.W, 16); a.tiles_y = yp_cdiv(dy.H, 8); a.ntiles = B * a.tiles_x * a.tiles_y;
+    const int grid = stem_wgrad_grid(B, dy.H, dy.W);
+    const int ncb = yp_cdiv(dy.C, 16);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e;
+#define YP_S(DT) (ncb == 1 ? launch_stem_wgrad<DT, 1>(a, grid, st) : ncb == 2 ? launch_stem_wgrad<DT, 2>(a, grid, st) : ncb == 3 ? launch_stem_wgrad<DT, 3>(a, grid, st) \
+                  : ncb == 4 ? launch_stem_wgrad<DT, 4>(a, grid, st) : launch_stem_wgrad<DT, 5>(a, grid, st))
+    e = dtype == YP_F16 ? YP_S(YP_F16) : YP_S(YP_BF16);
+#undef YP_S
+    if (e != hipSuccess) { yp_set_error("yp_stem_wgrad: launch failed: %s", hipGetErrorString(e)); return YP_ERR_HIP; }
+    // (512 slabs of a few thousand floats: a fixed two-level tree, 16 slabs per first-level group)
+    if (grid % 16 == 0) return yp_sum_slabs_tree(slabs, dw, (size_t)4 * 36 * dy.C, grid, 16, stream);
+    return yp_sum_slabs(slabs, dw, (size_t)4 * 36 * dy.C, grid, stream);
+}
 
 // argument set + launch geometry of one weight gradient (shared by the single and the grouped entry points)
 static int wgrad_make_args(YpView x, YpView dy, int dtype, int B, int k, int stride, float* dw, WgradArgs* out, int* nblk_out, int* split_out, int target = 256) {

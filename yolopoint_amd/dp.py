@@ -51,12 +51,19 @@ class GradAllReducer:
                     self._close(cur, size, gname)
                     cur, size = [], 0
                 cur.append((p, size, n))
-                size += n
+                size += -(-n // 4) * 4                             # (every slot starts 16-byte aligned: FlatAdam / vector loads)
                 if not bucket_bytes and size >= limit:              # bucket count: close once the share is reached (no dangling remainder)
                     self._close(cur, size, gname)
                     cur, size = [], 0
             if cur:
                 self._close(cur, size, gname)
+        # all buckets are slices of ONE arena (bucket order), so that an optimizer can walk every gradient in one launch (optim.FlatAdam)
+        dev = self.buckets[0][1][0][0].device
+        sizes = [sz for sz, _ in self.buckets]
+        self.arena = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        self.bucket_offsets = [sum(sizes[:i]) for i in range(len(sizes))]
+        self.buckets = [(self.arena[o:o + sz], entries) for o, (sz, entries) in zip(self.bucket_offsets, self.buckets)]
+        self.param_arena = None
         self._bucket_of = {id(p): bi for bi, (_, entries) in enumerate(self.buckets) for p, _, _ in entries}
         self.expected = {id(p): 1 for p in self.params}     # gradient contributions per micro-batch (set_expected)
         self.sync = True
@@ -65,9 +72,28 @@ class GradAllReducer:
         self._pending, self._works, self._launched = None, {}, set()
 
     def _close(self, entries, size, gname):
-        dev = entries[0][0].device
-        self.buckets.append((torch.zeros(size, dtype=torch.float32, device=dev), entries))
+        self.buckets.append((size, entries))                # (the flat buffers are cut from one arena at the end of __init__)
         self.bucket_group.append(gname)
+
+    def flatten_parameters(self):
+        """Move every parameter into one flat fp32 arena laid out exactly like the gradient arena (p.data becomes a view; values kept).
+        Returns the arena.  The parameters' addresses change: plans built over the old ones are never used again (they are keyed by
+        address) and the packed filters are re-derived."""
+        if self.param_arena is None:
+            arena = torch.zeros_like(self.arena)
+            with torch.no_grad():
+                for o, (_, entries) in zip(self.bucket_offsets, self.buckets):
+                    for p, off, n in entries:
+                        slot = arena[o + off:o + off + n].view_as(p)
+                        slot.copy_(p.data)
+                        p.data = slot
+            self.param_arena = arena
+            from .models.common import invalidate_packed_weights
+            invalidate_packed_weights()
+        return self.param_arena
+
+    def grads_bound(self):
+        return self._views is not None and all(self._bound(bi) for bi in range(len(self.buckets)))
 
     @property
     def world(self):
@@ -90,9 +116,9 @@ class GradAllReducer:
         optimizer.zero_grad() at the start of an optimizer step (zero=False on the later micro-batches of an accumulation)."""
         if self._views is None:
             self._views = [[flat[off:off + n].view_as(p) for p, off, n in entries] for flat, entries in self.buckets]
+        if zero:
+            self.arena.zero_()                  # (all buckets: one launch)
         for (flat, entries), views in zip(self.buckets, self._views):
-            if zero:
-                flat.zero_()
             for (p, _, _), v in zip(entries, views):
                 if p.grad is not v:
                     p.grad = v

@@ -76,8 +76,6 @@ class TrainStep:
         self.det_loss = ComputeDetectorLoss(device)
         # the reference's optimizer (train.py:88) in its single-kernel implementation: the default multi-tensor one re-reads the 7.6 M
         # parameters / moments in ~10 passes (2.5-3 ms of the step); same update rule, fp32
-        self.opt = torch.optim.Adam(model.parameters(), lr=lr, fused=torch.device(device).type == "cuda" and os.environ.get("YP_ADAM_FUSED", "1") != "0")
-        self.scheduler = torch.optim.lr_scheduler.LambdaLR(self.opt, lr_lambda=lr_lambda) if lr_lambda is not None else None
         self.gas, self.max_grad_norm = int(gas), max_grad_norm
         # gradient buckets in the order the gradients become final: the parameters only the full backward reaches first (all-reduced
         # while the keypoint-only backward of the warped pass runs), the shared trunk + keypoint / descriptor heads last
@@ -90,6 +88,15 @@ class TrainStep:
         # contributions a gradient receives per micro-batch: pair mode -- one backward plan reaches each parameter; two-graph mode -- the
         # trunk / keypoint-head parameters are reached by both passes' backward
         self.reducer.set_expected({p: (2 if (id(p) in kp and not self.pair) else 1) for p in self.reducer.params})
+        # the reference's optimizer (train.py:88).  Default: optim.FlatAdam -- parameters / gradients / moments as four flat arrays, one
+        # launch per step (torch's fused multi-tensor Adam: 6 launches, 0.38 ms for the 7.6 M parameters of YOLOPoint-s; its default
+        # multi-tensor one re-reads them in ~10 passes, 2.5-3 ms).  YP_ADAM=torch: torch.optim.Adam(fused=True) over the same parameters.
+        if os.environ.get("YP_ADAM", "flat") == "flat" and torch.device(device).type == "cuda":
+            from .optim import FlatAdam
+            self.opt = FlatAdam(self.reducer, params=[p for p in model.parameters() if p.requires_grad], lr=lr)
+        else:
+            self.opt = torch.optim.Adam(model.parameters(), lr=lr, fused=torch.device(device).type == "cuda" and os.environ.get("YP_ADAM_FUSED", "1") != "0")
+        self.scheduler = torch.optim.lr_scheduler.LambdaLR(self.opt, lr_lambda=lr_lambda) if lr_lambda is not None else None
         self.sparse = dict(SPARSE)
         self.comm_events = None
         self.side_stream = torch.cuda.Stream(device=device) if os.environ.get("YP_TRAIN_SIDE_STREAM") == "1" else None

@@ -252,6 +252,13 @@ class TrainGraph:
                 # nothing in the rest of the backward reads dW or overwrites x / dy: the weight gradients of a filter class are
                 # collected and run as ONE grouped launch at the end of the pass (emit())
                 self.wgroups.setdefault((k, s), []).append((src, draw, dwb, 2 * B * Ho * Wo * Cj * k * k * Cout))
+            elif image and code != _hip.YP_F32 and (k, s, p) == (6, 2, 2) and Cout_pad <= 80 and os.environ.get("YP_STEM_WGRAD", "1") != "0":
+                # the stem: its own kernel over the packed image (no pixel-major copies of the two largest tensors of the pass)
+                nsl = lib().yp_stem_wgrad_slabs(B, Hi, Wi)
+                slabs = torch.empty((nsl, 144 * Cout_pad), dtype=torch.float32, device=self.device)
+                self.keep.append(slabs)
+                b.op(_hip.OP_STEM_WGRAD, [src, draw], [dwb.view(), self.T(slabs)], "wgrad_stem", v=[src, draw], i=[code, B], p=[slabs, dwb.flat])
+                b.records[-1].kind, b.records[-1].flops = "conv", 2 * B * Ho * Wo * 3 * k * k * Cout
             elif direct and not image:
                 b.op(_hip.OP_WGRAD, [src, draw], [dwb.view()], "wgrad", v=[src, draw], i=[code, B, k, s], p=[dwb.flat])
                 b.records[-1].kind, b.records[-1].flops = "conv", 2 * B * Ho * Wo * Cj * k * k * Cout
@@ -377,12 +384,15 @@ class TrainGraph:
         else:
             t = self.c3(net.BottleneckDet, x8)
             semi = self.conv_plain(net.ConvDet.weight, None, t, 1, 1, 0, "ConvDet")
-        self.g_semi = torch.zeros((B, 65, Hc, Wc), dtype=torch.float32, device=self.device)
-        semi_code = _hip.YP_F32 if semi.buf.t.dtype == torch.float32 else code
+        # The head gradients arrive from autograd as [B,C,H,W]-shaped tensors (usually already channels-innermost in memory: the heads are
+        # handed out as permuted views).  backward() copies them straight into the NHWC gradient buffers through permuted views
+        # (Tensor.copy_ converts layout and dtype in one pass) -- no NCHW staging buffer and no pack launch (2 x 95 us per step).
+        def head_view(gv, C_):
+            return gv.buf.t[..., gv.coff:gv.coff + C_].permute(0, 3, 1, 2)
 
         def semi_seed():
             gsemi_v, _ = self.gview(semi)
-            self.bwd.op(_hip.OP_PACK_NCHW, [self.T(self.g_semi)], [gsemi_v], "seed_semi", f=[self.g_semi], v=[gsemi_v], i=[semi_code, self.bwd.B, 65])
+            self.seed_semi = head_view(gsemi_v, 65)
         xb = blk(net.Bottleneck2, x8)
         # descriptor head
         if v52:
@@ -391,12 +401,11 @@ class TrainGraph:
             dB = self.conv_bn_act(net.ConvDescB, xb)
             craw = self.c2f(net.BottleneckDesc, [dA, dB.up()])
             c3ch = net._desc_channels
-            self.g_desc = torch.zeros((B, c3ch, Hc, Wc), dtype=torch.float32, device=self.device)
             dnorm = craw
 
             def desc_seed():
                 gcraw, _ = self.gview(craw)
-                self.bwd.op(_hip.OP_PACK_NCHW, [self.T(self.g_desc)], [gcraw], "seed_desc", f=[self.g_desc], v=[gcraw], i=[code, self.bwd.B, c3ch])
+                self.seed_desc = head_view(gcraw, c3ch)
         else:
             dA = self.conv_bn_act(net.ConvDescA, xa)
             dB = self.conv_bn_act(net.ConvDescB, xb)
@@ -405,14 +414,13 @@ class TrainGraph:
             c3ch = net.ConvDesc.out_channels
             dnorm = f.new_buf(Hc, Wc, craw.C, f32=True).view()
             f.op(_hip.OP_L2NORM, [craw], [dnorm], "l2norm", v=[craw, dnorm], i=[0, B, c3ch])
-            self.g_desc = torch.zeros((B, c3ch, Hc, Wc), dtype=torch.float32, device=self.device)
             gd = Buf(B, Hc, Wc, craw.C, torch.float32, self.device)
             self.keep.append(gd.flat)
 
             def desc_seed():
                 b = self.bwd
                 gcraw, _ = self.gview(craw)
-                b.op(_hip.OP_PACK_NCHW, [self.T(self.g_desc)], [gd.view()], "seed_desc", f=[self.g_desc], v=[gd.view()], i=[_hip.YP_F32, b.B, c3ch])
+                self.seed_desc = head_view(gd.view(), c3ch)
                 b.op(_hip.OP_L2NORM_BWD, [craw, gd.view()], [gcraw], "l2norm_bwd", v=[craw, gd.view(), gcraw], i=[0, b.B, c3ch])
         self.desc_channels = c3ch
         # YOLO encoder + PAN: nothing below feeds semi / desc
@@ -618,7 +626,7 @@ class TrainGraph:
         first = {p_: self.pgrads[p_] for p_ in self.params if p_ in self.bwd_params}
         if between is not None:
             between(first)
-        for dst, src in ((self.g_semi, g_semi), (self.g_desc, g_desc)):
+        for dst, src in ((self.seed_semi, g_semi), (self.seed_desc, g_desc)):
             if src is None:
                 dst.zero_()
             else:
@@ -637,7 +645,7 @@ class TrainGraph:
             got = self.backward_pair(g_semi, g_desc, g_xs)
             return [got.get(p_) for p_ in self.params]
         kp_only = all(g is None for g in g_xs)
-        for dst, src in [(self.g_semi, g_semi), (self.g_desc, g_desc)] + ([] if kp_only else list(zip(self.g_xs, g_xs))):
+        for dst, src in [(self.seed_semi, g_semi), (self.seed_desc, g_desc)] + ([] if kp_only else list(zip(self.g_xs, g_xs))):
             if src is None:
                 dst.zero_()
             else:
