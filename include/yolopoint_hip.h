@@ -244,7 +244,7 @@ int yp_bn_act_bwd_grouped(YpView raw, YpView dy, YpView dx, int dtype, int B, in
 /* One Adam step over a flat fp32 range (all parameters of the model laid out back to back, their gradients / moments likewise):
  * torch.optim.Adam's update rule -- the reference's optimizer (src/train.py:88 Adam(lr), :252 optimizer.step()) -- amsgrad / maximize off;
  * step = 1 for the first update (bias corrections 1 - beta^step, computed in double on the host).  n % 4 == 0, 16-byte aligned arrays. */
-int yp_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+int yp_adam_step(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1, double beta2, double eps, double weight_decay, int step,
                  void* stream);
 
 /* out (+)= 2x2 block sums of `in` (backward of nn.Upsample(2,'nearest'), models/YOLOPoint.py:192) */
@@ -330,6 +330,13 @@ int yp_pack_weight_batch(const YpPackEntry* table_dev, int n_entries, int total_
  *             dda, ddb [n][D]; `order` / `offsets` are the edge list (edge = i*E + j) sorted by idx value and its CSR offsets
  *             [n+1] (built once with the sampling); w_scratch [n][E] fp32. */
 int yp_infonce_fwd(const float* da, const float* db, const int* idx, int n, int E, int D, float inv_tau, float* logits, float* loss_rows, void* stream);
+/* Training variant: the forward and the anchor-side gradient in ONE gather pass (a streaming softmax over the E logits of each anchor):
+ * dda_unscaled[i] = sum_j softmax_j * db[idx[i][j]] - db[idx[i][0]]; the caller multiplies by dL/dloss / (tau * n).  lse[i] = the row's
+ * log-sum-exp.  yp_infonce_bwd_db then gives ddb (already scaled by *grad_scale_dev) from the stored logits and lse. */
+int yp_infonce_fwd_grad(const float* da, const float* db, const int* idx, int n, int E, int D, float inv_tau, float* logits, float* loss_rows, float* lse,
+                        float* dda_unscaled, void* stream);
+int yp_infonce_bwd_db(const float* da, const int* order, const int* offsets, const float* logits, const float* lse, int n, int E, int D,
+                      const float* grad_scale_dev, float* ddb, void* stream);
 int yp_infonce_bwd(const float* da, const float* db, const int* idx, const int* order, const int* offsets, const float* logits, int n, int E, int D,
                    const float* grad_scale_dev, float* w_scratch, float* dda, float* ddb, void* stream);
 

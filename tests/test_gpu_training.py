@@ -587,7 +587,7 @@ def test_flat_adam_matches_torch_adam(cuda):
             o.param_groups[0]["lr"] = 1e-2 / (1 + it)
             o.step()
     for (k, p), q in zip(m.named_parameters(), ref.parameters()):
-        assert rel_err(p, q)[0] < 2e-6, k
+        assert rel_err(p, q)[0] < 2e-6, (k, rel_err(p, q), float(q.abs().max()), float((p - q).abs().max()))
     sd = opt.state_dict()
     t2 = torch.optim.Adam(m.parameters(), lr=1.0)
     t2.load_state_dict(sd)

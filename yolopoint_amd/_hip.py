@@ -64,7 +64,7 @@ SIGNATURES = {
     "yp_conv2d_detect": (_i, [C.POINTER(YpConvDesc), C.POINTER(YpDetectDesc), _p]),
     "yp_conv_kpad": (_i, [_i, _i]),
     "yp_sum_slabs": (_i, [_p, _p, _sz, _i, _p]),
-    "yp_adam_step": (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _f, _i, _p]),
+    "yp_adam_step": (_i, [_p, _p, _p, _p, _sz, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i, _p]),
     "yp_sum_slabs_tree": (_i, [_p, _p, _sz, _i, _i, _p]),
     "yp_stem_wgrad": (_i, [YpView, YpView, _i, _i, _p, _p, _p]),
     "yp_stem_wgrad_slabs": (_i, [_i, _i, _i]),
@@ -104,6 +104,8 @@ SIGNATURES = {
     "yp_pack_weight_batch": (_i, [_p, _i, _i, _i, _p]),
     "yp_wgrad_unpack_batch": (_i, [_p, _i, _i, _p]),
     "yp_infonce_fwd": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _p, _p]),
+    "yp_infonce_fwd_grad": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p]),
+    "yp_infonce_bwd_db": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p]),
     "yp_infonce_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p]),
     "yp_homo_combine": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p]),
     "yp_points_sample_fwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p]),

@@ -1111,7 +1111,7 @@ extern "C" int yp_sum_slabs_tree(float* slabs, float* dst, size_t elems, int n_s
 // one pass over the four arrays instead of a multi-tensor launch per 30-odd parameters (6 launches, 380 us for 7.6 M parameters).
 namespace {
 __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n4,
-                                                        float b1, float b2, float eps, float wd, float step_size, float bc2_sqrt) {
+                                                        float omb1, float b2, float omb2, float eps, float wd, float step_size, float bc2_sqrt) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         float4 pp = reinterpret_cast<float4*>(p)[i], mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
         const float4 gg = reinterpret_cast<const float4*>(g)[i];
@@ -1122,8 +1122,8 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, c
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float gr = wd != 0.f ? ga[k] + wd * pa[k] : ga[k];
-            ma[k] = ma[k] + (1.0f - b1) * (gr - ma[k]);                  // (torch: exp_avg.lerp_(grad, 1 - beta1))
-            va[k] = b2 * va[k] + (1.0f - b2) * gr * gr;
+            ma[k] = ma[k] + omb1 * (gr - ma[k]);                         // (torch: exp_avg.lerp_(grad, 1 - beta1); 1 - beta in double on the host)
+            va[k] = b2 * va[k] + omb2 * gr * gr;
             const float denom = sqrtf(va[k]) / bc2_sqrt + eps;
             pa[k] -= step_size * (ma[k] / denom);
         }
@@ -1132,15 +1132,16 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, c
 }
 }  // namespace
 
-extern "C" int yp_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+extern "C" int yp_adam_step(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1, double beta2, double eps, double weight_decay, int step,
                             void* stream) {
     YP_REQUIRE(p && g && m && v && n > 0 && n % 4 == 0 && step >= 1, "yp_adam_step: bad arguments (n must be a multiple of 4)");
     YP_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "yp_adam_step: arrays must be 16-byte aligned");
-    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
     const size_t n4 = n / 4;
     size_t grid = (n4 + 255) / 256;
     if (grid > 256 * 16) grid = 256 * 16;
-    adam_flat_kernel<<<(unsigned)grid, 256, 0, (hipStream_t)stream>>>(p, g, m, v, n4, beta1, beta2, eps, weight_decay, (float)(lr / bc1), (float)sqrt(bc2));
+    adam_flat_kernel<<<(unsigned)grid, 256, 0, (hipStream_t)stream>>>(p, g, m, v, n4, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay,
+                                                                          (float)(lr / bc1), (float)sqrt(bc2));
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
 }

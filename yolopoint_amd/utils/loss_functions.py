@@ -260,26 +260,35 @@ class _InfoNCENative(torch.autograd.Function):
         E = idx.shape[1]
         logits = torch.empty((n, E), dtype=torch.float32, device=da.device)     # saved for the backward: owned by this call
         rows = torch.empty((n,), dtype=torch.float32, device=da.device)
-        _hip.check(_hip.lib().yp_infonce_fwd(da.data_ptr(), db.data_ptr(), idx.data_ptr(), n, E, D, 1.0 / tau, logits.data_ptr(), rows.data_ptr(),
-                                             _hip.stream_ptr()))
-        ctx.save_for_backward(da, db, idx, order, offsets, logits)
         ctx.tau = tau
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            # training: the anchor-side gradient (up to the scalar dL/dloss / (tau n)) comes out of the same gather pass as the logits
+            lse = torch.empty((n,), dtype=torch.float32, device=da.device)
+            dda_u = torch.empty_like(da)
+            _hip.check(_hip.lib().yp_infonce_fwd_grad(da.data_ptr(), db.data_ptr(), idx.data_ptr(), n, E, D, 1.0 / tau, logits.data_ptr(), rows.data_ptr(),
+                                                      lse.data_ptr(), dda_u.data_ptr(), _hip.stream_ptr()))
+            ctx.save_for_backward(da, order, offsets, logits, lse, dda_u)
+            ctx.fused = True
+        else:
+            _hip.check(_hip.lib().yp_infonce_fwd(da.data_ptr(), db.data_ptr(), idx.data_ptr(), n, E, D, 1.0 / tau, logits.data_ptr(), rows.data_ptr(),
+                                                 _hip.stream_ptr()))
+            ctx.fused = False
         return rows.mean()
 
     @staticmethod
     @_guarded
     def backward(ctx, g):
         from .. import _hip
-        da, db, idx, order, offsets, logits = ctx.saved_tensors
+        if not ctx.fused:
+            raise RuntimeError("InfoNCE: backward of a forward that ran without gradient inputs")
+        da, order, offsets, logits, lse, dda_u = ctx.saved_tensors
         n, D = da.shape
-        E = idx.shape[1]
-        sc = _scratch(da.device, n, E)
-        scale, w = sc["scale"], sc["w"]
-        scale.copy_((g.float() * (1.0 / (ctx.tau * n))).reshape(1))
-        dda, ddb = torch.empty_like(da), torch.empty_like(db)
-        _hip.check(_hip.lib().yp_infonce_bwd(da.data_ptr(), db.data_ptr(), idx.data_ptr(), order.data_ptr(), offsets.data_ptr(), logits.data_ptr(), n, E, D,
-                                             scale.data_ptr(), w.data_ptr(), dda.data_ptr(), ddb.data_ptr(), _hip.stream_ptr()))
-        return dda, ddb, None, None, None, None
+        E = logits.shape[1]
+        scale = (g.float() * (1.0 / (ctx.tau * n))).reshape(1)
+        ddb = torch.empty_like(da)
+        _hip.check(_hip.lib().yp_infonce_bwd_db(da.data_ptr(), order.data_ptr(), offsets.data_ptr(), logits.data_ptr(), lse.data_ptr(), n, E, D,
+                                                scale.data_ptr(), ddb.data_ptr(), _hip.stream_ptr()))
+        return dda_u * scale, ddb, None, None, None, None
 
 
 class _PointSampleNative(torch.autograd.Function):
