@@ -332,7 +332,8 @@ int yp_pack_weight_batch(const YpPackEntry* table_dev, int n_entries, int total_
 int yp_infonce_fwd(const float* da, const float* db, const int* idx, int n, int E, int D, float inv_tau, float* logits, float* loss_rows, void* stream);
 /* Training variant: the forward and the anchor-side gradient in ONE gather pass (a streaming softmax over the E logits of each anchor):
  * dda_unscaled[i] = sum_j softmax_j * db[idx[i][j]] - db[idx[i][0]]; the caller multiplies by dL/dloss / (tau * n).  lse[i] = the row's
- * log-sum-exp.  yp_infonce_bwd_db then gives ddb (already scaled by *grad_scale_dev) from the stored logits and lse. */
+ * log-sum-exp; `logits` receives the softmax weights w[i][j] = exp(l_ij - lse_i) - [j == 0], not the logits.  yp_infonce_bwd_db then gives
+ * ddb (already scaled by *grad_scale_dev) from those weights. */
 int yp_infonce_fwd_grad(const float* da, const float* db, const int* idx, int n, int E, int D, float inv_tau, float* logits, float* loss_rows, float* lse,
                         float* dda_unscaled, void* stream);
 int yp_infonce_bwd_db(const float* da, const int* order, const int* offsets, const float* logits, const float* lse, int n, int E, int D,

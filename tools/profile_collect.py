@@ -122,7 +122,7 @@ def main():
         open(os.path.join(OUT, f"{R}_train_kernel_trace.txt"), "w").write("\n".join(tl[:80]) + "\n")
         # one steady-state optimizer step: the dispatches between the last two Adam kernels
         rows = sorted(csv.DictReader(open(tt)), key=lambda r: int(r["Start_Timestamp"]))
-        adam = [i for i, r in enumerate(rows) if "FusedAdam" in r["Kernel_Name"] or "fused_adam" in r["Kernel_Name"].lower()]
+        adam = [i for i, r in enumerate(rows) if "FusedAdam" in r["Kernel_Name"] or "fused_adam" in r["Kernel_Name"].lower() or "adam_flat_kernel" in r["Kernel_Name"]]
         ends = [i for i in adam if i + 1 >= len(rows) or (i + 1) not in set(adam)]       # last kernel of each step's optimizer run
         if len(ends) >= 2:
             win = rows[ends[-2] + 1:ends[-1] + 1]
@@ -136,6 +136,14 @@ def main():
             for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
                 sl.append(f"{k:102s} {len(v):7d} {sum(v) / 1e3:11.1f} {sum(v) / len(v) / 1e3:9.2f} {100 * sum(v) / tot:6.2f}")
             open(os.path.join(OUT, f"{R}_train_step_kernels.txt"), "w").write("\n".join(sl[:70]) + "\n")
+            # the same step in launch order: start offset, duration, gap to the previous kernel's end
+            t0, prev = int(win[0]["Start_Timestamp"]), None
+            seq = ["# launch order of the step above: start_us dur_us gap_us kernel"]
+            for r in win:
+                st_, en_ = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+                seq.append(f"{(st_ - t0) / 1e3:9.1f} {(en_ - st_) / 1e3:8.1f} {((st_ - prev) / 1e3 if prev else 0):7.1f}  {short(r['Kernel_Name'])[:110]}")
+                prev = en_
+            open(os.path.join(OUT, f"{R}_train_step_sequence.txt"), "w").write("\n".join(seq) + "\n")
     json.dump(res, open(os.path.join(OUT, f"{R}_collect.json"), "w"), indent=1)
     print(json.dumps(res, indent=1))
 

@@ -86,8 +86,8 @@ __global__ __launch_bounds__(256) void infonce_fwd_kernel(const float* __restric
 // The forward WITH the anchor-side gradient in the same gather pass (training: the loss is always back-propagated): the rows db[idx[i][j]]
 // are the traffic of both passes (n * E rows of D floats: 4.8 GB for 24 000 anchors x 201 x 256), so
 //   dda_u[i] = sum_j softmax_j(l_i) * db[idx[i][j]] - db[idx[i][0]]        (= d loss_i / d da_i * tau, the backward scales it)
-// is accumulated while the logits are computed, with a running maximum as in a streaming softmax; lse[i] lets the db-side pass rebuild
-// w[i][j] = exp(l_ij - lse_i) - [j == 0] from the stored logits.  Replaces infonce_fwd + infonce_bwd_a (356 + 381 us -> ~400 us).
+// is accumulated while the logits are computed, with a running maximum as in a streaming softmax; the `logits` array receives
+// w[i][j] = exp(l_ij - lse_i) - [j == 0] (what the db-side pass needs), lse[i] the row's log-sum-exp.  Replaces infonce_fwd + infonce_bwd_a (356 + 381 us -> ~400 us).
 template <int VPL>
 __global__ __launch_bounds__(256) void infonce_fwd_grad_kernel(const float* __restrict__ da, const float* __restrict__ db, const int* __restrict__ idx, int n, int E,
                                                                int D, float inv_tau, float* __restrict__ logits, float* __restrict__ loss,
@@ -148,12 +148,13 @@ __global__ __launch_bounds__(256) void infonce_fwd_grad_kernel(const float* __re
             }
         }
     }
+    const float ls = mx + logf(s);
+    // the row's softmax weights w[i][j] = exp(l_ij - lse_i) - [j == 0] replace the logits (what the db-side pass multiplies da[i] with)
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int j = q * 64 + lane;
-        if (j < E) lrow[j] = mine[q];
+        if (j < E) lrow[j] = __expf(mine[q] - ls) - (j == 0 ? 1.0f : 0.0f);
     }
-    const float ls = mx + logf(s);
     if (lane == 0) { loss[i] = ls - l0; lse[i] = ls; }
     const float inv_s = 1.0f / s;
     float* o = dda_u + (size_t)i * D + lane * VPL;
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(256) void infonce_fwd_grad_kernel(const float* __re
     for (int k = 0; k < VPL; ++k) o[k] = acc[k] * inv_s - b0[k];
 }
 
-// ddb[k] = scale * sum over the edges (i, j) with idx[i][j] == k of (exp(l_ij - lse_i) - [j == 0]) * da[i]; edges sorted by k
+// ddb[k] = scale * sum over the edges (i, j) with idx[i][j] == k of w[i][j] * da[i]; edges sorted by k
 template <int VPL>
 __global__ __launch_bounds__(256) void infonce_bwd_b2_kernel(const float* __restrict__ da, const float* __restrict__ logits, const float* __restrict__ lse,
                                                              const int* __restrict__ order, const int* __restrict__ offsets, int n, int E, int D,
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256) void infonce_bwd_b2_kernel(const float* __rest
             const int edge = order[ee];
             const int i = edge / E;
             a[u] = load_row<VPL>(da, (size_t)i, D, lane);
-            we[u] = e + u < e1 ? (__expf(logits[edge] - lse[i]) - (edge - i * E == 0 ? 1.0f : 0.0f)) : 0.f;
+            we[u] = e + u < e1 ? logits[edge] : 0.f;          // (the weights yp_infonce_fwd_grad left in place of the logits)
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
