@@ -99,7 +99,7 @@ class TrainStep:
         self.scheduler = torch.optim.lr_scheduler.LambdaLR(self.opt, lr_lambda=lr_lambda) if lr_lambda is not None else None
         self.sparse = dict(SPARSE)
         self.comm_events = None
-        self.side_stream = torch.cuda.Stream(device=device) if os.environ.get("YP_TRAIN_SIDE_STREAM") == "1" else None
+        self.side_stream = torch.cuda.Stream(device=device) if os.environ.get("YP_TRAIN_SIDE_STREAM", "1") == "1" and torch.device(device).type == "cuda" else None
         self.reducer.broadcast_parameters(model)
 
     def __call__(self, batch):
@@ -145,32 +145,43 @@ class TrainStep:
         self.reducer.bind_grads(zero=first_micro)   # (instead of optimizer.zero_grad: gradients accumulate straight into the all-reduce buckets)
         img = batch['image']
         B, S = img.shape[0], img.shape[-1]
-        # both forwards are launched first; the label-only parts then run while the device works through them
+        # The label-only parts of the losses (YOLO target assignment, InfoNCE sampling with its one host synchronisation, the 65-channel
+        # keypoint labels and cell masks: ~100 small launches that depend on the batch only) run on a side stream that forks from the main
+        # stream at a point BEFORE the forward: they execute beside the forward pass instead of between it and the losses, and the host
+        # synchronisation waits for the side stream only.  YP_TRAIN_SIDE_STREAM=0: everything on the main stream, after the forward launch.
+        main = torch.cuda.current_stream(dev)
+        side = self.side_stream if (prepare and self.side_stream is not None) else main
+        fork = main.record_event() if side is not main else None      # (the batch tensors were produced on the main stream before this point)
+
+        def label_work():
+            det = m.model.Detect
+            shapes = [(B, det.na, img.shape[-2] // int(st), S // int(st), det.no) for st in det.stride]
+            tgt_ = self.obj_loss.assign(shapes, batch['box_labels']) if prepare else None
+            dch = getattr(m.model, "_desc_channels", None) or m.model.ConvDesc.out_channels
+            nce_ = infonce_prepare(batch['warped_valid_mask'], batch['inv_homographies'], (B, dch, img.shape[-2] // 8, S // 8), True,
+                                   self.sparse['num_samples_per_image'], self.sparse['num_masked_non_matches_per_match'], 8, dev) if prepare else None
+            lab_ = (labels2Dto3D(batch['labels_2D']), getMasks(batch['valid_mask'], dev),
+                    labels2Dto3D(batch['warped_labels']), getMasks(batch['warped_valid_mask'], dev))
+            return tgt_, nce_, lab_
         if self.pair:
             outs, outs_w, raw, graph = m.model.forward_pair(img, batch['warped_image'])
         else:
             outs, raw, graph = m.model.forward_with_graph(img)
             outs_w, raw_w, graph_w = m.model.forward_with_graph(batch['warped_image'])
-        tgt = nce = None
-        if prepare:
-            main = torch.cuda.current_stream(dev)
-            side = self.side_stream if self.side_stream is not None else main
-            if side is not main:
-                side.wait_stream(main)          # (the forwards are queued ahead of this point; the side stream only overlaps with them)
+        # (enqueued after the forward launch so that the host never waits before the device has the forward to work on; on the device the
+        # side stream depends on the fork event only)
+        if side is not main:
+            side.wait_event(fork)
             with torch.cuda.stream(side):
-                det = m.model.Detect
-                shapes = [(B, det.na, img.shape[-2] // int(st), S // int(st), det.no) for st in det.stride]
-                tgt = self.obj_loss.assign(shapes, batch['box_labels'])
-                dch = getattr(m.model, "_desc_channels", None) or m.model.ConvDesc.out_channels
-                nce = infonce_prepare(batch['warped_valid_mask'], batch['inv_homographies'], (B, dch, img.shape[-2] // 8, S // 8), True,
-                                      self.sparse['num_samples_per_image'], self.sparse['num_masked_non_matches_per_match'], 8, dev)
-                if side is not main:
-                    _record_stream((tgt, nce), main)
-            if side is not main:
-                main.wait_stream(side)
+                early = label_work()
+                _record_stream(early, main)
+            main.wait_stream(side)
+        else:
+            early = label_work()
+        tgt, nce, (lab, msk, lab_w, msk_w) = early
         l_obj = self.obj_loss(outs['objects'], batch['box_labels'], prepared=tgt)[0]
-        l_det = self.det_loss(outs['semi'], labels2Dto3D(batch['labels_2D']), getMasks(batch['valid_mask'], dev))
-        l_det_w = self.det_loss(outs_w['semi'], labels2Dto3D(batch['warped_labels']), getMasks(batch['warped_valid_mask'], dev))
+        l_det = self.det_loss(outs['semi'], lab, msk)
+        l_det_w = self.det_loss(outs_w['semi'], lab_w, msk_w)
         l_desc = infonce(outs['desc'], outs_w['desc'], batch['warped_valid_mask'], batch['inv_homographies'], device=dev, prepared=nce, **self.sparse)
         loss = (l_det + l_det_w) + LAMBDA_DESC * l_desc + LAMBDA_OBJ * l_obj
         if scale != 1.0:
