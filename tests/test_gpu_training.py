@@ -598,3 +598,42 @@ def test_flat_adam_matches_torch_adam(cuda):
         for p in m.parameters():
             p.grad = None
         opt.step()
+
+
+def test_pair_losses_equal_the_per_pass_losses(cuda):
+    """The pair-mode loss entry points of the training step -- ComputeDetectorLoss(groups=2) over both passes' logits in one tensor,
+    infonce(descriptors_pair=...) over both passes' descriptor maps in one tensor -- against the per-pass calls of the reference step
+    (train.py:228-232: two detector losses added; :236: infonce(desc, desc_warp)): values and gradients."""
+    from yolopoint_amd.utils.loss_functions import ComputeDetectorLoss, infonce, infonce_prepare
+    torch.manual_seed(4)
+    B, Hc, Wc, D = 3, 16, 24, 128
+    buf = torch.randn(2 * B, Hc, Wc, 72, device=cuda)
+    semi = buf[..., :65].permute(0, 3, 1, 2).requires_grad_()          # channels-innermost memory, as the network hands it out
+    lab = torch.zeros(2 * B, 65, Hc, Wc, device=cuda)
+    lab.scatter_(1, torch.randint(0, 65, (2 * B, 1, Hc, Wc), device=cuda), 1.0)
+    msk = (torch.rand(2 * B, Hc, Wc, device=cuda) < 0.8).float()
+    msk[B:] *= (torch.rand(B, Hc, Wc, device=cuda) < 0.5).float()     # (different normalisations for the two passes)
+    det = ComputeDetectorLoss(cuda)
+    ref = det(semi[:B], lab[:B], msk[:B]) + det(semi[B:], lab[B:], msk[B:])
+    (ref * 2.0).backward()
+    gref = semi.grad.clone()
+    semi.grad = None
+    got = det(semi, lab, msk, groups=2)
+    (got * 2.0).backward()
+    assert abs(float(got) - float(ref)) <= 1e-6 * abs(float(ref))
+    assert rel_err(semi.grad, gref)[0] < 1e-6
+    # descriptors
+    dbuf = torch.nn.functional.normalize(torch.randn(2 * B, Hc, Wc, D, device=cuda), dim=-1)
+    desc = dbuf.permute(0, 3, 1, 2).requires_grad_()
+    mask = torch.ones(B, 1, Hc * 8, Wc * 8, device=cuda)
+    Hinv = torch.eye(3, device=cuda).repeat(B, 1, 1)
+    prep = infonce_prepare(mask, Hinv, (B, D, Hc, Wc), True, 100, 30, 8, cuda)
+    ref = infonce(desc[:B], desc[B:], mask, Hinv, device=cuda, prepared=prep, num_samples_per_image=100, num_masked_non_matches_per_match=30)
+    (ref * 0.3).backward()
+    gref = desc.grad.clone()
+    desc.grad = None
+    got = infonce(desc[:B], desc[B:], mask, Hinv, device=cuda, prepared=prep, descriptors_pair=desc, num_samples_per_image=100,
+                  num_masked_non_matches_per_match=30)
+    (got * 0.3).backward()
+    assert abs(float(got) - float(ref)) <= 1e-5 * abs(float(ref))
+    assert rel_err(desc.grad, gref)[0] < 1e-5

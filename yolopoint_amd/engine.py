@@ -160,8 +160,12 @@ class TrainStep:
             dch = getattr(m.model, "_desc_channels", None) or m.model.ConvDesc.out_channels
             nce_ = infonce_prepare(batch['warped_valid_mask'], batch['inv_homographies'], (B, dch, img.shape[-2] // 8, S // 8), True,
                                    self.sparse['num_samples_per_image'], self.sparse['num_masked_non_matches_per_match'], 8, dev) if prepare else None
-            lab_ = (labels2Dto3D(batch['labels_2D']), getMasks(batch['valid_mask'], dev),
-                    labels2Dto3D(batch['warped_labels']), getMasks(batch['warped_valid_mask'], dev))
+            if self.pair:       # both passes' labels / masks as one 2B batch (image pass first)
+                lab_ = (labels2Dto3D(torch.cat((batch['labels_2D'], batch['warped_labels']))),
+                        getMasks(torch.cat((batch['valid_mask'], batch['warped_valid_mask'])), dev), None, None)
+            else:
+                lab_ = (labels2Dto3D(batch['labels_2D']), getMasks(batch['valid_mask'], dev),
+                        labels2Dto3D(batch['warped_labels']), getMasks(batch['warped_valid_mask'], dev))
             return tgt_, nce_, lab_
         if self.pair:
             outs, outs_w, raw, graph = m.model.forward_pair(img, batch['warped_image'])
@@ -180,10 +184,16 @@ class TrainStep:
             early = label_work()
         tgt, nce, (lab, msk, lab_w, msk_w) = early
         l_obj = self.obj_loss(outs['objects'], batch['box_labels'], prepared=tgt)[0]
-        l_det = self.det_loss(outs['semi'], lab, msk)
-        l_det_w = self.det_loss(outs_w['semi'], lab_w, msk_w)
-        l_desc = infonce(outs['desc'], outs_w['desc'], batch['warped_valid_mask'], batch['inv_homographies'], device=dev, prepared=nce, **self.sparse)
-        loss = (l_det + l_det_w) + LAMBDA_DESC * l_desc + LAMBDA_OBJ * l_obj
+        if self.pair:
+            # both passes' heads are halves of one tensor: the detector loss of both in one call (sum of the two per-pass losses), the
+            # descriptors sampled by one launch -- each head receives ONE gradient tensor in its own memory layout
+            l_dets = self.det_loss(outs['semi_pair'], lab, msk, groups=2)
+            l_desc = infonce(outs['desc'], outs_w['desc'], batch['warped_valid_mask'], batch['inv_homographies'], device=dev, prepared=nce,
+                             descriptors_pair=outs['desc_pair'], **self.sparse)
+        else:
+            l_dets = self.det_loss(outs['semi'], lab, msk) + self.det_loss(outs_w['semi'], lab_w, msk_w)
+            l_desc = infonce(outs['desc'], outs_w['desc'], batch['warped_valid_mask'], batch['inv_homographies'], device=dev, prepared=nce, **self.sparse)
+        loss = l_dets + LAMBDA_DESC * l_desc + LAMBDA_OBJ * l_obj
         if scale != 1.0:
             loss = loss * scale                     # accelerator.backward divides by the accumulation steps
         if self.pair:

@@ -791,7 +791,7 @@ def train_forward_pair(net, x, x_w):
     semi, desc = heads[0], heads[1]
     if type(net).__name__ == "YOLOPointv52":
         desc = desc.div(torch.unsqueeze(torch.norm(desc, p=2, dim=1), 1))
-    outs = {'semi': semi[:B], 'desc': desc[:B], 'objects': list(heads[2:])}
+    outs = {'semi': semi[:B], 'desc': desc[:B], 'objects': list(heads[2:]), 'semi_pair': semi, 'desc_pair': desc}
     outs_w = {'semi': semi[B:], 'desc': desc[B:], 'objects': None}
     return outs, outs_w, tuple(heads), heads[0].grad_fn.graph
 

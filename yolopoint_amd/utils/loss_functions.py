@@ -35,10 +35,16 @@ class ComputeDetectorLoss:
     def __init__(self, device):
         self.device = device
 
-    def __call__(self, inp, target, mask):
+    def __call__(self, inp, target, mask, groups=1):
+        """groups > 1 (device path): `inp` / `target` / `mask` hold `groups` consecutive sample sets and the result is the SUM of the
+        losses of the sets (train.py:232: loss_det + loss_det_warp with both passes' logits in one tensor) -- one gradient tensor for
+        the whole input instead of one zero-padded tensor per set."""
         if (inp.is_cuda and inp.dtype == torch.float32 and inp.dim() == 4 and inp.shape[1] == 65 and target.dtype == torch.float32
                 and os.environ.get("YP_NATIVE_DETLOSS", "1") != "0"):
-            return _DetLossNative.apply(inp, target, mask.float().contiguous())
+            return _DetLossNative.apply(inp, target, mask.float().contiguous(), groups)
+        if groups != 1:
+            n = inp.shape[0] // groups
+            return sum(self(inp[g * n:(g + 1) * n], target[g * n:(g + 1) * n], mask[g * n:(g + 1) * n]) for g in range(groups))
         per_cell = F.binary_cross_entropy(torch.softmax(inp, dim=1), target, reduction='none').sum(dim=1)
         return (per_cell * mask).sum() / (mask.sum() + 1e-10)
 
@@ -50,7 +56,7 @@ class _DetLossNative(torch.autograd.Function):
 
     @staticmethod
     @_guarded
-    def forward(ctx, inp, target, mask):
+    def forward(ctx, inp, target, mask, groups=1):
         from .. import _hip
         import ctypes as C
         B, _, Hc, Wc = inp.shape
@@ -59,21 +65,29 @@ class _DetLossNative(torch.autograd.Function):
         if dz.stride() != inp.stride():
             inp = inp.contiguous()
             dz = torch.empty_like(inp)
-        sums = torch.empty(2, dtype=torch.float32, device=inp.device)
-        nb = l.yp_detloss_workspace_bytes(B, Hc, Wc)
+        target = target if target.shape[0] == B else target.contiguous()
+        sums = torch.empty((groups, 2), dtype=torch.float32, device=inp.device)
+        Bg = B // groups
+        nb = l.yp_detloss_workspace_bytes(Bg, Hc, Wc)
         ws = torch.empty(nb, dtype=torch.uint8, device=inp.device)
         zs, ts = (C.c_int64 * 4)(*inp.stride()), (C.c_int64 * 4)(*target.stride())
-        _hip.check(l.yp_detloss(inp.data_ptr(), zs, target.data_ptr(), ts, mask.data_ptr(), B, Hc, Wc, dz.data_ptr(), sums.data_ptr(), ws.data_ptr(), nb,
-                                _hip.stream_ptr()))
-        inv = 1.0 / (sums[1] + 1e-10)
+        for g in range(groups):                         # (one launch pair per sample set: each has its own mask normalisation)
+            _hip.check(l.yp_detloss(inp.data_ptr() + 4 * g * Bg * inp.stride(0), zs, target.data_ptr() + 4 * g * Bg * target.stride(0), ts,
+                                    mask.data_ptr() + 4 * g * Bg * Hc * Wc, Bg, Hc, Wc, dz.data_ptr() + 4 * g * Bg * dz.stride(0), sums[g].data_ptr(),
+                                    ws.data_ptr(), nb, _hip.stream_ptr()))
+        inv = 1.0 / (sums[:, 1] + 1e-10)                # [groups]
         ctx.save_for_backward(dz, inv)
-        return sums[0] * inv
+        ctx.groups = groups
+        return (sums[:, 0] * inv).sum() if groups > 1 else sums[0, 0] * inv[0]
 
     @staticmethod
     @_guarded
     def backward(ctx, g):
         dz, inv = ctx.saved_tensors
-        return dz * (g * inv), None, None
+        if ctx.groups == 1:
+            return dz * (g * inv[0]), None, None, None
+        per_sample = (g * inv).repeat_interleave(dz.shape[0] // ctx.groups).view(-1, 1, 1, 1)
+        return dz * per_sample, None, None, None
 
 
 class ComputeObjectLoss:
@@ -291,6 +305,42 @@ class _InfoNCENative(torch.autograd.Function):
         return dda_u * scale, ddb, None, None, None, None
 
 
+class _InfoNCEPairNative(torch.autograd.Function):
+    """_InfoNCENative over ONE [2n, D] tensor of sampled descriptors (rows [0, n): the image's, rows [n, 2n): the warped image's --
+    what one yp_points_sample launch over both passes' descriptor maps returns): one gradient tensor for both halves, no zero-padded
+    slice gradients (training step, pair mode)."""
+
+    @staticmethod
+    @_guarded
+    def forward(ctx, dab, idx, order, offsets, tau):
+        from .. import _hip
+        dab = dab.contiguous()
+        n, D = dab.shape[0] // 2, dab.shape[1]
+        E = idx.shape[1]
+        w = torch.empty((n, E), dtype=torch.float32, device=dab.device)
+        rows, lse = torch.empty((n,), dtype=torch.float32, device=dab.device), torch.empty((n,), dtype=torch.float32, device=dab.device)
+        grad = torch.empty_like(dab)                    # [dda (unscaled until the backward) | ddb]
+        pa, pb = dab.data_ptr(), dab.data_ptr() + 4 * n * D
+        _hip.check(_hip.lib().yp_infonce_fwd_grad(pa, pb, idx.data_ptr(), n, E, D, 1.0 / tau, w.data_ptr(), rows.data_ptr(), lse.data_ptr(), grad.data_ptr(),
+                                                  _hip.stream_ptr()))
+        ctx.save_for_backward(dab, order, offsets, w, lse, grad)
+        ctx.tau = tau
+        return rows.mean()
+
+    @staticmethod
+    @_guarded
+    def backward(ctx, g):
+        from .. import _hip
+        dab, order, offsets, w, lse, grad = ctx.saved_tensors
+        n, D = dab.shape[0] // 2, dab.shape[1]
+        E = w.shape[1]
+        scale = (g.float() * (1.0 / (ctx.tau * n))).reshape(1)
+        _hip.check(_hip.lib().yp_infonce_bwd_db(dab.data_ptr(), order.data_ptr(), offsets.data_ptr(), w.data_ptr(), lse.data_ptr(), n, E, D,
+                                                scale.data_ptr(), grad.data_ptr() + 4 * n * D, _hip.stream_ptr()))
+        grad[:n].mul_(scale)                            # (saved by this call only: scaled in place)
+        return grad, None, None, None, None
+
+
 class _PointSampleNative(torch.autograd.Function):
     """F.grid_sample(desc, uv, bilinear, align_corners=True) at [B,P] points -> [B,P,D], for a descriptor map whose memory is
     channels-innermost (what the network emits): csrc/losses.hip yp_points_sample_fwd / _bwd, one wavefront per point.  The
@@ -335,7 +385,8 @@ def infonce_edges(rnd):
 
 
 def infonce(descriptors, descriptors_warped, mask_valid_warp, inv_homographies, num_samples_per_image=1500,
-            num_masked_non_matches_per_match=120, cell_size=8, device='cpu', tau=0.07, perm_fn=None, randint_fn=None, prepared=None):
+            num_masked_non_matches_per_match=120, cell_size=8, device='cpu', tau=0.07, perm_fn=None, randint_fn=None, prepared=None,
+            descriptors_pair=None):
     """Cross-image InfoNCE between the descriptors of an image and of its warp (reference utils/loss_functions.py:484-597):
     every valid cell of image A is matched to the cell its inverse homography maps it to in image B;
     `num_masked_non_matches_per_match` random other matches are the negatives;
@@ -358,6 +409,13 @@ def infonce(descriptors, descriptors_warped, mask_valid_warp, inv_homographies, 
             return _PointSampleNative.apply(desc, idx.contiguous())
         return F.grid_sample(desc, idx.unsqueeze(1), mode='bilinear', align_corners=True).squeeze(2).transpose(1, 2)
 
+    if descriptors_pair is not None and rnd.shape[1] + 1 <= 512 and os.environ.get("YP_NATIVE_INFONCE", "1") != "0":
+        # both passes' descriptor maps as one [2B, D, Hc, Wc] tensor (image pass first; `descriptors` / `descriptors_warped` are its halves):
+        # one sampling launch, one loss call, ONE gradient map for the whole tensor
+        dab = sample(descriptors_pair, torch.cat((ua, ub)))
+        if edges is None:
+            edges = infonce_edges(rnd)
+        return _InfoNCEPairNative.apply(dab.flatten(0, 1), *edges, float(tau))
     da = sample(descriptors, ua)                       # [B, pool, D]
     db = sample(descriptors_warped, ub)
     D = da.shape[-1]
