@@ -386,13 +386,21 @@ def test_backward_matches_reference_golden(cuda, tag, version, B, S, seed):
     print(tag, "worst normalised deviation from the reference gradients:", worst)
 
 
-@pytest.mark.parametrize("name,version,B,H,W", [("YOLOPoint", "n", 2, 64, 64), ("YOLOPoint", "s", 3, 128, 64), ("YOLOPointv52", "n", 2, 64, 128)])
-def test_pair_pass_matches_two_oracle_passes(cuda, name, version, B, H, W):
+@pytest.mark.parametrize("name,version,B,H,W,flat", [("YOLOPoint", "n", 2, 64, 64, False), ("YOLOPoint", "s", 3, 128, 64, False),
+                                                      ("YOLOPointv52", "n", 2, 64, 128, False), ("YOLOPoint", "s", 2, 128, 128, True)])
+def test_pair_pass_matches_two_oracle_passes(cuda, name, version, B, H, W, flat):
     """forward_pair(img, img_warp) == model(img); model(img_warp) of the reference step (train.py:208,220) run through the oracle one
     after the other: outputs of both passes, BatchNorm running statistics after both updates, and every parameter gradient of a loss
     over the image pass's three heads and the warped pass's semi / desc (fp32 compute path: the two-call bars)."""
     m, sd = make_model(version, 41, dtype="f32", model_name=name)
     m = m.to(cuda).train()
+    if flat:
+        # the layout a TrainStep gives the model (flat parameter arena in gradient-ready order, C3 siblings back to back): cv1 + cv2 of
+        # every C3 block then run as ONE layer with 2c_ output channels
+        from yolopoint_amd.dp import GradAllReducer
+        from yolopoint_amd.training import grad_ready_groups, link_siblings
+        GradAllReducer(None, groups=grad_ready_groups(m.model)).flatten_parameters()
+        link_siblings(m.model)
     x, xw = net_oracle.synth_image(B, 3, H, W, 41), net_oracle.synth_image(B, 3, H, W, 42)
     fwd = net_oracle.yolopointv52_forward if name == "YOLOPointv52" else net_oracle.yolopoint_forward
     leaf = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in sd.items()}
@@ -413,6 +421,7 @@ def test_pair_pass_matches_two_oracle_passes(cuda, name, version, B, H, W):
     loss_of(ref, ref_w, "cpu").backward()
     out, out_w, heads, graph = m.model.forward_pair(x.to(cuda), xw.to(cuda))
     assert out_w["objects"] is None and graph.G == 2
+    assert len(graph.vparts) == (3 * 10 if flat else 0)       # (10 C3 blocks x {filter, BN weight, BN bias} merged, or none)
     for k in ("semi", "desc"):
         assert rel_err(out[k], ref[k].detach())[0] < 1e-3 and rel_err(out_w[k], ref_w[k].detach())[0] < 1e-3, k
     for t, r in zip(out["objects"], ref["objects"]):

@@ -79,8 +79,9 @@ class TrainStep:
         self.gas, self.max_grad_norm = int(gas), max_grad_norm
         # gradient buckets in the order the gradients become final: the parameters only the full backward reaches first (all-reduced
         # while the keypoint-only backward of the warped pass runs), the shared trunk + keypoint / descriptor heads last
-        from .training import grad_ready_groups
+        from .training import grad_ready_groups, link_siblings
         groups = grad_ready_groups(model.model)
+        link_siblings(model.model)
         self.reducer = GradAllReducer(None, group=group, groups=groups)
         kp = set(id(p) for p in groups[1][1])
         # YP_TRAIN_PAIR=0: the two forwards of a step as two native passes (two graphs, the schedule of round 1) instead of one 2B-sample pass

@@ -59,6 +59,7 @@ class TrainGraph:
         self.gwritten = {}         # data_ptr -> list of written (lo, hi) channel ranges
         self.collect = []          # callables run after the backward plan: native buffers -> parameter gradients
         self.pgrads = {}           # parameter -> fp32 gradient tensor (reference layout)
+        self.vparts = {}           # id(merged view of adjacent parameters) -> [the parameters]
         self.keep = []
         self.busy = False
         wsb = lib().yp_bn_workspace_bytes(B, H // 2, W // 2, 1024) + 8 * self.G * 2048 + 4096
@@ -83,6 +84,18 @@ class TrainGraph:
 
     # ------------------------------------------------------------------ helpers
     def pgrad(self, param):
+        parts = self.vparts.get(id(param))
+        if parts is not None:
+            # the merged tensor of adjacent parameters (c3: cv1 + cv2 as one layer): one gradient tensor, the real parameters' are its slices
+            if param not in self.pgrads:
+                g = torch.zeros_like(param, dtype=torch.float32)
+                self.pgrads[param] = g
+                off = 0
+                for rp in parts:
+                    self.pgrads[rp] = g.view(-1)[off:off + rp.numel()].view_as(rp)
+                    off += rp.numel()
+            self.touched.update(parts)
+            return self.pgrads[param]
         if param not in self.pgrads:
             self.pgrads[param] = torch.zeros_like(param, dtype=torch.float32)
         self.touched.add(param)
@@ -313,8 +326,43 @@ class TrainGraph:
         t = self.conv_bn_act(m.cv1, x)
         return self.conv_bn_act(m.cv2, t, out=out, res=x if m.add else None)
 
+    def merged_siblings(self, a, b):
+        """cv1 / cv2 of a C3 block read the same input through 1x1 convolutions: when their parameters and BatchNorm buffers lie back to
+        back in memory (optim.FlatAdam's arena in training.grad_ready_groups order + training.link_siblings) they ARE one Conv with
+        2c_ output channels -- returns that layer (a namespace with the attributes conv_bn_act reads), else None."""
+        import types
+        if os.environ.get("YP_MERGE_SIBLINGS", "1") == "0" or type(a.act) is not type(b.act) or a.bn.eps != b.bn.eps or a.bn.momentum != b.bn.momentum:
+            return None
+        pairs = [(a.conv.weight, b.conv.weight), (a.bn.weight, b.bn.weight), (a.bn.bias, b.bn.bias), (a.bn.running_mean, b.bn.running_mean),
+                 (a.bn.running_var, b.bn.running_var)]
+        if a.conv.weight.shape != b.conv.weight.shape or a.conv.kernel_size != (1, 1) or a.conv.stride != (1, 1) or a.conv.bias is not None:
+            return None
+        if any(u.dtype != torch.float32 or not u.is_contiguous() or u.data_ptr() + 4 * u.numel() != v.data_ptr() or
+               u.untyped_storage().data_ptr() != v.untyped_storage().data_ptr() for u, v in pairs):
+            return None
+
+        def both(u, v):
+            t = torch.as_strided(u.detach(), (2 * u.shape[0],) + tuple(u.shape[1:]), u.stride())
+            self.vparts[id(t)] = [u, v]
+            self.keep.append(t)
+            return t
+        w, g_, b_ = (both(u, v) for u, v in pairs[:3])
+        rm, rv = (torch.as_strided(u, (2 * u.shape[0],), (1,)) for u, v in pairs[3:])
+        return types.SimpleNamespace(conv=types.SimpleNamespace(weight=w, kernel_size=(1, 1), stride=(1, 1), padding=(0, 0), out_channels=w.shape[0]),
+                                     bn=types.SimpleNamespace(weight=g_, bias=b_, running_mean=rm, running_var=rv, eps=a.bn.eps, momentum=a.bn.momentum),
+                                     act=a.act)
+
     def c3(self, m, x, out=None):
         c_ = m.cv1.conv.out_channels
+        both = self.merged_siblings(m.cv1, m.cv2)
+        if both is not None:
+            # one convolution + one BatchNorm for cv1 and cv2 (forward: 1 conv + 2 BN launches instead of 2 + 4; backward: one BN backward,
+            # one dgrad with K = 2c_ instead of two accumulating ones, one weight-gradient entry); cv3 reads [m(t), u] as two sources
+            tu = self.conv_bn_act(both, x)
+            t, u = tu.buf.view(tu.coff, c_), tu.buf.view(tu.coff + c_, c_)
+            for blk in m.m:
+                t = self.bottleneck(blk, t)
+            return self.conv_bn_act(m.cv3, [t, u], out=out)
         x0 = x[0] if isinstance(x, (list, tuple)) else x
         cat = self.fwd.new_buf(x0.LH, x0.LW, 2 * c_)
         t = self.conv_bn_act(m.cv1, x)
@@ -771,12 +819,40 @@ def grad_ready_groups(net):
     (Detect, PAN, YOLO encoder -- in reverse registration order, heads first), then the shared trunk and the keypoint / descriptor
     heads, which both passes contribute to.  Returns [("detector", [...]), ("keypoint", [...])]: the bucket plan of dp.GradAllReducer
     -- the detector buckets are all-reduced while the second backward pass is still running."""
+    named = list(reversed(list(net.named_parameters())))
+    # cv1 / cv2 of every C3 block side by side, tensor kind by tensor kind: laid out back to back (dp.GradAllReducer.flatten_parameters)
+    # the two layers are one Conv with 2c_ output channels for the training plans (TrainGraph.merged_siblings)
+    by_name = dict(named)
+    for prefix, mod in net.named_modules():
+        if type(mod).__name__ != "C3":
+            continue
+        six = [f"{prefix}.{cv}.{t}" for t in ("conv.weight", "bn.weight", "bn.bias") for cv in ("cv1", "cv2")]
+        if not all(k in by_name and by_name[k].requires_grad for k in six):
+            continue
+        pos = min(i for i, (k, _) in enumerate(named) if k in six)
+        named = [kv for kv in named if kv[0] not in six]
+        named[pos:pos] = [(k, by_name[k]) for k in six]
     kp, det = [], []
-    for name, p in reversed(list(net.named_parameters())):
+    for name, p in named:
         if not p.requires_grad:
             continue
         (kp if name.split(".")[0] in KP_BRANCH_MODULES else det).append(p)
     return [("detector", det), ("keypoint", kp)]
+
+
+def link_siblings(net):
+    """BatchNorm running statistics of every C3 block's cv1 / cv2 back to back in memory (values kept; the buffers become views of one
+    tensor) -- the buffer half of what TrainGraph.merged_siblings needs; the parameter half is the arena order of grad_ready_groups."""
+    with torch.no_grad():
+        for mod in net.modules():
+            if type(mod).__name__ != "C3" or not hasattr(mod.cv1, "bn"):
+                continue
+            for name in ("running_mean", "running_var"):
+                u, v = getattr(mod.cv1.bn, name), getattr(mod.cv2.bn, name)
+                if u.data_ptr() + 4 * u.numel() == v.data_ptr() and u.untyped_storage().data_ptr() == v.untyped_storage().data_ptr():
+                    continue
+                both = torch.cat((u, v))
+                u.data, v.data = both[:u.numel()], both[u.numel():]
 
 
 def train_forward_pair(net, x, x_w):
