@@ -16,7 +16,7 @@ Sub-records of the same line (each measured in this process, after the top-level
                 launches' durations, HIP events on the launch stream; `backbone` = the same for Conv1..SPPooling (F_bb)
   cpu_baseline  the oracle's PyTorch-CPU fp32 forward timed on this host's cores (rank 0, N = 1), >= 3 warm-ups
   train         BASELINE configs[2]: the reference's optimizer step (train.py:189-259: two train-mode forwards, detector + object + InfoNCE
-                losses, native backward, bucketed gradient all-reduce overlapped with the second backward pass, fused Adam), 8 samples per
+                losses, native backward, bucketed gradient all-reduce overlapped with the trunk backward plan, one-launch Adam), 8 samples per
                 GPU, 640x640, bf16 -- DATA PARALLEL over all N ranks (weak scaling: 8 samples per GPU); reports the bucket plan, payload
                 and the time the compute stream waits for the collectives (exposed communication)
   train_bs64    (N = 1) the metric's "train bs=64" on one GPU the way the reference reaches its nominal batch (train.py:38-43):
@@ -344,9 +344,11 @@ def run_train(a, rank, world, dev, version, batch, steps, warmup, gas=1, size=64
     samples = batch * gas * world * steps
     gflop_sample = TRAIN_GFLOP_PER_SAMPLE.get(version, 0.0) * (size / 640.0) ** 2
     achieved = gflop_sample * samples / wall / 1e3 / max(world, 1)          # TFLOP/s per GPU
-    rec = {"workload": f"BASELINE.json configs[{2 if version == 's' else 4}] shape: YOLOPoint-{version} optimizer step as src/train.py:189-259 (2 train-mode "
-                       f"forwards, detector + object + InfoNCE losses through csrc/losses.hip, native backward, bucketed gradient all-reduce overlapped with "
-                       f"the keypoint-only backward, fused Adam), {batch} samples/GPU/micro-batch x gas {gas}, {size}x{size}, {dtype}",
+    rec = {"workload": f"BASELINE.json configs[{2 if version == 's' else 4}] shape: YOLOPoint-{version} optimizer step as src/train.py:189-259 (both train-mode "
+                       f"forwards as one 2B-sample native pass with per-pass BatchNorm statistics, detector + object + InfoNCE losses through csrc/losses.hip, "
+                       f"native backward = YOLO-branch plan over the image pass then trunk plan over both passes, bucketed gradient all-reduce of the "
+                       f"detector-group buckets overlapped with the trunk plan, one-launch Adam over flat arenas), {batch} samples/GPU/micro-batch x gas {gas}, "
+                       f"{size}x{size}, {dtype}",
            "value": round(2 * samples / wall, 1), "unit": "images/s (an image pair counts as 2 images)", "samples_per_s": round(samples / wall, 1),
            "ms_per_step": round(wall / steps * 1e3, 3), "steps": steps, "warmup": warmup, "n_gpus": world, "dtype": dtype, "scaling": "weak",
            "per_gpu_batch": batch, "gas": gas, "global_batch": batch * gas * world, "parallelism": f"dp{world}",
