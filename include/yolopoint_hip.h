@@ -37,7 +37,11 @@ enum {
 };
 
 /* arithmetic type of activations / packed weights */
-enum { YP_F16 = 0, YP_BF16 = 1, YP_F32 = 2 };
+enum { YP_F16 = 0, YP_BF16 = 1, YP_F32 = 2,
+       /* 8-bit OCP floating point INPUTS of a convolution (one byte per element; results are bf16, the accumulation fp32):
+        * YP_FP8 = filter e4m3 x activation e4m3 (forward), YP_FP8_BF8 = filter e4m3 x activation e5m2 (dgrad: the "activation" is dy).
+        * Per-tensor scales: real value = stored value * scale (YpConvDesc.scale_in / scale_w, yp_quantize_fp8). */
+       YP_FP8 = 3, YP_FP8_BF8 = 4 };
 /* fused activation */
 enum { YP_ACT_NONE = 0, YP_ACT_SILU = 1 };
 
@@ -132,6 +136,11 @@ typedef struct YpConvDesc {
      * into the zero-initialised `out` (order of arrival). */
     float* split_slabs;
     int64_t split_stride;
+    /* dtype YP_FP8 / YP_FP8_BF8: device scalars, the dequantisation scales of in0 / in1 (one common scale) and of the packed filter; the
+     * accumulators are multiplied by *scale_in * *scale_w before bias / BatchNorm statistics / the 16-bit store.  Channels % 64 == 0,
+     * Kpad % 64 == 0 (bytes = elements), tail_zero, no out_f32 / split / Detect / pointwise prologue; generic kernel only. */
+    const float* scale_in;
+    const float* scale_w;
 } YpConvDesc;
 
 /* Number of bn_partial rows the launch described by `d` (its tile id included) writes; rows are batch-major, so with `groups` statistics
@@ -321,6 +330,23 @@ typedef struct YpPackEntry {
     int64_t Cout, Cin, R, S, c0, Cj, mode, Cout_pad, Kpad, Npad, blk0;
 } YpPackEntry;
 int yp_pack_weight_batch(const YpPackEntry* table_dev, int n_entries, int total_blocks, int dtype, void* stream);
+
+/* ---- 8-bit (OCP fp8) training convolutions: BASELINE.json configs[4].  real = stored * scale, per tensor; scales are device scalars.
+ * yp_quantize_fp8: 16-bit NHWC view -> 1-byte NHWC view (format 0 = e4m3, saturating at 448; 1 = e5m2, saturating at 57344) with the
+ * CURRENT *scale, and max|src| recorded into *amax (atomic max; may be NULL).  yp_fp8_update_scales: for n tensors at once,
+ * scale[i] = amax[i] * margin / fmax[i] where amax[i] > 0 (else kept), amax[i] = 0 -- the next step's scales ("delayed scaling").
+ * yp_pack_weight_fp8_batch: yp_pack_weight_batch for e4m3 packed filters (blocks of 1024 packed elements; each entry quantises with
+ * its *scale and records max|w| into *amax). */
+int yp_quantize_fp8(YpView src, YpView dst, int src_dtype, int B, int format, const float* scale, float* amax, void* stream);
+int yp_fp8_update_scales(float* scale, float* amax, const float* fmax, int n, float margin, void* stream);
+typedef struct YpPackEntry8 {
+    const float* w;
+    void* dst;
+    const float* scale;
+    float* amax;
+    int64_t Cout, Cin, R, S, c0, Cj, mode, Cout_pad, Kpad, Npad, blk0;
+} YpPackEntry8;
+int yp_pack_weight_fp8_batch(const YpPackEntry8* table_dev, int n_entries, int total_blocks, void* stream);
 
 /* InfoNCE descriptor loss (reference utils/loss_functions.py:484-597) without the gathered-negatives / Gram-matrix tensors.
  *   da, db [n][D] fp32 (D a multiple of 64, <= 256): sampled descriptors of the image / the warped image

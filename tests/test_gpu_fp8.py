@@ -1,0 +1,155 @@
+"""8-bit (OCP fp8) convolution path of BASELINE.json configs[4]: the quantiser, the e4m3 filter packer and the generic implicit-GEMM
+kernel's YP_FP8 (e4m3 x e4m3, forward) / YP_FP8_BF8 (filter e4m3 x dy e5m2, dgrad) instantiations, each against PyTorch on the SAME
+8-bit operands (torch.float8_e4m3fn / float8_e5m2 are the OCP formats gfx950 implements): the kernel's only freedom is the fp32
+accumulation order and the final bf16 rounding."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from yolopoint_amd import _hip
+from yolopoint_amd._hip import YpView, YpConvDesc, lib, check
+
+pytestmark = pytest.mark.gpu
+E4, E5 = torch.float8_e4m3fn, torch.float8_e5m2
+
+
+def padded(B, H, W, C_, dtype, dev):
+    """[B,H,W,C] tensor inside a flat buffer followed by zeros (YpConvDesc.tail_zero)."""
+    flat = torch.zeros(B * H * W * C_ + C_ + 256, dtype=dtype, device=dev)
+    return flat, flat[:B * H * W * C_].view(B, H, W, C_)
+
+
+def view(t, coff, C_, ups=0):
+    v = YpView()
+    v.ptr, v.H, v.W, v.cstride, v.coff, v.C, v.ups = t.data_ptr(), t.shape[1], t.shape[2], t.shape[3], coff, C_, ups
+    return v
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+@pytest.mark.parametrize("B,H,W,Cbuf,coff,C_", [(2, 20, 20, 128, 0, 128), (3, 7, 9, 192, 64, 64), (1, 40, 40, 64, 0, 64)])
+def test_quantizer_matches_torch_float8(cuda, fmt, B, H, W, Cbuf, coff, C_):
+    torch.manual_seed(H + fmt)
+    src = (torch.randn(B, H, W, Cbuf, device=cuda) * 3.0).to(torch.bfloat16)
+    src[0, 0, 0, coff] = 1e4                                   # saturates e4m3 (448 * scale) but not e5m2
+    dst = torch.zeros(B, H, W, Cbuf, dtype=torch.uint8, device=cuda)
+    scale, amax = torch.tensor([0.05], device=cuda), torch.zeros(1, device=cuda)
+    check(lib().yp_quantize_fp8(view(src, coff, C_), view(dst, coff, C_), _hip.YP_BF16, B, fmt, scale.data_ptr(), amax.data_ptr(), _hip.stream_ptr()))
+    torch.cuda.synchronize()
+    x = src[..., coff:coff + C_].float() / 0.05
+    mx = 448.0 if fmt == 0 else 57344.0
+    ref = x.clamp(-mx, mx).to(E4 if fmt == 0 else E5)
+    got = dst[..., coff:coff + C_].view(E4 if fmt == 0 else E5)
+    assert torch.equal(got.view(torch.uint8), ref.view(torch.uint8))
+    assert float(amax) == float(src[..., coff:coff + C_].float().abs().max())
+    assert int(dst[..., :coff].sum()) == 0 and int(dst[..., coff + C_:].sum()) == 0      # the other channels of the buffer are untouched
+    # the recorded maximum becomes the next scale
+    fmax = torch.tensor([mx], device=cuda)
+    top = float(amax)
+    check(lib().yp_fp8_update_scales(scale.data_ptr(), amax.data_ptr(), fmax.data_ptr(), 1, 1.0, _hip.stream_ptr()))
+    assert abs(float(scale) - top / mx) < 1e-6 * top / mx and float(amax) == 0.0
+
+
+def pack_e4m3(w, sw, Kpad, Npad, mode=0, cout_pad=None):
+    """torch statement of yp_pack_weight's layouts, quantised: [Npad + 1][Kpad] bytes."""
+    Cout, Cin, R, S = w.shape
+    q = (w / sw).clamp(-448, 448)
+    out = torch.zeros(Npad + 1, Kpad, dtype=torch.uint8, device=w.device)
+    if mode == 0:
+        rows = q.permute(0, 2, 3, 1).reshape(Cout, R * S * Cin)
+        out[:Cout, :R * S * Cin] = rows.to(E4).view(torch.uint8)
+    else:
+        cp = cout_pad
+        t = torch.zeros(Cin, R, S, cp, device=w.device)
+        t[..., :Cout] = q.flip(2, 3).permute(1, 2, 3, 0)
+        out[:Cin, :R * S * cp] = t.reshape(Cin, R * S * cp).to(E4).view(torch.uint8)
+    return out
+
+
+CONVS = {
+    "pointwise_256_256": dict(cin=(256,), cout=256, k=1, s=1, H=20, B=2),
+    "pointwise_two_sources_upsampled": dict(cin=(128, 64), ups0=True, cout=192, k=1, s=1, H=16, B=2),
+    "conv3x3_residual": dict(cin=(64,), cout=64, k=3, s=1, H=20, B=2, res=True),
+    "conv3x3_stride2": dict(cin=(128,), cout=256, k=3, s=2, H=10, B=3),
+    "ragged_m_and_n": dict(cin=(192,), cout=72, k=1, s=1, H=9, B=5),
+}
+
+
+@pytest.mark.parametrize("act_fmt", [0, 1])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("name", list(CONVS))
+def test_fp8_convolution_matches_torch_on_the_same_bytes(cuda, name, tile, act_fmt):
+    c = CONVS[name]
+    cins, cout, k, s, Ho, B = c["cin"], c["cout"], c["k"], c["s"], c["H"], c["B"]
+    Hi = Ho * s
+    ups0 = c.get("ups0", False)
+    torch.manual_seed(len(name) + tile)
+    sx, sw = 0.031, 0.0017
+    fmt = E4 if act_fmt == 0 else E5
+    srcs, keep = [], []
+    for i, ci in enumerate(cins):
+        h = Hi >> (1 if (i == 0 and ups0) else 0)
+        flat, t = padded(B, h, h, ci, torch.uint8, cuda)
+        t.copy_((torch.randn(B, h, h, ci, device=cuda) * 2.0 / sx).clamp(-448, 448).to(fmt).view(torch.uint8))
+        srcs.append(t); keep.append(flat)
+    w = torch.randn(cout, sum(cins), k, k, device=cuda) * (1.5 / (sum(cins) * k * k) ** 0.5)
+    Kpad, Npad = lib().yp_conv_kpad(k * k * sum(cins), _hip.YP_FP8), (cout + 7) // 8 * 8
+    wq = pack_e4m3(w, sw, Kpad, Npad)
+    out = torch.zeros(B, Ho, Ho, Npad, dtype=torch.bfloat16, device=cuda)
+    res = (torch.randn(B, Ho, Ho, Npad, device=cuda)).to(torch.bfloat16) if c.get("res") else None
+    scales = torch.tensor([sx, sw], device=cuda)
+    d = YpConvDesc()
+    d.in0 = view(srcs[0], 0, cins[0], 1 if ups0 else 0)
+    if len(srcs) == 2:
+        d.in1 = view(srcs[1], 0, cins[1])
+    d.out = view(out, 0, Npad)
+    if res is not None:
+        d.res = view(res, 0, Npad)
+    d.weight, d.bias = wq.data_ptr(), None
+    d.dtype, d.out_f32, d.B = (_hip.YP_FP8 if act_fmt == 0 else _hip.YP_FP8_BF8), 0, B
+    d.Hi, d.Wi, d.Ho, d.Wo = Hi, Hi, Ho, Ho
+    d.R, d.S, d.stride_h, d.stride_w, d.pad_h, d.pad_w = k, k, s, s, k // 2, k // 2
+    d.Kpad, d.Npad, d.act, d.tile, d.tail_zero = Kpad, Npad, _hip.YP_ACT_NONE, tile, 1
+    d.dil_h = d.dil_w = 1
+    d.ksplit = 1
+    d.scale_in, d.scale_w = scales.data_ptr(), scales.data_ptr() + 4
+    check(lib().yp_conv2d(C.byref(d), _hip.stream_ptr()))
+    torch.cuda.synchronize()
+    xs = []
+    for i, t in enumerate(srcs):
+        x = t.view(fmt).float().permute(0, 3, 1, 2) * sx
+        xs.append(F.interpolate(x, scale_factor=2, mode="nearest") if (i == 0 and ups0) else x)
+    wr = wq[:cout, :k * k * sum(cins)].view(E4).float().reshape(cout, k, k, sum(cins)).permute(0, 3, 1, 2) * sw
+    ref = F.conv2d(torch.cat(xs, 1), wr, None, s, k // 2).permute(0, 2, 3, 1)
+    if res is not None:
+        ref = ref + res[..., :cout].float()
+    got = out[..., :cout].float()
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err < 6e-3, (name, tile, err)                 # one bf16 rounding of the result
+    assert float(out[..., cout:].float().abs().max()) == 0.0 if Npad > cout else True
+
+
+def test_fp8_filter_packer_matches_torch(cuda):
+    """yp_pack_weight_fp8_batch: forward (mode 0) and dgrad (mode 1: flipped, channel-transposed) packed e4m3 filters of one master."""
+    torch.manual_seed(3)
+    Cout, Cin, k = 96, 128, 3
+    w = torch.randn(Cout, Cin, k, k, device=cuda) * 0.05
+    sw = float(w.abs().max()) / 448.0
+    scale, amax = torch.tensor([sw, sw], device=cuda), torch.zeros(2, device=cuda)
+    l = lib()
+    ents, bufs, blk0 = [], [], 0
+    for mode in (0, 1):
+        cq, nreal = (Cin, Cout) if mode == 0 else (Cout, Cin)
+        Kpad, Npad = l.yp_conv_kpad(k * k * cq, _hip.YP_FP8), (nreal + 7) // 8 * 8
+        dst = torch.full((Npad + 1, Kpad), 255, dtype=torch.uint8, device=cuda)
+        bufs.append((dst, Kpad, Npad))
+        ents.append([w.data_ptr(), dst.data_ptr(), scale.data_ptr() + 4 * mode, amax.data_ptr() + 4 * mode, Cout, Cin, k, k, 0, Cin, mode, Cout, Kpad, Npad, blk0])
+        blk0 += -(-((Npad + 1) * Kpad) // 1024)
+    table = torch.tensor(ents, dtype=torch.int64, device=cuda)
+    check(l.yp_pack_weight_fp8_batch(table.data_ptr(), 2, blk0, _hip.stream_ptr()))
+    torch.cuda.synchronize()
+    for mode, (dst, Kpad, Npad) in enumerate(bufs):
+        ref = pack_e4m3(w, sw, Kpad, Npad, mode, Cout)
+        assert torch.equal(dst, ref), mode
+    assert float(amax[0]) == float(w.abs().max()) == float(amax[1])

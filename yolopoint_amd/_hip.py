@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libyolopoint_hip.so")
 
 YP_F16, YP_BF16, YP_F32 = 0, 1, 2
+YP_FP8, YP_FP8_BF8 = 3, 4          # 8-bit convolution INPUTS (e4m3 x e4m3 | filter e4m3 x activation e5m2); results are bf16
 YP_ACT_NONE, YP_ACT_SILU = 0, 1
 
 
@@ -36,7 +37,8 @@ class YpConvDesc(C.Structure):
                 ("pre_weight", C.c_void_p), ("pre_bias", C.c_void_p), ("pre_Kpad", C.c_int32), ("pre_Npad", C.c_int32),
                 ("pre_act", C.c_int32), ("post_act", C.c_int32),
                 ("post_weight", C.c_void_p), ("post_bias", C.c_void_p), ("post_Kpad", C.c_int32), ("post_Npad", C.c_int32),
-                ("bn_partial", C.c_void_p), ("split_slabs", C.c_void_p), ("split_stride", C.c_int64)]
+                ("bn_partial", C.c_void_p), ("split_slabs", C.c_void_p), ("split_stride", C.c_int64),
+                ("scale_in", C.c_void_p), ("scale_w", C.c_void_p)]
 
 
 class YpDetectDesc(C.Structure):
@@ -64,6 +66,9 @@ SIGNATURES = {
     "yp_conv2d_detect": (_i, [C.POINTER(YpConvDesc), C.POINTER(YpDetectDesc), _p]),
     "yp_conv_kpad": (_i, [_i, _i]),
     "yp_sum_slabs": (_i, [_p, _p, _sz, _i, _p]),
+    "yp_quantize_fp8": (_i, [YpView, YpView, _i, _i, _i, _p, _p, _p]),
+    "yp_fp8_update_scales": (_i, [_p, _p, _p, _i, _f, _p]),
+    "yp_pack_weight_fp8_batch": (_i, [_p, _i, _i, _p]),
     "yp_adam_step": (_i, [_p, _p, _p, _p, _sz, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i, _p]),
     "yp_sum_slabs_tree": (_i, [_p, _p, _sz, _i, _i, _p]),
     "yp_stem_wgrad": (_i, [YpView, YpView, _i, _i, _p, _p, _p]),

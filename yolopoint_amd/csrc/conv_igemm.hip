@@ -31,7 +31,7 @@ template <int DT> struct Elem;
 template <> struct Elem<YP_F16> {
     using frag = f16x8;
     using scalar = _Float16;
-    static constexpr int BYTES = 2, KPL = 8, KM = 32;
+    static constexpr int BYTES = 2, OBYTES = 2, KPL = 8, KM = 32;
     static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
     }
@@ -39,15 +39,39 @@ template <> struct Elem<YP_F16> {
 template <> struct Elem<YP_BF16> {
     using frag = bf16x8;
     using scalar = __bf16;
-    static constexpr int BYTES = 2, KPL = 8, KM = 32;
+    static constexpr int BYTES = 2, OBYTES = 2, KPL = 8, KM = 32;
     static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+// 8-bit inputs (OCP fp8, one byte per element), bf16 results.  A 64-byte k tile row holds 64 elements; a lane's 16-byte fragment feeds
+// TWO 16x16x32 MFMAs (its low and its high 8 bytes): filter and activation fragments are cut the same way, so the k permutation inside
+// the tile cancels in the dot product and the DMA / LDS layout / swizzle of the 16-bit kernels carries over byte for byte.
+//   YP_FP8:     filter e4m3 x activation e4m3 (forward)        YP_FP8_BF8: filter e4m3 x activation e5m2 (dgrad: the activation is dy)
+template <> struct Elem<YP_FP8> {
+    using frag = u32x4;
+    using scalar = __bf16;
+    static constexpr int BYTES = 1, OBYTES = 2, KPL = 16, KM = 64;
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+        const long a0 = ((long)a[1] << 32) | a[0], a1 = ((long)a[3] << 32) | a[2], b0 = ((long)b[1] << 32) | b[0], b1 = ((long)b[3] << 32) | b[2];
+        c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a0, b0, c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a1, b1, c, 0, 0, 0);
+    }
+};
+template <> struct Elem<YP_FP8_BF8> {
+    using frag = u32x4;
+    using scalar = __bf16;
+    static constexpr int BYTES = 1, OBYTES = 2, KPL = 16, KM = 64;
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+        const long a0 = ((long)a[1] << 32) | a[0], a1 = ((long)a[3] << 32) | a[2], b0 = ((long)b[1] << 32) | b[0], b1 = ((long)b[3] << 32) | b[2];
+        c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(a0, b0, c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(a1, b1, c, 0, 0, 0);
     }
 };
 template <> struct Elem<YP_F32> {
     using frag = float;
     using scalar = float;
-    static constexpr int BYTES = 4, KPL = 1, KM = 4;
+    static constexpr int BYTES = 4, OBYTES = 4, KPL = 1, KM = 4;
     static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
     }
@@ -120,6 +144,8 @@ struct ConvKArgs {
     float* det_x;
     float* det_z;
     float* stats;                  // STATS instantiations: per-64-pixel-row-block column sums [row block][2][Cout] (BatchNorm statistics)
+    const float* scale_in;         // 8-bit input types: the accumulators are multiplied by *scale_in * *scale_w (device scalars: the
+    const float* scale_w;          // dequantisation scales of the activation and of the filter) before the epilogue
 };
 
 // sigmoid as v_mul, v_exp_f32, v_add, v_rcp_f32 (rel. error ~1e-7); a plain 1/(1+expf(-x)) is ~25 instructions
@@ -136,7 +162,7 @@ __device__ __forceinline__ float yp_silu(float x) {
 template <int DT, bool OUT_F32, int CW>
 __device__ __forceinline__ void yp_store_chunk(const ConvKArgs& a, int m, int nc, float (&v)[CW]) {
     using E = Elem<DT>;
-    constexpr int EB = E::BYTES;
+    constexpr int EB = E::OBYTES;        // (results and the residual they add are 16-bit for the 8-bit input types)
     if (a.has_res) {
         const char* rp = a.res + ((size_t)m * a.res_cs + a.res_co + nc) * EB;
         if constexpr (DT == YP_F32) {
@@ -700,6 +726,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     }
     }
 
+    if constexpr (E::BYTES == 1) {          // 8-bit inputs: back to real units (dequantisation scales of activation and filter)
+        const float osc = a.scale_in[0] * a.scale_w[0];
+#pragma unroll
+        for (int f = 0; f < FN; ++f)
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) acc[f][fm] *= osc;
+    }
     YP_TL(40);
     // ---- epilogue: bias -> activation -> (+ residual) -> store, 16-byte vectors per pixel
 #pragma unroll
@@ -1626,7 +1659,7 @@ hipError_t launch_tile(const ConvKArgs& a, int nblk, hipStream_t st) {
 
 template <int DT, bool OUT_F32, bool FAST, bool DETECT = false, bool STATS = false>
 hipError_t launch_cfg(int tile, const ConvKArgs& a, int nblk, hipStream_t st) {
-    constexpr bool V2OK = FAST && DT != YP_F32 && !STATS;
+    constexpr bool V2OK = FAST && (DT == YP_F16 || DT == YP_BF16) && !STATS;
     switch (tile) {
         case 1: return launch_tile<DT, OUT_F32, FAST, DETECT, 128, 32, 4, 1, 4, STATS>(a, nblk, st);
         case 2: return launch_tile<DT, OUT_F32, FAST, DETECT, 128, 64, 4, 1, 4, STATS>(a, nblk, st);
@@ -1725,7 +1758,7 @@ int pick_tile(int M, int N) {
 }  // namespace
 
 extern "C" int yp_conv_kpad(int K, int dtype) {
-    const int g = dtype == YP_F32 ? 32 : 64;   // 128 bytes of k per packed row granule
+    const int g = dtype == YP_F32 ? 32 : ((dtype == YP_FP8 || dtype == YP_FP8_BF8) ? 128 : 64);   // 128 bytes of k per packed row granule
     return yp_cdiv(K, g) * g;
 }
 
@@ -1734,8 +1767,12 @@ static thread_local int* g_bn_rows_query = nullptr;
 
 int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t stream) {
     YP_REQUIRE(d != nullptr, "yp_conv2d: null descriptor");
-    YP_REQUIRE(d->dtype == YP_F16 || d->dtype == YP_BF16 || d->dtype == YP_F32, "yp_conv2d: bad dtype %d", d->dtype);
-    const int ce = d->dtype == YP_F32 ? 4 : 8;
+    YP_REQUIRE(d->dtype == YP_F16 || d->dtype == YP_BF16 || d->dtype == YP_F32 || d->dtype == YP_FP8 || d->dtype == YP_FP8_BF8, "yp_conv2d: bad dtype %d", d->dtype);
+    const bool q8 = d->dtype == YP_FP8 || d->dtype == YP_FP8_BF8;
+    const int ce = d->dtype == YP_F32 ? 4 : (q8 ? 16 : 8);
+    YP_REQUIRE(!q8 || (d->scale_in != nullptr && d->scale_w != nullptr && det == nullptr && d->pre_weight == nullptr && !d->out_f32 && d->ksplit <= 1 &&
+                       !d->atomic_accumulate && d->tail_zero),
+               "yp_conv2d: 8-bit inputs need scale_in / scale_w, tail_zero buffers and a plain 16-bit-output convolution");
     // fused C3 tail (post_weight): in1 is the second input of the TAIL convolution and `out` its destination; the 3x3 itself maps
     // in0.C -> in0.C channels
     const bool post = d->post_weight != nullptr;
@@ -1765,7 +1802,7 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
     YP_REQUIRE(ksplit == 1 || (d->out_f32 && d->act == YP_ACT_NONE && d->res.C == 0 && d->out2.C == 0 && d->bias == nullptr && ksplit <= 4096), "yp_conv2d: split-K needs a plain fp32 accumulation target");
     YP_REQUIRE(!d->in0_zero_stuffed || d->in0.ups == 1, "yp_conv2d: a zero-stuffed input is addressed through ups = 1");
     const int Kreal = d->R * d->S * Cin;
-    YP_REQUIRE(d->Kpad >= Kreal && d->Kpad % (d->dtype == YP_F32 ? 16 : 32) == 0, "yp_conv2d: Kpad %d invalid for K=%d", d->Kpad, Kreal);
+    YP_REQUIRE(d->Kpad >= Kreal && d->Kpad % (d->dtype == YP_F32 ? 16 : (q8 ? 64 : 32)) == 0, "yp_conv2d: Kpad %d invalid for K=%d", d->Kpad, Kreal);
     YP_REQUIRE(d->Npad >= Cout, "yp_conv2d: Npad %d < Cout %d", d->Npad, Cout);
     const long Ml = (long)d->B * d->Ho * d->Wo;
     YP_REQUIRE(Ml < (1l << 30), "yp_conv2d: too many output pixels");
@@ -1781,7 +1818,8 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
     a.Hi = d->Hi; a.Wi = d->Wi; a.Wo = d->Wo; a.HoWo = d->Ho * d->Wo;
     a.Cin = Cin; a.Cout = Cout; a.Kreal = Kreal; a.Kpad = d->Kpad; a.Npad = d->Npad;
     a.R = d->R; a.S = d->S; a.RS = d->R * d->S; a.invS = (65536 + d->S - 1) / d->S;
-    { const int bk = d->dtype == YP_F32 ? 16 : 32; a.dt = bk / Cin; a.dc = bk % Cin; }
+    { const int bk = d->dtype == YP_F32 ? 16 : (q8 ? 64 : 32); a.dt = bk / Cin; a.dc = bk % Cin; }
+    a.scale_in = d->scale_in; a.scale_w = d->scale_w;
     a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w;
     a.act = d->act; a.M = (int)Ml;
     a.dil_h = dil_h; a.dil_w = dil_w; a.in0_zs = d->in0_zero_stuffed ? 1 : 0; a.ksplit = ksplit; a.atomic_out = ksplit > 1 || d->atomic_accumulate;
@@ -1797,7 +1835,7 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
 
     // FAST DMA addressing: wave-uniform taps (k tile never straddles a tap or the source boundary), 16 zero
     // bytes behind each input buffer and a zero filter row behind the packed weights, 32-bit byte offsets.
-    const int bk = d->dtype == YP_F32 ? 16 : 32;
+    const int bk = d->dtype == YP_F32 ? 16 : (q8 ? 64 : 32);
     const int eb = yp_dtype_bytes(d->dtype);
     const size_t in0_bytes = (size_t)d->B * d->in0.H * d->in0.W * d->in0.cstride * eb;
     const size_t in1_bytes = d->in1.C ? (size_t)d->B * d->in1.H * d->in1.W * d->in1.cstride * eb : 0;
@@ -1826,7 +1864,9 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
     }
     // 3x3 / pad 1 / stride 1|2, single un-upsampled source, 16-bit types, Cin % 32 == 0: LDS halo-reuse kernel
     // (tile ids 10..12 force it with BN = 32/64/128; tile 0 picks BN by the channel count; ids 1..5 force the generic kernel)
-    const bool halo_base = fast && d->dtype != YP_F32 && d->R == 3 && d->S == 3 && d->pad_h == 1 && d->pad_w == 1 &&
+    YP_REQUIRE(!q8 || fast, "yp_conv2d: 8-bit inputs need the fast addressing path (channels %% 64 == 0, tail_zero)");
+    YP_REQUIRE(!q8 || d->tile < 10 || d->tile > 15, "yp_conv2d: tile %d (3x3 halo kernel) has no 8-bit instantiation", d->tile);
+    const bool halo_base = fast && !q8 && d->dtype != YP_F32 && d->R == 3 && d->S == 3 && d->pad_h == 1 && d->pad_w == 1 &&
                            d->stride_h == d->stride_w && (d->stride_h == 1 || d->stride_h == 2) && d->in0.ups == 0 && ksplit == 1 && !d->atomic_accumulate &&
                            in0_bytes + (size_t)d->in0.cstride * eb + 64 < (1ull << 31);
     const bool halo_ok = halo_base && (d->in1.C == 0 || post);
@@ -1894,6 +1934,8 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
         switch (d->dtype) {
             case YP_F16: e = launch_cfg<YP_F16, false, true, false, true>(tile, a, nblk, stream); break;
             case YP_BF16: e = launch_cfg<YP_BF16, false, true, false, true>(tile, a, nblk, stream); break;
+            case YP_FP8: e = launch_cfg<YP_FP8, false, true, false, true>(tile, a, nblk, stream); break;
+            case YP_FP8_BF8: e = hipErrorInvalidValue; break;
             default: e = launch_cfg<YP_F32, false, true, false, true>(tile, a, nblk, stream); break;
         }
         if (e != hipSuccess) {
@@ -1908,6 +1950,8 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
     switch (d->dtype) {
         case YP_F16: e = YP_DISPATCH(YP_F16); break;
         case YP_BF16: e = YP_DISPATCH(YP_BF16); break;
+        case YP_FP8: e = launch_cfg<YP_FP8, false, true>(tile, a, nblk, stream); break;
+        case YP_FP8_BF8: e = launch_cfg<YP_FP8_BF8, false, true>(tile, a, nblk, stream); break;
         default: e = fast ? launch_cfg<YP_F32, false, true>(tile, a, nblk, stream) : launch_cfg<YP_F32, false, false>(tile, a, nblk, stream); break;
     }
 #undef YP_DISPATCH

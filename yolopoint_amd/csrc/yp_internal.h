@@ -26,7 +26,7 @@ void yp_set_error(const char* fmt, ...);
         }                                                                          \
     } while (0)
 
-static inline int yp_dtype_bytes(int dtype) { return dtype == YP_F32 ? 4 : 2; }
+static inline int yp_dtype_bytes(int dtype) { return dtype == YP_F32 ? 4 : ((dtype == YP_FP8 || dtype == YP_FP8_BF8) ? 1 : 2); }
 static inline int yp_cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // launchers living in other translation units (used by the plan)
