@@ -323,9 +323,10 @@ def run_train(a, rank, world, dev, version, batch, steps, warmup, gas=1, size=64
     from yolopoint_amd.utils.synthetic import make_model
     from yolopoint_amd.engine import TrainStep, synthetic_batch
     from yolopoint_amd.dp import timed_region
-    m, _ = make_model(version, 1234, dtype=dtype)
+    fp8 = dtype == "fp8"          # configs[4]: 8-bit Conv operands on top of the bf16 path (engine.TrainStep(fp8=True))
+    m, _ = make_model(version, 1234, dtype="bf16" if fp8 else dtype)
     m = m.to(dev).train()
-    step = TrainStep(m, dev, img_size=size, gas=gas)
+    step = TrainStep(m, dev, img_size=size, gas=gas, fp8=fp8)
     step.comm_events = [] if world > 1 else None
     micro = [synthetic_batch(batch, size, dev, 1234 + rank * 97 + i) for i in range(gas)]
     arg = micro if gas > 1 else micro[0]

@@ -29,9 +29,17 @@ def arch(version):
     return c, n
 
 
+# Test hook: when set to a callable (name, x, w) -> (x, w), every Conv block passes its input and filter through it before the
+# convolution -- the fp8 parity test installs per-tensor e4m3 fake quantisation here (BASELINE.json configs[4] has no reference
+# implementation: the oracle for it is this restatement + the quantisation rule stated in csrc/fp8.hip).
+FAKE_QUANT = None
+
+
 def conv_block(sd, p, x, k, s, pad, training=False, stats=None):
     """Conv: SiLU(BN(conv(x))) or, after fuse(), SiLU(conv(x)+b)   (models/common.py:22-34)."""
     w = sd[p + ".conv.weight"]
+    if FAKE_QUANT is not None:
+        x, w = FAKE_QUANT(p, x, w)
     if p + ".bn.weight" in sd:
         y = F.conv2d(x, w, None, s, pad)
         rm, rv = sd[p + ".bn.running_mean"], sd[p + ".bn.running_var"]

@@ -53,7 +53,7 @@ class YpOpArgs(C.Structure):
 
 (OP_BN_STATS, OP_BN_APPLY, OP_BN_BWD, OP_UPS2_BWD, OP_ADD_VIEWS, OP_MAXPOOL5_BWD, OP_L2NORM_BWD, OP_DETECT_BWD_PACK, OP_TO_CHWB,
  OP_COL_SUM, OP_MEMSET0, OP_PACK_NCHW, OP_L2NORM, OP_SPPF_POOL, OP_CAST_F32, OP_MAXPOOL2, OP_PACK_WEIGHT, OP_WGRAD, OP_WGRAD_UNPACK, OP_MAXPOOL2_BWD, OP_WGRAD_UNPACK_BATCH, OP_WGRAD_GROUP,
- OP_SUM_SLABS, OP_STEM_WGRAD) = range(10, 34)
+ OP_SUM_SLABS, OP_STEM_WGRAD, OP_QUANT_FP8) = range(10, 35)
 LANE_MAIN, LANE_SIDE, LANE_JOIN = 0, 1, 2
 
 _i, _f, _p, _sz, _i64 = C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_int64

@@ -1184,6 +1184,7 @@ extern "C" int yp_run_op(const YpOpArgs* a, void* stream) {
         case YP_OP_MAXPOOL2_BWD: return yp_maxpool2_bwd(a->v[0], a->v[1], a->v[2], dt, B, a->i[2], stream);
         case YP_OP_WGRAD_UNPACK: return yp_wgrad_unpack((const float*)a->p[0], a->g[0], a->i[1], a->i[2], a->i[3], a->i[4], a->i[5], a->i[6], stream);
         case YP_OP_WGRAD_UNPACK_BATCH: return yp_wgrad_unpack_batch((const YpUnpackEntry*)a->p[0], a->i[1], a->i[2], stream);
+        case YP_OP_QUANT_FP8: return yp_quantize_fp8(a->v[0], a->v[1], dt, B, a->i[2], (const float*)a->p[0], (float*)a->p[1], stream);
         case YP_OP_STEM_WGRAD: return yp_stem_wgrad(a->v[0], a->v[1], dt, B, (float*)a->p[0], (float*)a->p[1], stream);
         case YP_OP_SUM_SLABS: return yp_sum_slabs((const float*)a->p[0], (float*)a->p[1], a->n[0], (int)a->n[1], stream);
         case YP_OP_WGRAD_GROUP: return yp_wgrad_group_run_det(a->p[0], a->i[1], a->i[2], a->i[5], dt, a->i[3], a->i[4], stream);

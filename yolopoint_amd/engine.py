@@ -65,8 +65,14 @@ class TrainStep:
     on the last one only), optional gradient clipping (train.py:249-250) and LambdaLR schedule (train.py:91-93, stepped by the caller
     once per epoch: `step.scheduler`)."""
 
-    def __init__(self, model, device, img_size=640, lr=1e-3, group=None, gas=1, max_grad_norm=None, lr_lambda=None):
+    def __init__(self, model, device, img_size=640, lr=1e-3, group=None, gas=1, max_grad_norm=None, lr_lambda=None, fp8=False):
+        """fp8 (BASELINE.json configs[4]; the model's compute dtype must be bf16): the Conv layers with channel counts that are multiples
+        of 64 multiply 8-bit operands (training.TrainGraph); the first call runs two extra forward / backward passes on its batch, without
+        an optimizer step, to calibrate the per-tensor scales (they start at 1 and follow the previous step's maxima afterwards)."""
         self.model, self.device = model, device
+        self.fp8 = bool(fp8)
+        model.model.fp8_train = self.fp8
+        self._calibrated = not self.fp8
         det = model.model.Detect
         hyp = dict(HYP)
         hyp['box'] *= 3 / det.nl                                    # train.py:158-165
@@ -112,6 +118,13 @@ class TrainStep:
         micro = list(batch) if isinstance(batch, (list, tuple)) else [batch]
         if len(micro) != self.gas:
             raise ValueError(f"TrainStep(gas={self.gas}) takes {self.gas} micro-batch(es) per optimizer step, got {len(micro)}")
+        if not self._calibrated:
+            from .models.common import invalidate_packed_weights
+            with self.reducer.no_sync():
+                for _ in range(2):
+                    self.loss_and_grads(micro[0])
+                    invalidate_packed_weights()       # (the next forward turns the recorded maxima into scales, as after an optimizer step)
+            self._calibrated = True
         total = None
         for i, mb in enumerate(micro):
             last = i == len(micro) - 1

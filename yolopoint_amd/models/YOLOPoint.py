@@ -167,12 +167,12 @@ class YOLOPoint(HipModule):
             pack_input(x, img.view(), plan.code)
         plan.run()
 
-    def _train_graph(self, x, pair=False):
+    def _train_graph(self, x, pair=False, fp8=False):
         """A free TrainGraph (static forward + backward plans and all their buffers) for this input shape.  The two
         forwards of one training step (image, warped image: reference train.py:208,220) get two graphs."""
         from ..training import TrainGraph
         code = _hip.dtype_code(self.compute_dtype)
-        key = (tuple(x.shape), code, x.device.index, tuple(p.data_ptr() for p in self.parameters()), bool(pair))
+        key = (tuple(x.shape), code, x.device.index, tuple(p.data_ptr() for p in self.parameters()), bool(pair), bool(fp8))
         pool = self.__dict__.setdefault("_train_graphs", {})
         graphs = pool.setdefault(key, [])
         for g in graphs:
@@ -180,7 +180,7 @@ class YOLOPoint(HipModule):
                 return g
         if len(graphs) >= 4:
             raise _hip.YpError("more than 4 un-backpropagated train-mode forwards in flight for one input shape")
-        g = TrainGraph(self, x.shape[0], x.shape[2], x.shape[3], code, x.device, pair=pair)
+        g = TrainGraph(self, x.shape[0], x.shape[2], x.shape[3], code, x.device, pair=pair, fp8=fp8)
         graphs.append(g)
         return g
 

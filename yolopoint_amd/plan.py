@@ -123,13 +123,48 @@ class MasterWeight:
     mode 0: forward filter of input channels [c0, c0+cj); mode 1: the dgrad filter (flipped, channel-transposed,
     output channels zero-padded to cout_pad) of the same slice."""
 
-    def __init__(self, param, bias=None, mode=0, c0=0, cj=None, cout_pad=None):
-        self.param, self.bias, self.mode, self.c0 = param, bias, mode, c0
+    def __init__(self, param, bias=None, mode=0, c0=0, cj=None, cout_pad=None, q8=False):
+        self.param, self.bias, self.mode, self.c0, self.q8 = param, bias, mode, c0, q8      # q8: packed as e4m3 (Fp8State scale of the parameter)
         Cout, Cin, R, S = param.shape
         self.cj = Cin - c0 if cj is None else cj
         self.cout_pad = round_up(Cout, 8) if cout_pad is None else cout_pad
         # logical OIHW shape of the filter the convolution sees
         self.shape = (Cout, self.cj, R, S) if mode == 0 else (self.cj, self.cout_pad, R, S)
+
+
+class Fp8State:
+    """Per-tensor scales of the 8-bit training convolutions (csrc/fp8.hip): device arrays scale / amax / fmax with one slot per
+    quantised tensor (activation buffer, output-gradient buffer, parameter); real = stored * scale.  Quantisation passes read scale[i] and
+    record max|x| into amax[i]; update() -- once per optimizer step -- turns the recorded maxima into the next step's scales."""
+    FMAX = (448.0, 57344.0)        # e4m3, e5m2
+
+    def __init__(self, device, capacity=8192):
+        self.device = device
+        self.scale = torch.ones(capacity, dtype=torch.float32, device=device)
+        self.amax = torch.zeros(capacity, dtype=torch.float32, device=device)
+        self.fmax = torch.full((capacity,), 448.0, dtype=torch.float32, device=device)
+        self.n, self.by_key = 0, {}
+
+    def slot(self, key, fmt, init=None):
+        if key not in self.by_key:
+            assert self.n < self.scale.numel(), "Fp8State: out of scale slots"
+            i = self.n
+            self.n += 1
+            self.by_key[key] = i
+            self.fmax[i] = self.FMAX[fmt]
+            if init is not None:
+                self.scale[i] = max(float(init), 1e-12)
+        return self.by_key[key]
+
+    def scale_ptr(self, i):
+        return self.scale.data_ptr() + 4 * i
+
+    def amax_ptr(self, i):
+        return self.amax.data_ptr() + 4 * i
+
+    def update(self, margin=1.0):
+        if self.n:
+            check(lib().yp_fp8_update_scales(self.scale.data_ptr(), self.amax.data_ptr(), self.fmax.data_ptr(), self.n, float(margin), _hip.stream_ptr()))
 
 
 class OpRecord:
@@ -169,6 +204,7 @@ class PlanBuilder:
         self.accesses = []      # per-op (reads, writes) as (buffer key, lo, hi) ranges, for the graph schedule
         self.refreshers = []    # callables that re-pack weights from their (changing) sources: training plans
         self.pack_target = None # (PlanBuilder, cache dict): where MasterWeight pack ops are emitted (None: into this plan)
+        self.fp8 = None         # Fp8State of the 8-bit convolutions this plan may hold (TrainGraph sets it)
         self.scope = []
 
     # -- naming -------------------------------------------------------------------------
@@ -272,7 +308,9 @@ class PlanBuilder:
         Wo = (Wi + 2 * pw - dil * (S - 1) - 1) // sw + 1
         if "out_hw" in extra:
             Ho, Wo = extra["out_hw"]
-        thin = raw_weight is None and len(srcs) == 1 and v0.C == 4 and v0.cstride == 4 and Cin <= 4
+        q8 = extra.get("q8")                        # dict(dtype=YP_FP8 | YP_FP8_BF8, slot=Fp8State slot of the (common) input scale): srcs are 1-byte views
+        conv_dtype = q8["dtype"] if q8 else self.code
+        thin = q8 is None and raw_weight is None and len(srcs) == 1 and v0.C == 4 and v0.cstride == 4 and Cin <= 4
         pair = thin and self.ce == 8
         if pair:
             # 16-bit stem (6x6/s2/p2, models/YOLOPoint.py:156): pair adjacent pixels -> view [H, W/2, 8]; taps pair up along s
@@ -311,13 +349,30 @@ class PlanBuilder:
             self.keep += [wp]
         elif master is not None:
             assert not thin, "image-like (thin) inputs keep the host packer"
-            Kpad, Npad = lib().yp_conv_kpad(R * S * Cin, self.code), round_up(Cout, 8)
+            Kpad, Npad = lib().yp_conv_kpad(R * S * Cin, conv_dtype), round_up(Cout, 8)
+            assert bool(master.q8) == (q8 is not None)
             # the pack op goes into `pack_target` (a builder shared by every plan over the same parameters, replayed once per
             # optimizer step) when one is set, else in front of the convolution in this plan
             tgt, cache = self.pack_target if self.pack_target is not None else (self, None)
-            key = (master.param.data_ptr(), master.bias.data_ptr() if master.bias is not None else 0, master.mode, master.c0, master.cj, master.cout_pad)
+            key = (master.param.data_ptr(), master.bias.data_ptr() if master.bias is not None else 0, master.mode, master.c0, master.cj, master.cout_pad,
+                   bool(master.q8))
+            w_slot = None
+            if master.q8:
+                # e4m3 packed copy: one scale slot per parameter (its forward and dgrad copies hold the same values)
+                w_slot = self.fp8.slot(("w", master.param.data_ptr()), 0, init=float(master.param.detach().abs().max()) / 448.0)
             if cache is not None and key in cache:
                 wp, bp = cache[key]
+            elif master.q8:
+                assert master.bias is None
+                wp = torch.zeros((Npad + 1, Kpad), dtype=torch.uint8, device=self.device)
+                bp = torch.zeros((Npad,), dtype=torch.float32, device=self.device)
+                mo, mi, mr, ms = master.param.shape
+                tgt.keep += [wp, bp, master.param]
+                tgt.__dict__.setdefault("pack8_entries", []).append(
+                    [master.param.data_ptr(), wp.data_ptr(), self.fp8.scale_ptr(w_slot), self.fp8.amax_ptr(w_slot), mo, mi, mr, ms,
+                     master.c0, master.cj, master.mode, master.cout_pad, Kpad, Npad])
+                if cache is not None:
+                    cache[key] = (wp, bp)
             else:
                 wp = torch.zeros((Npad + 1, Kpad), dtype=self.tdtype, device=self.device)
                 bp = torch.zeros((Npad,), dtype=torch.float32, device=self.device)
@@ -351,7 +406,10 @@ class PlanBuilder:
         d.out2 = out2.c() if out2 is not None else NULL_VIEW
         d.weight = wp.data_ptr()
         d.bias = bp.data_ptr() if (bias is not None and bp is not None) else None
-        d.dtype, d.out_f32, d.B = self.code, int(out_f32), extra.get("batch", self.B)
+        d.dtype, d.out_f32, d.B = conv_dtype, int(out_f32), extra.get("batch", self.B)
+        if q8 is not None:
+            assert master is not None and w_slot is not None
+            d.scale_in, d.scale_w = self.fp8.scale_ptr(q8["slot"]), self.fp8.scale_ptr(w_slot)
         d.Hi, d.Wi, d.Ho, d.Wo = Hi, Wi, Ho, Wo
         d.R, d.S, d.stride_h, d.stride_w, d.pad_h, d.pad_w = R, S, sh, sw, ph, pw
         d.dil_h = d.dil_w = dil
@@ -394,7 +452,7 @@ class PlanBuilder:
             det.rows_total, det.row_offset = detect["rows_total"], detect["row_offset"]
         tuned_ms = None
         if tile == 0 and self.autotune and d.ksplit == 1 and not d.atomic_accumulate:
-            d.tile, tuned_ms = self._autotune(d, det, (self.code, d.B, Hi, Wi, tuple((v.C, v.ups) for v in srcs), Cout_pad, R, S, sh, sw, dil, zs,
+            d.tile, tuned_ms = self._autotune(d, det, (conv_dtype, d.B, Hi, Wi, tuple((v.C, v.ups) for v in srcs), Cout_pad, R, S, sh, sw, dil, zs,
                                                        int(out_f32), res is not None, c2, act, detect is not None, pre is not None, post is not None,
                                                        bn_partial is not None))
         if bn_partial is not None:                  # how many partial rows the chosen kernel variant writes (they are batch-major)

@@ -31,13 +31,16 @@ import torch
 
 from . import _hip
 from ._hip import lib, check
-from .plan import PlanBuilder, Buf, View, MasterWeight, round_up, pack_input
+from .plan import PlanBuilder, Buf, View, MasterWeight, Fp8State, round_up, pack_input
 from .models.common import weights_generation
 
 
 class TrainGraph:
-    def __init__(self, net, B, H, W, code, device, pair=False):
-        """B: samples per forward pass.  pair: this graph runs two passes (image, warped image) as one launch list over 2B samples."""
+    def __init__(self, net, B, H, W, code, device, pair=False, fp8=False):
+        """B: samples per forward pass.  pair: this graph runs two passes (image, warped image) as one launch list over 2B samples.
+        fp8 (BASELINE configs[4], with code = bf16): the Conv layers whose channel counts are multiples of 64 multiply 8-bit operands --
+        forward: e4m3 activations x e4m3 filters, dgrad: e5m2 output gradients x e4m3 filters, per-tensor delayed scaling (plan.Fp8State);
+        results, BatchNorm, the weight gradients and everything else stay bf16 / fp32."""
         if H % 64 or W % 64:
             raise _hip.YpError("training needs image sizes that are multiples of 64")
         self.G, self.Bs = (2 if pair else 1), B          # statistics groups (= passes per launch list), samples per pass
@@ -52,6 +55,14 @@ class TrainGraph:
         pkey = (code, torch.device(device).index, tuple(p_.data_ptr() for p_ in net.parameters()))
         self.pack = net.__dict__.setdefault("_pack_states", {}).setdefault(pkey, {"pb": PlanBuilder(B, code, device), "cache": {}, "version": None})
         self.fwd.pack_target = (self.pack["pb"], self.pack["cache"])
+        self.fp8 = bool(fp8) and code == _hip.YP_BF16
+        if fp8 and not self.fp8:
+            raise _hip.YpError("fp8 training runs on top of the bf16 compute path (model.bfloat16())")
+        if self.fp8:
+            self.pack.setdefault("fp8", Fp8State(device))
+            self.fwd.fp8 = self.pack["pb"].fp8 = self.pack["fp8"]
+        self.twins = {}            # fp8 mode: (address of a 16-bit activation buffer, format) -> its 1-byte twin Buf
+        self.n_q8 = 0              # convolutions emitted with 8-bit operands
         self.tape = []             # (branch, emitter): 'kp' feeds the keypoint / descriptor heads, 'yolo' only the Detect head
         self.branch = "kp"
         self.touched = set()       # parameters whose gradient the plan being emitted writes
@@ -140,6 +151,44 @@ class TrainGraph:
     def T(self, t):
         return (t, 0, 1 << 30)
 
+    # ------------------------------------------------------------------ fp8 mode
+    @staticmethod
+    def q8_ok(views):
+        """8-bit operands need the kernels' 64-byte k chunks: every source slice a multiple of 64 channels, 16-byte aligned."""
+        return all(v.geom is None and v.C % 64 == 0 and v.coff % 16 == 0 and v.cstride % 16 == 0 for v in views)
+
+    def q8_sources(self, pb, srcs, fmt):
+        """1-byte twins of the 16-bit views `srcs` + the quantisation launches that fill them, and the scale slot they share.  A single
+        source is quantised into its buffer's own twin (one twin and one scale per activation buffer, reused by every consumer);
+        channel-concatenated sources of one convolution need ONE scale, so they get twins private to that convolution."""
+        st = pb.fp8
+        fmax_fmt = fmt
+        if len(srcs) == 1:
+            v = srcs[0]
+            key = (v.buf.t.data_ptr(), fmt)
+            if key not in self.twins:
+                tb = Buf(v.buf.B, v.buf.H, v.buf.W, v.buf.C, torch.uint8, self.device)
+                self.keep.append(tb.flat)
+                self.twins[key] = tb
+            tb = self.twins[key]
+            slot = st.slot(("act", key, v.coff, v.C), fmax_fmt)       # (one scale per consumed channel slice of the buffer)
+            done = pb.__dict__.setdefault("quantized", set())
+            tag = (key, v.coff, v.C)
+            if tag not in done:
+                done.add(tag)
+                sv, dv = View(v.buf, v.coff, v.C), View(tb, v.coff, v.C)
+                pb.op(_hip.OP_QUANT_FP8, [sv], [dv], "quant", v=[sv, dv], i=[self.code, pb.B, fmt], p=[st.scale_ptr(slot), st.amax_ptr(slot)])
+            return [View(tb, v.coff, v.C, v.ups)], slot
+        slot = st.slot(("cat", pb.handle.value, len(pb.records)), fmax_fmt)
+        out = []
+        for v in srcs:
+            tb = Buf(pb.B, v.buf.H, v.buf.W, v.C, torch.uint8, self.device)
+            self.keep.append(tb.flat)
+            sv, dv = View(v.buf, v.coff, v.C), tb.view()
+            pb.op(_hip.OP_QUANT_FP8, [sv], [dv], "quant", v=[sv, dv], i=[self.code, pb.B, fmt], p=[st.scale_ptr(slot), st.amax_ptr(slot)])
+            out.append(View(tb, 0, v.C, v.ups))
+        return out, slot
+
     # ------------------------------------------------------------------ forward emitters (+ tape)
     def conv_bn_act(self, m, x, out=None, res=None):
         srcs = list(x) if isinstance(x, (list, tuple)) else [x]
@@ -162,7 +211,14 @@ class TrainGraph:
         if fuse_stats:
             rows = max(-(-(B * Ho_ * Wo_) // 64), B * -(-Ho_ // 4) * -(-Wo_ // 16) if k == 3 else 0)
             partial = torch.zeros((rows, 2, round_up(conv.out_channels, 8)), dtype=torch.float32, device=self.device)
-        raw = f.conv(srcs, wsrc, None, k, s, p, _hip.YP_ACT_NONE, extra=dict(bn_partial=partial) if fuse_stats else None)
+        q8 = self.fp8 and not image and self.q8_ok(srcs) and os.environ.get("YP_FP8_FWD", "1") != "0"
+        conv_srcs, extra = srcs, (dict(bn_partial=partial) if fuse_stats else {})
+        if q8:
+            conv_srcs, slot = self.q8_sources(f, srcs, 0)
+            wsrc = MasterWeight(conv.weight, q8=True)
+            extra["q8"] = dict(dtype=_hip.YP_FP8, slot=slot)
+            self.n_q8 += 1
+        raw = f.conv(conv_srcs, wsrc, None, k, s, p, _hip.YP_ACT_NONE, extra=extra or None)
         if fuse_stats:
             partial.zero_()          # (the autotuner ran several kernel variants, which write different row sets: start from zeros with the chosen one)
         Cc, Cp = conv.out_channels, raw.C
@@ -252,6 +308,7 @@ class TrainGraph:
         # copies -- the output gradient becomes the "filter" [Cout_pad (+1 zero row)][K].
         direct = code != _hip.YP_F32 and p == k // 2 and ((k == 1 and s == 1) or (k == 3 and s in (1, 2)))
         dyp = None
+        dq = None
         c0 = 0
         for src in srcs:
             image = src.geom is None and src.cstride == 4 and src.C == 4
@@ -309,17 +366,25 @@ class TrainGraph:
                 cs, ce_ = c0, c0 + Cj
 
                 # dgrad = convolution with the flipped, channel-transposed filter [Cj, Cout_pad, k, k], packed on the device
-                w_dgrad = MasterWeight(weight, mode=1, c0=cs, cj=Cj, cout_pad=Cout_pad)
+                q8 = (self.fp8 and bias is None and draw.buf.t.dtype == torch.bfloat16 and self.q8_ok([draw]) and Cj % 8 == 0
+                      and os.environ.get("YP_FP8_DGRAD", "1") != "0")
+                w_dgrad = MasterWeight(weight, mode=1, c0=cs, cj=Cj, cout_pad=Cout_pad, q8=q8)
+                dsrc, dextra = draw, {}
+                if q8:      # e5m2 copy of the output gradient (one per convolution, shared by its sources' dgrads) x e4m3 filter
+                    if dq is None:
+                        dq = self.q8_sources(b, [draw], 1)
+                    dsrc, dextra = dq[0][0], dict(q8=dict(dtype=_hip.YP_FP8_BF8, slot=dq[1]))
+                    self.n_q8 += 1
                 base = View(src.buf, src.coff, src.C, 0, src.geom)
                 if src.ups:
                     tmp = b.new_buf(Hi, Wi, Cj).view()
-                    b.conv([draw], w_dgrad, None, k, 1, k - 1 - p, _hip.YP_ACT_NONE, out=tmp, extra=dict(zero_stuffed=(s == 2)))
+                    b.conv([dsrc], w_dgrad, None, k, 1, k - 1 - p, _hip.YP_ACT_NONE, out=tmp, extra=dict(zero_stuffed=(s == 2), **dextra))
                     gv, acc = self.gview(base)
                     b.op(_hip.OP_UPS2_BWD, [tmp, gv], [gv], "ups_bwd", v=[tmp, gv], i=[code, B, int(acc)])
                 else:
                     gv, acc = self.gview(base)
-                    b.conv([draw], w_dgrad, None, k, 1, k - 1 - p, _hip.YP_ACT_NONE, out=gv, res=gv if acc else None,
-                           extra=dict(zero_stuffed=(s == 2)))
+                    b.conv([dsrc], w_dgrad, None, k, 1, k - 1 - p, _hip.YP_ACT_NONE, out=gv, res=gv if acc else None,
+                           extra=dict(zero_stuffed=(s == 2), **dextra))
             c0 += Cj
 
     def bottleneck(self, m, x, out=None):
@@ -531,6 +596,7 @@ class TrainGraph:
             Detect), B samples, `groups` statistics groups.  fresh=False: the activation gradients an earlier plan of the same pass wrote
             stay valid (pair mode: the trunk plan accumulates onto what the YOLO-branch plan left in the backbone output's gradient)."""
             self.bwd = bb = PlanBuilder(B, code, self.device)
+            bb.fp8 = self.fwd.fp8
             self.bG = groups
             bb.pack_target = self.fwd.pack_target
             if fresh:
@@ -618,7 +684,12 @@ class TrainGraph:
             self.bwd_kp_plan.refresh()
             self._packed_version = ver
         nops = lib().yp_plan_num_ops(self.pack["pb"].handle)
-        if (ver, nops) != self.pack["version"]:                 # device-packed filters shared by all graphs: one batched launch
+        ents8 = getattr(self.pack["pb"], "pack8_entries", [])
+        if (ver, nops, len(ents8)) != self.pack["version"]:     # device-packed filters shared by all graphs: one batched launch
+            if "fp8" in self.pack:
+                # once per optimizer step: last step's recorded maxima become this step's quantisation scales (delayed scaling), then
+                # the e4m3 filter copies are re-derived with their new scales
+                self.pack["fp8"].update(float(os.environ.get("YP_FP8_MARGIN", "1.0")))
             ents = getattr(self.pack["pb"], "pack_entries", [])
             if len(ents) == nops and os.environ.get("YP_PACK_BATCH", "1") != "0":
                 if self.pack.get("table_n") != nops:
@@ -628,9 +699,17 @@ class TrainGraph:
                         blk0 += -(-((e[13] + 1) * e[12]) // 1024)
                     self.pack["table"], self.pack["table_n"], self.pack["blocks"] = torch.tensor(rows, dtype=torch.int64).to(self.device), nops, blk0
                 check(lib().yp_pack_weight_batch(self.pack["table"].data_ptr(), nops, self.pack["blocks"], self.code, _hip.stream_ptr()))
-            else:
+            elif nops:
                 check(lib().yp_plan_run(self.pack["pb"].handle, _hip.stream_ptr()))
-            self.pack["version"] = (ver, nops)
+            if ents8:
+                if self.pack.get("table8_n") != len(ents8):
+                    rows, blk0 = [], 0
+                    for e in ents8:
+                        rows.append(e + [blk0])
+                        blk0 += -(-((e[13] + 1) * e[12]) // 1024)
+                    self.pack["table8"], self.pack["table8_n"], self.pack["blocks8"] = torch.tensor(rows, dtype=torch.int64).to(self.device), len(ents8), blk0
+                check(lib().yp_pack_weight_fp8_batch(self.pack["table8"].data_ptr(), len(ents8), self.pack["blocks8"], _hip.stream_ptr()))
+            self.pack["version"] = (ver, nops, len(ents8))
         for fn in self.pre_forward:
             fn()
         if self.G == 1:
@@ -713,7 +792,7 @@ class _YOLOPointTrainFn(torch.autograd.Function):
     @staticmethod
     @_hip.guarded
     def forward(ctx, net, x, *params):
-        g = net._train_graph(x)
+        g = net._train_graph(x, fp8=bool(getattr(net, "fp8_train", False)))
         ctx.graph = g
         ctx.set_materialize_grads(False)       # a head that took no part in the loss arrives as None
         semi, desc, xs = g.forward(x)
@@ -740,7 +819,7 @@ class _YOLOPointPairFn(torch.autograd.Function):
     @staticmethod
     @_hip.guarded
     def forward(ctx, net, x, x_w, *params):
-        g = net._train_graph(x, pair=True)
+        g = net._train_graph(x, pair=True, fp8=bool(getattr(net, "fp8_train", False)))
         ctx.graph = g
         ctx.set_materialize_grads(False)
         semi, desc, xs = g.forward(x, x_w)
