@@ -256,6 +256,15 @@ int yp_bn_act_bwd_grouped(YpView raw, YpView dy, YpView dx, int dtype, int B, in
 int yp_adam_step(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1, double beta2, double eps, double weight_decay, int step,
                  void* stream);
 
+/* fp8 training: the same two passes also writing a 1-byte twin of their result (q8: a view with the shape of `raw`; e4m3 of the forward
+ * output = the next Conv's activation; e5m2 of dx = the dgrad's output gradient), quantised with *q_scale, max|result| recorded into
+ * q_amax (256 floats, see yp_quantize_fp8) -- the separate quantisation pass disappears.  q8.ptr == NULL: exactly the functions above. */
+int yp_bn_act_apply_grouped_q8(YpView raw, YpView out, YpView res, int dtype, int B, int groups, const float* mean, const float* invstd,
+                               const float* gamma, const float* beta, int act, YpView q8, const float* q_scale, float* q_amax, void* stream);
+int yp_bn_act_bwd_grouped_q8(YpView raw, YpView dy, YpView dx, int dtype, int B, int groups, const float* mean, const float* invstd,
+                             const float* gamma, const float* beta, int act, float* dgamma, float* dbeta, int accumulate_param_grads,
+                             void* workspace, size_t workspace_bytes, YpView q8, const float* q_scale, float* q_amax, void* stream);
+
 /* out (+)= 2x2 block sums of `in` (backward of nn.Upsample(2,'nearest'), models/YOLOPoint.py:192) */
 int yp_ups2_bwd(YpView in, YpView out, int dtype, int B, int accumulate, void* stream);
 /* dst (+)= src (gradient fan-in) */
@@ -333,8 +342,10 @@ int yp_pack_weight_batch(const YpPackEntry* table_dev, int n_entries, int total_
 
 /* ---- 8-bit (OCP fp8) training convolutions: BASELINE.json configs[4].  real = stored * scale, per tensor; scales are device scalars.
  * yp_quantize_fp8: 16-bit NHWC view -> 1-byte NHWC view (format 0 = e4m3, saturating at 448; 1 = e5m2, saturating at 57344) with the
- * CURRENT *scale, and max|src| recorded into *amax (atomic max; may be NULL).  yp_fp8_update_scales: for n tensors at once,
- * scale[i] = amax[i] * margin / fmax[i] where amax[i] > 0 (else kept), amax[i] = 0 -- the next step's scales ("delayed scaling").
+ * CURRENT *scale, and max|src| recorded into amax (may be NULL): amax points at 256 floats, the recorded maximum is their maximum (the
+ * workgroups spread their atomic max over them).  yp_fp8_update_scales: for n tensors at once (amax: n x 256 floats),
+ * scale[i] = max(amax[i][:]) * margin / fmax[i] where that maximum is > 0 (else kept), amax[i][:] = 0 -- the next step's scales
+ * ("delayed scaling").
  * yp_pack_weight_fp8_batch: yp_pack_weight_batch for e4m3 packed filters (blocks of 1024 packed elements; each entry quantises with
  * its *scale and records max|w| into *amax). */
 int yp_quantize_fp8(YpView src, YpView dst, int src_dtype, int B, int format, const float* scale, float* amax, void* stream);
@@ -411,8 +422,8 @@ int yp_detloss(const float* semi, const int64_t* semi_strides, const float* targ
 enum {
     YP_OP_BN_STATS = 10,      /* v0=raw; i0=dtype i1=B; s0=eps s1=momentum; g0=mean g1=invstd g2=running_mean g3=running_var; p0=ws n0=ws_bytes;
                                  i2=rows > 0: finalize only (yp_bn_finalize) from p1 = the partial sums a convolution wrote; i3=groups (0 = 1) */
-    YP_OP_BN_APPLY = 11,      /* v0=raw v1=out v2=res; i0=dtype i1=B i2=act i3=groups; f0=mean f1=invstd f2=gamma f3=beta */
-    YP_OP_BN_BWD = 12,        /* v0=raw v1=dy v2=dx; i0=dtype i1=B i2=act i3=accumulate i4=groups; f0..f3 as above; g0=dgamma g1=dbeta; p0=ws n0=ws_bytes */
+    YP_OP_BN_APPLY = 11,      /* v0=raw v1=out v2=res; i0=dtype i1=B i2=act i3=groups; f0=mean f1=invstd f2=gamma f3=beta; v3=1-byte twin (ptr NULL: none) g2=its scale g3=its amax */
+    YP_OP_BN_BWD = 12,        /* v0=raw v1=dy v2=dx; i0=dtype i1=B i2=act i3=accumulate i4=groups; f0..f3 as above; g0=dgamma g1=dbeta; p0=ws n0=ws_bytes; v3 / g2 / g3: 1-byte twin of dx as for BN_APPLY */
     YP_OP_UPS2_BWD = 13,      /* v0=in v1=out; i0=dtype i1=B i2=accumulate */
     YP_OP_ADD_VIEWS = 14,     /* v0=src v1=dst; i0=dtype i1=B i2=accumulate */
     YP_OP_MAXPOOL5_BWD = 15,  /* v0=x v1=dy v2=dx; i0=dtype i1=B i2=accumulate; p0=ws n0=ws_bytes */

@@ -66,6 +66,8 @@ SIGNATURES = {
     "yp_conv2d_detect": (_i, [C.POINTER(YpConvDesc), C.POINTER(YpDetectDesc), _p]),
     "yp_conv_kpad": (_i, [_i, _i]),
     "yp_sum_slabs": (_i, [_p, _p, _sz, _i, _p]),
+    "yp_bn_act_apply_grouped_q8": (_i, [YpView, YpView, YpView, _i, _i, _i, _p, _p, _p, _p, _i, YpView, _p, _p, _p]),
+    "yp_bn_act_bwd_grouped_q8": (_i, [YpView, YpView, YpView, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _i, _p, _sz, YpView, _p, _p, _p]),
     "yp_quantize_fp8": (_i, [YpView, YpView, _i, _i, _i, _p, _p, _p]),
     "yp_fp8_update_scales": (_i, [_p, _p, _p, _i, _f, _p]),
     "yp_pack_weight_fp8_batch": (_i, [_p, _i, _i, _p]),

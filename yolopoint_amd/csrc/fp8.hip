@@ -1,6 +1,7 @@
 // 8-bit (OCP fp8) support of the training convolutions: quantisation of activations / gradients / filters with per-tensor scales.
 //
 //   stored = saturate(real / scale) in e4m3 (|max| 448: activations, filters) or e5m2 (|max| 57344: gradients); real = stored * scale.
+//   A tensor's recorded maximum is YP_FP8_AMAX_SLOTS (256) floats (the workgroups spread their atomics over them; the maximum is their max).
 //   Scales are device scalars that lag one step behind ("delayed scaling"): a quantisation pass uses the scale derived from the absolute
 //   maximum the SAME tensor had in the previous step and records this step's maximum (atomic max on the float bits: values are >= 0);
 //   yp_fp8_update_scales turns the recorded maxima into the next step's scales in one launch for all tensors.
@@ -15,35 +16,10 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
-template <int FMT> __device__ __forceinline__ unsigned pack4(float a, float b, float c, float d) {
-    constexpr float MX = FMT == 0 ? 448.0f : 57344.0f;
-    a = fminf(fmaxf(a, -MX), MX); b = fminf(fmaxf(b, -MX), MX); c = fminf(fmaxf(c, -MX), MX); d = fminf(fmaxf(d, -MX), MX);
-    int v = 0;
-    if constexpr (FMT == 0) {
-        v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false);
-        v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
-    } else {
-        v = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, v, false);
-        v = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, v, true);
-    }
-    return (unsigned)v;
-}
-
 __device__ __forceinline__ float wave_max_f(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
-}
-// one atomic per WORKGROUP (a wave-level atomic per 64 lanes had every wave of the chip queue on one address: 160 us per launch)
-__device__ __forceinline__ void block_amax(float mx, float* amax) {
-    __shared__ float wmax[4];
-    mx = wave_max_f(mx);
-    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    if (threadIdx.x == 0 && amax != nullptr) {
-        const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-        if (m > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(m));
-    }
 }
 
 // src: 16-bit (f16 / bf16) NHWC view; dst: 1-byte NHWC view with the same logical shape; 8 channels per thread
@@ -64,19 +40,21 @@ __global__ __launch_bounds__(256) void quantize_kernel(const char* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 8; ++j) { v[j] = (float)e[j]; mx = fmaxf(mx, fabsf(v[j])); }
         u32x2 o;
-        o[0] = pack4<FMT>(v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv);
-        o[1] = pack4<FMT>(v[4] * inv, v[5] * inv, v[6] * inv, v[7] * inv);
+        o[0] = yp_fp8_pack4<FMT>(v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv);
+        o[1] = yp_fp8_pack4<FMT>(v[4] * inv, v[5] * inv, v[6] * inv, v[7] * inv);
         *reinterpret_cast<u32x2*>(dst + r * dcs + dco + ch * 8) = o;
     }
-    block_amax(mx, amax);
+    yp_block_amax(mx, amax);
 }
 
-__global__ void update_scales_kernel(float* __restrict__ scale, float* __restrict__ amax, const float* __restrict__ fmax, int n, float margin) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void update_scales_kernel(float* __restrict__ scale, float* __restrict__ amax, const float* __restrict__ fmax, int n, float margin) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;      // one wavefront per tensor
     if (i >= n) return;
-    const float m = amax[i];
-    if (m > 0.f) scale[i] = m * margin / fmax[i];
-    amax[i] = 0.f;
+    float m = 0.f;
+#pragma unroll
+    for (int k = lane; k < YP_FP8_AMAX_SLOTS; k += 64) { m = fmaxf(m, amax[(size_t)i * YP_FP8_AMAX_SLOTS + k]); amax[(size_t)i * YP_FP8_AMAX_SLOTS + k] = 0.f; }
+    m = wave_max_f(m);
+    if (lane == 0 && m > 0.f) scale[i] = m * margin / fmax[i];
 }
 
 // fp32 master filter -> packed e4m3 [Npad + 1][Kpad] (yp_pack_weight's layouts), one table entry per packed copy; real = stored * *scale.
@@ -111,9 +89,9 @@ __global__ __launch_bounds__(256) void pack_weight_fp8_kernel(const YpPackEntry8
             mx = fmaxf(mx, fabsf(x));
             v[u] = x * inv;
         }
-        *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(en.dst) + base) = pack4<0>(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(en.dst) + base) = yp_fp8_pack4<0>(v[0], v[1], v[2], v[3]);
     }
-    block_amax(mx, en.amax);
+    yp_block_amax(mx, en.amax);
 }
 
 }  // namespace
@@ -136,7 +114,7 @@ extern "C" int yp_quantize_fp8(YpView src, YpView dst, int src_dtype, int B, int
 
 extern "C" int yp_fp8_update_scales(float* scale, float* amax, const float* fmax, int n, float margin, void* stream) {
     YP_REQUIRE(scale && amax && fmax && n > 0 && margin > 0.f, "yp_fp8_update_scales: bad arguments");
-    update_scales_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(scale, amax, fmax, n, margin);
+    update_scales_kernel<<<(n + 3) / 4, 256, 0, (hipStream_t)stream>>>(scale, amax, fmax, n, margin);
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
 }

@@ -374,8 +374,13 @@ __global__ __launch_bounds__(256) void bn_rows_fast_kernel(const char* __restric
                                                            char* __restrict__ out, int ocs, int oco, const char* __restrict__ res, int scs, int sco,
                                                            unsigned M, int C, int lg, const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta, int act,
-                                                           const float* __restrict__ dgamma, const float* __restrict__ dbeta) {
+                                                           const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                           unsigned char* __restrict__ q8, int qcs, int qco, const float* __restrict__ qscale,
+                                                           float* __restrict__ qamax) {
     // blockIdx.y = statistics group: M rows each, mean / invstd / dgamma / dbeta [groups][C]
+    // q8 != nullptr (fp8 training): the result is ALSO written as 1-byte values q8[row * qcs + qco + c] = saturate(result / *qscale) --
+    // e4m3 for the forward output (the next Conv's activation), e5m2 for the backward's dx (the dgrad's output gradient) -- and its
+    // max|result| recorded into qamax (csrc/fp8.hip): the separate quantisation pass over the tensor disappears.
     const int t = threadIdx.x;
     const int ch = t & ((1 << lg) - 1), rl = t >> lg, rlanes = 256 >> lg;
     float mu[8], is[8], ga[8], be[8], k0[8], k1[8];
@@ -387,7 +392,10 @@ __global__ __launch_bounds__(256) void bn_rows_fast_kernel(const char* __restric
         out += roff * ocs * esize<DT>();
         if (dy != nullptr) dy += roff * dcs * esize<DT>();
         if (res != nullptr) res += roff * scs * esize<DT>();
+        if (q8 != nullptr) q8 += roff * qcs;
     }
+    const float qinv = q8 != nullptr ? 1.0f / qscale[0] : 0.f;
+    float qmx = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int c = ch * 8 + j;
@@ -415,6 +423,14 @@ __global__ __launch_bounds__(256) void bn_rows_fast_kernel(const char* __restric
             }
         }
         store8<DT>(out, r * ocs + oco + ch * 8, o);
+        if (q8 != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qmx = fmaxf(qmx, fabsf(o[j]));
+            uint2 pk;
+            pk.x = yp_fp8_pack4<BWD ? 1 : 0>(o[0] * qinv, o[1] * qinv, o[2] * qinv, o[3] * qinv);
+            pk.y = yp_fp8_pack4<BWD ? 1 : 0>(o[4] * qinv, o[5] * qinv, o[6] * qinv, o[7] * qinv);
+            *reinterpret_cast<uint2*>(q8 + r * qcs + qco + ch * 8) = pk;
+        }
     };
     unsigned r = blockIdx.x * rlanes + rl;
     for (; (size_t)r + stride < M; r += 2 * stride) {       // two independent rows in flight
@@ -444,6 +460,7 @@ __global__ __launch_bounds__(256) void bn_rows_fast_kernel(const char* __restric
         }
         body(r, x, g);
     }
+    if (q8 != nullptr) yp_block_amax(qmx, qamax);
 }
 
 // out[pix, c] (+)= sum of the 2x2 block of `in` it was upsampled to  (backward of nn.Upsample(2,'nearest'))
@@ -706,6 +723,11 @@ extern "C" int yp_bn_finalize(const float* partial, int rows, int C, double M, f
 
 extern "C" int yp_bn_act_apply_grouped(YpView raw, YpView out, YpView res, int dtype, int B, int groups, const float* mean, const float* invstd,
                                        const float* gamma, const float* beta, int act, void* stream) {
+    YpView none{};
+    return yp_bn_act_apply_grouped_q8(raw, out, res, dtype, B, groups, mean, invstd, gamma, beta, act, none, nullptr, nullptr, stream);
+}
+extern "C" int yp_bn_act_apply_grouped_q8(YpView raw, YpView out, YpView res, int dtype, int B, int groups, const float* mean, const float* invstd,
+                                          const float* gamma, const float* beta, int act, YpView q8, const float* q_scale, float* q_amax, void* stream) {
     if (int rc = check_view8(raw, "yp_bn_act_apply")) return rc;
     if (int rc = check_view8(out, "yp_bn_act_apply")) return rc;
     YP_REQUIRE(out.C == raw.C && (res.C == 0 || res.C == raw.C) && mean && invstd && gamma && beta && groups >= 1 && B % groups == 0, "yp_bn_act_apply: bad arguments");
@@ -713,11 +735,14 @@ extern "C" int yp_bn_act_apply_grouped(YpView raw, YpView out, YpView res, int d
     hipStream_t st = (hipStream_t)stream;
     const int g = grid_for(M * (raw.C / 8), 256);
     const int lg = fast_lg(raw.C);
+    YP_REQUIRE(q8.ptr == nullptr || (lg >= 0 && M < (1ull << 31) && q8.C == raw.C && q8.H == raw.H && q8.W == raw.W && q8.cstride % 8 == 0 && q8.coff % 8 == 0 && q_scale),
+               "yp_bn_act_apply: the 1-byte twin needs C/8 a power of two <= 256, a matching view and a scale");
     if (lg >= 0 && M < (1ull << 31)) {
         const int gf = grid_for((Mg * (raw.C / 8) + 1) / 2, 256, (size_t)(256 * 16) / groups);      // ~2 rows per thread
         YP_DT_SWITCH(dtype, (bn_rows_fast_kernel<DT, false><<<dim3(gf, groups), 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, nullptr, 0, 0, (char*)out.ptr, out.cstride,
                                                                                out.coff, res.C ? (const char*)res.ptr : nullptr, res.cstride, res.coff, (unsigned)Mg, raw.C, lg,
-                                                                               mean, invstd, gamma, beta, act, nullptr, nullptr)));
+                                                                               mean, invstd, gamma, beta, act, nullptr, nullptr, (unsigned char*)q8.ptr, q8.cstride, q8.coff,
+                                                                               q_scale, q_amax)));
     } else {
         YP_DT_SWITCH(dtype, (bn_apply_kernel<DT><<<g, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, (char*)out.ptr, out.cstride, out.coff,
                                                                     res.C ? (const char*)res.ptr : nullptr, res.cstride, res.coff, M, Mg, raw.C, mean,
@@ -734,6 +759,13 @@ extern "C" int yp_bn_act_apply(YpView raw, YpView out, YpView res, int dtype, in
 extern "C" int yp_bn_act_bwd_grouped(YpView raw, YpView dy, YpView dx, int dtype, int B, int groups, const float* mean, const float* invstd,
                                      const float* gamma, const float* beta, int act, float* dgamma, float* dbeta, int accumulate_param_grads,
                                      void* ws, size_t ws_bytes, void* stream) {
+    YpView none{};
+    return yp_bn_act_bwd_grouped_q8(raw, dy, dx, dtype, B, groups, mean, invstd, gamma, beta, act, dgamma, dbeta, accumulate_param_grads, ws, ws_bytes, none, nullptr,
+                                    nullptr, stream);
+}
+extern "C" int yp_bn_act_bwd_grouped_q8(YpView raw, YpView dy, YpView dx, int dtype, int B, int groups, const float* mean, const float* invstd,
+                                        const float* gamma, const float* beta, int act, float* dgamma, float* dbeta, int accumulate_param_grads,
+                                        void* ws, size_t ws_bytes, YpView q8, const float* q_scale, float* q_amax, void* stream) {
     if (int rc = check_view8(raw, "yp_bn_act_bwd")) return rc;
     if (int rc = check_view8(dy, "yp_bn_act_bwd")) return rc;
     if (int rc = check_view8(dx, "yp_bn_act_bwd")) return rc;
@@ -748,6 +780,8 @@ extern "C" int yp_bn_act_bwd_grouped(YpView raw, YpView dy, YpView dx, int dtype
     float* db = dg + (size_t)groups * raw.C;
     const int lg = fast_lg(raw.C);
     const bool fastp = lg >= 0 && M < (1ull << 31);
+    YP_REQUIRE(q8.ptr == nullptr || (fastp && q8.C == raw.C && q8.H == raw.H && q8.W == raw.W && q8.cstride % 8 == 0 && q8.coff % 8 == 0 && q_scale),
+               "yp_bn_act_bwd: the 1-byte twin needs C/8 a power of two <= 256, a matching view and a scale");
     if (fastp) {
         unsigned rpb;
         nbg = fast_reduce_blocks(Mg, lg, &rpb, 2048 / groups);
@@ -765,7 +799,7 @@ extern "C" int yp_bn_act_bwd_grouped(YpView raw, YpView dy, YpView dx, int dtype
         const int gf = grid_for((Mg * (raw.C / 8) + 1) / 2, 256, (size_t)(256 * 16) / groups);
         YP_DT_SWITCH(dtype, (bn_rows_fast_kernel<DT, true><<<dim3(gf, groups), 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, (const char*)dy.ptr, dy.cstride, dy.coff,
                                                                               (char*)dx.ptr, dx.cstride, dx.coff, nullptr, 0, 0, (unsigned)Mg, raw.C, lg, mean, invstd, gamma, beta,
-                                                                              act, dg, db)));
+                                                                              act, dg, db, (unsigned char*)q8.ptr, q8.cstride, q8.coff, q_scale, q_amax)));
     } else {
         YP_DT_SWITCH(dtype, (bn_bwd_apply_kernel<DT><<<g, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, (const char*)dy.ptr, dy.cstride, dy.coff,
                                                                         (char*)dx.ptr, dx.cstride, dx.coff, M, Mg, raw.C, mean, invstd, gamma, beta, act, dg, db)));
@@ -1156,10 +1190,11 @@ extern "C" int yp_run_op(const YpOpArgs* a, void* stream) {
                                               a->g[0], a->g[1], a->g[2], a->g[3], stream);
             return yp_bn_stats_grouped(a->v[0], dt, B, a->i[3] > 0 ? a->i[3] : 1, a->s[0], a->s[1], a->g[0], a->g[1], a->g[2], a->g[3], a->p[0], a->n[0], stream);
         case YP_OP_BN_APPLY:
-            return yp_bn_act_apply_grouped(a->v[0], a->v[1], a->v[2], dt, B, a->i[3] > 0 ? a->i[3] : 1, a->f[0], a->f[1], a->f[2], a->f[3], a->i[2], stream);
+            return yp_bn_act_apply_grouped_q8(a->v[0], a->v[1], a->v[2], dt, B, a->i[3] > 0 ? a->i[3] : 1, a->f[0], a->f[1], a->f[2], a->f[3], a->i[2], a->v[3],
+                                              a->g[2], a->g[3], stream);
         case YP_OP_BN_BWD:
-            return yp_bn_act_bwd_grouped(a->v[0], a->v[1], a->v[2], dt, B, a->i[4] > 0 ? a->i[4] : 1, a->f[0], a->f[1], a->f[2], a->f[3], a->i[2], a->g[0], a->g[1], a->i[3],
-                                         a->p[0], a->n[0], stream);
+            return yp_bn_act_bwd_grouped_q8(a->v[0], a->v[1], a->v[2], dt, B, a->i[4] > 0 ? a->i[4] : 1, a->f[0], a->f[1], a->f[2], a->f[3], a->i[2], a->g[0], a->g[1],
+                                            a->i[3], a->p[0], a->n[0], a->v[3], a->g[2], a->g[3], stream);
         case YP_OP_UPS2_BWD: return yp_ups2_bwd(a->v[0], a->v[1], dt, B, a->i[2], stream);
         case YP_OP_ADD_VIEWS: return yp_add_views(a->v[0], a->v[1], dt, B, a->i[2], stream);
         case YP_OP_MAXPOOL5_BWD: return yp_maxpool5_bwd(a->v[0], a->v[1], a->v[2], dt, B, a->i[2], a->p[0], a->n[0], stream);

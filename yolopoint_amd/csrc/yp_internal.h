@@ -31,3 +31,34 @@ static inline int yp_cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // launchers living in other translation units (used by the plan)
 int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t stream);
+
+// ---- 8-bit (OCP fp8) helpers shared by csrc/fp8.hip and the BatchNorm kernels that write 1-byte twins of their outputs (csrc/train.hip)
+// four floats -> four saturated e4m3 (FMT 0, |max| 448) / e5m2 (FMT 1, |max| 57344) bytes
+template <int FMT> __device__ __forceinline__ unsigned yp_fp8_pack4(float a, float b, float c, float d) {
+    constexpr float MX = FMT == 0 ? 448.0f : 57344.0f;
+    a = fminf(fmaxf(a, -MX), MX); b = fminf(fmaxf(b, -MX), MX); c = fminf(fmaxf(c, -MX), MX); d = fminf(fmaxf(d, -MX), MX);
+    int v = 0;
+    if constexpr (FMT == 0) {
+        v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false);
+        v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+    } else {
+        v = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, v, false);
+        v = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, v, true);
+    }
+    return (unsigned)v;
+}
+// max|x| of a 256-thread workgroup -> ONE atomic max on the float bits (values >= 0), spread over the YP_FP8_AMAX_SLOTS sub-slots of the
+// tensor's maximum.  Atomics on one address retire one after the other in L2 (~0.1 us each): a wave-level atomic per 64 lanes on a single
+// address cost 160 us per launch, one per workgroup over 16 addresses still 25 us for the 4096 workgroups of a BatchNorm pass.
+#define YP_FP8_AMAX_SLOTS 256
+__device__ __forceinline__ void yp_block_amax(float mx, float* amax) {
+    __shared__ float yp_wmax[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) yp_wmax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0 && amax != nullptr) {
+        const float m = fmaxf(fmaxf(yp_wmax[0], yp_wmax[1]), fmaxf(yp_wmax[2], yp_wmax[3]));
+        if (m > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax) + ((blockIdx.x + blockIdx.y) & (YP_FP8_AMAX_SLOTS - 1)), __float_as_uint(m));
+    }
+}

@@ -141,7 +141,7 @@ class Fp8State:
     def __init__(self, device, capacity=8192):
         self.device = device
         self.scale = torch.ones(capacity, dtype=torch.float32, device=device)
-        self.amax = torch.zeros(capacity, dtype=torch.float32, device=device)
+        self.amax = torch.zeros(capacity * 256, dtype=torch.float32, device=device)     # 256 sub-slots per tensor (YP_FP8_AMAX_SLOTS)
         self.fmax = torch.full((capacity,), 448.0, dtype=torch.float32, device=device)
         self.n, self.by_key = 0, {}
 
@@ -160,7 +160,7 @@ class Fp8State:
         return self.scale.data_ptr() + 4 * i
 
     def amax_ptr(self, i):
-        return self.amax.data_ptr() + 4 * i
+        return self.amax.data_ptr() + 1024 * i
 
     def update(self, margin=1.0):
         if self.n:

@@ -157,29 +157,49 @@ class TrainGraph:
         """8-bit operands need the kernels' 64-byte k chunks: every source slice a multiple of 64 channels, 16-byte aligned."""
         return all(v.geom is None and v.C % 64 == 0 and v.coff % 16 == 0 and v.cstride % 16 == 0 for v in views)
 
+    def q8_twin(self, pb, v, fmt):
+        """The 1-byte twin Buf of view `v`'s buffer and its scale slot (one twin, one scale per activation / gradient buffer and format)."""
+        key = (v.buf.t.data_ptr(), fmt)
+        if key not in self.twins:
+            tb = Buf(v.buf.B, v.buf.H, v.buf.W, v.buf.C, torch.uint8, self.device)
+            self.keep.append(tb.flat)
+            self.twins[key] = tb
+        return self.twins[key], pb.fp8.slot(("act", key), fmt), key
+
+    @staticmethod
+    def q8_fusable(v):
+        """The BatchNorm passes write the twin themselves when their fast path serves the channel count (C/8 a power of two <= 256)."""
+        ch = v.C // 8
+        return v.C % 8 == 0 and 1 <= ch <= 256 and (ch & (ch - 1)) == 0
+
+    def q8_produced(self, pb, v, fmt):
+        """Arguments that make a BatchNorm pass write view `v`'s twin (forward output: fmt 0 = e4m3; dx: fmt 1 = e5m2), or None."""
+        if not (self.fp8 and self.q8_ok([v]) and self.q8_fusable(v) and os.environ.get("YP_FP8_FUSE", "1") != "0"):
+            return None
+        tb, slot, key = self.q8_twin(pb, v, fmt)
+        pb.__dict__.setdefault("quantized", {}).setdefault(key, []).append((v.coff, v.coff + v.C))
+        return View(tb, v.coff, v.C), pb.fp8.scale_ptr(slot), pb.fp8.amax_ptr(slot)
+
     def q8_sources(self, pb, srcs, fmt):
-        """1-byte twins of the 16-bit views `srcs` + the quantisation launches that fill them, and the scale slot they share.  A single
-        source is quantised into its buffer's own twin (one twin and one scale per activation buffer, reused by every consumer);
-        channel-concatenated sources of one convolution need ONE scale, so they get twins private to that convolution."""
+        """1-byte twins of the 16-bit views `srcs`, the quantisation launches that fill them where no producer did, and the scale slot
+        they share.  A single source reads its buffer's own twin (reused by every consumer); channel-concatenated sources of one
+        convolution need ONE scale, so they get twins private to that convolution."""
         st = pb.fp8
-        fmax_fmt = fmt
         if len(srcs) == 1:
             v = srcs[0]
-            key = (v.buf.t.data_ptr(), fmt)
-            if key not in self.twins:
-                tb = Buf(v.buf.B, v.buf.H, v.buf.W, v.buf.C, torch.uint8, self.device)
-                self.keep.append(tb.flat)
-                self.twins[key] = tb
-            tb = self.twins[key]
-            slot = st.slot(("act", key, v.coff, v.C), fmax_fmt)       # (one scale per consumed channel slice of the buffer)
-            done = pb.__dict__.setdefault("quantized", set())
-            tag = (key, v.coff, v.C)
-            if tag not in done:
-                done.add(tag)
+            tb, slot, key = self.q8_twin(pb, v, fmt)
+            done = pb.__dict__.setdefault("quantized", {}).setdefault(key, [])
+            lo, covered = v.coff, False
+            for a_, b_ in sorted(done):               # is [coff, coff + C) covered by the slices written so far?
+                if a_ <= lo < b_:
+                    lo = b_
+            covered = lo >= v.coff + v.C
+            if not covered:
+                done.append((v.coff, v.coff + v.C))
                 sv, dv = View(v.buf, v.coff, v.C), View(tb, v.coff, v.C)
                 pb.op(_hip.OP_QUANT_FP8, [sv], [dv], "quant", v=[sv, dv], i=[self.code, pb.B, fmt], p=[st.scale_ptr(slot), st.amax_ptr(slot)])
             return [View(tb, v.coff, v.C, v.ups)], slot
-        slot = st.slot(("cat", pb.handle.value, len(pb.records)), fmax_fmt)
+        slot = st.slot(("cat", pb.handle.value, len(pb.records)), fmt)
         out = []
         for v in srcs:
             tb = Buf(pb.B, v.buf.H, v.buf.W, v.C, torch.uint8, self.device)
@@ -250,8 +270,13 @@ class TrainGraph:
                  g=[mean, invstd, rmean, rvar], p=[self.ws], n=[self.ws.numel()])
         if out is None:
             out = f.new_buf(raw.H, raw.W, raw.C).view()
-        f.op(_hip.OP_BN_APPLY, [raw, res, self.T(mean), self.T(invstd)], [out], "bn_act", v=[raw, out, res], i=[code, B, act, G],
-             f=[mean, invstd, gamma, beta])
+        tw = self.q8_produced(f, out, 0)             # fp8 mode: the e4m3 twin of the output comes out of the same pass
+        if tw is None:
+            f.op(_hip.OP_BN_APPLY, [raw, res, self.T(mean), self.T(invstd)], [out], "bn_act", v=[raw, out, res], i=[code, B, act, G],
+                 f=[mean, invstd, gamma, beta])
+        else:
+            f.op(_hip.OP_BN_APPLY, [raw, res, self.T(mean), self.T(invstd)], [out, tw[0]], "bn_act", v=[raw, out, res, tw[0]], i=[code, B, act, G],
+                 f=[mean, invstd, gamma, beta], g=[None, None, tw[1], tw[2]])
 
         def backward():
             b = self.bwd
@@ -263,8 +288,14 @@ class TrainGraph:
             draw = b.new_buf(raw.H, raw.W, raw.C).view()
             gw_, gb_ = self.pgrad(bn.weight), self.pgrad(bn.bias)
             dg, db = (b.new_tensor((Cp,)), b.new_tensor((Cp,))) if padded else (gw_, gb_)
-            b.op(_hip.OP_BN_BWD, [raw, gy], [draw, self.T(self.ws)], "bn_act_bwd", v=[raw, gy, draw], i=[code, B, act, 0, self.bG],
-                 f=[mean, invstd, gamma, beta], g=[dg, db], p=[self.ws], n=[self.ws.numel()])
+            # fp8 mode: the e5m2 twin of dx (the dgrad's operand) comes out of the same pass
+            tw = self.q8_produced(b, draw, 1) if (os.environ.get("YP_FP8_DGRAD", "1") != "0" and not image) else None
+            if tw is None:
+                b.op(_hip.OP_BN_BWD, [raw, gy], [draw, self.T(self.ws)], "bn_act_bwd", v=[raw, gy, draw], i=[code, B, act, 0, self.bG],
+                     f=[mean, invstd, gamma, beta], g=[dg, db], p=[self.ws], n=[self.ws.numel()])
+            else:
+                b.op(_hip.OP_BN_BWD, [raw, gy], [draw, self.T(self.ws), tw[0]], "bn_act_bwd", v=[raw, gy, draw, tw[0]], i=[code, B, act, 0, self.bG],
+                     f=[mean, invstd, gamma, beta], g=[dg, db, tw[1], tw[2]], p=[self.ws], n=[self.ws.numel()])
             if padded:
                 self.collect.append(lambda dg=dg, db=db, gw_=gw_, gb_=gb_: (gw_.copy_(dg[:Cc]), gb_.copy_(db[:Cc])))
             self.conv_backward(srcs, conv.weight, None, draw, k, s, p)
