@@ -21,6 +21,8 @@ Sub-records of the same line (each measured in this process, after the top-level
                 and the time the compute stream waits for the collectives (exposed communication)
   train_bs64    (N = 1) the metric's "train bs=64" on one GPU the way the reference reaches its nominal batch (train.py:38-43):
                 gas = 8 micro-batches of 8 per optimizer step
+  train_l_fp8   (N = 1) BASELINE configs[4] shape: YOLOPoint-l optimizer step, 8 samples, fp8 Conv operands (e4m3 x e4m3 forward, e5m2 x e4m3 dgrad,
+                bf16 storage / BatchNorm / weight gradients); `bf16_ms_per_step` = the same step in bf16
   frame         (N = 1) BASELINE configs[3]: YOLOPoint-l, one 1280x1280 frame end to end (forward + keypoint decode / NMS + box NMS on 100 800
                 rows + box-mask filter + descriptor sampling + MNN matching against the previous frame)
 `--only infer|train|frame` restricts the run; `--mode train|frame|export` prints that workload as the top-level record (round-1 CLI).
@@ -55,7 +57,7 @@ def parse():
     ap.add_argument("--postproc", action="store_true", help="also time the post-processing kernels on planted head outputs")
     ap.add_argument("--mode", default="infer", choices=["infer", "train", "frame", "export"],
                     help="infer (default, BASELINE.json configs[1] + sub-records) or one workload as the top-level record")
-    ap.add_argument("--only", default="", help="comma list of sub-records to run beside the top level: train,train64,frame (default: all)")
+    ap.add_argument("--only", default="", help="comma list of sub-records to run beside the top level: train,train64,frame,fp8 (default: all)")
     ap.add_argument("--train-steps", type=int, default=20)
     ap.add_argument("--train-warmup", type=int, default=3)
     ap.add_argument("--frame-steps", type=int, default=60)
@@ -279,7 +281,7 @@ def main():
         if a.postproc:
             out["postproc"] = bench_postproc(dev)
     # ---- sub-records (every rank takes part in the data-parallel training; the rest is rank 0, N = 1)
-    only = set(k for k in a.only.split(",") if k) or {"train", "train64", "frame"}
+    only = set(k for k in a.only.split(",") if k) or {"train", "train64", "frame", "fp8"}
     del plan, img, outs
     net.__dict__.pop("_plans", None)
     torch.cuda.empty_cache()
@@ -289,6 +291,12 @@ def main():
             out["train"] = rec
     if world == 1 and "train64" in only:
         out["train_bs64"] = run_train(a, rank, world, dev, a.version, 8, max(3, a.train_steps // 4), 1, gas=8)
+    if world == 1 and "fp8" in only:
+        # BASELINE configs[4] shape on one GPU: YOLOPoint-l, 8 samples per GPU, fp8 Conv operands; the bf16 step of the same model beside it
+        torch.cuda.empty_cache()
+        out["train_l_fp8"] = run_train(a, rank, world, dev, "l", 8, max(4, a.train_steps // 3), 2, gas=1, dtype="fp8")
+        ref = run_train(a, rank, world, dev, "l", 8, max(4, a.train_steps // 3), 2, gas=1, dtype="bf16")
+        out["train_l_fp8"]["bf16_ms_per_step"] = ref["ms_per_step"]
     if world == 1 and "frame" in only:
         torch.cuda.empty_cache()
         out["frame"] = run_frame(dev, "l", 1280, a.dtype, a.frame_steps, max(3, a.frame_steps // 6))
@@ -357,7 +365,9 @@ def run_train(a, rank, world, dev, version, batch, steps, warmup, gas=1, size=64
            "bucket_launch_order": list(step.reducer.launch_log), "exposed_comm_ms_per_step": exposed,
            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS["bf16"], 4),
                         "traffic": None, "per_gpu": True, "algorithmic_gflop_per_sample": round(gflop_sample, 2),
-                        "note": "whole step (losses, BN / elementwise passes, optimizer included) against the conv FLOP the reference executes per sample"}}
+                        "note": "whole step (losses, BN / elementwise passes, optimizer included) against the conv FLOP the reference executes per sample"
+                                + ("; the fp8 convolutions use the non-scaled 16x16x32 fp8 MFMAs, which issue at the bf16 rate (2.5 PFLOP/s dense), not the MX-scaled "
+                                   "K = 128 forms (5 PFLOP/s)" if fp8 else "")}}
     del step, m, micro
     torch.cuda.empty_cache()
     return rec if rank == 0 else None
