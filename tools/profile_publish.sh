@@ -14,6 +14,10 @@ cp $S/${R}_train_kernel_trace.txt profiles/${R}_train_kernel_trace.txt
 cp $S/${R}_train_step_kernels.txt profiles/${R}_train_step_kernels.txt
 cp $S/train_fwd_ops.txt profiles/${R}_train_fwd_ops.txt
 cp $S/train_bwd_ops.txt profiles/${R}_train_bwd_ops.txt
+cp $S/${R}_train_step_sequence.txt profiles/${R}_train_step_sequence.txt
+cp $S/bench_train_l_fp8.json profiles/${R}_bench_train_l_fp8.json
+cp $S/bench_train_l_bf16.json profiles/${R}_bench_train_l_bf16.json
+cp $S/${R}_train_l_fp8_step_kernels.txt profiles/${R}_train_l_fp8_step_kernels.txt
 cp $S/bench_frame.json profiles/${R}_bench_frame.json
 cp $S/bench_export.json profiles/${R}_bench_export.json
 ls -la profiles/

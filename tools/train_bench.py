@@ -25,7 +25,9 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
 print(f"YOLOPoint-{a.version} train step B={a.batch} {a.size}x{a.size} {a.dtype}: {dt*1e3:.1f} ms/step = {a.batch/dt:.1f} samples/s ({2*a.batch/dt:.1f} images/s), loss={float(l):.4f}")
 g = next(iter(m.model._train_graphs.values()))[0]
-for name, plan in (("fwd", g.fwd_plan), ("bwd", g.bwd_plan)):
+# (the first graph of the pool is the pair graph of TrainStep: forward over 2B samples, YOLO-branch backward plan, trunk backward plan)
+PLANS = (("fwd", g.fwd_plan), ("bwd_yolo", g.bwd_plan), ("bwd_trunk", g.bwd_kp_plan))
+for name, plan in PLANS:
     ms = plan.profile()
     print(f"  {name} plan: {len(ms)} launches, {sum(ms):.2f} ms eager")
     top = sorted(zip(ms, [r.name for r in plan.records]), reverse=True)[:8]
@@ -39,7 +41,7 @@ from yolopoint_amd.engine import SPARSE, LAMBDA_DESC, LAMBDA_OBJ
 def tick(label, t=[time.perf_counter()]):
     torch.cuda.synchronize(); now = time.perf_counter(); print(f"    {label:28s} {(now - t[0])*1e3:7.1f} ms"); t[0] = now
 print("  phase breakdown (synchronised):")
-step.opt.zero_grad(set_to_none=True); tick("zero_grad")
+step.reducer.bind_grads(zero=True); tick("zero_grad (bind_grads)")
 o = m(batch['image']); tick("forward 1")
 ow = m(batch['warped_image']); tick("forward 2")
 lo = step.obj_loss(o['objects'], batch['box_labels'])[0]; tick("object loss")
@@ -55,7 +57,9 @@ t0 = time.perf_counter(); gg.bwd_plan.run(); torch.cuda.synchronize(); print(f" 
 
 # ---- aggregated per-kind table of both plans
 import collections
-for name, plan in (("fwd", g.fwd_plan), ("bwd", g.bwd_plan)):
+for f_ in ("train_fwd_ops.txt", "train_bwd_ops.txt"):
+    open(os.path.join(ROOT, "gpurun_out", f_), "w").close()
+for name, plan in PLANS:
     ms = plan.profile()
     agg = collections.defaultdict(lambda: [0, 0.0])
     for t, r in zip(ms, plan.records):
@@ -64,7 +68,8 @@ for name, plan in (("fwd", g.fwd_plan), ("bwd", g.bwd_plan)):
     print(f"  {name} plan by kind:")
     for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print(f"    {k[0]:8s} {k[1]:24s} n={n:4d} {t:8.3f} ms")
-    with open(os.path.join(ROOT, "gpurun_out", f"train_{name}_ops.txt"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "train_fwd_ops.txt" if name == "fwd" else "train_bwd_ops.txt"), "a") as f:
+        f.write(f"# {name} plan (pair graph), {len(ms)} launches, {sum(ms):.3f} ms eager\n")
         for t, r in sorted(zip(ms, plan.records), key=lambda x: -x[0]):
             f.write(f"{t*1e3:9.1f} us  {r.kind:8s} {r.name:50s} M={r.M} N={r.N} K={r.K} flops={r.flops}\n")
 
