@@ -77,11 +77,13 @@ CONVS = {
 
 
 @pytest.mark.parametrize("act_fmt", [0, 1])
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 10, 11, 12, 13, 14])        # 1-5: generic kernel tiles; 10-15: the 3x3 halo kernel (3x3 cases only)
 @pytest.mark.parametrize("name", list(CONVS))
 def test_fp8_convolution_matches_torch_on_the_same_bytes(cuda, name, tile, act_fmt):
     c = CONVS[name]
     cins, cout, k, s, Ho, B = c["cin"], c["cout"], c["k"], c["s"], c["H"], c["B"]
+    if tile >= 10 and (k != 3 or (tile - 10) % 3 == 2 and cout < 128 or (tile - 10) % 3 == 1 and cout < 64):
+        pytest.skip("halo tiles: 3x3 convolutions, tile width <= output channels")
     Hi = Ho * s
     ups0 = c.get("ups0", False)
     torch.manual_seed(len(name) + tile)

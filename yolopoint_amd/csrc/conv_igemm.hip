@@ -900,8 +900,8 @@ template <int DT, bool OUT_F32, int STRIDE, int BN, int WAVES_M, int TH = 8, boo
 __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvKArgs a) {
     using E = Elem<DT>;
     using frag_t = typename E::frag;
-    static_assert(E::BYTES == 2, "halo kernel: 16-bit element types");
-    constexpr int EB = 2, BK = 32;
+    static_assert(E::BYTES <= 2, "halo kernel: 16-bit or 8-bit element types");
+    constexpr int EB = E::BYTES, BK = 64 / EB;          // 64 bytes of k per chunk: 32 16-bit channels, 64 8-bit ones (Elem<YP_FP8>)
     constexpr int TW = 16;
     constexpr int WAVES_N = 4 / WAVES_M;
     constexpr int FM = TH / WAVES_M;                 // output rows (16-pixel fragments) per wave
@@ -1044,6 +1044,13 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvKArgs a) {
     }
 
     YP_TL(40);
+    if constexpr (E::BYTES == 1) {          // 8-bit inputs: back to real units (dequantisation scales of activation and filter)
+        const float osc = a.scale_in[0] * a.scale_w[0];
+#pragma unroll
+        for (int f = 0; f < FN; ++f)
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) acc[f][fm] *= osc;
+    }
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm) {
         const int oy = y0 + wm * FM + fm, ox = x0 + p;
@@ -1865,8 +1872,7 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
     // 3x3 / pad 1 / stride 1|2, single un-upsampled source, 16-bit types, Cin % 32 == 0: LDS halo-reuse kernel
     // (tile ids 10..12 force it with BN = 32/64/128; tile 0 picks BN by the channel count; ids 1..5 force the generic kernel)
     YP_REQUIRE(!q8 || fast, "yp_conv2d: 8-bit inputs need the fast addressing path (channels %% 64 == 0, tail_zero)");
-    YP_REQUIRE(!q8 || d->tile < 10 || d->tile > 15, "yp_conv2d: tile %d (3x3 halo kernel) has no 8-bit instantiation", d->tile);
-    const bool halo_base = fast && !q8 && d->dtype != YP_F32 && d->R == 3 && d->S == 3 && d->pad_h == 1 && d->pad_w == 1 &&
+    const bool halo_base = fast && d->dtype != YP_F32 && d->R == 3 && d->S == 3 && d->pad_h == 1 && d->pad_w == 1 &&
                            d->stride_h == d->stride_w && (d->stride_h == 1 || d->stride_h == 2) && d->in0.ups == 0 && ksplit == 1 && !d->atomic_accumulate &&
                            in0_bytes + (size_t)d->in0.cstride * eb + 64 < (1ull << 31);
     const bool halo_ok = halo_base && (d->in1.C == 0 || post);
@@ -1916,8 +1922,12 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
                        "yp_conv2d: bn_partial needs a plain convolution (no bias / activation / residual / second output)");
             a.stats = d->bn_partial;
             if (g_bn_rows_query != nullptr) { *g_bn_rows_query = d->B * a.tiles_y * a.tiles_x; return YP_OK; }
-            e = d->dtype == YP_F16 ? dispatch_halo<YP_F16, false, true>(d->stride_h, bn, th, a, nb3, stream) : dispatch_halo<YP_BF16, false, true>(d->stride_h, bn, th, a, nb3, stream);
-        } else if (d->dtype == YP_F16) e = of32 ? dispatch_halo<YP_F16, true>(d->stride_h, bn, th, a, nb3, stream) : dispatch_halo<YP_F16, false>(d->stride_h, bn, th, a, nb3, stream);
+            e = d->dtype == YP_F16 ? dispatch_halo<YP_F16, false, true>(d->stride_h, bn, th, a, nb3, stream)
+                : d->dtype == YP_BF16 ? dispatch_halo<YP_BF16, false, true>(d->stride_h, bn, th, a, nb3, stream)
+                : d->dtype == YP_FP8 ? dispatch_halo<YP_FP8, false, true>(d->stride_h, bn, th, a, nb3, stream) : hipErrorInvalidValue;
+        } else if (d->dtype == YP_FP8) e = dispatch_halo<YP_FP8, false>(d->stride_h, bn, th, a, nb3, stream);
+        else if (d->dtype == YP_FP8_BF8) e = dispatch_halo<YP_FP8_BF8, false>(d->stride_h, bn, th, a, nb3, stream);
+        else if (d->dtype == YP_F16) e = of32 ? dispatch_halo<YP_F16, true>(d->stride_h, bn, th, a, nb3, stream) : dispatch_halo<YP_F16, false>(d->stride_h, bn, th, a, nb3, stream);
         else e = of32 ? dispatch_halo<YP_BF16, true>(d->stride_h, bn, th, a, nb3, stream) : dispatch_halo<YP_BF16, false>(d->stride_h, bn, th, a, nb3, stream);
         if (e != hipSuccess) {
             yp_set_error("yp_conv2d: halo kernel launch failed: %s", hipGetErrorString(e));
