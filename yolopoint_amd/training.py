@@ -597,7 +597,7 @@ class TrainGraph:
             xo = f.new_tensor((B, det.na, ny, nx, det.no))
             stride = float(det.stride[i])
             mi = det.m[i]
-            f.conv(v, lambda mi=mi: (mi.weight.detach().float(), mi.bias.detach().float()), mi.bias, 1, 1, 0, _hip.YP_ACT_NONE, out_f32=True,
+            f.conv(v, MasterWeight(mi.weight, mi.bias), mi.bias, 1, 1, 0, _hip.YP_ACT_NONE, out_f32=True,      # (packed on the device with all other filters)
                    detect=dict(na=det.na, no=det.no, stride=stride, anchors_px=[0.0] * (2 * det.na), x_out=xo, z_out=None, rows_total=0,
                                row_offset=0))
             gx = torch.zeros_like(xo)
