@@ -21,8 +21,9 @@ Sub-records of the same line (each measured in this process, after the top-level
                 and the time the compute stream waits for the collectives (exposed communication)
   train_bs64    (N = 1) the metric's "train bs=64" on one GPU the way the reference reaches its nominal batch (train.py:38-43):
                 gas = 8 micro-batches of 8 per optimizer step
-  train_l_fp8   (N = 1) BASELINE configs[4] shape: YOLOPoint-l optimizer step, 8 samples, fp8 Conv operands (e4m3 x e4m3 forward, e5m2 x e4m3 dgrad,
-                bf16 storage / BatchNorm / weight gradients); `bf16_ms_per_step` = the same step in bf16
+  train_l_fp8   BASELINE configs[4]: YOLOPoint-l optimizer step, 16 samples per GPU (bs 128 over 8 GPUs), data parallel over all N ranks, fp8 Conv
+                operands (e4m3 x e4m3 forward, e5m2 x e4m3 dgrad, bf16 storage / BatchNorm / weight gradients); at N = 1 `bf16_ms_per_step` = the
+                same step in bf16
   frame         (N = 1) BASELINE configs[3]: YOLOPoint-l, one 1280x1280 frame end to end (forward + keypoint decode / NMS + box NMS on 100 800
                 rows + box-mask filter + descriptor sampling + MNN matching against the previous frame)
 `--only infer|train|frame` restricts the run; `--mode train|frame|export` prints that workload as the top-level record (round-1 CLI).
@@ -291,12 +292,16 @@ def main():
             out["train"] = rec
     if world == 1 and "train64" in only:
         out["train_bs64"] = run_train(a, rank, world, dev, a.version, 8, max(3, a.train_steps // 4), 1, gas=8)
-    if world == 1 and "fp8" in only:
-        # BASELINE configs[4] shape on one GPU: YOLOPoint-l, 8 samples per GPU, fp8 Conv operands; the bf16 step of the same model beside it
+    if "fp8" in only:
+        # BASELINE configs[4]: YOLOPoint-l, 16 samples per GPU (bs 128 over 8 GPUs), fp8 Conv operands, data parallel over all N ranks;
+        # at N = 1 the bf16 step of the same model is timed beside it
         torch.cuda.empty_cache()
-        out["train_l_fp8"] = run_train(a, rank, world, dev, "l", 8, max(4, a.train_steps // 3), 2, gas=1, dtype="fp8")
-        ref = run_train(a, rank, world, dev, "l", 8, max(4, a.train_steps // 3), 2, gas=1, dtype="bf16")
-        out["train_l_fp8"]["bf16_ms_per_step"] = ref["ms_per_step"]
+        rec = run_train(a, rank, world, dev, "l", 16, max(4, a.train_steps // 4), 2, gas=1, dtype="fp8")
+        if world == 1:
+            ref = run_train(a, rank, world, dev, "l", 16, max(4, a.train_steps // 4), 2, gas=1, dtype="bf16")
+            rec["bf16_ms_per_step"] = ref["ms_per_step"]
+        if rank == 0:
+            out["train_l_fp8"] = rec
     if world == 1 and "frame" in only:
         torch.cuda.empty_cache()
         out["frame"] = run_frame(dev, "l", 1280, a.dtype, a.frame_steps, max(3, a.frame_steps // 6))

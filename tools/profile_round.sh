@@ -28,8 +28,8 @@ python tools/train_bench.py > $OUT/train_bench.log 2>&1
 cp gpurun_out/train_fwd_ops.txt gpurun_out/train_bwd_ops.txt $OUT/ 2>/dev/null
 cp $OUT/${R}_train_step_kernels.txt $OUT/keep_train_step_kernels.txt 2>/dev/null
 # BASELINE configs[4] shape on one GPU: YOLOPoint-l, fp8 Conv operands (and the same step in bf16), + the kernel list of one fp8 step
-python bench.py --mode train --version l --batch 8 --dtype fp8 --steps 10 --warmup 3 > $OUT/bench_train_l_fp8.json 2> $OUT/bench_train_l_fp8.err
-python bench.py --mode train --version l --batch 8 --dtype bf16 --steps 10 --warmup 3 > $OUT/bench_train_l_bf16.json 2>> $OUT/bench_train_l_fp8.err
+python bench.py --mode train --version l --batch 16 --dtype fp8 --steps 8 --warmup 3 > $OUT/bench_train_l_fp8.json 2> $OUT/bench_train_l_fp8.err
+python bench.py --mode train --version l --batch 16 --dtype bf16 --steps 8 --warmup 3 > $OUT/bench_train_l_bf16.json 2>> $OUT/bench_train_l_fp8.err
 python bench.py --mode frame --version l --size 1280 > $OUT/bench_frame.json 2> $OUT/bench_frame.err
 python bench.py --mode export > $OUT/bench_export.json 2> $OUT/bench_export.err
 python tools/profile_collect.py $R
@@ -37,7 +37,7 @@ python tools/profile_collect.py $R
 mkdir -p $OUT/fp8 && mv $OUT/${R}_train_step_kernels.txt $OUT/${R}_train_step_sequence.txt $OUT/${R}_train_kernel_trace.txt $OUT/fp8/ 2>/dev/null
 rm -rf $OUT/trace_train
 cd /tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_train -o t -- python $ROOT/bench.py --mode train --version l --batch 8 --dtype fp8 --steps 4 --warmup 2 > $OUT/trace_train_fp8.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_train -o t -- python $ROOT/bench.py --mode train --version l --batch 16 --dtype fp8 --steps 4 --warmup 2 > $OUT/trace_train_fp8.log 2>&1
 cd $ROOT
 python tools/profile_collect.py $R > /dev/null 2>&1
 mv $OUT/${R}_train_step_kernels.txt $OUT/${R}_train_l_fp8_step_kernels.txt
