@@ -91,7 +91,7 @@ def test_gradient_allreduce_two_ranks():
 # The network itself has no CPU path, so the per-rank compute is the oracle's forward + PyTorch autograd (test infrastructure)
 # -- what is under test is the product's bucket plan (training.grad_ready_groups) and reducer (dp.GradAllReducer).
 # ---------------------------------------------------------------------------------------------------------------------------
-def _schedule_worker(rank, world, port, q):
+def _schedule_worker(rank, world, port, q, pair=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import sys
@@ -109,7 +109,10 @@ def _schedule_worker(rank, world, port, q):
     groups = grad_ready_groups(net)
     red = GradAllReducer(None, groups=groups)
     kp = set(id(p) for p in groups[1][1])
-    red.set_expected({p: (2 if id(p) in kp else 1) for p in red.params})
+    # two-graph schedule: the trunk / keypoint-head parameters receive two contributions per micro-batch (full backward of the image pass +
+    # keypoint-only backward of the warped pass); pair schedule (engine.TrainStep's default): every parameter exactly one -- the YOLO-branch
+    # plan reaches the detector group, the trunk plan (both passes at once) the keypoint group
+    red.set_expected({p: (2 if (id(p) in kp and not pair) else 1) for p in red.params})
     names = {id(p): n for n, p in net.named_parameters()}
     out = {"nbuckets": len(red.buckets), "groups": red.bucket_group,
            "kp_ok": all(names[id(p)].split(".")[0] in KP_BRANCH_MODULES for p in groups[1][1]) and
@@ -139,14 +142,25 @@ def _schedule_worker(rank, world, port, q):
         ctx = red.no_sync() if micro == 0 else __import__("contextlib").nullcontext()
         with ctx:
             red.begin()
-            for p, g in zip(red.params, full):                     # "full backward": every parameter
-                p.grad += g * 0.5
-            red.notify(red.params)
-            after_full = list(red.launch_log)
-            for p in red.params:                                   # "keypoint-only backward": the trunk and the keypoint / descriptor heads
-                if id(p) in kp:
-                    p.grad += part[id(p)] * 0.5
-            red.notify([p for p in red.params if id(p) in kp])
+            if pair:
+                for p, g in zip(red.params, full):                 # "YOLO-branch plan": the detector group only
+                    if id(p) not in kp:
+                        p.grad += g * 0.5
+                red.notify([p for p in red.params if id(p) not in kp])
+                after_full = list(red.launch_log)
+                for p, g in zip(red.params, full):                 # "trunk plan": both passes' contributions to the keypoint group at once
+                    if id(p) in kp:
+                        p.grad += (g + part[id(p)]) * 0.5
+                red.notify([p for p in red.params if id(p) in kp])
+            else:
+                for p, g in zip(red.params, full):                 # "full backward": every parameter
+                    p.grad += g * 0.5
+                red.notify(red.params)
+                after_full = list(red.launch_log)
+                for p in red.params:                               # "keypoint-only backward": the trunk and the keypoint / descriptor heads
+                    if id(p) in kp:
+                        p.grad += part[id(p)] * 0.5
+                red.notify([p for p in red.params if id(p) in kp])
             log.append((after_full, list(red.launch_log)))
     red.finish()
     out["log"] = log
@@ -168,12 +182,12 @@ def _schedule_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_overlapped_bucket_schedule_and_dp_equivalence(world):
+@pytest.mark.parametrize("world,pair", [(2, False), (4, False), (2, True)])
+def test_overlapped_bucket_schedule_and_dp_equivalence(world, pair):
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_schedule_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_schedule_worker, args=(r, world, port, q, pair)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=600) for _ in range(world))
