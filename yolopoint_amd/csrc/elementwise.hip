@@ -147,18 +147,33 @@ __global__ __launch_bounds__(256) void sppf_pool_lds_kernel(const char* __restri
     const int chunks = C / CE;
     const int b = blockIdx.x / chunks, ch = blockIdx.x % chunks;
     const size_t pix0 = (size_t)b * HW;
-    for (int i = threadIdx.x; i < HW; i += 256)
-        p0[i] = *reinterpret_cast<const u32x4*>(x + ((pix0 + i) * xcs + xco + ch * CE) * sizeof(T));
-    __syncthreads();
-    auto vmax = [](u32x4 a, u32x4 c) -> u32x4 {
-        const T* ea = reinterpret_cast<const T*>(&a);
-        const T* ec = reinterpret_cast<const T*>(&c);
-        u32x4 r;
-        T* er = reinterpret_cast<T*>(&r);
-#pragma unroll
-        for (int j = 0; j < CE; ++j) er[j] = (float)ea[j] >= (float)ec[j] ? ea[j] : ec[j];
-        return r;
+    // 16-bit types: the planes hold ORDER KEYS instead of the values -- a sign-magnitude 16-bit float x becomes the two's-complement integer
+    // x ^ (x < 0 ? 0x7fff : 0), whose signed order is the float order (f16 and bf16 alike) -- so that a maximum of 8 channels is four packed
+    // 16-bit integer maxima instead of 8 conversions + compares + selects; keys are turned back into values where they are stored.
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+    auto key = [](u32x4 v) -> u32x4 {
+        if constexpr (sizeof(T) == 2) {
+            s16x8_t h = __builtin_bit_cast(s16x8_t, v);
+            h = h ^ ((h >> 15) & (short)0x7fff);
+            return __builtin_bit_cast(u32x4, h);
+        } else return v;
     };
+    auto vmax = [](u32x4 a, u32x4 c) -> u32x4 {
+        if constexpr (sizeof(T) == 2) {
+            return __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(s16x8_t, a), __builtin_bit_cast(s16x8_t, c)));
+        } else {
+            const T* ea = reinterpret_cast<const T*>(&a);
+            const T* ec = reinterpret_cast<const T*>(&c);
+            u32x4 r;
+            T* er = reinterpret_cast<T*>(&r);
+#pragma unroll
+            for (int j = 0; j < CE; ++j) er[j] = (float)ea[j] >= (float)ec[j] ? ea[j] : ec[j];
+            return r;
+        }
+    };
+    for (int i = threadIdx.x; i < HW; i += 256)
+        p0[i] = key(*reinterpret_cast<const u32x4*>(x + ((pix0 + i) * xcs + xco + ch * CE) * sizeof(T)));
+    __syncthreads();
     auto rowpass = [&](const u32x4* src, u32x4* dst) {
         for (int i = threadIdx.x; i < HW; i += 256) {
             const int w = i % W;
@@ -180,7 +195,7 @@ __global__ __launch_bounds__(256) void sppf_pool_lds_kernel(const char* __restri
                 if (h + d < H) m = vmax(m, src[i + d * W]);
             }
             dst[i] = m;
-            *reinterpret_cast<u32x4*>(y + ((pix0 + i) * ycs + yco + ch * CE) * sizeof(T)) = m;
+            *reinterpret_cast<u32x4*>(y + ((pix0 + i) * ycs + yco + ch * CE) * sizeof(T)) = key(m);       // (the key map is its own inverse)
         }
         __syncthreads();
     };
