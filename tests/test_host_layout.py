@@ -227,3 +227,38 @@ def test_model_ema_matches_reference_formula():
                 assert torch.equal(v, before[k])
     assert ema.updates == 2
     deepcopy(m)
+
+
+def test_flat_parameter_arena_keeps_values_and_puts_c3_siblings_back_to_back():
+    """dp.GradAllReducer.flatten_parameters() + training.link_siblings (what engine.TrainStep does to a model): every parameter becomes a
+    view of one arena laid out like the gradient arena (values, state_dict keys and shapes unchanged, 16-byte aligned slots), and cv1 /
+    cv2 of every C3 block -- filters, BatchNorm weights, biases and running statistics -- lie back to back, which is what lets the training
+    plans run the two layers as one (TrainGraph.merged_siblings).  CPU tensors: pure host logic."""
+    from yolopoint_amd.dp import GradAllReducer
+    from yolopoint_amd.training import grad_ready_groups, link_siblings
+    m, sd = make_model("n", 9)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    red = GradAllReducer(None, groups=grad_ready_groups(m.model))
+    arena = red.flatten_parameters()
+    link_siblings(m.model)
+    assert arena.numel() == red.arena.numel() and arena.numel() % 4 == 0
+    after = m.state_dict()
+    assert list(after) == list(before) and all(torch.equal(after[k], before[k]) for k in before)
+    base = arena.untyped_storage().data_ptr()
+    for p in m.parameters():
+        assert p.data.untyped_storage().data_ptr() == base and (p.data_ptr() - arena.data_ptr()) % 16 == 0
+    red.bind_grads()
+    for (flat, entries), off in zip(red.buckets, red.bucket_offsets):      # the gradient views mirror the parameter slots
+        for p, o, n in entries:
+            assert p.grad.data_ptr() - red.arena.data_ptr() == p.data_ptr() - arena.data_ptr() == 4 * (off + o)
+    n_c3 = 0
+    for mod in m.model.modules():
+        if type(mod).__name__ != "C3":
+            continue
+        n_c3 += 1
+        for a, b in ((mod.cv1.conv.weight, mod.cv2.conv.weight), (mod.cv1.bn.weight, mod.cv2.bn.weight), (mod.cv1.bn.bias, mod.cv2.bn.bias),
+                     (mod.cv1.bn.running_mean, mod.cv2.bn.running_mean), (mod.cv1.bn.running_var, mod.cv2.bn.running_var)):
+            assert a.data_ptr() + 4 * a.numel() == b.data_ptr()
+    assert n_c3 == 10
+    # the bucket plan still separates the groups: detector buckets first, then the keypoint group
+    assert red.bucket_group == sorted(red.bucket_group, key=lambda g: g != "detector")
