@@ -413,6 +413,7 @@ def run_frame(dev, version, S, dtype, steps, warmup):
     from yolopoint_amd.models.model_wrap import PointTracker
     from yolopoint_amd.utils.synthetic import synth_image
     m, _ = build_model(version, dtype, dev)
+    m.model.use_graph = True          # the forward as one hipGraph replay (its independent head branches run side by side), as the headline record
     fe = YoloPointFrontend(m, dev, yolo_config=dict(conf_thres_box=0.25, iou_thres_box=0.45, max_det=300), filter_pts=True)
     frames = [synth_image(1, 3, S, S, 100 + i).to(dev) for i in range(4)]
     # Seeded random heads saturate (every pixel a keypoint, every anchor a box), which is not the load of a trained model: the

@@ -66,7 +66,7 @@ class HipModule(nn.Module):
     """Base class: standalone forward through a cached native plan."""
 
     compute_dtype = "f16"
-    _NATIVE_CACHES = ("_plans", "_train_graphs", "_pack_states")      # per-object native plans / graphs: never copied or pickled
+    _NATIVE_CACHES = ("_plans", "_train_graphs", "_pack_states", "_mods_cache")      # per-object native plans / graphs / caches: never copied or pickled
 
     def __deepcopy__(self, memo):
         import copy
@@ -84,7 +84,16 @@ class HipModule(nn.Module):
         """Changes whenever the parameters / buffers may have changed: tensor version counters and storage addresses, plus the
         process-wide optimizer-step count -- fused optimizers (torch.optim.Adam(fused=True)) update parameters WITHOUT bumping
         Tensor._version, so a key built on the counters alone keeps replaying plans packed from the old filters."""
-        return (weights_generation(),) + tuple((t._version, t.data_ptr()) for t in list(self.parameters()) + list(self.buffers()))
+        # (Module.parameters() / buffers() re-walk the module tree with de-duplication on every call: 1.5 ms per forward for YOLOPoint-l,
+        # as much host time as the forward takes on the device.  The module list is cached and re-walked only when the tree changed --
+        # detected by the child counts, which fuse() / add_module change -- or an explicit invalidation; the tensors are read from the
+        # modules' own dicts every time, so replaced parameters are seen.)
+        gen = weights_generation()
+        cache = self.__dict__.get("_mods_cache")
+        if cache is None or cache[0] != gen or cache[1] != sum(len(m._modules) for m in cache[2]):
+            mods = list(self.modules())
+            cache = self.__dict__["_mods_cache"] = (gen, sum(len(m._modules) for m in mods), mods)
+        return (gen,) + tuple((t._version, t.data_ptr()) for m in cache[2] for d in (m._parameters, m._buffers) for t in d.values() if t is not None)
 
     def _plan_key(self, x):
         return (tuple(x.shape), _hip.dtype_code(self.compute_dtype), self.training, self._weights_version(), x.device.index)
