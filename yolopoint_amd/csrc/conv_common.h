@@ -1,0 +1,211 @@
+// Pieces shared by the convolution translation units (conv_igemm.hip, conv_mma8.hip): element types, kernel arguments,
+// epilogue store helpers, the XCD-aware tile remap and the LDS-DMA issue helpers.
+#pragma once
+#include "yp_internal.h"
+#include <type_traits>
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+template <int DT> struct Elem;
+template <> struct Elem<YP_F16> {
+    using frag = f16x8;
+    using scalar = _Float16;
+    static constexpr int BYTES = 2, OBYTES = 2, KPL = 8, KM = 32;
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Elem<YP_BF16> {
+    using frag = bf16x8;
+    using scalar = __bf16;
+    static constexpr int BYTES = 2, OBYTES = 2, KPL = 8, KM = 32;
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+// 8-bit inputs (OCP fp8, one byte per element), bf16 results.  A 64-byte k tile row holds 64 elements; a lane's 16-byte fragment feeds
+// TWO 16x16x32 MFMAs (its low and its high 8 bytes): filter and activation fragments are cut the same way, so the k permutation inside
+// the tile cancels in the dot product and the DMA / LDS layout / swizzle of the 16-bit kernels carries over byte for byte.
+//   YP_FP8:     filter e4m3 x activation e4m3 (forward)        YP_FP8_BF8: filter e4m3 x activation e5m2 (dgrad: the activation is dy)
+template <> struct Elem<YP_FP8> {
+    using frag = u32x4;
+    using scalar = __bf16;
+    static constexpr int BYTES = 1, OBYTES = 2, KPL = 16, KM = 64;
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+        const long a0 = ((long)a[1] << 32) | a[0], a1 = ((long)a[3] << 32) | a[2], b0 = ((long)b[1] << 32) | b[0], b1 = ((long)b[3] << 32) | b[2];
+        c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a0, b0, c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a1, b1, c, 0, 0, 0);
+    }
+};
+template <> struct Elem<YP_FP8_BF8> {
+    using frag = u32x4;
+    using scalar = __bf16;
+    static constexpr int BYTES = 1, OBYTES = 2, KPL = 16, KM = 64;
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+        const long a0 = ((long)a[1] << 32) | a[0], a1 = ((long)a[3] << 32) | a[2], b0 = ((long)b[1] << 32) | b[0], b1 = ((long)b[3] << 32) | b[2];
+        c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(a0, b0, c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(a1, b1, c, 0, 0, 0);
+    }
+};
+template <> struct Elem<YP_F32> {
+    using frag = float;
+    using scalar = float;
+    static constexpr int BYTES = 4, OBYTES = 4, KPL = 1, KM = 4;
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+};
+
+#define YP_PIN2(T, name) T name = a.name; asm volatile("" : "+s"(name))
+
+
+struct ConvKArgs {
+    const char* in0;
+    const char* in1;
+    const char* wgt;
+    const float* bias;
+    const char* res;
+    char* out;
+    int in0_cs, in0_co, in0_C, in0_ups, in0_H, in0_W;
+    int in1_cs, in1_co, in1_ups, in1_H, in1_W;
+    int res_cs, res_co, has_res;
+    int out_cs, out_co;
+    char* out2; int out2_cs, out2_co, split;      // channels >= split go to out2 (split == Cout: unused)
+    int Hi, Wi, Wo, HoWo;
+    int Cin, Cout, Kreal, Kpad, Npad;
+    int R, S, RS, invS, dt, dc, sh, sw, ph, pw;
+    int dil_h, dil_w;              // filter dilation (wgrad-as-convolution of a strided conv)
+    int in0_zs;                    // in0 is a zero-stuffed view: logical (2H x 2W), odd rows/cols are zero (dgrad of stride 2)
+    int ksplit, atomic_out;        // split-K over blockIdx.y with fp32 atomicAdd epilogue
+    float* split_slabs;            // ... or (non-null) a plain fp32 store of slice y's partial tile to split_slabs + y * split_stride
+    long split_stride;
+    unsigned in0_zoff, in1_zoff, wgt_zrow;   // FAST path: byte offsets of the 16 zero bytes behind each input / the zero filter row
+    int act;
+    int M, tiles_n;
+    int tiles_x, tiles_y, Ho;      // 3x3 halo kernel: 8x16 output tiles
+    const char* pre_wgt;           // fused Bottleneck: 1x1 prologue filter / bias
+    const float* pre_bias;
+    int pre_Kpad, pre_act;
+    const char* post_wgt;          // fused C3 tail: 1x1 conv over cat(bottleneck output, in1) -> out
+    const float* post_bias;
+    int post_Kpad, post_Npad, post_act, post_N;
+    unsigned post_zrow;
+    // fused Detect decode (EPI_DETECT instantiations)
+    int det_na, det_no, det_invno, det_rows_total, det_row_off;
+    float det_stride;
+    float det_anchor[16];
+    float* det_x;
+    float* det_z;
+    float* stats;                  // STATS instantiations: per-64-pixel-row-block column sums [row block][2][Cout] (BatchNorm statistics)
+    const float* scale_in;         // 8-bit input types: the accumulators are multiplied by *scale_in * *scale_w (device scalars: the
+    const float* scale_w;          // dequantisation scales of the activation and of the filter) before the epilogue
+};
+
+// sigmoid as v_mul, v_exp_f32, v_add, v_rcp_f32 (rel. error ~1e-7); a plain 1/(1+expf(-x)) is ~25 instructions
+__device__ __forceinline__ float yp_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f)); }
+
+__device__ __forceinline__ float yp_silu(float x) {
+    // x * sigmoid(x) as v_mul, v_exp_f32, v_add, v_rcp_f32, v_mul (rel. error ~1e-7).  NOT __frcp_rn / a plain divide: those
+    // expand to the 12-instruction IEEE division sequence, and every output element of every convolution passes through here.
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
+
+// Epilogue tail shared by the convolution kernels: (+ residual) -> convert -> store CW consecutive
+// channels [nc, nc+CW) of output pixel m as 8/16-byte vectors, into `out` or (nc >= split) `out2`.
+template <int DT, bool OUT_F32, int CW>
+__device__ __forceinline__ void yp_store_chunk(const ConvKArgs& a, int m, int nc, float (&v)[CW]) {
+    using E = Elem<DT>;
+    constexpr int EB = E::OBYTES;        // (results and the residual they add are 16-bit for the 8-bit input types)
+    if (a.has_res) {
+        const char* rp = a.res + ((size_t)m * a.res_cs + a.res_co + nc) * EB;
+        if constexpr (DT == YP_F32) {
+#pragma unroll
+            for (int j = 0; j < CW; j += 4) {
+                const f32x4 r4 = *reinterpret_cast<const f32x4*>(rp + j * 4);
+                v[j] += r4[0]; v[j + 1] += r4[1]; v[j + 2] += r4[2]; v[j + 3] += r4[3];
+            }
+        } else {
+            using sc = typename E::scalar;
+            if constexpr (CW == 8) {
+                const u32x4 raw = *reinterpret_cast<const u32x4*>(rp);
+                const sc* e = reinterpret_cast<const sc*>(&raw);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
+            } else {
+                const u32x2 raw = *reinterpret_cast<const u32x2*>(rp);
+                const sc* e = reinterpret_cast<const sc*>(&raw);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += (float)e[j];
+            }
+        }
+    }
+    const bool second = nc >= a.split;
+    char* const obase = second ? a.out2 : a.out;
+    const size_t oidx = second ? (size_t)m * a.out2_cs + a.out2_co + (nc - a.split) : (size_t)m * a.out_cs + a.out_co + nc;
+    if constexpr (OUT_F32 || DT == YP_F32) {
+        char* op = obase + oidx * 4;
+#pragma unroll
+        for (int j = 0; j < CW; j += 4) *reinterpret_cast<f32x4*>(op + j * 4) = f32x4{v[j], v[j + 1], v[j + 2], v[j + 3]};
+    } else {
+        using sc = typename E::scalar;
+        char* op = obase + oidx * 2;
+        if constexpr (CW == 8) {
+            u32x4 pk;
+            sc* e = reinterpret_cast<sc*>(&pk);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = (sc)v[j];
+            *reinterpret_cast<u32x4*>(op) = pk;
+        } else {
+            u32x2 pk;
+            sc* e = reinterpret_cast<sc*>(&pk);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = (sc)v[j];
+            *reinterpret_cast<u32x2*>(op) = pk;
+        }
+    }
+}
+
+// bias -> activation -> yp_store_chunk for the LPG consecutive channels [nb, nb+LPG) a lane owns at pixel m;
+// acc(j) returns the accumulator of lane-local channel j.
+// Workgroup b runs on XCD b % 8 (round-robin dispatch) and every XCD has its own L2: give each XCD a contiguous run of
+// logical tile ids so that tiles which share input pixels / filter rows (neighbouring ids) hit the same L2.
+__device__ __forceinline__ int yp_xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// One LDS-DMA instruction: 64 lanes x 16 B -> 1 KiB at LDS byte address `lds_dst` (wave-uniform, in
+// an SGPR), lane l landing at lds_dst + 16*l.  Issued through inline asm so that the compiler's
+// LDS-DMA alias tracking does not put s_waitcnt vmcnt(0) in front of the fragment reads; the
+// pipeline below counts these loads itself (they are the only VMEM operations inside the k loop).
+__device__ __forceinline__ void yp_glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+// Same, with the source given as a wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset.
+__device__ __forceinline__ void yp_glds16_s(const void* sbase, unsigned voff, unsigned lds_dst) {
+    // (the scalar operands go through readfirstlane: a no-op where the compiler already holds them in SGPRs, and the guarantee the "s"
+    // constraints need where register pressure made it keep a uniform value in a VGPR -- "illegal VGPR to SGPR copy" otherwise)
+    const unsigned long long b = (unsigned long long)sbase;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    const void* sb = (const void*)(((unsigned long long)hi << 32) | lo);
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sb), "s"(dst)
+                 : "memory");
+}
+
+// 8-wave 32x32x16 kernels (conv_mma8.hip), tile ids 41..44
+bool yp_mma8_tile_dims(int tile, int* bp, int* bc, int* stat_rows_px);
+hipError_t yp_mma8_launch(int tile, int dtype, bool out_f32, bool stats, const ConvKArgs& a, int nblk, hipStream_t st);
