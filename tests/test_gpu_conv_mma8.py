@@ -12,7 +12,7 @@ from yolopoint_amd import _hip
 from yolopoint_amd.plan import PlanBuilder
 
 pytestmark = pytest.mark.gpu
-TILES = (41, 42, 43, 44)
+TILES = (41, 42, 43, 44, 57, 61)
 
 CASES = {
     "pointwise_256_256_ragged_m": dict(cin=256, cout=256, k=1, s=1, H=21, B=3),
@@ -89,7 +89,7 @@ def test_every_tile(cuda, name, dtype):
         assert err < bar, (name, tile, err)
 
 
-@pytest.mark.parametrize("tile", TILES)
+@pytest.mark.parametrize("tile", TILES + (51, 52, 53, 54))
 def test_matches_the_first_generation_kernel_on_a_deep_layer(cuda, tile):
     """3x3 256 -> 256 at 40x40, batch 4 (K = 2304: 36 k tiles, 9 taps x 4 tiles): against the 4-wave generic kernel (tile 3) on the same
     buffers -- both accumulate in fp32 over the same 16-bit operands, only the summation order differs."""
@@ -104,13 +104,13 @@ def test_matches_the_first_generation_kernel_on_a_deep_layer(cuda, tile):
         pb.autotune = False
         buf = pb.new_buf(Ho, Ho, C)
         buf.t.copy_(x.to(cuda))
-        out = pb.conv(buf.view(), w, b, 3, 1, 1, _hip.YP_ACT_NONE, out_f32=True, tile=tl)
+        out = pb.conv(buf.view(), w, b, 3, 1, 1, _hip.YP_ACT_NONE, out_f32=(tile < 50), tile=tl)
         plan = pb.finish()
         plan.run()
         torch.cuda.synchronize()
         outs.append(out.buf.t[..., :C].float().cpu())
     err = float((outs[0] - outs[1]).abs().max()) / float(outs[0].abs().max())
-    assert err < 2e-5, (tile, err)
+    assert err < (2e-5 if tile < 50 else 1e-3), (tile, err)          # (the schedule experiments 51.. only have the 16-bit store)
 
 
 @pytest.mark.parametrize("tile", TILES)
@@ -160,8 +160,8 @@ def test_batchnorm_statistics_epilogue(cuda, tile):
         plan.run()
         torch.cuda.synchronize()
         runs.append((part.cpu().clone(), out.buf.t[..., :Cout].float().cpu().reshape(-1, Cout)))
-        assert rows == (B * Ho * Ho + (128 if tile == 41 else 64) - 1) // (128 if tile == 41 else 64)
-        assert float(part[rows:].abs().max()) == 0.0
+        assert rows == (B * Ho * Ho + (128 if tile in (41, 57, 61) else 64) - 1) // (128 if tile in (41, 57, 61) else 64)
+        assert rows == part.shape[0] or float(part[rows:].abs().max()) == 0.0
     (p0, y0), (p1, _) = runs
     assert torch.equal(p0, p1)
     assert float((y0 - ref).abs().max()) / float(ref.abs().max()) < 1.6e-2

@@ -103,6 +103,7 @@ struct ConvKArgs {
     float* stats;                  // STATS instantiations: per-64-pixel-row-block column sums [row block][2][Cout] (BatchNorm statistics)
     const float* scale_in;         // 8-bit input types: the accumulators are multiplied by *scale_in * *scale_w (device scalars: the
     const float* scale_w;          // dequantisation scales of the activation and of the filter) before the epilogue
+    int probe;                     // -DYP_PROBE8 builds of conv_mma8.hip: elimination experiments (1 no MFMA, 2 no steady-state DMA, 4 L2-resident pixels)
 };
 
 // sigmoid as v_mul, v_exp_f32, v_add, v_rcp_f32 (rel. error ~1e-7); a plain 1/(1+expf(-x)) is ~25 instructions

@@ -17,8 +17,22 @@
 // on the DMA source side and by the readers.  Filter rows are permuted when fetched so that a lane's accumulators are 16 * CT consecutive
 // channels of one pixel (MFMA row 8j + 4h + i of channel tile ct = channel h*16*CT + ct*16 + 4j + i): 16-byte NHWC stores.
 #include "conv_common.h"
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#ifdef YP_PROBE8
+// probe build: waves 0 and 4 of workgroup 0 record the shader clock at the segment boundaries of k tile 6 (YP8_TS(i))
+__device__ unsigned long long yp8_timeline[8][32];
+extern "C" int yp_debug_mma8_timeline(unsigned long long* out_host) { return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(yp8_timeline), sizeof(unsigned long long) * 256); }
+#define YP8_TS_DECL unsigned long long yp8_ts[24]; _Pragma("unroll") for (int i_ = 0; i_ < 24; ++i_) yp8_ts[i_] = 0; const bool yp8_rec = blockIdx.x == 0
+#define YP8_TS(i) do { if (yp8_rec && kt == 6) { __builtin_amdgcn_sched_barrier(0); yp8_ts[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define YP8_TS_FLUSH() do { if (yp8_rec && lane == 0) { _Pragma("unroll") for (int i_ = 0; i_ < 24; ++i_) yp8_timeline[wave][i_] = yp8_ts[i_]; } } while (0)
+#else
+#define YP8_TS_DECL do {} while (0)
+#define YP8_TS(i) do {} while (0)
+#define YP8_TS_FLUSH() do {} while (0)
+#endif
 
 template <int DT> struct Mma32;
 template <> struct Mma32<YP_F16> {
@@ -30,15 +44,27 @@ template <> struct Mma32<YP_BF16> {
     static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 };
 
-template <int DT, bool OUT_F32, int BP, int BC, int WP, int WC, int NS, bool STATS>
+// SCHED: where the NL LDS-DMA instructions of the next k tile are issued and how many 16-deep MFMA steps form a phase
+//   0: phases of one step (8 MFMAs for the 256 x 256 tile), DMA in the load segments of phases 0..2
+//   1: phases of one step, DMA inside the MFMA segments of phases 0..2 (one instruction behind every other MFMA)
+//   2: phases of two steps (16 MFMAs), half of the DMA in the load segment of phase 0, half inside its MFMA segment
+//   3: phases of two steps, all DMA inside the MFMA segment of phase 0
+//   7: phases of two steps; every wave fetches pixel rows of its OWN group only: the 4 filter-row instructions go out in the load segment
+//      of phase 0, the 4 pixel-row instructions in the load segment of phase 1 (they are awaited behind that phase's MFMAs: only the
+//      issuing group reads them, one segment later than the filter rows are needed) -- no load segment is longer than an MFMA segment
+//   5: k tiles of 32 elements (64-byte rows, NS = 4 stages): ONE phase of two steps per tile, all DMA (of tile t+3) in its load segment
+template <int DT, bool OUT_F32, int BP, int BC, int WP, int WC, int NS, bool STATS, int SCHED = 0>
 __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
     using MM = Mma32<DT>;
     using frag_t = typename MM::frag;
-    constexpr int ROWB = 128, BK = 64, EB = 2;
+    constexpr int BK = SCHED == 5 ? 32 : 64, EB = 2, ROWB = BK * EB;
+    constexpr int RPI = 1024 / ROWB, CPR = ROWB / 16, KS = BK / 16;      // rows per DMA instruction, 16-byte chunks per row, MFMA steps per k tile
     constexpr int TP = BP / (2 * WP), TC = BC / WC, PT = TP / 32, CT = TC / 32;
-    constexpr int NLP = BP / 64, NLW = BC / 64, NL = NLP + NLW;           // DMA instructions per wave per k tile
+    constexpr int NLP = BP / (8 * RPI), NLW = BC / (8 * RPI), NL = NLP + NLW;           // DMA instructions per wave per k tile
     constexpr int STAGE = (BP + BC) * ROWB;
-    static_assert(WP * WC == 4 && PT >= 1 && CT >= 1 && BP % 64 == 0 && BC % 64 == 0 && NS >= 2 && NS <= 4, "unsupported tile");
+    constexpr int PH = (SCHED == 2 || SCHED == 3 || SCHED == 5 || SCHED == 7) ? 2 : 1, NPH = KS / PH;
+    constexpr bool OWNP = SCHED == 7;                                     // pixel-row DMA of a wave covers its own group's rows only                  // 16-deep MFMA steps per phase, phases per k tile
+    static_assert(WP * WC == 4 && PT >= 1 && CT >= 1 && BP % (8 * RPI) == 0 && BC % (8 * RPI) == 0 && NS >= 2 && NS <= 4, "unsupported tile");
     static_assert((NS - 1) * NL <= 60, "vmcnt immediate range");
 
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -52,9 +78,15 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int g = wave >> 2, wi = wave & 3, wp = wi % WP, wc = wi / WP;
 
+#ifdef YP_PROBE8
+    const int probe = __builtin_amdgcn_readfirstlane(a.probe);
+#else
+    constexpr int probe = 0;
+#endif
     // ---- DMA lane constants: an instruction covers rows 8j .. 8j+7 (j = wave + 8i: its parity is the wave's), lane -> row lane/8, chunk lane%8
-    const int lrow = lane >> 3;
-    const unsigned lanec = (unsigned)(((lane & 7) ^ (4 * (wave & 1) + (lane >> 4))) << 4);
+    // (64-byte rows: 16 rows x 4 chunks per instruction, chunk ^= (row >> 2) & 3 = lane >> 4)
+    const int lrow = lane / CPR;
+    const unsigned lanec = BK == 64 ? (unsigned)(((lane & 7) ^ (4 * (wave & 1) + (lane >> 4))) << 4) : (unsigned)(((lane & 3) ^ (lane >> 4)) << 4);
 
     YP_PIN2(const char*, in0); YP_PIN2(const char*, in1); YP_PIN2(const char*, wgt);
     YP_PIN2(int, in0_cs); YP_PIN2(int, in1_cs); YP_PIN2(int, in0_co); YP_PIN2(int, in1_co); YP_PIN2(int, in0_C);
@@ -65,7 +97,7 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
     int hi0[NLP], wi0[NLP], bb[NLP];
 #pragma unroll
     for (int i = 0; i < NLP; ++i) {
-        const int m = m0 + 8 * (wave + 8 * i) + lrow;
+        const int m = m0 + RPI * (OWNP ? g * (BP / (2 * RPI)) + wi + 4 * i : wave + 8 * i) + lrow;
         if (m < a.M) {
             const int b = m / a.HoWo;
             const int rem = m - b * a.HoWo;
@@ -80,10 +112,21 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
             bb[i] = 0;
         }
     }
+    // Pixel byte offsets of filter tap (0, 0) per source (+ the lane's chunk): for sources read at their own resolution a tap only adds the
+    // wave-uniform (kr * W + ks) * pixel pitch, so a segment change costs two adds, two compares and a select per row -- the full
+    // (b, y, x) -> offset arithmetic (integer multiplies; ~850 clocks per wave and filter tap when it sat in the k loop) runs once here.
+    // Upsampled / zero-stuffed sources keep the general formula (`slow`).
+    const bool slow = (in0_ups | in1_ups) != 0;
+    unsigned pb0[NLP], pb1[NLP];
+#pragma unroll
+    for (int i = 0; i < NLP; ++i) {
+        pb0[i] = (unsigned)((bb[i] * in0_H + hi0[i]) * in0_W + wi0[i]) * (unsigned)(in0_cs * EB) + lanec;
+        pb1[i] = (unsigned)((bb[i] * in1_H + hi0[i]) * in1_W + wi0[i]) * (unsigned)(in1_cs * EB) + lanec;
+    }
     unsigned w_off[NLW];
 #pragma unroll
     for (int i = 0; i < NLW; ++i) {
-        const int rl = 8 * (wave + 8 * i) + lrow;                // LDS filter row -> output channel (see the header comment)
+        const int rl = RPI * (wave + 8 * i) + lrow;              // LDS filter row -> output channel (see the header comment)
         const int wcx = rl / TC, q = rl % TC;
         const int ct = q >> 5, rho = q & 31;
         const int n = n0 + wcx * TC + ((rho >> 2) & 1) * (16 * CT) + ct * 16 + (rho >> 3) * 4 + (rho & 3);
@@ -115,12 +158,22 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
             seg_left = ((s0 ? in0_C : Cin - in0_C) - c_in_src) / BK;
             seg_base = base + (size_t)((s0 ? in0_co : in1_co) + c_in_src) * EB;
             const int csb = cs * EB;
+            if (!slow) {
+                const unsigned d = (unsigned)((kr * Wp + ks) * csb);
 #pragma unroll
-            for (int i = 0; i < NLP; ++i) {
-                const int hi = hi0[i] + kr, wi_ = wi0[i] + ks;
-                const bool ok = (unsigned)hi < (unsigned)Hi && (unsigned)wi_ < (unsigned)Wi && !(zs && ((hi | wi_) & 1));
-                const int pix = (bb[i] * Hp + (hi >> ups)) * Wp + (wi_ >> ups);
-                seg_voff[i] = ok ? (unsigned)(pix * csb) + lanec : zoff;     // (out-of-image rows read the zero tail behind the buffer)
+                for (int i = 0; i < NLP; ++i) {
+                    const int hi = hi0[i] + kr, wi_ = wi0[i] + ks;
+                    const bool ok = (unsigned)hi < (unsigned)Hi && (unsigned)wi_ < (unsigned)Wi;
+                    seg_voff[i] = ok ? (s0 ? pb0[i] : pb1[i]) + d : zoff;      // (out-of-image rows read the zero tail behind the buffer)
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NLP; ++i) {
+                    const int hi = hi0[i] + kr, wi_ = wi0[i] + ks;
+                    const bool ok = (unsigned)hi < (unsigned)Hi && (unsigned)wi_ < (unsigned)Wi && !(zs && ((hi | wi_) & 1));
+                    const int pix = (bb[i] * Hp + (hi >> ups)) * Wp + (wi_ >> ups);
+                    seg_voff[i] = ok ? (unsigned)(pix * csb) + lanec : zoff;
+                }
             }
         }
         cur_p = seg_base;
@@ -131,24 +184,23 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
         if (s_c0 >= Cin) { s_c0 -= Cin; ++s_tap; }
         ++kt_prep;
     };
-    // DMA instructions [lo, hi) of the prepared k tile -> ring stage `stage` (pixel rows first, then filter rows)
-    auto issue_range = [&](int stage, auto lo_c, auto hi_c) {
-        constexpr int lo = decltype(lo_c)::value, hi = decltype(hi_c)::value;
+    // DMA instruction idx of the prepared k tile -> ring stage `stage` (pixel rows first, then filter rows)
+    auto issue_one = [&](int stage, int idx) {
         const unsigned sbase = lds0 + (unsigned)stage * STAGE;
-#pragma unroll
-        for (int idx = lo; idx < hi; ++idx) {
-            if (idx < NLP) yp_glds16_s(cur_p, seg_voff[idx < NLP ? idx : 0], sbase + (unsigned)(wave + 8 * idx) * 1024u);
-            else yp_glds16_s(cur_w, w_off[idx >= NLP ? idx - NLP : 0], sbase + (unsigned)(BP * ROWB) + (unsigned)(wave + 8 * (idx - NLP)) * 1024u);
-        }
+        if (idx < NLP) yp_glds16_s(cur_p, seg_voff[idx < NLP ? idx : 0], sbase + (unsigned)(OWNP ? g * (BP / (2 * RPI)) + wi + 4 * idx : wave + 8 * idx) * 1024u);
+        else yp_glds16_s(cur_w, w_off[idx >= NLP ? idx - NLP : 0], sbase + (unsigned)(BP * ROWB) + (unsigned)(wave + 8 * (idx - NLP)) * 1024u);
     };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, (NL + 2) / 3>;
-    using I2 = std::integral_constant<int, (2 * NL + 2) / 3>;
-    using I3 = std::integral_constant<int, NL>;
+    // the instructions [dma_lo(slot), dma_lo(slot + 1)) go out in slot `slot` of a k tile (slots are phases; see SCHED)
+    auto dma_lo = [](int slot) -> int {
+        if (SCHED == 5) return slot <= 0 ? 0 : NL;
+        if (SCHED <= 1) return slot >= 3 ? NL : (slot * NL + 2) / 3;
+        if (SCHED == 2) return slot <= 0 ? 0 : (slot == 1 ? NL / 2 : NL);          // slot 0 = load segment of phase 0, 1 = its MFMA segment
+        return slot <= 0 ? 0 : NL;
+    };
 
     // ---- fragment read offsets: lane -> row lane%32, logical chunk 2p + lane/32 of phase p; physical chunk = logical ^ ((row >> 1) & 7)
     const int lr = lane & 31, hh = lane >> 5;
-    const int rd_lane = lr * ROWB + ((hh ^ ((lr >> 1) & 7)) << 4);
+    const int rd_lane = lr * ROWB + ((hh ^ (BK == 64 ? (lr >> 1) & 7 : (lr >> 2) & 3)) << 4);
     const char* const p_rd = smem + (g * (BP / 2) + wp * TP) * ROWB;
     const char* const w_rd = smem + (BP + wc * TC) * ROWB;
 
@@ -161,17 +213,74 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
             for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.f;
 
     const int nk = a.Kreal / BK;
+    YP8_TS_DECL;
 
     // ---- prologue: tiles 0 .. NS-2 in flight, tile NS-1 prepared
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s) {
-        if (s < nk) { prepare(); issue_range(s, I0{}, I3{}); }
+        if (s < nk) {
+            prepare();
+#pragma unroll
+            for (int idx = 0; idx < NL; ++idx) issue_one(s, idx);
+        }
     }
     if (NS - 1 < nk) prepare();
     // tile 0 has landed (up to NS-2 younger tiles stay in flight)
     if (nk >= NS - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * NL) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if constexpr (SCHED == 4) {
+        // ---- one barrier per k tile: every wave walks the four 16-deep steps of a tile on its own, fragments double-buffered in registers
+        // (the reads of step p+1 are in flight while the MFMAs of step p issue), two DMA instructions of the next tile per step between
+        // the MFMAs.  The two waves of a SIMD interleave freely; s_barrier costs ~170 clocks here, this loop pays it once per 32 MFMAs.
+        static_assert(NS == 2 && NL % 4 == 0, "SCHED 4: two stages, DMA instructions spread over the four steps");
+        int stage = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* const ps = p_rd + stage * STAGE;
+            const char* const ws = w_rd + stage * STAGE;
+            const int nstage = stage ^ 1;
+            const bool more = kt + 1 < nk;
+            frag_t wf[2][CT], pf[2][PT];
+            auto load = [&](int p, frag_t (&w_)[CT], frag_t (&p_)[PT]) {
+                const int off = rd_lane ^ (p << 5);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) w_[ct] = *reinterpret_cast<const frag_t*>(ws + ct * 32 * ROWB + off);
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) p_[pt] = *reinterpret_cast<const frag_t*>(ps + pt * 32 * ROWB + off);
+            };
+            YP8_TS(0);
+            load(0, wf[0], pf[0]);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                if (p < 3) load(p + 1, wf[(p + 1) & 1], pf[(p + 1) & 1]);
+                YP8_TS(1 + 2 * p);
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr int NM = CT * PT, DPS = NL / 4;                 // MFMAs / DMA instructions per step
+                constexpr int every = NM / DPS > 0 ? NM / DPS : 1;
+#pragma unroll
+                for (int i = 0; i < NM; ++i) {
+                    const int ct = i / PT, pt = i % PT;
+                    if (!(probe & 1)) acc[ct][pt] = MM::mma(wf[p & 1][ct], pf[p & 1][pt], acc[ct][pt]);
+                    if ((i + 1) % every == 0 && (i + 1) / every <= DPS) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (more && !(probe & 2)) issue_one(nstage, p * DPS + (i + 1) / every - 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                YP8_TS(2 + 2 * p);
+            }
+            if (kt + 2 < nk) prepare();
+            YP8_TS(9);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            YP8_TS(10);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            YP8_TS(11);
+            stage ^= 1;
+        }
+    } else {
     if (g == 1) __builtin_amdgcn_s_barrier();                     // group 1 runs one segment behind group 0
 
     int stage = 0;
@@ -180,22 +289,36 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
         const char* const ws = w_rd + stage * STAGE;
         int nstage = stage + NS - 1;
         if (nstage >= NS) nstage -= NS;
-        const bool more = kt + NS - 1 < nk;                       // tile kt+NS-1 exists: its DMA is issued during this tile's load segments
+        const bool more = kt + NS - 1 < nk;                       // tile kt+NS-1 exists: its DMA is issued during this tile
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < NPH; ++p) {
             // ---- load segment
-            frag_t wf[CT], pf[PT];
-            const int off = rd_lane ^ (p << 5);
+            YP8_TS(5 * p);
+            frag_t wf[PH][CT], pf[PH][PT];
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) wf[ct] = *reinterpret_cast<const frag_t*>(ws + ct * 32 * ROWB + off);
+            for (int kk = 0; kk < PH; ++kk) {
+                const int off = rd_lane ^ ((p * PH + kk) << 5);
 #pragma unroll
-            for (int pt = 0; pt < PT; ++pt) pf[pt] = *reinterpret_cast<const frag_t*>(ps + pt * 32 * ROWB + off);
-            if (more) {
-                if (p == 0) issue_range(nstage, I0{}, I1{});
-                if (p == 1) issue_range(nstage, I1{}, I2{});
-                if (p == 2) issue_range(nstage, I2{}, I3{});
+                for (int ct = 0; ct < CT; ++ct) wf[kk][ct] = *reinterpret_cast<const frag_t*>(ws + ct * 32 * ROWB + off);
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) pf[kk][pt] = *reinterpret_cast<const frag_t*>(ps + pt * 32 * ROWB + off);
             }
-            if (p == 3) {
+            if (SCHED == 7 && more && !(probe & 2)) {
+#pragma unroll
+                for (int idx = 0; idx < NL; ++idx)
+                    if (p == 0 ? idx >= NLP : idx < NLP) issue_one(nstage, idx);
+            }
+            if (more && !(probe & 2) && (SCHED == 0 || SCHED == 5 || (SCHED == 2 && p == 0))) {
+#pragma unroll
+                for (int idx = 0; idx < NL; ++idx)
+                    if (idx >= dma_lo(p) && idx < dma_lo(p + 1)) issue_one(nstage, idx);
+            }
+            YP8_TS(5 * p + 1);
+            if (SCHED == 7 && p == NPH - 1) {
+                if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLP) : "memory");       // the filter rows of tile kt+1 (older than this segment's pixel rows)
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if (SCHED != 7 && p == NPH - 1) {
                 // tile kt+1 must have landed before its first read (next load segment, after the barrier below publishes it)
                 int younger = nk - kt - 2;
                 if (younger > NS - 2) younger = NS - 2;
@@ -203,18 +326,39 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
                 else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS > 2 ? NL : 0) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS > 3 ? 2 * NL : 0) : "memory");
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // (the reads of a tile's LAST phase retire before the barrier: behind it the other group's DMA may refill this stage;
+            // in the other phases the LDS latency overlaps the barrier wait)
+            if (p == NPH - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            YP8_TS(5 * p + 2);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
+            YP8_TS(5 * p + 3);
             // ---- MFMA segment
-            __builtin_amdgcn_s_setprio(1);
+            if (!(probe & 16)) __builtin_amdgcn_s_setprio(1);
+            constexpr int NM = PH * CT * PT;
+            // DMA instructions issued from inside this segment: [mlo, mhi), one behind every `every`-th MFMA
+            const int mlo = SCHED == 1 ? dma_lo(p) : (SCHED == 2 && p == 0 ? dma_lo(1) : (SCHED == 3 && p == 0 ? 0 : NL));
+            const int mhi = SCHED == 1 ? dma_lo(p + 1) : NL;
+            const int every = (mhi - mlo) > 0 ? (NM / (mhi - mlo) > 0 ? NM / (mhi - mlo) : 1) : NM + 1;
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = MM::mma(wf[ct], pf[pt], acc[ct][pt]);
+            for (int i = 0; i < NM; ++i) {
+                const int kk = i / (CT * PT), ct = (i / PT) % CT, pt = i % PT;
+                if (!(probe & 1)) acc[ct][pt] = MM::mma(wf[kk][ct], pf[kk][pt], acc[ct][pt]);
+                if (SCHED != 0 && SCHED != 5 && (i + 1) % every == 0) {
+                    const int di = mlo + (i + 1) / every - 1;
+                    if (di < mhi) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (more && !(probe & 2)) issue_one(nstage, di);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
             __builtin_amdgcn_s_setprio(0);
-            if (p == 3 && kt + NS < nk) prepare();                 // (address arithmetic of the next tile to issue: VALU beside the MFMAs)
+            YP8_TS(5 * p + 4);
+            if (SCHED == 7 && p == NPH - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // own group's pixel rows of tile kt+1
+            if (p == NPH - 1 && kt + NS < nk && !(probe & 8)) prepare();           // (address arithmetic of the next tile to issue: VALU beside the MFMAs)
+            if (p == NPH - 1) YP8_TS(20);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -222,7 +366,9 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
         stage = stage + 1 == NS ? 0 : stage + 1;
     }
     if (g == 0) __builtin_amdgcn_s_barrier();                     // (group 0 waits out group 1's last segment: equal barrier counts)
+    }
 
+    YP8_TS_FLUSH();
     // ---- epilogue: lane = pixel lr of each pixel tile, 16 * CT consecutive channels starting at nb
     const int nb = n0 + wc * TC + hh * (16 * CT);
     if constexpr (STATS) {
@@ -301,11 +447,11 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
 
 namespace {
 
-template <int DT, bool OUT_F32, int BP, int BC, int WP, int WC, int NS, bool STATS>
+template <int DT, bool OUT_F32, int BP, int BC, int WP, int WC, int NS, bool STATS, int SCHED = 0>
 hipError_t launch_mma8(const ConvKArgs& a, int nblk, hipStream_t st) {
-    constexpr size_t lds = (size_t)NS * (BP + BC) * 128;
+    constexpr size_t lds = (size_t)NS * (BP + BC) * (SCHED == 5 ? 64 : 128);
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = conv_mma8_kernel<DT, OUT_F32, BP, BC, WP, WC, NS, STATS>;
+    auto kern = conv_mma8_kernel<DT, OUT_F32, BP, BC, WP, WC, NS, STATS, SCHED>;
     static bool attr_set = false;        // per instantiation
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -323,6 +469,12 @@ hipError_t dispatch_mma8(int tile, const ConvKArgs& a, int nblk, hipStream_t st)
         case 42: return launch_mma8<DT, OUT_F32, 256, 128, 2, 2, 3, STATS>(a, nblk, st);
         case 43: return launch_mma8<DT, OUT_F32, 128, 256, 1, 4, 3, STATS>(a, nblk, st);
         case 44: return launch_mma8<DT, OUT_F32, 128, 128, 1, 4, 2, STATS>(a, nblk, st);
+        case 51: if constexpr (!STATS && !OUT_F32) return launch_mma8<DT, OUT_F32, 256, 256, 1, 4, 2, STATS, 1>(a, nblk, st); else return hipErrorInvalidValue;
+        case 52: if constexpr (!STATS && !OUT_F32) return launch_mma8<DT, OUT_F32, 256, 256, 1, 4, 2, STATS, 2>(a, nblk, st); else return hipErrorInvalidValue;
+        case 53: if constexpr (!STATS && !OUT_F32) return launch_mma8<DT, OUT_F32, 256, 256, 1, 4, 2, STATS, 3>(a, nblk, st); else return hipErrorInvalidValue;
+        case 57: return launch_mma8<DT, OUT_F32, 256, 256, 1, 4, 2, STATS, 7>(a, nblk, st);
+        case 61: return launch_mma8<DT, OUT_F32, 256, 256, 1, 4, 4, STATS, 5>(a, nblk, st);
+        case 54: if constexpr (!STATS && !OUT_F32) return launch_mma8<DT, OUT_F32, 256, 256, 1, 4, 2, STATS, 4>(a, nblk, st); else return hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }
 }
@@ -332,7 +484,7 @@ hipError_t dispatch_mma8(int tile, const ConvKArgs& a, int nblk, hipStream_t st)
 bool yp_mma8_tile_dims(int tile, int* bp, int* bc, int* stat_rows_px) {
     int p = 0, c = 0, r = 0;
     switch (tile) {
-        case 41: p = 256; c = 256; r = 128; break;
+        case 41: case 51: case 52: case 53: case 54: case 57: case 61: p = 256; c = 256; r = 128; break;
         case 42: p = 256; c = 128; r = 64; break;
         case 43: p = 128; c = 256; r = 64; break;
         case 44: p = 128; c = 128; r = 64; break;
@@ -344,7 +496,11 @@ bool yp_mma8_tile_dims(int tile, int* bp, int* bc, int* stat_rows_px) {
     return true;
 }
 
-hipError_t yp_mma8_launch(int tile, int dtype, bool out_f32, bool stats, const ConvKArgs& a, int nblk, hipStream_t st) {
+hipError_t yp_mma8_launch(int tile, int dtype, bool out_f32, bool stats, const ConvKArgs& a0, int nblk, hipStream_t st) {
+    ConvKArgs a = a0;
+#ifdef YP_PROBE8
+    { const char* e = getenv("YP_MMA8_PROBE"); a.probe = e ? atoi(e) : 0; }
+#endif
     if (dtype == YP_F16) {
         if (stats) return dispatch_mma8<YP_F16, false, true>(tile, a, nblk, st);
         return out_f32 ? dispatch_mma8<YP_F16, true, false>(tile, a, nblk, st) : dispatch_mma8<YP_F16, false, false>(tile, a, nblk, st);

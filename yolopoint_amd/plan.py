@@ -182,7 +182,11 @@ _TUNE_CACHE = {}
 # reachable by explicit id only; 10..12 the 3x3 halo kernel
 # with 32/64/128 output channels per workgroup on 8x16 pixel tiles, 13..15 the same on 4x16 tiles (rejected by the library
 # when it does not apply)
-_TUNE_CANDIDATES = (1, 2, 3, 4, 5, 21, 22, 23, 24, 25, 26, 27, 10, 11, 12, 13, 14, 15)
+# 41..44 / 57: the 8-wave 32x32x16 kernels of csrc/conv_mma8.hip (256x256 / 256x128 / 128x256 / 128x128 tiles; 57 = 256x256 with two-step
+# phases), for 16-bit layers whose channel counts are multiples of 64
+_TUNE_CANDIDATES = (1, 2, 3, 4, 5, 21, 22, 23, 24, 25, 26, 27, 10, 11, 12, 13, 14, 15, 41, 42, 43, 44, 57)
+# pixels per BatchNorm-statistics row of the variants whose rows are plain pixel blocks (the 3x3 halo kernels write one row per image tile)
+_STAT_ROW_PX = {41: 128, 57: 128, 61: 128}
 if os.environ.get("YP_TUNE_ONLY"):           # A/B experiments: restrict the autotuner to a subset of the variants
     _TUNE_CANDIDATES = tuple(int(v) for v in os.environ["YP_TUNE_ONLY"].split(","))
 
@@ -454,7 +458,7 @@ class PlanBuilder:
         if tile == 0 and self.autotune and d.ksplit == 1 and not d.atomic_accumulate:
             d.tile, tuned_ms = self._autotune(d, det, (conv_dtype, d.B, Hi, Wi, tuple((v.C, v.ups) for v in srcs), Cout_pad, R, S, sh, sw, dil, zs,
                                                        int(out_f32), res is not None, c2, act, detect is not None, pre is not None, post is not None,
-                                                       bn_partial is not None))
+                                                       bn_partial is not None, extra.get("stat_group_px")), stat_group_px=extra.get("stat_group_px"))
         if bn_partial is not None:                  # how many partial rows the chosen kernel variant writes (they are batch-major)
             rows = C.c_int(0)
             check(lib().yp_conv_bn_partial_rows(C.byref(d), C.byref(rows)))
@@ -535,7 +539,7 @@ class PlanBuilder:
         for fn in self.refreshers:
             fn()
 
-    def _autotune(self, d, det, key):
+    def _autotune(self, d, det, key, stat_group_px=None):
         """Pick the fastest kernel variant for this convolution by timing each candidate on the plan's own buffers
         (HIP events on the current stream).  Every variant computes the same convolution; the choice is cached per
         signature so that equal layers always run the same kernel within a process."""
@@ -550,6 +554,8 @@ class PlanBuilder:
         for cand in _TUNE_CANDIDATES:
             if det is not None and 10 <= cand <= 15:
                 continue
+            if stat_group_px and d.bn_partial and stat_group_px % _STAT_ROW_PX.get(cand, 64 if cand < 10 or cand > 15 else 1):
+                continue                              # a statistics row of this variant would straddle two BatchNorm statistics groups
             d.tile = cand
             if run() != 0:
                 continue                              # variant does not apply to this convolution

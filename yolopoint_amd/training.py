@@ -232,7 +232,7 @@ class TrainGraph:
             rows = max(-(-(B * Ho_ * Wo_) // 64), B * -(-Ho_ // 4) * -(-Wo_ // 16) if k == 3 else 0)
             partial = torch.zeros((rows, 2, round_up(conv.out_channels, 8)), dtype=torch.float32, device=self.device)
         q8 = self.fp8 and not image and self.q8_ok(srcs) and os.environ.get("YP_FP8_FWD", "1") != "0"
-        conv_srcs, extra = srcs, (dict(bn_partial=partial) if fuse_stats else {})
+        conv_srcs, extra = srcs, (dict(bn_partial=partial, stat_group_px=(self.Bs * Ho_ * Wo_ if G > 1 else None)) if fuse_stats else {})
         if q8:
             conv_srcs, slot = self.q8_sources(f, srcs, 0)
             wsrc = MasterWeight(conv.weight, q8=True)
