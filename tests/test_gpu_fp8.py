@@ -81,9 +81,31 @@ CONVS = {
 @pytest.mark.parametrize("name", list(CONVS))
 def test_fp8_convolution_matches_torch_on_the_same_bytes(cuda, name, tile, act_fmt):
     c = CONVS[name]
-    cins, cout, k, s, Ho, B = c["cin"], c["cout"], c["k"], c["s"], c["H"], c["B"]
+    cout, k = c["cout"], c["k"]
     if tile >= 10 and (k != 3 or (tile - 10) % 3 == 2 and cout < 128 or (tile - 10) % 3 == 1 and cout < 64):
         pytest.skip("halo tiles: 3x3 convolutions, tile width <= output channels")
+    _check_fp8_conv(cuda, name, c, tile, act_fmt)
+
+
+# The 8-wave kernel's 8-bit instantiation (csrc/conv_mma8.hip, tile 57): block-scaled K = 64 MFMAs (v_mfma_scale_f32_32x32x64_f8f6f4, unit
+# block scales) -- the fp8 forms that issue at TWICE the 16-bit rate; every source a multiple of 128 channels (one 128-byte k row).
+CONVS_MX = {
+    "pointwise_256_256_ragged_m": dict(cin=(256,), cout=256, k=1, s=1, H=21, B=3),
+    "pointwise_k128_single_tile": dict(cin=(128,), cout=136, k=1, s=1, H=12, B=2),
+    "pointwise_two_sources_upsampled": dict(cin=(128, 128), ups0=True, cout=192, k=1, s=1, H=16, B=2),
+    "conv3x3_residual": dict(cin=(128,), cout=128, k=3, s=1, H=20, B=2, res=True),
+    "conv3x3_stride2_deep": dict(cin=(256,), cout=512, k=3, s=2, H=10, B=3),
+}
+
+
+@pytest.mark.parametrize("act_fmt", [0, 1])
+@pytest.mark.parametrize("name", list(CONVS_MX))
+def test_fp8_mx_kernel_matches_torch_on_the_same_bytes(cuda, name, act_fmt):
+    _check_fp8_conv(cuda, name, CONVS_MX[name], 57, act_fmt)
+
+
+def _check_fp8_conv(cuda, name, c, tile, act_fmt):
+    cins, cout, k, s, Ho, B = c["cin"], c["cout"], c["k"], c["s"], c["H"], c["B"]
     Hi = Ho * s
     ups0 = c.get("ups0", False)
     torch.manual_seed(len(name) + tile)

@@ -1658,9 +1658,10 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
     {   // 8-wave 32x32x16 kernels (conv_mma8.hip), tile ids 41..44: the compute-bound 16-bit layers (every source a multiple of 64 channels)
         int bp8 = 0, bc8 = 0, srows = 0;
         if (yp_mma8_tile_dims(d->tile, &bp8, &bc8, &srows)) {
-            YP_REQUIRE(fast && (d->dtype == YP_F16 || d->dtype == YP_BF16) && Cin % 64 == 0 && d->in0.C % 64 == 0 && d->Kpad % 64 == 0 && det == nullptr &&
+            const int cg = q8 ? 128 : 64;        // channels per 128-byte k row; the 8-bit (block-scaled MFMA) instantiation exists for tile 57 only
+            YP_REQUIRE(fast && d->dtype != YP_F32 && (!q8 || d->tile == 57) && Cin % cg == 0 && d->in0.C % cg == 0 && d->Kpad % cg == 0 && det == nullptr &&
                        d->pre_weight == nullptr && ksplit == 1 && !a.atomic_out,
-                       "yp_conv2d: tile %d (8-wave kernel) needs a 16-bit fast-path convolution with channel counts %% 64 == 0 (Cin %d, in0.C %d)", d->tile, Cin, d->in0.C);
+                       "yp_conv2d: tile %d (8-wave kernel) needs a 16-bit (8-bit: tile 57) fast-path convolution with channel counts %% %d == 0 (Cin %d, in0.C %d)", d->tile, cg, Cin, d->in0.C);
             a.tiles_n = yp_cdiv(Cout, bc8);
             const int nblk8 = yp_cdiv(a.M, bp8) * a.tiles_n;
             const bool stats = d->bn_partial != nullptr;

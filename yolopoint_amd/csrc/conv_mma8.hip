@@ -43,6 +43,24 @@ template <> struct Mma32<YP_BF16> {
     using frag = bf16x8;
     static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 };
+// 8-bit inputs (OCP fp8) at the fp8 rate: the block-scaled K = 64 form v_mfma_scale_f32_32x32x64_f8f6f4 (the only fp8 MFMA that issues at
+// twice the 16-bit rate; the non-scaled 32x32x16 / 16x16x32 fp8 forms run at the bf16 rate) with UNIT block scales (E8M0 127 = 2^0): the
+// per-tensor dequantisation scales multiply the accumulators in the epilogue, exactly as in the 4-wave kernel.  A fragment is 32 bytes per
+// lane (two 16-byte LDS reads); filter and activation fragments are cut the same way, so the k order inside a step cancels.
+//   YP_FP8: filter e4m3 x activation e4m3 (forward)      YP_FP8_BF8: filter e4m3 x activation e5m2 (dgrad: the activation is dy)
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+template <> struct Mma32<YP_FP8> {
+    using frag = i32x8;
+    static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    }
+};
+template <> struct Mma32<YP_FP8_BF8> {
+    using frag = i32x8;
+    static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 1, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    }
+};
 
 // SCHED: where the NL LDS-DMA instructions of the next k tile are issued and how many 16-deep MFMA steps form a phase
 //   0: phases of one step (8 MFMAs for the 256 x 256 tile), DMA in the load segments of phases 0..2
@@ -57,12 +75,15 @@ template <int DT, bool OUT_F32, int BP, int BC, int WP, int WC, int NS, bool STA
 __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
     using MM = Mma32<DT>;
     using frag_t = typename MM::frag;
-    constexpr int BK = SCHED == 5 ? 32 : 64, EB = 2, ROWB = BK * EB;
-    constexpr int RPI = 1024 / ROWB, CPR = ROWB / 16, KS = BK / 16;      // rows per DMA instruction, 16-byte chunks per row, MFMA steps per k tile
+    constexpr int EB = Elem<DT>::BYTES;                                   // 2, or 1 (OCP fp8: a 128-byte row holds 128 k elements = two K = 64 MFMA steps)
+    constexpr bool Q8 = EB == 1;
+    constexpr int ROWB = SCHED == 5 ? 64 : 128, BK = ROWB / EB;
+    constexpr int RPI = 1024 / ROWB, CPR = ROWB / 16, KS = ROWB / (Q8 ? 64 : 32);      // rows per DMA instruction, 16-byte chunks per row, MFMA steps per k tile
+    static_assert(!Q8 || SCHED == 7, "8-bit inputs: the two-phase schedule");
     constexpr int TP = BP / (2 * WP), TC = BC / WC, PT = TP / 32, CT = TC / 32;
     constexpr int NLP = BP / (8 * RPI), NLW = BC / (8 * RPI), NL = NLP + NLW;           // DMA instructions per wave per k tile
     constexpr int STAGE = (BP + BC) * ROWB;
-    constexpr int PH = (SCHED == 2 || SCHED == 3 || SCHED == 5 || SCHED == 7) ? 2 : 1, NPH = KS / PH;
+    constexpr int PH = (SCHED == 7) ? KS / 2 : ((SCHED == 2 || SCHED == 3 || SCHED == 5) ? 2 : 1), NPH = KS / PH;
     constexpr bool OWNP = SCHED == 7;                                     // pixel-row DMA of a wave covers its own group's rows only                  // 16-deep MFMA steps per phase, phases per k tile
     static_assert(WP * WC == 4 && PT >= 1 && CT >= 1 && BP % (8 * RPI) == 0 && BC % (8 * RPI) == 0 && NS >= 2 && NS <= 4, "unsupported tile");
     static_assert((NS - 1) * NL <= 60, "vmcnt immediate range");
@@ -86,7 +107,7 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
     // ---- DMA lane constants: an instruction covers rows 8j .. 8j+7 (j = wave + 8i: its parity is the wave's), lane -> row lane/8, chunk lane%8
     // (64-byte rows: 16 rows x 4 chunks per instruction, chunk ^= (row >> 2) & 3 = lane >> 4)
     const int lrow = lane / CPR;
-    const unsigned lanec = BK == 64 ? (unsigned)(((lane & 7) ^ (4 * (wave & 1) + (lane >> 4))) << 4) : (unsigned)(((lane & 3) ^ (lane >> 4)) << 4);
+    const unsigned lanec = ROWB == 128 ? (unsigned)(((lane & 7) ^ (4 * (wave & 1) + (lane >> 4))) << 4) : (unsigned)(((lane & 3) ^ (lane >> 4)) << 4);
 
     YP_PIN2(const char*, in0); YP_PIN2(const char*, in1); YP_PIN2(const char*, wgt);
     YP_PIN2(int, in0_cs); YP_PIN2(int, in1_cs); YP_PIN2(int, in0_co); YP_PIN2(int, in1_co); YP_PIN2(int, in0_C);
@@ -200,7 +221,19 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
 
     // ---- fragment read offsets: lane -> row lane%32, logical chunk 2p + lane/32 of phase p; physical chunk = logical ^ ((row >> 1) & 7)
     const int lr = lane & 31, hh = lane >> 5;
-    const int rd_lane = lr * ROWB + ((hh ^ (BK == 64 ? (lr >> 1) & 7 : (lr >> 2) & 3)) << 4);
+    // (8-bit: step ks reads chunks 4ks + 2hh + {0, 1}; 16-bit: step p reads chunk 2p + hh)
+    const int rd_lane = lr * ROWB + (((Q8 ? 2 * hh : hh) ^ (ROWB == 128 ? (lr >> 1) & 7 : (lr >> 2) & 3)) << 4);
+    auto ld_frag = [&](const char* base, int step) -> frag_t {
+        if constexpr (Q8) {
+            const int off = rd_lane ^ (step << 6);
+            frag_t f;
+            reinterpret_cast<u32x4*>(&f)[0] = *reinterpret_cast<const u32x4*>(base + off);
+            reinterpret_cast<u32x4*>(&f)[1] = *reinterpret_cast<const u32x4*>(base + (off ^ 16));
+            return f;
+        } else {
+            return *reinterpret_cast<const frag_t*>(base + (rd_lane ^ (step << 5)));
+        }
+    };
     const char* const p_rd = smem + (g * (BP / 2) + wp * TP) * ROWB;
     const char* const w_rd = smem + (BP + wc * TC) * ROWB;
 
@@ -242,11 +275,10 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
             const bool more = kt + 1 < nk;
             frag_t wf[2][CT], pf[2][PT];
             auto load = [&](int p, frag_t (&w_)[CT], frag_t (&p_)[PT]) {
-                const int off = rd_lane ^ (p << 5);
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) w_[ct] = *reinterpret_cast<const frag_t*>(ws + ct * 32 * ROWB + off);
+                for (int ct = 0; ct < CT; ++ct) w_[ct] = ld_frag(ws + ct * 32 * ROWB, p);
 #pragma unroll
-                for (int pt = 0; pt < PT; ++pt) p_[pt] = *reinterpret_cast<const frag_t*>(ps + pt * 32 * ROWB + off);
+                for (int pt = 0; pt < PT; ++pt) p_[pt] = ld_frag(ps + pt * 32 * ROWB, p);
             };
             YP8_TS(0);
             load(0, wf[0], pf[0]);
@@ -297,11 +329,10 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
             frag_t wf[PH][CT], pf[PH][PT];
 #pragma unroll
             for (int kk = 0; kk < PH; ++kk) {
-                const int off = rd_lane ^ ((p * PH + kk) << 5);
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) wf[kk][ct] = *reinterpret_cast<const frag_t*>(ws + ct * 32 * ROWB + off);
+                for (int ct = 0; ct < CT; ++ct) wf[kk][ct] = ld_frag(ws + ct * 32 * ROWB, p * PH + kk);
 #pragma unroll
-                for (int pt = 0; pt < PT; ++pt) pf[kk][pt] = *reinterpret_cast<const frag_t*>(ps + pt * 32 * ROWB + off);
+                for (int pt = 0; pt < PT; ++pt) pf[kk][pt] = ld_frag(ps + pt * 32 * ROWB, p * PH + kk);
             }
             if (SCHED == 7 && more && !(probe & 2)) {
 #pragma unroll
@@ -341,6 +372,16 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
             const int mlo = SCHED == 1 ? dma_lo(p) : (SCHED == 2 && p == 0 ? dma_lo(1) : (SCHED == 3 && p == 0 ? 0 : NL));
             const int mhi = SCHED == 1 ? dma_lo(p + 1) : NL;
             const int every = (mhi - mlo) > 0 ? (NM / (mhi - mlo) > 0 ? NM / (mhi - mlo) : 1) : NM + 1;
+            // (MFMAs have no side effects: nothing but data dependences keeps them between the two barriers.  The fragments pass through an
+            // empty asm behind barrier a and the accumulators through one in front of barrier b -- without them the 8-bit instantiation
+            // had BOTH phases' MFMAs sunk behind the second phase's loads: all fragments live at once, spilled)
+#pragma unroll
+            for (int kk = 0; kk < PH; ++kk) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) asm volatile("" : "+v"(wf[kk][ct]));
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) asm volatile("" : "+v"(pf[kk][pt]));
+            }
 #pragma unroll
             for (int i = 0; i < NM; ++i) {
                 const int kk = i / (CT * PT), ct = (i / PT) % CT, pt = i % PT;
@@ -354,6 +395,10 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
                     }
                 }
             }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) asm volatile("" : "+v"(acc[ct][pt]));
             __builtin_amdgcn_s_setprio(0);
             YP8_TS(5 * p + 4);
             if (SCHED == 7 && p == NPH - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // own group's pixel rows of tile kt+1
@@ -369,6 +414,13 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
     }
 
     YP8_TS_FLUSH();
+    if constexpr (Q8) {                       // back to real units: the dequantisation scales of the activation and of the filter
+        const float osc = a.scale_in[0] * a.scale_w[0];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) acc[ct][pt] *= osc;
+    }
     // ---- epilogue: lane = pixel lr of each pixel tile, 16 * CT consecutive channels starting at nb
     const int nb = n0 + wc * TC + hh * (16 * CT);
     if constexpr (STATS) {
@@ -508,6 +560,10 @@ hipError_t yp_mma8_launch(int tile, int dtype, bool out_f32, bool stats, const C
     if (dtype == YP_BF16) {
         if (stats) return dispatch_mma8<YP_BF16, false, true>(tile, a, nblk, st);
         return out_f32 ? dispatch_mma8<YP_BF16, true, false>(tile, a, nblk, st) : dispatch_mma8<YP_BF16, false, false>(tile, a, nblk, st);
+    }
+    if ((dtype == YP_FP8 || dtype == YP_FP8_BF8) && tile == 57 && !out_f32) {        // 8-bit inputs: the 256 x 256 two-phase kernel only
+        if (dtype == YP_FP8) return stats ? launch_mma8<YP_FP8, false, 256, 256, 1, 4, 2, true, 7>(a, nblk, st) : launch_mma8<YP_FP8, false, 256, 256, 1, 4, 2, false, 7>(a, nblk, st);
+        if (!stats) return launch_mma8<YP_FP8_BF8, false, 256, 256, 1, 4, 2, false, 7>(a, nblk, st);
     }
     return hipErrorInvalidValue;
 }
