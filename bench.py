@@ -26,6 +26,10 @@ Sub-records of the same line (each measured in this process, after the top-level
                 same step in bf16
   frame         (N = 1) BASELINE configs[3]: YOLOPoint-l, one 1280x1280 frame end to end (forward + keypoint decode / NMS + box NMS on 100 800
                 rows + box-mask filter + descriptor sampling + MNN matching against the previous frame)
+  v52           (N = 1) the model the reference's shipped inference config selects (configs/kitti_inference.yaml:2): YOLOPointv52-s, batch 8,
+                640x640, f16, hipGraph replay, with its own `parity` against the oracle at that shape
+`cpu_baseline` objects: top level (oracle forward), `train.cpu_baseline` (oracle forward + autograd backward + torch.optim.Adam of one image
+pair, fp32), `frame.cpu_baseline` (oracle forward of one 1280x1280 frame + the oracle's sequential post-processing on the same planted heads).
 `--only infer|train|frame` restricts the run; `--mode train|frame|export` prints that workload as the top-level record (round-1 CLI).
 """
 import argparse
@@ -39,7 +43,7 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-PEAK_TFLOPS = {"f16": 2500.0, "bf16": 2500.0, "f32": 157.3}     # MI355X_MICROARCH.md dense MFMA peaks
+PEAK_TFLOPS = {"f16": 2500.0, "bf16": 2500.0, "f32": 157.3, "fp8": 5000.0}     # MI355X_MICROARCH.md dense MFMA peaks (fp8: the block-scaled K = 64 / 128 forms)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -109,6 +113,8 @@ def cpu_baseline(version, B, S, budget_s=14.0, gpu_outs=None):
             times.append(time.perf_counter() - t0)
     med = sorted(times)[len(times) // 2]
     base = {"value": round(Bc / med, 2), "unit": "images/s", "cores": best_n, "kind": "port",
+            "threads_note": f"{best_n} threads = the fastest of 16 / 32 / 64 on this {cores}-thread host (SURVEY 8d says os.cpu_count(): oversubscribing ATen's small "
+                            f"convolutions is slower, so the probe favours the CPU)",
             "sample": f"oracle (PyTorch-CPU fp32, eval) forward of YOLOPoint-{version} batch {Bc} {S}x{S}: {best_n} threads "
                       f"(best of 16/32/64 on a {cores}-thread host), 3 warm-ups + {len(times)} timed iterations, median"}
     parity = None
@@ -122,7 +128,19 @@ def cpu_baseline(version, B, S, budget_s=14.0, gpu_outs=None):
         parity["pred_rel_l2"] = round(rel(gpu_outs["pred"], ref["objects"][0])[1], 6)
         parity["raw_levels_rel_l2"] = [round(rel(a, b)[1], 6) for a, b in zip(gpu_outs["xs"], ref["objects"][1])]
         parity["keypoint_cell_argmax_agreement"] = round(float((gpu_outs["semi"].argmax(1).cpu() == ref["semi"].argmax(1)).float().mean()), 6)
-        parity["bars"] = "tests/test_gpu_bench_shapes.py: f16 semi/desc rel-L2 < 3e-3, max < 1.5e-2, argmax > 0.97; the f32 path meets 1e-3 of max|ref|"
+        # the floor of 16-bit inference itself: the oracle with fp16 storage of activations / BN-folded filters and fp32 accumulation
+        # (PyTorch's half-precision arithmetic on the CPU) against the fp32 oracle -- the HIP path is held to 1.15x of it in relative L2
+        with torch.no_grad(), net_oracle.half_storage(torch.float16 if gpu_outs["dtype"] == "f16" else torch.bfloat16):
+            flo = net_oracle.yolopoint_forward(net_oracle.fused_state_dict(sd), x, version)
+        fl = {"semi": rel(flo["semi"], ref["semi"])[1], "desc": rel(flo["desc"], ref["desc"])[1], "pred": rel(flo["objects"][0], ref["objects"][0])[1],
+              "raw_levels": [rel(a, b)[1] for a, b in zip(flo["objects"][1], ref["objects"][1])]}
+        parity["floor_rel_l2"] = {k: ([round(v, 6) for v in fl[k]] if isinstance(fl[k], list) else round(fl[k], 6)) for k in fl}
+        parity["ratio_to_floor"] = {"semi": round(parity["semi_rel_l2"] / fl["semi"], 3), "desc": round(parity["desc_rel_l2"] / fl["desc"], 3),
+                                    "pred": round(parity["pred_rel_l2"] / fl["pred"], 3),
+                                    "raw_levels": [round(a / b, 3) for a, b in zip(parity["raw_levels_rel_l2"], fl["raw_levels"])]}
+        parity["floor_argmax_agreement"] = round(float((flo["semi"].argmax(1) == ref["semi"].argmax(1)).float().mean()), 6)
+        parity["bars"] = ("tests/test_gpu_bench_shapes.py: every head tensor's relative L2 <= 1.15 x floor_rel_l2 (max-abs <= 1.5 x), argmax mismatches only on "
+                          "reference near-ties within one 16-bit step; the f32 path meets the north-star 1e-3 of max|ref| with bit-exact argmax")
     return base, parity
 
 
@@ -282,7 +300,14 @@ def main():
         if a.postproc:
             out["postproc"] = bench_postproc(dev)
     # ---- sub-records (every rank takes part in the data-parallel training; the rest is rank 0, N = 1)
-    only = set(k for k in a.only.split(",") if k) or {"train", "train64", "frame", "fp8"}
+    only = set(k for k in a.only.split(",") if k) or {"train", "train64", "frame", "fp8", "v52"}
+    a.cpu_threads = None
+    parity = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"], parity = cpu_baseline(a.version, B, S, gpu_outs=gpu_outs)
+        a.cpu_threads = out["cpu_baseline"]["cores"]
+        if parity is not None:
+            out["parity"] = parity
     del plan, img, outs
     net.__dict__.pop("_plans", None)
     torch.cuda.empty_cache()
@@ -304,13 +329,12 @@ def main():
             out["train_l_fp8"] = rec
     if world == 1 and "frame" in only:
         torch.cuda.empty_cache()
-        out["frame"] = run_frame(dev, "l", 1280, a.dtype, a.frame_steps, max(3, a.frame_steps // 6))
+        out["frame"] = run_frame(dev, "l", 1280, a.dtype, a.frame_steps, max(3, a.frame_steps // 6), cpu_threads=a.cpu_threads)
     if rank != 0:
         return
-    if world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"], parity = cpu_baseline(a.version, B, S, gpu_outs=gpu_outs)
-        if parity is not None:
-            out["parity"] = parity
+    if world == 1 and "v52" in only:
+        torch.cuda.empty_cache()
+        out["v52"] = run_v52(dev, 100, 10, a.cpu_threads or 16, a.cpu_threads is not None)
     print(json.dumps(out), flush=True)
 
 
@@ -325,6 +349,152 @@ def mfma_busy_record():
             return None
     return None
 
+
+
+def train_traffic_record(version, batch, dtype):
+    """HBM bytes of one optimizer step from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
+    `bench.py --mode train`, FETCH_SIZE x2 per MI355X_MICROARCH.md): the latest committed measurement, profiles/train_traffic.json."""
+    path = os.path.join(ROOT, "profiles", "train_traffic.json")
+    try:
+        d = json.load(open(path))
+        return d.get(f"{version}_{batch}_{dtype}")
+    except Exception:
+        return None
+
+
+def cpu_train_baseline(version, S, threads, budget_s=18.0):
+    """The reference optimizer step on the host cores, bounded: ONE image pair (B = 1 sample: two train-mode forwards through the oracle,
+    fp32), autograd backward, torch.optim.Adam over all parameters.  The three loss heads are replaced by seeded projections of the
+    outputs (oracle.net_oracle.projected_loss: the reference's losses are < 1 % of the step's FLOP); the warped pass back-propagates its
+    keypoint / descriptor outputs only, as in src/train.py:208-245."""
+    from oracle import net_oracle
+    from yolopoint_amd.utils.synthetic import NAMES80, layout_of, GAIN
+    from yolopoint_amd import models
+    torch.set_num_threads(threads)
+    layout = layout_of(models.Model(names=NAMES80, version=version))
+    sd = net_oracle.synth_state_dict(layout, 1234, gain=GAIN.get(version, 1.6))
+    leaf = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in sd.items()}
+    params = [v for v in leaf.values() if v.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-4)
+    x, xw = net_oracle.synth_image(1, 3, S, S, 1), net_oracle.synth_image(1, 3, S, S, 2)
+    proj = None
+
+    def step():
+        nonlocal proj
+        opt.zero_grad(set_to_none=True)
+        o = net_oracle.yolopoint_forward(leaf, x, version, training=True, stats={})
+        ow = net_oracle.yolopoint_forward(leaf, xw, version, training=True, stats={})
+        if proj is None:
+            proj = net_oracle.output_projections(o, 3)
+        loss = net_oracle.projected_loss(o, proj) + (ow["semi"] * proj["semi"]).sum() * 0.01 + (ow["desc"] * proj["desc"]).sum()
+        loss.backward()
+        opt.step()
+    step()
+    times, t_start = [], time.perf_counter()
+    while len(times) < 5 and (len(times) < 2 or (time.perf_counter() - t_start) < budget_s):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(2.0 / med, 3), "unit": "images/s (an image pair counts as 2 images)", "cores": threads, "kind": "port",
+            "sample": f"oracle (PyTorch-CPU fp32) optimizer step of YOLOPoint-{version} on ONE {S}x{S} image pair (the GPU record runs 8-16 pairs per step): two "
+                      f"train-mode forwards, autograd backward (warped pass: keypoint / descriptor heads only), torch.optim.Adam; losses = seeded output "
+                      f"projections; {threads} threads (the count the forward probe picked), 1 warm-up + {len(times)} timed steps, median"}
+
+
+def cpu_frame_baseline(version, S, threads, semis, preds, budget_s=25.0):
+    """One frame on the host cores: the oracle's fp32 forward of one SxS image + the oracle's sequential post-processing (keypoint decode,
+    greedy grid NMS, box NMS, box-mask filter, descriptor sampling) on the SAME planted heads the GPU record uses + mutual-NN matching
+    against the previous frame."""
+    from oracle import net_oracle, postproc_oracle as po
+    from yolopoint_amd.utils.synthetic import NAMES80, layout_of, GAIN
+    from yolopoint_amd import models
+    torch.set_num_threads(threads)
+    layout = layout_of(models.Model(names=NAMES80, version=version))
+    sd = net_oracle.synth_state_dict(layout, 1234, gain=GAIN.get(version, 1.6))
+    fused = sd
+    prev = [None]
+    times, t_start = [], time.perf_counter()
+    i = 0
+    with torch.no_grad():
+        while len(times) < 4 and (len(times) < 2 or (time.perf_counter() - t_start) < budget_s):
+            x = net_oracle.synth_image(1, 3, S, S, 100 + i)
+            t0 = time.perf_counter()
+            o = net_oracle.yolopoint_forward(fused, x, version)
+            k = i % len(semis)
+            r = po.frontend_postprocess(semis[k][0].numpy(), o["desc"][0].numpy(), preds[k][0].numpy())
+            desc = r[1] if isinstance(r, tuple) else r["desc"]
+            if prev[0] is not None and desc is not None and desc.shape[1] and prev[0].shape[1]:
+                po.nn_match_two_way(desc, prev[0], 0.7)
+            prev[0] = desc
+            dt = time.perf_counter() - t0
+            if i > 0:
+                times.append(dt)          # (the first frame is the warm-up and has no previous frame to match)
+            i += 1
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(1.0 / med, 3), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"oracle forward (PyTorch-CPU fp32) of one {S}x{S} frame through YOLOPoint-{version} + oracle/postproc_oracle.py on the planted heads of the "
+                      f"GPU record (sequential greedy NMS loops as the reference runs them) + matching; {threads} threads, 1 warm-up + {len(times)} timed frames, median"}
+
+
+def run_v52(dev, steps, warmup, threads, with_cpu):
+    """YOLOPointv52-s (the model reference configs/kitti_inference.yaml:2 selects), batch 8, 640x640, f16, hipGraph: images/s + parity at
+    that shape against the oracle's fp32 forward."""
+    from yolopoint_amd.utils.synthetic import make_model, synth_image
+    B, S = 8, 640
+    m, sd = make_model("s", 1234, dtype="f16", model_name="YOLOPointv52")
+    m = m.to(dev)
+    m.fuse()
+    m.model.static_outputs = True
+    net = m.model
+    x = synth_image(B, 3, S, S, 1234).to(dev)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        plan, img, outs = net.build_plan(B, S, S, dev, graph=True)
+        for _ in range(warmup):
+            net.run_plan(plan, img, x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            net.run_plan(plan, img, x)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        per_op = plan.profile()
+    recs = list(plan.records)
+    conv_ms = sum(ms for ms, r in zip(per_op, recs) if r.kind == "conv")
+    conv_flops = sum(r.flops for r in recs if r.kind == "conv")
+    rec = {"metric": "images/sec at 640x640 (YOLOPointv52-s inference, bs=8, fp16)", "value": round(B * steps / wall, 1), "unit": "images/s",
+           "ms_per_step": round(wall / steps * 1e3, 4), "steps": steps, "warmup": warmup, "dtype": "f16",
+           "config": {"workload": "reference configs/kitti_inference.yaml:2 model (YOLOPointv52, version s: C2f blocks, MaxPool descriptor branch, 65-channel C2f "
+                                  "keypoint head), batch 8, 640x640, BN folded, hipGraph replay", "ops_per_step": len(per_op)},
+           "roofline": {"bound": "mfma", "achieved": round(conv_flops / (conv_ms * 1e-3) / 1e12, 2) if conv_ms > 0 else None, "peak": 2500.0, "unit": "TFLOP/s",
+                        "frac": round(conv_flops / (conv_ms * 1e-3) / 1e12 / 2500.0, 4) if conv_ms > 0 else None, "traffic": None,
+                        "algorithmic_gflop_per_step": round(conv_flops / 1e9, 3), "note": "conv launches of the plan (eager, HIP events) against their algorithmic FLOP"}}
+    if with_cpu:
+        from oracle import net_oracle
+        torch.set_num_threads(threads)
+        net.run_plan(plan, img, x)
+        torch.cuda.synchronize()
+        dch = net._desc_channels if hasattr(net, "_desc_channels") else outs["desc"].buf.t.shape[-1]
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            ref = net_oracle.yolopointv52_forward(sd, x.cpu(), "s")
+            dt = time.perf_counter() - t0
+
+        def rel(a_, b_):
+            a_, b_ = a_.detach().double().cpu(), b_.detach().double()
+            return round(float((a_ - b_).norm() / b_.norm().clamp_min(1e-30)), 6)
+        semi = outs["semi"].buf.t[..., :65].permute(0, 3, 1, 2).float()
+        desc = outs["desc"].buf.t[..., :ref["desc"].shape[1]].permute(0, 3, 1, 2).float()
+        rec["parity"] = {"against": "oracle.net_oracle.yolopointv52_forward (fp32 CPU), same weights and input", "semi_rel_l2": rel(semi, ref["semi"]),
+                         "desc_rel_l2": rel(desc, ref["desc"]), "pred_rel_l2": rel(outs["z"].float(), ref["objects"][0]),
+                         "keypoint_cell_argmax_agreement": round(float((semi.argmax(1).cpu() == ref["semi"].argmax(1)).float().mean()), 6)}
+        rec["cpu_baseline"] = {"value": round(B / dt, 2), "unit": "images/s", "cores": threads, "kind": "port",
+                               "sample": f"ONE oracle forward (PyTorch-CPU fp32) of YOLOPointv52-s batch 8 640x640, {threads} threads (also the parity reference)"}
+    del plan, img, outs
+    net.__dict__.pop("_plans", None)
+    torch.cuda.empty_cache()
+    return rec
 
 TRAIN_GFLOP_PER_SAMPLE = {"n": 27.77, "s": 103.28, "m": 299.67, "l": 657.56}      # SURVEY.md 8(d): 4 F_fwd + 2 F_kp at 640x640
 
@@ -368,11 +538,14 @@ def run_train(a, rank, world, dev, version, batch, steps, warmup, gas=1, size=64
            "per_gpu_batch": batch, "gas": gas, "global_batch": batch * gas * world, "parallelism": f"dp{world}",
            "grad_allreduce_bytes": step.reducer.payload_bytes(), "buckets": step.reducer.describe(),
            "bucket_launch_order": list(step.reducer.launch_log), "exposed_comm_ms_per_step": exposed,
-           "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS["bf16"], 4),
-                        "traffic": None, "per_gpu": True, "algorithmic_gflop_per_sample": round(gflop_sample, 2),
+           "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS[dtype], 4),
+                        "traffic": train_traffic_record(version, batch, dtype), "per_gpu": True, "algorithmic_gflop_per_sample": round(gflop_sample, 2),
                         "note": "whole step (losses, BN / elementwise passes, optimizer included) against the conv FLOP the reference executes per sample"
-                                + ("; the fp8 convolutions use the non-scaled 16x16x32 fp8 MFMAs, which issue at the bf16 rate (2.5 PFLOP/s dense), not the MX-scaled "
-                                   "K = 128 forms (5 PFLOP/s)" if fp8 else "")}}
+                                + ("; priced against the 5 PFLOP/s dense fp8 peak: layers whose channel counts are multiples of 128 run on the block-scaled "
+                                   "K = 64 fp8 MFMAs (csrc/conv_mma8.hip, twice the 16-bit rate), the rest on the non-scaled 16x16x32 forms (bf16 rate); "
+                                   "weight gradients, BatchNorm and losses stay 16-bit" if fp8 else "")}}
+    if world == 1 and rank == 0 and getattr(a, "cpu_threads", None) and not a.no_cpu_baseline and gas == 1:
+        rec["cpu_baseline"] = cpu_train_baseline(version, size, a.cpu_threads)
     del step, m, micro
     torch.cuda.empty_cache()
     return rec if rank == 0 else None
@@ -381,6 +554,7 @@ def run_train(a, rank, world, dev, version, batch, steps, warmup, gas=1, size=64
 def bench_train(a, rank, world, dev):
     """--mode train: the training step as the top-level record (per-GPU batch a.batch, a.gas micro-batches per step)."""
     dtype = a.dtype if a.dtype != "f16" else "bf16"
+    a.cpu_threads = None if a.no_cpu_baseline else min(os.cpu_count() or 1, 16)
     rec = run_train(a, rank, world, dev, a.version, a.batch, a.steps, a.warmup, gas=a.gas, size=a.size, dtype=dtype)
     if rank != 0:
         return
@@ -391,6 +565,8 @@ def bench_train(a, rank, world, dev):
                       "grad_allreduce_bytes": rec["grad_allreduce_bytes"], "buckets": rec["buckets"], "bucket_launch_order": rec["bucket_launch_order"],
                       "exposed_comm_ms_per_step": rec["exposed_comm_ms_per_step"]},
            "roofline": rec["roofline"]}
+    if "cpu_baseline" in rec:
+        top["cpu_baseline"] = rec["cpu_baseline"]
     print(json.dumps(top), flush=True)
 
 
@@ -406,7 +582,7 @@ def bench_frame(a, dev):
 FWD_GFLOP_PER_IMAGE = {"n": 5.642, "s": 21.023, "m": 61.477, "l": 135.526}       # SURVEY.md 8(d) F_fwd at 640x640
 
 
-def run_frame(dev, version, S, dtype, steps, warmup):
+def run_frame(dev, version, S, dtype, steps, warmup, cpu_threads=None):
     """SURVEY.md 8(f) row 2 / BASELINE.json configs[3]: one frame through the GPU-resident front end (forward, keypoint decode +
     NMS, box NMS, box-mask keypoint filter, descriptor sampling) + mutual-NN matching against the previous frame's descriptors."""
     from yolopoint_amd.frontend import YoloPointFrontend
@@ -472,6 +648,8 @@ def run_frame(dev, version, S, dtype, steps, warmup):
                         "note": "whole frame (post-processing and host syncs included) against the forward's algorithmic conv FLOP"}}
     del fe, m
     torch.cuda.empty_cache()
+    if cpu_threads:
+        rec["cpu_baseline"] = cpu_frame_baseline(version, S, cpu_threads, [t.cpu() for t in semis], [t.cpu() for t in preds])
     return rec
 
 

@@ -177,6 +177,57 @@ def fuse_conv_bn(w, gamma, beta, mean, var, eps=BN_EPS):
 
 
 # ---------------------------------------------------------------------------------------------
+# the 16-bit noise floor of the network itself (what PyTorch's own half-precision inference differs from fp32 by)
+# ---------------------------------------------------------------------------------------------
+class half_storage:
+    """Context manager: inside it every convolution of this module rounds its input and its filter to `dtype` (fp16 | bf16) and
+    accumulates in fp32 -- the arithmetic of PyTorch's half-precision inference (16-bit storage of activations and BN-folded filters,
+    fp32 accumulation), stated on the CPU.  The difference between this forward and the plain fp32 oracle is the FLOOR any 16-bit
+    implementation of the network sits on; the HIP path's 16-bit outputs are held to a small multiple of it
+    (tests/test_gpu_bench_shapes.py) instead of to free-standing bars."""
+
+    def __init__(self, dtype=torch.float16):
+        self.dtype = dtype
+
+    def __enter__(self):
+        import torch.nn.functional as F0
+        dt = self.dtype
+
+        class Shim:
+            def __getattr__(self, name):
+                return getattr(F0, name)
+
+            @staticmethod
+            def conv2d(x, w, b=None, *a, **k):
+                return F0.conv2d(x.to(dt).float(), w.to(dt).float(), b, *a, **k)
+        global F
+        self.saved = F
+        F = Shim()
+        return self
+
+    def __exit__(self, *exc):
+        global F
+        F = self.saved
+        return False
+
+
+def fused_state_dict(sd):
+    """BN folded into every Conv block of a reference-layout state_dict (utils/torch_utils_yolo.py:194-214 through the oracle's
+    fuse_conv_bn): `.conv.weight` / `.conv.bias`, no `.bn.*` keys -- the tensors the inference path rounds to 16 bits."""
+    out = {}
+    for k, v in sd.items():
+        if ".bn." in k:
+            continue
+        if k.endswith(".conv.weight") and k[:-len(".conv.weight")] + ".bn.weight" in sd:
+            p = k[:-len(".conv.weight")]
+            w, b = fuse_conv_bn(v, sd[p + ".bn.weight"], sd[p + ".bn.bias"], sd[p + ".bn.running_mean"], sd[p + ".bn.running_var"])
+            out[k], out[p + ".conv.bias"] = w, b
+        else:
+            out[k] = v
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
 # deterministic synthetic weights / images: data generators shared with the benchmarks (yolopoint_amd/utils/synthetic.py)
 # ---------------------------------------------------------------------------------------------
 from yolopoint_amd.utils.synthetic import synth_state_dict, synth_image  # noqa: E402,F401

@@ -68,3 +68,6 @@ def argmax_mismatches(got, ref, tie_tol):
     margin = (ref.gather(1, ib) - ref.gather(1, ia))[bad]
     assert float(margin.max()) <= tie_tol, f"argmax differs on a non-tie: margin {float(margin.max()):.3e} > {tie_tol:.1e}"
     return int(bad.sum()), float(margin.max())
+
+
+half_storage_oracle, fused_state_dict = net_oracle.half_storage, net_oracle.fused_state_dict          # the 16-bit floor of the network (oracle/net_oracle.py)

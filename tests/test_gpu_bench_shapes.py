@@ -18,15 +18,44 @@ from yolopoint_amd.utils.general_yolo import non_max_suppression
 
 pytestmark = pytest.mark.gpu
 
-# bars of the 16-bit inference path at the benchmarked shapes: relative L2 of the head outputs / max-abs relative to max|ref| /
-# fraction of keypoint cells whose argmax agrees (ties within the 16-bit error may flip)
-F16_BARS = dict(head_l2=3e-3, head_max=1.5e-2, raw_l2=1e-2, pred_l2=2e-2, argmax=0.97)
+# The 16-bit inference path is held to the FLOOR of 16-bit inference itself, measured in the same test: the oracle evaluated with
+# PyTorch's half-precision arithmetic (fp16 storage of activations and BN-folded filters, fp32 accumulation:
+# oracle.net_oracle.half_storage) differs from the fp32 oracle by floor(t) for every head tensor t; the HIP path must stay within
+#   relative L2   <= 1.15 x floor    (measured: 1.00 - 1.10 x at configs[1] and configs[3])
+#   max-abs error <= 1.5  x floor    (the maximum of ~1e7 rounding errors is a noisy statistic: measured 0.88 - 1.36 x)
+# and every keypoint cell whose argmax differs from the fp32 oracle's must be a near-tie of the REFERENCE within one 16-bit step of the
+# logit scale (2^-10 max|semi|), no more such cells than 1.5 x the floor's own count + 5.
+F16_L2, F16_MAX = 1.15, 1.5
+
+
+def _heads(o):
+    return {"semi": o["semi"], "desc": o["desc"], "pred": o["objects"][0], **{f"raw{i}": t for i, t in enumerate(o["objects"][1])}}
+
+
+def _check_against_f16_floor(got, ref, floor):
+    G, R, F_ = _heads(got), _heads(ref), _heads(floor)
+    for k in R:
+        f_max, f_l2 = rel_err(F_[k], R[k])
+        g_max, g_l2 = rel_err(G[k], R[k])
+        print(f"{k:5s} floor l2 {f_l2:.3e} max {f_max:.3e} | hip l2 {g_l2:.3e} ({g_l2 / f_l2:.2f}x) max {g_max:.3e} ({g_max / f_max:.2f}x)")
+        assert g_l2 <= F16_L2 * f_l2, (k, g_l2, f_l2)
+        assert g_max <= F16_MAX * f_max, (k, g_max, f_max)
+    tie = float(ref["semi"].abs().max()) * 2.0 ** -10
+    n_floor, _ = argmax_mismatches(floor["semi"], ref["semi"], tie)
+    n_hip, margin = argmax_mismatches(got["semi"], ref["semi"], tie)
+    print(f"argmax: {n_hip} cells differ (floor: {n_floor}), largest reference margin {margin:.2e} <= one 16-bit step {tie:.2e}")
+    assert n_hip <= 1.5 * n_floor + 5, (n_hip, n_floor)
 
 
 def _oracle(version, sd, x):
     torch.set_num_threads(min(32, torch.get_num_threads() or 8))
     with torch.no_grad():
         return net_oracle.yolopoint_forward(sd, x, version)
+
+
+def _oracle_f16_floor(version, sd, x):
+    with torch.no_grad(), net_oracle.half_storage(torch.float16):
+        return net_oracle.yolopoint_forward(net_oracle.fused_state_dict(sd), x, version)
 
 
 def test_config1_s_bs8_640_f32(cuda):
@@ -61,16 +90,7 @@ def test_config1_s_bs8_640_f16_graph_as_benchmarked(cuda):
     with torch.no_grad():
         m(x.to(cuda))
         got = m(x.to(cuda))                        # second call = graph replay
-    t = F16_BARS
-    for name in ("semi", "desc"):
-        e_max, e_l2 = rel_err(got[name], ref[name])
-        print(name, f"max {e_max:.2e} l2 {e_l2:.2e}")
-        assert e_l2 < t["head_l2"] and e_max < t["head_max"], (name, e_max, e_l2)
-    for a, b in zip(got["objects"][1], ref["objects"][1]):
-        assert rel_err(a, b)[1] < t["raw_l2"]
-    assert rel_err(got["objects"][0], ref["objects"][0])[1] < t["pred_l2"]
-    same = (got["semi"].argmax(1).cpu() == ref["semi"].argmax(1)).float().mean()
-    assert same > t["argmax"], float(same)
+    _check_against_f16_floor(got, ref, _oracle_f16_floor("s", sd, x))
 
 
 def test_config1_forward_is_deterministic(cuda):
@@ -103,14 +123,7 @@ def test_config3_l_bs1_1280_f16(cuda):
     with torch.no_grad():
         got = m(x.to(cuda))
     assert got["objects"][0].shape == (1, 100800, 85) and got["desc"].shape == (1, 256, 160, 160)
-    t = F16_BARS
-    for name in ("semi", "desc"):
-        e_max, e_l2 = rel_err(got[name], ref[name])
-        print(name, f"max {e_max:.2e} l2 {e_l2:.2e}")
-        assert e_l2 < 2 * t["head_l2"] and e_max < 2 * t["head_max"], (name, e_max, e_l2)      # -l is three times as deep as -s
-    assert rel_err(got["objects"][0], ref["objects"][0])[1] < 2 * t["pred_l2"]
-    same = (got["semi"].argmax(1).cpu() == ref["semi"].argmax(1)).float().mean()
-    assert same > 0.95, float(same)
+    _check_against_f16_floor(got, ref, _oracle_f16_floor("l", sd, x))
 
 
 def test_config3_keypoint_nms_1280_4000_peaks(cuda):

@@ -262,3 +262,29 @@ def test_flat_parameter_arena_keeps_values_and_puts_c3_siblings_back_to_back():
     assert n_c3 == 10
     # the bucket plan still separates the groups: detector buckets first, then the keypoint group
     assert red.bucket_group == sorted(red.bucket_group, key=lambda g: g != "detector")
+
+
+def test_plan_key_sees_a_same_shape_module_replacement():
+    """The cached inference plan is keyed on the parameters' identities: assigning a NEW module of the same shape (net.ConvDescA = ...)
+    must change the key -- a key built on child COUNTS kept replaying the plan packed from the old module's filters."""
+    from yolopoint_amd.models import common
+    from helpers import make_model
+    m, _ = make_model("n", 3)
+    net = m.model
+    v0 = net._weights_version()
+    assert net._weights_version() == v0
+    net.ConvDescA = common.Conv(net.ConvDescA.conv.in_channels, net.ConvDescA.conv.out_channels, 3, 2)
+    v1 = net._weights_version()
+    assert v1 != v0
+    net.Detect.m[1] = torch.nn.Conv2d(net.Detect.m[1].in_channels, net.Detect.m[1].out_channels, 1)
+    assert net._weights_version() != v1
+
+
+def test_bbox_iou_public_helper_matches_the_oracle_ciou():
+    from yolopoint_amd.utils.metrics_yolo import bbox_iou
+    from oracle import loss_oracle
+    g = torch.Generator().manual_seed(2)
+    a, b = torch.rand(64, 4, generator=g) + 0.05, torch.rand(64, 4, generator=g) + 0.05
+    assert float((bbox_iou(a, b, CIoU=True).squeeze(-1) - loss_oracle.ciou(a, b)).abs().max()) < 1e-6
+    iou = bbox_iou(a, a)
+    assert float((iou - 1).abs().max()) < 1e-4          # (eps = 1e-7 in the union of boxes with area ~1e-2)

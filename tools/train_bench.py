@@ -12,9 +12,10 @@ ap.add_argument("--version", default="s"); ap.add_argument("--batch", type=int, 
 ap.add_argument("--dtype", default="bf16"); ap.add_argument("--steps", type=int, default=5)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
-m, _ = make_model(a.version, 1, dtype=a.dtype)
+fp8 = a.dtype == "fp8"          # configs[4]: 8-bit Conv operands on top of the bf16 path
+m, _ = make_model(a.version, 1, dtype="bf16" if fp8 else a.dtype)
 m = m.to(dev).train()
-step = TrainStep(m, dev, img_size=a.size)
+step = TrainStep(m, dev, img_size=a.size, fp8=fp8)
 batch = synthetic_batch(a.batch, a.size, dev, 1234)
 t0 = time.perf_counter(); l = step(batch); torch.cuda.synchronize(); print(f"first step (plan build + autotune): {time.perf_counter()-t0:.1f}s loss={float(l):.4f}")
 l = step(batch); torch.cuda.synchronize()

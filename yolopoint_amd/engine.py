@@ -120,10 +120,20 @@ class TrainStep:
             raise ValueError(f"TrainStep(gas={self.gas}) takes {self.gas} micro-batch(es) per optimizer step, got {len(micro)}")
         if not self._calibrated:
             from .models.common import invalidate_packed_weights
+            # The two calibration passes only record tensor maxima: the BatchNorm running statistics / batch counters they update and the
+            # random draws they consume (InfoNCE sampling) are put back, so an fp8 run starts from the same buffers and the same RNG
+            # stream as the bf16 run it is compared with -- and as a resume from a checkpoint.
+            buffers = [(b, b.detach().clone()) for b in self.model.buffers()]
+            cpu_rng, dev_rng = torch.get_rng_state(), torch.cuda.get_rng_state(self.device)
             with self.reducer.no_sync():
                 for _ in range(2):
                     self.loss_and_grads(micro[0])
                     invalidate_packed_weights()       # (the next forward turns the recorded maxima into scales, as after an optimizer step)
+            with torch.no_grad():
+                for b, saved in buffers:
+                    b.copy_(saved)
+            torch.set_rng_state(cpu_rng)
+            torch.cuda.set_rng_state(dev_rng, self.device)
             self._calibrated = True
         total = None
         for i, mb in enumerate(micro):

@@ -86,13 +86,14 @@ class HipModule(nn.Module):
         Tensor._version, so a key built on the counters alone keeps replaying plans packed from the old filters."""
         # (Module.parameters() / buffers() re-walk the module tree with de-duplication on every call: 1.5 ms per forward for YOLOPoint-l,
         # as much host time as the forward takes on the device.  The module list is cached and re-walked only when the tree changed --
-        # detected by the child counts, which fuse() / add_module change -- or an explicit invalidation; the tensors are read from the
-        # modules' own dicts every time, so replaced parameters are seen.)
+        # detected by the IDENTITIES of every module's children (fuse() / add_module / `net.ConvDet = new_head` all change them; a child
+        # count alone misses a same-shape replacement, which would keep replaying a plan packed from the old module's filters) -- or an
+        # explicit invalidation; the tensors are read from the modules' own dicts every time, so replaced parameters are seen.)
         gen = weights_generation()
         cache = self.__dict__.get("_mods_cache")
-        if cache is None or cache[0] != gen or cache[1] != sum(len(m._modules) for m in cache[2]):
+        if cache is None or cache[0] != gen or cache[1] != tuple(id(c) for m in cache[2] for c in m._modules.values()):
             mods = list(self.modules())
-            cache = self.__dict__["_mods_cache"] = (gen, sum(len(m._modules) for m in mods), mods)
+            cache = self.__dict__["_mods_cache"] = (gen, tuple(id(c) for m in mods for c in m._modules.values()), mods)
         return (gen,) + tuple((t._version, t.data_ptr()) for m in cache[2] for d in (m._parameters, m._buffers) for t in d.values() if t is not None)
 
     def _plan_key(self, x):

@@ -335,10 +335,13 @@ class _InfoNCEPairNative(torch.autograd.Function):
         n, D = dab.shape[0] // 2, dab.shape[1]
         E = w.shape[1]
         scale = (g.float() * (1.0 / (ctx.tau * n))).reshape(1)
+        # (out of place: a second backward through this node -- retain_graph, autograd.grad followed by .backward -- must see the saved,
+        # unscaled anchor half again and must not overwrite a tensor that was already handed out)
+        out = torch.empty_like(grad)
         _hip.check(_hip.lib().yp_infonce_bwd_db(dab.data_ptr(), order.data_ptr(), offsets.data_ptr(), w.data_ptr(), lse.data_ptr(), n, E, D,
-                                                scale.data_ptr(), grad.data_ptr() + 4 * n * D, _hip.stream_ptr()))
-        grad[:n].mul_(scale)                            # (saved by this call only: scaled in place)
-        return grad, None, None, None, None
+                                                scale.data_ptr(), out.data_ptr() + 4 * n * D, _hip.stream_ptr()))
+        torch.mul(grad[:n], scale, out=out[:n])
+        return out, None, None, None, None
 
 
 class _PointSampleNative(torch.autograd.Function):
@@ -490,3 +493,8 @@ def infonce_prepare(mask_valid_warp, inv_homographies, desc_shape, on_device, nu
 
 
 descriptor_loss_sparse = infonce      # the name train.py imports it under (train.py:8)
+
+
+def smooth_BCE(eps=0.1):
+    """Label-smoothing BCE targets (positive, negative) -- reference utils/loss_functions.py (YOLOv5's helper), kept for its callers."""
+    return 1.0 - 0.5 * eps, 0.5 * eps
