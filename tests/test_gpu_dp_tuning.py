@@ -1,0 +1,56 @@
+"""Data-parallel replicas share ONE kernel-variant table: rank 0 times the candidates of a convolution signature and broadcasts its choice
+(yolopoint_amd/plan.py::_autotune), so that every rank of a job runs the same kernels (same fp32 summation orders, same step time).
+Two processes on this one GPU (gloo carries the two-float broadcast; NCCL refuses two ranks on one device) build the same small plan."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from yolopoint_amd import _hip, plan
+        from yolopoint_amd.plan import PlanBuilder
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        choices = []
+        for cin, cout, k, H in ((128, 128, 3, 40), (256, 256, 1, 20), (64, 128, 1, 40)):
+            pb = PlanBuilder(4, _hip.YP_F16, dev)
+            x = pb.new_buf(H, H, cin)
+            x.t.normal_()
+            g = torch.Generator().manual_seed(cin + k)
+            pb.conv(x.view(), torch.randn(cout, cin, k, k, generator=g) * 0.05, torch.zeros(cout), k, 1, k // 2, _hip.YP_ACT_SILU)
+            p = pb.finish()
+            p.run()
+            torch.cuda.synchronize()
+        choices = sorted((str(k_), v[0]) for k_, v in plan._TUNE_CACHE.items())
+        q.put((rank, choices))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_run_the_same_kernel_variants(cuda):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got[0] == got[1] and len(got[0]) == 3, got

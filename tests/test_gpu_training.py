@@ -646,3 +646,58 @@ def test_pair_losses_equal_the_per_pass_losses(cuda):
     (got * 0.3).backward()
     assert abs(float(got) - float(ref)) <= 1e-5 * abs(float(ref))
     assert rel_err(desc.grad, gref)[0] < 1e-5
+
+
+def test_model_wrapped_in_ddp_gets_the_same_gradients_through_autograd(cuda):
+    """Opt-in `net.autograd_param_grads = True`: the native backward RETURNS the parameter gradients to autograd (instead of writing
+    p.grad as a side effect), so the reference's own data-parallel wrapper works -- accelerator.prepare(model) = DistributedDataParallel
+    (src/train.py:44-46,174,245): AccumulateGrad hooks fire, DDP's reducer all-reduces (RCCL, world 1 here), torch.autograd.grad and
+    no_sync() behave.  The gradients equal the default side-effect path bit for bit."""
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29519")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        m, _ = make_model("n", 7, dtype="bf16")
+        m = m.to(cuda).train()
+        x = net_oracle.synth_image(2, 3, 128, 128, 9).to(cuda)
+
+        def loss_of(o):
+            return o["semi"].square().mean() + o["desc"][:, :16].mean() + sum(t.tanh().mean() for t in o["objects"])
+        bn0 = [b.clone() for b in m.buffers()]
+
+        def reset():
+            m.zero_grad(set_to_none=True)
+            for b, s in zip(m.buffers(), bn0):
+                b.copy_(s)
+        # default path: p.grad written by the native backward
+        reset()
+        loss_of(m(x)).backward()
+        ref = [p.grad.clone() for p in m.parameters()]
+        # autograd-visible path, plain module: torch.autograd.grad returns every gradient
+        m.model.autograd_param_grads = True
+        reset()
+        params = [p for p in m.parameters()]
+        got = torch.autograd.grad(loss_of(m(x)), params, allow_unused=True)
+        assert all(p.grad is None for p in params)
+        for g_, r_ in zip(got, ref):
+            assert g_ is not None and torch.equal(g_, r_)
+        # the reference's wrapper: DDP over RCCL (world 1: the all-reduce is the identity, the hooks and buckets are real)
+        reset()
+        ddp = DDP(m, device_ids=[cuda.index or 0], broadcast_buffers=False)      # train.py:44-46: no buffer broadcast (per-rank BN statistics)
+        fired = []
+        hooks = [p.register_post_accumulate_grad_hook(lambda p_: fired.append(1)) for p in m.parameters()]
+        loss_of(ddp(x)).backward()
+        torch.cuda.synchronize()
+        assert len(fired) == len(params)
+        for p, r_ in zip(m.parameters(), ref):
+            assert torch.equal(p.grad, r_)
+        with ddp.no_sync():                                  # accumulation without communication, then a synchronising pass: 2x the gradient
+            loss_of(ddp(x)).backward()
+        for p, r_ in zip(m.parameters(), ref):
+            assert torch.equal(p.grad, r_ + r_)
+        for h in hooks:
+            h.remove()
+    finally:
+        dist.destroy_process_group()

@@ -191,6 +191,19 @@ if os.environ.get("YP_TUNE_ONLY"):           # A/B experiments: restrict the aut
     _TUNE_CANDIDATES = tuple(int(v) for v in os.environ["YP_TUNE_ONLY"].split(","))
 
 
+def _shared_tuning_group():
+    """(torch.distributed module, rank) when the autotuner's choices are shared across the ranks of a data-parallel job, else None."""
+    if os.environ.get("YP_TUNE_SHARED", "1") == "0":
+        return None
+    try:
+        import torch.distributed as dist
+    except Exception:
+        return None
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() < 2:
+        return None
+    return dist, dist.get_rank()
+
+
 class PlanBuilder:
     """Collects launches into a native YpPlan; owns every buffer the plan touches."""
 
@@ -545,6 +558,15 @@ class PlanBuilder:
         signature so that equal layers always run the same kernel within a process."""
         if key in _TUNE_CACHE:
             return _TUNE_CACHE[key]
+        # Data-parallel runs: every rank builds the same plans in the same order; rank 0 times the candidates and broadcasts its choice, so that
+        # all replicas run the SAME kernel variant for a layer (timings differ by a few percent from GPU to GPU: per-process tuning let ranks
+        # pick different tiles -- different fp32 summation orders and step times across the replicas of one job).  YP_TUNE_SHARED=0: per rank.
+        shared = _shared_tuning_group()
+        if shared is not None and shared[1] != 0:
+            t = torch.zeros(2, dtype=torch.float32, device=self.device)
+            shared[0].broadcast(t, src=0)
+            _TUNE_CACHE[key] = (int(t[0].item()), (float(t[1].item()) if float(t[1].item()) > 0 else None))
+            return _TUNE_CACHE[key]
         st = _hip.stream_ptr()
         if det is not None:
             run = lambda: lib().yp_conv2d_detect(C.byref(d), C.byref(det), st)
@@ -572,6 +594,8 @@ class PlanBuilder:
             if best_ms is None or ms < best_ms:
                 best, best_ms = cand, ms
         _TUNE_CACHE[key] = (best, (best_ms / 8 if best_ms is not None else None))
+        if shared is not None:
+            shared[0].broadcast(torch.tensor([float(best), float(best_ms / 8 if best_ms is not None else 0.0)], dtype=torch.float32, device=self.device), src=0)
         return _TUNE_CACHE[key]
 
     def sppf_pool(self, x, y1, y2, y3):

@@ -841,6 +841,21 @@ class _YOLOPointTrainFn(torch.autograd.Function):
 
     @staticmethod
     def _backward(ctx, g, g_semi, g_desc, g_xs):
+        if getattr(g.net, "autograd_param_grads", False):
+            # Opt-in (net.autograd_param_grads = True): the parameter gradients go back THROUGH autograd -- one tensor per parameter, as
+            # loss.backward() of the reference produces them (train.py:245) -- so that AccumulateGrad hooks fire: the model can be wrapped in
+            # torch.nn.parallel.DistributedDataParallel / accelerate.prepare (train.py:44-46,174), torch.autograd.grad works and
+            # no_sync() behaves.  Copies of the plan's gradient buffers (the plans own those and overwrite them on the next pass).
+            grads = g.backward(g_semi, g_desc, list(g_xs))
+            g.busy = False
+            live = [(i, gr) for i, (p_, gr) in enumerate(zip(g.params, grads)) if gr is not None and p_.requires_grad]
+            fresh = [torch.empty_like(g.params[i]) for i, _ in live]
+            if fresh:
+                torch._foreach_copy_(fresh, [gr for _, gr in live])
+            out = [None] * len(g.params)
+            for (i, _), f_ in zip(live, fresh):
+                out[i] = f_
+            return (None, None, *out)
         run_native_backward(g, g_semi, g_desc, list(g_xs))
         return (None, None, *([None] * len(g.params)))
 
