@@ -12,7 +12,7 @@ from yolopoint_amd import _hip
 from yolopoint_amd.plan import PlanBuilder
 
 pytestmark = pytest.mark.gpu
-TILES = (41, 42, 43, 44, 57, 61)
+TILES = (41, 42, 43, 44, 57, 58, 61)
 
 CASES = {
     "pointwise_256_256_ragged_m": dict(cin=256, cout=256, k=1, s=1, H=21, B=3),
@@ -160,7 +160,7 @@ def test_batchnorm_statistics_epilogue(cuda, tile):
         plan.run()
         torch.cuda.synchronize()
         runs.append((part.cpu().clone(), out.buf.t[..., :Cout].float().cpu().reshape(-1, Cout)))
-        assert rows == (B * Ho * Ho + (128 if tile in (41, 57, 61) else 64) - 1) // (128 if tile in (41, 57, 61) else 64)
+        assert rows == (B * Ho * Ho + (128 if tile in (41, 57, 58, 61) else 64) - 1) // (128 if tile in (41, 57, 58, 61) else 64)
         assert rows == part.shape[0] or float(part[rows:].abs().max()) == 0.0
     (p0, y0), (p1, _) = runs
     assert torch.equal(p0, p1)

@@ -23,3 +23,5 @@ base = min(buf[w * 32] for w in range(8) if buf[w * 32])
 for w in range(8):
     ts = [buf[w * 32 + i] for i in range(24)]
     print(f"tile {tile} wave {w}: " + " ".join(f"{(t - base) if t else -1:5d}" for t in ts))
+    xs = [buf[w * 32 + 24 + i] for i in range(6)]
+    print(f"   kernel phases (clk): entry->setup {xs[1]-xs[0]}, prologue DMA {xs[2]-xs[1]}, k loop {xs[3]-xs[2]}, stats/bias {xs[4]-xs[3]}, stores {xs[5]-xs[4]}, total {xs[5]-xs[0]}")

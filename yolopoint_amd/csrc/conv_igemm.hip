@@ -22,6 +22,8 @@
 #include "yp_internal.h"
 #include "conv_common.h"
 
+struct __attribute__((packed, aligned(4))) YpF4U { f32x4 v; };      // a 16-byte vector at a 4-byte-aligned address (Detect rows: 85 floats)
+
 // Probe builds (-DYP_TIMELINE, tools/probe/timeline.py): workgroup 0 / lane 0 records the shader clock at phase boundaries.
 #ifdef YP_TIMELINE
 __device__ long long yp_timeline[64];
@@ -648,8 +650,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
                 const float v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
                 const size_t cell = (size_t)(b * a.det_na + an) * a.HoWo + rem;
                 float* xp = a.det_x + cell * no + o;
-                __builtin_nontemporal_store(v0, xp); __builtin_nontemporal_store(v1, xp + 1);
-                __builtin_nontemporal_store(v2, xp + 2); __builtin_nontemporal_store(v3, xp + 3);
+                // ONE 16-byte store per lane (rows of no = 85 floats are only 4-byte aligned: the unaligned dwordx4 form; four dword stores
+                // per lane wrote every cache line of the run four times)
+                reinterpret_cast<YpF4U*>(xp)->v = f32x4{v0, v1, v2, v3};
                 if (a.det_z != nullptr) {
                     float zz[4];
                     const float vv[4] = {v0, v1, v2, v3};
@@ -667,8 +670,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
                     }
                     const size_t row = (size_t)a.det_row_off + (size_t)an * a.HoWo + rem;
                     float* zp = a.det_z + ((size_t)b * a.det_rows_total + row) * no + o;
-                    __builtin_nontemporal_store(zz[0], zp); __builtin_nontemporal_store(zz[1], zp + 1);
-                    __builtin_nontemporal_store(zz[2], zp + 2); __builtin_nontemporal_store(zz[3], zp + 3);
+                    reinterpret_cast<YpF4U*>(zp)->v = f32x4{zz[0], zz[1], zz[2], zz[3]};
                 }
             } else {
 #pragma unroll

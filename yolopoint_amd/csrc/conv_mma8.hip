@@ -25,13 +25,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // probe build: waves 0 and 4 of workgroup 0 record the shader clock at the segment boundaries of k tile 6 (YP8_TS(i))
 __device__ unsigned long long yp8_timeline[8][32];
 extern "C" int yp_debug_mma8_timeline(unsigned long long* out_host) { return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(yp8_timeline), sizeof(unsigned long long) * 256); }
-#define YP8_TS_DECL unsigned long long yp8_ts[24]; _Pragma("unroll") for (int i_ = 0; i_ < 24; ++i_) yp8_ts[i_] = 0; const bool yp8_rec = blockIdx.x == 0
+#define YP8_TS_DECL unsigned long long yp8_x[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long yp8_ts[24]; _Pragma("unroll") for (int i_ = 0; i_ < 24; ++i_) yp8_ts[i_] = 0; const bool yp8_rec = blockIdx.x == 0 && wave0_ >= 0
 #define YP8_TS(i) do { if (yp8_rec && kt == 6) { __builtin_amdgcn_sched_barrier(0); yp8_ts[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define YP8_TSX(i) do { if (blockIdx.x == 0) { __builtin_amdgcn_sched_barrier(0); yp8_x[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define YP8_TS_FLUSH2() do { if (blockIdx.x == 0 && lane == 0) { _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) yp8_timeline[wave][24 + i_] = yp8_x[i_]; } } while (0)
 #define YP8_TS_FLUSH() do { if (yp8_rec && lane == 0) { _Pragma("unroll") for (int i_ = 0; i_ < 24; ++i_) yp8_timeline[wave][i_] = yp8_ts[i_]; } } while (0)
 #else
 #define YP8_TS_DECL do {} while (0)
 #define YP8_TS(i) do {} while (0)
 #define YP8_TS_FLUSH() do {} while (0)
+#define YP8_TSX(i) do {} while (0)
+#define YP8_TS_FLUSH2() do {} while (0)
 #endif
 
 template <int DT> struct Mma32;
@@ -91,6 +95,9 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
 
+    const int wave0_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    YP8_TS_DECL;
+    YP8_TSX(0);
     const int logical = yp_xcd_remap(blockIdx.x, gridDim.x);
     const int tile_n = logical % a.tiles_n, tile_m = logical / a.tiles_n;
     const int m0 = tile_m * BP, n0 = tile_n * BC;
@@ -246,8 +253,8 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
             for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.f;
 
     const int nk = a.Kreal / BK;
-    YP8_TS_DECL;
 
+    YP8_TSX(1);
     // ---- prologue: tiles 0 .. NS-2 in flight, tile NS-1 prepared
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s) {
@@ -262,7 +269,72 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
     if (nk >= NS - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * NL) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if constexpr (SCHED == 4) {
+    YP8_TSX(2);
+    if constexpr (SCHED == 8) {
+        // ---- free-running schedule: ONE barrier per k tile, no wave groups.  Measured (tools/probe/lds_read_probe.hip): a wave alone on its
+        // SIMD gets one ds_read_b128 per ~29 clocks (6 reads: 176 clocks), two waves reading together get the full 256 B/clk -- and in the
+        // ping-pong schedules every wave's own instruction stream (24 reads ~700 clocks + 8 DMA issues ~560 + 32 MFMAs 1024 + eight barrier
+        // round trips) is the period of the k tile, ~3000 clocks however the segments are arranged.  Here both waves of a SIMD run the same
+        // code and interleave freely on the matrix pipe (2 x 32 MFMAs = 2048 clocks per tile); what a wave does besides its MFMAs (reads for
+        // the next step into the second fragment set, DMA issues between MFMAs) hides under the partner's MFMAs.  The barrier sits between
+        // steps 2 and 3: tile t+1 (DMA parts issued in step 3 of tile t-1 and steps 0, 1 of tile t: at least one step of slack) is awaited and
+        // published there, every wave's last reads of tile t (the fragments of step 3) have retired there (WAR for the DMA that refills the
+        // stage from step 3 on), and step 3 loads the first fragments of tile t+1 beside its MFMAs -- no wave ever waits for LDS or DMA with
+        // nothing to multiply except in the barrier itself.
+        static_assert(NS == 2 && KS == 4 && NL >= 3, "SCHED 8: two stages, four 16-deep steps per k tile");
+        constexpr int NM = CT * PT;
+        constexpr int DA = NL / 4, DB = DA + (NL - DA + 1) / 2;               // DMA parts of a tile: [0, DA) | [DA, DB) | [DB, NL)
+        frag_t wf[2][CT], pf[2][PT];
+        auto load = [&](int stage_, int step, frag_t (&w_)[CT], frag_t (&p_)[PT]) {
+            const char* const ps = p_rd + stage_ * STAGE;
+            const char* const ws = w_rd + stage_ * STAGE;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) w_[ct] = ld_frag(ws + ct * 32 * ROWB, step);
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) p_[pt] = ld_frag(ps + pt * 32 * ROWB, step);
+        };
+        // (prologue above: tile 0 issued and awaited, tile 1 prepared)  part A of tile 1 now, then the first fragments
+        if (1 < nk) {
+#pragma unroll
+            for (int idx = 0; idx < DA; ++idx) issue_one(1, idx);
+        }
+        load(0, 0, wf[0], pf[0]);
+        int stage = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                if (p < 3) load(stage, p + 1, wf[(p + 1) & 1], pf[(p + 1) & 1]);
+                else if (more1) load(stage ^ 1, 0, wf[0], pf[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                const int lo = p == 0 ? DA : (p == 1 ? DB : 0), hi = p == 0 ? DB : (p == 1 ? NL : (p == 3 ? DA : 0));
+                const int nd = hi - lo;
+                const int every = nd > 0 ? (NM / nd > 0 ? NM / nd : 1) : NM + 1;
+                __builtin_amdgcn_s_setprio(1);                     // (tools/probe/mfma_lds_probe.hip mode 7 vs 5: -8 % with the MFMA cluster prioritised)
+#pragma unroll
+                for (int i = 0; i < NM; ++i) {
+                    const int ct = i / PT, pt = i % PT;
+                    if (!(probe & 1)) acc[ct][pt] = MM::mma(wf[p & 1][ct], pf[p & 1][pt], acc[ct][pt]);
+                    if ((i + 1) % every == 0 && (i + 1) / every <= nd) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if ((p == 3 ? more2 : more1) && !(probe & 2)) issue_one(p == 3 ? stage : stage ^ 1, lo + (i + 1) / every - 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(0);
+                if (p == 2) {
+                    if (more2) prepare();                          // (tile kt+2: its part A goes out in step 3, behind the barrier)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            stage ^= 1;
+        }
+    } else if constexpr (SCHED == 4) {
         // ---- one barrier per k tile: every wave walks the four 16-deep steps of a tile on its own, fragments double-buffered in registers
         // (the reads of step p+1 are in flight while the MFMAs of step p issue), two DMA instructions of the next tile per step between
         // the MFMAs.  The two waves of a SIMD interleave freely; s_barrier costs ~170 clocks here, this loop pays it once per 32 MFMAs.
@@ -474,6 +546,7 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
         if (a.bias != nullptr && nb + 4 * q < a.Cout) b4 = *reinterpret_cast<const f32x4*>(a.bias + nb + 4 * q);
         bias[4 * q] = b4[0]; bias[4 * q + 1] = b4[1]; bias[4 * q + 2] = b4[2]; bias[4 * q + 3] = b4[3];
     }
+    YP8_TSX(4);
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
         const int m = m0 + g * (BP / 2) + wp * TP + pt * 32 + lr;
@@ -495,6 +568,8 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
             }
         }
     }
+    YP8_TSX(5);
+    YP8_TS_FLUSH2();
 }
 
 namespace {
@@ -525,6 +600,7 @@ hipError_t dispatch_mma8(int tile, const ConvKArgs& a, int nblk, hipStream_t st)
         case 52: if constexpr (!STATS && !OUT_F32) return launch_mma8<DT, OUT_F32, 256, 256, 1, 4, 2, STATS, 2>(a, nblk, st); else return hipErrorInvalidValue;
         case 53: if constexpr (!STATS && !OUT_F32) return launch_mma8<DT, OUT_F32, 256, 256, 1, 4, 2, STATS, 3>(a, nblk, st); else return hipErrorInvalidValue;
         case 57: return launch_mma8<DT, OUT_F32, 256, 256, 1, 4, 2, STATS, 7>(a, nblk, st);
+        case 58: return launch_mma8<DT, OUT_F32, 256, 256, 1, 4, 2, STATS, 8>(a, nblk, st);
         case 61: return launch_mma8<DT, OUT_F32, 256, 256, 1, 4, 4, STATS, 5>(a, nblk, st);
         case 54: if constexpr (!STATS && !OUT_F32) return launch_mma8<DT, OUT_F32, 256, 256, 1, 4, 2, STATS, 4>(a, nblk, st); else return hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
@@ -536,7 +612,7 @@ hipError_t dispatch_mma8(int tile, const ConvKArgs& a, int nblk, hipStream_t st)
 bool yp_mma8_tile_dims(int tile, int* bp, int* bc, int* stat_rows_px) {
     int p = 0, c = 0, r = 0;
     switch (tile) {
-        case 41: case 51: case 52: case 53: case 54: case 57: case 61: p = 256; c = 256; r = 128; break;
+        case 41: case 51: case 52: case 53: case 54: case 57: case 58: case 61: p = 256; c = 256; r = 128; break;
         case 42: p = 256; c = 128; r = 64; break;
         case 43: p = 128; c = 256; r = 64; break;
         case 44: p = 128; c = 128; r = 64; break;
