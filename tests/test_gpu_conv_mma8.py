@@ -1,4 +1,5 @@
-"""The 8-wave 32x32x16 convolution kernels (csrc/conv_mma8.hip, tile ids 41-44) on shapes that exercise their corner cases: ragged M and
+"""The 8-wave 32x32x16 convolution kernels (csrc/conv_mma8.hip, tile ids 41-44: ping-pong schedule on four tile shapes; 57: two-phase
+schedule, the one with the 8-bit instantiation; 58: free-running schedule) on shapes that exercise their corner cases: ragged M and
 N tails, one / several filter taps, K of one, two and many 64-deep k tiles (ring prologue / tail), two channel-concatenated sources (one
 read through a 2x upsample), residual add, split destination, stride 2, fp32 output, the zero-stuffed input of a stride-2 dgrad and the
 BatchNorm-statistics epilogue.  Reference: torch conv2d on the CPU in fp32 on the SAME 16-bit-rounded operands (what the kernel
@@ -12,7 +13,7 @@ from yolopoint_amd import _hip
 from yolopoint_amd.plan import PlanBuilder
 
 pytestmark = pytest.mark.gpu
-TILES = (41, 42, 43, 44, 57, 58, 61)
+TILES = (41, 42, 43, 44, 57, 58)
 
 CASES = {
     "pointwise_256_256_ragged_m": dict(cin=256, cout=256, k=1, s=1, H=21, B=3),
@@ -89,7 +90,7 @@ def test_every_tile(cuda, name, dtype):
         assert err < bar, (name, tile, err)
 
 
-@pytest.mark.parametrize("tile", TILES + (51, 52, 53, 54))
+@pytest.mark.parametrize("tile", TILES)
 def test_matches_the_first_generation_kernel_on_a_deep_layer(cuda, tile):
     """3x3 256 -> 256 at 40x40, batch 4 (K = 2304: 36 k tiles, 9 taps x 4 tiles): against the 4-wave generic kernel (tile 3) on the same
     buffers -- both accumulate in fp32 over the same 16-bit operands, only the summation order differs."""
@@ -104,13 +105,13 @@ def test_matches_the_first_generation_kernel_on_a_deep_layer(cuda, tile):
         pb.autotune = False
         buf = pb.new_buf(Ho, Ho, C)
         buf.t.copy_(x.to(cuda))
-        out = pb.conv(buf.view(), w, b, 3, 1, 1, _hip.YP_ACT_NONE, out_f32=(tile < 50), tile=tl)
+        out = pb.conv(buf.view(), w, b, 3, 1, 1, _hip.YP_ACT_NONE, out_f32=True, tile=tl)
         plan = pb.finish()
         plan.run()
         torch.cuda.synchronize()
         outs.append(out.buf.t[..., :C].float().cpu())
     err = float((outs[0] - outs[1]).abs().max()) / float(outs[0].abs().max())
-    assert err < (2e-5 if tile < 50 else 1e-3), (tile, err)          # (the schedule experiments 51.. only have the 16-bit store)
+    assert err < 2e-5, (tile, err)
 
 
 @pytest.mark.parametrize("tile", TILES)
@@ -160,7 +161,7 @@ def test_batchnorm_statistics_epilogue(cuda, tile):
         plan.run()
         torch.cuda.synchronize()
         runs.append((part.cpu().clone(), out.buf.t[..., :Cout].float().cpu().reshape(-1, Cout)))
-        assert rows == (B * Ho * Ho + (128 if tile in (41, 57, 58, 61) else 64) - 1) // (128 if tile in (41, 57, 58, 61) else 64)
+        assert rows == (B * Ho * Ho + (128 if tile in (41, 57, 58) else 64) - 1) // (128 if tile in (41, 57, 58) else 64)
         assert rows == part.shape[0] or float(part[rows:].abs().max()) == 0.0
     (p0, y0), (p1, _) = runs
     assert torch.equal(p0, p1)

@@ -66,28 +66,28 @@ template <> struct Mma32<YP_FP8_BF8> {
     }
 };
 
-// SCHED: where the NL LDS-DMA instructions of the next k tile are issued and how many 16-deep MFMA steps form a phase
-//   0: phases of one step (8 MFMAs for the 256 x 256 tile), DMA in the load segments of phases 0..2
-//   1: phases of one step, DMA inside the MFMA segments of phases 0..2 (one instruction behind every other MFMA)
-//   2: phases of two steps (16 MFMAs), half of the DMA in the load segment of phase 0, half inside its MFMA segment
-//   3: phases of two steps, all DMA inside the MFMA segment of phase 0
-//   7: phases of two steps; every wave fetches pixel rows of its OWN group only: the 4 filter-row instructions go out in the load segment
-//      of phase 0, the 4 pixel-row instructions in the load segment of phase 1 (they are awaited behind that phase's MFMAs: only the
-//      issuing group reads them, one segment later than the filter rows are needed) -- no load segment is longer than an MFMA segment
-//   5: k tiles of 32 elements (64-byte rows, NS = 4 stages): ONE phase of two steps per tile, all DMA (of tile t+3) in its load segment
+// SCHED: the main-loop schedule.
+//   0: ping-pong, phases of one 16-deep step (8 MFMAs for the 256 x 256 tile), the DMA of the next k tile in the load segments of phases 0..2
+//   7: ping-pong, TWO phases per k tile (16-bit: two steps each; 8-bit: one K = 64 step each); every wave fetches pixel rows of its OWN group
+//      only: the filter-row instructions go out in the load segment of phase 0, the pixel-row instructions in the load segment of phase 1
+//      (awaited behind that phase's MFMAs: only the issuing group reads them, one segment later than the filter rows are needed)
+//   8: free-running, ONE barrier per k tile, fragments double-buffered in registers (see the loop)
+// Measured and dropped (same layer, same session; all within +-5 % of schedule 0): DMA inside the MFMA segments,
+// phases of two steps with the DMA split between a load and an MFMA segment, 64-byte rows with a 4-stage ring, one barrier per k tile
+// without the early publication of schedule 8.  tools/probe/mfma_lds_probe.hip reproduces the plateau outside the kernel.
 template <int DT, bool OUT_F32, int BP, int BC, int WP, int WC, int NS, bool STATS, int SCHED = 0>
 __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
     using MM = Mma32<DT>;
     using frag_t = typename MM::frag;
     constexpr int EB = Elem<DT>::BYTES;                                   // 2, or 1 (OCP fp8: a 128-byte row holds 128 k elements = two K = 64 MFMA steps)
     constexpr bool Q8 = EB == 1;
-    constexpr int ROWB = SCHED == 5 ? 64 : 128, BK = ROWB / EB;
+    constexpr int ROWB = 128, BK = ROWB / EB;
     constexpr int RPI = 1024 / ROWB, CPR = ROWB / 16, KS = ROWB / (Q8 ? 64 : 32);      // rows per DMA instruction, 16-byte chunks per row, MFMA steps per k tile
     static_assert(!Q8 || SCHED == 7, "8-bit inputs: the two-phase schedule");
     constexpr int TP = BP / (2 * WP), TC = BC / WC, PT = TP / 32, CT = TC / 32;
     constexpr int NLP = BP / (8 * RPI), NLW = BC / (8 * RPI), NL = NLP + NLW;           // DMA instructions per wave per k tile
     constexpr int STAGE = (BP + BC) * ROWB;
-    constexpr int PH = (SCHED == 7) ? KS / 2 : ((SCHED == 2 || SCHED == 3 || SCHED == 5) ? 2 : 1), NPH = KS / PH;
+    constexpr int PH = (SCHED == 7) ? KS / 2 : 1, NPH = KS / PH;          // MFMA steps per phase, phases per k tile
     constexpr bool OWNP = SCHED == 7;                                     // pixel-row DMA of a wave covers its own group's rows only                  // 16-deep MFMA steps per phase, phases per k tile
     static_assert(WP * WC == 4 && PT >= 1 && CT >= 1 && BP % (8 * RPI) == 0 && BC % (8 * RPI) == 0 && NS >= 2 && NS <= 4, "unsupported tile");
     static_assert((NS - 1) * NL <= 60, "vmcnt immediate range");
@@ -112,9 +112,8 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
     constexpr int probe = 0;
 #endif
     // ---- DMA lane constants: an instruction covers rows 8j .. 8j+7 (j = wave + 8i: its parity is the wave's), lane -> row lane/8, chunk lane%8
-    // (64-byte rows: 16 rows x 4 chunks per instruction, chunk ^= (row >> 2) & 3 = lane >> 4)
     const int lrow = lane / CPR;
-    const unsigned lanec = ROWB == 128 ? (unsigned)(((lane & 7) ^ (4 * (wave & 1) + (lane >> 4))) << 4) : (unsigned)(((lane & 3) ^ (lane >> 4)) << 4);
+    const unsigned lanec = (unsigned)(((lane & 7) ^ (4 * (wave & 1) + (lane >> 4))) << 4);
 
     YP_PIN2(const char*, in0); YP_PIN2(const char*, in1); YP_PIN2(const char*, wgt);
     YP_PIN2(int, in0_cs); YP_PIN2(int, in1_cs); YP_PIN2(int, in0_co); YP_PIN2(int, in1_co); YP_PIN2(int, in0_C);
@@ -218,18 +217,13 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
         if (idx < NLP) yp_glds16_s(cur_p, seg_voff[idx < NLP ? idx : 0], sbase + (unsigned)(OWNP ? g * (BP / (2 * RPI)) + wi + 4 * idx : wave + 8 * idx) * 1024u);
         else yp_glds16_s(cur_w, w_off[idx >= NLP ? idx - NLP : 0], sbase + (unsigned)(BP * ROWB) + (unsigned)(wave + 8 * (idx - NLP)) * 1024u);
     };
-    // the instructions [dma_lo(slot), dma_lo(slot + 1)) go out in slot `slot` of a k tile (slots are phases; see SCHED)
-    auto dma_lo = [](int slot) -> int {
-        if (SCHED == 5) return slot <= 0 ? 0 : NL;
-        if (SCHED <= 1) return slot >= 3 ? NL : (slot * NL + 2) / 3;
-        if (SCHED == 2) return slot <= 0 ? 0 : (slot == 1 ? NL / 2 : NL);          // slot 0 = load segment of phase 0, 1 = its MFMA segment
-        return slot <= 0 ? 0 : NL;
-    };
+    // schedule 0: the instructions [dma_lo(p), dma_lo(p + 1)) go out in the load segment of phase p (none in the last phase)
+    auto dma_lo = [](int slot) -> int { return slot >= 3 ? NL : (slot * NL + 2) / 3; };
 
     // ---- fragment read offsets: lane -> row lane%32, logical chunk 2p + lane/32 of phase p; physical chunk = logical ^ ((row >> 1) & 7)
     const int lr = lane & 31, hh = lane >> 5;
     // (8-bit: step ks reads chunks 4ks + 2hh + {0, 1}; 16-bit: step p reads chunk 2p + hh)
-    const int rd_lane = lr * ROWB + (((Q8 ? 2 * hh : hh) ^ (ROWB == 128 ? (lr >> 1) & 7 : (lr >> 2) & 3)) << 4);
+    const int rd_lane = lr * ROWB + (((Q8 ? 2 * hh : hh) ^ ((lr >> 1) & 7)) << 4);
     auto ld_frag = [&](const char* base, int step) -> frag_t {
         if constexpr (Q8) {
             const int off = rd_lane ^ (step << 6);
@@ -334,56 +328,6 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
             }
             stage ^= 1;
         }
-    } else if constexpr (SCHED == 4) {
-        // ---- one barrier per k tile: every wave walks the four 16-deep steps of a tile on its own, fragments double-buffered in registers
-        // (the reads of step p+1 are in flight while the MFMAs of step p issue), two DMA instructions of the next tile per step between
-        // the MFMAs.  The two waves of a SIMD interleave freely; s_barrier costs ~170 clocks here, this loop pays it once per 32 MFMAs.
-        static_assert(NS == 2 && NL % 4 == 0, "SCHED 4: two stages, DMA instructions spread over the four steps");
-        int stage = 0;
-        for (int kt = 0; kt < nk; ++kt) {
-            const char* const ps = p_rd + stage * STAGE;
-            const char* const ws = w_rd + stage * STAGE;
-            const int nstage = stage ^ 1;
-            const bool more = kt + 1 < nk;
-            frag_t wf[2][CT], pf[2][PT];
-            auto load = [&](int p, frag_t (&w_)[CT], frag_t (&p_)[PT]) {
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) w_[ct] = ld_frag(ws + ct * 32 * ROWB, p);
-#pragma unroll
-                for (int pt = 0; pt < PT; ++pt) p_[pt] = ld_frag(ps + pt * 32 * ROWB, p);
-            };
-            YP8_TS(0);
-            load(0, wf[0], pf[0]);
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                if (p < 3) load(p + 1, wf[(p + 1) & 1], pf[(p + 1) & 1]);
-                YP8_TS(1 + 2 * p);
-                __builtin_amdgcn_sched_barrier(0);
-                constexpr int NM = CT * PT, DPS = NL / 4;                 // MFMAs / DMA instructions per step
-                constexpr int every = NM / DPS > 0 ? NM / DPS : 1;
-#pragma unroll
-                for (int i = 0; i < NM; ++i) {
-                    const int ct = i / PT, pt = i % PT;
-                    if (!(probe & 1)) acc[ct][pt] = MM::mma(wf[p & 1][ct], pf[p & 1][pt], acc[ct][pt]);
-                    if ((i + 1) % every == 0 && (i + 1) / every <= DPS) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (more && !(probe & 2)) issue_one(nstage, p * DPS + (i + 1) / every - 1);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-                YP8_TS(2 + 2 * p);
-            }
-            if (kt + 2 < nk) prepare();
-            YP8_TS(9);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            YP8_TS(10);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            YP8_TS(11);
-            stage ^= 1;
-        }
     } else {
     if (g == 1) __builtin_amdgcn_s_barrier();                     // group 1 runs one segment behind group 0
 
@@ -411,7 +355,7 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
                 for (int idx = 0; idx < NL; ++idx)
                     if (p == 0 ? idx >= NLP : idx < NLP) issue_one(nstage, idx);
             }
-            if (more && !(probe & 2) && (SCHED == 0 || SCHED == 5 || (SCHED == 2 && p == 0))) {
+            if (SCHED == 0 && more && !(probe & 2)) {
 #pragma unroll
                 for (int idx = 0; idx < NL; ++idx)
                     if (idx >= dma_lo(p) && idx < dma_lo(p + 1)) issue_one(nstage, idx);
@@ -440,10 +384,6 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
             // ---- MFMA segment
             if (!(probe & 16)) __builtin_amdgcn_s_setprio(1);
             constexpr int NM = PH * CT * PT;
-            // DMA instructions issued from inside this segment: [mlo, mhi), one behind every `every`-th MFMA
-            const int mlo = SCHED == 1 ? dma_lo(p) : (SCHED == 2 && p == 0 ? dma_lo(1) : (SCHED == 3 && p == 0 ? 0 : NL));
-            const int mhi = SCHED == 1 ? dma_lo(p + 1) : NL;
-            const int every = (mhi - mlo) > 0 ? (NM / (mhi - mlo) > 0 ? NM / (mhi - mlo) : 1) : NM + 1;
             // (MFMAs have no side effects: nothing but data dependences keeps them between the two barriers.  The fragments pass through an
             // empty asm behind barrier a and the accumulators through one in front of barrier b -- without them the 8-bit instantiation
             // had BOTH phases' MFMAs sunk behind the second phase's loads: all fragments live at once, spilled)
@@ -458,14 +398,6 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
             for (int i = 0; i < NM; ++i) {
                 const int kk = i / (CT * PT), ct = (i / PT) % CT, pt = i % PT;
                 if (!(probe & 1)) acc[ct][pt] = MM::mma(wf[kk][ct], pf[kk][pt], acc[ct][pt]);
-                if (SCHED != 0 && SCHED != 5 && (i + 1) % every == 0) {
-                    const int di = mlo + (i + 1) / every - 1;
-                    if (di < mhi) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (more && !(probe & 2)) issue_one(nstage, di);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
             }
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
@@ -576,7 +508,7 @@ namespace {
 
 template <int DT, bool OUT_F32, int BP, int BC, int WP, int WC, int NS, bool STATS, int SCHED = 0>
 hipError_t launch_mma8(const ConvKArgs& a, int nblk, hipStream_t st) {
-    constexpr size_t lds = (size_t)NS * (BP + BC) * (SCHED == 5 ? 64 : 128);
+    constexpr size_t lds = (size_t)NS * (BP + BC) * 128;
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = conv_mma8_kernel<DT, OUT_F32, BP, BC, WP, WC, NS, STATS, SCHED>;
     static bool attr_set = false;        // per instantiation
@@ -596,13 +528,8 @@ hipError_t dispatch_mma8(int tile, const ConvKArgs& a, int nblk, hipStream_t st)
         case 42: return launch_mma8<DT, OUT_F32, 256, 128, 2, 2, 3, STATS>(a, nblk, st);
         case 43: return launch_mma8<DT, OUT_F32, 128, 256, 1, 4, 3, STATS>(a, nblk, st);
         case 44: return launch_mma8<DT, OUT_F32, 128, 128, 1, 4, 2, STATS>(a, nblk, st);
-        case 51: if constexpr (!STATS && !OUT_F32) return launch_mma8<DT, OUT_F32, 256, 256, 1, 4, 2, STATS, 1>(a, nblk, st); else return hipErrorInvalidValue;
-        case 52: if constexpr (!STATS && !OUT_F32) return launch_mma8<DT, OUT_F32, 256, 256, 1, 4, 2, STATS, 2>(a, nblk, st); else return hipErrorInvalidValue;
-        case 53: if constexpr (!STATS && !OUT_F32) return launch_mma8<DT, OUT_F32, 256, 256, 1, 4, 2, STATS, 3>(a, nblk, st); else return hipErrorInvalidValue;
         case 57: return launch_mma8<DT, OUT_F32, 256, 256, 1, 4, 2, STATS, 7>(a, nblk, st);
         case 58: return launch_mma8<DT, OUT_F32, 256, 256, 1, 4, 2, STATS, 8>(a, nblk, st);
-        case 61: return launch_mma8<DT, OUT_F32, 256, 256, 1, 4, 4, STATS, 5>(a, nblk, st);
-        case 54: if constexpr (!STATS && !OUT_F32) return launch_mma8<DT, OUT_F32, 256, 256, 1, 4, 2, STATS, 4>(a, nblk, st); else return hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }
 }
@@ -612,7 +539,7 @@ hipError_t dispatch_mma8(int tile, const ConvKArgs& a, int nblk, hipStream_t st)
 bool yp_mma8_tile_dims(int tile, int* bp, int* bc, int* stat_rows_px) {
     int p = 0, c = 0, r = 0;
     switch (tile) {
-        case 41: case 51: case 52: case 53: case 54: case 57: case 58: case 61: p = 256; c = 256; r = 128; break;
+        case 41: case 57: case 58: p = 256; c = 256; r = 128; break;
         case 42: p = 256; c = 128; r = 64; break;
         case 43: p = 128; c = 256; r = 64; break;
         case 44: p = 128; c = 128; r = 64; break;

@@ -183,10 +183,10 @@ _TUNE_CACHE = {}
 # with 32/64/128 output channels per workgroup on 8x16 pixel tiles, 13..15 the same on 4x16 tiles (rejected by the library
 # when it does not apply)
 # 41..44 / 57: the 8-wave 32x32x16 kernels of csrc/conv_mma8.hip (256x256 / 256x128 / 128x256 / 128x128 tiles; 57 = 256x256 with two-step
-# phases), for 16-bit layers whose channel counts are multiples of 64
-_TUNE_CANDIDATES = (1, 2, 3, 4, 5, 21, 22, 23, 24, 25, 26, 27, 10, 11, 12, 13, 14, 15, 41, 42, 43, 44, 57)
+# phases, 58 = 256x256 free-running), for 16-bit layers whose channel counts are multiples of 64
+_TUNE_CANDIDATES = (1, 2, 3, 4, 5, 21, 22, 23, 24, 25, 26, 27, 10, 11, 12, 13, 14, 15, 41, 42, 43, 44, 57, 58)
 # pixels per BatchNorm-statistics row of the variants whose rows are plain pixel blocks (the 3x3 halo kernels write one row per image tile)
-_STAT_ROW_PX = {41: 128, 57: 128, 61: 128}
+_STAT_ROW_PX = {41: 128, 57: 128, 58: 128}
 if os.environ.get("YP_TUNE_ONLY"):           # A/B experiments: restrict the autotuner to a subset of the variants
     _TUNE_CANDIDATES = tuple(int(v) for v in os.environ["YP_TUNE_ONLY"].split(","))
 
