@@ -260,3 +260,135 @@ def test_fp8_loss_curve_tracks_bf16(cuda):
     print("loss bf16: first20 %.4f last20 %.4f | fp8: first20 %.4f last20 %.4f" % (head(b), tail(b), head(f), tail(f)))
     assert tail(b) < head(b) and tail(f) < head(f)
     assert abs(tail(f) - tail(b)) <= 0.10 * abs(tail(b)), (tail(b), tail(f))
+
+
+# ---------------------------------------------------------------------------------------------
+# fp8 GRADIENTS: the dgrad path (e5m2 output gradient x e4m3 flipped filter) end to end
+# ---------------------------------------------------------------------------------------------
+class _FakeQuantTraining:
+    """The oracle with the product's 8-bit rule stated in PyTorch autograd (BASELINE.json configs[4] has no reference implementation; the
+    rule is csrc/fp8.hip's): every Conv block whose input channels are a multiple of 64 multiplies e4m3(x) by e4m3(w) (per-tensor scale
+    amax / 448); its input gradient is conv_transpose(e5m2(dy), e4m3(w)) (scale amax / 57344) when the OUTPUT channels are a multiple of 64;
+    weight gradients use the unquantised x and dy.  `storage`: None (fp32 between layers) or torch.bfloat16 (the product's storage: each
+    convolution's input, output and both gradients rounded to bf16) -- the distance between the two is the resolution of an end-to-end
+    comparison, exactly as the 16-bit floor of tests/test_gpu_bench_shapes.py."""
+
+    def __init__(self, storage):
+        self.storage, self.flag = storage, [False]
+
+    def __enter__(self):
+        import torch.nn.functional as F0
+        from oracle import net_oracle
+        st, flag = self.storage, self.flag
+        rnd = (lambda t: t.to(st).float()) if st is not None else (lambda t: t)
+        q4 = lambda v: ((v / (v.abs().amax().clamp_min(1e-30) / 448.0)).clamp(-448, 448).to(E4).float() * (v.abs().amax().clamp_min(1e-30) / 448.0))
+        q5 = lambda v: ((v / (v.abs().amax().clamp_min(1e-30) / 57344.0)).clamp(-57344, 57344).to(E5).float() * (v.abs().amax().clamp_min(1e-30) / 57344.0))
+
+        class Fn(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x, w, stride, pad, quant):
+                xs = rnd(x)
+                q_fwd, q_bwd = quant and x.shape[1] % 64 == 0, quant and w.shape[0] % 64 == 0
+                wq = q4(w) if (q_fwd or q_bwd) else rnd(w)
+                ctx.save_for_backward(xs, wq if q_bwd else rnd(w))
+                ctx.cfg = (stride, pad, q_bwd, tuple(w.shape))
+                return rnd(F0.conv2d(q4(xs) if q_fwd else xs, wq if q_fwd else rnd(w), None, stride, pad))
+
+            @staticmethod
+            def backward(ctx, dy):
+                xs, wb = ctx.saved_tensors
+                stride, pad, q_bwd, wshape = ctx.cfg
+                dys = rnd(dy)
+                dx = torch.nn.grad.conv2d_input(xs.shape, wb, q5(dys) if q_bwd else dys, stride, pad)
+                dw = torch.nn.grad.conv2d_weight(xs, wshape, dys, stride, pad)
+                return rnd(dx), dw, None, None, None
+
+        class Shim:
+            def __getattr__(self, name):
+                return getattr(F0, name)
+
+            @staticmethod
+            def conv2d(x, w, b=None, stride=1, padding=0):
+                quant, flag[0] = flag[0], False
+                y = Fn.apply(x, w, stride, padding, quant)
+                return y if b is None else y + b.view(1, -1, 1, 1)
+
+        def mark(name, x, w):
+            flag[0] = True
+            return x, w
+        self.saved = (net_oracle.F, net_oracle.FAKE_QUANT)
+        net_oracle.F, net_oracle.FAKE_QUANT = Shim(), mark
+        return self
+
+    def __exit__(self, *exc):
+        from oracle import net_oracle
+        net_oracle.F, net_oracle.FAKE_QUANT = self.saved
+        return False
+
+
+FP8_GRAD = dict(median=1.15, p90=1.15, worst=1.25, worst_abs=0.05, cosine=0.5)
+
+
+def test_fp8_parameter_gradients_against_the_fake_quantised_oracle(cuda):
+    """All parameter gradients of YOLOPoint-l with fp8 Conv operands (forward e4m3 x e4m3, dgrad e5m2 x e4m3, 16-bit weight gradients)
+    against PyTorch autograd through the oracle with the same rule (_FakeQuantTraining).  e4m3 / e5m2 rounding is discontinuous, so two
+    PyTorch statements of the same network that differ only by bf16 storage between layers already end far apart; that distance is the
+    floor, and the product -- which IS the bf16-storage variant -- must sit within 1.15x of it on the median and the 90th percentile of
+    the per-tensor relative L2 errors (1.25x + 0.05 on the worst tensor); tensors whose direction survives in the floor keep it in the product.
+    (Exactness of the dgrad kernels themselves: test_fp8_convolution_matches_torch_on_the_same_bytes / test_fp8_mx_kernel_... with act_fmt = 1.)
+    The product's scales are delayed by one pass: three identical forward / backward passes calibrate them to the current maxima."""
+    from helpers import make_model, rel_err
+    from oracle import net_oracle
+    from yolopoint_amd.models.common import invalidate_packed_weights
+    version, B, S, seed = "s", 4, 128, 41
+    m, sd = make_model(version, seed, dtype="bf16")
+    m = m.to(cuda).train()
+    m.model.fp8_train = True
+    x = net_oracle.synth_image(B, 3, S, S, seed)
+    grads = {}
+    for storage in (None, torch.bfloat16):
+        leaf = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in sd.items()}
+        with _FakeQuantTraining(storage):
+            o = net_oracle.yolopoint_forward(leaf, x, version, training=True, stats={})
+            if storage is None:
+                proj = net_oracle.output_projections(o, seed)
+            net_oracle.projected_loss(o, proj).backward()
+        grads[storage] = leaf
+    bn0 = [b.clone() for b in m.buffers()]
+    for i in range(3):                                   # passes 1, 2 calibrate the delayed scales (activations, gradients, filters)
+        m.zero_grad(set_to_none=True)
+        for b, s0 in zip(m.buffers(), bn0):
+            b.copy_(s0)
+        out = m(x.to(cuda))
+        net_oracle.projected_loss(out, proj, cuda).backward()
+        invalidate_packed_weights()
+    graph = next(iter(m.model._train_graphs.values()))[0]
+    assert graph.fp8 and graph.n_q8 >= 60, graph.n_q8     # forward AND dgrad convolutions ran on 8-bit operands
+    ref, floor_leaf = grads[None], grads[torch.bfloat16]
+    hip, floor, cosines = [], [], []
+    cosine = lambda a, b: float(torch.nn.functional.cosine_similarity(a.detach().cpu().flatten().double(), b.detach().cpu().flatten().double(), dim=0))
+    for name, p in m.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        g = ref[name].grad
+        hip.append((rel_err(p.grad, g)[1], name))
+        floor.append((rel_err(floor_leaf[name].grad, g)[1], name))
+        cosines.append((cosine(p.grad, g), cosine(floor_leaf[name].grad, g), name))
+    hip.sort(); floor.sort()
+    n = len(hip)
+    stats = lambda e: (e[n // 2][0], e[int(n * 0.9)][0], e[-1][0])
+    (hm, h9, hw), (fm, f9, fw) = stats(hip), stats(floor)
+    worst_cos = min(cosines)
+    print(f"fp8 gradient rel-L2 vs the fake-quantised oracle: HIP median {hm:.3f} p90 {h9:.3f} worst {hw:.3f} ({hip[-1][1]}) | "
+          f"oracle bf16-storage variant median {fm:.3f} p90 {f9:.3f} worst {fw:.3f} ({floor[-1][1]}); lowest HIP cosine {worst_cos[0]:.3f} "
+          f"(floor's for that tensor {worst_cos[1]:.3f}, {worst_cos[2]}), lowest floor cosine {min(c[1] for c in cosines):.3f}")
+    t = FP8_GRAD
+    assert hm <= t["median"] * fm and h9 <= t["p90"] * f9 and hw <= t["worst"] * fw + t["worst_abs"]
+    # Direction: 8-bit rounding through ~70 layers decorrelates most gradients of this random-weight network even between the two PyTorch
+    # statements (median relative error ~1.0, cosines around 0): there only the error STATISTICS above are comparable.  Where the floor
+    # itself keeps the direction (the layers within a few convolutions of the loss), the product must keep it as well.
+    stable = [(c_hip, c_floor, name) for c_hip, c_floor, name in cosines if c_floor >= 0.8]
+    print(f"{len(stable)} of {n} tensors keep their direction in the floor (cosine >= 0.8); lowest HIP cosine among them "
+          f"{min((c[0] for c in stable), default=1.0):.3f}")
+    assert len(stable) >= 4
+    for c_hip, c_floor, name in stable:
+        assert c_hip >= c_floor - 0.1, (name, c_hip, c_floor)
