@@ -286,7 +286,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": round(conv_bytes / max(n_conv, 1)),
-                         "kernel": "the convolution kernels: conv_igemm / conv3x3_halo / bottleneck_halo / stem_conv (all instantiations)",
+                         "kernel": "the convolution kernels: conv_igemm / conv_mma8 / conv3x3_halo / bottleneck_halo / stem_conv (all instantiations)",
                          "launches_per_step": n_conv, "conv_us_per_step": round(conv_ms * 1e3, 1),
                          "algorithmic_gflop_per_step": round(conv_flops / 1e9, 3),
                          "algorithmic_hbm_frac": round(conv_bytes / (conv_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if conv_ms > 0 else None,

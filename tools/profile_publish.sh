@@ -20,4 +20,6 @@ cp $S/bench_train_l_bf16.json profiles/${R}_bench_train_l_bf16.json
 cp $S/${R}_train_l_fp8_step_kernels.txt profiles/${R}_train_l_fp8_step_kernels.txt
 cp $S/bench_frame.json profiles/${R}_bench_frame.json
 cp $S/bench_export.json profiles/${R}_bench_export.json
+cp $S/train_traffic.json profiles/train_traffic.json
+cp $S/${R}_conv_bench_*.txt $S/${R}_mma8_pmc_*.txt profiles/
 ls -la profiles/

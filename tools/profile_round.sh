@@ -42,6 +42,23 @@ cd $ROOT
 python tools/profile_collect.py $R > /dev/null 2>&1
 mv $OUT/${R}_train_step_kernels.txt $OUT/${R}_train_l_fp8_step_kernels.txt
 mv $OUT/fp8/* $OUT/ && rmdir $OUT/fp8
+# HBM traffic of the training steps (roofline.traffic of the train / train_l_fp8 records): separate PMC passes
+cd /tmp
+for cfg in "s 8 bf16" "l 16 fp8"; do
+  set -- $cfg
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_tf -o f -- python $ROOT/bench.py --mode train --version $1 --batch $2 --dtype $3 --steps 3 --warmup 2 --no-cpu-baseline > $OUT/pmc_tf.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_tw -o w -- python $ROOT/bench.py --mode train --version $1 --batch $2 --dtype $3 --steps 3 --warmup 2 --no-cpu-baseline > $OUT/pmc_tw.log 2>&1
+  python $ROOT/tools/train_traffic.py $OUT/pmc_tf $OUT/pmc_tw ${1}_${2}_${3} $OUT/train_traffic.json
+  rm -rf $OUT/pmc_tf $OUT/pmc_tw
+done
+cd $ROOT
+# the 8-wave kernels: per-layer tables (16-bit and 8-bit) and the SQ / LDS counters of one deep layer per schedule
+python tools/conv_bench.py --set l32 --dtype bf16 --tiles 0,3,41,42,43,44,57,58 --min-cin 64 > $OUT/${R}_conv_bench_l32_bf16.txt 2>/dev/null
+python tools/conv_bench.py --set s64 --dtype f16 --tiles 0,3,41,42,43,44,57,58 --min-cin 64 > $OUT/${R}_conv_bench_s64_f16.txt 2>/dev/null
+python tools/conv_bench_fp8.py --tiles 0,2,3,57 > $OUT/${R}_conv_bench_fp8_l32.txt 2>/dev/null
+bash tools/probe/pmc_mma8.sh l32 c256_256_k3_40 41,57,58,3 > $OUT/${R}_mma8_pmc_c256_256_k3_40.txt 2>&1
+bash tools/probe/pmc_mma8.sh l32 c2048_1024_k1_20 41,57,3 > $OUT/${R}_mma8_pmc_c2048_1024_k1_20.txt 2>&1
+rm -rf $ROOT/gpurun_out/pmc8_*
 # raw traces are large: keep only what profile_collect distilled
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma $OUT/trace_train
 ls -la $OUT
