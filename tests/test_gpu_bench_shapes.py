@@ -93,6 +93,25 @@ def test_config1_s_bs8_640_f16_graph_as_benchmarked(cuda):
     _check_against_f16_floor(got, ref, _oracle_f16_floor("s", sd, x))
 
 
+def test_v52_s_bs8_640_f16_graph_as_benchmarked(cuda):
+    """The `v52` record of bench.py: YOLOPointv52-s (the model reference configs/kitti_inference.yaml:2 selects), batch 8, 640x640, f16,
+    fused BN, hipGraph replay -- against the fp32 oracle, held to the fp16 floor of the v52 network."""
+    m, sd = make_model("s", 1234, dtype="f16", model_name="YOLOPointv52")
+    x = net_oracle.synth_image(8, 3, 640, 640, 1234)
+    torch.set_num_threads(min(32, torch.get_num_threads() or 8))
+    with torch.no_grad():
+        ref = net_oracle.yolopointv52_forward(sd, x, "s")
+        with net_oracle.half_storage(torch.float16):
+            floor = net_oracle.yolopointv52_forward(net_oracle.fused_state_dict(sd), x, "s")
+    m = m.to(cuda)
+    m.fuse()
+    m.model.use_graph = True
+    with torch.no_grad():
+        m(x.to(cuda))
+        got = m(x.to(cuda))
+    _check_against_f16_floor(got, ref, floor)
+
+
 def test_config1_forward_is_deterministic(cuda):
     """Six replays of the benchmarked plan (three eager, three through the hipGraph) are bit-identical.  Regression test: the fused
     Bottleneck kernel refilled a filter-ring stage one barrier after its last read WITHOUT retiring the reads first -- the compiler had

@@ -151,11 +151,62 @@ __global__ __launch_bounds__(1024) void k16(unsigned long long* out, float* sink
     float s = 0; for (int i = 0; i < 4; ++i) s += acc[i][lane & 15];
     if (s == 123.25f || racc[0] == 0x1234567u) sink[0] = s + racc[1];
 }
+//   k4: FOUR waves per workgroup (one per SIMD), TWO workgroups per CU (64 KiB of LDS each): per round 8 MFMAs + 6 reads + NDMA DMA instructions,
+//   s_barrier (4 waves) every `bar_every` rounds -- the two waves of a SIMD belong to different workgroups: one's barrier stall is the other's MFMA time
+template <int NDMA>
+__global__ __launch_bounds__(256) void k4(unsigned long long* out, float* sink, int rounds, int prio, int bar_every, const char* gsrc) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < 16384; i += blockDim.x) reinterpret_cast<unsigned*>(smem)[i] = 0x3c003c00u + i;
+    __syncthreads();
+    const int lr = lane & 31, hh = lane >> 5;
+    const int base = lr * 128 + ((hh ^ ((lr >> 1) & 7)) << 4) + (wave & 1) * 16384;
+    f32x16 acc[8];
+    for (int i = 0; i < 8; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    bf16x8 fa[2], fb[4];
+    for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(smem + base + i * 4096);
+    for (int i = 0; i < 4; ++i) fb[i] = *reinterpret_cast<const bf16x8*>(smem + base + 8192 + i * 2048);
+    u32x4 racc = {0, 0, 0, 0};
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
+    const char* src = gsrc + (size_t)(blockIdx.x & 255) * 65536;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int t = 0; t < rounds; ++t) {
+        u32x4 v[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) v[r] = *reinterpret_cast<const u32x4*>(smem + base + ((t & 3) << 5) + (r & 3) * 2048 + (r >> 2) * 4096);
+        __builtin_amdgcn_sched_barrier(0);
+        if (prio) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i >> 2], fb[i & 3], acc[i], 0, 0, 0);
+            if ((NDMA >= 1 && i == 1) || (NDMA >= 2 && i == 4) || (NDMA >= 3 && i == 6)) {
+                __builtin_amdgcn_sched_barrier(0);
+                glds16(src, (unsigned)((t & 3) * 12288 + i * 4096 / 2 + wave * 1024 + lane * 16) & 65535u, lds0 + 32768 + (unsigned)(((t & 1) * 3 + (i > 1) + (i > 4)) * 4096 + wave * 1024));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (prio) __builtin_amdgcn_s_setprio(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (bar_every && (t % bar_every) == bar_every - 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) racc += v[r];
+        asm volatile("" : "+v"(racc));
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
+    float s = 0; for (int i = 0; i < 8; ++i) s += acc[i][lane & 15];
+    if (s == 123.25f || racc[0] == 0x1234567u) sink[0] = s + racc[1];
+}
 int main() {
     unsigned long long* d; float* sink; char* g; hipMalloc(&d, 8 * 8192); hipMalloc(&sink, 64); hipMalloc(&g, 256 * 65536 + 4096); hipMemset(g, 0, 256 * 65536 + 4096);
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     const int rounds = 2000;
-    for (int mode = 3; mode < 9; ++mode) {
+    for (int mode = 5; mode < 8; mode += 2) {
         for (int rep = 0; rep < 2; ++rep) { k<<<256, 512, 131072>>>(d, sink, rounds, mode, g); hipDeviceSynchronize(); }
         static unsigned long long h[8192]; hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
         double mf = 0, rd = 0, tot = 0;
@@ -169,6 +220,17 @@ int main() {
         static unsigned long long h[8192]; hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
         double tot = 0; for (int b = 0; b < 256; ++b) tot += h[b]; tot /= 256;
         printf("k16 (16 waves, 4 MFMA + 4 reads + 1 DMA per round) prio %d barrier %d: workgroup %8.0f clk = %6.1f per 16 MFMAs per SIMD (ideal 512)\n", prio, bar, tot, tot / (rounds / 2));
+    }
+    hipFuncSetAttribute((const void*)k4<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipFuncSetAttribute((const void*)k4<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    for (int ndma = 2; ndma <= 3; ++ndma) for (int prio = 0; prio < 2; ++prio) for (int bar : {0, 2, 4}) {
+        for (int rep = 0; rep < 2; ++rep) {
+            if (ndma == 2) k4<2><<<512, 256, 65536>>>(d, sink, rounds / 2, prio, bar, g); else k4<3><<<512, 256, 65536>>>(d, sink, rounds / 2, prio, bar, g);
+            hipDeviceSynchronize();
+        }
+        static unsigned long long h[8192]; hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+        double tot = 0; for (int b = 0; b < 512; ++b) tot += h[b]; tot /= 512;
+        printf("k4 (2 workgroups of 4 waves per CU, 8 MFMA + 6 reads + %d DMA per round) prio %d barrier every %d: %8.0f clk = %6.1f per 16 MFMAs per SIMD (ideal 512)\n", ndma, prio, bar, tot, tot / (rounds / 2));
     }
     printf("(8 MFMAs of 32 clk = 256 clk per round; 6 reads alone on a SIMD ~176 clk per round)\n");
     return 0;
