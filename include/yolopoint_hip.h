@@ -384,6 +384,14 @@ int yp_infonce_bwd(const float* da, const float* db, const int* idx, const int* 
  * backward accumulates with atomics. */
 int yp_points_sample_fwd(const float* map_nhwc, int B, int H, int W, int D, const float* uv, int P, float* out, void* stream);
 int yp_points_sample_bwd(const float* g, int B, int H, int W, int D, const float* uv, int P, float* gmap_nhwc, void* stream);
+/* The backward of the lookup without atomics and without a zeroed map: yp_points_sample_taps writes, per (point, tap), the cell it touches
+ * (b*H*W + y*W + x, INT_MAX for taps outside the map / of weight 0) into keys [B*P*4]; the caller sorts (key, 4*point + tap) pairs by key
+ * (stable) and builds CSR offsets [B*H*W + 1] over the cells -- label-only work, once per batch of sample points; yp_points_sample_bwd_sorted
+ * then writes EVERY row of gmap [B][H][W][D]: the sum of its contributions in sorted order (bit-reproducible), zeros where nothing lands.
+ * replaces: the scatter of grid_sampler_2d_backward in loss.backward() (utils/loss_functions.py:553-560, train.py:245). */
+int yp_points_sample_taps(const float* uv, int B, int P, int H, int W, int* keys, void* stream);
+int yp_points_sample_bwd_sorted(const float* g, int B, int H, int W, int D, const float* uv, int P, const int* order, const int* offsets, float* gmap_nhwc,
+                                void* stream);
 
 /* YOLOv5 object loss of ONE Detect level, value and gradient (reference utils/loss_functions.py:90-176 ComputeLoss.__call__ body
  * of the per-level loop; CIoU: utils/metrics_yolo.py:202-240).  p / dp: [cells, no] fp32 with cells = B*na*ny*nx and no = 5 + nc;

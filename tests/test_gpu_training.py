@@ -233,6 +233,19 @@ def test_native_point_sample_matches_grid_sample(cuda, B, D, H, W, P):
     assert got.shape == ref.shape
     assert rel_err(got, ref)[0] < 1e-5
     assert rel_err(desc.grad, gref)[0] < 1e-5
+    # the atomic-free backward (cell-sorted (point, tap) list, every cell written once, fixed summation order): same gradient, and
+    # bit-identical from run to run although many points share cells here (P points on an H x W map)
+    from yolopoint_amd.utils.loss_functions import point_sample_index
+    inv = point_sample_index(uv, H, W)
+    runs = []
+    for _ in range(2):
+        desc.grad = None
+        got2 = _PointSampleNative.apply(desc, uv, *inv)
+        (got2 * proj).sum().backward()
+        runs.append(desc.grad.clone())
+    assert torch.equal(got2, got)
+    assert rel_err(runs[0], gref)[0] < 1e-5
+    assert torch.equal(runs[0], runs[1])
 
 
 @pytest.mark.parametrize("B,Hc,Wc,layout", [(8, 80, 80, "nhwc"), (2, 8, 12, "nchw"), (3, 5, 7, "nhwc")])

@@ -115,6 +115,8 @@ SIGNATURES = {
     "yp_infonce_bwd_db": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p]),
     "yp_infonce_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p]),
     "yp_homo_combine": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p]),
+    "yp_points_sample_taps": (_i, [_p, _i, _i, _i, _i, _p, _p]),
+    "yp_points_sample_bwd_sorted": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p]),
     "yp_points_sample_fwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p]),
     "yp_points_sample_bwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p]),
     "yp_detloss_workspace_bytes": (_sz, [_i, _i, _i]),

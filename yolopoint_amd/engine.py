@@ -183,7 +183,7 @@ class TrainStep:
             tgt_ = self.obj_loss.assign(shapes, batch['box_labels']) if prepare else None
             dch = getattr(m.model, "_desc_channels", None) or m.model.ConvDesc.out_channels
             nce_ = infonce_prepare(batch['warped_valid_mask'], batch['inv_homographies'], (B, dch, img.shape[-2] // 8, S // 8), True,
-                                   self.sparse['num_samples_per_image'], self.sparse['num_masked_non_matches_per_match'], 8, dev) if prepare else None
+                                   self.sparse['num_samples_per_image'], self.sparse['num_masked_non_matches_per_match'], 8, dev, pair_index=self.pair) if prepare else None
             if self.pair:       # both passes' labels / masks as one 2B batch (image pass first)
                 lab_ = (labels2Dto3D(torch.cat((batch['labels_2D'], batch['warped_labels']))),
                         getMasks(torch.cat((batch['valid_mask'], batch['warped_valid_mask'])), dev), None, None)

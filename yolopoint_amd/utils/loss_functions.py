@@ -351,13 +351,13 @@ class _PointSampleNative(torch.autograd.Function):
 
     @staticmethod
     @_guarded
-    def forward(ctx, desc, uv):
+    def forward(ctx, desc, uv, order=None, offsets=None):
         from .. import _hip
         B, D, H, W = desc.shape
         P = uv.shape[1]
         out = torch.empty((B, P, D), dtype=torch.float32, device=desc.device)
         _hip.check(_hip.lib().yp_points_sample_fwd(desc.data_ptr(), B, H, W, D, uv.data_ptr(), P, out.data_ptr(), _hip.stream_ptr()))
-        ctx.save_for_backward(uv)
+        ctx.save_for_backward(uv, order, offsets)
         ctx.dims = (B, D, H, W, P)
         return out
 
@@ -365,12 +365,31 @@ class _PointSampleNative(torch.autograd.Function):
     @_guarded
     def backward(ctx, g):
         from .. import _hip
-        (uv,) = ctx.saved_tensors
+        uv, order, offsets = ctx.saved_tensors
         B, D, H, W, P = ctx.dims
-        gmap = torch.zeros((B, H, W, D), dtype=torch.float32, device=g.device)
         g = g.contiguous()
-        _hip.check(_hip.lib().yp_points_sample_bwd(g.data_ptr(), B, H, W, D, uv.data_ptr(), P, gmap.data_ptr(), _hip.stream_ptr()))
-        return gmap.permute(0, 3, 1, 2), None
+        if order is not None:        # cell-sorted (point, tap) list (point_sample_index): one pass, no atomics, no zero-fill, fixed summation order
+            gmap = torch.empty((B, H, W, D), dtype=torch.float32, device=g.device)
+            _hip.check(_hip.lib().yp_points_sample_bwd_sorted(g.data_ptr(), B, H, W, D, uv.data_ptr(), P, order.data_ptr(), offsets.data_ptr(), gmap.data_ptr(),
+                                                              _hip.stream_ptr()))
+        else:
+            gmap = torch.zeros((B, H, W, D), dtype=torch.float32, device=g.device)
+            _hip.check(_hip.lib().yp_points_sample_bwd(g.data_ptr(), B, H, W, D, uv.data_ptr(), P, gmap.data_ptr(), _hip.stream_ptr()))
+        return gmap.permute(0, 3, 1, 2), None, None, None
+
+
+def point_sample_index(uv, H, W):
+    """uv [B, P, 2] (normalised sample coordinates on an H x W map) -> (order int32 [B*P*4], offsets int32 [B*H*W + 1]): the (point, tap)
+    pairs of the bilinear lookup sorted by the cell they touch and the CSR offsets of the cells, for _PointSampleNative's atomic-free
+    backward.  Label-only work (it depends on the sample points alone): a training step builds it beside the forward pass."""
+    from .. import _hip
+    B, P = uv.shape[0], uv.shape[1]
+    uv = uv.contiguous()
+    keys = torch.empty((B * P * 4,), dtype=torch.int32, device=uv.device)
+    _hip.check(_hip.lib().yp_points_sample_taps(uv.data_ptr(), B, P, H, W, keys.data_ptr(), _hip.stream_ptr()))
+    skeys, order = torch.sort(keys, stable=True)
+    offsets = torch.searchsorted(skeys, torch.arange(B * H * W + 1, device=uv.device, dtype=torch.int32)).to(torch.int32)
+    return order.to(torch.int32), offsets
 
 
 def infonce_edges(rnd):
@@ -406,16 +425,20 @@ def infonce(descriptors, descriptors_warped, mask_valid_warp, inv_homographies, 
     ua, ub, rnd = prepared[:3]
     edges = prepared[3] if len(prepared) > 3 else None
 
-    def sample(desc, idx):
+    def sample(desc, idx, inverse=None):
         if (desc.is_cuda and desc.dtype == torch.float32 and desc.shape[1] % 64 == 0 and desc.shape[1] <= 256 and desc.stride(1) == 1
                 and desc.permute(0, 2, 3, 1).is_contiguous() and os.environ.get("YP_NATIVE_INFONCE", "1") != "0"):
+            if inverse is not None:
+                return _PointSampleNative.apply(desc, idx.contiguous(), *inverse)
             return _PointSampleNative.apply(desc, idx.contiguous())
         return F.grid_sample(desc, idx.unsqueeze(1), mode='bilinear', align_corners=True).squeeze(2).transpose(1, 2)
 
     if descriptors_pair is not None and rnd.shape[1] + 1 <= 512 and os.environ.get("YP_NATIVE_INFONCE", "1") != "0":
         # both passes' descriptor maps as one [2B, D, Hc, Wc] tensor (image pass first; `descriptors` / `descriptors_warped` are its halves):
         # one sampling launch, one loss call, ONE gradient map for the whole tensor
-        dab = sample(descriptors_pair, torch.cat((ua, ub)))
+        # (prepared[4], when present: the pair's sample points and their cell-sorted tap list, built with the sampling)
+        pair_inv = prepared[4] if len(prepared) > 4 else None
+        dab = sample(descriptors_pair, pair_inv[0], pair_inv[1:]) if pair_inv is not None else sample(descriptors_pair, torch.cat((ua, ub)))
         if edges is None:
             edges = infonce_edges(rnd)
         return _InfoNCEPairNative.apply(dab.flatten(0, 1), *edges, float(tau))
@@ -435,7 +458,7 @@ def infonce(descriptors, descriptors_warped, mask_valid_warp, inv_homographies, 
 
 
 def infonce_prepare(mask_valid_warp, inv_homographies, desc_shape, on_device, num_samples_per_image=1500,
-                    num_masked_non_matches_per_match=120, cell_size=8, device='cpu', perm_fn=None, randint_fn=None):
+                    num_masked_non_matches_per_match=120, cell_size=8, device='cpu', perm_fn=None, randint_fn=None, pair_index=False):
     """The label-only half of `infonce`: which cells are matched (normalised sample coordinates ua, ub [B, pool, 2]) and
     which matches serve as negatives (rnd [n, negs]).  It needs one host sync (the common pool size), so a training step
     calls it before the forward passes are launched."""
@@ -489,7 +512,11 @@ def infonce_prepare(mask_valid_warp, inv_homographies, desc_shape, on_device, nu
                         break
             rnd = torch.from_numpy(np.ascontiguousarray(rnd.T)).to(ua.device)
         edges = infonce_edges(rnd) if (on_device and rnd.is_cuda) else None
-    return ua, ub, rnd, edges
+        pair_inv = None
+        if pair_index and on_device and ua.is_cuda and os.environ.get("YP_SAMPLE_SORTED", "1") != "0":
+            uab = torch.cat((ua, ub)).contiguous()
+            pair_inv = (uab,) + point_sample_index(uab, Hc, Wc)
+    return (ua, ub, rnd, edges, pair_inv) if pair_inv is not None else (ua, ub, rnd, edges)
 
 
 descriptor_loss_sparse = infonce      # the name train.py imports it under (train.py:8)
