@@ -276,8 +276,9 @@ int yp_maxpool5_bwd(YpView x, YpView dy, YpView dx, int dtype, int B, int accumu
 int yp_l2norm_bwd_f32(YpView x, YpView g, YpView dx, int B, int C, void* stream);
 /* backward of MaxPool2d(2,2) (YOLOPointv52 descriptor branch, reference models/YOLOPoint.py:311): dx (+)= dy at the first maximum of each window */
 int yp_maxpool2_bwd(YpView x, YpView dy, YpView dx, int dtype, int B, int accumulate, void* stream);
-/* fp32 gradient of the permuted Detect output [B,na,ny,nx,no] -> NHWC view in `dtype` (inverse of models/yolo.py:53) */
-int yp_detect_bwd_pack(const float* gx, int B, int na, int no, YpView out, int dtype, void* stream);
+/* fp32 gradient of the permuted Detect output [B,na,ny,nx,no] -> NHWC view in `dtype` (inverse of models/yolo.py:53), multiplied by
+ * the device scalar *scale_dev first (NULL: 1) -- the upstream factor of the object loss in train.py:240, folded into this pass */
+int yp_detect_bwd_pack(const float* gx, int B, int na, int no, YpView out, int dtype, const float* scale_dev, void* stream);
 /* NHWC view (optionally through its 2x upsample) -> [C][H][W][Bpad] copy, batch zero-padded (wgrad operand layout) */
 int yp_to_chwb(YpView in, int dtype, int B, int C, void* out, int Bpad, void* stream);
 /* out[c] (+)= sum over the B*H*W rows of view[., c]  (bias gradients); workspace as yp_bn_workspace_bytes */
@@ -323,6 +324,9 @@ int yp_wgrad_unpack_batch(const YpUnpackEntry* table_dev, int n_entries, int tot
  * zero row last), so a training step re-derives its 16-bit filters on the device without host work:
  *   mode 0  forward filter of input-channel slice [c0, c0+Cj):  dst[n][(r*S+s)*Cj + c]       = w[n][c0+c][r][s]
  *   mode 1  dgrad filter (flipped, channel-transposed):         dst[c][(r*S+s)*Cout_pad + n] = w[n][c0+c][R-1-r][S-1-s]
+ *   mode 2  image-like filter (Cin <= 4, S even) for the 16-bit stem, which reads the packed image as [H][W/2][8] (two pixels of
+ *           4 channels):                                        dst[n][(r*S/2 + s/2)*8 + (s%2)*4 + c] = w[n][c][r][s]  (c < Cin, else 0)
+ *   mode 3  the same filter padded to 4 channels (fp32 plans):  dst[n][(r*S+s)*4 + c]        = w[n][c][r][s]
  * bias (may be NULL) is copied, zero padded, to bias_dst[Npad].
  * replaces: the conv.weight casts autocast performs every forward (reference train.py:206) + autograd's filter transposes */
 int yp_pack_weight(const float* w, int Cout, int Cin, int R, int S, int c0, int Cj, int mode, int Cout_pad, void* dst, int Kpad,
@@ -388,10 +392,12 @@ int yp_points_sample_bwd(const float* g, int B, int H, int W, int D, const float
  * (b*H*W + y*W + x, INT_MAX for taps outside the map / of weight 0) into keys [B*P*4]; the caller sorts (key, 4*point + tap) pairs by key
  * (stable) and builds CSR offsets [B*H*W + 1] over the cells -- label-only work, once per batch of sample points; yp_points_sample_bwd_sorted
  * then writes EVERY row of gmap [B][H][W][D]: the sum of its contributions in sorted order (bit-reproducible), zeros where nothing lands.
+ * row_scale_dev (may be NULL): rows [0, n_scaled_rows) of g are multiplied by this device scalar before they are used (the anchor half of
+ * yp_infonce_fwd_grad's gradient, which still lacks dL/dloss / (tau * n)) -- no separate scaling pass.
  * replaces: the scatter of grid_sampler_2d_backward in loss.backward() (utils/loss_functions.py:553-560, train.py:245). */
 int yp_points_sample_taps(const float* uv, int B, int P, int H, int W, int* keys, void* stream);
-int yp_points_sample_bwd_sorted(const float* g, int B, int H, int W, int D, const float* uv, int P, const int* order, const int* offsets, float* gmap_nhwc,
-                                void* stream);
+int yp_points_sample_bwd_sorted(const float* g, int B, int H, int W, int D, const float* uv, int P, const int* order, const int* offsets,
+                                const float* row_scale_dev, int n_scaled_rows, float* gmap_nhwc, void* stream);
 
 /* YOLOv5 object loss of ONE Detect level, value and gradient (reference utils/loss_functions.py:90-176 ComputeLoss.__call__ body
  * of the per-level loop; CIoU: utils/metrics_yolo.py:202-240).  p / dp: [cells, no] fp32 with cells = B*na*ny*nx and no = 5 + nc;
@@ -425,6 +431,37 @@ size_t yp_detloss_workspace_bytes(int B, int Hc, int Wc);
 int yp_detloss(const float* semi, const int64_t* semi_strides, const float* target, const int64_t* target_strides, const float* mask, int B, int Hc, int Wc,
                float* dsemi, float* sums, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same loss straight from the 2-D label maps, as train.py:212-231 feeds it (labels2Dto3D(labels_2D) / getMasks(valid_mask),
+ * utils/utils.py:184-209 / :103-116) -- neither the [B,65,Hc,Wc] target nor the cell mask is built by framework kernels:
+ *   yp_cell_mask   valid2d [B,1,H,W] fp32 -> mask [B,H/8,W/8] (product of a cell's 64 pixels) and mask_sum[0] = its sum.  Label-only.
+ *   yp_detloss2d   semi as above; labels2d [B,1,H,W]: the target of a cell is its 64 pixels and the dustbin 1 - sum (0 when < 1),
+ *                  divided by their sum.  loss[0] = sum(mask * BCE) / (mask_sum + 1e-10); dsemi (its own strides: the network's
+ *                  gradient buffer) = d loss / d semi * gscale -- the final gradient, no scaling pass.
+ * Both take a workspace of yp_cell_mask_workspace_bytes(B, H, W). */
+size_t yp_cell_mask_workspace_bytes(int B, int H, int W);
+int yp_cell_mask(const float* valid2d, int B, int H, int W, float* mask, float* mask_sum, void* workspace, size_t workspace_bytes, void* stream);
+int yp_detloss2d(const float* semi, const int64_t* semi_strides, const float* labels2d, const float* mask, const float* mask_sum, float gscale, int B, int H,
+                 int W, float* dsemi, const int64_t* dsemi_strides, float* loss, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The pieces between the plans of a training step (reference train.py:189-259), one launch each (csrc/step.hip):
+ *   yp_fill_zero     optimizer.zero_grad() over the gradient arena (16-byte aligned pointer and size)
+ *   yp_multi_add     loss.backward()'s accumulation into p.grad for a whole table of (dst, src, n) at once: dst += src (mode 0) or
+ *                    dst = src (mode 1); blocks of 1024 elements are numbered across the table, blk0 = an entry's first, sorted by blk0
+ *   yp_counters_add  BatchNorm's num_batches_tracked (+= inc for every int64 counter of a device pointer table)
+ *   yp_loss_combine  train.py:232-241: out4[0] = (sum(det_losses[0..n_det)) + lambda_desc * mean(nce_rows[0..n_rows))) + lambda_obj *
+ *                    sum(obj_sums[0..3)), times `scale` when it is not 1; out4[1..3] = the detector / descriptor / object terms;
+ *                    *desc_scale_out = desc_scale (the device scalar yp_infonce_bwd_db reads; NULL: not written) */
+typedef struct YpAddEntry {
+    float* dst;
+    const float* src;
+    int64_t n, mode, blk0;
+} YpAddEntry;
+int yp_fill_zero(void* p, size_t bytes, void* stream);
+int yp_multi_add(const YpAddEntry* table_dev, int n_entries, int total_blocks, void* stream);
+int yp_counters_add(int64_t* const* table_dev, int n, int64_t inc, void* stream);
+int yp_loss_combine(const float* det_losses, int n_det, const float* nce_rows, int n_rows, const float* obj_sums, float lambda_desc, float lambda_obj, float scale,
+                    float desc_scale, float* out4, float* desc_scale_out, void* stream);
+
 /* One generic launch record: `op` selects one of the functions above, the slots carry its arguments in the
  * order documented next to each opcode.  Lets training plans replay any mix of launches (yp_plan_add_op). */
 enum {
@@ -436,7 +473,7 @@ enum {
     YP_OP_ADD_VIEWS = 14,     /* v0=src v1=dst; i0=dtype i1=B i2=accumulate */
     YP_OP_MAXPOOL5_BWD = 15,  /* v0=x v1=dy v2=dx; i0=dtype i1=B i2=accumulate; p0=ws n0=ws_bytes */
     YP_OP_L2NORM_BWD = 16,    /* v0=x v1=g v2=dx; i1=B i2=C */
-    YP_OP_DETECT_BWD_PACK = 17, /* f0=gx; v0=out; i0=dtype i1=B i2=na i3=no */
+    YP_OP_DETECT_BWD_PACK = 17, /* f0=gx f1=scale (device scalar, may be NULL); v0=out; i0=dtype i1=B i2=na i3=no */
     YP_OP_TO_CHWB = 18,       /* v0=in; i0=dtype i1=B i2=C i3=Bpad; p0=out */
     YP_OP_COL_SUM = 19,       /* v0=view; i0=dtype i1=B i2=accumulate; g0=out; p0=ws n0=ws_bytes */
     YP_OP_MEMSET0 = 20,       /* p0=ptr n0=bytes */

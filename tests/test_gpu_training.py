@@ -714,3 +714,40 @@ def test_model_wrapped_in_ddp_gets_the_same_gradients_through_autograd(cuda):
             h.remove()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("gas", [1, 2])
+def test_native_loss_stage_equals_the_autograd_stage(cuda, monkeypatch, gas):
+    """engine.TrainStep's native loss stage (losses read the heads in the plan's buffers and write final head gradients into the backward
+    plans' seeds; label preparation and the loss sum of train.py:232-241 as native launches) against the autograd formulation of the same
+    step (YP_NATIVE_STAGE=0): same draws, same weights -> every parameter gradient bit for bit, the loss to fp32 rounding, and the same
+    weights after the optimizer steps.  gas = 2 exercises the 1 / gas factor on every head."""
+    import copy
+    from yolopoint_amd.engine import TrainStep, synthetic_batch
+    m, _ = make_model("n", 21, dtype="bf16")
+    m = m.to(cuda).train()
+    m2 = copy.deepcopy(m)
+    batches = [synthetic_batch(2, 128, cuda, 50 + i) for i in range(gas)]
+    # warped-valid masks with holes and non-identity homographies, so that cell masks and sampling are not the trivial case
+    for i, b in enumerate(batches):
+        b['warped_valid_mask'][:, :, 16 * i:16 * i + 24, 40:88] = 0.0
+        b['valid_mask'][:, :, 100:, :30] = 0.0
+        b['inv_homographies'] = b['inv_homographies'] + torch.tensor([[0.0, 0.02, 0.05], [-0.03, 0.0, 0.02], [0.0, 0.0, 0.0]], device=cuda)
+    out = []
+    for mode, mm in (("0", m), ("1", m2)):
+        monkeypatch.setenv("YP_NATIVE_STAGE", mode)
+        step = TrainStep(mm, cuda, img_size=128, gas=gas)
+        step.sparse = dict(num_samples_per_image=100, num_masked_non_matches_per_match=30)
+        losses = []
+        for it in range(2):
+            torch.manual_seed(1234 + it)
+            losses.append(float(step(batches if gas > 1 else batches[0])))
+            if it == 0:
+                grads = [p.grad.clone() for p in mm.parameters()]
+        out.append((losses, grads, [p.detach().clone() for p in mm.parameters()], [b.detach().clone() for b in mm.buffers()]))
+    (l0, g0, p0, b0), (l1, g1, p1, b1) = out
+    assert all(abs(a - b) <= 2e-6 * abs(a) for a, b in zip(l0, l1)), (l0, l1)
+    bad = [k for (k, _), a, b in zip(m.named_parameters(), g0, g1) if not torch.equal(a, b)]
+    assert not bad, bad[:5]
+    assert all(torch.equal(a, b) for a, b in zip(p0, p1))
+    assert all(torch.equal(a, b) for a, b in zip(b0, b1))

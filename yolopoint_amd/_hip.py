@@ -91,7 +91,7 @@ SIGNATURES = {
     "yp_maxpool5_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "yp_maxpool5_bwd": (_i, [YpView, YpView, YpView, _i, _i, _i, _p, _sz, _p]),
     "yp_l2norm_bwd_f32": (_i, [YpView, YpView, YpView, _i, _i, _p]),
-    "yp_detect_bwd_pack": (_i, [_p, _i, _i, _i, YpView, _i, _p]),
+    "yp_detect_bwd_pack": (_i, [_p, _i, _i, _i, YpView, _i, _p, _p]),
     "yp_to_chwb": (_i, [YpView, _i, _i, _i, _p, _i, _p]),
     "yp_cast_from_f32": (_i, [YpView, YpView, _i, _i, _p]),
     "yp_conv_wgrad": (_i, [YpView, YpView, _i, _i, _i, _i, _p, _p]),
@@ -116,11 +116,18 @@ SIGNATURES = {
     "yp_infonce_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p]),
     "yp_homo_combine": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p]),
     "yp_points_sample_taps": (_i, [_p, _i, _i, _i, _i, _p, _p]),
-    "yp_points_sample_bwd_sorted": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p]),
+    "yp_points_sample_bwd_sorted": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _i, _p, _p]),
     "yp_points_sample_fwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p]),
     "yp_points_sample_bwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p]),
     "yp_detloss_workspace_bytes": (_sz, [_i, _i, _i]),
     "yp_detloss": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _sz, _p]),
+    "yp_cell_mask_workspace_bytes": (_sz, [_i, _i, _i]),
+    "yp_cell_mask": (_i, [_p, _i, _i, _i, _p, _p, _p, _sz, _p]),
+    "yp_detloss2d": (_i, [_p, _p, _p, _p, _p, _f, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
+    "yp_fill_zero": (_i, [_p, _sz, _p]),
+    "yp_multi_add": (_i, [_p, _i, _i, _p]),
+    "yp_counters_add": (_i, [_p, _i, _i64, _p]),
+    "yp_loss_combine": (_i, [_p, _i, _p, _i, _p, _f, _f, _f, _f, _p, _p, _p]),
     "yp_objloss_level": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _i, _f, _f, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p]),
     "yp_objloss_level_dev": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _f, _f, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p]),
     "yp_build_targets": (_i, [_p, _i, _p, _i, _i, _p, _f, _i, _p, _p, _p, _p, _p, _p]),

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void points_taps_kernel(const float* __restric
 template <int VPL>
 __global__ __launch_bounds__(256) void points_sample_bwd_sorted_kernel(const float* __restrict__ g, int H, int W, int D, const float* __restrict__ uv, int ncells,
                                                                        const int* __restrict__ order, const int* __restrict__ offsets,
-                                                                       float* __restrict__ gmap) {
+                                                                       const float* __restrict__ row_scale, int n_scaled, float* __restrict__ gmap) {
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= ncells) return;
@@ -360,11 +360,16 @@ __global__ __launch_bounds__(256) void points_sample_bwd_sorted_kernel(const flo
 #pragma unroll
     for (int k = 0; k < VPL; ++k) acc[k] = 0.f;
     const int e0 = offsets[c], e1 = offsets[c + 1];
+    const float rs = row_scale != nullptr ? row_scale[0] : 1.0f;
     for (int e = e0; e < e1; ++e) {
         const int ent = order[e], i = ent >> 2, q = ent & 3;
         const Taps t = bilinear_taps(uv[2 * i], uv[2 * i + 1], H, W);
         const float w = q == 0 ? t.w[0] : (q == 1 ? t.w[1] : (q == 2 ? t.w[2] : t.w[3]));
-        const Row<VPL> r = load_row<VPL>(g, (size_t)i, D, lane);
+        Row<VPL> r = load_row<VPL>(g, (size_t)i, D, lane);
+        if (i < n_scaled) {              // rows that still carry an unscaled gradient (the anchor half of yp_infonce_fwd_grad): scaled first,
+#pragma unroll                           // rounded to fp32, exactly as a separate scaling pass would leave them
+            for (int k = 0; k < VPL; ++k) r.v[k] = __fmul_rn(r.v[k], rs);
+        }
 #pragma unroll
         for (int k = 0; k < VPL; ++k) acc[k] += w * r.v[k];
     }
@@ -435,6 +440,100 @@ __global__ __launch_bounds__(256) void detloss_fold_kernel(const float* __restri
         sums[0] = (float)(sh[0][0] + sh[1][0] + sh[2][0] + sh[3][0]);
         sums[1] = (float)(sh[0][1] + sh[1][1] + sh[2][1] + sh[3][1]);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same loss straight from the 2-D label maps (reference train.py:212-231 feeds ComputeDetectorLoss with labels2Dto3D(labels_2D) and
+// getMasks(valid_mask), utils/utils.py:184-209 / :103-116): the 65-channel target of a cell is its 64 label pixels plus the dustbin,
+// divided by their sum; a cell is valid when all of its 64 mask pixels are.  Neither the [B,65,Hc,Wc] target nor a concatenated batch
+// is materialised.  cell_mask_kernel (label-only, runs beside the forward) leaves the cell mask and its sum; detloss2d_kernel then writes
+// the FINAL gradient -- the per-cell gradient times gscale / (sum(mask) + 1e-10) -- into the network's gradient buffer.
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cell_mask_kernel(const float* __restrict__ valid, int B, int H, int W, float* __restrict__ mask, float* __restrict__ partial) {
+    __shared__ float sh[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int Hc = H >> 3, Wc = W >> 3;
+    const long cell = (long)blockIdx.x * 4 + wave, ncell = (long)B * Hc * Wc;
+    float m = 0.f;
+    if (cell < ncell) {
+        const int b = (int)(cell / (Hc * Wc)), rem = (int)(cell - (long)b * Hc * Wc), cy = rem / Wc, cx = rem - cy * Wc;
+        m = valid[((size_t)b * H + cy * 8 + (lane >> 3)) * W + cx * 8 + (lane & 7)];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m *= __shfl_xor(m, o, 64);
+        if (lane == 0) mask[cell] = m;
+    }
+    if (lane == 0) sh[wave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void cell_mask_fold_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ msum) {
+    __shared__ double sh[4];
+    double a = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) a += partial[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        a += __longlong_as_double(((long long)__shfl_xor((int)(__double_as_longlong(a) >> 32), o, 64) << 32) | (unsigned)__shfl_xor((int)(__double_as_longlong(a) & 0xffffffffll), o, 64));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) msum[0] = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void detloss2d_kernel(const float* __restrict__ z, long zb, long zc, long zy, long zx, const float* __restrict__ labels, int H, int W,
+                                                        const float* __restrict__ mask, const float* __restrict__ msum, float gscale, int B,
+                                                        float* __restrict__ dz, long db, long dc, long dy, long dx, float* __restrict__ partial) {
+    __shared__ float sh[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int Hc = H >> 3, Wc = W >> 3;
+    const long cell = (long)blockIdx.x * 4 + wave, ncell = (long)B * Hc * Wc;
+    float lsum = 0.f;
+    if (cell < ncell) {
+        const int b = (int)(cell / (Hc * Wc)), rem = (int)(cell - (long)b * Hc * Wc), cy = rem / Wc, cx = rem - cy * Wc;
+        const float* zp = z + b * zb + cy * zy + cx * zx;
+        const float m = mask[cell];
+        const float gi = gscale * (1.0f / (msum[0] + 1e-10f));
+        const float lab = labels[((size_t)b * H + cy * 8 + (lane >> 3)) * W + cx * 8 + (lane & 7)];
+        const float s = wave_sum(lab);
+        float dust = 1.0f - s;
+        dust = dust < 1.0f ? 0.0f : dust;
+        const float tot = s + dust;
+        const float z0 = zp[lane * zc], z1 = lane == 0 ? zp[64 * zc] : -3.0e38f;       // lane 0: channels 0 and 64
+        const float t0 = lab / tot, t1 = lane == 0 ? dust / tot : 0.f;
+        const float mx = wave_max(fmaxf(z0, z1));
+        const float e0 = expf(z0 - mx), e1 = lane == 0 ? expf(z1 - mx) : 0.f;
+        const float inv = 1.0f / wave_sum(e0 + e1);
+        const float p0 = e0 * inv, p1 = e1 * inv;
+        auto bce = [](float p, float t, float& g) {
+            const float l = -(t * fmaxf(logf(p), -100.0f) + (1.0f - t) * fmaxf(logf(1.0f - p), -100.0f));
+            g = (p - t) / fmaxf((1.0f - p) * p, 1e-12f);
+            return l;
+        };
+        float g0, g1 = 0.f;
+        float l = bce(p0, t0, g0);
+        if (lane == 0) l += bce(p1, t1, g1);
+        lsum = wave_sum(l) * m;
+        g0 *= m; g1 *= m;
+        const float dot = wave_sum(p0 * g0 + (lane == 0 ? p1 * g1 : 0.f));
+        float* dp = dz + b * db + cy * dy + cx * dx;
+        const float u0 = p0 * (g0 - dot), u1 = p1 * (g1 - dot);          // (the unscaled gradient, rounded as yp_detloss stores it)
+        dp[lane * dc] = u0 * gi;
+        if (lane == 0) dp[64 * dc] = u1 * gi;
+    }
+    if (lane == 0) sh[wave] = lsum;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void detloss2d_fold_kernel(const float* __restrict__ partial, int nblk, const float* __restrict__ msum, float* __restrict__ loss) {
+    __shared__ double sh[4];
+    double a = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) a += partial[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        a += __longlong_as_double(((long long)__shfl_xor((int)(__double_as_longlong(a) >> 32), o, 64) << 32) | (unsigned)__shfl_xor((int)(__double_as_longlong(a) & 0xffffffffll), o, 64));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = (float)(sh[0] + sh[1] + sh[2] + sh[3]) * (1.0f / (msum[0] + 1e-10f));
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -757,10 +856,11 @@ extern "C" int yp_points_sample_taps(const float* uv, int B, int P, int H, int W
 }
 
 extern "C" int yp_points_sample_bwd_sorted(const float* g, int B, int H, int W, int D, const float* uv, int P, const int* order, const int* offsets,
-                                           float* gmap_nhwc, void* stream) {
+                                           const float* row_scale_dev, int n_scaled_rows, float* gmap_nhwc, void* stream) {
     YP_REQUIRE(g && uv && order && offsets && gmap_nhwc && B > 0 && H > 0 && W > 0 && P > 0 && D > 0 && D % 64 == 0, "yp_points_sample_bwd_sorted: bad arguments (D %% 64 == 0)");
     const int ncells = B * H * W, grid = (ncells + 3) / 4;
-    YP_VPL_SWITCH(D, (points_sample_bwd_sorted_kernel<VPL><<<grid, 256, 0, (hipStream_t)stream>>>(g, H, W, D, uv, ncells, order, offsets, gmap_nhwc)));
+    YP_VPL_SWITCH(D, (points_sample_bwd_sorted_kernel<VPL><<<grid, 256, 0, (hipStream_t)stream>>>(g, H, W, D, uv, ncells, order, offsets, row_scale_dev,
+                                                                                                        row_scale_dev != nullptr ? n_scaled_rows : 0, gmap_nhwc)));
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
 }
@@ -780,6 +880,33 @@ extern "C" int yp_detloss(const float* semi, const int64_t* semi_strides, const 
     return YP_OK;
 }
 
+
+extern "C" size_t yp_cell_mask_workspace_bytes(int B, int H, int W) { return (((size_t)B * (H / 8) * (W / 8) + 3) / 4 + 4) * sizeof(float); }
+
+extern "C" int yp_cell_mask(const float* valid2d, int B, int H, int W, float* mask, float* mask_sum, void* workspace, size_t workspace_bytes, void* stream) {
+    YP_REQUIRE(valid2d && mask && mask_sum && workspace && B > 0 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0, "yp_cell_mask: bad arguments (H, W multiples of 8)");
+    YP_REQUIRE(workspace_bytes >= yp_cell_mask_workspace_bytes(B, H, W), "yp_cell_mask: workspace too small");
+    const int nblk = (int)(((size_t)B * (H / 8) * (W / 8) + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+    cell_mask_kernel<<<nblk, 256, 0, st>>>(valid2d, B, H, W, mask, (float*)workspace);
+    cell_mask_fold_kernel<<<1, 256, 0, st>>>((const float*)workspace, nblk, mask_sum);
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
+extern "C" int yp_detloss2d(const float* semi, const int64_t* semi_strides, const float* labels2d, const float* mask, const float* mask_sum, float gscale, int B,
+                            int H, int W, float* dsemi, const int64_t* dsemi_strides, float* loss, void* workspace, size_t workspace_bytes, void* stream) {
+    YP_REQUIRE(semi && semi_strides && labels2d && mask && mask_sum && dsemi && dsemi_strides && loss && workspace && B > 0 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0,
+               "yp_detloss2d: bad arguments (H, W multiples of 8)");
+    YP_REQUIRE(workspace_bytes >= yp_cell_mask_workspace_bytes(B, H, W), "yp_detloss2d: workspace too small");
+    const int nblk = (int)(((size_t)B * (H / 8) * (W / 8) + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+    detloss2d_kernel<<<nblk, 256, 0, st>>>(semi, semi_strides[0], semi_strides[1], semi_strides[2], semi_strides[3], labels2d, H, W, mask, mask_sum, gscale, B, dsemi,
+                                           dsemi_strides[0], dsemi_strides[1], dsemi_strides[2], dsemi_strides[3], (float*)workspace);
+    detloss2d_fold_kernel<<<1, 256, 0, st>>>((const float*)workspace, nblk, mask_sum, loss);
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
 
 extern "C" int yp_build_targets(const float* targets, int nt, const float* anchors, int nl, int na, const int* shapes_dev, float anchor_t, int cap, int* cell,
                                 int* tcls, float* tbox, float* anch, int* count, void* stream) {

@@ -583,10 +583,11 @@ __global__ void l2norm_bwd_kernel(const float* __restrict__ x, int xcs, int xco,
 
 // fp32 [B,na,ny,nx,no] gradient of the permuted Detect output -> NHWC view [B,ny,nx,na*no (+pad)] in dtype
 template <int DT>
-__global__ void detect_bwd_pack_kernel(const float* __restrict__ gx, int B, int na, int no, int ny, int nx,
+__global__ void detect_bwd_pack_kernel(const float* __restrict__ gx, const float* __restrict__ scale, int B, int na, int no, int ny, int nx,
                                        typename Sc<DT>::t* __restrict__ out, int cs, int co, int Cpad) {
     using T = typename Sc<DT>::t;
     const size_t n = (size_t)B * ny * nx * Cpad;
+    const float sc = scale != nullptr ? scale[0] : 1.0f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % Cpad);
         const size_t pix = i / Cpad;
@@ -595,7 +596,7 @@ __global__ void detect_bwd_pack_kernel(const float* __restrict__ gx, int B, int 
         float v = 0.f;
         if (c < na * no) {
             const int a = c / no, o = c - a * no;
-            v = gx[((b * na + a) * hw + rem) * no + o];
+            v = gx[((b * na + a) * hw + rem) * no + o] * sc;
         }
         out[pix * cs + co + c] = (T)v;
     }
@@ -858,10 +859,10 @@ extern "C" int yp_l2norm_bwd_f32(YpView x, YpView g, YpView dx, int B, int C, vo
     return YP_OK;
 }
 
-extern "C" int yp_detect_bwd_pack(const float* gx, int B, int na, int no, YpView out, int dtype, void* stream) {
+extern "C" int yp_detect_bwd_pack(const float* gx, int B, int na, int no, YpView out, int dtype, const float* scale_dev, void* stream) {
     YP_REQUIRE(gx && out.ptr && B > 0 && na > 0 && no > 0 && out.C >= na * no, "yp_detect_bwd_pack: bad arguments");
     const size_t n = (size_t)B * out.H * out.W * out.C;
-    YP_DT_SWITCH(dtype, (detect_bwd_pack_kernel<DT><<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(gx, B, na, no, out.H, out.W,
+    YP_DT_SWITCH(dtype, (detect_bwd_pack_kernel<DT><<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(gx, scale_dev, B, na, no, out.H, out.W,
                                                                                                       (typename Sc<DT>::t*)out.ptr, out.cstride, out.coff, out.C)));
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
@@ -904,23 +905,34 @@ extern "C" int yp_cast_from_f32(YpView in, YpView out, int dtype, int B, void* s
     return YP_OK;
 }
 
+// element (n, k) of a packed filter image.  mode 0: forward filter of input channels [c0, c0 + Cj); 1: the dgrad filter of that slice
+// (flipped, channel-transposed); 2 / 3: the image-like (<= 4 channel) stem filter for 16-bit / fp32 plans -- 2 pairs adjacent pixels
+// (k = (r * S/2 + s/2) * 8 + (s % 2) * 4 + c, what the [H, W/2, 8] view of the packed image multiplies), 3 pads to 4 channels.
+__device__ __forceinline__ float pack_elem(const float* __restrict__ w, int Cout, int Cin, int R, int S, int c0, int Cj, int mode, int Cout_pad, int n, int k) {
+    if (mode >= 2) {
+        const int Cq = mode == 2 ? 8 : 4, Sq = mode == 2 ? S / 2 : S;
+        if (n >= Cout || k >= R * Sq * Cq) return 0.f;
+        const int tap = k / Cq, j = k - tap * Cq;
+        const int r = tap / Sq, sq = tap - r * Sq;
+        const int c = j & 3, s_ = mode == 2 ? 2 * sq + (j >> 2) : sq;
+        return c < Cin ? w[(((size_t)n * Cin + c) * R + r) * S + s_] : 0.f;
+    }
+    const int Cq = mode == 0 ? Cj : Cout_pad, Nreal = mode == 0 ? Cout : Cj;
+    if (n >= Nreal || k >= R * S * Cq) return 0.f;
+    const int tap = k / Cq, c = k - tap * Cq;
+    const int r = tap / S, s_ = tap - r * S;
+    if (mode == 0) return w[(((size_t)n * Cin + c0 + c) * R + r) * S + s_];
+    return c < Cout ? w[(((size_t)c * Cin + c0 + n) * R + (R - 1 - r)) * S + (S - 1 - s_)] : 0.f;
+}
+
 template <int DT>
 __global__ void pack_weight_kernel(const float* __restrict__ w, int Cout, int Cin, int R, int S, int c0, int Cj, int mode, int Cout_pad,
                                    char* __restrict__ dst, int Kpad, int Npad, const float* __restrict__ bias, float* __restrict__ bias_dst) {
     using sc = typename Sc<DT>::t;
     const size_t total = (size_t)(Npad + 1) * Kpad;
-    const int Cq = mode == 0 ? Cj : Cout_pad;          // channels per tap along k
-    const int Nreal = mode == 0 ? Cout : Cj;
-    const int Kreal = R * S * Cq;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int n = (int)(i / Kpad), k = (int)(i - (size_t)n * Kpad);
-        float v = 0.f;
-        if (n < Nreal && k < Kreal) {
-            const int tap = k / Cq, c = k - tap * Cq;
-            const int r = tap / S, s_ = tap - r * S;
-            if (mode == 0) v = w[(((size_t)n * Cin + c0 + c) * R + r) * S + s_];
-            else if (c < Cout) v = w[(((size_t)c * Cin + c0 + n) * R + (R - 1 - r)) * S + (S - 1 - s_)];
-        }
+        const float v = pack_elem(w, Cout, Cin, R, S, c0, Cj, mode, Cout_pad, n, k);
         reinterpret_cast<sc*>(dst)[i] = (sc)v;
         if (bias_dst != nullptr && i < (size_t)Npad) bias_dst[i] = (bias != nullptr && (int)i < Cout) ? bias[i] : 0.f;
     }
@@ -928,9 +940,10 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int Cout, int Ci
 
 extern "C" int yp_pack_weight(const float* w, int Cout, int Cin, int R, int S, int c0, int Cj, int mode, int Cout_pad, void* dst, int Kpad,
                               int Npad, int dtype, const float* bias, float* bias_dst, void* stream) {
-    YP_REQUIRE(w && dst && Cout > 0 && Cin > 0 && R > 0 && S > 0 && c0 >= 0 && Cj > 0 && c0 + Cj <= Cin && (mode == 0 || mode == 1), "yp_pack_weight: bad arguments");
-    const int Cq = mode == 0 ? Cj : Cout_pad, Nreal = mode == 0 ? Cout : Cj;
-    YP_REQUIRE((mode == 0 || Cout_pad >= Cout) && Kpad >= R * S * Cq && Npad >= Nreal, "yp_pack_weight: packed dims %dx%d too small", Npad, Kpad);
+    YP_REQUIRE(w && dst && Cout > 0 && Cin > 0 && R > 0 && S > 0 && c0 >= 0 && Cj > 0 && c0 + Cj <= Cin && mode >= 0 && mode <= 3, "yp_pack_weight: bad arguments");
+    YP_REQUIRE(mode < 2 || (Cin <= 4 && c0 == 0 && (mode == 3 || S % 2 == 0)), "yp_pack_weight: modes 2 / 3 pack an image-like filter (<= 4 input channels; 2: even width)");
+    const int Cq = mode == 0 ? Cj : (mode == 1 ? Cout_pad : 4), Nreal = mode == 1 ? Cj : Cout;       // (modes 2 / 3: 4 k slots per filter pixel)
+    YP_REQUIRE((mode != 1 || Cout_pad >= Cout) && Kpad >= R * S * Cq && Npad >= Nreal, "yp_pack_weight: packed dims %dx%d too small", Npad, Kpad);
     const size_t total = (size_t)(Npad + 1) * Kpad;
     YP_DT_SWITCH(dtype, (pack_weight_kernel<DT><<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(w, Cout, Cin, R, S, c0, Cj, mode, Cout_pad, (char*)dst, Kpad, Npad,
                                                                                                      bias, bias_dst)));
@@ -954,20 +967,13 @@ __global__ __launch_bounds__(256) void pack_weight_batch_kernel(const YpPackEntr
     const int Cout = (int)en.Cout, Cin = (int)en.Cin, R = (int)en.R, S = (int)en.S, c0 = (int)en.c0, Cj = (int)en.Cj, mode = (int)en.mode;
     const int Cout_pad = (int)en.Cout_pad, Kpad = (int)en.Kpad, Npad = (int)en.Npad;
     const size_t total = (size_t)(Npad + 1) * Kpad;
-    const int Cq = mode == 0 ? Cj : Cout_pad, Nreal = mode == 0 ? Cout : Cj, Kreal = R * S * Cq;
     const size_t base = (size_t)(bid - (int)en.blk0) * 1024;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const size_t i = base + u * 256 + threadIdx.x;
         if (i >= total) break;
         const int n = (int)(i / Kpad), k = (int)(i - (size_t)n * Kpad);
-        float v = 0.f;
-        if (n < Nreal && k < Kreal) {
-            const int tap = k / Cq, c = k - tap * Cq;
-            const int r = tap / S, s_ = tap - r * S;
-            if (mode == 0) v = en.w[(((size_t)n * Cin + c0 + c) * R + r) * S + s_];
-            else if (c < Cout) v = en.w[(((size_t)c * Cin + c0 + n) * R + (R - 1 - r)) * S + (S - 1 - s_)];
-        }
+        const float v = pack_elem(en.w, Cout, Cin, R, S, c0, Cj, mode, Cout_pad, n, k);
         reinterpret_cast<sc*>(en.dst)[i] = (sc)v;
         if (en.bias_dst != nullptr && i < (size_t)Npad) en.bias_dst[i] = (en.bias != nullptr && (int)i < Cout) ? en.bias[i] : 0.f;
     }
@@ -1199,7 +1205,7 @@ extern "C" int yp_run_op(const YpOpArgs* a, void* stream) {
         case YP_OP_ADD_VIEWS: return yp_add_views(a->v[0], a->v[1], dt, B, a->i[2], stream);
         case YP_OP_MAXPOOL5_BWD: return yp_maxpool5_bwd(a->v[0], a->v[1], a->v[2], dt, B, a->i[2], a->p[0], a->n[0], stream);
         case YP_OP_L2NORM_BWD: return yp_l2norm_bwd_f32(a->v[0], a->v[1], a->v[2], B, a->i[2], stream);
-        case YP_OP_DETECT_BWD_PACK: return yp_detect_bwd_pack(a->f[0], B, a->i[2], a->i[3], a->v[0], dt, stream);
+        case YP_OP_DETECT_BWD_PACK: return yp_detect_bwd_pack(a->f[0], B, a->i[2], a->i[3], a->v[0], dt, a->f[1], stream);
         case YP_OP_TO_CHWB: return yp_to_chwb(a->v[0], dt, B, a->i[2], a->p[0], a->i[3], stream);
         case YP_OP_COL_SUM: return yp_col_sum(a->v[0], dt, B, a->g[0], a->i[2], a->p[0], a->n[0], stream);
         case YP_OP_MEMSET0: {

@@ -60,7 +60,8 @@ class GradAllReducer:
         # all buckets are slices of ONE arena (bucket order), so that an optimizer can walk every gradient in one launch (optim.FlatAdam)
         dev = self.buckets[0][1][0][0].device
         sizes = [sz for sz, _ in self.buckets]
-        self.arena = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        self._arena_store = torch.zeros((sum(sizes) + 3) // 4 * 4, dtype=torch.float32, device=dev)     # (whole 16-byte units: yp_fill_zero)
+        self.arena = self._arena_store[:sum(sizes)]
         self.bucket_offsets = [sum(sizes[:i]) for i in range(len(sizes))]
         self.buckets = [(self.arena[o:o + sz], entries) for o, (sz, entries) in zip(self.bucket_offsets, self.buckets)]
         self.param_arena = None
@@ -116,8 +117,12 @@ class GradAllReducer:
         optimizer.zero_grad() at the start of an optimizer step (zero=False on the later micro-batches of an accumulation)."""
         if self._views is None:
             self._views = [[flat[off:off + n].view_as(p) for p, off, n in entries] for flat, entries in self.buckets]
-        if zero:
-            self.arena.zero_()                  # (all buckets: one launch)
+        if zero:                                # (all buckets: one launch)
+            if self.arena.is_cuda:
+                from . import _hip
+                _hip.check(_hip.lib().yp_fill_zero(self._arena_store.data_ptr(), self._arena_store.numel() * 4, _hip.stream_ptr()))
+            else:
+                self.arena.zero_()
         for (flat, entries), views in zip(self.buckets, self._views):
             for (p, _, _), v in zip(entries, views):
                 if p.grad is not v:

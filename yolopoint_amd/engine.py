@@ -8,6 +8,7 @@ Forward/backward of the network run through the native plans (yolopoint_amd/trai
 autograd; Adam is torch.optim.Adam (train.py:88).  Data: SURVEY.md 8(d) synthetic recipe, generated on the device.
 """
 import contextlib
+import ctypes as C
 import os
 
 import torch
@@ -154,6 +155,125 @@ class TrainStep:
         self.opt.step()
         return total
 
+    # ------------------------------------------------------------------------------------------------------------------------------
+    # The loss stage without the framework: the native loss kernels read the heads where the forward plan left them and write the FINAL
+    # head gradients where the backward plans read them; the label-only work is native kernels on the side stream; the loss sum of
+    # train.py:232-241 is one tiny launch.  Same values as the autograd formulation below -- the gradients bit for bit
+    # (tests/test_gpu_training.py) -- and no ATen / rocPRIM / hipBLASLt kernel in a steady-state step.  YP_NATIVE_STAGE=0: the autograd
+    # formulation (also what YOLOPointv52, two-graph mode and CPU tensors use).
+    # ------------------------------------------------------------------------------------------------------------------------------
+    def _native_stage_ok(self, batch):
+        if not self.pair or os.environ.get("YP_NATIVE_STAGE", "1") == "0" or type(self.model.model).__name__ != "YOLOPoint":
+            return False
+        img = batch['image']
+        ok = img.is_cuda and img.dim() == 4 and img.shape[-1] % 8 == 0 and img.shape[-2] % 8 == 0 and tuple(batch['warped_image'].shape) == tuple(img.shape)
+        for k in ('labels_2D', 'warped_labels', 'valid_mask', 'warped_valid_mask'):
+            t = batch[k]
+            ok = ok and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == img.shape[0] * img.shape[-2] * img.shape[-1]
+        return bool(ok)
+
+    def _loss_and_grads_native(self, batch, first_micro, scale):
+        import numpy as np
+        from types import SimpleNamespace
+        from . import _hip
+        from .training import run_native_backward_pair, SEEDED
+        lib, check, sp = _hip.lib(), _hip.check, _hip.stream_ptr
+        m, dev = self.model, self.device
+        net = m.model
+        self.reducer.bind_grads(zero=first_micro)
+        img, img_w = batch['image'].contiguous().float(), batch['warped_image'].contiguous().float()
+        B, H, W = img.shape[0], img.shape[-2], img.shape[-1]
+        Hc, Wc = H // 8, W // 8
+        main = torch.cuda.current_stream(dev)
+        side = self.side_stream if self.side_stream is not None else main
+        fork = main.record_event() if side is not main else None
+        g = net._train_graph(img, pair=True, fp8=bool(getattr(net, "fp8_train", False)))
+        g.busy = True
+        g.forward(img, img_w, export=False)
+        D = g.desc_channels
+        stg = getattr(g, "_stage", None)
+        if stg is None:
+            wsb = lib.yp_cell_mask_workspace_bytes(B, H, W)
+            sv = g.semi_v.buf.t[..., g.semi_v.coff:g.semi_v.coff + 65].permute(0, 3, 1, 2)
+            gd = getattr(g, "seed_desc_buf", None)
+            if not (sv.dtype == torch.float32 and g.seed_semi.dtype == torch.float32 and gd is not None and gd.C == D and g.desc_v.coff == 0
+                    and g.desc_v.buf.C == D and g.desc_v.buf.t.dtype == torch.float32 and D % 64 == 0 and D <= 256):
+                raise _hip.YpError("native loss stage: unexpected head buffer layout (set YP_NATIVE_STAGE=0)")
+            stg = g._stage = SimpleNamespace(
+                ws_bytes=wsb, ws_side=torch.empty(wsb, dtype=torch.uint8, device=dev), ws_main=torch.empty(wsb, dtype=torch.uint8, device=dev),
+                mask=torch.empty((2, B, Hc, Wc), dtype=torch.float32, device=dev), scal=torch.zeros(16, dtype=torch.float32, device=dev),
+                semi_ptr=sv.data_ptr(), zs=(C.c_int64 * 4)(*sv.stride()), dsemi_ptr=g.seed_semi.data_ptr(), ds=(C.c_int64 * 4)(*g.seed_semi.stride()),
+                desc_ptr=g.desc_v.buf.t.data_ptr(), gdesc_ptr=gd.t.data_ptr())
+        det = net.Detect
+        shapes = [(B, det.na, H // int(st), W // int(st), det.no) for st in det.stride]
+        scal = stg.scal.data_ptr()           # floats: [0:3] object-loss sums, [4:6] detector losses, [6:8] mask sums, [12] InfoNCE gradient scale
+
+        def label_work():
+            tgt_ = self.obj_loss.assign(shapes, batch['box_labels'])
+            nce_ = infonce_prepare(batch['warped_valid_mask'], batch['inv_homographies'], (B, D, Hc, Wc), True, self.sparse['num_samples_per_image'],
+                                   self.sparse['num_masked_non_matches_per_match'], 8, dev, pair_index=True)
+            for j, key in enumerate(('valid_mask', 'warped_valid_mask')):
+                check(lib.yp_cell_mask(batch[key].data_ptr(), B, H, W, stg.mask[j].data_ptr(), scal + 4 * (6 + j), stg.ws_side.data_ptr(), stg.ws_bytes, sp()))
+            return tgt_, nce_
+        if side is not main:
+            side.wait_event(fork)
+            with torch.cuda.stream(side):
+                early = label_work()
+                _record_stream(early, main)
+            main.wait_stream(side)
+        else:
+            early = label_work()
+        tgt, nce = early
+        f32 = np.float32
+        # ---- object loss (reference utils/loss_functions.py:90-176): value into scal[0:3], UNSCALED gradient straight into the backward
+        # plan's Detect seeds; its upstream factor lambda_obj * scale is applied by the plan's first op (TrainGraph.head_scale)
+        want = float(f32(f32(scale) * f32(LAMBDA_OBJ))) if scale != 1.0 else float(f32(LAMBDA_OBJ))
+        g.set_head_scale(want)
+        check(lib.yp_fill_zero(scal, 16, sp()))
+        ol, hyp = self.obj_loss, self.obj_loss.hyp
+        cap = tgt["cap"] if tgt["nt"] else 0
+        cap_alloc = max(cap, 1)
+        for i, xo in enumerate(g.xs):
+            no = xo.shape[-1]
+            cells = (xo.numel() // xo.shape[0]) * B // no
+            iou = torch.empty((cap_alloc,), dtype=torch.float32, device=dev)
+            own = torch.empty((cells,), dtype=torch.int32, device=dev)
+            check(lib.yp_objloss_level_dev(xo.data_ptr(), cells, no, ol.nc, tgt["cell"].data_ptr() + 4 * i * tgt["cap"], tgt["box"].data_ptr() + 16 * i * tgt["cap"],
+                                           tgt["anchor"].data_ptr() + 8 * i * tgt["cap"], tgt["cls"].data_ptr() + 4 * i * tgt["cap"], cap,
+                                           tgt["count"].data_ptr() + 4 * i, float(ol.cp), float(ol.cn), float(hyp['cls_pw']), float(hyp['obj_pw']),
+                                           float(hyp['box']), float(hyp['obj']) * float(ol.balance[i]), float(hyp['cls']), iou.data_ptr(), own.data_ptr(),
+                                           g.g_xs[i].data_ptr(), scal, sp()))
+        # ---- detector loss of both passes (utils/loss_functions.py:600-619 on labels2Dto3D / getMasks of the 2-D maps): final gradients
+        # into the semi seed
+        for j, key in enumerate(('labels_2D', 'warped_labels')):
+            check(lib.yp_detloss2d(stg.semi_ptr + 4 * j * B * stg.zs[0], stg.zs, batch[key].data_ptr(), stg.mask[j].data_ptr(), scal + 4 * (6 + j), float(f32(scale)),
+                                   B, H, W, stg.dsemi_ptr + 4 * j * B * stg.ds[0], stg.ds, scal + 4 * (4 + j), stg.ws_main.data_ptr(), stg.ws_bytes, sp()))
+        # ---- InfoNCE (utils/loss_functions.py:484-597): one lookup over both passes' descriptor maps, loss rows + anchor-side gradient in
+        # one gather pass, the loss sum, the match-side gradient, the scatter into the descriptor seed
+        ua, _, _, (idx, order, offsets), (uab, s_order, s_offsets) = nce
+        pool, E, tau = ua.shape[1], idx.shape[1], 0.07
+        n = B * pool
+        dab = torch.empty((2 * n, D), dtype=torch.float32, device=dev)
+        grad = torch.empty((2 * n, D), dtype=torch.float32, device=dev)
+        w = torch.empty((n, E), dtype=torch.float32, device=dev)
+        rows, lse = torch.empty((n,), dtype=torch.float32, device=dev), torch.empty((n,), dtype=torch.float32, device=dev)
+        out4 = torch.empty((4,), dtype=torch.float32, device=dev)
+        check(lib.yp_points_sample_fwd(stg.desc_ptr, 2 * B, Hc, Wc, D, uab.data_ptr(), pool, dab.data_ptr(), sp()))
+        check(lib.yp_infonce_fwd_grad(dab.data_ptr(), dab.data_ptr() + 4 * n * D, idx.data_ptr(), n, E, D, 1.0 / tau, w.data_ptr(), rows.data_ptr(), lse.data_ptr(),
+                                      grad.data_ptr(), sp()))
+        g_desc = f32(f32(scale) * f32(LAMBDA_DESC)) if scale != 1.0 else f32(LAMBDA_DESC)
+        desc_scale = float(f32(g_desc * f32(1.0 / (tau * n))))
+        check(lib.yp_loss_combine(scal + 16, 2, rows.data_ptr(), n, scal, LAMBDA_DESC, LAMBDA_OBJ, float(scale), desc_scale, out4.data_ptr(), scal + 48, sp()))
+        check(lib.yp_infonce_bwd_db(dab.data_ptr(), order.data_ptr(), offsets.data_ptr(), w.data_ptr(), lse.data_ptr(), n, E, D, scal + 48,
+                                    grad.data_ptr() + 4 * n * D, sp()))
+        check(lib.yp_points_sample_bwd_sorted(grad.data_ptr(), 2 * B, Hc, Wc, D, uab.data_ptr(), pool, s_order.data_ptr(), s_offsets.data_ptr(), scal + 48, n,
+                                              stg.gdesc_ptr, sp()))
+        # ---- backward: YOLO-branch plan -> its buckets go out -> trunk plan over both passes
+        self.reducer.begin()
+        run_native_backward_pair(g, SEEDED, SEEDED, [SEEDED] * len(g.xs), notify=self.reducer.notify)
+        self.last_loss_terms = out4              # [total, detector, descriptor, object] (device)
+        return out4[0]
+
     def loss_and_grads(self, batch, prepare=True, first_micro=True, scale=1.0):
         """loss = (det + det_warp) + lambda_desc * infonce + lambda_obj * obj and its backward (reference train.py:208-245).
         With `prepare`, the label-only parts of the losses (YOLO target assignment: a device kernel; InfoNCE sampling: one host sync)
@@ -166,6 +286,8 @@ class TrainStep:
         overlap wins: 40-48 ms vs 38 ms per step.)"""
         from .training import run_native_backward, run_native_backward_pair
         m, dev = self.model, self.device
+        if prepare and self._native_stage_ok(batch):
+            return self._loss_and_grads_native(batch, first_micro, scale)
         self.reducer.bind_grads(zero=first_micro)   # (instead of optimizer.zero_grad: gradients accumulate straight into the all-reduce buckets)
         img = batch['image']
         B, S = img.shape[0], img.shape[-1]

@@ -129,7 +129,9 @@ class MasterWeight:
         self.cj = Cin - c0 if cj is None else cj
         self.cout_pad = round_up(Cout, 8) if cout_pad is None else cout_pad
         # logical OIHW shape of the filter the convolution sees
-        self.shape = (Cout, self.cj, R, S) if mode == 0 else (self.cj, self.cout_pad, R, S)
+        # (mode "image": the <= 4-channel stem filter; the plan picks the packed form -- pixel pairs for 16-bit plans, 4-channel padding
+        # for fp32 ones: yp_pack_weight modes 2 / 3)
+        self.shape = (Cout, self.cj, R, S) if mode in (0, "image") else (self.cj, self.cout_pad, R, S)
 
 
 class Fp8State:
@@ -365,13 +367,15 @@ class PlanBuilder:
             bp = None
             self.keep += [wp]
         elif master is not None:
-            assert not thin, "image-like (thin) inputs keep the host packer"
-            Kpad, Npad = lib().yp_conv_kpad(R * S * Cin, conv_dtype), round_up(Cout, 8)
+            assert thin == (master.mode == "image"), "image-like (thin) inputs take MasterWeight(mode='image')"
+            pmode = (2 if pair else 3) if thin else master.mode
+            # (thin: 4 k slots per filter pixel -- S was halved above when pixels are paired and each tap covers 8)
+            Kpad, Npad = lib().yp_conv_kpad(R * S * ((8 if pair else 4) if thin else Cin), conv_dtype), round_up(Cout, 8)
             assert bool(master.q8) == (q8 is not None)
             # the pack op goes into `pack_target` (a builder shared by every plan over the same parameters, replayed once per
             # optimizer step) when one is set, else in front of the convolution in this plan
             tgt, cache = self.pack_target if self.pack_target is not None else (self, None)
-            key = (master.param.data_ptr(), master.bias.data_ptr() if master.bias is not None else 0, master.mode, master.c0, master.cj, master.cout_pad,
+            key = (master.param.data_ptr(), master.bias.data_ptr() if master.bias is not None else 0, pmode, master.c0, master.cj, master.cout_pad,
                    bool(master.q8))
             w_slot = None
             if master.q8:
@@ -396,11 +400,11 @@ class PlanBuilder:
                 mo, mi, mr, ms = master.param.shape
                 tgt.keep += [wp, bp, master.param] + ([master.bias] if master.bias is not None else [])
                 tgt.op(_hip.OP_PACK_WEIGHT, [], [(wp, 0, 1 << 30)], "pack_w", f=[master.param, master.bias], g=[bp], p=[wp],
-                       i=[self.code, mo, mi, mr, ms, master.c0, master.cj, master.mode], n=[Kpad, Npad | (master.cout_pad << 32)])
+                       i=[self.code, mo, mi, mr, ms, master.c0, master.cj, pmode], n=[Kpad, Npad | (master.cout_pad << 32)])
                 # (the same arguments as a row of the batched packer's table: yp_pack_weight_batch, TrainGraph.forward)
                 tgt.__dict__.setdefault("pack_entries", []).append(
                     [master.param.data_ptr(), wp.data_ptr(), master.bias.data_ptr() if master.bias is not None else 0, bp.data_ptr(), mo, mi, mr, ms,
-                     master.c0, master.cj, master.mode, master.cout_pad, Kpad, Npad])
+                     master.c0, master.cj, pmode, master.cout_pad, Kpad, Npad])
                 if cache is not None:
                     cache[key] = (wp, bp)
             self.keep += [wp, bp]

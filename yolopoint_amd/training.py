@@ -77,6 +77,10 @@ class TrainGraph:
         self.ws = torch.empty(wsb, dtype=torch.uint8, device=device)
         self.Bpad = round_up(B, 8)
         self._nbt = None
+        # device scalars the backward plans read: [0] = the upstream factor of the Detect-level gradients (1 unless a caller that hands the
+        # plan UNSCALED object-loss gradients sets it: engine.TrainStep's native loss stage)
+        self.head_scale = torch.ones(4, dtype=torch.float32, device=device)
+        self._head_scale_val = 1.0
         self.pre_forward, self.post_forward = [], []      # host callables around every forward (padded BN parameter copies)
         # every per-layer weight-gradient accumulator (fp32 [Cin][k][k][Cout_pad]) lives in one arena that the backward plan
         # clears with a single memset
@@ -216,8 +220,8 @@ class TrainGraph:
         k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
         act = _hip.YP_ACT_SILU if isinstance(m.act, torch.nn.SiLU) else _hip.YP_ACT_NONE
         f, B, code, G = self.fwd, self.B, self.code, self.G
-        image = len(srcs) == 1 and srcs[0].geom is None and srcs[0].cstride == 4 and srcs[0].C == 4      # the stem keeps the host packer
-        wsrc = (lambda: (conv.weight.detach().float(), None)) if image else MasterWeight(conv.weight)
+        image = len(srcs) == 1 and srcs[0].geom is None and srcs[0].cstride == 4 and srcs[0].C == 4      # the stem: its own packed filter form
+        wsrc = MasterWeight(conv.weight, mode="image" if image else 0)
         # The BatchNorm column sums come out of the convolution's epilogue (YpConvDesc.bn_partial: one partial row per block of 64 pixels in
         # the generic kernel, per pixel tile in the 3x3 halo kernels) -- no separate reduction pass over the raw output.
         # YP_BN_EPILOGUE=0: the reduction kernel everywhere; =1: 1x1 convolutions only (the first version).
@@ -332,8 +336,12 @@ class TrainGraph:
         if bias is not None:
             gb_full = b.new_tensor((Cout_pad,))
             b.op(_hip.OP_COL_SUM, [draw], [self.T(gb_full), self.T(self.ws)], "bias_grad", v=[draw], i=[code, B, 0], g=[gb_full], p=[self.ws], n=[self.ws.numel()])
-            gbias = self.pgrad(bias)
-            self.collect.append(lambda: gbias.copy_(gb_full[:Cout]))
+            if bias not in self.pgrads and self.vparts.get(id(bias)) is None:
+                self.pgrads[bias] = gb_full[:Cout]         # the column sums ARE the bias gradient: no copy
+                self.touched.add(bias)
+            else:
+                gbias = self.pgrad(bias)
+                self.collect.append(lambda: gbias.copy_(gb_full[:Cout]))
         # ---- wgrad.  Stride-1 1x1 / 3x3 convolutions in a 16-bit dtype: yp_conv_wgrad reads the NHWC tensors directly
         # (LDS transpose reads; 3x3 also at stride 2).  Everything else (the 6x6 stem, fp32): wgrad as a convolution of pixel-major
         # copies -- the output gradient becomes the "filter" [Cout_pad (+1 zero row)][K].
@@ -565,6 +573,7 @@ class TrainGraph:
                 b = self.bwd
                 gcraw, _ = self.gview(craw)
                 self.seed_desc = head_view(gd.view(), c3ch)
+                self.seed_desc_buf = gd
                 b.op(_hip.OP_L2NORM_BWD, [craw, gd.view()], [gcraw], "l2norm_bwd", v=[craw, gd.view(), gcraw], i=[0, b.B, c3ch])
         self.desc_channels = c3ch
         # YOLO encoder + PAN: nothing below feeds semi / desc
@@ -607,7 +616,7 @@ class TrainGraph:
             def det_backward(v=v, mi=mi, gx=gx, ny=ny, nx=nx):
                 b = self.bwd
                 draw = b.new_buf(ny, nx, round_up(det.na * det.no, 8)).view()
-                b.op(_hip.OP_DETECT_BWD_PACK, [self.T(gx)], [draw], "seed_det", f=[gx], v=[draw], i=[code, b.B, det.na, det.no])
+                b.op(_hip.OP_DETECT_BWD_PACK, [self.T(gx)], [draw], "seed_det", f=[gx, self.head_scale], v=[draw], i=[code, b.B, det.na, det.no])
                 self.conv_backward([v], mi.weight, mi.bias, draw, 1, 1, 0)
             det_seeds.append(det_backward)
         self.semi_v, self.desc_v = semi, dnorm
@@ -702,9 +711,11 @@ class TrainGraph:
         self.params = [p_ for p_ in net.parameters()]
 
     # ------------------------------------------------------------------ run
-    def forward(self, x, x_w=None):
+    def forward(self, x, x_w=None, export=True):
         """x: [B,3,H,W] fp32 (pair mode: x = the image batch, x_w = the warped image batch; the heads come back for all 2B samples, image
-        pass first; the Detect levels for the image pass only)."""
+        pass first; the Detect levels for the image pass only).  export=False: nothing is returned -- the caller reads the heads where
+        the plan left them (semi_v / desc_v buffers, xs) and writes their gradients where the backward plans read them (seed_semi,
+        seed_desc_buf, g_xs), then calls backward_pair with SEEDED."""
         assert (x_w is not None) == (self.G > 1)
         # packed weights (forward + dgrad) are re-derived only when an optimizer step (or a load) changed the masters
         # (the optimizer-step count is part of the key: fused optimizers do not bump Tensor._version)
@@ -757,8 +768,13 @@ class TrainGraph:
         if self._nbt is None:
             self._nbt = [m.num_batches_tracked for m in self.net.modules()
                          if isinstance(m, torch.nn.BatchNorm2d) and m.num_batches_tracked is not None]
-        if self._nbt:
-            torch._foreach_add_(self._nbt, self.G)     # one launch for all BatchNorm counters
+        if self._nbt:                                  # one launch for all BatchNorm counters (through a table of their addresses)
+            if getattr(self, "_nbt_table", None) is None:
+                assert all(t.dtype == torch.int64 and t.is_cuda for t in self._nbt)
+                self._nbt_table = torch.tensor([t.data_ptr() for t in self._nbt], dtype=torch.int64).to(self.device)
+            check(lib().yp_counters_add(self._nbt_table.data_ptr(), len(self._nbt), self.G, _hip.stream_ptr()))
+        if not export:
+            return None
         c3ch = self.desc_channels
         semi = self.semi_v.buf.t[..., :65].permute(0, 3, 1, 2).float()      # (a copy: fp32 heads are cloned, 16-bit ones converted)
         desc = self.desc_v.buf.t[..., :c3ch].permute(0, 3, 1, 2).float()
@@ -768,12 +784,22 @@ class TrainGraph:
             desc = desc.clone()
         return semi, desc, [t[:self.Bs].clone() for t in self.xs]
 
+    def set_head_scale(self, val):
+        """The factor the backward plan applies to the Detect-level seeds (a device scalar: the plans are replayed as hipGraphs)."""
+        if self._head_scale_val != val:
+            self.head_scale[0:1].fill_(val)
+            self._head_scale_val = val
+
     def backward_pair(self, g_semi, g_desc, g_xs, between=None):
         """Pair mode: head gradients (semi / desc over the 2B samples, the Detect levels over the image pass's B; None = zero) ->
         parameter gradients.  Runs the YOLO-branch plan, calls between(parameter -> gradient of the parameters it reached) -- they are
         final: a data-parallel step starts their all-reduce here --, then the trunk plan; returns its dict."""
         assert self.G > 1
+        if not all(src is SEEDED for src in g_xs):
+            self.set_head_scale(1.0)                 # (gradients that arrive from autograd carry their upstream factor already)
         for dst, src in zip(self.g_xs, g_xs):
+            if src is SEEDED:
+                continue
             if src is None:
                 dst[:self.Bs].zero_()
             else:
@@ -785,6 +811,8 @@ class TrainGraph:
         if between is not None:
             between(first)
         for dst, src in ((self.seed_semi, g_semi), (self.seed_desc, g_desc)):
+            if src is SEEDED:
+                continue
             if src is None:
                 dst.zero_()
             else:
@@ -803,6 +831,7 @@ class TrainGraph:
             got = self.backward_pair(g_semi, g_desc, g_xs)
             return [got.get(p_) for p_ in self.params]
         kp_only = all(g is None for g in g_xs)
+        self.set_head_scale(1.0)
         for dst, src in [(self.seed_semi, g_semi), (self.seed_desc, g_desc)] + ([] if kp_only else list(zip(self.g_xs, g_xs))):
             if src is None:
                 dst.zero_()
@@ -813,6 +842,9 @@ class TrainGraph:
         for fn in collect:
             fn()
         return [self.pgrads[p_] if p_ in touched else None for p_ in self.params]
+
+
+SEEDED = object()       # backward_pair: "this head's gradient is already in the plan's seed buffer"
 
 
 def _release(g):
@@ -927,8 +959,31 @@ def _deliver(params, grads):
         for p_, f_ in zip(new_p, fresh):
             p_.grad = f_
     if acc_p:
-        torch._foreach_add_(acc_p, acc_g)
+        _multi_add(acc_p, acc_g)
     return touched
+
+
+_ADD_TABLES = {}
+
+
+def _multi_add(dsts, srcs):
+    """dst += src for a list of fp32 tensor pairs in ONE native launch (yp_multi_add) through a device table that is built once per
+    distinct list (the plans' gradient buffers and the p.grad views of a bound reducer do not move between steps)."""
+    if not (dsts[0].is_cuda and all(d.dtype == torch.float32 and s_.dtype == torch.float32 and d.is_contiguous() and s_.is_contiguous()
+                                    for d, s_ in zip(dsts, srcs))):
+        torch._foreach_add_(dsts, srcs)
+        return
+    key = tuple((d.data_ptr(), s_.data_ptr(), d.numel()) for d, s_ in zip(dsts, srcs))
+    ent = _ADD_TABLES.get(key)
+    if ent is None:
+        rows, blk0 = [], 0
+        for dptr, sptr, n in key:
+            rows.append([dptr, sptr, n, 0, blk0])
+            blk0 += -(-n // 1024)
+        if len(_ADD_TABLES) > 64:
+            _ADD_TABLES.clear()
+        ent = _ADD_TABLES[key] = (torch.tensor(rows, dtype=torch.int64).to(dsts[0].device), len(rows), blk0)
+    check(lib().yp_multi_add(ent[0].data_ptr(), ent[1], ent[2], _hip.stream_ptr()))
 
 
 # modules whose parameters the keypoint / descriptor heads depend on (everything a forward whose Detect outputs take no part in the loss

@@ -370,8 +370,8 @@ class _PointSampleNative(torch.autograd.Function):
         g = g.contiguous()
         if order is not None:        # cell-sorted (point, tap) list (point_sample_index): one pass, no atomics, no zero-fill, fixed summation order
             gmap = torch.empty((B, H, W, D), dtype=torch.float32, device=g.device)
-            _hip.check(_hip.lib().yp_points_sample_bwd_sorted(g.data_ptr(), B, H, W, D, uv.data_ptr(), P, order.data_ptr(), offsets.data_ptr(), gmap.data_ptr(),
-                                                              _hip.stream_ptr()))
+            _hip.check(_hip.lib().yp_points_sample_bwd_sorted(g.data_ptr(), B, H, W, D, uv.data_ptr(), P, order.data_ptr(), offsets.data_ptr(), None, 0,
+                                                              gmap.data_ptr(), _hip.stream_ptr()))
         else:
             gmap = torch.zeros((B, H, W, D), dtype=torch.float32, device=g.device)
             _hip.check(_hip.lib().yp_points_sample_bwd(g.data_ptr(), B, H, W, D, uv.data_ptr(), P, gmap.data_ptr(), _hip.stream_ptr()))
