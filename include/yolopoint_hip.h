@@ -443,6 +443,25 @@ int yp_cell_mask(const float* valid2d, int B, int H, int W, float* mask, float* 
 int yp_detloss2d(const float* semi, const int64_t* semi_strides, const float* labels2d, const float* mask, const float* mask_sum, float gscale, int B, int H,
                  int W, float* dsemi, const int64_t* dsemi_strides, float* loss, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The label-only half of the InfoNCE loss (reference utils/loss_functions.py:484-552: warp the validity mask back, keep the cells whose
+ * 64 pixels are all valid, map the cell grid through the inverse homography, shuffle, draw the negatives) as device kernels around a
+ * counter-based generator (Philox 4x32-10 keyed by `seed`) -- csrc/sampling.hip:
+ *   yp_nce_cells      mask [B,1,H,W] fp32, inv_h [B,3,3] (normalised coordinates) -> valid [B*Hc*Wc] bytes, uvb [B*Hc*Wc][2] = the rounded
+ *                     cell coordinates in the warped image (Hc = H/8, Wc = W/8)
+ *   yp_nce_select     pool = min(samples, min over images of #valid) cells per image, uniformly without replacement, in cell order:
+ *                     uab [2B][pool][2] normalised (x, y) (rows [0,B): the cells, rows [B,2B): their matches; capacity 2*B*samples*2 floats);
+ *                     meta[0] = pool, meta[1] = n = B*pool, meta[2] = 0
+ *   yp_nce_negatives  idx [n][1+negs] int32: column 0 the row itself, then uniform draws from [0, n); a draw equal to its row is replaced by
+ *                     floor(U * #such draws) (the reference's redraw from [0, #collisions)); meta[2] receives that count
+ *   yp_csr_build      keys [n_items] (values outside [0, n_buckets) are skipped) -> order: the item ids grouped by key, ascending inside a
+ *                     group; offsets [n_buckets + 1]; cursor_ws [n_buckets] scratch.  wide_buckets: groups of hundreds (one wavefront
+ *                     each) instead of a few (one thread each).  The InfoNCE backward walks (idx.flatten() -> n buckets) and the descriptor
+ *                     lookup backward (yp_points_sample_taps keys -> B*H*W buckets) with it. */
+int yp_nce_cells(const float* mask, const float* inv_h, int B, int H, int W, unsigned char* valid, float* uvb, void* stream);
+int yp_nce_select(const unsigned char* valid, const float* uvb, int B, int Hc, int Wc, int samples, uint64_t seed, float* uab, int* meta, void* stream);
+int yp_nce_negatives(int n, int negs, uint64_t seed, int* meta, int* idx, void* stream);
+int yp_csr_build(const int* keys, int n_items, int n_buckets, int wide_buckets, int* order, int* offsets, int* cursor_ws, void* stream);
+
 /* The pieces between the plans of a training step (reference train.py:189-259), one launch each (csrc/step.hip):
  *   yp_fill_zero     optimizer.zero_grad() over the gradient arena (16-byte aligned pointer and size)
  *   yp_multi_add     loss.backward()'s accumulation into p.grad for a whole table of (dst, src, n) at once: dst += src (mode 0) or

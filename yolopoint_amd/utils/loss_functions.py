@@ -378,32 +378,77 @@ class _PointSampleNative(torch.autograd.Function):
         return gmap.permute(0, 3, 1, 2), None, None, None
 
 
+def _csr(keys, n_buckets, wide):
+    """int32 keys [n_items] -> (order: item ids grouped by key, ascending inside a group; offsets [n_buckets + 1]) -- csrc/sampling.hip
+    yp_csr_build (a counting sort whose result does not depend on the order of arrival)."""
+    from .. import _hip
+    dev = keys.device
+    order = torch.empty((keys.numel(),), dtype=torch.int32, device=dev)
+    offsets = torch.empty((n_buckets + 1,), dtype=torch.int32, device=dev)
+    cursor = torch.empty((n_buckets,), dtype=torch.int32, device=dev)
+    _hip.check(_hip.lib().yp_csr_build(keys.data_ptr(), keys.numel(), n_buckets, 1 if wide else 0, order.data_ptr(), offsets.data_ptr(), cursor.data_ptr(),
+                                       _hip.stream_ptr()))
+    return order, offsets
+
+
 def point_sample_index(uv, H, W):
     """uv [B, P, 2] (normalised sample coordinates on an H x W map) -> (order int32 [B*P*4], offsets int32 [B*H*W + 1]): the (point, tap)
-    pairs of the bilinear lookup sorted by the cell they touch and the CSR offsets of the cells, for _PointSampleNative's atomic-free
-    backward.  Label-only work (it depends on the sample points alone): a training step builds it beside the forward pass."""
+    pairs of the bilinear lookup grouped by the cell they touch (ascending inside a cell; taps outside the map / of weight 0 are not
+    listed) and the CSR offsets of the cells, for _PointSampleNative's atomic-free backward.  Label-only work (it depends on the sample
+    points alone): a training step builds it beside the forward pass."""
     from .. import _hip
     B, P = uv.shape[0], uv.shape[1]
     uv = uv.contiguous()
     keys = torch.empty((B * P * 4,), dtype=torch.int32, device=uv.device)
     _hip.check(_hip.lib().yp_points_sample_taps(uv.data_ptr(), B, P, H, W, keys.data_ptr(), _hip.stream_ptr()))
-    skeys, order = torch.sort(keys, stable=True)
-    offsets = torch.searchsorted(skeys, torch.arange(B * H * W + 1, device=uv.device, dtype=torch.int32)).to(torch.int32)
-    return order.to(torch.int32), offsets
+    return _csr(keys, B * H * W, wide=False)
 
 
 def infonce_edges(rnd):
-    """rnd [n, negs] (negatives of each match) -> (idx [n, 1+negs] int32 with the match itself in column 0, edge ids sorted by
-    column, CSR offsets [n+1]): the backward of the native kernel walks the transposed edge list instead of scattering."""
+    """rnd [n, negs] (negatives of each match) -> (idx [n, 1+negs] int32 with the match itself in column 0, edge ids grouped by the
+    column they point at (ascending inside a group), CSR offsets [n+1]): the backward of the native kernel walks the transposed edge
+    list instead of scattering."""
     n = rnd.shape[0]
     idx = torch.cat((torch.arange(n, device=rnd.device).unsqueeze(1), rnd), 1).to(torch.int32).contiguous()
-    # stable sort of the column ids; int16 keys when they fit (2 radix passes instead of the 8 of int64), CSR offsets by binary
-    # search in the sorted keys (bincount's atomics histogram was 0.2 ms)
-    keys = idx.flatten().to(torch.int16) if n < 32768 else idx.flatten()
-    skeys, order = torch.sort(keys, stable=True)
-    order = order.to(torch.int32)
+    if idx.is_cuda:
+        return (idx,) + _csr(idx.view(-1), n, wide=True)
+    skeys, order = torch.sort(idx.flatten(), stable=True)
     offsets = torch.searchsorted(skeys, torch.arange(n + 1, device=rnd.device, dtype=skeys.dtype)).to(torch.int32)
-    return idx, order, offsets
+    return idx, order.to(torch.int32), offsets
+
+
+def _prepare_native(mask_valid_warp, inv_homographies, B, Hc, Wc, samples, negs, pair_index):
+    """infonce_prepare on the device (csrc/sampling.hip): validity of the cells and their matches, the uniform draw of `pool` cells per
+    image, the negatives, the transposed edge list and (pair_index) the cell-sorted tap list -- ~16 native launches, one host
+    synchronisation (the common pool size fixes the tensor shapes).  The two Philox keys come from torch's CPU generator:
+    torch.manual_seed reproduces the draws."""
+    from .. import _hip
+    lib, check, sp = _hip.lib(), _hip.check, _hip.stream_ptr
+    dev = mask_valid_warp.device
+    H, W, Nc = Hc * 8, Wc * 8, Hc * Wc
+    mask = mask_valid_warp.float().contiguous()
+    inv = inv_homographies.to(dev, torch.float32).contiguous()
+    assert mask.numel() == B * H * W and inv.numel() == 9 * B
+    seeds = torch.empty((2,), dtype=torch.int64).random_()
+    s0, s1 = int(seeds[0]), int(seeds[1])
+    valid = torch.empty((B * Nc,), dtype=torch.uint8, device=dev)
+    uvb = torch.empty((B * Nc, 2), dtype=torch.float32, device=dev)
+    store = torch.empty((2 * B * samples * 2,), dtype=torch.float32, device=dev)
+    meta = torch.empty((4,), dtype=torch.int32, device=dev)
+    check(lib.yp_nce_cells(mask.data_ptr(), inv.data_ptr(), B, H, W, valid.data_ptr(), uvb.data_ptr(), sp()))
+    check(lib.yp_nce_select(valid.data_ptr(), uvb.data_ptr(), B, Hc, Wc, samples, s0, store.data_ptr(), meta.data_ptr(), sp()))
+    pool = int(meta[0])                                 # (the one host synchronisation)
+    if pool <= 0:
+        raise _hip.YpError("infonce: an image of the batch has no valid cell")
+    n, E = B * pool, negs + 1
+    uab = store[:2 * n * 2].view(2 * B, pool, 2)
+    idx = torch.empty((n, E), dtype=torch.int32, device=dev)
+    check(lib.yp_nce_negatives(n, negs, s1, meta.data_ptr(), idx.data_ptr(), sp()))
+    edges = (idx,) + _csr(idx.view(-1), n, wide=True)
+    out = (uab[:B], uab[B:], idx[:, 1:], edges)
+    if pair_index and os.environ.get("YP_SAMPLE_SORTED", "1") != "0":
+        out = out + ((uab,) + point_sample_index(uab, Hc, Wc),)
+    return out
 
 
 def infonce(descriptors, descriptors_warped, mask_valid_warp, inv_homographies, num_samples_per_image=1500,
@@ -452,7 +497,7 @@ def infonce(descriptors, descriptors_warped, mask_valid_warp, inv_homographies, 
         return _InfoNCENative.apply(da.flatten(0, 1), db.flatten(0, 1), *edges, float(tau))
     pos = (da * db).sum(-1).flatten()
     da, db = da.flatten(0, 1), db.flatten(0, 1)
-    neg = (da @ db.t()).gather(1, rnd)                 # [n, negs] = <da[i], db[rnd[i, j]]>
+    neg = (da @ db.t()).gather(1, rnd.long())          # [n, negs] = <da[i], db[rnd[i, j]]>
     logits = torch.cat([pos.unsqueeze(1), neg], dim=1) / tau
     return -F.log_softmax(logits, dim=1)[:, 0].mean()
 
@@ -466,6 +511,9 @@ def infonce_prepare(mask_valid_warp, inv_homographies, desc_shape, on_device, nu
         "Number of samples per image must be greater than number of pixels in image"
     with torch.no_grad():
         B, Hc, Wc = desc_shape[0], desc_shape[2], desc_shape[3]
+        if (perm_fn is None and randint_fn is None and on_device and mask_valid_warp.is_cuda and cell_size == 8 and Hc * Wc < 36864
+                and mask_valid_warp.shape[-2] == 8 * Hc and mask_valid_warp.shape[-1] == 8 * Wc and os.environ.get("YP_NATIVE_PREPARE", "1") != "0"):
+            return _prepare_native(mask_valid_warp, inv_homographies, B, Hc, Wc, num_samples_per_image, num_masked_non_matches_per_match, pair_index)
         uv_a = get_coor_cells(Hc, Wc, uv=True).to(device)
         inv_h = inv_homographies.to(device)
         valid = warp_image_batch(mask_valid_warp, inv_h, mode='nearest', device=device)
