@@ -454,13 +454,14 @@ int yp_detloss2d(const float* semi, const int64_t* semi_strides, const float* la
  *   yp_nce_negatives  idx [n][1+negs] int32: column 0 the row itself, then uniform draws from [0, n); a draw equal to its row is replaced by
  *                     floor(U * #such draws) (the reference's redraw from [0, #collisions)); meta[2] receives that count
  *   yp_csr_build      keys [n_items] (values outside [0, n_buckets) are skipped) -> order: the item ids grouped by key, ascending inside a
- *                     group; offsets [n_buckets + 1]; cursor_ws [n_buckets] scratch.  wide_buckets: groups of hundreds (one wavefront
+ *                     group; offsets [n_buckets + 1]; workspace: yp_csr_workspace_ints(n_items, n_buckets) ints.  wide_buckets: groups of hundreds (one wavefront
  *                     each) instead of a few (one thread each).  The InfoNCE backward walks (idx.flatten() -> n buckets) and the descriptor
  *                     lookup backward (yp_points_sample_taps keys -> B*H*W buckets) with it. */
 int yp_nce_cells(const float* mask, const float* inv_h, int B, int H, int W, unsigned char* valid, float* uvb, void* stream);
 int yp_nce_select(const unsigned char* valid, const float* uvb, int B, int Hc, int Wc, int samples, uint64_t seed, float* uab, int* meta, void* stream);
 int yp_nce_negatives(int n, int negs, uint64_t seed, int* meta, int* idx, void* stream);
-int yp_csr_build(const int* keys, int n_items, int n_buckets, int wide_buckets, int* order, int* offsets, int* cursor_ws, void* stream);
+size_t yp_csr_workspace_ints(int n_items, int n_buckets);
+int yp_csr_build(const int* keys, int n_items, int n_buckets, int wide_buckets, int* order, int* offsets, int* workspace, void* stream);
 
 /* The pieces between the plans of a training step (reference train.py:189-259), one launch each (csrc/step.hip):
  *   yp_fill_zero     optimizer.zero_grad() over the gradient arena (16-byte aligned pointer and size)

@@ -128,6 +128,7 @@ SIGNATURES = {
     "yp_nce_select": (_i, [_p, _p, _i, _i, _i, _i, C.c_uint64, _p, _p, _p]),
     "yp_nce_negatives": (_i, [_i, _i, C.c_uint64, _p, _p, _p]),
     "yp_csr_build": (_i, [_p, _i, _i, _i, _p, _p, _p, _p]),
+    "yp_csr_workspace_ints": (_sz, [_i, _i]),
     "yp_fill_zero": (_i, [_p, _sz, _p]),
     "yp_multi_add": (_i, [_p, _i, _i, _p]),
     "yp_counters_add": (_i, [_p, _i, _i64, _p]),

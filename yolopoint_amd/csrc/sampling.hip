@@ -10,9 +10,9 @@
 //                         coordinates ua | ub
 //   nce_negatives_*       rnd[i][j] uniform in [0, n); a draw equal to its own row is replaced by floor(U * #such draws) -- the reference's
 //                         redraw from [0, #collisions)
-//   csr_*                 (key, item) pairs -> items grouped by key, ascending inside a group, + CSR offsets: counting sort (integer
-//                         atomics for the histogram and the slot claim, then every bucket is put in ascending order, so the result does not
-//                         depend on the order of arrival)
+//   csr_*                 (key, item) pairs -> items grouped by key, ascending inside a group, + CSR offsets: counting sort (one integer
+//                         atomic per item gives the bucket sizes and an arrival rank; a three-step scan gives the offsets; then every
+//                         bucket is put in ascending order, so the result does not depend on the order of arrival)
 #include "yp_internal.h"
 
 namespace {
@@ -194,44 +194,79 @@ __global__ __launch_bounds__(256) void csr_zero_kernel(int* __restrict__ p, int 
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = 0;
 }
 
-__global__ __launch_bounds__(256) void csr_hist_kernel(const int* __restrict__ keys, int n_items, int n_buckets, int* __restrict__ cursor) {
+// one atomic per item: its arrival rank inside its bucket (the bucket sizes are what the counters end at)
+__global__ __launch_bounds__(256) void csr_rank_kernel(const int* __restrict__ keys, int n_items, int n_buckets, int* __restrict__ count, int* __restrict__ rank) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_items) return;
     const int k = keys[i];
-    if (k >= 0 && k < n_buckets) atomicAdd(&cursor[k], 1);
+    if (k >= 0 && k < n_buckets) rank[i] = atomicAdd(&count[k], 1);
 }
 
-// offsets[0 .. n_buckets] = exclusive scan of the bucket sizes (one workgroup; every thread owns a contiguous segment); cursor := offsets
-__global__ __launch_bounds__(1024) void csr_scan_kernel(int* __restrict__ cursor, int n_buckets, int* __restrict__ offsets) {
+// exclusive scan of the bucket sizes in three steps: sums of 4096-bucket chunks, scan of the chunk sums (one workgroup), scan inside the chunks
+constexpr int SCAN_CHUNK = 4096;
+
+__global__ __launch_bounds__(256) void csr_chunk_sum_kernel(const int* __restrict__ count, int n_buckets, int* __restrict__ chunk_sum) {
+    __shared__ int sh[4];
+    const int base = blockIdx.x * SCAN_CHUNK;
+    int s = 0;
+    for (int i = threadIdx.x; i < SCAN_CHUNK; i += 256) s += base + i < n_buckets ? count[base + i] : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_sum[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(1024) void csr_chunk_scan_kernel(int* __restrict__ chunk_sum, int n_chunks, int* __restrict__ total_out) {
     __shared__ int sh[16];
     const int t = threadIdx.x;
-    const int per = (n_buckets + 1023) / 1024;
-    const int i0 = min(t * per, n_buckets), i1 = min(i0 + per, n_buckets);
-    int s = 0;
-    for (int i = i0; i < i1; ++i) s += cursor[i];
+    int run = 0;
+    for (int i0 = 0; i0 < n_chunks; i0 += 1024) {          // (one trip up to 4 M buckets)
+        const int v = i0 + t < n_chunks ? chunk_sum[i0 + t] : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if ((t & 63) >= o) incl += u; }
+        __syncthreads();
+        if ((t & 63) == 63) sh[t >> 6] = incl;
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int wv = 0; wv < 16; ++wv) { const int s_ = sh[wv]; if (wv < (t >> 6)) before += s_; total += s_; }
+        if (i0 + t < n_chunks) chunk_sum[i0 + t] = run + before + incl - v;
+        run += total;
+    }
+    if (t == 0) *total_out = run;
+}
+
+// offsets[b] for the buckets of one chunk (thread t owns buckets [16 t, 16 t + 16) of it)
+__global__ __launch_bounds__(256) void csr_offsets_kernel(const int* __restrict__ count, const int* __restrict__ chunk_base, int n_buckets, int* __restrict__ offsets) {
+    __shared__ int sh[4];
+    const int t = threadIdx.x, base = blockIdx.x * SCAN_CHUNK + t * 16;
+    int c[16], s = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { c[i] = base + i < n_buckets ? count[base + i] : 0; s += c[i]; }
     int incl = s;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if ((t & 63) >= o) incl += u; }
     if ((t & 63) == 63) sh[t >> 6] = incl;
     __syncthreads();
-    int before = 0, total = 0;
+    int before = 0;
 #pragma unroll
-    for (int wv = 0; wv < 16; ++wv) { const int s_ = sh[wv]; if (wv < (t >> 6)) before += s_; total += s_; }
-    int run = before + incl - s;
-    for (int i = i0; i < i1; ++i) {
-        const int c = cursor[i];
-        offsets[i] = run;
-        cursor[i] = run;
-        run += c;
+    for (int wv = 0; wv < 4; ++wv) if (wv < (t >> 6)) before += sh[wv];
+    int run = chunk_base[blockIdx.x] + before + incl - s;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (base + i < n_buckets) offsets[base + i] = run;
+        run += c[i];
     }
-    if (t == 0) offsets[n_buckets] = total;
 }
 
-__global__ __launch_bounds__(256) void csr_fill_kernel(const int* __restrict__ keys, int n_items, int n_buckets, int* __restrict__ cursor, int* __restrict__ order) {
+__global__ __launch_bounds__(256) void csr_scatter_kernel(const int* __restrict__ keys, const int* __restrict__ rank, int n_items, int n_buckets,
+                                                          const int* __restrict__ offsets, int* __restrict__ order) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_items) return;
     const int k = keys[i];
-    if (k >= 0 && k < n_buckets) order[atomicAdd(&cursor[k], 1)] = i;
+    if (k >= 0 && k < n_buckets) order[offsets[k] + rank[i]] = i;
 }
 
 // every bucket into ascending item order.  WAVE: one wavefront per bucket (rank sort through LDS; buckets of ~E entries), else one thread
@@ -313,14 +348,22 @@ extern "C" int yp_nce_negatives(int n, int negs, uint64_t seed, int* meta, int* 
     return YP_OK;
 }
 
-extern "C" int yp_csr_build(const int* keys, int n_items, int n_buckets, int wide_buckets, int* order, int* offsets, int* cursor_ws, void* stream) {
-    YP_REQUIRE(keys && order && offsets && cursor_ws && n_items > 0 && n_buckets > 0, "yp_csr_build: bad arguments");
+extern "C" size_t yp_csr_workspace_ints(int n_items, int n_buckets) { return (size_t)n_items + n_buckets + (n_buckets + 4095) / 4096 + 8; }
+
+extern "C" int yp_csr_build(const int* keys, int n_items, int n_buckets, int wide_buckets, int* order, int* offsets, int* workspace, void* stream) {
+    YP_REQUIRE(keys && order && offsets && workspace && n_items > 0 && n_buckets > 0, "yp_csr_build: bad arguments");
     hipStream_t st = (hipStream_t)stream;
+    const int n_chunks = (n_buckets + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    int* count = workspace;                    // [n_buckets]
+    int* chunk = count + n_buckets;            // [n_chunks]
+    int* rank = chunk + n_chunks;              // [n_items]
     const int zb = (n_buckets + 255) / 256;
-    csr_zero_kernel<<<zb < 1024 ? zb : 1024, 256, 0, st>>>(cursor_ws, n_buckets);
-    csr_hist_kernel<<<(n_items + 255) / 256, 256, 0, st>>>(keys, n_items, n_buckets, cursor_ws);
-    csr_scan_kernel<<<1, 1024, 0, st>>>(cursor_ws, n_buckets, offsets);
-    csr_fill_kernel<<<(n_items + 255) / 256, 256, 0, st>>>(keys, n_items, n_buckets, cursor_ws, order);
+    csr_zero_kernel<<<zb < 1024 ? zb : 1024, 256, 0, st>>>(count, n_buckets);
+    csr_rank_kernel<<<(n_items + 255) / 256, 256, 0, st>>>(keys, n_items, n_buckets, count, rank);
+    csr_chunk_sum_kernel<<<n_chunks, 256, 0, st>>>(count, n_buckets, chunk);
+    csr_chunk_scan_kernel<<<1, 1024, 0, st>>>(chunk, n_chunks, offsets + n_buckets);
+    csr_offsets_kernel<<<n_chunks, 256, 0, st>>>(count, chunk, n_buckets, offsets);
+    csr_scatter_kernel<<<(n_items + 255) / 256, 256, 0, st>>>(keys, rank, n_items, n_buckets, offsets, order);
     if (wide_buckets) csr_sort_kernel<true><<<(n_buckets + 3) / 4, 256, 0, st>>>(offsets, n_buckets, order);
     else csr_sort_kernel<false><<<(n_buckets + 255) / 256, 256, 0, st>>>(offsets, n_buckets, order);
     YP_CHECK_HIP(hipGetLastError());

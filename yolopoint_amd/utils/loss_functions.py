@@ -385,8 +385,8 @@ def _csr(keys, n_buckets, wide):
     dev = keys.device
     order = torch.empty((keys.numel(),), dtype=torch.int32, device=dev)
     offsets = torch.empty((n_buckets + 1,), dtype=torch.int32, device=dev)
-    cursor = torch.empty((n_buckets,), dtype=torch.int32, device=dev)
-    _hip.check(_hip.lib().yp_csr_build(keys.data_ptr(), keys.numel(), n_buckets, 1 if wide else 0, order.data_ptr(), offsets.data_ptr(), cursor.data_ptr(),
+    ws = torch.empty((_hip.lib().yp_csr_workspace_ints(keys.numel(), n_buckets),), dtype=torch.int32, device=dev)
+    _hip.check(_hip.lib().yp_csr_build(keys.data_ptr(), keys.numel(), n_buckets, 1 if wide else 0, order.data_ptr(), offsets.data_ptr(), ws.data_ptr(),
                                        _hip.stream_ptr()))
     return order, offsets
 
