@@ -126,10 +126,12 @@ typedef struct YpConvDesc {
     int32_t post_Kpad, post_Npad;
     /* BatchNorm statistics in the epilogue (training forward of Conv = conv -> BN -> SiLU, reference models/common.py:22-34): when
      * non-NULL the generic kernel also writes, per block of 64 output pixels rb, the column sums of the raw output and of its square:
-     * bn_partial[(rb*2 + 0)*C + c] and [(rb*2 + 1)*C + c], C = out.C, ceil(B*Ho*Wo / 64) row blocks; yp_bn_finalize folds them.
+     * bn_partial[(0*C + c)*R + rb] and [(1*C + c)*R + rb], C = out.C, R = ceil(B*Ho*Wo / 64) row blocks (a channel's partials lie
+     * together: yp_bn_finalize reads them as contiguous runs).
      * Needs tail_zero, a 16-bit or fp32 store of the same dtype, no bias / activation / residual / out2 / ksplit.  The 3x3 halo kernels
-     * (tile ids 10..15) write one row per pixel tile instead: B * ceil(Ho/8 | Ho/4) * ceil(Wo/16) rows; size the buffer for
-     * B * ceil(Ho/4) * ceil(Wo/16) rows (>= every variant's count), zero it once after the kernel variant is fixed and fold all rows. */
+     * (tile ids 10..15) write one row per pixel tile instead: R = B * ceil(Ho/8 | Ho/4) * ceil(Wo/16); the 8-wave kernels one per 64 or 128
+     * pixels.  Size the buffer for B * ceil(Ho/4) * ceil(Wo/16) rows (>= every variant's count); R of the variant a descriptor selects is
+     * yp_conv_bn_partial_rows -- the fold must be given exactly that count (it is the stride of the layout). */
     float* bn_partial;
     /* Deterministic split-K (ksplit > 1): when non-NULL, k slice y writes its partial output -- laid out like `out` -- to
      * split_slabs + y * split_stride floats with plain stores, and the caller sums the slices in order (yp_sum_slabs); NULL: fp32 atomics
@@ -224,7 +226,7 @@ int yp_bn_stats(YpView raw, int dtype, int B, float eps, float momentum, float* 
                 float* running_mean, float* running_var, void* workspace, size_t workspace_bytes, void* stream);
 
 /* mean / invstd (+ running statistics) from the per-row-block partial sums a convolution wrote (YpConvDesc.bn_partial): the second half
- * of yp_bn_stats without its reduction pass.  partial [rows][2][C]; M = the number of pixels the sums cover. */
+ * of yp_bn_stats without its reduction pass.  partial [2][C][rows]; M = the number of pixels the sums cover. */
 int yp_bn_finalize(const float* partial, int rows, int C, double M, float eps, float momentum, float* mean, float* invstd, float* running_mean,
                    float* running_var, void* stream);
 /* out = act(gamma*(raw-mean)*invstd + beta) [+ res] */

@@ -100,7 +100,8 @@ struct ConvKArgs {
     float det_anchor[16];
     float* det_x;
     float* det_z;
-    float* stats;                  // STATS instantiations: per-64-pixel-row-block column sums [row block][2][Cout] (BatchNorm statistics)
+    float* stats;                  // STATS instantiations: per-row-block column sums [2][Cout][stats_rows] (BatchNorm statistics; a channel's
+    int stats_rows;                // partials lie together: the fold that follows reads them as contiguous runs)
     const float* scale_in;         // 8-bit input types: the accumulators are multiplied by *scale_in * *scale_w (device scalars: the
     const float* scale_w;          // dequantisation scales of the activation and of the filter) before the epilogue
     int probe;                     // -DYP_PROBE8 builds of conv_mma8.hip: elimination experiments (1 no MFMA, 2 no steady-state DMA, 4 L2-resident pixels)

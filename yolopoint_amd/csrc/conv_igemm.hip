@@ -617,7 +617,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
             float v = 0.f;
 #pragma unroll
             for (int w = 0; w < WPH; ++w) v += red[((h * WPH + w) * 2 + w2) * BN + cl];
-            if (c < a.Cout && rb * 64 < a.M) a.stats[((size_t)rb * 2 + w2) * a.Cout + c] = v;
+            if (c < a.Cout && rb * 64 < a.M) a.stats[((size_t)w2 * a.Cout + c) * a.stats_rows + rb] = v;
         }
     }
     YP_TL(41);
@@ -913,7 +913,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvKArgs a) {
             float v = 0.f;
 #pragma unroll
             for (int w = 0; w < WAVES_M; ++w) v += red[(w * 2 + w2) * BN + cl];
-            if (c < a.Cout) a.stats[((size_t)tile * 2 + w2) * a.Cout + c] = v;
+            if (c < a.Cout) a.stats[((size_t)w2 * a.Cout + c) * a.stats_rows + tile] = v;
         }
     }
     YP_TL(41);
@@ -1671,7 +1671,8 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
                 YP_REQUIRE(!of32 && d->bias == nullptr && d->act == YP_ACT_NONE && d->res.C == 0 && d->out2.C == 0,
                            "yp_conv2d: bn_partial needs a plain convolution (no bias / activation / residual / second output)");
                 a.stats = d->bn_partial;
-                if (g_bn_rows_query != nullptr) { *g_bn_rows_query = yp_cdiv(a.M, srows); return YP_OK; }
+                a.stats_rows = yp_cdiv(a.M, srows);
+                if (g_bn_rows_query != nullptr) { *g_bn_rows_query = a.stats_rows; return YP_OK; }
             }
             e = yp_mma8_launch(d->tile, d->dtype, of32, stats, a, nblk8, stream);
             if (e != hipSuccess) { yp_set_error("yp_conv2d: 8-wave kernel launch failed: %s", hipGetErrorString(e)); return YP_ERR_HIP; }
@@ -1746,7 +1747,8 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
             YP_REQUIRE(!of32 && d->bias == nullptr && d->act == YP_ACT_NONE && d->res.C == 0 && d->out2.C == 0 && d->in1.C == 0,
                        "yp_conv2d: bn_partial needs a plain convolution (no bias / activation / residual / second output)");
             a.stats = d->bn_partial;
-            if (g_bn_rows_query != nullptr) { *g_bn_rows_query = d->B * a.tiles_y * a.tiles_x; return YP_OK; }
+            a.stats_rows = d->B * a.tiles_y * a.tiles_x;
+            if (g_bn_rows_query != nullptr) { *g_bn_rows_query = a.stats_rows; return YP_OK; }
             e = d->dtype == YP_F16 ? dispatch_halo<YP_F16, false, true>(d->stride_h, bn, th, a, nb3, stream)
                 : d->dtype == YP_BF16 ? dispatch_halo<YP_BF16, false, true>(d->stride_h, bn, th, a, nb3, stream)
                 : d->dtype == YP_FP8 ? dispatch_halo<YP_FP8, false, true>(d->stride_h, bn, th, a, nb3, stream) : hipErrorInvalidValue;
@@ -1765,7 +1767,8 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
         YP_REQUIRE(fast && !of32 && ksplit <= 1 && !a.atomic_out && d->bias == nullptr && d->act == YP_ACT_NONE && d->res.C == 0 && d->out2.C == 0,
                    "yp_conv2d: bn_partial needs the plain fast path (tail_zero, no bias / activation / residual / split / second output)");
         a.stats = d->bn_partial;
-        if (g_bn_rows_query != nullptr) { *g_bn_rows_query = (int)(((size_t)a.M + 63) / 64); return YP_OK; }
+        a.stats_rows = (int)(((size_t)a.M + 63) / 64);
+        if (g_bn_rows_query != nullptr) { *g_bn_rows_query = a.stats_rows; return YP_OK; }
         switch (d->dtype) {
             case YP_F16: e = launch_cfg<YP_F16, false, true, false, true>(tile, a, nblk, stream); break;
             case YP_BF16: e = launch_cfg<YP_BF16, false, true, false, true>(tile, a, nblk, stream); break;

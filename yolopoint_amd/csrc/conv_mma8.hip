@@ -467,8 +467,8 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
         const int c = nb + mych;
         const int rb = (tile_m * 2 + g) * WP + wp;
         if (owner && c < a.Cout && (size_t)rb * (32 * PT) < (size_t)a.M) {
-            a.stats[((size_t)rb * 2 + 0) * a.Cout + c] = sv[0];
-            a.stats[((size_t)rb * 2 + 1) * a.Cout + c] = sq[0];
+            a.stats[((size_t)0 * a.Cout + c) * a.stats_rows + rb] = sv[0];
+            a.stats[((size_t)1 * a.Cout + c) * a.stats_rows + rb] = sq[0];
         }
     }
     float bias[16 * CT];

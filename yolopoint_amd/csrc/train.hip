@@ -123,8 +123,8 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const char* __restrict_
         for (int j = 0; j < 8; ++j) {
             float a0 = 0.f, a1 = 0.f;
             for (int q = 0; q < rlanes; ++q) { a0 += red[0][q * chunks + ch][j]; a1 += red[1][q * chunks + ch][j]; }
-            part[((size_t)blockIdx.x * 2 + 0) * C + ch * 8 + j] = a0;
-            part[((size_t)blockIdx.x * 2 + 1) * C + ch * 8 + j] = a1;
+            part[((size_t)0 * C + ch * 8 + j) * gridDim.x + blockIdx.x] = a0;      // part[stat][channel][row block]: a channel's partials lie together
+            part[((size_t)1 * C + ch * 8 + j) * gridDim.x + blockIdx.x] = a1;
         }
     }
 }
@@ -141,12 +141,15 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 // (256 threads per channel: with one wavefront the 2048 partial rows of a large layer were 32 dependent round trips)
-__device__ __forceinline__ void fold_partials(const float* __restrict__ part, int nblk, int C, int c, double& s, double& ss) {
+// part[stat][channel][R row blocks] (R = all groups' rows); this group's rows are [row0, row0 + nblk): contiguous per channel
+__device__ __forceinline__ void fold_partials(const float* __restrict__ part, int R, int row0, int nblk, int C, int c, double& s, double& ss) {
     __shared__ double fold_sh[8];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     double a = 0.0, b = 0.0;
+    const float* pa = part + (size_t)c * R + row0;
+    const float* pb = part + ((size_t)C + c) * R + row0;
 #pragma unroll 4
-    for (int q = t; q < nblk; q += 256) { a += part[((size_t)q * 2) * C + c]; b += part[((size_t)q * 2 + 1) * C + c]; }
+    for (int q = t; q < nblk; q += 256) { a += pa[q]; b += pb[q]; }
     a = wave_sum_d(a);
     b = wave_sum_d(b);
     if (lane == 0) { fold_sh[2 * w] = a; fold_sh[2 * w + 1] = b; }
@@ -157,19 +160,21 @@ __device__ __forceinline__ void fold_partials(const float* __restrict__ part, in
 // WAVE variants (few partial rows, <= 256): one wavefront per channel, four channels per workgroup, no LDS / barrier -- these kernels
 // are pure launch latency (237 of them per training step), so the lighter they are the better.
 template <bool WAVE>
-__device__ __forceinline__ bool fold_dispatch(const float* __restrict__ part, int nblk, int C, int& c, double& s, double& ss) {
+__device__ __forceinline__ bool fold_dispatch(const float* __restrict__ part, int R, int row0, int nblk, int C, int& c, double& s, double& ss) {
     if constexpr (WAVE) {
         c = blockIdx.x * 4 + (threadIdx.x >> 6);
         if (c >= C) return false;
         const int lane = threadIdx.x & 63;
         double a = 0.0, b = 0.0;
-        for (int q = lane; q < nblk; q += 64) { a += part[((size_t)q * 2) * C + c]; b += part[((size_t)q * 2 + 1) * C + c]; }
+        const float* pa = part + (size_t)c * R + row0;
+        const float* pb = part + ((size_t)C + c) * R + row0;
+        for (int q = lane; q < nblk; q += 64) { a += pa[q]; b += pb[q]; }
         s = wave_sum_d(a);
         ss = wave_sum_d(b);
         return lane == 0;
     } else {
         c = blockIdx.x;
-        fold_partials(part, nblk, C, c, s, ss);
+        fold_partials(part, R, row0, nblk, C, c, s, ss);
         return threadIdx.x == 0;
     }
 }
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
     for (int g = 0; g < groups; ++g) {
         int c;
         double s, ss;
-        if (fold_dispatch<WAVE>(part + (size_t)g * nblk * 2 * C, nblk, C, c, s, ss)) {
+        if (fold_dispatch<WAVE>(part, nblk * groups, g * nblk, nblk, C, c, s, ss)) {
             const double mu = s / M;
             double var = ss / M - mu * mu;
             if (var < 0.0) var = 0.0;
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(256) void pair_finalize_kernel(const float* __restr
     bool lead = false;
     for (int g = 0; g < groups; ++g) {
         double s, ss;
-        if (fold_dispatch<WAVE>(part + (size_t)g * nblk * 2 * C, nblk, C, c, s, ss)) {
+        if (fold_dispatch<WAVE>(part, nblk * groups, g * nblk, nblk, C, c, s, ss)) {
             lead = true;
             if (o0) o0[g * C + c] = (float)s;
             if (o1) o1[g * C + c] = (float)ss;
@@ -363,8 +368,8 @@ __global__ __launch_bounds__(256) void col_reduce_fast_kernel(const char* __rest
     if (rl == 0) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            part[((size_t)blockIdx.x * 2 + 0) * C + ch * 8 + j] = red[t][j];
-            part[((size_t)blockIdx.x * 2 + 1) * C + ch * 8 + j] = red[t][8 + j];
+            part[((size_t)0 * C + ch * 8 + j) * gridDim.x + blockIdx.x] = red[t][j];
+            part[((size_t)1 * C + ch * 8 + j) * gridDim.x + blockIdx.x] = red[t][8 + j];
         }
     }
 }
