@@ -293,20 +293,25 @@ int yp_col_sum(YpView v, int dtype, int B, float* out, int accumulate, void* wor
  * 16-bit dtypes.  replaces: autograd's conv2d weight gradient (reference train.py:245 loss.backward()). */
 int yp_conv_wgrad(YpView x, YpView dy, int dtype, int B, int k, int stride, float* dw, void* stream);
 
-/* Every weight gradient of ONE filter class (k, stride as yp_conv_wgrad) of a backward pass in a single launch.  yp_wgrad_group_pack
- * fills a host table of n entries of yp_wgrad_group_entry_bytes() bytes each (argument checks as yp_conv_wgrad) and returns the
- * launch size; the caller copies the table to device memory and replays yp_wgrad_group_run(table_dev, n, total_blocks, ...). */
+/* Every weight gradient of ONE filter class (k, stride as yp_conv_wgrad, and one workgroup block size) of a backward pass in a single
+ * launch.  yp_wgrad_group_pack fills a host table of n entries of yp_wgrad_group_entry_bytes() bytes each (argument checks as
+ * yp_conv_wgrad) and returns the launch size; the caller copies the table to device memory and replays
+ * yp_wgrad_group_run(table_dev, n, total_blocks, ...).
+ * block: a workgroup owns a [block ci x block co] piece of dW -- 64, or 128 for 1x1 filters with >= 128 channels on both sides and enough
+ * pixels per workgroup (every LDS fragment feeds four MFMAs instead of two; yp_wgrad_block tells which one yp_conv_wgrad itself would
+ * take for a pair of views at batch B). */
 size_t yp_wgrad_group_entry_bytes(void);
-int yp_wgrad_group_pack(const YpView* xs, const YpView* dys, float* const* dws, int n, int dtype, int B, int k, int stride, void* table_host,
+int yp_wgrad_block(YpView x, YpView dy, int B, int k);
+int yp_wgrad_group_pack(const YpView* xs, const YpView* dys, float* const* dws, int n, int dtype, int B, int k, int stride, int block, void* table_host,
                         int* total_blocks);
-int yp_wgrad_group_run(const void* table_dev, int n, int total_blocks, int dtype, int k, int stride, void* stream);
+int yp_wgrad_group_run(const void* table_dev, int n, int total_blocks, int dtype, int k, int stride, int block, void* stream);
 /* Deterministic variant: every pixel slice of an entry writes its own partial slab (plain stores, parts[i] = device buffer of
  * yp_wgrad_partial_elems(...) floats, 16-byte aligned) and a second launch sums the slabs in slice order into dW -- bit-reproducible
  * gradients, no floating-point atomics, dW needs no clearing.  pack_det also returns the fold launch size for run_det. */
-size_t yp_wgrad_partial_elems(YpView x, YpView dy, int dtype, int B, int k, int stride);
+size_t yp_wgrad_partial_elems(YpView x, YpView dy, int dtype, int B, int k, int stride, int block);
 int yp_wgrad_group_pack_det(const YpView* xs, const YpView* dys, float* const* dws, float* const* parts, int n, int dtype, int B, int k, int stride,
-                            void* table_host, int* total_blocks, int* fold_chunks);
-int yp_wgrad_group_run_det(const void* table_dev, int n, int total_blocks, int fold_chunks, int dtype, int k, int stride, void* stream);
+                            int block, void* table_host, int* total_blocks, int* fold_chunks);
+int yp_wgrad_group_run_det(const void* table_dev, int n, int total_blocks, int fold_chunks, int dtype, int k, int stride, int block, void* stream);
 
 /* dw[ci][r][s][co] (fp32, Cout_pad channels per tap: the layout yp_conv_wgrad / the wgrad-as-convolution path produce)
  * -> grad[co][c0+ci][r][s] for ci < creal, co < Cout: the reference layout of conv.weight.grad */
@@ -512,7 +517,7 @@ enum {
     YP_OP_SUM_SLABS = 32,     /* p0=slabs p1=dst; n0=elements per slab (multiple of 4) n1=slabs: dst = slab0 + slab1 + ... in order */
     YP_OP_QUANT_FP8 = 34,     /* v0=src (16-bit) v1=dst (1-byte); i0=src dtype i1=B i2=format (0 e4m3 | 1 e5m2); p0=scale p1=amax: yp_quantize_fp8 */
     YP_OP_STEM_WGRAD = 33,    /* v0=image v1=dy; i0=dtype i1=B; p0=slabs p1=dw */
-    YP_OP_WGRAD_GROUP = 31,   /* p0=device table (yp_wgrad_group_pack[_det]); i0=dtype i1=entries i2=total blocks i3=k i4=stride i5=fold chunks (0: atomics) */
+    YP_OP_WGRAD_GROUP = 31,   /* p0=device table (yp_wgrad_group_pack[_det]); i0=dtype i1=entries i2=total blocks i3=k i4=stride i5=fold chunks (0: atomics) i6=block (0 = 64) */
     YP_OP_PACK_WEIGHT = 26    /* f0=w f1=bias; g0=bias_dst; p0=dst; i0=dtype i1=Cout i2=Cin i3=R i4=S i5=c0 i6=Cj i7=mode; n0=Kpad n1=Npad | Cout_pad<<32 */
 };
 typedef struct YpOpArgs {

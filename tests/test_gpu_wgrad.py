@@ -14,6 +14,9 @@ CASES = [
     # Cin, Cout, k, B, H, W, ups, (x channel offset, x cstride extra)
     (32, 32, 1, 2, 24, 40, 0), (64, 128, 1, 1, 17, 13, 0), (128, 64, 1, 3, 20, 20, 1), (256, 256, 1, 1, 10, 10, 0),
     (72, 40, 1, 2, 9, 11, 0),                    # channel counts that are not multiples of the 16 / 64 blocks
+    # 1x1 with >= 128 channels on both sides and enough pixels per workgroup: the 128 x 128-block kernel (ragged channel blocks, a source
+    # read through its 2x upsample, the many-block / small-split corner)
+    (1024, 1024, 1, 2, 40, 40, 0), (200, 136, 1, 2, 160, 160, 0), (256, 128, 1, 4, 160, 160, 1),
     (32, 32, 3, 2, 24, 40, 0), (64, 64, 3, 1, 20, 20, 0), (64, 128, 3, 2, 19, 23, 0), (128, 128, 3, 1, 16, 16, 0),
     (136, 72, 3, 1, 9, 21, 0), (256, 256, 3, 1, 8, 8, 0), (64, 64, 3, 1, 16, 16, 1),
     # 3x3 stride 2 (H, W are the INPUT size; output = ceil / 2): trailing 8th field = stride
@@ -52,6 +55,17 @@ def test_wgrad_matches_autograd(cuda, case, dtype):
     ref = w.grad.permute(1, 2, 3, 0)                                       # [ci][r][s][co]
     err = float((dw - ref).abs().max() / ref.abs().max())
     assert err < 2e-5, (case, dtype, err)      # same products, fp32 accumulation in a different order
+
+
+def test_block_size_selection(cuda):
+    """yp_wgrad_block: 128 x 128 blocks for 1x1 filters with >= 128 channels on both sides when a workgroup keeps >= 12 pixel tiles."""
+    def blk(Cin, Cout, k, B, H, W):
+        x = torch.empty(1, H, W, Cin, device=cuda, dtype=torch.bfloat16)
+        dy = torch.empty(1, H, W, Cout, device=cuda, dtype=torch.bfloat16)
+        return lib().yp_wgrad_block(view(x, 0, Cin), view(dy, 0, Cout), B, k)
+    assert blk(1024, 1024, 1, 2, 40, 40) == 128 and blk(200, 136, 1, 2, 160, 160) == 128 and blk(256, 128, 1, 4, 160, 160) == 128
+    assert blk(256, 256, 1, 16, 40, 40) == 64          # YOLOPoint-s P4 at 8 samples per GPU: too few tiles per workgroup
+    assert blk(64, 256, 1, 32, 160, 160) == 64 and blk(256, 256, 3, 32, 80, 80) == 64
 
 
 def test_wgrad_rejects_bad_arguments(cuda):

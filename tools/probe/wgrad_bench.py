@@ -14,7 +14,9 @@ SHAPES = [  # Cin, Cout, k, stride, Hout
     (256, 512, 3, 2, 20), (256, 256, 3, 1, 20), (512, 256, 1, 1, 20), (512, 512, 1, 1, 20), (1024, 512, 1, 1, 20),
 ]
 dev = torch.device("cuda:0")
-B = 8
+B = int(os.environ.get("WG_BATCH", "8"))
+SCALE = int(os.environ.get("WG_SCALE", "1"))          # 2: the YOLOPoint-l channel counts
+SHAPES = [(a * SCALE, b * SCALE, k, s_, h) for a, b, k, s_, h in SHAPES]
 
 
 def view(t, C_):

@@ -103,11 +103,12 @@ SIGNATURES = {
     "yp_bn_act_bwd_grouped": (_i, [YpView, YpView, YpView, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _i, _p, _sz, _p]),
     "yp_conv_bn_partial_rows": (_i, [_p, _p]),
     "yp_wgrad_group_entry_bytes": (_sz, []),
-    "yp_wgrad_group_pack": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
-    "yp_wgrad_group_run": (_i, [_p, _i, _i, _i, _i, _i, _p]),
-    "yp_wgrad_partial_elems": (_sz, [YpView, YpView, _i, _i, _i, _i]),
-    "yp_wgrad_group_pack_det": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
-    "yp_wgrad_group_run_det": (_i, [_p, _i, _i, _i, _i, _i, _i, _p]),
+    "yp_wgrad_group_pack": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "yp_wgrad_block": (_i, [YpView, YpView, _i, _i]),
+    "yp_wgrad_group_run": (_i, [_p, _i, _i, _i, _i, _i, _i, _p]),
+    "yp_wgrad_partial_elems": (_sz, [YpView, YpView, _i, _i, _i, _i, _i]),
+    "yp_wgrad_group_pack_det": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "yp_wgrad_group_run_det": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "yp_pack_weight_batch": (_i, [_p, _i, _i, _i, _p]),
     "yp_wgrad_unpack_batch": (_i, [_p, _i, _i, _p]),
     "yp_infonce_fwd": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _p, _p]),

@@ -1233,7 +1233,7 @@ extern "C" int yp_run_op(const YpOpArgs* a, void* stream) {
         case YP_OP_QUANT_FP8: return yp_quantize_fp8(a->v[0], a->v[1], dt, B, a->i[2], (const float*)a->p[0], (float*)a->p[1], stream);
         case YP_OP_STEM_WGRAD: return yp_stem_wgrad(a->v[0], a->v[1], dt, B, (float*)a->p[0], (float*)a->p[1], stream);
         case YP_OP_SUM_SLABS: return yp_sum_slabs((const float*)a->p[0], (float*)a->p[1], a->n[0], (int)a->n[1], stream);
-        case YP_OP_WGRAD_GROUP: return yp_wgrad_group_run_det(a->p[0], a->i[1], a->i[2], a->i[5], dt, a->i[3], a->i[4], stream);
+        case YP_OP_WGRAD_GROUP: return yp_wgrad_group_run_det(a->p[0], a->i[1], a->i[2], a->i[5], dt, a->i[3], a->i[4], a->i[6] > 0 ? a->i[6] : 64, stream);
         case YP_OP_WGRAD: return yp_conv_wgrad(a->v[0], a->v[1], dt, B, a->i[2], a->i[3] > 0 ? a->i[3] : 1, (float*)a->p[0], stream);
         case YP_OP_PACK_WEIGHT:
             return yp_pack_weight(a->f[0], a->i[1], a->i[2], a->i[3], a->i[4], a->i[5], a->i[6], a->i[7], (int)(a->n[1] >> 32), a->p[0], (int)a->n[0],

@@ -38,6 +38,7 @@ struct WgradArgs {
     int n_co_blk;
     int tiles_x, tiles_y, ntiles, M;
     int skip_store;                        // probe only (YP_WG_NOSTORE): time the reduction without the final atomics
+    int blk;                               // channels per (ci x co) block side: 64, or 128 (1x1 filters with >= 128 channels on both sides)
     int g_blk0, g_nblk, g_split;           // grouped launch: first flat workgroup of this entry, its (ci x co) blocks and pixel split
     float* part;                           // deterministic mode: partial slabs [g_split][Cj][taps][Cout_pad] (plain stores, folded in order by
     int f_chunk0, f_chunks;                // wgrad_fold_kernel: this entry's first 1024-element chunk and chunk count); nullptr: fp32 atomics into dw
@@ -62,7 +63,10 @@ __device__ __forceinline__ s16x8 wg_tr8(const char* lds_lo, const char* lds_hi) 
     return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-template <int DT, int TAPS, int ST>
+// NB = 16-channel fragments per wave and side: the workgroup (2 x 2 waves) owns a [32 NB ci x 32 NB co] block of dW.  NB = 4 (1x1 only):
+// 128 x 128 blocks, 64 x 64 per wave -- every fragment read from LDS feeds four MFMAs instead of two and a 128-pixel tile carries 1024 clk
+// of MFMA work per wave between its two barriers instead of 256 (the 64 x 64 blocks ran every 1x1 shape at ~210 TFLOP/s, barrier-bound).
+template <int DT, int TAPS, int ST, int NB = 2>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bx, const int first, const int step) {
     constexpr int KS = TAPS == 9 ? 3 : 1;
     constexpr int TH = (TAPS == 9 && ST == 2) ? 4 : 8;     // output rows of a 3x3 tile (16 columns)
@@ -73,14 +77,17 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bx, con
     constexpr int XR = TAPS == 9 ? (HROWS + 31) / 32 * 32 : 128;   // LDS rows (pixels) of the x image per 16-channel block
     constexpr int XI = XR / 32;                            // DMA instructions per channel block (32 rows x 32 B each)
     constexpr int DYI = NPIX / 32;
-    constexpr int XBYTES = 4 * XR * 32, DYBYTES = 4 * NPIX * 32, STAGE = XBYTES + DYBYTES;
-    constexpr int NDMA = XI + DYI;                         // per wave and tile
+    constexpr int NCB = 2 * NB;                            // 16-channel blocks per operand tile
+    constexpr int XBYTES = NCB * XR * 32, DYBYTES = NCB * NPIX * 32, STAGE = XBYTES + DYBYTES;
+    constexpr int XN = XI * NB / 2, DYN = DYI * NB / 2;    // DMA instructions per wave and tile (x | dy)
+    constexpr int NDMA = XN + DYN;
     static_assert(TAPS == 9 || ST == 1, "1x1: stride 1 only");
+    static_assert(NB == 2 || TAPS == 1, "128 x 128 blocks: 1x1 filters only (a 3x3 block holds 9 accumulator sets)");
 
-    extern __shared__ __attribute__((aligned(1024))) char wsm[];      // 2 stages of [x: 4 cb][XR][32 B] [dy: 4 cb][NPIX][32 B]
+    extern __shared__ __attribute__((aligned(1024))) char wsm[];      // 2 stages of [x: NCB cb][XR][32 B] [dy: NCB cb][NPIX][32 B]
     const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)wsm);
 
-    const int ci0 = (bx / a.n_co_blk) * 64, co0 = (bx % a.n_co_blk) * 64;
+    const int ci0 = (bx / a.n_co_blk) * (32 * NB), co0 = (bx % a.n_co_blk) * (32 * NB);
     const int t = threadIdx.x, l = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int half = l & 1, prow = l >> 1;                 // DMA: this lane moves channels [half*8, +8) of row prow of its 32-row slab
@@ -96,8 +103,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bx, con
         } else { b = 0; y0 = 0; x0 = 0; }
         // ---- x rows
 #pragma unroll
-        for (int i = 0; i < XI; ++i) {
-            const int q = wave + 4 * i;                    // q in [0, 4*XI): channel block q / XI, row slab q % XI
+        for (int i = 0; i < XN; ++i) {
+            const int q = wave + 4 * i;                    // q in [0, NCB*XI): channel block q / XI, row slab q % XI
             const int cb = q / XI, rb = q - cb * XI;
             const int row = rb * 32 + prow;
             const int ch = ci0 + cb * 16 + half * 8;
@@ -120,8 +127,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bx, con
         }
         // ---- dy rows
 #pragma unroll
-        for (int i = 0; i < DYI; ++i) {
-            const int q = wave + 4 * i;                    // q in [0, 4*DYI)
+        for (int i = 0; i < DYN; ++i) {
+            const int q = wave + 4 * i;                    // q in [0, NCB*DYI)
             const int cb = q / DYI, rb = q - cb * DYI;
             const int row = rb * 32 + prow;
             const int ch = co0 + cb * 16 + half * 8;
@@ -152,15 +159,15 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bx, con
         else xoff[h] = k32 * 32 + q4 * 8;
         yoff[h] = k32 * 32 + q4 * 8;
     }
-    const int wci = wave & 1, wco = wave >> 1;             // wave tile: ci [wci*32, +32), co [wco*32, +32)
+    const int wci = wave & 1, wco = wave >> 1;             // wave tile: ci [wci*16*NB, +16*NB), co [wco*16*NB, +16*NB)
 
-    f32x4 acc[TAPS][2][2];
+    f32x4 acc[TAPS][NB][NB];
 #pragma unroll
     for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
-        for (int fa = 0; fa < 2; ++fa)
+        for (int fa = 0; fa < NB; ++fa)
 #pragma unroll
-            for (int fb = 0; fb < 2; ++fb) acc[tp][fa][fb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int fb = 0; fb < NB; ++fb) acc[tp][fa][fb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     if (first < a.ntiles) issue(first, 0);
     int it = 0;
@@ -174,25 +181,25 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bx, con
         const char* ys = xs + XBYTES;
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
-            s16x8 yf[2];
+            s16x8 yf[NB];
 #pragma unroll
-            for (int fb = 0; fb < 2; ++fb) {
-                const char* base = ys + ((wco * 2 + fb) * NPIX + kk * 32) * 32;
+            for (int fb = 0; fb < NB; ++fb) {
+                const char* base = ys + ((wco * NB + fb) * NPIX + kk * 32) * 32;
                 yf[fb] = wg_tr8(base + yoff[0], base + yoff[1]);
             }
 #pragma unroll
             for (int tp = 0; tp < TAPS; ++tp) {
                 const int r = tp / KS, s = tp - r * KS;
-                s16x8 xf[2];
+                s16x8 xf[NB];
 #pragma unroll
-                for (int fa = 0; fa < 2; ++fa) {
-                    const char* base = xs + (wci * 2 + fa) * XR * 32 + (TAPS == 9 ? (kk * 2 * ST * HP + r * HP + s) * 32 : kk * 32 * 32);
+                for (int fa = 0; fa < NB; ++fa) {
+                    const char* base = xs + (wci * NB + fa) * XR * 32 + (TAPS == 9 ? (kk * 2 * ST * HP + r * HP + s) * 32 : kk * 32 * 32);
                     xf[fa] = wg_tr8(base + xoff[0], base + xoff[1]);
                 }
 #pragma unroll
-                for (int fa = 0; fa < 2; ++fa)
+                for (int fa = 0; fa < NB; ++fa)
 #pragma unroll
-                    for (int fb = 0; fb < 2; ++fb) acc[tp][fa][fb] = wg_mma<DT>(xf[fa], yf[fb], acc[tp][fa][fb]);
+                    for (int fb = 0; fb < NB; ++fb) acc[tp][fa][fb] = wg_mma<DT>(xf[fa], yf[fb], acc[tp][fa][fb]);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the compiler may sink the last MFMAs, and the wait for their operands, below a barrier)
@@ -208,14 +215,14 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bx, con
 #pragma unroll
         for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
-            for (int fa = 0; fa < 2; ++fa)
+            for (int fa = 0; fa < NB; ++fa)
 #pragma unroll
-                for (int fb = 0; fb < 2; ++fb) {
-                    const int co = co0 + (wco * 2 + fb) * 16 + li;
+                for (int fb = 0; fb < NB; ++fb) {
+                    const int co = co0 + (wco * NB + fb) * 16 + li;
                     if (co >= a.Cout_pad) continue;
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) {
-                        const int ci = ci0 + (wci * 2 + fa) * 16 + 4 * g + jj;
+                        const int ci = ci0 + (wci * NB + fa) * 16 + 4 * g + jj;
                         if (ci < a.Cj) slab[((size_t)ci * TAPS + tp) * a.Cout_pad + co] = acc[tp][fa][fb][jj];
                     }
                 }
@@ -224,28 +231,28 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bx, con
 #pragma unroll
     for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
-        for (int fa = 0; fa < 2; ++fa)
+        for (int fa = 0; fa < NB; ++fa)
 #pragma unroll
-            for (int fb = 0; fb < 2; ++fb) {
-                const int co = co0 + (wco * 2 + fb) * 16 + li;
+            for (int fb = 0; fb < NB; ++fb) {
+                const int co = co0 + (wco * NB + fb) * 16 + li;
                 if (co >= a.Cout_pad) continue;
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
-                    const int ci = ci0 + (wci * 2 + fa) * 16 + 4 * g + jj;
+                    const int ci = ci0 + (wci * NB + fa) * 16 + 4 * g + jj;
                     if (ci < a.Cj && !a.skip_store) atomicAdd(a.dw + ((size_t)ci * TAPS + tp) * a.Cout_pad + co, acc[tp][fa][fb][jj]);
                 }
             }
 }
 
-template <int DT, int TAPS, int ST>
+template <int DT, int TAPS, int ST, int NB = 2>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
-    wgrad_body<DT, TAPS, ST>(a, blockIdx.x, blockIdx.y, gridDim.y);
+    wgrad_body<DT, TAPS, ST, NB>(a, blockIdx.x, blockIdx.y, gridDim.y);
 }
 
 // All weight gradients of one filter class (1x1 | 3x3 stride 1 | 3x3 stride 2) of a backward pass in ONE launch: a device table of
 // argument sets, flat workgroup ids mapped to (entry, channel block, pixel-split slice).  81 + 20 + 12 launches per training step
 // become 3 per backward pass; the small 1x1 gradients no longer leave most of the chip idle between launches.
-template <int DT, int TAPS, int ST>
+template <int DT, int TAPS, int ST, int NB = 2>
 __global__ __launch_bounds__(256) void wgrad_group_kernel(const WgradArgs* __restrict__ table, int n_entries) {
     const int bid = blockIdx.x;                                   // (everything below depends on blockIdx only: scalar loads, SGPR arguments)
     int e = 0;
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(256) void wgrad_group_kernel(const WgradArgs* __res
     }
     const WgradArgs a = table[e];
     const int local = bid - a.g_blk0;
-    wgrad_body<DT, TAPS, ST>(a, local % a.g_nblk, local / a.g_nblk, a.g_split);
+    wgrad_body<DT, TAPS, ST, NB>(a, local % a.g_nblk, local / a.g_nblk, a.g_split);
 }
 
 // dW = slab[0] + slab[1] + ... + slab[split-1], in that order, for every entry of a grouped launch (1024 elements per workgroup).
@@ -278,14 +285,14 @@ __global__ __launch_bounds__(256) void wgrad_fold_kernel(const WgradArgs* __rest
     *reinterpret_cast<f32x4*>(a.dw + i) = v;
 }
 
-template <int DT, int TAPS, int ST>
+template <int DT, int TAPS, int ST, int NB = 2>
 hipError_t launch_wgrad(const WgradArgs& a, dim3 grid, hipStream_t st) {
     constexpr int TH = (TAPS == 9 && ST == 2) ? 4 : 8;
     constexpr int HP = 16 * ST + (ST == 1 ? 2 : 1);
     constexpr int HROWS = (TH * ST + (ST == 1 ? 2 : 1)) * HP;
     constexpr int XR = TAPS == 9 ? (HROWS + 31) / 32 * 32 : 128;
-    constexpr size_t lds = (size_t)2 * (4 * XR * 32 + 4 * TH * 16 * 32);
-    auto kern = wgrad_kernel<DT, TAPS, ST>;
+    constexpr size_t lds = (size_t)2 * (2 * NB * XR * 32 + 2 * NB * TH * 16 * 32);
+    auto kern = wgrad_kernel<DT, TAPS, ST, NB>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -298,7 +305,7 @@ hipError_t launch_wgrad(const WgradArgs& a, dim3 grid, hipStream_t st) {
 
 template <int DT>
 hipError_t dispatch_wgrad(int k, int stride, const WgradArgs& a, dim3 grid, hipStream_t st) {
-    if (k == 1) return launch_wgrad<DT, 1, 1>(a, grid, st);
+    if (k == 1) return a.blk == 128 ? launch_wgrad<DT, 1, 1, 4>(a, grid, st) : launch_wgrad<DT, 1, 1>(a, grid, st);
     return stride == 2 ? launch_wgrad<DT, 9, 2>(a, grid, st) : launch_wgrad<DT, 9, 1>(a, grid, st);
 }
 
@@ -477,7 +484,20 @@ extern "C" int yp_stem_wgrad(YpView x, YpView dy, int dtype, int B, float* slabs
 }
 
 // argument set + launch geometry of one weight gradient (shared by the single and the grouped entry points)
-static int wgrad_make_args(YpView x, YpView dy, int dtype, int B, int k, int stride, float* dw, WgradArgs* out, int* nblk_out, int* split_out, int target = 256) {
+// block: channels per side of a workgroup's dW block -- 64, 128 (1x1 filters), or 0 = 128 where it applies (1x1, >= 128 channels on both sides)
+// (the larger block pays off when a workgroup still walks >= 12 pixel tiles after the pixel split -- with few tiles per workgroup its
+// longer fill / drain and the single workgroup per CU cost more than the better MFMA : LDS ratio wins: YOLOPoint-s at 8 samples per GPU)
+static bool wgrad_big_ok(YpView x, YpView dy, int B, int k) {
+    if (k != 1 || x.C < 128 || dy.C < 128 || getenv("YP_WG_BLOCK64") != nullptr) return false;
+    const long ntiles = ((long)B * dy.H * dy.W + 127) / 128;
+    const int nblk = yp_cdiv(x.C, 128) * yp_cdiv(dy.C, 128);
+    const int split = yp_cdiv(128, nblk);
+    return ntiles >= 12l * split;
+}
+static int wgrad_make_args(YpView x, YpView dy, int dtype, int B, int k, int stride, float* dw, WgradArgs* out, int* nblk_out, int* split_out, int target = 256,
+                           int block = 0) {
+    YP_REQUIRE(block == 0 || block == 64 || (block == 128 && k == 1), "yp_conv_wgrad: block is 64, or 128 for 1x1 filters");
+    const int blk = block == 0 ? (wgrad_big_ok(x, dy, B, k) ? 128 : 64) : block;
     YP_REQUIRE(dtype == YP_F16 || dtype == YP_BF16, "yp_conv_wgrad: 16-bit element types only");
     YP_REQUIRE((k == 1 && stride == 1) || (k == 3 && (stride == 1 || stride == 2)), "yp_conv_wgrad: 1x1 (stride 1) or 3x3 (pad 1, stride 1 | 2) filters only");
     YP_REQUIRE(x.ptr && dy.ptr && dw && B > 0, "yp_conv_wgrad: null buffer");
@@ -493,9 +513,10 @@ static int wgrad_make_args(YpView x, YpView dy, int dtype, int B, int k, int str
     a.x_cs = x.cstride; a.x_co = x.coff; a.x_ups = x.ups; a.x_H = x.H; a.x_W = x.W;
     a.dy_cs = dy.cstride; a.dy_co = dy.coff;
     a.B = B; a.H = dy.H; a.W = dy.W; a.Cj = x.C; a.Cout_pad = dy.C; a.M = (int)M;
-    a.n_co_blk = yp_cdiv(dy.C, 64);
+    a.blk = blk;
+    a.n_co_blk = yp_cdiv(dy.C, blk);
     a.skip_store = getenv("YP_WG_NOSTORE") != nullptr;
-    const int nblk = yp_cdiv(x.C, 64) * a.n_co_blk;
+    const int nblk = yp_cdiv(x.C, blk) * a.n_co_blk;
     if (k == 3) { a.tiles_x = yp_cdiv(dy.W, 16); a.tiles_y = yp_cdiv(dy.H, stride == 2 ? 4 : 8); a.ntiles = B * a.tiles_x * a.tiles_y; }
     else a.ntiles = yp_cdiv((int)M, 128);
     // pixel split: one workgroup per CU.  Every workgroup ends in 64*64*taps fp32 atomics and the chip retires only ~250 G of them
@@ -528,27 +549,30 @@ extern "C" int yp_conv_wgrad(YpView x, YpView dy, int dtype, int B, int k, int s
 
 extern "C" size_t yp_wgrad_group_entry_bytes(void) { return sizeof(WgradArgs); }
 
-extern "C" int yp_wgrad_group_pack(const YpView* xs, const YpView* dys, float* const* dws, int n, int dtype, int B, int k, int stride, void* table_host,
+extern "C" int yp_wgrad_group_pack(const YpView* xs, const YpView* dys, float* const* dws, int n, int dtype, int B, int k, int stride, int block, void* table_host,
                                    int* total_blocks) {
-    return yp_wgrad_group_pack_det(xs, dys, dws, nullptr, n, dtype, B, k, stride, table_host, total_blocks, nullptr);
+    return yp_wgrad_group_pack_det(xs, dys, dws, nullptr, n, dtype, B, k, stride, block, table_host, total_blocks, nullptr);
 }
 
-extern "C" size_t yp_wgrad_partial_elems(YpView x, YpView dy, int dtype, int B, int k, int stride) {
+extern "C" int yp_wgrad_block(YpView x, YpView dy, int B, int k) { return wgrad_big_ok(x, dy, B, k) ? 128 : 64; }
+
+extern "C" size_t yp_wgrad_partial_elems(YpView x, YpView dy, int dtype, int B, int k, int stride, int block) {
     WgradArgs a;
     int nblk, split;
     float dummy;
-    if (wgrad_make_args(x, dy, dtype, B, k, stride, &dummy, &a, &nblk, &split, 128) != YP_OK) return 0;
+    if (wgrad_make_args(x, dy, dtype, B, k, stride, &dummy, &a, &nblk, &split, 128, block) != YP_OK) return 0;
     return (size_t)split * a.Cj * (k * k) * a.Cout_pad;
 }
 
 extern "C" int yp_wgrad_group_pack_det(const YpView* xs, const YpView* dys, float* const* dws, float* const* parts, int n, int dtype, int B, int k, int stride,
-                                       void* table_host, int* total_blocks, int* fold_chunks) {
+                                       int block, void* table_host, int* total_blocks, int* fold_chunks) {
+    YP_REQUIRE(block == 64 || block == 128, "yp_wgrad_group_pack: a grouped launch runs ONE block size (64 | 128: yp_wgrad_block of its entries)");
     YP_REQUIRE(xs && dys && dws && table_host && total_blocks && n > 0 && (parts == nullptr || fold_chunks != nullptr), "yp_wgrad_group_pack: bad arguments");
     WgradArgs* t = (WgradArgs*)table_host;
     int blk0 = 0, chunk0 = 0;
     for (int i = 0; i < n; ++i) {
         int nblk, split;
-        if (int rc = wgrad_make_args(xs[i], dys[i], dtype, B, k, stride, dws[i], &t[i], &nblk, &split, 128)) return rc;
+        if (int rc = wgrad_make_args(xs[i], dys[i], dtype, B, k, stride, dws[i], &t[i], &nblk, &split, 128, block)) return rc;
         t[i].g_blk0 = blk0;
         blk0 += nblk * split;
         if (parts != nullptr) {
@@ -564,14 +588,14 @@ extern "C" int yp_wgrad_group_pack_det(const YpView* xs, const YpView* dys, floa
     return YP_OK;
 }
 
-template <int DT, int TAPS, int ST>
+template <int DT, int TAPS, int ST, int NB = 2>
 static hipError_t launch_wgrad_group(const WgradArgs* table, int n, int blocks, hipStream_t st) {
     constexpr int TH = (TAPS == 9 && ST == 2) ? 4 : 8;
     constexpr int HP = 16 * ST + (ST == 1 ? 2 : 1);
     constexpr int HROWS = (TH * ST + (ST == 1 ? 2 : 1)) * HP;
     constexpr int XR = TAPS == 9 ? (HROWS + 31) / 32 * 32 : 128;
-    constexpr size_t lds = (size_t)2 * (4 * XR * 32 + 4 * TH * 16 * 32);
-    auto kern = wgrad_group_kernel<DT, TAPS, ST>;
+    constexpr size_t lds = (size_t)2 * (2 * NB * XR * 32 + 2 * NB * TH * 16 * 32);
+    auto kern = wgrad_group_kernel<DT, TAPS, ST, NB>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -582,17 +606,18 @@ static hipError_t launch_wgrad_group(const WgradArgs* table, int n, int blocks, 
     return hipGetLastError();
 }
 
-extern "C" int yp_wgrad_group_run(const void* table_dev, int n, int total_blocks, int dtype, int k, int stride, void* stream) {
-    return yp_wgrad_group_run_det(table_dev, n, total_blocks, 0, dtype, k, stride, stream);
+extern "C" int yp_wgrad_group_run(const void* table_dev, int n, int total_blocks, int dtype, int k, int stride, int block, void* stream) {
+    return yp_wgrad_group_run_det(table_dev, n, total_blocks, 0, dtype, k, stride, block, stream);
 }
 
-extern "C" int yp_wgrad_group_run_det(const void* table_dev, int n, int total_blocks, int fold_chunks, int dtype, int k, int stride, void* stream) {
+extern "C" int yp_wgrad_group_run_det(const void* table_dev, int n, int total_blocks, int fold_chunks, int dtype, int k, int stride, int block, void* stream) {
     YP_REQUIRE(table_dev && n > 0 && total_blocks > 0 && fold_chunks >= 0 && (dtype == YP_F16 || dtype == YP_BF16), "yp_wgrad_group_run: bad arguments");
+    YP_REQUIRE(block == 64 || (block == 128 && k == 1), "yp_wgrad_group_run: block is 64, or 128 for 1x1 filters");
     YP_REQUIRE((k == 1 && stride == 1) || (k == 3 && (stride == 1 || stride == 2)), "yp_wgrad_group_run: 1x1 (stride 1) or 3x3 (stride 1 | 2)");
     const WgradArgs* t = (const WgradArgs*)table_dev;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e;
-#define YP_G(DT) (k == 1 ? launch_wgrad_group<DT, 1, 1>(t, n, total_blocks, st) : (stride == 2 ? launch_wgrad_group<DT, 9, 2>(t, n, total_blocks, st) : launch_wgrad_group<DT, 9, 1>(t, n, total_blocks, st)))
+#define YP_G(DT) (k == 1 ? (block == 128 ? launch_wgrad_group<DT, 1, 1, 4>(t, n, total_blocks, st) : launch_wgrad_group<DT, 1, 1>(t, n, total_blocks, st)) : (stride == 2 ? launch_wgrad_group<DT, 9, 2>(t, n, total_blocks, st) : launch_wgrad_group<DT, 9, 1>(t, n, total_blocks, st)))
     e = dtype == YP_F16 ? YP_G(YP_F16) : YP_G(YP_BF16);
 #undef YP_G
     if (e != hipSuccess) { yp_set_error("yp_wgrad_group_run: launch failed: %s", hipGetErrorString(e)); return YP_ERR_HIP; }

@@ -4,8 +4,11 @@
   loss   = (det + det_warp) + lambda_loss * infonce + lambda_loss_obj * obj    (train.py:238-241)
   loss.backward(); [gradient all-reduce over ranks]; optimizer.step()         (train.py:245-252)
 
-Forward/backward of the network run through the native plans (yolopoint_amd/training.py); the losses are PyTorch
-autograd; Adam is torch.optim.Adam (train.py:88).  Data: SURVEY.md 8(d) synthetic recipe, generated on the device.
+Forward/backward of the network run through the native plans (yolopoint_amd/training.py).  The loss stage has two formulations with
+bit-identical gradients: the native one (TrainStep._loss_and_grads_native: loss kernels between the plans' own buffers, label
+preparation and the loss sum as native launches -- no framework kernel in a steady-state step) and the autograd one over the
+reference's loss API (utils/loss_functions.py), which YOLOPointv52 / two-graph mode use.  Adam: optim.FlatAdam (one launch) or
+torch.optim.Adam (train.py:88).  Data: SURVEY.md 8(d) synthetic recipe, generated on the device.
 """
 import contextlib
 import ctypes as C

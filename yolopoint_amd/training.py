@@ -360,7 +360,8 @@ class TrainGraph:
             if direct and not image and self.group_wgrad:
                 # nothing in the rest of the backward reads dW or overwrites x / dy: the weight gradients of a filter class are
                 # collected and run as ONE grouped launch at the end of the pass (emit())
-                self.wgroups.setdefault((k, s), []).append((src, draw, dwb, 2 * B * Ho * Wo * Cj * k * k * Cout))
+                # (a class = filter size, stride and the workgroup block size the entry runs with: one kernel instantiation per launch)
+                self.wgroups.setdefault((k, s, lib().yp_wgrad_block(src.c(), draw.c(), B, k)), []).append((src, draw, dwb, 2 * B * Ho * Wo * Cj * k * k * Cout))
             elif image and code != _hip.YP_F32 and (k, s, p) == (6, 2, 2) and Cout_pad <= 80 and os.environ.get("YP_STEM_WGRAD", "1") != "0":
                 # the stem: its own kernel over the packed image (no pixel-major copies of the two largest tensors of the pass)
                 nsl = lib().yp_stem_wgrad_slabs(B, Hi, Wi)
@@ -656,7 +657,7 @@ class TrainGraph:
             for branch, fn in reversed(self.tape):
                 if branch in branches:
                     fn()
-            for (gk, gs), ents in sorted(self.wgroups.items()):
+            for (gk, gs, gblk), ents in sorted(self.wgroups.items()):
                 n = len(ents)
                 xs, dys = (_hip.YpView * n)(*[e[0].c() for e in ents]), (_hip.YpView * n)(*[e[1].c() for e in ents])
                 dws = (C.c_void_p * n)(*[e[2].flat.data_ptr() for e in ents])
@@ -665,22 +666,22 @@ class TrainGraph:
                 if self.det_wgrad:
                     # deterministic reduction: every pixel slice of an entry writes its own slab, a second launch sums them in order.
                     # The slab arena is shared by the filter classes of all backward plans of this graph (they run one after another).
-                    sizes = [round_up(lib().yp_wgrad_partial_elems(e[0].c(), e[1].c(), code, B, gk, gs), 64) for e in ents]
+                    sizes = [round_up(lib().yp_wgrad_partial_elems(e[0].c(), e[1].c(), code, B, gk, gs, gblk), 64) for e in ents]
                     if self.wpart is None:      # sized by the largest filter class of the FULL backward (emitted first; the keypoint-only plan is a subset)
-                        self.wpart = torch.empty(max(sum(round_up(lib().yp_wgrad_partial_elems(e[0].c(), e[1].c(), code, B, k_, s_), 64) for e in es)
-                                                     for (k_, s_), es in self.wgroups.items()), dtype=torch.float32, device=self.device)
+                        self.wpart = torch.empty(max(sum(round_up(lib().yp_wgrad_partial_elems(e[0].c(), e[1].c(), code, B, k_, s_, b_), 64) for e in es)
+                                                     for (k_, s_, b_), es in self.wgroups.items()), dtype=torch.float32, device=self.device)
                         self.keep.append(self.wpart)
                     assert sum(sizes) <= self.wpart.numel()
                     offs = [sum(sizes[:i]) for i in range(n)]
                     parts = (C.c_void_p * n)(*[self.wpart.data_ptr() + 4 * o for o in offs])
-                    check(lib().yp_wgrad_group_pack_det(xs, dys, dws, parts, n, code, B, gk, gs, host, C.byref(blocks), C.byref(fold)))
+                    check(lib().yp_wgrad_group_pack_det(xs, dys, dws, parts, n, code, B, gk, gs, gblk, host, C.byref(blocks), C.byref(fold)))
                 else:
-                    check(lib().yp_wgrad_group_pack(xs, dys, dws, n, code, B, gk, gs, host, C.byref(blocks)))
+                    check(lib().yp_wgrad_group_pack(xs, dys, dws, n, code, B, gk, gs, gblk, host, C.byref(blocks)))
                 wtab = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(self.device)
                 self.keep.append(wtab)
                 bb.op(_hip.OP_WGRAD_GROUP, [v for e in ents for v in e[:2]], [e[2].view() for e in ents] + ([self.T(self.wpart)] if self.det_wgrad else []),
-                      f"wgrad_k{gk}s{gs}", p=[wtab],
-                      i=[code, n, blocks.value, gk, gs, fold.value])
+                      f"wgrad_k{gk}s{gs}" + ("b128" if gblk == 128 else ""), p=[wtab],
+                      i=[code, n, blocks.value, gk, gs, fold.value, gblk])
                 bb.records[-1].kind, bb.records[-1].flops = "conv", sum(e[3] for e in ents)
             rows, tile0 = [], 0
             for u in self.unpack:
