@@ -33,7 +33,7 @@ def test_train_forward_matches_reference_golden(cuda):
 
 
 @pytest.mark.parametrize("version,B,H,W", [("n", 2, 64, 64), ("s", 2, 128, 128), ("n", 3, 128, 192), ("s", 5, 64, 192)])
-def test_backward_matches_oracle_autograd(cuda, version, B, H, W):
+def test_backward_matches_oracle_autograd(cuda, fixed_kernel_variants, version, B, H, W):
     """(square and non-square inputs, odd batch sizes)"""
     m, sd = make_model(version, 31, dtype="f32")
     m = m.to(cuda).train()
@@ -63,7 +63,7 @@ def test_backward_matches_oracle_autograd(cuda, version, B, H, W):
     print("largest gradient rel-L2 errors:", sorted(worst)[-3:])
 
 
-def test_keypoint_only_backward_matches_oracle_autograd(cuda):
+def test_keypoint_only_backward_matches_oracle_autograd(cuda, fixed_kernel_variants):
     """A forward whose `objects` take no part in the loss (the warped pass of a training step, train.py:220-241) is
     back-propagated through the semi / desc sub-graph only: its parameters match PyTorch-CPU autograd through the oracle,
     and the Detect / PAN / YOLO-encoder parameters receive no gradient at all (as with autograd)."""
@@ -132,7 +132,7 @@ def test_train_step_with_precomputed_label_parts(cuda):
 
 
 @pytest.mark.parametrize("kp_only", [False, True])
-def test_v52_backward_matches_oracle_autograd(cuda, kp_only):
+def test_v52_backward_matches_oracle_autograd(cuda, fixed_kernel_variants, kp_only):
     """YOLOPointv52 training path (C2f / Bottleneckv8 blocks, MaxPool2d descriptor branch, the 65-channel BN keypoint head with
     padded BN parameters, descriptor normalisation differentiated in PyTorch) against CPU autograd through the oracle:
     train-mode outputs, running statistics of the 65-channel BN, and every parameter gradient."""
@@ -383,7 +383,7 @@ def test_train_forward_without_backward_releases_its_plans(cuda):
 
 
 @pytest.mark.parametrize("tag,version,B,S,seed", [("s64", "s", 2, 64, 31), ("n128", "n", 3, 128, 32)])
-def test_backward_matches_reference_golden(cuda, tag, version, B, S, seed):
+def test_backward_matches_reference_golden(cuda, fixed_kernel_variants, tag, version, B, S, seed):
     """The f32 HIP path against the REFERENCE's loss.backward() (train.py:245): all 215 parameter gradients and the train-mode loss
     of seeded output projections, tests/golden/backward.npz (sketches: norm + 8 projections + small tensors whole)."""
     from helpers import check_grad_sketch
@@ -401,7 +401,7 @@ def test_backward_matches_reference_golden(cuda, tag, version, B, S, seed):
 
 @pytest.mark.parametrize("name,version,B,H,W,flat", [("YOLOPoint", "n", 2, 64, 64, False), ("YOLOPoint", "s", 3, 128, 64, False),
                                                       ("YOLOPointv52", "n", 2, 64, 128, False), ("YOLOPoint", "s", 2, 128, 128, True)])
-def test_pair_pass_matches_two_oracle_passes(cuda, name, version, B, H, W, flat):
+def test_pair_pass_matches_two_oracle_passes(cuda, fixed_kernel_variants, name, version, B, H, W, flat):
     """forward_pair(img, img_warp) == model(img); model(img_warp) of the reference step (train.py:208,220) run through the oracle one
     after the other: outputs of both passes, BatchNorm running statistics after both updates, and every parameter gradient of a loss
     over the image pass's three heads and the warped pass's semi / desc (fp32 compute path: the two-call bars)."""

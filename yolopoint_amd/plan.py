@@ -577,6 +577,8 @@ class PlanBuilder:
         else:
             run = lambda: lib().yp_conv2d(C.byref(d), st)
         best, best_ms = 0, None
+        rnd = os.environ.get("YP_TUNE_RANDOM")        # stress mode (tests): a pseudo-random applicable variant per signature instead of the fastest
+        applicable = []
         for cand in _TUNE_CANDIDATES:
             if det is not None and 10 <= cand <= 15:
                 continue
@@ -585,6 +587,9 @@ class PlanBuilder:
             d.tile = cand
             if run() != 0:
                 continue                              # variant does not apply to this convolution
+            if rnd is not None:
+                applicable.append(cand)
+                continue
             run()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -597,6 +602,17 @@ class PlanBuilder:
                 print(f"[tune] {self.name():40s} cand {cand:2d}: {ms / 8 * 1e3:7.1f} us", flush=True)
             if best_ms is None or ms < best_ms:
                 best, best_ms = cand, ms
+        if rnd is not None and applicable:
+            import random
+            best, best_ms = random.Random(f"{rnd}:{len(_TUNE_CACHE)}").choice(applicable), None
+            force = dict(tuple(int(v) for v in kv.split(":")) for kv in os.environ.get("YP_TUNE_FORCE", "").split(",") if kv)
+            if force:                                             # explicit mixture: signature index -> variant, everything else the first one
+                best = force.get(len(_TUNE_CACHE), applicable[0])
+            lim = os.environ.get("YP_TUNE_RANDOM_LIMIT")          # bisecting a failing mixture: signatures past the limit take the first variant
+            if lim is not None and not any(int(r_.split(",")[0]) <= len(_TUNE_CACHE) < int(r_.split(",")[1]) for r_ in lim.split(";")):
+                best = applicable[0]
+            if os.environ.get("YP_TUNE_DEBUG"):
+                print(f"[tune-random] {self.name():44s} pick {best:2d} of {applicable} zs={int(d.in0_zero_stuffed)} k={d.R}x{d.S} s={d.stride_h} Cin={d.in0.C}+{d.in1.C} N={d.Npad} M={d.B * d.Ho * d.Wo}", flush=True)
         _TUNE_CACHE[key] = (best, (best_ms / 8 if best_ms is not None else None))
         if shared is not None:
             shared[0].broadcast(torch.tensor([float(best), float(best_ms / 8 if best_ms is not None else 0.0)], dtype=torch.float32, device=self.device), src=0)
