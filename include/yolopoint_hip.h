@@ -143,6 +143,12 @@ typedef struct YpConvDesc {
      * Kpad % 64 == 0 (bytes = elements), tail_zero, no out_f32 / split / Detect / pointwise prologue; generic kernel only. */
     const float* scale_in;
     const float* scale_w;
+    /* out_phase = 1 + 2 py + px: `out` (and `res`) are the pixels of parity (py, px) of a [2 out.H][2 out.W] tensor -- output pixel (b, y, x)
+     * lands at (b, 2y + py, 2x + px); out.ptr is that tensor's base.  0: dense.  The dgrad of a 3x3 / stride-2 convolution is four such
+     * launches with yp_pack_weight modes 4..7 ((1 + py) x (1 + px) taps each, pad 0, out dims = dout's) instead of one 3x3 launch over a
+     * zero-stuffed tensor: a quarter of the multiply-adds.  No out2 / Detect / bn_partial / ksplit / pointwise prologue. */
+    int32_t out_phase;
+    int32_t reserved_;
 } YpConvDesc;
 
 /* Number of bn_partial rows the launch described by `d` (its tile id included) writes; rows are batch-major, so with `groups` statistics
@@ -334,6 +340,8 @@ int yp_wgrad_unpack_batch(const YpUnpackEntry* table_dev, int n_entries, int tot
  *   mode 2  image-like filter (Cin <= 4, S even) for the 16-bit stem, which reads the packed image as [H][W/2][8] (two pixels of
  *           4 channels):                                        dst[n][(r*S/2 + s/2)*8 + (s%2)*4 + c] = w[n][c][r][s]  (c < Cin, else 0)
  *   mode 3  the same filter padded to 4 channels (fp32 plans):  dst[n][(r*S+s)*4 + c]        = w[n][c][r][s]
+ *   mode 4 + 2 py + px  (3x3 filters) the dgrad filter of a stride-2 / pad-1 convolution for the input pixels of parity (py, px):
+ *           dst[c][(r'*(1+px) + s')*Cout_pad + n] = w[n][c0+c][r][s],  r = 1 (py = 0) | 2 - 2 r' (py = 1), s likewise  (YpConvDesc.out_phase)
  * bias (may be NULL) is copied, zero padded, to bias_dst[Npad].
  * replaces: the conv.weight casts autocast performs every forward (reference train.py:206) + autograd's filter transposes */
 int yp_pack_weight(const float* w, int Cout, int Cin, int R, int S, int c0, int Cj, int mode, int Cout_pad, void* dst, int Kpad,

@@ -74,6 +74,7 @@ struct ConvKArgs {
     int in1_cs, in1_co, in1_ups, in1_H, in1_W;
     int res_cs, res_co, has_res;
     int out_cs, out_co;
+    int out_sub, out_py, out_px;   // out_sub: `out` / `res` are the parity-(py, px) pixels of a [2 Ho][2 Wo] tensor (YpConvDesc.out_phase)
     char* out2; int out2_cs, out2_co, split;      // channels >= split go to out2 (split == Cout: unused)
     int Hi, Wi, Wo, HoWo;
     int Cin, Cout, Kreal, Kpad, Npad;
@@ -122,6 +123,10 @@ template <int DT, bool OUT_F32, int CW>
 __device__ __forceinline__ void yp_store_chunk(const ConvKArgs& a, int m, int nc, float (&v)[CW]) {
     using E = Elem<DT>;
     constexpr int EB = E::OBYTES;        // (results and the residual they add are 16-bit for the 8-bit input types)
+    if (a.out_sub) {                     // pixel (b, y, x) of the Ho x Wo launch grid -> (b, 2y + py, 2x + px) of the tensor behind `out` / `res`
+        const int b = m / a.HoWo, rem = m - b * a.HoWo, y = rem / a.Wo, x = rem - y * a.Wo;
+        m = (b * 2 * (a.HoWo / a.Wo) + 2 * y + a.out_py) * (2 * a.Wo) + 2 * x + a.out_px;
+    }
     if (a.has_res) {
         const char* rp = a.res + ((size_t)m * a.res_cs + a.res_co + nc) * EB;
         if constexpr (DT == YP_F32) {

@@ -1606,9 +1606,15 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
     {   // the caller may ask for fewer output rows / columns than the full convolution yields (wgrad of a strided conv)
         const int fullH = (d->Hi + 2 * d->pad_h - dil_h * (d->R - 1) - 1) / d->stride_h + 1;
         const int fullW = (d->Wi + 2 * d->pad_w - dil_w * (d->S - 1) - 1) / d->stride_w + 1;
-        YP_REQUIRE(d->Ho <= fullH && d->Wo <= fullW && (dil_h > 1 || dil_w > 1 || (d->Ho == fullH && d->Wo == fullW)),
+        // (out_phase: a (1 + py) x (1 + px)-tap launch over dout with as many output pixels as dout has -- the taps behind the last row / column
+        // read zeros through the kernels' bounds checks)
+        YP_REQUIRE(d->out_phase != 0 || (d->Ho <= fullH && d->Wo <= fullW && (dil_h > 1 || dil_w > 1 || (d->Ho == fullH && d->Wo == fullW))),
                    "yp_conv2d: Ho/Wo (%d,%d) inconsistent with input, filter, stride, pad, dilation (%d,%d)", d->Ho, d->Wo, fullH, fullW);
     }
+    YP_REQUIRE(d->out_phase == 0 || (d->out_phase >= 1 && d->out_phase <= 4 && d->out2.C == 0 && det == nullptr && d->bn_partial == nullptr && d->ksplit <= 1 &&
+                                     !d->atomic_accumulate && d->pre_weight == nullptr && d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 0 && d->pad_w == 0 &&
+                                     d->Ho == d->Hi && d->Wo == d->Wi && d->R <= 2 && d->S <= 2 && dil_h == 1 && dil_w == 1),
+               "yp_conv2d: out_phase is a plain stride-1, pad-0 launch of at most 2x2 taps with Ho x Wo = Hi x Wi (no out2 / Detect / bn_partial / ksplit / prologue)");
     const int ksplit = d->ksplit > 1 ? d->ksplit : 1;
     YP_REQUIRE(ksplit == 1 || (d->out_f32 && d->act == YP_ACT_NONE && d->res.C == 0 && d->out2.C == 0 && d->bias == nullptr && ksplit <= 4096), "yp_conv2d: split-K needs a plain fp32 accumulation target");
     YP_REQUIRE(!d->in0_zero_stuffed || d->in0.ups == 1, "yp_conv2d: a zero-stuffed input is addressed through ups = 1");
@@ -1625,6 +1631,7 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
     a.in1_cs = d->in1.cstride; a.in1_co = d->in1.coff; a.in1_ups = d->in1.ups; a.in1_H = d->in1.H; a.in1_W = d->in1.W;
     a.res_cs = d->res.cstride; a.res_co = d->res.coff; a.has_res = d->res.C != 0;
     a.out_cs = d->out.cstride; a.out_co = d->out.coff;
+    a.out_sub = d->out_phase != 0; a.out_py = (d->out_phase - 1) >> 1; a.out_px = (d->out_phase - 1) & 1;
     a.out2 = (char*)d->out2.ptr; a.out2_cs = d->out2.cstride; a.out2_co = d->out2.coff; a.split = d->out.C;
     a.Hi = d->Hi; a.Wi = d->Wi; a.Wo = d->Wo; a.HoWo = d->Ho * d->Wo;
     a.Cin = Cin; a.Cout = Cout; a.Kreal = Kreal; a.Kpad = d->Kpad; a.Npad = d->Npad;

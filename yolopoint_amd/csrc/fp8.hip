@@ -69,7 +69,6 @@ __global__ __launch_bounds__(256) void pack_weight_fp8_kernel(const YpPackEntry8
     const int Cout = (int)en.Cout, Cin = (int)en.Cin, R = (int)en.R, S = (int)en.S, c0 = (int)en.c0, Cj = (int)en.Cj, mode = (int)en.mode;
     const int Cout_pad = (int)en.Cout_pad, Kpad = (int)en.Kpad, Npad = (int)en.Npad;
     const size_t total = (size_t)(Npad + 1) * Kpad;
-    const int Cq = mode == 0 ? Cj : Cout_pad, Nreal = mode == 0 ? Cout : Cj, Kreal = R * S * Cq;
     const float inv = 1.0f / en.scale[0];
     const size_t base = ((size_t)(bid - (int)en.blk0) * 256 + threadIdx.x) * 4;       // 4 consecutive k of one row per thread (Kpad % 4 == 0)
     float mx = 0.f;
@@ -79,13 +78,7 @@ __global__ __launch_bounds__(256) void pack_weight_fp8_kernel(const YpPackEntry8
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int k = k0 + u;
-            float x = 0.f;
-            if (n < Nreal && k < Kreal) {
-                const int tap = k / Cq, c = k - tap * Cq;
-                const int r = tap / S, s_ = tap - r * S;
-                if (mode == 0) x = en.w[(((size_t)n * Cin + c0 + c) * R + r) * S + s_];
-                else if (c < Cout) x = en.w[(((size_t)c * Cin + c0 + n) * R + (R - 1 - r)) * S + (S - 1 - s_)];
-            }
+            const float x = yp_pack_elem(en.w, Cout, Cin, R, S, c0, Cj, mode, Cout_pad, n, k);
             mx = fmaxf(mx, fabsf(x));
             v[u] = x * inv;
         }

@@ -910,26 +910,6 @@ extern "C" int yp_cast_from_f32(YpView in, YpView out, int dtype, int B, void* s
     return YP_OK;
 }
 
-// element (n, k) of a packed filter image.  mode 0: forward filter of input channels [c0, c0 + Cj); 1: the dgrad filter of that slice
-// (flipped, channel-transposed); 2 / 3: the image-like (<= 4 channel) stem filter for 16-bit / fp32 plans -- 2 pairs adjacent pixels
-// (k = (r * S/2 + s/2) * 8 + (s % 2) * 4 + c, what the [H, W/2, 8] view of the packed image multiplies), 3 pads to 4 channels.
-__device__ __forceinline__ float pack_elem(const float* __restrict__ w, int Cout, int Cin, int R, int S, int c0, int Cj, int mode, int Cout_pad, int n, int k) {
-    if (mode >= 2) {
-        const int Cq = mode == 2 ? 8 : 4, Sq = mode == 2 ? S / 2 : S;
-        if (n >= Cout || k >= R * Sq * Cq) return 0.f;
-        const int tap = k / Cq, j = k - tap * Cq;
-        const int r = tap / Sq, sq = tap - r * Sq;
-        const int c = j & 3, s_ = mode == 2 ? 2 * sq + (j >> 2) : sq;
-        return c < Cin ? w[(((size_t)n * Cin + c) * R + r) * S + s_] : 0.f;
-    }
-    const int Cq = mode == 0 ? Cj : Cout_pad, Nreal = mode == 0 ? Cout : Cj;
-    if (n >= Nreal || k >= R * S * Cq) return 0.f;
-    const int tap = k / Cq, c = k - tap * Cq;
-    const int r = tap / S, s_ = tap - r * S;
-    if (mode == 0) return w[(((size_t)n * Cin + c0 + c) * R + r) * S + s_];
-    return c < Cout ? w[(((size_t)c * Cin + c0 + n) * R + (R - 1 - r)) * S + (S - 1 - s_)] : 0.f;
-}
-
 template <int DT>
 __global__ void pack_weight_kernel(const float* __restrict__ w, int Cout, int Cin, int R, int S, int c0, int Cj, int mode, int Cout_pad,
                                    char* __restrict__ dst, int Kpad, int Npad, const float* __restrict__ bias, float* __restrict__ bias_dst) {
@@ -937,7 +917,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int Cout, int Ci
     const size_t total = (size_t)(Npad + 1) * Kpad;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int n = (int)(i / Kpad), k = (int)(i - (size_t)n * Kpad);
-        const float v = pack_elem(w, Cout, Cin, R, S, c0, Cj, mode, Cout_pad, n, k);
+        const float v = yp_pack_elem(w, Cout, Cin, R, S, c0, Cj, mode, Cout_pad, n, k);
         reinterpret_cast<sc*>(dst)[i] = (sc)v;
         if (bias_dst != nullptr && i < (size_t)Npad) bias_dst[i] = (bias != nullptr && (int)i < Cout) ? bias[i] : 0.f;
     }
@@ -945,10 +925,13 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int Cout, int Ci
 
 extern "C" int yp_pack_weight(const float* w, int Cout, int Cin, int R, int S, int c0, int Cj, int mode, int Cout_pad, void* dst, int Kpad,
                               int Npad, int dtype, const float* bias, float* bias_dst, void* stream) {
-    YP_REQUIRE(w && dst && Cout > 0 && Cin > 0 && R > 0 && S > 0 && c0 >= 0 && Cj > 0 && c0 + Cj <= Cin && mode >= 0 && mode <= 3, "yp_pack_weight: bad arguments");
-    YP_REQUIRE(mode < 2 || (Cin <= 4 && c0 == 0 && (mode == 3 || S % 2 == 0)), "yp_pack_weight: modes 2 / 3 pack an image-like filter (<= 4 input channels; 2: even width)");
-    const int Cq = mode == 0 ? Cj : (mode == 1 ? Cout_pad : 4), Nreal = mode == 1 ? Cj : Cout;       // (modes 2 / 3: 4 k slots per filter pixel)
-    YP_REQUIRE((mode != 1 || Cout_pad >= Cout) && Kpad >= R * S * Cq && Npad >= Nreal, "yp_pack_weight: packed dims %dx%d too small", Npad, Kpad);
+    YP_REQUIRE(w && dst && Cout > 0 && Cin > 0 && R > 0 && S > 0 && c0 >= 0 && Cj > 0 && c0 + Cj <= Cin && mode >= 0 && mode <= 7, "yp_pack_weight: bad arguments");
+    YP_REQUIRE(mode < 2 || mode > 3 || (Cin <= 4 && c0 == 0 && (mode == 3 || S % 2 == 0)), "yp_pack_weight: modes 2 / 3 pack an image-like filter (<= 4 input channels; 2: even width)");
+    YP_REQUIRE(mode < 4 || (R == 3 && S == 3), "yp_pack_weight: modes 4..7 are the parity classes of a 3x3 stride-2 dgrad");
+    const bool tr = mode == 1 || mode >= 4;                                // channel-transposed (dgrad) forms: rows = input channels
+    const int taps = mode >= 4 ? (1 + ((mode - 4) >> 1)) * (1 + ((mode - 4) & 1)) : R * S;
+    const int Cq = mode == 0 ? Cj : (tr ? Cout_pad : 4), Nreal = tr ? Cj : Cout;       // (modes 2 / 3: 4 k slots per filter pixel)
+    YP_REQUIRE((!tr || Cout_pad >= Cout) && Kpad >= taps * Cq && Npad >= Nreal, "yp_pack_weight: packed dims %dx%d too small", Npad, Kpad);
     const size_t total = (size_t)(Npad + 1) * Kpad;
     YP_DT_SWITCH(dtype, (pack_weight_kernel<DT><<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(w, Cout, Cin, R, S, c0, Cj, mode, Cout_pad, (char*)dst, Kpad, Npad,
                                                                                                      bias, bias_dst)));
@@ -978,7 +961,7 @@ __global__ __launch_bounds__(256) void pack_weight_batch_kernel(const YpPackEntr
         const size_t i = base + u * 256 + threadIdx.x;
         if (i >= total) break;
         const int n = (int)(i / Kpad), k = (int)(i - (size_t)n * Kpad);
-        const float v = pack_elem(en.w, Cout, Cin, R, S, c0, Cj, mode, Cout_pad, n, k);
+        const float v = yp_pack_elem(en.w, Cout, Cin, R, S, c0, Cj, mode, Cout_pad, n, k);
         reinterpret_cast<sc*>(en.dst)[i] = (sc)v;
         if (en.bias_dst != nullptr && i < (size_t)Npad) en.bias_dst[i] = (en.bias != nullptr && (int)i < Cout) ? en.bias[i] : 0.f;
     }

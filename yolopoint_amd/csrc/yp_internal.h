@@ -29,6 +29,37 @@ void yp_set_error(const char* fmt, ...);
 static inline int yp_dtype_bytes(int dtype) { return dtype == YP_F32 ? 4 : ((dtype == YP_FP8 || dtype == YP_FP8_BF8) ? 1 : 2); }
 static inline int yp_cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// element (n, k) of a packed filter image (yp_pack_weight).  mode 0: forward filter of input channels [c0, c0 + Cj); 1: the dgrad filter of
+// that slice (flipped, channel-transposed); 2 / 3: the image-like (<= 4 channel) stem filter for 16-bit / fp32 plans -- 2 pairs adjacent pixels
+// (k = (r * S/2 + s/2) * 8 + (s % 2) * 4 + c, what the [H, W/2, 8] view of the packed image multiplies), 3 pads to 4 channels;
+// 4 + 2 py + px: the dgrad filter of a 3x3 / stride-2 / pad-1 convolution for the input pixels of parity (py, px) -- only the taps that
+// reach such a pixel: din(2y + py, 2x + px) = sum over r' < 1 + py, s' < 1 + px of dout(y + r', x + s') . w[.][.][r][s] with r = 1 (py = 0) or
+// r = 2 - 2 r' (py = 1), the same along x: a (1 + py) x (1 + px) stride-1 convolution over dout instead of a 3x3 one over a zero-stuffed tensor.
+__device__ __forceinline__ float yp_pack_elem(const float* __restrict__ w, int Cout, int Cin, int R, int S, int c0, int Cj, int mode, int Cout_pad, int n, int k) {
+    if (mode >= 4) {
+        const int py = (mode - 4) >> 1, px = (mode - 4) & 1, Sp = 1 + px;
+        if (n >= Cj || k >= (1 + py) * Sp * Cout_pad) return 0.f;
+        const int tap = k / Cout_pad, c = k - tap * Cout_pad;
+        const int rp = tap / Sp, sp = tap - rp * Sp;
+        const int r = py ? 2 - 2 * rp : 1, s_ = px ? 2 - 2 * sp : 1;
+        return c < Cout ? w[(((size_t)c * Cin + c0 + n) * R + r) * S + s_] : 0.f;
+    }
+    if (mode >= 2) {
+        const int Cq = mode == 2 ? 8 : 4, Sq = mode == 2 ? S / 2 : S;
+        if (n >= Cout || k >= R * Sq * Cq) return 0.f;
+        const int tap = k / Cq, j = k - tap * Cq;
+        const int r = tap / Sq, sq = tap - r * Sq;
+        const int c = j & 3, s_ = mode == 2 ? 2 * sq + (j >> 2) : sq;
+        return c < Cin ? w[(((size_t)n * Cin + c) * R + r) * S + s_] : 0.f;
+    }
+    const int Cq = mode == 0 ? Cj : Cout_pad, Nreal = mode == 0 ? Cout : Cj;
+    if (n >= Nreal || k >= R * S * Cq) return 0.f;
+    const int tap = k / Cq, c = k - tap * Cq;
+    const int r = tap / S, s_ = tap - r * S;
+    if (mode == 0) return w[(((size_t)n * Cin + c0 + c) * R + r) * S + s_];
+    return c < Cout ? w[(((size_t)c * Cin + c0 + n) * R + (R - 1 - r)) * S + (S - 1 - s_)] : 0.f;
+}
+
 // launchers living in other translation units (used by the plan)
 int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t stream);
 

@@ -131,7 +131,13 @@ class MasterWeight:
         # logical OIHW shape of the filter the convolution sees
         # (mode "image": the <= 4-channel stem filter; the plan picks the packed form -- pixel pairs for 16-bit plans, 4-channel padding
         # for fp32 ones: yp_pack_weight modes 2 / 3)
-        self.shape = (Cout, self.cj, R, S) if mode in (0, "image") else (self.cj, self.cout_pad, R, S)
+        # (mode ("phase", py, px): the dgrad filter of a 3x3 / stride-2 / pad-1 convolution for the input pixels of parity (py, px) -- the
+        # (1 + py) x (1 + px) taps that reach them: yp_pack_weight modes 4..7, YpConvDesc.out_phase)
+        if isinstance(mode, tuple):
+            assert mode[0] == "phase" and (R, S) == (3, 3)
+            self.shape = (self.cj, self.cout_pad, 1 + mode[1], 1 + mode[2])
+        else:
+            self.shape = (Cout, self.cj, R, S) if mode in (0, "image") else (self.cj, self.cout_pad, R, S)
 
 
 class Fp8State:
@@ -368,7 +374,7 @@ class PlanBuilder:
             self.keep += [wp]
         elif master is not None:
             assert thin == (master.mode == "image"), "image-like (thin) inputs take MasterWeight(mode='image')"
-            pmode = (2 if pair else 3) if thin else master.mode
+            pmode = (2 if pair else 3) if thin else (4 + 2 * master.mode[1] + master.mode[2] if isinstance(master.mode, tuple) else master.mode)
             # (thin: 4 k slots per filter pixel -- S was halved above when pixels are paired and each tap covers 8)
             Kpad, Npad = lib().yp_conv_kpad(R * S * ((8 if pair else 4) if thin else Cin), conv_dtype), round_up(Cout, 8)
             assert bool(master.q8) == (q8 is not None)
@@ -391,7 +397,7 @@ class PlanBuilder:
                 tgt.keep += [wp, bp, master.param]
                 tgt.__dict__.setdefault("pack8_entries", []).append(
                     [master.param.data_ptr(), wp.data_ptr(), self.fp8.scale_ptr(w_slot), self.fp8.amax_ptr(w_slot), mo, mi, mr, ms,
-                     master.c0, master.cj, master.mode, master.cout_pad, Kpad, Npad])
+                     master.c0, master.cj, pmode, master.cout_pad, Kpad, Npad])
                 if cache is not None:
                     cache[key] = (wp, bp)
             else:
@@ -441,6 +447,8 @@ class PlanBuilder:
             d.split_slabs, d.split_stride = slabs[0].data_ptr(), int(slabs[1])
             self.keep.append(slabs[0])
         d.atomic_accumulate = int(extra.get("atomic", 0))
+        if extra.get("out_phase") is not None:      # (py, px): `out` / `res` are that parity class of a [2 Ho][2 Wo] tensor (views with geom = (Ho, Wo, cstride))
+            d.out_phase = 1 + 2 * int(extra["out_phase"][0]) + int(extra["out_phase"][1])
         d.Kpad, d.Npad, d.act, d.tile, d.tail_zero = Kpad, Npad, act, tile, 1
         bn_partial = extra.get("bn_partial")        # fp32 [ceil(M/64)][2][Cout_pad]: BatchNorm column sums written by the epilogue
         if bn_partial is not None:
@@ -475,7 +483,7 @@ class PlanBuilder:
         if tile == 0 and self.autotune and d.ksplit == 1 and not d.atomic_accumulate:
             d.tile, tuned_ms = self._autotune(d, det, (conv_dtype, d.B, Hi, Wi, tuple((v.C, v.ups) for v in srcs), Cout_pad, R, S, sh, sw, dil, zs,
                                                        int(out_f32), res is not None, c2, act, detect is not None, pre is not None, post is not None,
-                                                       bn_partial is not None, extra.get("stat_group_px")), stat_group_px=extra.get("stat_group_px"))
+                                                       bn_partial is not None, extra.get("stat_group_px"), extra.get("out_phase")), stat_group_px=extra.get("stat_group_px"))
         if bn_partial is not None:                  # how many partial rows the chosen kernel variant writes (they are batch-major)
             rows = C.c_int(0)
             check(lib().yp_conv_bn_partial_rows(C.byref(d), C.byref(rows)))
