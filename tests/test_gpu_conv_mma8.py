@@ -170,3 +170,42 @@ def test_batchnorm_statistics_epilogue(cuda, tile):
     s1, s2 = p0[0].sum(1), p0[1].sum(1)
     assert float((s1 - ref.sum(0)).abs().max()) / float(ref.sum(0).abs().max()) < 1e-4
     assert float((s2 - (ref * ref).sum(0)).abs().max()) / float((ref * ref).sum(0).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("Cin,Cout,B,Ho,Wo,tile", [(32, 64, 2, 10, 14, 0), (64, 128, 3, 8, 8, 4), (128, 128, 2, 12, 10, 44), (128, 256, 1, 9, 7, 3)])
+def test_stride2_dgrad_as_four_parity_class_convolutions(cuda, dtype, Cin, Cout, B, Ho, Wo, tile):
+    """Gradient of Conv(Cin, Cout, 3, 2, 1) w.r.t. its input (reference: autograd through models/common.py:22-34 at stride 2): the input pixels
+    of parity (py, px) receive (1 + py) x (1 + px) of the nine taps, so the gradient is four small stride-1 convolutions over dy
+    (yp_pack_weight modes 4..7) whose epilogues write their parity class of the [2 Ho][2 Wo] tensor (YpConvDesc.out_phase) -- against
+    torch's conv_transpose2d on the same rounded operands, overwriting and accumulating into an existing gradient."""
+    from yolopoint_amd.plan import MasterWeight, View
+    if dtype == "f32" and tile == 44:
+        pytest.skip("the 8-wave kernel has no fp32 instantiation")
+    code = _hip.dtype_code(dtype)
+    dt = _hip.torch_dtype(code)
+    g = torch.Generator().manual_seed(Cin + Ho)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (1.0 / (Cout * 9) ** 0.5)).to(cuda)
+    dy = torch.randn(B, Ho, Wo, Cout, generator=g).to(dt)
+    prev = torch.randn(B, 2 * Ho, 2 * Wo, Cin, generator=g).to(dt)
+    wq = w.cpu().to(dt).float() if dtype != "f32" else w.cpu()
+    ref = F.conv_transpose2d(dy.float().permute(0, 3, 1, 2), wq, None, 2, 1, output_padding=1).permute(0, 2, 3, 1)
+    for acc in (False, True):
+        pb = PlanBuilder(B, code, cuda)
+        pb.autotune = False
+        src = pb.new_buf(Ho, Wo, Cout)
+        src.t.copy_(dy.to(cuda))
+        dst = pb.new_buf(2 * Ho, 2 * Wo, Cin)
+        dst.t.copy_(prev.to(cuda))
+        for py in (0, 1):
+            for px in (0, 1):
+                ph = View(dst, 0, Cin, 0, geom=(Ho, Wo, dst.C))
+                pb.conv([src.view()], MasterWeight(w, mode=("phase", py, px), c0=0, cj=Cin, cout_pad=Cout), None, 0, 1, 0, _hip.YP_ACT_NONE, out=ph,
+                        res=ph if acc else None, tile=tile, extra=dict(out_phase=(py, px), out_hw=(Ho, Wo)))
+        plan = pb.finish()
+        plan.run()
+        torch.cuda.synchronize()
+        got = dst.t.float().cpu()
+        want = ref + (prev.float() if acc else 0.0)
+        err = float((got - want).abs().max()) / float(want.abs().max())
+        assert err < (2e-5 if dtype == "f32" else 1.6e-2), (acc, err)
