@@ -625,6 +625,39 @@ def test_flat_adam_matches_torch_adam(cuda):
         opt.step()
 
 
+def test_flat_adam_state_numbering_with_frozen_layers(cuda):
+    """A partly frozen model (freeze_layers: requires_grad = False on some parameters): the reference gives Adam ALL parameters
+    (train.py:88) and torch numbers its state by that position; FlatAdam(all_params=model.parameters()) writes the same numbering, so the
+    checkpoint loads into torch.optim.Adam(model.parameters()) with every moment on its own parameter."""
+    from yolopoint_amd.dp import GradAllReducer
+    from yolopoint_amd.optim import FlatAdam
+    m, _ = make_model("n", 6, dtype="bf16")
+    m = m.to(cuda).train()
+    allp = list(m.parameters())
+    for p in allp[:7]:
+        p.requires_grad_(False)                               # (the first layers frozen)
+    live = [p for p in allp if p.requires_grad]
+    red = GradAllReducer(live)
+    opt = FlatAdam(red, params=live, lr=1e-3, all_params=allp)
+    red.bind_grads(zero=True)
+    gen = torch.Generator(device=cuda).manual_seed(2)
+    for p in live:
+        p.grad.copy_(torch.randn(p.shape, device=cuda, generator=gen))
+    opt.step()
+    sd = opt.state_dict()
+    assert sorted(sd["state"]) == list(range(7, len(allp))) and sd["param_groups"][0]["params"] == list(range(len(allp)))
+    t2 = torch.optim.Adam(allp, lr=1.0)
+    t2.load_state_dict(sd)
+    for i, p in enumerate(allp):
+        if i < 7:
+            assert p not in t2.state or len(t2.state[p]) == 0
+        else:
+            assert torch.equal(t2.state[p]["exp_avg"], sd["state"][i]["exp_avg"]) and t2.state[p]["exp_avg"].shape == p.shape
+    opt2 = FlatAdam(red, params=live, lr=1e-3, all_params=allp)
+    opt2.load_state_dict(sd)
+    assert torch.equal(opt2.flat_m, opt.flat_m) and torch.equal(opt2.flat_v, opt.flat_v) and opt2.steps == 1
+
+
 def test_pair_losses_equal_the_per_pass_losses(cuda):
     """The pair-mode loss entry points of the training step -- ComputeDetectorLoss(groups=2) over both passes' logits in one tensor,
     infonce(descriptors_pair=...) over both passes' descriptor maps in one tensor -- against the per-pass calls of the reference step

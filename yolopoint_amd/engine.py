@@ -104,7 +104,7 @@ class TrainStep:
         # multi-tensor one re-reads them in ~10 passes, 2.5-3 ms).  YP_ADAM=torch: torch.optim.Adam(fused=True) over the same parameters.
         if os.environ.get("YP_ADAM", "flat") == "flat" and torch.device(device).type == "cuda":
             from .optim import FlatAdam
-            self.opt = FlatAdam(self.reducer, params=[p for p in model.parameters() if p.requires_grad], lr=lr)
+            self.opt = FlatAdam(self.reducer, params=[p for p in model.parameters() if p.requires_grad], lr=lr, all_params=list(model.parameters()))
         else:
             self.opt = torch.optim.Adam(model.parameters(), lr=lr, fused=torch.device(device).type == "cuda" and os.environ.get("YP_ADAM_FUSED", "1") != "0")
         self.scheduler = torch.optim.lr_scheduler.LambdaLR(self.opt, lr_lambda=lr_lambda) if lr_lambda is not None else None

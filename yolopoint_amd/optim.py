@@ -14,11 +14,16 @@ from ._hip import lib, check
 
 
 class FlatAdam(torch.optim.Optimizer):
-    def __init__(self, reducer, params=None, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, reducer, params=None, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, all_params=None):
         """reducer: dp.GradAllReducer over the parameters to optimize (its arena is the gradient array; bind_grads() must be in effect
         when step() runs).  params: the same parameters in the order torch.optim.Adam would have been given them (model.parameters()):
-        it numbers the entries of state_dict(); default: the reducer's order."""
+        it numbers the entries of state_dict(); default: the reducer's order.
+        all_params: every parameter of the model in model.parameters() order, frozen ones included -- the reference hands all of them to
+        Adam (train.py:88), which numbers its state by that position and simply skips parameters without a gradient; with it a checkpoint
+        of a partly frozen model (freeze_layers) lines up with torch.optim.Adam's."""
         self.reducer = reducer
+        self._numbering = None if all_params is None else {id(p): i for i, p in enumerate(all_params)}
+        self._n_all = None if all_params is None else len(self._numbering)
         self.flat_p = reducer.flatten_parameters()
         order = list(params) if params is not None else list(reducer.params)
         if set(id(p) for p in order) != set(id(p) for p in reducer.params):
@@ -55,11 +60,14 @@ class FlatAdam(torch.optim.Optimizer):
                 o[id(p)] = (off + po, n)
         for i, p in enumerate(self.param_groups[0]["params"]):
             a, n = o[id(p)]
-            state[i] = {"step": torch.tensor(float(self.steps)), "exp_avg": self.flat_m[a:a + n].view_as(p).clone(),
-                        "exp_avg_sq": self.flat_v[a:a + n].view_as(p).clone()}
+            state[self._index(i, p)] = {"step": torch.tensor(float(self.steps)), "exp_avg": self.flat_m[a:a + n].view_as(p).clone(),
+                                        "exp_avg_sq": self.flat_v[a:a + n].view_as(p).clone()}
         groups = [{k: v for k, v in self.param_groups[0].items() if k != "params"}]
-        groups[0]["params"] = list(range(len(self.param_groups[0]["params"])))
+        groups[0]["params"] = list(range(self._n_all if self._n_all is not None else len(self.param_groups[0]["params"])))
         return {"state": state, "param_groups": groups}
+
+    def _index(self, i, p):
+        return i if self._numbering is None else self._numbering[id(p)]
 
     def load_state_dict(self, sd):
         o = {}
@@ -71,7 +79,7 @@ class FlatAdam(torch.optim.Optimizer):
                 self.param_groups[0][k] = v
         with torch.no_grad():
             for i, p in enumerate(self.param_groups[0]["params"]):
-                st = sd["state"].get(i)
+                st = sd["state"].get(self._index(i, p))
                 if st is None:
                     continue
                 a, n = o[id(p)]
