@@ -558,6 +558,8 @@ int yp_kp_decode(const float* semi, int B, int Hc, int Wc, int64_t sb, int64_t s
  *   out_xyc [B,max_out,3] fp32 (x, y, conf); out_count [B] int32
  * replaces: utils/utils.py:118-182 (nms_fast) + :465-485 (getPtsFromHeatmap) */
 size_t yp_kp_nms_workspace_bytes(int B, int H, int W);
+/* byte offset, inside that workspace, of the per-image count (int32 [B]) of pixels that passed conf_thresh in the last yp_kp_nms* call */
+size_t yp_kp_nms_candidate_count_offset(int B, int H, int W);
 int yp_kp_nms(const float* heat, int B, int H, int W, float conf_thresh, int radius, int border,
               float* out_xyc, int32_t* out_count, int max_out, void* workspace, size_t workspace_bytes,
               void* stream);

@@ -146,6 +146,7 @@ SIGNATURES = {
     "yp_plan_add_op": (_i, [_p, C.POINTER(YpOpArgs)]),
     "yp_kp_decode": (_i, [_p, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _p, _p]),
     "yp_kp_nms_workspace_bytes": (_sz, [_i, _i, _i]),
+    "yp_kp_nms_candidate_count_offset": (_sz, [_i, _i, _i]),
     "yp_kp_nms": (_i, [_p, _i, _i, _i, _f, _i, _i, _p, _p, _i, _p, _sz, _p]),
     "yp_kp_nms_async": (_i, [_p, _i, _i, _i, _f, _i, _i, _p, _p, _i, _p, _sz, _i, _p, _p]),
     "yp_box_nms_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),

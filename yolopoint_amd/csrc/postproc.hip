@@ -803,6 +803,13 @@ extern "C" size_t yp_kp_nms_workspace_bytes(int B, int H, int W) {
     return align_up(hw, 256) + 3 * align_up(hw * 4, 256) + 2 * align_up((size_t)B * 4, 256) + align_up((size_t)KP_MAX_ROUNDS * 4, 256);
 }
 
+// byte offset, inside that workspace, of the per-image count of pixels that passed the confidence threshold (int32 [B]) -- for callers that
+// read it back with their own synchronisation instead of re-deriving the layout
+extern "C" size_t yp_kp_nms_candidate_count_offset(int B, int H, int W) {
+    const size_t hw = (size_t)B * H * W;
+    return align_up(hw, 256) + 3 * align_up(hw * 4, 256);
+}
+
 // fixed_rounds == 0: rounds in batches of KP_ROUND_BATCH until the undecided counter read back by the host is 0 (one stream
 // synchronisation per batch).  fixed_rounds > 0: exactly that many rounds, no host synchronisation; the last round's undecided counter
 // goes to *undecided_out (device) for the caller to check at its own synchronisation point.

@@ -87,9 +87,8 @@ class YoloPointFrontend:
         else:
             kept = pts
             counts[2:3].copy_(counts[0:1])
-        # pixels that passed the threshold: the NMS kernels' candidate counter (workspace layout of yp_kp_nms_workspace_bytes)
-        al = lambda v: -(-v // 256) * 256
-        off = al(H * W) + 3 * al(H * W * 4)
+        # pixels that passed the threshold: the NMS kernels' candidate counter, where the library says it lives in their workspace
+        off = l.yp_kp_nms_candidate_count_offset(1, H, W)
         counts[4:5].copy_(ws[off:off + 4].view(torch.int32))
         n_nms, n_box, n_pts, undecided, n_cand = counts.cpu().tolist()            # the frame's only host sync
         if undecided:                                                              # the greedy NMS needed more rounds than enqueued: redo with the

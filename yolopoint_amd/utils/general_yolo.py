@@ -76,9 +76,7 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
             c = int(c)
             if 0 <= c < nc:
                 words[c >> 5] |= 1 << (c & 31)
-        mask = torch.tensor(words, dtype=torch.int64, device=pred.device).to(torch.int32) if words else None
-        if mask is not None:
-            mask = torch.tensor([w - (1 << 32) if w >= (1 << 31) else w for w in words], dtype=torch.int32, device=pred.device)
+        mask = torch.tensor([w - (1 << 32) if w >= (1 << 31) else w for w in words], dtype=torch.int32, device=pred.device) if words else None
     max_wh, max_nms = 7680.0, 30000     # reference constants (general_yolo.py:154-155)
     l = _hip.lib()
     out = torch.empty((B, max_det, 6), dtype=torch.float32, device=pred.device)
