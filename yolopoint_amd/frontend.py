@@ -39,7 +39,8 @@ class YoloPointFrontend:
         cut_w0, cut_w1 = int(np.ceil(cut_w)), int(np.floor(cut_w))
         return img[cut_h0:h0 - cut_h1, cut_w0:w0 - cut_w1], cut_h0, cut_w0, 1.0
 
-    NMS_ROUNDS = 12       # fix-point rounds enqueued per frame by the non-synchronising keypoint NMS (planted 1280x1280 maps need ~6)
+    NMS_ROUNDS = 8        # fix-point rounds enqueued per frame by the non-synchronising keypoint NMS (planted 1280x1280 maps need ~6; a frame that
+                          # needs more is redone with the converging variant below -- 21 us per round at 1280x1280)
 
     @_hip.guarded
     @torch.no_grad()
