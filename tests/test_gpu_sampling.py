@@ -163,3 +163,30 @@ def test_prepare_is_reproducible_and_feeds_the_loss(cuda):
     logits = torch.cat(((da * db).sum(-1, keepdim=True), (da @ db.t()).gather(1, rnd.long())), 1) / 0.07
     ref = -torch.log_softmax(logits, 1)[:, 0].mean()
     assert abs(float(got) - float(ref)) <= 1e-5 * abs(float(ref))
+
+
+@pytest.mark.parametrize("B,Hc,Wc,samples,negs", [(1, 8, 20, 50, 7), (5, 160, 160, 3000, 40), (2, 24, 16, 300, 200)])
+def test_prepare_shapes_and_scarce_cells(cuda, B, Hc, Wc, samples, negs):
+    """One image, rectangular maps, a 1280 x 1280 image (25 600 cells per image in the selection kernel's LDS) and masks that leave fewer valid
+    cells than `samples`: pool = min(samples, fewest valid cells); every index structure is consistent with it."""
+    mask = torch.ones(B, 1, Hc * 8, Wc * 8, device=cuda)
+    mask[-1, :, : (Hc * 8) // 2 + 8] = 0.0                      # the last image keeps less than half of its cells
+    Hinv = torch.eye(3, device=cuda).repeat(B, 1, 1)
+    torch.manual_seed(B + Hc)
+    ua, ub, rnd, (idx, order, offsets), (uab, s_order, s_offsets) = LF.infonce_prepare(mask, Hinv, (B, 64, Hc, Wc), True, samples, negs, 8, cuda, pair_index=True)
+    valid_last = (Hc - (Hc // 2 + 1)) * Wc
+    pool = min(samples, valid_last)
+    n = B * pool
+    assert tuple(ua.shape) == (B, pool, 2) and tuple(ub.shape) == (B, pool, 2) and tuple(uab.shape) == (2 * B, pool, 2)
+    assert tuple(idx.shape) == (n, negs + 1) and tuple(rnd.shape) == (n, negs) and offsets.numel() == n + 1 and int(offsets[-1]) == n * (negs + 1)
+    assert torch.equal(ua, ub)                                  # identity homography: every cell matches itself
+    cy = torch.round((ua[..., 1] + 1) / 2 * Hc).long()
+    assert int(cy[-1].min()) >= Hc // 2 + 1                     # only valid cells of the masked image
+    # the transposed edge list really is the transpose
+    flat = idx.flatten().long()
+    assert torch.equal(flat[order.long()], torch.repeat_interleave(torch.arange(n, device=cuda), (offsets[1:] - offsets[:-1]).long()))
+    # the tap list: 2 * n points, up to four bilinear taps each (normPts divides by the map size, grid_sample's align_corners maps [-1, 1] to
+    # [0, size - 1]: cell x is sampled at x * (W - 1) / W, as in the reference), grouped by cell
+    assert 2 * n <= int(s_offsets[-1]) <= 8 * n and s_offsets.numel() == 2 * B * Hc * Wc + 1
+    taps = s_order[:int(s_offsets[-1])].long()
+    assert int(taps.min()) >= 0 and int(taps.max()) < 8 * n and taps.unique().numel() == taps.numel()
