@@ -139,7 +139,7 @@ def cpu_baseline(version, B, S, budget_s=14.0, gpu_outs=None):
                                     "pred": round(parity["pred_rel_l2"] / fl["pred"], 3),
                                     "raw_levels": [round(a / b, 3) for a, b in zip(parity["raw_levels_rel_l2"], fl["raw_levels"])]}
         parity["floor_argmax_agreement"] = round(float((flo["semi"].argmax(1) == ref["semi"].argmax(1)).float().mean()), 6)
-        parity["bars"] = ("tests/test_gpu_bench_shapes.py: every head tensor's relative L2 <= 1.15 x floor_rel_l2 (max-abs <= 1.5 x), argmax mismatches only on "
+        parity["bars"] = ("tests/test_gpu_bench_shapes.py: every head tensor's relative L2 <= 1.15 x floor_rel_l2 (max-abs <= 3.0 x), argmax mismatches only on "
                           "reference near-ties within one 16-bit step; the f32 path meets the north-star 1e-3 of max|ref| with bit-exact argmax")
     return base, parity
 
