@@ -954,16 +954,21 @@ __global__ __launch_bounds__(256) void pack_weight_batch_kernel(const YpPackEntr
     const YpPackEntry en = table[e];
     const int Cout = (int)en.Cout, Cin = (int)en.Cin, R = (int)en.R, S = (int)en.S, c0 = (int)en.c0, Cj = (int)en.Cj, mode = (int)en.mode;
     const int Cout_pad = (int)en.Cout_pad, Kpad = (int)en.Kpad, Npad = (int)en.Npad;
-    const size_t total = (size_t)(Npad + 1) * Kpad;
-    const size_t base = (size_t)(bid - (int)en.blk0) * 1024;
+    // four consecutive k of one packed row per thread (Kpad is a multiple of 4: they share their row), 32-bit index arithmetic (a packed
+    // image has < 2^31 elements), one 8-byte store
+    const unsigned total = (unsigned)(Npad + 1) * (unsigned)Kpad;
+    const unsigned i = (unsigned)(bid - (int)en.blk0) * 1024u + 4u * threadIdx.x;
+    if (i >= total) return;
+    const int n = (int)(i / (unsigned)Kpad), k0 = (int)(i - (unsigned)n * (unsigned)Kpad);
+    sc o[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const size_t i = base + u * 256 + threadIdx.x;
-        if (i >= total) break;
-        const int n = (int)(i / Kpad), k = (int)(i - (size_t)n * Kpad);
-        const float v = yp_pack_elem(en.w, Cout, Cin, R, S, c0, Cj, mode, Cout_pad, n, k);
-        reinterpret_cast<sc*>(en.dst)[i] = (sc)v;
-        if (en.bias_dst != nullptr && i < (size_t)Npad) en.bias_dst[i] = (en.bias != nullptr && (int)i < Cout) ? en.bias[i] : 0.f;
+    for (int u = 0; u < 4; ++u) o[u] = (sc)yp_pack_elem(en.w, Cout, Cin, R, S, c0, Cj, mode, Cout_pad, n, k0 + u);
+    if constexpr (sizeof(sc) == 2) *reinterpret_cast<uint2*>(reinterpret_cast<sc*>(en.dst) + i) = *reinterpret_cast<const uint2*>(o);
+    else *reinterpret_cast<uint4*>(reinterpret_cast<sc*>(en.dst) + i) = *reinterpret_cast<const uint4*>(o);
+    if (en.bias_dst != nullptr && i < (unsigned)Npad) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + u < (unsigned)Npad) en.bias_dst[i + u] = (en.bias != nullptr && (int)(i + u) < Cout) ? en.bias[i + u] : 0.f;
     }
 }
 
