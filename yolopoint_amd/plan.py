@@ -195,6 +195,7 @@ _TUNE_CACHE = {}
 _TUNE_CANDIDATES = (1, 2, 3, 4, 5, 21, 22, 23, 24, 25, 26, 27, 10, 11, 12, 13, 14, 15, 41, 42, 43, 44, 57, 58)
 # pixels per BatchNorm-statistics row of the variants whose rows are plain pixel blocks (the 3x3 halo kernels write one row per image tile)
 _STAT_ROW_PX = {41: 128, 57: 128, 58: 128}
+_TUNE_ITERS = int(os.environ.get("YP_TUNE_ITERS", "8"))      # timed launches per candidate
 if os.environ.get("YP_TUNE_ONLY"):           # A/B experiments: restrict the autotuner to a subset of the variants
     _TUNE_CANDIDATES = tuple(int(v) for v in os.environ["YP_TUNE_ONLY"].split(","))
 
@@ -600,12 +601,13 @@ class PlanBuilder:
                 continue
             run()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            iters = _TUNE_ITERS
             e0.record()
-            for _ in range(8):
+            for _ in range(iters):
                 run()
             e1.record()
             e1.synchronize()
-            ms = e0.elapsed_time(e1)
+            ms = e0.elapsed_time(e1) * 8.0 / iters          # (kept in units of 8 launches: the cache stores ms / 8)
             if os.environ.get("YP_TUNE_DEBUG"):
                 print(f"[tune] {self.name():40s} cand {cand:2d}: {ms / 8 * 1e3:7.1f} us", flush=True)
             if best_ms is None or ms < best_ms:
