@@ -391,9 +391,9 @@ int yp_infonce_fwd(const float* da, const float* db, const int* idx, int n, int 
  * log-sum-exp; `logits` receives the softmax weights w[i][j] = exp(l_ij - lse_i) - [j == 0], not the logits.  yp_infonce_bwd_db then gives
  * ddb (already scaled by *grad_scale_dev) from those weights. */
 int yp_infonce_fwd_grad(const float* da, const float* db, const int* idx, int n, int E, int D, float inv_tau, float* logits, float* loss_rows, float* lse,
-                        float* dda_unscaled, void* stream);
+                       float* dda_unscaled, const int* n_dev, void* stream);
 int yp_infonce_bwd_db(const float* da, const int* order, const int* offsets, const float* logits, const float* lse, int n, int E, int D,
-                      const float* grad_scale_dev, float* ddb, void* stream);
+                      const float* grad_scale_dev, float* ddb, const int* n_dev, void* stream);
 int yp_infonce_bwd(const float* da, const float* db, const int* idx, const int* order, const int* offsets, const float* logits, int n, int E, int D,
                    const float* grad_scale_dev, float* w_scratch, float* dda, float* ddb, void* stream);
 
@@ -401,18 +401,23 @@ int yp_infonce_bwd(const float* da, const float* db, const int* idx, const int* 
  * points per image (reference utils/loss_functions.py:553-560).  map / gmap: [B,H,W,D] fp32, channels innermost (the layout the
  * network emits; D % 64 == 0, D <= 256); uv [B*P,2] normalised (x, y); out / g [B*P, D].  gmap must be ZEROED by the caller; the
  * backward accumulates with atomics. */
-int yp_points_sample_fwd(const float* map_nhwc, int B, int H, int W, int D, const float* uv, int P, float* out, void* stream);
+int yp_points_sample_fwd(const float* map_nhwc, int B, int H, int W, int D, const float* uv, int P, float* out, const int* p_dev, void* stream);
 int yp_points_sample_bwd(const float* g, int B, int H, int W, int D, const float* uv, int P, float* gmap_nhwc, void* stream);
 /* The backward of the lookup without atomics and without a zeroed map: yp_points_sample_taps writes, per (point, tap), the cell it touches
  * (b*H*W + y*W + x, INT_MAX for taps outside the map / of weight 0) into keys [B*P*4]; the caller sorts (key, 4*point + tap) pairs by key
  * (stable) and builds CSR offsets [B*H*W + 1] over the cells -- label-only work, once per batch of sample points; yp_points_sample_bwd_sorted
  * then writes EVERY row of gmap [B][H][W][D]: the sum of its contributions in sorted order (bit-reproducible), zeros where nothing lands.
+ * Device-side counts (the trailing *_dev pointers of these entry points, all may be NULL): the InfoNCE sampling leaves its counts on the
+ * device (yp_nce_select's meta: [0] = points per image P, [1] = matched rows n); with them the host passes CAPACITIES (P = samples per image,
+ * n = B * samples) for the launch sizes and the kernels read the real counts -- arrays stay compact ([B][P] points, [2n][D] descriptors with the
+ * second half at row n), entries behind the counts are skipped.  yp_infonce_fwd_grad with n_dev: db may be NULL, = da + n * D;
+ * yp_infonce_bwd_db with n_dev: pass the BASE of the [2n][D] gradient as ddb.  No host synchronisation in the loss stage.
  * row_scale_dev (may be NULL): rows [0, n_scaled_rows) of g are multiplied by this device scalar before they are used (the anchor half of
  * yp_infonce_fwd_grad's gradient, which still lacks dL/dloss / (tau * n)) -- no separate scaling pass.
  * replaces: the scatter of grid_sampler_2d_backward in loss.backward() (utils/loss_functions.py:553-560, train.py:245). */
-int yp_points_sample_taps(const float* uv, int B, int P, int H, int W, int* keys, void* stream);
+int yp_points_sample_taps(const float* uv, int B, int P, int H, int W, int* keys, const int* p_dev, void* stream);
 int yp_points_sample_bwd_sorted(const float* g, int B, int H, int W, int D, const float* uv, int P, const int* order, const int* offsets,
-                                const float* row_scale_dev, int n_scaled_rows, float* gmap_nhwc, void* stream);
+                                const float* row_scale_dev, int n_scaled_rows, float* gmap_nhwc, const int* n_scaled_dev, void* stream);
 
 /* YOLOv5 object loss of ONE Detect level, value and gradient (reference utils/loss_functions.py:90-176 ComputeLoss.__call__ body
  * of the per-level loop; CIoU: utils/metrics_yolo.py:202-240).  p / dp: [cells, no] fp32 with cells = B*na*ny*nx and no = 5 + nc;
@@ -467,14 +472,15 @@ int yp_detloss2d(const float* semi, const int64_t* semi_strides, const float* la
  *                     uab [2B][pool][2] normalised (x, y) (rows [0,B): the cells, rows [B,2B): their matches; capacity 2*B*samples*2 floats);
  *                     meta[0] = pool, meta[1] = n = B*pool, meta[2] = 0
  *   yp_nce_negatives  idx [n][1+negs] int32: column 0 the row itself, then uniform draws from [0, n); a draw equal to its row is replaced by
- *                     floor(U * #such draws) (the reference's redraw from [0, #collisions)); meta[2] receives that count
+ *                     floor(U * #such draws) (the reference's redraw from [0, #collisions)); meta[2] receives that count.  n_from_meta: `n` is
+ *                     the CAPACITY of idx, the row count is meta[1] (no host read-back); rows [meta[1], n) get keys the sort skips
  *   yp_csr_build      keys [n_items] (values outside [0, n_buckets) are skipped) -> order: the item ids grouped by key, ascending inside a
  *                     group; offsets [n_buckets + 1]; workspace: yp_csr_workspace_ints(n_items, n_buckets) ints.  wide_buckets: groups of hundreds (one wavefront
  *                     each) instead of a few (one thread each).  The InfoNCE backward walks (idx.flatten() -> n buckets) and the descriptor
  *                     lookup backward (yp_points_sample_taps keys -> B*H*W buckets) with it. */
 int yp_nce_cells(const float* mask, const float* inv_h, int B, int H, int W, unsigned char* valid, float* uvb, void* stream);
 int yp_nce_select(const unsigned char* valid, const float* uvb, int B, int Hc, int Wc, int samples, uint64_t seed, float* uab, int* meta, void* stream);
-int yp_nce_negatives(int n, int negs, uint64_t seed, int* meta, int* idx, void* stream);
+int yp_nce_negatives(int n, int negs, uint64_t seed, int* meta, int* idx, int n_from_meta, void* stream);
 size_t yp_csr_workspace_ints(int n_items, int n_buckets);
 int yp_csr_build(const int* keys, int n_items, int n_buckets, int wide_buckets, int* order, int* offsets, int* workspace, void* stream);
 
@@ -485,7 +491,8 @@ int yp_csr_build(const int* keys, int n_items, int n_buckets, int wide_buckets, 
  *   yp_counters_add  BatchNorm's num_batches_tracked (+= inc for every int64 counter of a device pointer table)
  *   yp_loss_combine  train.py:232-241: out4[0] = (sum(det_losses[0..n_det)) + lambda_desc * mean(nce_rows[0..n_rows))) + lambda_obj *
  *                    sum(obj_sums[0..3)), times `scale` when it is not 1; out4[1..3] = the detector / descriptor / object terms;
- *                    *desc_scale_out = desc_scale (the device scalar yp_infonce_bwd_db reads; NULL: not written) */
+ *                    *desc_scale_out = desc_scale (the device scalar yp_infonce_bwd_db reads; NULL: not written).  n_rows_dev (may be NULL):
+ *                    the row count lives on the device (yp_nce_select's meta[1]); desc_scale is then g_desc / (tau * n) computed there */
 typedef struct YpAddEntry {
     float* dst;
     const float* src;
@@ -495,7 +502,7 @@ int yp_fill_zero(void* p, size_t bytes, void* stream);
 int yp_multi_add(const YpAddEntry* table_dev, int n_entries, int total_blocks, void* stream);
 int yp_counters_add(int64_t* const* table_dev, int n, int64_t inc, void* stream);
 int yp_loss_combine(const float* det_losses, int n_det, const float* nce_rows, int n_rows, const float* obj_sums, float lambda_desc, float lambda_obj, float scale,
-                    float desc_scale, float* out4, float* desc_scale_out, void* stream);
+                    float desc_scale, float* out4, float* desc_scale_out, const int* n_rows_dev, float g_desc, double tau, void* stream);
 
 /* One generic launch record: `op` selects one of the functions above, the slots carry its arguments in the
  * order documented next to each opcode.  Lets training plans replay any mix of launches (yp_plan_add_op). */

@@ -103,10 +103,10 @@ def test_negatives_follow_the_reference_rule(cuda):
     n, negs = 5000, 60
     meta = torch.zeros(4, dtype=torch.int32, device=cuda)
     idx = torch.full((n, negs + 1), -1, dtype=torch.int32, device=cuda)
-    _hip.check(_hip.lib().yp_nce_negatives(n, negs, 77, meta.data_ptr(), idx.data_ptr(), _hip.stream_ptr()))
+    _hip.check(_hip.lib().yp_nce_negatives(n, negs, 77, meta.data_ptr(), idx.data_ptr(), 0, _hip.stream_ptr()))
     idx2 = torch.empty_like(idx)
     meta2 = torch.zeros(4, dtype=torch.int32, device=cuda)
-    _hip.check(_hip.lib().yp_nce_negatives(n, negs, 77, meta2.data_ptr(), idx2.data_ptr(), _hip.stream_ptr()))
+    _hip.check(_hip.lib().yp_nce_negatives(n, negs, 77, meta2.data_ptr(), idx2.data_ptr(), 0, _hip.stream_ptr()))
     assert torch.equal(idx, idx2) and int(meta[2]) == int(meta2[2])
     assert torch.equal(idx[:, 0].long(), torch.arange(n, device=cuda))
     r = idx[:, 1:].long()
@@ -120,7 +120,7 @@ def test_negatives_follow_the_reference_rule(cuda):
     assert abs(float(r.float().mean()) - (n - 1) / 2) < 0.01 * n
     hist = torch.bincount(r.flatten() * 10 // n, minlength=10).float()
     assert float((hist / hist.sum() - 0.1).abs().max()) < 0.005
-    _hip.check(_hip.lib().yp_nce_negatives(n, negs, 78, meta2.zero_().data_ptr(), idx2.data_ptr(), _hip.stream_ptr()))
+    _hip.check(_hip.lib().yp_nce_negatives(n, negs, 78, meta2.zero_().data_ptr(), idx2.data_ptr(), 0, _hip.stream_ptr()))
     assert not torch.equal(idx, idx2)
 
 
@@ -190,3 +190,27 @@ def test_prepare_shapes_and_scarce_cells(cuda, B, Hc, Wc, samples, negs):
     assert 2 * n <= int(s_offsets[-1]) <= 8 * n and s_offsets.numel() == 2 * B * Hc * Wc + 1
     taps = s_order[:int(s_offsets[-1])].long()
     assert int(taps.min()) >= 0 and int(taps.max()) < 8 * n and taps.unique().numel() == taps.numel()
+
+
+@pytest.mark.parametrize("scarce", [False, True])
+def test_prepare_without_host_synchronisation_equals_the_synchronising_form(cuda, scarce):
+    """infonce_prepare(sync=False): counts stay on the device (meta[0] = points per image, meta[1] = matched rows), arrays keep their capacity;
+    their valid prefixes equal what the synchronising form returns for the same seed, rows behind the counts carry keys the sort skips."""
+    B, Hc, Wc, D, samples, negs = 3, 16, 20, 64, 120, 25
+    mask = torch.ones(B, 1, Hc * 8, Wc * 8, device=cuda)
+    if scarce:
+        mask[1, :, 40:] = 0.0                                   # image 1 keeps 5 cell rows: 100 valid cells < samples
+    Hinv = torch.eye(3, device=cuda).repeat(B, 1, 1)
+    Hinv[:, 1, 2] = -0.05
+    torch.manual_seed(8)
+    ua, ub, rnd, (idx, order, offsets), (uab, s_order, s_offsets) = LF.infonce_prepare(mask, Hinv, (B, D, Hc, Wc), True, samples, negs, 8, cuda, pair_index=True)
+    torch.manual_seed(8)
+    d = LF.infonce_prepare(mask, Hinv, (B, D, Hc, Wc), True, samples, negs, 8, cuda, pair_index=True, sync=False)
+    pool, n = int(d["meta"][0]), int(d["meta"][1])
+    assert pool == ua.shape[1] and n == B * pool and (pool < samples) == scarce
+    E = negs + 1
+    assert torch.equal(d["uab"][:4 * n].view(2 * B, pool, 2), uab)
+    assert torch.equal(d["idx"][:n], idx) and bool((d["idx"][n:] == 2 ** 31 - 1).all())
+    assert torch.equal(d["offsets"][:n + 1], offsets) and bool((d["offsets"][n:] == n * E).all())
+    assert torch.equal(d["order"][:n * E], order)
+    assert torch.equal(d["s_offsets"], s_offsets) and torch.equal(d["s_order"][:int(s_offsets[-1])], s_order[:int(s_offsets[-1])])

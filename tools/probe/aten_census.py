@@ -53,6 +53,8 @@ def main():
     torch.cuda.synchronize()
     launching = {k: v for k, v in c.ops.items() if k not in VIEWS}
     print(f"# one training step: {sum(c.ops.values())} ATen dispatches, {sum(launching.values())} of them not view-only")
+    syncs = {k: c.ops[k] for k in ("_local_scalar_dense", "item", "is_nonzero") if c.ops.get(k)}
+    print(f"# host read-backs of device values (synchronisations): {syncs if syncs else 'none'}")
     by_site = collections.Counter()
     for name, n in sorted(launching.items(), key=lambda kv: -kv[1]):
         sites = ", ".join(f"{s} x{k}" for s, k in c.where[name].most_common(6))

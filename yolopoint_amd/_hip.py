@@ -112,13 +112,13 @@ SIGNATURES = {
     "yp_pack_weight_batch": (_i, [_p, _i, _i, _i, _p]),
     "yp_wgrad_unpack_batch": (_i, [_p, _i, _i, _p]),
     "yp_infonce_fwd": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _p, _p]),
-    "yp_infonce_fwd_grad": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p]),
-    "yp_infonce_bwd_db": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p]),
+    "yp_infonce_fwd_grad": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p]),
+    "yp_infonce_bwd_db": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
     "yp_infonce_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p]),
     "yp_homo_combine": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p]),
-    "yp_points_sample_taps": (_i, [_p, _i, _i, _i, _i, _p, _p]),
-    "yp_points_sample_bwd_sorted": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _i, _p, _p]),
-    "yp_points_sample_fwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p]),
+    "yp_points_sample_taps": (_i, [_p, _i, _i, _i, _i, _p, _p, _p]),
+    "yp_points_sample_bwd_sorted": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _i, _p, _p, _p]),
+    "yp_points_sample_fwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p, _p]),
     "yp_points_sample_bwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p]),
     "yp_detloss_workspace_bytes": (_sz, [_i, _i, _i]),
     "yp_detloss": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _sz, _p]),
@@ -127,13 +127,13 @@ SIGNATURES = {
     "yp_detloss2d": (_i, [_p, _p, _p, _p, _p, _f, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
     "yp_nce_cells": (_i, [_p, _p, _i, _i, _i, _p, _p, _p]),
     "yp_nce_select": (_i, [_p, _p, _i, _i, _i, _i, C.c_uint64, _p, _p, _p]),
-    "yp_nce_negatives": (_i, [_i, _i, C.c_uint64, _p, _p, _p]),
+    "yp_nce_negatives": (_i, [_i, _i, C.c_uint64, _p, _p, _i, _p]),
     "yp_csr_build": (_i, [_p, _i, _i, _i, _p, _p, _p, _p]),
     "yp_csr_workspace_ints": (_sz, [_i, _i]),
     "yp_fill_zero": (_i, [_p, _sz, _p]),
     "yp_multi_add": (_i, [_p, _i, _i, _p]),
     "yp_counters_add": (_i, [_p, _i, _i64, _p]),
-    "yp_loss_combine": (_i, [_p, _i, _p, _i, _p, _f, _f, _f, _f, _p, _p, _p]),
+    "yp_loss_combine": (_i, [_p, _i, _p, _i, _p, _f, _f, _f, _f, _p, _p, _p, _f, C.c_double, _p]),
     "yp_objloss_level": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _i, _f, _f, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p]),
     "yp_objloss_level_dev": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _f, _f, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p]),
     "yp_build_targets": (_i, [_p, _i, _p, _i, _i, _p, _f, _i, _p, _p, _p, _p, _p, _p]),

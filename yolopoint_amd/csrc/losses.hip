@@ -91,9 +91,10 @@ __global__ __launch_bounds__(256) void infonce_fwd_kernel(const float* __restric
 template <int VPL>
 __global__ __launch_bounds__(256) void infonce_fwd_grad_kernel(const float* __restrict__ da, const float* __restrict__ db, const int* __restrict__ idx, int n, int E,
                                                                int D, float inv_tau, float* __restrict__ logits, float* __restrict__ loss,
-                                                               float* __restrict__ lse, float* __restrict__ dda_u) {
+                                                               float* __restrict__ lse, float* __restrict__ dda_u, const int* __restrict__ n_dev) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n_dev != nullptr) { n = n_dev[0]; db = da + (size_t)n * D; }     // (device-side count: the matched rows are [0, n) of a capacity-sized array)
     if (i >= n) return;
     const Row<VPL> a = load_row<VPL>(da, i, D, lane);
     const int* row = idx + (size_t)i * E;
@@ -166,9 +167,10 @@ __global__ __launch_bounds__(256) void infonce_fwd_grad_kernel(const float* __re
 template <int VPL>
 __global__ __launch_bounds__(256) void infonce_bwd_b2_kernel(const float* __restrict__ da, const float* __restrict__ logits, const float* __restrict__ lse,
                                                              const int* __restrict__ order, const int* __restrict__ offsets, int n, int E, int D,
-                                                             const float* __restrict__ gscale, float* __restrict__ ddb) {
+                                                             const float* __restrict__ gscale, float* __restrict__ ddb, const int* __restrict__ n_dev) {
     const int lane = threadIdx.x & 63;
     const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n_dev != nullptr) { n = n_dev[0]; ddb += (size_t)n * D; }         // (ddb = the second half of a [2n][D] gradient whose base was passed)
     if (k >= n) return;
     const int e0 = offsets[k], e1 = offsets[k + 1];
     const float scale = gscale[0];
@@ -296,9 +298,10 @@ __device__ __forceinline__ Taps bilinear_taps(float u, float v, int H, int W) {
 
 template <int VPL>
 __global__ __launch_bounds__(256) void points_sample_fwd_kernel(const float* __restrict__ map, int H, int W, int D, const float* __restrict__ uv, int P, int n,
-                                                                float* __restrict__ out) {
+                                                                float* __restrict__ out, const int* __restrict__ p_dev, int B) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p_dev != nullptr) { P = p_dev[0]; n = B * P; }                      // (device-side points per image: the arrays are compact, [B][P])
     if (i >= n) return;
     const Taps t = bilinear_taps(uv[2 * i], uv[2 * i + 1], H, W);
     const float* base = map + (size_t)(i / P) * H * W * D;
@@ -340,9 +343,14 @@ __global__ __launch_bounds__(256) void points_sample_bwd_kernel(const float* __r
 // contributions in that order -- every cell of the map is written exactly once (zeros where nothing lands), the sums have a fixed order
 // (bit-reproducible also when taps of different points overlap), and 98 M same-address-class atomics (1.25 ms at YOLOPoint-l: the chip
 // retires ~250 G of them per second) become one streaming pass.
-__global__ __launch_bounds__(256) void points_taps_kernel(const float* __restrict__ uv, int P, int n, int H, int W, int* __restrict__ keys) {
+__global__ __launch_bounds__(256) void points_taps_kernel(const float* __restrict__ uv, int P, int n, int H, int W, int* __restrict__ keys,
+                                                          const int* __restrict__ p_dev, int B) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    if (p_dev != nullptr) {                                                // (device-side points per image: entries behind B * P are skipped by the sort)
+        P = p_dev[0];
+        if (i >= B * P) { keys[4 * i] = keys[4 * i + 1] = keys[4 * i + 2] = keys[4 * i + 3] = 0x7fffffff; return; }
+    }
     const Taps t = bilinear_taps(uv[2 * i], uv[2 * i + 1], H, W);
     const int base = (i / P) * H * W;
 #pragma unroll
@@ -352,8 +360,10 @@ __global__ __launch_bounds__(256) void points_taps_kernel(const float* __restric
 template <int VPL>
 __global__ __launch_bounds__(256) void points_sample_bwd_sorted_kernel(const float* __restrict__ g, int H, int W, int D, const float* __restrict__ uv, int ncells,
                                                                        const int* __restrict__ order, const int* __restrict__ offsets,
-                                                                       const float* __restrict__ row_scale, int n_scaled, float* __restrict__ gmap) {
+                                                                       const float* __restrict__ row_scale, int n_scaled, float* __restrict__ gmap,
+                                                                       const int* __restrict__ n_scaled_dev) {
     const int lane = threadIdx.x & 63;
+    if (n_scaled_dev != nullptr) n_scaled = n_scaled_dev[0];
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= ncells) return;
     float acc[VPL];
@@ -775,20 +785,20 @@ extern "C" int yp_infonce_fwd(const float* da, const float* db, const int* idx, 
 }
 
 extern "C" int yp_infonce_fwd_grad(const float* da, const float* db, const int* idx, int n, int E, int D, float inv_tau, float* logits, float* loss_rows,
-                                   float* lse, float* dda_unscaled, void* stream) {
-    YP_REQUIRE(da && db && idx && logits && loss_rows && lse && dda_unscaled && n > 0 && E > 0 && E <= 512 && D > 0 && D % 64 == 0,
+                                   float* lse, float* dda_unscaled, const int* n_dev, void* stream) {
+    YP_REQUIRE(da && (db || n_dev) && idx && logits && loss_rows && lse && dda_unscaled && n > 0 && E > 0 && E <= 512 && D > 0 && D % 64 == 0,
                "yp_infonce_fwd_grad: bad arguments (E <= 512, D %% 64 == 0)");
     const int grid = (n + 3) / 4;
-    YP_VPL_SWITCH(D, (infonce_fwd_grad_kernel<VPL><<<grid, 256, 0, (hipStream_t)stream>>>(da, db, idx, n, E, D, inv_tau, logits, loss_rows, lse, dda_unscaled)));
+    YP_VPL_SWITCH(D, (infonce_fwd_grad_kernel<VPL><<<grid, 256, 0, (hipStream_t)stream>>>(da, db, idx, n, E, D, inv_tau, logits, loss_rows, lse, dda_unscaled, n_dev)));
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
 }
 
 extern "C" int yp_infonce_bwd_db(const float* da, const int* order, const int* offsets, const float* logits, const float* lse, int n, int E, int D,
-                                 const float* grad_scale_dev, float* ddb, void* stream) {
+                                 const float* grad_scale_dev, float* ddb, const int* n_dev, void* stream) {
     YP_REQUIRE(da && order && offsets && logits && lse && grad_scale_dev && ddb && n > 0 && E > 0 && D > 0 && D % 64 == 0, "yp_infonce_bwd_db: bad arguments");
     const int grid = (n + 3) / 4;
-    YP_VPL_SWITCH(D, (infonce_bwd_b2_kernel<VPL><<<grid, 256, 0, (hipStream_t)stream>>>(da, logits, lse, order, offsets, n, E, D, grad_scale_dev, ddb)));
+    YP_VPL_SWITCH(D, (infonce_bwd_b2_kernel<VPL><<<grid, 256, 0, (hipStream_t)stream>>>(da, logits, lse, order, offsets, n, E, D, grad_scale_dev, ddb, n_dev)));
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
 }
@@ -831,10 +841,10 @@ extern "C" int yp_objloss_level_dev(const float* p, int cells, int no, int nc, c
     return YP_OK;
 }
 
-extern "C" int yp_points_sample_fwd(const float* map_nhwc, int B, int H, int W, int D, const float* uv, int P, float* out, void* stream) {
+extern "C" int yp_points_sample_fwd(const float* map_nhwc, int B, int H, int W, int D, const float* uv, int P, float* out, const int* p_dev, void* stream) {
     YP_REQUIRE(map_nhwc && uv && out && B > 0 && H > 0 && W > 0 && P > 0 && D > 0 && D % 64 == 0, "yp_points_sample_fwd: bad arguments (D %% 64 == 0)");
     const int n = B * P, grid = (n + 3) / 4;
-    YP_VPL_SWITCH(D, (points_sample_fwd_kernel<VPL><<<grid, 256, 0, (hipStream_t)stream>>>(map_nhwc, H, W, D, uv, P, n, out)));
+    YP_VPL_SWITCH(D, (points_sample_fwd_kernel<VPL><<<grid, 256, 0, (hipStream_t)stream>>>(map_nhwc, H, W, D, uv, P, n, out, p_dev, B)));
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
 }
@@ -847,20 +857,21 @@ extern "C" int yp_points_sample_bwd(const float* g, int B, int H, int W, int D, 
     return YP_OK;
 }
 
-extern "C" int yp_points_sample_taps(const float* uv, int B, int P, int H, int W, int* keys, void* stream) {
+extern "C" int yp_points_sample_taps(const float* uv, int B, int P, int H, int W, int* keys, const int* p_dev, void* stream) {
     YP_REQUIRE(uv && keys && B > 0 && P > 0 && H > 0 && W > 0 && (long)B * H * W < 0x7fffffffL, "yp_points_sample_taps: bad arguments");
     const int n = B * P;
-    points_taps_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(uv, P, n, H, W, keys);
+    points_taps_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(uv, P, n, H, W, keys, p_dev, B);
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
 }
 
 extern "C" int yp_points_sample_bwd_sorted(const float* g, int B, int H, int W, int D, const float* uv, int P, const int* order, const int* offsets,
-                                           const float* row_scale_dev, int n_scaled_rows, float* gmap_nhwc, void* stream) {
+                                           const float* row_scale_dev, int n_scaled_rows, float* gmap_nhwc, const int* n_scaled_dev, void* stream) {
     YP_REQUIRE(g && uv && order && offsets && gmap_nhwc && B > 0 && H > 0 && W > 0 && P > 0 && D > 0 && D % 64 == 0, "yp_points_sample_bwd_sorted: bad arguments (D %% 64 == 0)");
     const int ncells = B * H * W, grid = (ncells + 3) / 4;
     YP_VPL_SWITCH(D, (points_sample_bwd_sorted_kernel<VPL><<<grid, 256, 0, (hipStream_t)stream>>>(g, H, W, D, uv, ncells, order, offsets, row_scale_dev,
-                                                                                                        row_scale_dev != nullptr ? n_scaled_rows : 0, gmap_nhwc)));
+                                                                                                        row_scale_dev != nullptr ? n_scaled_rows : 0, gmap_nhwc,
+                                                                                                        row_scale_dev != nullptr ? n_scaled_dev : nullptr)));
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
 }

@@ -147,9 +147,10 @@ __global__ __launch_bounds__(1024) void nce_select_kernel(const unsigned char* _
 __device__ __forceinline__ int draw_row(unsigned r, int n) { return (int)(((unsigned long long)r * (unsigned)n) >> 32); }
 
 // draws equal to their own row, counted (integer atomics: one per workgroup)
-__global__ __launch_bounds__(256) void nce_negatives_count_kernel(int n, int negs, unsigned long long seed, int* __restrict__ meta) {
+__global__ __launch_bounds__(256) void nce_negatives_count_kernel(int n, int negs, unsigned long long seed, int* __restrict__ meta, int n_from_meta) {
     __shared__ int sh[4];
     const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;      // four draws per thread: one Philox call
+    if (n_from_meta) n = meta[1];                                  // (n = B * pool as nce_select_kernel left it; the launch covers the capacity)
     const size_t total = (size_t)n * negs;
     int c = 0;
     if (q * 4 < total) {
@@ -169,14 +170,29 @@ __global__ __launch_bounds__(256) void nce_negatives_count_kernel(int n, int neg
 }
 
 // idx[i][0] = i, idx[i][1 + j] = the j-th negative of match i
-__global__ __launch_bounds__(256) void nce_negatives_write_kernel(int n, int negs, unsigned long long seed, const int* __restrict__ meta, int* __restrict__ idx) {
+__global__ __launch_bounds__(256) void nce_negatives_write_kernel(int n, int negs, unsigned long long seed, const int* __restrict__ meta, int* __restrict__ idx,
+                                                                  int n_from_meta) {
     const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int E = negs + 1;
+    if (n_from_meta) {                                             // rows [n, capacity): no edges (keys the counting sort skips)
+        const size_t cap_total = (size_t)n * negs;
+        const int nn = meta[1];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t e = q * 4 + u;
+            if (e < cap_total && e >= (size_t)nn * negs) {
+                const int i = (int)(e / negs), j = (int)(e - (size_t)i * negs);
+                idx[(size_t)i * E + 1 + j] = 0x7fffffff;
+                if (j == 0) idx[(size_t)i * E] = 0x7fffffff;
+            }
+        }
+        n = nn;
+    }
     const size_t total = (size_t)n * negs;
     if (q * 4 >= total) return;
     const U4 r = philox4x32(seed, q, 1u);
     const unsigned rr[4] = {r.x, r.y, r.z, r.w};
     const float same = (float)meta[2];
-    const int E = negs + 1;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const size_t e = q * 4 + u;
@@ -338,12 +354,12 @@ extern "C" int yp_nce_select(const unsigned char* valid, const float* uvb, int B
     return YP_OK;
 }
 
-extern "C" int yp_nce_negatives(int n, int negs, uint64_t seed, int* meta, int* idx, void* stream) {
+extern "C" int yp_nce_negatives(int n, int negs, uint64_t seed, int* meta, int* idx, int n_from_meta, void* stream) {
     YP_REQUIRE(meta && idx && n > 0 && negs > 0, "yp_nce_negatives: bad arguments");
     const size_t quads = ((size_t)n * negs + 3) / 4;
     const unsigned grid = (unsigned)((quads + 255) / 256);
-    nce_negatives_count_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(n, negs, (unsigned long long)seed, meta);
-    nce_negatives_write_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(n, negs, (unsigned long long)seed, meta, idx);
+    nce_negatives_count_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(n, negs, (unsigned long long)seed, meta, n_from_meta);
+    nce_negatives_write_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(n, negs, (unsigned long long)seed, meta, idx, n_from_meta);
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
 }

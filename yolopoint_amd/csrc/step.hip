@@ -46,8 +46,13 @@ __device__ __forceinline__ double wave_sum_f64(double a) {
 // desc_scale_out (the scalar the InfoNCE backward multiplies its gradients with) = desc_scale.
 __global__ __launch_bounds__(256) void loss_combine_kernel(const float* __restrict__ det, int n_det, const float* __restrict__ rows, int n_rows,
                                                            const float* __restrict__ obj, float lambda_desc, float lambda_obj, float scale, float desc_scale,
-                                                           float* __restrict__ out, float* __restrict__ desc_scale_out) {
+                                                           float* __restrict__ out, float* __restrict__ desc_scale_out, const int* __restrict__ n_rows_dev,
+                                                           float g_desc, double tau) {
     __shared__ double sh[4];
+    if (n_rows_dev != nullptr) {           // device-side row count: desc_scale = g_desc / (tau * n), rounded as the host computes it
+        n_rows = n_rows_dev[0];
+        desc_scale = n_rows > 0 ? g_desc * (float)(1.0 / (tau * (double)n_rows)) : 0.f;
+    }
     double a = 0.0;
     for (int i = threadIdx.x; i < n_rows; i += 256) a += rows[i];
     a = wave_sum_f64(a);
@@ -92,10 +97,10 @@ extern "C" int yp_counters_add(int64_t* const* table_dev, int n, int64_t inc, vo
 }
 
 extern "C" int yp_loss_combine(const float* det_losses, int n_det, const float* nce_rows, int n_rows, const float* obj_sums, float lambda_desc, float lambda_obj,
-                               float scale, float desc_scale, float* out4, float* desc_scale_out, void* stream) {
+                               float scale, float desc_scale, float* out4, float* desc_scale_out, const int* n_rows_dev, float g_desc, double tau, void* stream) {
     YP_REQUIRE(out4 && n_det >= 0 && n_rows >= 0 && (n_det == 0 || det_losses) && (n_rows == 0 || nce_rows), "yp_loss_combine: bad arguments");
     loss_combine_kernel<<<1, 256, 0, (hipStream_t)stream>>>(det_losses, n_det, nce_rows, n_rows, obj_sums, lambda_desc, lambda_obj, scale, desc_scale, out4,
-                                                           desc_scale_out);
+                                                           desc_scale_out, n_rows_dev, g_desc, tau);
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
 }

@@ -214,7 +214,8 @@ class TrainStep:
         def label_work():
             tgt_ = self.obj_loss.assign(shapes, batch['box_labels'])
             nce_ = infonce_prepare(batch['warped_valid_mask'], batch['inv_homographies'], (B, D, Hc, Wc), True, self.sparse['num_samples_per_image'],
-                                   self.sparse['num_masked_non_matches_per_match'], 8, dev, pair_index=True)
+                                   self.sparse['num_masked_non_matches_per_match'], 8, dev, pair_index=True,
+                                   sync=os.environ.get("YP_PREPARE_SYNC", "0") == "1" or os.environ.get("YP_NATIVE_PREPARE", "1") == "0")
             for j, key in enumerate(('valid_mask', 'warped_valid_mask')):
                 check(lib.yp_cell_mask(batch[key].data_ptr(), B, H, W, stg.mask[j].data_ptr(), scal + 4 * (6 + j), stg.ws_side.data_ptr(), stg.ws_bytes, sp()))
             return tgt_, nce_
@@ -253,24 +254,36 @@ class TrainStep:
                                    B, H, W, stg.dsemi_ptr + 4 * j * B * stg.ds[0], stg.ds, scal + 4 * (4 + j), stg.ws_main.data_ptr(), stg.ws_bytes, sp()))
         # ---- InfoNCE (utils/loss_functions.py:484-597): one lookup over both passes' descriptor maps, loss rows + anchor-side gradient in
         # one gather pass, the loss sum, the match-side gradient, the scatter into the descriptor seed
-        ua, _, _, (idx, order, offsets), (uab, s_order, s_offsets) = nce
-        pool, E, tau = ua.shape[1], idx.shape[1], 0.07
-        n = B * pool
+        tau = 0.07
+        g_desc = f32(f32(scale) * f32(LAMBDA_DESC)) if scale != 1.0 else f32(LAMBDA_DESC)
+        out4 = torch.empty((4,), dtype=torch.float32, device=dev)
+        if isinstance(nce, dict):
+            # counts on the device (infonce_prepare(sync=False)): arrays at their capacity, the kernels read points-per-image / matched rows from
+            # the sampling's meta words -- no host synchronisation anywhere in the step
+            meta = nce["meta"].data_ptr()
+            p_dev, n_dev = meta, meta + 4
+            n, pool, E = nce["n_cap"], nce["pool_cap"], nce["E"]
+            uab, idx, order, offsets, s_order, s_offsets = (nce[k] for k in ("uab", "idx", "order", "offsets", "s_order", "s_offsets"))
+            desc_scale = 0.0
+        else:
+            ua, _, _, (idx, order, offsets), (uab, s_order, s_offsets) = nce
+            p_dev = n_dev = None
+            pool, E = ua.shape[1], idx.shape[1]
+            n = B * pool
+            desc_scale = float(f32(g_desc * f32(1.0 / (tau * n))))
         dab = torch.empty((2 * n, D), dtype=torch.float32, device=dev)
         grad = torch.empty((2 * n, D), dtype=torch.float32, device=dev)
         w = torch.empty((n, E), dtype=torch.float32, device=dev)
         rows, lse = torch.empty((n,), dtype=torch.float32, device=dev), torch.empty((n,), dtype=torch.float32, device=dev)
-        out4 = torch.empty((4,), dtype=torch.float32, device=dev)
-        check(lib.yp_points_sample_fwd(stg.desc_ptr, 2 * B, Hc, Wc, D, uab.data_ptr(), pool, dab.data_ptr(), sp()))
-        check(lib.yp_infonce_fwd_grad(dab.data_ptr(), dab.data_ptr() + 4 * n * D, idx.data_ptr(), n, E, D, 1.0 / tau, w.data_ptr(), rows.data_ptr(), lse.data_ptr(),
-                                      grad.data_ptr(), sp()))
-        g_desc = f32(f32(scale) * f32(LAMBDA_DESC)) if scale != 1.0 else f32(LAMBDA_DESC)
-        desc_scale = float(f32(g_desc * f32(1.0 / (tau * n))))
-        check(lib.yp_loss_combine(scal + 16, 2, rows.data_ptr(), n, scal, LAMBDA_DESC, LAMBDA_OBJ, float(scale), desc_scale, out4.data_ptr(), scal + 48, sp()))
+        check(lib.yp_points_sample_fwd(stg.desc_ptr, 2 * B, Hc, Wc, D, uab.data_ptr(), pool, dab.data_ptr(), p_dev, sp()))
+        check(lib.yp_infonce_fwd_grad(dab.data_ptr(), None if n_dev else dab.data_ptr() + 4 * n * D, idx.data_ptr(), n, E, D, 1.0 / tau, w.data_ptr(), rows.data_ptr(),
+                                      lse.data_ptr(), grad.data_ptr(), n_dev, sp()))
+        check(lib.yp_loss_combine(scal + 16, 2, rows.data_ptr(), n, scal, LAMBDA_DESC, LAMBDA_OBJ, float(scale), desc_scale, out4.data_ptr(), scal + 48, n_dev,
+                                  float(g_desc), tau, sp()))
         check(lib.yp_infonce_bwd_db(dab.data_ptr(), order.data_ptr(), offsets.data_ptr(), w.data_ptr(), lse.data_ptr(), n, E, D, scal + 48,
-                                    grad.data_ptr() + 4 * n * D, sp()))
+                                    grad.data_ptr() if n_dev else grad.data_ptr() + 4 * n * D, n_dev, sp()))
         check(lib.yp_points_sample_bwd_sorted(grad.data_ptr(), 2 * B, Hc, Wc, D, uab.data_ptr(), pool, s_order.data_ptr(), s_offsets.data_ptr(), scal + 48, n,
-                                              stg.gdesc_ptr, sp()))
+                                              stg.gdesc_ptr, n_dev, sp()))
         # ---- backward: YOLO-branch plan -> its buckets go out -> trunk plan over both passes
         self.reducer.begin()
         run_native_backward_pair(g, SEEDED, SEEDED, [SEEDED] * len(g.xs), notify=self.reducer.notify)
@@ -279,7 +292,7 @@ class TrainStep:
 
     def loss_and_grads(self, batch, prepare=True, first_micro=True, scale=1.0):
         """loss = (det + det_warp) + lambda_desc * infonce + lambda_obj * obj and its backward (reference train.py:208-245).
-        With `prepare`, the label-only parts of the losses (YOLO target assignment: a device kernel; InfoNCE sampling: one host sync)
+        With `prepare`, the label-only parts of the losses (YOLO target assignment: a device kernel; InfoNCE sampling: device kernels, counts stay on the device)
         run right after both forward passes have been launched.  The backward is driven explicitly: the loss kernels are
         differentiated down to the network's head outputs (torch.autograd.grad), then the FULL native backward of the image pass
         runs, the gradient buckets it completes are handed to the all-reduce, and the keypoint-only backward of the warped pass runs
@@ -294,7 +307,7 @@ class TrainStep:
         self.reducer.bind_grads(zero=first_micro)   # (instead of optimizer.zero_grad: gradients accumulate straight into the all-reduce buckets)
         img = batch['image']
         B, S = img.shape[0], img.shape[-1]
-        # The label-only parts of the losses (YOLO target assignment, InfoNCE sampling with its one host synchronisation, the 65-channel
+        # The label-only parts of the losses (YOLO target assignment, InfoNCE sampling, the 65-channel
         # keypoint labels and cell masks: ~100 small launches that depend on the batch only) run on a side stream that forks from the main
         # stream at a point BEFORE the forward: they execute beside the forward pass instead of between it and the losses, and the host
         # synchronisation waits for the side stream only.  YP_TRAIN_SIDE_STREAM=0: everything on the main stream, after the forward launch.

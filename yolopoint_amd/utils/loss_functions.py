@@ -280,7 +280,7 @@ class _InfoNCENative(torch.autograd.Function):
             lse = torch.empty((n,), dtype=torch.float32, device=da.device)
             dda_u = torch.empty_like(da)
             _hip.check(_hip.lib().yp_infonce_fwd_grad(da.data_ptr(), db.data_ptr(), idx.data_ptr(), n, E, D, 1.0 / tau, logits.data_ptr(), rows.data_ptr(),
-                                                      lse.data_ptr(), dda_u.data_ptr(), _hip.stream_ptr()))
+                                                      lse.data_ptr(), dda_u.data_ptr(), None, _hip.stream_ptr()))
             ctx.save_for_backward(da, order, offsets, logits, lse, dda_u)
             ctx.fused = True
         else:
@@ -301,7 +301,7 @@ class _InfoNCENative(torch.autograd.Function):
         scale = (g.float() * (1.0 / (ctx.tau * n))).reshape(1)
         ddb = torch.empty_like(da)
         _hip.check(_hip.lib().yp_infonce_bwd_db(da.data_ptr(), order.data_ptr(), offsets.data_ptr(), logits.data_ptr(), lse.data_ptr(), n, E, D,
-                                                scale.data_ptr(), ddb.data_ptr(), _hip.stream_ptr()))
+                                                scale.data_ptr(), ddb.data_ptr(), None, _hip.stream_ptr()))
         return dda_u * scale, ddb, None, None, None, None
 
 
@@ -322,7 +322,7 @@ class _InfoNCEPairNative(torch.autograd.Function):
         grad = torch.empty_like(dab)                    # [dda (unscaled until the backward) | ddb]
         pa, pb = dab.data_ptr(), dab.data_ptr() + 4 * n * D
         _hip.check(_hip.lib().yp_infonce_fwd_grad(pa, pb, idx.data_ptr(), n, E, D, 1.0 / tau, w.data_ptr(), rows.data_ptr(), lse.data_ptr(), grad.data_ptr(),
-                                                  _hip.stream_ptr()))
+                                                  None, _hip.stream_ptr()))
         ctx.save_for_backward(dab, order, offsets, w, lse, grad)
         ctx.tau = tau
         return rows.mean()
@@ -339,7 +339,7 @@ class _InfoNCEPairNative(torch.autograd.Function):
         # unscaled anchor half again and must not overwrite a tensor that was already handed out)
         out = torch.empty_like(grad)
         _hip.check(_hip.lib().yp_infonce_bwd_db(dab.data_ptr(), order.data_ptr(), offsets.data_ptr(), w.data_ptr(), lse.data_ptr(), n, E, D,
-                                                scale.data_ptr(), out.data_ptr() + 4 * n * D, _hip.stream_ptr()))
+                                                scale.data_ptr(), out.data_ptr() + 4 * n * D, None, _hip.stream_ptr()))
         torch.mul(grad[:n], scale, out=out[:n])
         return out, None, None, None, None
 
@@ -356,7 +356,7 @@ class _PointSampleNative(torch.autograd.Function):
         B, D, H, W = desc.shape
         P = uv.shape[1]
         out = torch.empty((B, P, D), dtype=torch.float32, device=desc.device)
-        _hip.check(_hip.lib().yp_points_sample_fwd(desc.data_ptr(), B, H, W, D, uv.data_ptr(), P, out.data_ptr(), _hip.stream_ptr()))
+        _hip.check(_hip.lib().yp_points_sample_fwd(desc.data_ptr(), B, H, W, D, uv.data_ptr(), P, out.data_ptr(), None, _hip.stream_ptr()))
         ctx.save_for_backward(uv, order, offsets)
         ctx.dims = (B, D, H, W, P)
         return out
@@ -371,7 +371,7 @@ class _PointSampleNative(torch.autograd.Function):
         if order is not None:        # cell-sorted (point, tap) list (point_sample_index): one pass, no atomics, no zero-fill, fixed summation order
             gmap = torch.empty((B, H, W, D), dtype=torch.float32, device=g.device)
             _hip.check(_hip.lib().yp_points_sample_bwd_sorted(g.data_ptr(), B, H, W, D, uv.data_ptr(), P, order.data_ptr(), offsets.data_ptr(), None, 0,
-                                                              gmap.data_ptr(), _hip.stream_ptr()))
+                                                              gmap.data_ptr(), None, _hip.stream_ptr()))
         else:
             gmap = torch.zeros((B, H, W, D), dtype=torch.float32, device=g.device)
             _hip.check(_hip.lib().yp_points_sample_bwd(g.data_ptr(), B, H, W, D, uv.data_ptr(), P, gmap.data_ptr(), _hip.stream_ptr()))
@@ -391,7 +391,7 @@ def _csr(keys, n_buckets, wide):
     return order, offsets
 
 
-def point_sample_index(uv, H, W):
+def point_sample_index(uv, H, W, count_dev=None):
     """uv [B, P, 2] (normalised sample coordinates on an H x W map) -> (order int32 [B*P*4], offsets int32 [B*H*W + 1]): the (point, tap)
     pairs of the bilinear lookup grouped by the cell they touch (ascending inside a cell; taps outside the map / of weight 0 are not
     listed) and the CSR offsets of the cells, for _PointSampleNative's atomic-free backward.  Label-only work (it depends on the sample
@@ -400,7 +400,8 @@ def point_sample_index(uv, H, W):
     B, P = uv.shape[0], uv.shape[1]
     uv = uv.contiguous()
     keys = torch.empty((B * P * 4,), dtype=torch.int32, device=uv.device)
-    _hip.check(_hip.lib().yp_points_sample_taps(uv.data_ptr(), B, P, H, W, keys.data_ptr(), _hip.stream_ptr()))
+    # (count_dev: device pointer to the real points-per-image count when uv is a capacity-sized compact array -- _prepare_native(sync=False))
+    _hip.check(_hip.lib().yp_points_sample_taps(uv.data_ptr(), B, P, H, W, keys.data_ptr(), count_dev, _hip.stream_ptr()))
     return _csr(keys, B * H * W, wide=False)
 
 
@@ -417,7 +418,7 @@ def infonce_edges(rnd):
     return idx, order.to(torch.int32), offsets
 
 
-def _prepare_native(mask_valid_warp, inv_homographies, B, Hc, Wc, samples, negs, pair_index):
+def _prepare_native(mask_valid_warp, inv_homographies, B, Hc, Wc, samples, negs, pair_index, sync=True):
     """infonce_prepare on the device (csrc/sampling.hip): validity of the cells and their matches, the uniform draw of `pool` cells per
     image, the negatives, the transposed edge list and (pair_index) the cell-sorted tap list -- ~16 native launches, one host
     synchronisation (the common pool size fixes the tensor shapes).  The two Philox keys come from torch's CPU generator:
@@ -437,13 +438,23 @@ def _prepare_native(mask_valid_warp, inv_homographies, B, Hc, Wc, samples, negs,
     meta = torch.empty((4,), dtype=torch.int32, device=dev)
     check(lib.yp_nce_cells(mask.data_ptr(), inv.data_ptr(), B, H, W, valid.data_ptr(), uvb.data_ptr(), sp()))
     check(lib.yp_nce_select(valid.data_ptr(), uvb.data_ptr(), B, Hc, Wc, samples, s0, store.data_ptr(), meta.data_ptr(), sp()))
+    if not sync:
+        # No read-back: every array keeps its CAPACITY (pool = samples) and the counts stay on the device -- meta[0] = points per image,
+        # meta[1] = matched rows; the consumers (engine.TrainStep's native loss stage) hand the kernels these pointers.  Returns a dict.
+        n_cap, E = B * samples, negs + 1
+        idx = torch.empty((n_cap, E), dtype=torch.int32, device=dev)
+        check(lib.yp_nce_negatives(n_cap, negs, s1, meta.data_ptr(), idx.data_ptr(), 1, sp()))
+        order, offsets = _csr(idx.view(-1), n_cap, wide=True)
+        uab = store.view(2 * B, samples, 2)             # (compact [2B][pool][2] at the front of the buffer)
+        s_order, s_offsets = point_sample_index(uab, Hc, Wc, count_dev=meta.data_ptr())
+        return dict(meta=meta, uab=store, idx=idx, order=order, offsets=offsets, s_order=s_order, s_offsets=s_offsets, n_cap=n_cap, pool_cap=samples, E=E)
     pool = int(meta[0])                                 # (the one host synchronisation)
     if pool <= 0:
         raise _hip.YpError("infonce: an image of the batch has no valid cell")
     n, E = B * pool, negs + 1
     uab = store[:2 * n * 2].view(2 * B, pool, 2)
     idx = torch.empty((n, E), dtype=torch.int32, device=dev)
-    check(lib.yp_nce_negatives(n, negs, s1, meta.data_ptr(), idx.data_ptr(), sp()))
+    check(lib.yp_nce_negatives(n, negs, s1, meta.data_ptr(), idx.data_ptr(), 0, sp()))
     edges = (idx,) + _csr(idx.view(-1), n, wide=True)
     out = (uab[:B], uab[B:], idx[:, 1:], edges)
     if pair_index and os.environ.get("YP_SAMPLE_SORTED", "1") != "0":
@@ -503,17 +514,20 @@ def infonce(descriptors, descriptors_warped, mask_valid_warp, inv_homographies, 
 
 
 def infonce_prepare(mask_valid_warp, inv_homographies, desc_shape, on_device, num_samples_per_image=1500,
-                    num_masked_non_matches_per_match=120, cell_size=8, device='cpu', perm_fn=None, randint_fn=None, pair_index=False):
+                    num_masked_non_matches_per_match=120, cell_size=8, device='cpu', perm_fn=None, randint_fn=None, pair_index=False, sync=True):
     """The label-only half of `infonce`: which cells are matched (normalised sample coordinates ua, ub [B, pool, 2]) and
-    which matches serve as negatives (rnd [n, negs]).  It needs one host sync (the common pool size), so a training step
-    calls it before the forward passes are launched."""
+    which matches serve as negatives (rnd [n, negs]).  With `sync` the common pool size is read back (one host synchronisation) and the
+    arrays are trimmed to it; `sync=False` (cuda, native sampling) keeps capacity-sized arrays with the counts in device memory (a dict,
+    see `_prepare_native`), which is what the training step uses."""
     assert desc_shape[-1] * desc_shape[-2] >= num_samples_per_image, \
         "Number of samples per image must be greater than number of pixels in image"
     with torch.no_grad():
         B, Hc, Wc = desc_shape[0], desc_shape[2], desc_shape[3]
         if (perm_fn is None and randint_fn is None and on_device and mask_valid_warp.is_cuda and cell_size == 8 and Hc * Wc < 36864
                 and mask_valid_warp.shape[-2] == 8 * Hc and mask_valid_warp.shape[-1] == 8 * Wc and os.environ.get("YP_NATIVE_PREPARE", "1") != "0"):
-            return _prepare_native(mask_valid_warp, inv_homographies, B, Hc, Wc, num_samples_per_image, num_masked_non_matches_per_match, pair_index)
+            return _prepare_native(mask_valid_warp, inv_homographies, B, Hc, Wc, num_samples_per_image, num_masked_non_matches_per_match, pair_index,
+                                   sync=sync)
+        assert sync, "infonce_prepare(sync=False) exists for the device-side formulation only"
         uv_a = get_coor_cells(Hc, Wc, uv=True).to(device)
         inv_h = inv_homographies.to(device)
         valid = warp_image_batch(mask_valid_warp, inv_h, mode='nearest', device=device)
