@@ -21,6 +21,7 @@ class Census(TorchDispatchMode):
         super().__init__()
         self.ops = collections.Counter()
         self.where = collections.defaultdict(collections.Counter)
+        self.syncs = collections.Counter()
 
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = func.overloadpacket.__name__
@@ -32,6 +33,8 @@ class Census(TorchDispatchMode):
                 break
         self.ops[name] += 1
         self.where[name][site] += 1
+        if name in ("_local_scalar_dense", "is_nonzero") and any(isinstance(x, torch.Tensor) and x.is_cuda for x in args):
+            self.syncs[site] += 1           # a device value read back by the host
         return func(*args, **(kwargs or {}))
 
 
@@ -53,8 +56,8 @@ def main():
     torch.cuda.synchronize()
     launching = {k: v for k, v in c.ops.items() if k not in VIEWS}
     print(f"# one training step: {sum(c.ops.values())} ATen dispatches, {sum(launching.values())} of them not view-only")
-    syncs = {k: c.ops[k] for k in ("_local_scalar_dense", "item", "is_nonzero") if c.ops.get(k)}
-    print(f"# host read-backs of device values (synchronisations): {syncs if syncs else 'none'}")
+    print(f"# host read-backs of device values (synchronisations): {dict(c.syncs) if c.syncs else 'none'}"
+          f"   (scalar reads of host tensors: {c.ops.get('_local_scalar_dense', 0) - sum(c.syncs.values())})")
     by_site = collections.Counter()
     for name, n in sorted(launching.items(), key=lambda kv: -kv[1]):
         sites = ", ".join(f"{s} x{k}" for s, k in c.where[name].most_common(6))

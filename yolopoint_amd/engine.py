@@ -175,6 +175,13 @@ class TrainStep:
             ok = ok and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == img.shape[0] * img.shape[-2] * img.shape[-1]
         return bool(ok)
 
+    def _det_strides(self):
+        # Detect.stride lives on the device: reading it per step would make the host wait for the forward it has just launched
+        st = getattr(self, "_det_strides_host", None)
+        if st is None:
+            st = self._det_strides_host = [int(v) for v in self.model.model.Detect.stride.tolist()]
+        return st
+
     def _loss_and_grads_native(self, batch, first_micro, scale):
         import numpy as np
         from types import SimpleNamespace
@@ -208,7 +215,7 @@ class TrainStep:
                 semi_ptr=sv.data_ptr(), zs=(C.c_int64 * 4)(*sv.stride()), dsemi_ptr=g.seed_semi.data_ptr(), ds=(C.c_int64 * 4)(*g.seed_semi.stride()),
                 desc_ptr=g.desc_v.buf.t.data_ptr(), gdesc_ptr=gd.t.data_ptr())
         det = net.Detect
-        shapes = [(B, det.na, H // int(st), W // int(st), det.no) for st in det.stride]
+        shapes = [(B, det.na, H // st, W // st, det.no) for st in self._det_strides()]
         scal = stg.scal.data_ptr()           # floats: [0:3] object-loss sums, [4:6] detector losses, [6:8] mask sums, [12] InfoNCE gradient scale
 
         def label_work():
@@ -317,7 +324,7 @@ class TrainStep:
 
         def label_work():
             det = m.model.Detect
-            shapes = [(B, det.na, img.shape[-2] // int(st), S // int(st), det.no) for st in det.stride]
+            shapes = [(B, det.na, img.shape[-2] // st, S // st, det.no) for st in self._det_strides()]
             tgt_ = self.obj_loss.assign(shapes, batch['box_labels']) if prepare else None
             dch = getattr(m.model, "_desc_channels", None) or m.model.ConvDesc.out_channels
             nce_ = infonce_prepare(batch['warped_valid_mask'], batch['inv_homographies'], (B, dch, img.shape[-2] // 8, S // 8), True,
