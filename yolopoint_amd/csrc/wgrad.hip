@@ -277,9 +277,19 @@ __global__ __launch_bounds__(256) void wgrad_fold_kernel(const WgradArgs* __rest
     const size_t n = (size_t)a.Cj * taps * a.Cout_pad;            // (a multiple of 8: Cout_pad is)
     const size_t i = ((size_t)(bid - a.f_chunk0) * 256 + threadIdx.x) * 4;
     if (i >= n) return;
-    f32x4 v = *reinterpret_cast<const f32x4*>(a.part + i);
-    for (int s = 1; s < a.g_split; ++s) {
-        const f32x4 u = *reinterpret_cast<const f32x4*>(a.part + (size_t)s * n + i);
+    // (eight slab reads in flight per thread; the additions keep the slab order)
+    const float* p = a.part + i;
+    f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    int s = 1;
+    for (; s + 8 <= a.g_split; s += 8) {
+        f32x4 u[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) u[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + (size_t)(s + j) * n));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[0] += u[j][0]; v[1] += u[j][1]; v[2] += u[j][2]; v[3] += u[j][3]; }
+    }
+    for (; s < a.g_split; ++s) {
+        const f32x4 u = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + (size_t)s * n));
         v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
     }
     *reinterpret_cast<f32x4*>(a.dw + i) = v;
