@@ -479,8 +479,7 @@ __global__ __launch_bounds__(256) void cell_mask_kernel(const float* __restrict_
 
 __global__ __launch_bounds__(256) void cell_mask_fold_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ msum) {
     __shared__ double sh[4];
-    double a = 0.0;
-    for (int i = threadIdx.x; i < nblk; i += 256) a += partial[i];
+    double a = yp_strided_sum256(partial, nblk);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
         a += __longlong_as_double(((long long)__shfl_xor((int)(__double_as_longlong(a) >> 32), o, 64) << 32) | (unsigned)__shfl_xor((int)(__double_as_longlong(a) & 0xffffffffll), o, 64));
@@ -536,8 +535,7 @@ __global__ __launch_bounds__(256) void detloss2d_kernel(const float* __restrict_
 
 __global__ __launch_bounds__(256) void detloss2d_fold_kernel(const float* __restrict__ partial, int nblk, const float* __restrict__ msum, float* __restrict__ loss) {
     __shared__ double sh[4];
-    double a = 0.0;
-    for (int i = threadIdx.x; i < nblk; i += 256) a += partial[i];
+    double a = yp_strided_sum256(partial, nblk);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
         a += __longlong_as_double(((long long)__shfl_xor((int)(__double_as_longlong(a) >> 32), o, 64) << 32) | (unsigned)__shfl_xor((int)(__double_as_longlong(a) & 0xffffffffll), o, 64));

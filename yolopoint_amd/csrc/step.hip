@@ -53,8 +53,7 @@ __global__ __launch_bounds__(256) void loss_combine_kernel(const float* __restri
         n_rows = n_rows_dev[0];
         desc_scale = n_rows > 0 ? g_desc * (float)(1.0 / (tau * (double)n_rows)) : 0.f;
     }
-    double a = 0.0;
-    for (int i = threadIdx.x; i < n_rows; i += 256) a += rows[i];
+    double a = yp_strided_sum256(rows, n_rows);
     a = wave_sum_f64(a);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
     __syncthreads();

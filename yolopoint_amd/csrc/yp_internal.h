@@ -93,3 +93,19 @@ __device__ __forceinline__ void yp_block_amax(float mx, float* amax) {
         if (m > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax) + ((blockIdx.x + blockIdx.y) & (YP_FP8_AMAX_SLOTS - 1)), __float_as_uint(m));
     }
 }
+
+// Thread t's sum of p[t], p[t + 256], p[t + 512], ... (i < n) in double precision, in that order, with eight loads in flight (the single-
+// workgroup folds behind the loss kernels walk 10-25 k partials: one dependent load per addition made them 13-25 us of pure latency).
+__device__ __forceinline__ double yp_strided_sum256(const float* __restrict__ p, int n) {
+    double a = 0.0;
+    int i = threadIdx.x;
+    for (; i + 7 * 256 < n; i += 8 * 256) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = p[i + j * 256];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a += v[j];
+    }
+    for (; i < n; i += 256) a += p[i];
+    return a;
+}
