@@ -240,25 +240,36 @@ class TrainStep:
         # plan's Detect seeds; its upstream factor lambda_obj * scale is applied by the plan's first op (TrainGraph.head_scale)
         want = float(f32(f32(scale) * f32(LAMBDA_OBJ))) if scale != 1.0 else float(f32(LAMBDA_OBJ))
         g.set_head_scale(want)
-        check(lib.yp_fill_zero(scal, 16, sp()))
-        ol, hyp = self.obj_loss, self.obj_loss.hyp
-        cap = tgt["cap"] if tgt["nt"] else 0
-        cap_alloc = max(cap, 1)
-        for i, xo in enumerate(g.xs):
-            no = xo.shape[-1]
-            cells = (xo.numel() // xo.shape[0]) * B // no
-            iou = torch.empty((cap_alloc,), dtype=torch.float32, device=dev)
-            own = torch.empty((cells,), dtype=torch.int32, device=dev)
-            check(lib.yp_objloss_level_dev(xo.data_ptr(), cells, no, ol.nc, tgt["cell"].data_ptr() + 4 * i * tgt["cap"], tgt["box"].data_ptr() + 16 * i * tgt["cap"],
-                                           tgt["anchor"].data_ptr() + 8 * i * tgt["cap"], tgt["cls"].data_ptr() + 4 * i * tgt["cap"], cap,
-                                           tgt["count"].data_ptr() + 4 * i, float(ol.cp), float(ol.cn), float(hyp['cls_pw']), float(hyp['obj_pw']),
-                                           float(hyp['box']), float(hyp['obj']) * float(ol.balance[i]), float(hyp['cls']), iou.data_ptr(), own.data_ptr(),
-                                           g.g_xs[i].data_ptr(), scal, sp()))
-        # ---- detector loss of both passes (utils/loss_functions.py:600-619 on labels2Dto3D / getMasks of the 2-D maps): final gradients
-        # into the semi seed
-        for j, key in enumerate(('labels_2D', 'warped_labels')):
-            check(lib.yp_detloss2d(stg.semi_ptr + 4 * j * B * stg.zs[0], stg.zs, batch[key].data_ptr(), stg.mask[j].data_ptr(), scal + 4 * (6 + j), float(f32(scale)),
-                                   B, H, W, stg.dsemi_ptr + 4 * j * B * stg.ds[0], stg.ds, scal + 4 * (4 + j), stg.ws_main.data_ptr(), stg.ws_bytes, sp()))
+        # The object loss and the detector loss read other heads than InfoNCE and write other seeds: with a side stream they run beside the
+        # InfoNCE gathers (a dozen small launches, ~150 us at -s) and join in front of the loss sum.
+        def small_losses():
+            check(lib.yp_fill_zero(scal, 16, sp()))
+            ol, hyp = self.obj_loss, self.obj_loss.hyp
+            cap = tgt["cap"] if tgt["nt"] else 0
+            cap_alloc = max(cap, 1)
+            for i, xo in enumerate(g.xs):
+                no = xo.shape[-1]
+                cells = (xo.numel() // xo.shape[0]) * B // no
+                iou = torch.empty((cap_alloc,), dtype=torch.float32, device=dev)
+                own = torch.empty((cells,), dtype=torch.int32, device=dev)
+                check(lib.yp_objloss_level_dev(xo.data_ptr(), cells, no, ol.nc, tgt["cell"].data_ptr() + 4 * i * tgt["cap"], tgt["box"].data_ptr() + 16 * i * tgt["cap"],
+                                               tgt["anchor"].data_ptr() + 8 * i * tgt["cap"], tgt["cls"].data_ptr() + 4 * i * tgt["cap"], cap,
+                                               tgt["count"].data_ptr() + 4 * i, float(ol.cp), float(ol.cn), float(hyp['cls_pw']), float(hyp['obj_pw']),
+                                               float(hyp['box']), float(hyp['obj']) * float(ol.balance[i]), float(hyp['cls']), iou.data_ptr(), own.data_ptr(),
+                                               g.g_xs[i].data_ptr(), scal, sp()))
+            # ---- detector loss of both passes (utils/loss_functions.py:600-619 on labels2Dto3D / getMasks of the 2-D maps): final gradients
+            # into the semi seed
+            for j, key in enumerate(('labels_2D', 'warped_labels')):
+                check(lib.yp_detloss2d(stg.semi_ptr + 4 * j * B * stg.zs[0], stg.zs, batch[key].data_ptr(), stg.mask[j].data_ptr(), scal + 4 * (6 + j), float(f32(scale)),
+                                       B, H, W, stg.dsemi_ptr + 4 * j * B * stg.ds[0], stg.ds, scal + 4 * (4 + j), stg.ws_main.data_ptr(), stg.ws_bytes, sp()))
+        if side is not main and os.environ.get("YP_LOSS_LANES", "1") != "0":
+            side.wait_event(main.record_event())
+            with torch.cuda.stream(side):
+                small_losses()
+            small_done = side.record_event()
+        else:
+            small_losses()
+            small_done = None
         # ---- InfoNCE (utils/loss_functions.py:484-597): one lookup over both passes' descriptor maps, loss rows + anchor-side gradient in
         # one gather pass, the loss sum, the match-side gradient, the scatter into the descriptor seed
         tau = 0.07
@@ -285,6 +296,8 @@ class TrainStep:
         check(lib.yp_points_sample_fwd(stg.desc_ptr, 2 * B, Hc, Wc, D, uab.data_ptr(), pool, dab.data_ptr(), p_dev, sp()))
         check(lib.yp_infonce_fwd_grad(dab.data_ptr(), None if n_dev else dab.data_ptr() + 4 * n * D, idx.data_ptr(), n, E, D, 1.0 / tau, w.data_ptr(), rows.data_ptr(),
                                       lse.data_ptr(), grad.data_ptr(), n_dev, sp()))
+        if small_done is not None:
+            main.wait_event(small_done)
         check(lib.yp_loss_combine(scal + 16, 2, rows.data_ptr(), n, scal, LAMBDA_DESC, LAMBDA_OBJ, float(scale), desc_scale, out4.data_ptr(), scal + 48, n_dev,
                                   float(g_desc), tau, sp()))
         check(lib.yp_infonce_bwd_db(dab.data_ptr(), order.data_ptr(), offsets.data_ptr(), w.data_ptr(), lse.data_ptr(), n, E, D, scal + 48,
