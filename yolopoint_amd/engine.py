@@ -262,51 +262,69 @@ class TrainStep:
             for j, key in enumerate(('labels_2D', 'warped_labels')):
                 check(lib.yp_detloss2d(stg.semi_ptr + 4 * j * B * stg.zs[0], stg.zs, batch[key].data_ptr(), stg.mask[j].data_ptr(), scal + 4 * (6 + j), float(f32(scale)),
                                        B, H, W, stg.dsemi_ptr + 4 * j * B * stg.ds[0], stg.ds, scal + 4 * (4 + j), stg.ws_main.data_ptr(), stg.ws_bytes, sp()))
-        if side is not main and os.environ.get("YP_LOSS_LANES", "1") != "0":
+        lanes = int(os.environ.get("YP_LOSS_LANES", "2")) if side is not main else 0
+        tau = 0.07
+        g_desc = f32(f32(scale) * f32(LAMBDA_DESC)) if scale != 1.0 else f32(LAMBDA_DESC)
+
+        # ---- InfoNCE (utils/loss_functions.py:484-597): one lookup over both passes' descriptor maps, loss rows + anchor-side gradient in
+        # one gather pass, the loss sum, the match-side gradient, the scatter into the descriptor seed
+        def infonce_chain(stream, small_done):
+            out4_ = torch.empty((4,), dtype=torch.float32, device=dev)
+            if isinstance(nce, dict):
+                # counts on the device (infonce_prepare(sync=False)): arrays at their capacity, the kernels read points-per-image / matched rows
+                # from the sampling's meta words -- no host synchronisation anywhere in the step
+                meta = nce["meta"].data_ptr()
+                p_dev, n_dev = meta, meta + 4
+                n, pool, E = nce["n_cap"], nce["pool_cap"], nce["E"]
+                uab, idx, order, offsets, s_order, s_offsets = (nce[k] for k in ("uab", "idx", "order", "offsets", "s_order", "s_offsets"))
+                desc_scale = 0.0
+            else:
+                ua, _, _, (idx, order, offsets), (uab, s_order, s_offsets) = nce
+                p_dev = n_dev = None
+                pool, E = ua.shape[1], idx.shape[1]
+                n = B * pool
+                desc_scale = float(f32(g_desc * f32(1.0 / (tau * n))))
+            dab = torch.empty((2 * n, D), dtype=torch.float32, device=dev)
+            grad = torch.empty((2 * n, D), dtype=torch.float32, device=dev)
+            w = torch.empty((n, E), dtype=torch.float32, device=dev)
+            rows, lse = torch.empty((n,), dtype=torch.float32, device=dev), torch.empty((n,), dtype=torch.float32, device=dev)
+            check(lib.yp_points_sample_fwd(stg.desc_ptr, 2 * B, Hc, Wc, D, uab.data_ptr(), pool, dab.data_ptr(), p_dev, sp()))
+            check(lib.yp_infonce_fwd_grad(dab.data_ptr(), None if n_dev else dab.data_ptr() + 4 * n * D, idx.data_ptr(), n, E, D, 1.0 / tau, w.data_ptr(),
+                                          rows.data_ptr(), lse.data_ptr(), grad.data_ptr(), n_dev, sp()))
+            if small_done is not None:
+                stream.wait_event(small_done)
+            check(lib.yp_loss_combine(scal + 16, 2, rows.data_ptr(), n, scal, LAMBDA_DESC, LAMBDA_OBJ, float(scale), desc_scale, out4_.data_ptr(), scal + 48, n_dev,
+                                      float(g_desc), tau, sp()))
+            check(lib.yp_infonce_bwd_db(dab.data_ptr(), order.data_ptr(), offsets.data_ptr(), w.data_ptr(), lse.data_ptr(), n, E, D, scal + 48,
+                                        grad.data_ptr() if n_dev else grad.data_ptr() + 4 * n * D, n_dev, sp()))
+            check(lib.yp_points_sample_bwd_sorted(grad.data_ptr(), 2 * B, Hc, Wc, D, uab.data_ptr(), pool, s_order.data_ptr(), s_offsets.data_ptr(), scal + 48, n,
+                                                  stg.gdesc_ptr, n_dev, sp()))
+            return out4_
+
+        join = None
+        if lanes >= 2:
+            # The whole InfoNCE chain (latency-bound gathers, 0.8 ms at -s / 2.5 ms at -l) on the side stream, beside the YOLO-branch backward
+            # plan, which only needs the Detect seeds of the object loss; the trunk plan waits for it.
+            fwd_done = main.record_event()
+            small_losses()
+            small_done = main.record_event()
+            side.wait_event(fwd_done)
+            with torch.cuda.stream(side):
+                out4 = infonce_chain(side, small_done)
+                out4.record_stream(main)
+            nce_done = side.record_event()
+            join = lambda: main.wait_event(nce_done)
+        elif lanes == 1:
             side.wait_event(main.record_event())
             with torch.cuda.stream(side):
                 small_losses()
-            small_done = side.record_event()
+            out4 = infonce_chain(main, side.record_event())
         else:
             small_losses()
-            small_done = None
-        # ---- InfoNCE (utils/loss_functions.py:484-597): one lookup over both passes' descriptor maps, loss rows + anchor-side gradient in
-        # one gather pass, the loss sum, the match-side gradient, the scatter into the descriptor seed
-        tau = 0.07
-        g_desc = f32(f32(scale) * f32(LAMBDA_DESC)) if scale != 1.0 else f32(LAMBDA_DESC)
-        out4 = torch.empty((4,), dtype=torch.float32, device=dev)
-        if isinstance(nce, dict):
-            # counts on the device (infonce_prepare(sync=False)): arrays at their capacity, the kernels read points-per-image / matched rows from
-            # the sampling's meta words -- no host synchronisation anywhere in the step
-            meta = nce["meta"].data_ptr()
-            p_dev, n_dev = meta, meta + 4
-            n, pool, E = nce["n_cap"], nce["pool_cap"], nce["E"]
-            uab, idx, order, offsets, s_order, s_offsets = (nce[k] for k in ("uab", "idx", "order", "offsets", "s_order", "s_offsets"))
-            desc_scale = 0.0
-        else:
-            ua, _, _, (idx, order, offsets), (uab, s_order, s_offsets) = nce
-            p_dev = n_dev = None
-            pool, E = ua.shape[1], idx.shape[1]
-            n = B * pool
-            desc_scale = float(f32(g_desc * f32(1.0 / (tau * n))))
-        dab = torch.empty((2 * n, D), dtype=torch.float32, device=dev)
-        grad = torch.empty((2 * n, D), dtype=torch.float32, device=dev)
-        w = torch.empty((n, E), dtype=torch.float32, device=dev)
-        rows, lse = torch.empty((n,), dtype=torch.float32, device=dev), torch.empty((n,), dtype=torch.float32, device=dev)
-        check(lib.yp_points_sample_fwd(stg.desc_ptr, 2 * B, Hc, Wc, D, uab.data_ptr(), pool, dab.data_ptr(), p_dev, sp()))
-        check(lib.yp_infonce_fwd_grad(dab.data_ptr(), None if n_dev else dab.data_ptr() + 4 * n * D, idx.data_ptr(), n, E, D, 1.0 / tau, w.data_ptr(), rows.data_ptr(),
-                                      lse.data_ptr(), grad.data_ptr(), n_dev, sp()))
-        if small_done is not None:
-            main.wait_event(small_done)
-        check(lib.yp_loss_combine(scal + 16, 2, rows.data_ptr(), n, scal, LAMBDA_DESC, LAMBDA_OBJ, float(scale), desc_scale, out4.data_ptr(), scal + 48, n_dev,
-                                  float(g_desc), tau, sp()))
-        check(lib.yp_infonce_bwd_db(dab.data_ptr(), order.data_ptr(), offsets.data_ptr(), w.data_ptr(), lse.data_ptr(), n, E, D, scal + 48,
-                                    grad.data_ptr() if n_dev else grad.data_ptr() + 4 * n * D, n_dev, sp()))
-        check(lib.yp_points_sample_bwd_sorted(grad.data_ptr(), 2 * B, Hc, Wc, D, uab.data_ptr(), pool, s_order.data_ptr(), s_offsets.data_ptr(), scal + 48, n,
-                                              stg.gdesc_ptr, n_dev, sp()))
-        # ---- backward: YOLO-branch plan -> its buckets go out -> trunk plan over both passes
+            out4 = infonce_chain(main, None)
+        # ---- backward: YOLO-branch plan -> its buckets go out (the InfoNCE lane joins) -> trunk plan over both passes
         self.reducer.begin()
-        run_native_backward_pair(g, SEEDED, SEEDED, [SEEDED] * len(g.xs), notify=self.reducer.notify)
+        run_native_backward_pair(g, SEEDED, SEEDED, [SEEDED] * len(g.xs), notify=self.reducer.notify, join=join)
         self.last_loss_terms = out4              # [total, detector, descriptor, object] (device)
         return out4[0]
 

@@ -936,15 +936,18 @@ def run_native_backward(g, g_semi, g_desc, g_xs):
     return _deliver(g.params, grads)
 
 
-def run_native_backward_pair(g, g_semi, g_desc, g_xs, notify=None):
+def run_native_backward_pair(g, g_semi, g_desc, g_xs, notify=None, join=None):
     """The backward of a pair-mode TrainGraph (both passes of a training step), parameter gradients accumulated into p.grad as
     run_native_backward does.  notify(parameters) is called twice: after the YOLO-branch plan (the detector-group parameters are final
-    while the trunk plan is still to run -- dp.GradAllReducer launches their buckets there) and after the trunk plan."""
+    while the trunk plan is still to run -- dp.GradAllReducer launches their buckets there) and after the trunk plan.  join() is called
+    in front of the trunk plan: a caller that fills the semi / desc seeds on another stream makes the current stream wait there."""
     def between(first):
         ps = list(first)
         done = _deliver(ps, [first[p_] for p_ in ps])
         if notify is not None:
             notify(done)
+        if join is not None:
+            join()
     rest = g.backward_pair(g_semi, g_desc, list(g_xs), between=between)
     g.busy = False
     ps = list(rest)
