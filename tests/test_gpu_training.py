@@ -789,3 +789,31 @@ def test_native_loss_stage_equals_the_autograd_stage(cuda, monkeypatch, gas):
     assert not bad, bad[:5]
     assert all(torch.equal(a, b) for a, b in zip(p0, p1))
     assert all(torch.equal(a, b) for a, b in zip(b0, b1))
+
+
+def test_loss_stage_lanes_and_the_bound_on_queued_steps(cuda, monkeypatch):
+    """The native loss stage on one stream (YP_LOSS_LANES=0), with the small losses beside InfoNCE (1) and with the InfoNCE chain beside the
+    YOLO-branch backward plan (2, the default): the same launches in another stream layout -> bit-identical gradients and weights (loss values to fp32
+    rounding).  Nothing in a step waits for the device, so TrainStep bounds the optimizer steps it leaves queued (YP_STEPS_IN_FLIGHT, default 2)."""
+    import copy
+    from yolopoint_amd.engine import TrainStep, synthetic_batch
+    m0, _ = make_model("n", 23, dtype="bf16")
+    m0 = m0.to(cuda).train()
+    batch = synthetic_batch(2, 128, cuda, 77)
+    batch['warped_valid_mask'][:, :, 30:70, 20:90] = 0.0
+    out = []
+    for lanes in ("0", "1", "2"):
+        monkeypatch.setenv("YP_LOSS_LANES", lanes)
+        mm = copy.deepcopy(m0)
+        step = TrainStep(mm, cuda, img_size=128)
+        step.sparse = dict(num_samples_per_image=100, num_masked_non_matches_per_match=30)
+        losses = []
+        for it in range(4):
+            torch.manual_seed(99 + it)
+            losses.append(step(batch))
+            assert len(step._in_flight) <= 2
+        out.append(([float(v) for v in losses], [p.grad.clone() for p in mm.parameters()], [p.detach().clone() for p in mm.parameters()]))
+    for l, g, p in out[1:]:
+        assert all(abs(a - b) <= 2e-6 * abs(a) for a, b in zip(l, out[0][0])), (l, out[0][0])     # (the object-loss VALUE is a sum of float atomics)
+        assert all(torch.equal(a, b) for a, b in zip(g, out[0][1]))
+        assert all(torch.equal(a, b) for a, b in zip(p, out[0][2]))

@@ -10,6 +10,7 @@ preparation and the loss sum as native launches -- no framework kernel in a stea
 reference's loss API (utils/loss_functions.py), which YOLOPointv52 / two-graph mode use.  Adam: optim.FlatAdam (one launch) or
 torch.optim.Adam (train.py:88).  Data: SURVEY.md 8(d) synthetic recipe, generated on the device.
 """
+import collections
 import contextlib
 import ctypes as C
 import os
@@ -110,6 +111,7 @@ class TrainStep:
         self.scheduler = torch.optim.lr_scheduler.LambdaLR(self.opt, lr_lambda=lr_lambda) if lr_lambda is not None else None
         self.sparse = dict(SPARSE)
         self.comm_events = None
+        self._in_flight, self._max_in_flight = collections.deque(), int(os.environ.get("YP_STEPS_IN_FLIGHT", "2"))
         self.side_stream = torch.cuda.Stream(device=device) if os.environ.get("YP_TRAIN_SIDE_STREAM", "1") == "1" and torch.device(device).type == "cuda" else None
         self.reducer.broadcast_parameters(model)
 
@@ -156,6 +158,15 @@ class TrainStep:
         if self.max_grad_norm:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=self.max_grad_norm)
         self.opt.step()
+        # Nothing in the step makes the host wait for the device any more, so a loop that never reads a loss value would queue steps without
+        # bound (and hold every step's side-stream buffers until the device catches up).  Back-pressure: at most YP_STEPS_IN_FLIGHT
+        # optimizer steps are queued (default 2: the host stays a full step ahead, which is all the overlap there is to have).
+        if self._max_in_flight > 0 and torch.device(self.device).type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record()
+            self._in_flight.append(ev)
+            if len(self._in_flight) > self._max_in_flight:
+                self._in_flight.popleft().synchronize()
         return total
 
     # ------------------------------------------------------------------------------------------------------------------------------
