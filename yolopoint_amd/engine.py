@@ -251,9 +251,8 @@ class TrainStep:
         # plan's Detect seeds; its upstream factor lambda_obj * scale is applied by the plan's first op (TrainGraph.head_scale)
         want = float(f32(f32(scale) * f32(LAMBDA_OBJ))) if scale != 1.0 else float(f32(LAMBDA_OBJ))
         g.set_head_scale(want)
-        # The object loss and the detector loss read other heads than InfoNCE and write other seeds: with a side stream they run beside the
-        # InfoNCE gathers (a dozen small launches, ~150 us at -s) and join in front of the loss sum.
-        def small_losses():
+        # The object loss and the detector loss read other heads than InfoNCE and write other seeds (YP_LOSS_LANES below).
+        def object_loss():
             check(lib.yp_fill_zero(scal, 16, sp()))
             ol, hyp = self.obj_loss, self.obj_loss.hyp
             cap = tgt["cap"] if tgt["nt"] else 0
@@ -268,8 +267,9 @@ class TrainStep:
                                                tgt["count"].data_ptr() + 4 * i, float(ol.cp), float(ol.cn), float(hyp['cls_pw']), float(hyp['obj_pw']),
                                                float(hyp['box']), float(hyp['obj']) * float(ol.balance[i]), float(hyp['cls']), iou.data_ptr(), own.data_ptr(),
                                                g.g_xs[i].data_ptr(), scal, sp()))
-            # ---- detector loss of both passes (utils/loss_functions.py:600-619 on labels2Dto3D / getMasks of the 2-D maps): final gradients
-            # into the semi seed
+        # ---- detector loss of both passes (utils/loss_functions.py:600-619 on labels2Dto3D / getMasks of the 2-D maps): final gradients
+        # into the semi seed
+        def detector_losses():
             for j, key in enumerate(('labels_2D', 'warped_labels')):
                 check(lib.yp_detloss2d(stg.semi_ptr + 4 * j * B * stg.zs[0], stg.zs, batch[key].data_ptr(), stg.mask[j].data_ptr(), scal + 4 * (6 + j), float(f32(scale)),
                                        B, H, W, stg.dsemi_ptr + 4 * j * B * stg.ds[0], stg.ds, scal + 4 * (4 + j), stg.ws_main.data_ptr(), stg.ws_bytes, sp()))
@@ -317,21 +317,24 @@ class TrainStep:
             # The whole InfoNCE chain (latency-bound gathers, 0.8 ms at -s / 2.5 ms at -l) on the side stream, beside the YOLO-branch backward
             # plan, which only needs the Detect seeds of the object loss; the trunk plan waits for it.
             fwd_done = main.record_event()
-            small_losses()
-            small_done = main.record_event()
+            object_loss()                           # (the only loss the YOLO-branch plan waits for)
+            obj_done = main.record_event()
             side.wait_event(fwd_done)
             with torch.cuda.stream(side):
-                out4 = infonce_chain(side, small_done)
+                detector_losses()
+                out4 = infonce_chain(side, obj_done)
                 out4.record_stream(main)
             nce_done = side.record_event()
             join = lambda: main.wait_event(nce_done)
         elif lanes == 1:
             side.wait_event(main.record_event())
             with torch.cuda.stream(side):
-                small_losses()
+                object_loss()
+                detector_losses()
             out4 = infonce_chain(main, side.record_event())
         else:
-            small_losses()
+            object_loss()
+            detector_losses()
             out4 = infonce_chain(main, None)
         # ---- backward: YOLO-branch plan -> its buckets go out (the InfoNCE lane joins) -> trunk plan over both passes
         self.reducer.begin()
