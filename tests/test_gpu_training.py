@@ -1,6 +1,7 @@
 """GPU parity of the training path: train-mode forward (batch-statistics BN, running-stat update) against the
 golden outputs of the reference, and the full backward (every parameter gradient) against PyTorch-CPU autograd
 through the oracle.  fp32 compute path: forward 1e-3 of max|ref|; gradients 2e-3 relative L2 per tensor."""
+import math
 import os
 
 import numpy as np
@@ -817,3 +818,28 @@ def test_loss_stage_lanes_and_the_bound_on_queued_steps(cuda, monkeypatch):
         assert all(abs(a - b) <= 2e-6 * abs(a) for a, b in zip(l, out[0][0])), (l, out[0][0])     # (the object-loss VALUE is a sum of float atomics)
         assert all(torch.equal(a, b) for a, b in zip(g, out[0][1]))
         assert all(torch.equal(a, b) for a, b in zip(p, out[0][2]))
+
+
+def test_image_without_valid_cells_under_the_warp(cuda, monkeypatch):
+    """An image whose warped valid mask is empty leaves the InfoNCE pool empty (the reference's descriptor_loss_sparse would average over
+    nothing: NaN).  The synchronising prepare form refuses loudly; the device-count form the training step uses cannot raise without a
+    read-back, so the descriptor term is exactly zero for that step (no rows, zero descriptor-seed gradient) and everything stays finite."""
+    from yolopoint_amd import _hip
+    from yolopoint_amd.engine import TrainStep, synthetic_batch
+    batch = synthetic_batch(2, 128, cuda, 3)
+    batch['warped_valid_mask'][1] = 0.0
+    for sync in ("1", "0"):
+        monkeypatch.setenv("YP_PREPARE_SYNC", sync)
+        m, _ = make_model("n", 5, dtype="bf16")
+        m = m.to(cuda).train()
+        step = TrainStep(m, cuda, img_size=128)
+        step.sparse = dict(num_samples_per_image=100, num_masked_non_matches_per_match=30)
+        if sync == "1":
+            with pytest.raises(_hip.YpError, match="no valid cell"):
+                step(batch)
+            continue
+        loss = float(step(batch))
+        total, det, desc, obj = step.last_loss_terms.tolist()
+        assert desc == 0.0 and math.isfinite(loss) and det > 0.0 and obj > 0.0
+        assert all(bool(torch.isfinite(p.grad).all()) for p in m.parameters() if p.grad is not None)
+        assert all(bool(torch.isfinite(p).all()) for p in m.parameters())

@@ -518,7 +518,9 @@ def infonce_prepare(mask_valid_warp, inv_homographies, desc_shape, on_device, nu
     """The label-only half of `infonce`: which cells are matched (normalised sample coordinates ua, ub [B, pool, 2]) and
     which matches serve as negatives (rnd [n, negs]).  With `sync` the common pool size is read back (one host synchronisation) and the
     arrays are trimmed to it; `sync=False` (cuda, native sampling) keeps capacity-sized arrays with the counts in device memory (a dict,
-    see `_prepare_native`), which is what the training step uses."""
+    see `_prepare_native`), which is what the training step uses.  An image without a valid cell empties the pool: the
+    synchronising form raises; the device-count form cannot (no read-back) and yields a step without a descriptor term (zero rows, zero
+    gradient) -- the reference would average over nothing there (NaN)."""
     assert desc_shape[-1] * desc_shape[-2] >= num_samples_per_image, \
         "Number of samples per image must be greater than number of pixels in image"
     with torch.no_grad():
