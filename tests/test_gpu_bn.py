@@ -115,3 +115,35 @@ def test_bn_statistics_groups(cuda, C, B, H, W, act, with_res, groups):
     assert torch.allclose(rvar, rv_ref, rtol=1e-4)
     assert torch.allclose(dgamma, g_.grad, rtol=2e-3, atol=2e-4 * float(g_.grad.abs().max()))
     assert torch.allclose(dbeta, b_.grad, rtol=2e-3, atol=2e-4 * float(b_.grad.abs().max()))
+
+
+@pytest.mark.parametrize("C,B,H,W,acc", [(64, 2, 20, 20, 0), (256, 3, 10, 12, 1), (8, 1, 7, 5, 1), (24, 2, 6, 6, 0)])
+def test_maxpool5_backward_vector_and_scalar_paths(cuda, C, B, H, W, acc):
+    """Gradient of MaxPool2d(5, 1, 2) (SPPF, reference models/common.py:200-214) on bf16 NHWC views: against torch's CPU backward on the
+    same rounded tensors (first maximum of the row-major window scan takes the gradient -- bf16 maps hold ties), and the 8-channels-per-
+    thread kernels against the one-element-per-thread kernels (a view that starts 2 bytes off a 16-byte boundary takes those): bit for bit."""
+    torch.manual_seed(C + H)
+    l, st = lib(), _hip.stream_ptr()
+    code = _hip.YP_BF16
+    nb = l.yp_maxpool5_bwd_workspace_bytes(B, H, W, C)
+    x = torch.randn(B, H, W, C + 8, device=cuda).to(torch.bfloat16)
+    dy = torch.randn(B, H, W, C, device=cuda).to(torch.bfloat16)
+    dx0 = torch.randn(B, H, W, C, device=cuda).to(torch.bfloat16)
+    outs = []
+    for shift in (0, 1):                 # 1: every tensor lives one element into its allocation -> unaligned -> scalar kernels
+        def place(t):
+            flat = torch.zeros(t.numel() + 16, dtype=t.dtype, device=cuda)
+            flat[shift:shift + t.numel()] = t.reshape(-1)
+            return flat, flat[shift:shift + t.numel()].view(t.shape)
+        (kx, xs), (kd, ds), (kg, gs) = place(x), place(dy), place(dx0)
+        ws = torch.empty(nb + 16, dtype=torch.uint8, device=cuda)
+        check(l.yp_maxpool5_bwd(view(xs, 8, C), view(ds, 0, C), view(gs, 0, C), code, B, acc, ws.data_ptr(), nb, st))
+        torch.cuda.synchronize()
+        outs.append(gs.clone())
+    assert torch.equal(outs[0], outs[1])
+    xr = x[..., 8:].float().permute(0, 3, 1, 2).cpu().contiguous().requires_grad_()
+    y = torch.nn.functional.max_pool2d(xr, 5, 1, 2)
+    y.backward(dy.float().permute(0, 3, 1, 2).cpu())
+    want = xr.grad.permute(0, 2, 3, 1) + (dx0.float().cpu() if acc else 0.0)
+    got = outs[0].float().cpu()
+    assert float((got - want).abs().max()) <= 2 ** -7 * float(want.abs().max())      # (one bf16 rounding of the sum)
