@@ -391,9 +391,12 @@ int yp_infonce_fwd(const float* da, const float* db, const int* idx, int n, int 
  * log-sum-exp; `logits` receives the softmax weights w[i][j] = exp(l_ij - lse_i) - [j == 0], not the logits.  yp_infonce_bwd_db then gives
  * ddb (already scaled by *grad_scale_dev) from those weights. */
 int yp_infonce_fwd_grad(const float* da, const float* db, const int* idx, int n, int E, int D, float inv_tau, float* logits, float* loss_rows, float* lse,
-                       float* dda_unscaled, const int* n_dev, void* stream);
+                       float* dda_unscaled, const int* n_dev, int max_workgroups, void* stream);
 int yp_infonce_bwd_db(const float* da, const int* order, const int* offsets, const float* logits, const float* lse, int n, int E, int D,
-                      const float* grad_scale_dev, float* ddb, const int* n_dev, void* stream);
+                      const float* grad_scale_dev, float* ddb, const int* n_dev, int max_workgroups, void* stream);
+/* max_workgroups (both): 0 = one workgroup per four rows.  > 0 caps the grid, the workgroups then walk the rows -- for a caller that runs
+ * these gathers on one stream beside other kernels on another (they are latency-bound and would otherwise take every CU slot): the training
+ * step passes 768 (3 per CU), which is worth 4 % of the step at -s; 256 starves the gathers themselves. */
 int yp_infonce_bwd(const float* da, const float* db, const int* idx, const int* order, const int* offsets, const float* logits, int n, int E, int D,
                    const float* grad_scale_dev, float* w_scratch, float* dda, float* ddb, void* stream);
 

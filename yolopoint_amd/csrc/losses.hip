@@ -93,9 +93,8 @@ __global__ __launch_bounds__(256) void infonce_fwd_grad_kernel(const float* __re
                                                                int D, float inv_tau, float* __restrict__ logits, float* __restrict__ loss,
                                                                float* __restrict__ lse, float* __restrict__ dda_u, const int* __restrict__ n_dev) {
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n_dev != nullptr) { n = n_dev[0]; db = da + (size_t)n * D; }     // (device-side count: the matched rows are [0, n) of a capacity-sized array)
-    if (i >= n) return;
+    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += gridDim.x * 4) {      // (a capped grid walks the rows: yp_infonce_set_grid_cap)
     const Row<VPL> a = load_row<VPL>(da, i, D, lane);
     const int* row = idx + (size_t)i * E;
     float* lrow = logits + (size_t)i * E;
@@ -161,6 +160,7 @@ __global__ __launch_bounds__(256) void infonce_fwd_grad_kernel(const float* __re
     float* o = dda_u + (size_t)i * D + lane * VPL;
 #pragma unroll
     for (int k = 0; k < VPL; ++k) o[k] = acc[k] * inv_s - b0[k];
+    }
 }
 
 // ddb[k] = scale * sum over the edges (i, j) with idx[i][j] == k of w[i][j] * da[i]; edges sorted by k
@@ -169,9 +169,8 @@ __global__ __launch_bounds__(256) void infonce_bwd_b2_kernel(const float* __rest
                                                              const int* __restrict__ order, const int* __restrict__ offsets, int n, int E, int D,
                                                              const float* __restrict__ gscale, float* __restrict__ ddb, const int* __restrict__ n_dev) {
     const int lane = threadIdx.x & 63;
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n_dev != nullptr) { n = n_dev[0]; ddb += (size_t)n * D; }         // (ddb = the second half of a [2n][D] gradient whose base was passed)
-    if (k >= n) return;
+    for (int k = blockIdx.x * 4 + (threadIdx.x >> 6); k < n; k += gridDim.x * 4) {
     const int e0 = offsets[k], e1 = offsets[k + 1];
     const float scale = gscale[0];
     float acc[VPL];
@@ -196,6 +195,7 @@ __global__ __launch_bounds__(256) void infonce_bwd_b2_kernel(const float* __rest
     float* o = ddb + (size_t)k * D + lane * VPL;
 #pragma unroll
     for (int q = 0; q < VPL; ++q) o[q] = acc[q] * scale;
+    }
 }
 
 // w[i][j] = (softmax_j - [j == 0]) * scale  and  dda[i] = sum_j w[i][j] * db[idx[i][j]]
@@ -782,20 +782,27 @@ extern "C" int yp_infonce_fwd(const float* da, const float* db, const int* idx, 
     return YP_OK;
 }
 
+// Workgroups of the two gather kernels: one wave per row, four rows per workgroup; max_workgroups > 0 caps the grid (the workgroups then
+// walk the rows), which leaves CU slots to kernels of another stream (engine.TrainStep runs this chain beside a backward plan).
+static int nce_grid(int n, int cap) {
+    const int g = (n + 3) / 4;
+    return cap > 0 && g > cap ? cap : g;
+}
+
 extern "C" int yp_infonce_fwd_grad(const float* da, const float* db, const int* idx, int n, int E, int D, float inv_tau, float* logits, float* loss_rows,
-                                   float* lse, float* dda_unscaled, const int* n_dev, void* stream) {
+                                   float* lse, float* dda_unscaled, const int* n_dev, int max_workgroups, void* stream) {
     YP_REQUIRE(da && (db || n_dev) && idx && logits && loss_rows && lse && dda_unscaled && n > 0 && E > 0 && E <= 512 && D > 0 && D % 64 == 0,
                "yp_infonce_fwd_grad: bad arguments (E <= 512, D %% 64 == 0)");
-    const int grid = (n + 3) / 4;
+    const int grid = nce_grid(n, max_workgroups);
     YP_VPL_SWITCH(D, (infonce_fwd_grad_kernel<VPL><<<grid, 256, 0, (hipStream_t)stream>>>(da, db, idx, n, E, D, inv_tau, logits, loss_rows, lse, dda_unscaled, n_dev)));
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
 }
 
 extern "C" int yp_infonce_bwd_db(const float* da, const int* order, const int* offsets, const float* logits, const float* lse, int n, int E, int D,
-                                 const float* grad_scale_dev, float* ddb, const int* n_dev, void* stream) {
+                                 const float* grad_scale_dev, float* ddb, const int* n_dev, int max_workgroups, void* stream) {
     YP_REQUIRE(da && order && offsets && logits && lse && grad_scale_dev && ddb && n > 0 && E > 0 && D > 0 && D % 64 == 0, "yp_infonce_bwd_db: bad arguments");
-    const int grid = (n + 3) / 4;
+    const int grid = nce_grid(n, max_workgroups);
     YP_VPL_SWITCH(D, (infonce_bwd_b2_kernel<VPL><<<grid, 256, 0, (hipStream_t)stream>>>(da, logits, lse, order, offsets, n, E, D, grad_scale_dev, ddb, n_dev)));
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;

@@ -280,6 +280,9 @@ class TrainStep:
         # ---- InfoNCE (utils/loss_functions.py:484-597): one lookup over both passes' descriptor maps, loss rows + anchor-side gradient in
         # one gather pass, the loss sum, the match-side gradient, the scatter into the descriptor seed
         def infonce_chain(stream, small_done):
+            # (beside the backward plan the gathers get 3 workgroups per CU: uncapped they take every slot and the plan's kernels queue behind
+            # them -- -s 7.85 -> 7.55 ms, -l 35.8 -> 35.4 at 768; 1024: 7.67, 512: 7.66, 256: 9.06)
+            nce_wgs = int(os.environ.get("YP_NCE_WGS", "768")) if lanes >= 2 else 0
             out4_ = torch.empty((4,), dtype=torch.float32, device=dev)
             if isinstance(nce, dict):
                 # counts on the device (infonce_prepare(sync=False)): arrays at their capacity, the kernels read points-per-image / matched rows
@@ -301,13 +304,13 @@ class TrainStep:
             rows, lse = torch.empty((n,), dtype=torch.float32, device=dev), torch.empty((n,), dtype=torch.float32, device=dev)
             check(lib.yp_points_sample_fwd(stg.desc_ptr, 2 * B, Hc, Wc, D, uab.data_ptr(), pool, dab.data_ptr(), p_dev, sp()))
             check(lib.yp_infonce_fwd_grad(dab.data_ptr(), None if n_dev else dab.data_ptr() + 4 * n * D, idx.data_ptr(), n, E, D, 1.0 / tau, w.data_ptr(),
-                                          rows.data_ptr(), lse.data_ptr(), grad.data_ptr(), n_dev, sp()))
+                                          rows.data_ptr(), lse.data_ptr(), grad.data_ptr(), n_dev, nce_wgs, sp()))
             if small_done is not None:
                 stream.wait_event(small_done)
             check(lib.yp_loss_combine(scal + 16, 2, rows.data_ptr(), n, scal, LAMBDA_DESC, LAMBDA_OBJ, float(scale), desc_scale, out4_.data_ptr(), scal + 48, n_dev,
                                       float(g_desc), tau, sp()))
             check(lib.yp_infonce_bwd_db(dab.data_ptr(), order.data_ptr(), offsets.data_ptr(), w.data_ptr(), lse.data_ptr(), n, E, D, scal + 48,
-                                        grad.data_ptr() if n_dev else grad.data_ptr() + 4 * n * D, n_dev, sp()))
+                                        grad.data_ptr() if n_dev else grad.data_ptr() + 4 * n * D, n_dev, nce_wgs, sp()))
             check(lib.yp_points_sample_bwd_sorted(grad.data_ptr(), 2 * B, Hc, Wc, D, uab.data_ptr(), pool, s_order.data_ptr(), s_offsets.data_ptr(), scal + 48, n,
                                                   stg.gdesc_ptr, n_dev, sp()))
             return out4_

@@ -280,7 +280,7 @@ class _InfoNCENative(torch.autograd.Function):
             lse = torch.empty((n,), dtype=torch.float32, device=da.device)
             dda_u = torch.empty_like(da)
             _hip.check(_hip.lib().yp_infonce_fwd_grad(da.data_ptr(), db.data_ptr(), idx.data_ptr(), n, E, D, 1.0 / tau, logits.data_ptr(), rows.data_ptr(),
-                                                      lse.data_ptr(), dda_u.data_ptr(), None, _hip.stream_ptr()))
+                                                      lse.data_ptr(), dda_u.data_ptr(), None, 0, _hip.stream_ptr()))
             ctx.save_for_backward(da, order, offsets, logits, lse, dda_u)
             ctx.fused = True
         else:
@@ -301,7 +301,7 @@ class _InfoNCENative(torch.autograd.Function):
         scale = (g.float() * (1.0 / (ctx.tau * n))).reshape(1)
         ddb = torch.empty_like(da)
         _hip.check(_hip.lib().yp_infonce_bwd_db(da.data_ptr(), order.data_ptr(), offsets.data_ptr(), logits.data_ptr(), lse.data_ptr(), n, E, D,
-                                                scale.data_ptr(), ddb.data_ptr(), None, _hip.stream_ptr()))
+                                                scale.data_ptr(), ddb.data_ptr(), None, 0, _hip.stream_ptr()))
         return dda_u * scale, ddb, None, None, None, None
 
 
@@ -322,7 +322,7 @@ class _InfoNCEPairNative(torch.autograd.Function):
         grad = torch.empty_like(dab)                    # [dda (unscaled until the backward) | ddb]
         pa, pb = dab.data_ptr(), dab.data_ptr() + 4 * n * D
         _hip.check(_hip.lib().yp_infonce_fwd_grad(pa, pb, idx.data_ptr(), n, E, D, 1.0 / tau, w.data_ptr(), rows.data_ptr(), lse.data_ptr(), grad.data_ptr(),
-                                                  None, _hip.stream_ptr()))
+                                                  None, 0, _hip.stream_ptr()))
         ctx.save_for_backward(dab, order, offsets, w, lse, grad)
         ctx.tau = tau
         return rows.mean()
@@ -339,7 +339,7 @@ class _InfoNCEPairNative(torch.autograd.Function):
         # unscaled anchor half again and must not overwrite a tensor that was already handed out)
         out = torch.empty_like(grad)
         _hip.check(_hip.lib().yp_infonce_bwd_db(dab.data_ptr(), order.data_ptr(), offsets.data_ptr(), w.data_ptr(), lse.data_ptr(), n, E, D,
-                                                scale.data_ptr(), out.data_ptr() + 4 * n * D, None, _hip.stream_ptr()))
+                                                scale.data_ptr(), out.data_ptr() + 4 * n * D, None, 0, _hip.stream_ptr()))
         torch.mul(grad[:n], scale, out=out[:n])
         return out, None, None, None, None
 
