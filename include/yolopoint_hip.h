@@ -466,6 +466,10 @@ int yp_cell_mask(const float* valid2d, int B, int H, int W, float* mask, float* 
 int yp_detloss2d(const float* semi, const int64_t* semi_strides, const float* labels2d, const float* mask, const float* mask_sum, float gscale, int B, int H,
                  int W, float* dsemi, const int64_t* dsemi_strides, float* loss, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Process-wide tuning knob: caps the grids of the large launches of yp_nce_cells / yp_csr_build (their workgroups then walk the items).
+ * 0 (default) = no cap.  engine.TrainStep sets it: its label work runs on a side stream beside the forward pass, where thousands of tiny
+ * workgroups would take the CU slots the convolutions wait for.  Results do not depend on it. */
+int yp_sampling_set_max_workgroups(int n);
 /* The label-only half of the InfoNCE loss (reference utils/loss_functions.py:484-552: warp the validity mask back, keep the cells whose
  * 64 pixels are all valid, map the cell grid through the inverse homography, shuffle, draw the negatives) as device kernels around a
  * counter-based generator (Philox 4x32-10 keyed by `seed`) -- csrc/sampling.hip:

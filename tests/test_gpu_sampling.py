@@ -214,3 +214,21 @@ def test_prepare_without_host_synchronisation_equals_the_synchronising_form(cuda
     assert torch.equal(d["offsets"][:n + 1], offsets) and bool((d["offsets"][n:] == n * E).all())
     assert torch.equal(d["order"][:n * E], order)
     assert torch.equal(d["s_offsets"], s_offsets) and torch.equal(d["s_order"][:int(s_offsets[-1])], s_order[:int(s_offsets[-1])])
+
+
+@pytest.fixture
+def capped_grids():
+    """yp_sampling_set_max_workgroups(3): the large launches run as 3 workgroups that walk their items (what a training step does with 256,
+    so that label work beside the forward leaves the CU slots to the convolutions)."""
+    from yolopoint_amd import _hip
+    _hip.check(_hip.lib().yp_sampling_set_max_workgroups(3))
+    yield
+    _hip.check(_hip.lib().yp_sampling_set_max_workgroups(0))
+
+
+def test_capped_grids_give_the_same_results(cuda, capped_grids):
+    for args in [(100000, 500, True), (60000, 48000, False), (9000, 3, True)]:
+        test_counting_sort_into_csr(cuda, *args)
+    test_cell_validity_and_matches(cuda, 2, 256, 256, "general")
+    test_prepare_without_host_synchronisation_equals_the_synchronising_form(cuda, True)
+    test_prepare_is_reproducible_and_feeds_the_loss(cuda)

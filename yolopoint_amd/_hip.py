@@ -112,6 +112,7 @@ SIGNATURES = {
     "yp_pack_weight_batch": (_i, [_p, _i, _i, _i, _p]),
     "yp_wgrad_unpack_batch": (_i, [_p, _i, _i, _p]),
     "yp_infonce_fwd": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _p, _p]),
+    "yp_sampling_set_max_workgroups": (_i, [_i]),
     "yp_infonce_fwd_grad": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p, _i, _p]),
     "yp_infonce_bwd_db": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _i, _p]),
     "yp_infonce_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p]),

@@ -41,8 +41,7 @@ __global__ __launch_bounds__(256) void nce_cells_kernel(const float* __restrict_
                                                         unsigned char* __restrict__ valid, float* __restrict__ uvb) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int Hc = H >> 3, Wc = W >> 3;
-    const long cell = (long)blockIdx.x * 4 + wave;
-    if (cell >= (long)B * Hc * Wc) return;
+    for (long cell = (long)blockIdx.x * 4 + wave; cell < (long)B * Hc * Wc; cell += (long)gridDim.x * 4) {
     const int b = (int)(cell / (Hc * Wc)), rem = (int)(cell - (long)b * Hc * Wc), cy = rem / Wc, cx = rem - cy * Wc;
     const float* h = inv_h + 9 * b;
     const int y = cy * 8 + (lane >> 3), x = cx * 8 + (lane & 7);
@@ -66,6 +65,7 @@ __global__ __launch_bounds__(256) void nce_cells_kernel(const float* __restrict_
         const float a2 = M[2][0] * px + M[2][1] * py + M[2][2];
         uvb[2 * cell] = nearbyintf(a0 / a2);
         uvb[2 * cell + 1] = nearbyintf(a1 / a2);
+    }
     }
 }
 
@@ -212,10 +212,10 @@ __global__ __launch_bounds__(256) void csr_zero_kernel(int* __restrict__ p, int 
 
 // one atomic per item: its arrival rank inside its bucket (the bucket sizes are what the counters end at)
 __global__ __launch_bounds__(256) void csr_rank_kernel(const int* __restrict__ keys, int n_items, int n_buckets, int* __restrict__ count, int* __restrict__ rank) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_items) return;
-    const int k = keys[i];
-    if (k >= 0 && k < n_buckets) rank[i] = atomicAdd(&count[k], 1);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_items; i += gridDim.x * 256) {
+        const int k = keys[i];
+        if (k >= 0 && k < n_buckets) rank[i] = atomicAdd(&count[k], 1);
+    }
 }
 
 // exclusive scan of the bucket sizes in three steps: sums of 4096-bucket chunks, scan of the chunk sums (one workgroup), scan inside the chunks
@@ -279,10 +279,10 @@ __global__ __launch_bounds__(256) void csr_offsets_kernel(const int* __restrict_
 
 __global__ __launch_bounds__(256) void csr_scatter_kernel(const int* __restrict__ keys, const int* __restrict__ rank, int n_items, int n_buckets,
                                                           const int* __restrict__ offsets, int* __restrict__ order) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_items) return;
-    const int k = keys[i];
-    if (k >= 0 && k < n_buckets) order[offsets[k] + rank[i]] = i;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_items; i += gridDim.x * 256) {
+        const int k = keys[i];
+        if (k >= 0 && k < n_buckets) order[offsets[k] + rank[i]] = i;
+    }
 }
 
 // every bucket into ascending item order.  WAVE: one wavefront per bucket (rank sort through LDS; buckets of ~E entries), else one thread
@@ -293,10 +293,9 @@ __global__ __launch_bounds__(256) void csr_sort_kernel(const int* __restrict__ o
     __shared__ int stage[WAVE ? 4 * CAP : 1];
     if constexpr (WAVE) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int bk = blockIdx.x * 4 + wave;
-        if (bk >= n_buckets) return;
+        for (int bk = blockIdx.x * 4 + wave; bk < n_buckets; bk += gridDim.x * 4) {
         const int e0 = offsets[bk], k = offsets[bk + 1] - e0;
-        if (k <= 1) return;
+        if (k <= 1) continue;
         if (k <= CAP) {
             int* st = stage + wave * CAP;
             for (int i = lane; i < k; i += 64) st[i] = order[e0 + i];
@@ -308,14 +307,16 @@ __global__ __launch_bounds__(256) void csr_sort_kernel(const int* __restrict__ o
                 for (int j = 0; j < k; ++j) rank += st[j] < a ? 1 : 0;
                 order[e0 + rank] = a;                      // (item ids are distinct: ranks are a permutation)
             }
-            return;
+            __builtin_amdgcn_wave_barrier();               // (the next bucket of this wave overwrites its LDS stage)
+            continue;
         }
-        if (lane != 0) return;
+        if (lane != 0) continue;
         for (int i = 1; i < k; ++i) {                      // (oversized bucket: correct, slow, not expected)
             const int a = order[e0 + i];
             int j = i - 1;
             while (j >= 0 && order[e0 + j] > a) { order[e0 + j + 1] = order[e0 + j]; --j; }
             order[e0 + j + 1] = a;
+        }
         }
     } else {
         const int bk = blockIdx.x * 256 + threadIdx.x;
@@ -332,10 +333,20 @@ __global__ __launch_bounds__(256) void csr_sort_kernel(const int* __restrict__ o
 
 }  // namespace
 
+// Grid cap of the large launches in this file (yp_sampling_set_max_workgroups; 0 = none): the label work of a training step runs on a side
+// stream beside the forward pass, and thousands of tiny workgroups would take the CU slots the convolutions wait for.
+static int g_max_wgs = 0;
+static unsigned capped(size_t want) { return (unsigned)(g_max_wgs > 0 && want > (size_t)g_max_wgs ? (size_t)g_max_wgs : want); }
+extern "C" int yp_sampling_set_max_workgroups(int n) {
+    YP_REQUIRE(n >= 0, "yp_sampling_set_max_workgroups: n >= 0");
+    g_max_wgs = n;
+    return YP_OK;
+}
+
 extern "C" int yp_nce_cells(const float* mask, const float* inv_h, int B, int H, int W, unsigned char* valid, float* uvb, void* stream) {
     YP_REQUIRE(mask && inv_h && valid && uvb && B > 0 && H >= 16 && W >= 16 && H % 8 == 0 && W % 8 == 0, "yp_nce_cells: bad arguments (H, W multiples of 8)");
     const long cells = (long)B * (H / 8) * (W / 8);
-    nce_cells_kernel<<<(unsigned)((cells + 3) / 4), 256, 0, (hipStream_t)stream>>>(mask, inv_h, B, H, W, valid, uvb);
+    nce_cells_kernel<<<capped((size_t)(cells + 3) / 4), 256, 0, (hipStream_t)stream>>>(mask, inv_h, B, H, W, valid, uvb);
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
 }
@@ -375,12 +386,12 @@ extern "C" int yp_csr_build(const int* keys, int n_items, int n_buckets, int wid
     int* rank = chunk + n_chunks;              // [n_items]
     const int zb = (n_buckets + 255) / 256;
     csr_zero_kernel<<<zb < 1024 ? zb : 1024, 256, 0, st>>>(count, n_buckets);
-    csr_rank_kernel<<<(n_items + 255) / 256, 256, 0, st>>>(keys, n_items, n_buckets, count, rank);
+    csr_rank_kernel<<<capped((size_t)(n_items + 255) / 256), 256, 0, st>>>(keys, n_items, n_buckets, count, rank);
     csr_chunk_sum_kernel<<<n_chunks, 256, 0, st>>>(count, n_buckets, chunk);
     csr_chunk_scan_kernel<<<1, 1024, 0, st>>>(chunk, n_chunks, offsets + n_buckets);
     csr_offsets_kernel<<<n_chunks, 256, 0, st>>>(count, chunk, n_buckets, offsets);
-    csr_scatter_kernel<<<(n_items + 255) / 256, 256, 0, st>>>(keys, rank, n_items, n_buckets, offsets, order);
-    if (wide_buckets) csr_sort_kernel<true><<<(n_buckets + 3) / 4, 256, 0, st>>>(offsets, n_buckets, order);
+    csr_scatter_kernel<<<capped((size_t)(n_items + 255) / 256), 256, 0, st>>>(keys, rank, n_items, n_buckets, offsets, order);
+    if (wide_buckets) csr_sort_kernel<true><<<capped((size_t)(n_buckets + 3) / 4), 256, 0, st>>>(offsets, n_buckets, order);
     else csr_sort_kernel<false><<<(n_buckets + 255) / 256, 256, 0, st>>>(offsets, n_buckets, order);
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;

@@ -111,6 +111,9 @@ class TrainStep:
         self.scheduler = torch.optim.lr_scheduler.LambdaLR(self.opt, lr_lambda=lr_lambda) if lr_lambda is not None else None
         self.sparse = dict(SPARSE)
         self.comm_events = None
+        if torch.device(device).type == "cuda" and os.environ.get("YP_TRAIN_SIDE_STREAM", "1") == "1":
+            from . import _hip
+            _hip.check(_hip.lib().yp_sampling_set_max_workgroups(int(os.environ.get("YP_SIDE_WGS", "256"))))
         self._in_flight, self._max_in_flight = collections.deque(), int(os.environ.get("YP_STEPS_IN_FLIGHT", "2"))
         self.side_stream = torch.cuda.Stream(device=device) if os.environ.get("YP_TRAIN_SIDE_STREAM", "1") == "1" and torch.device(device).type == "cuda" else None
         self.reducer.broadcast_parameters(model)
