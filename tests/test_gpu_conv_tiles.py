@@ -1,5 +1,6 @@
 """Every tile / main-loop variant of the generic implicit-GEMM convolution kernel (ids 1-5: first-generation loop, 21-27: several k
-tiles per barrier + register double-buffered fragments, 31 / 33: waves split k) on the layer shapes that exercise its corner cases:
+tiles per barrier + register double-buffered fragments, 31 / 33: waves split k; 71-73: the wave-private split-K kernels of
+csrc/conv_wsk.hip) on the layer shapes that exercise its corner cases:
 ragged M and N tails, N = 65 with fp32 output (the keypoint head), K that is not a multiple of the stage depth, two channel-
 concatenated sources (one read through a 2x upsample), residual add, split destinations, stride 2, and the Detect decode epilogue.
 The plan-time autotuner picks among these per layer, so each must be right on its own.  Reference: torch conv2d on the CPU in fp32
@@ -13,7 +14,7 @@ from yolopoint_amd import _hip
 from yolopoint_amd.plan import PlanBuilder
 
 pytestmark = pytest.mark.gpu
-TILES = (1, 2, 3, 4, 5, 21, 22, 23, 24, 25, 26, 27, 31, 33)
+TILES = (1, 2, 3, 4, 5, 21, 22, 23, 24, 25, 26, 27, 31, 33, 71, 72, 73, 74, 75, 76)
 
 # name: Cin (or (C0, C1) for two sources), Cout, k, stride, Hout, batch, extras
 CASES = {
@@ -26,6 +27,11 @@ CASES = {
     "conv3x3_residual": dict(cin=64, cout=64, k=3, s=1, H=20, B=2, res=True),
     "conv3x3_stride2_deep": dict(cin=256, cout=512, k=3, s=2, H=10, B=2),
     "conv3x3_k288": dict(cin=32, cout=64, k=3, s=2, H=24, B=1),
+    # the wave-private split-K tiles (71-73): fewer k tiles than waves, many tiles per wave across filter taps and sources, ragged tails
+    "pointwise_k64_two_tiles": dict(cin=64, cout=96, k=1, s=1, H=11, B=3),
+    "conv3x3_deep_256": dict(cin=256, cout=256, k=3, s=1, H=20, B=2),
+    "conv3x3_concat_stride2": dict(cin=(64, 96), cout=72, k=3, s=2, H=7, B=3),
+    "pointwise_1024_512": dict(cin=1024, cout=512, k=1, s=1, H=10, B=2),
 }
 
 
@@ -91,4 +97,4 @@ def test_every_tile_variant(cuda, name):
         bar = 2e-5 if out_f32 else 2e-3
         assert err < bar, (name, tile, err)
         ran.append(tile)
-    assert {1, 4, 24, 31} <= set(ran), ran             # both generations and the waves-split-k loop were exercised
+    assert {1, 4, 24, 31, 71, 72, 73} <= set(ran), ran # both generations, the waves-split-k loop and the wave-private split-K kernels were exercised

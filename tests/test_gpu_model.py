@@ -104,9 +104,10 @@ def test_cpu_tensor_raises():
         m(torch.zeros(1, 3, 64, 64))
 
 
-def test_multistream_graph_equals_eager(cuda):
-    """The hipGraph replay (branches captured on forked streams) must reproduce the eager, single-stream
-    launch order bit for bit — the schedule only reorders independent launches."""
+def test_multistream_graph_equals_eager(cuda, monkeypatch):
+    """The one-lane hipGraph replay (YP_INFER_LANES=0: branches as graph edges) and the two-lane replay must reproduce the eager,
+    single-stream launch order bit for bit -- a schedule only reorders independent launches."""
+    monkeypatch.setenv("YP_INFER_LANES", "0")
     m, _ = make_model("s", 9, dtype="f16")
     m = m.to(cuda)
     x = net_oracle.synth_image(2, 3, 128, 128, 9).to(cuda)
@@ -116,9 +117,45 @@ def test_multistream_graph_equals_eager(cuda):
     c = m(x)      # replay
     plan = next(iter(m.model._plans.values()))[0]
     assert plan.graph and plan.parallel
+    monkeypatch.setenv("YP_INFER_LANES", "1")
+    m.model._plans.clear()
+    d = m(x)
+    plan = next(iter(m.model._plans.values()))[0]
+    assert plan.has_lanes and plan.parallel
     for k in ("semi", "desc"):
-        assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k
-    assert torch.equal(a["objects"][0], b["objects"][0]) and torch.equal(a["objects"][0], c["objects"][0])
+        assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]) and torch.equal(a[k], d[k]), k
+    assert torch.equal(a["objects"][0], b["objects"][0]) and torch.equal(a["objects"][0], c["objects"][0]) and torch.equal(a["objects"][0], d["objects"][0])
+
+
+@pytest.mark.parametrize("capture", [False, True])
+@pytest.mark.parametrize("model_name", ["YOLOPoint", "YOLOPointv52"])
+def test_two_lane_schedule_tracks_changing_inputs(cuda, monkeypatch, capture, model_name):
+    """The inference plan runs the keypoint / descriptor heads and two Detect levels on a side lane (PlanBuilder.side).  Every replay must
+    equal the one-lane result for ITS OWN input, bit for bit: with a static input a missing dependency hides behind the previous replay's
+    (identical) values -- which is how a captured graph whose main chain had lost an edge (every side op re-forking from the same node:
+    ROCm 7.2 then started the next main-lane kernel early) passed every fixed-input test while it was a third faster than legal.
+    capture=True: the lanes as a forked branch of a hipGraph (YP_LANES_EAGER=0); False: two plain streams (the default)."""
+    m, _ = make_model("s", 21, dtype="f16", model_name=model_name)
+    m = m.to(cuda)
+    m.fuse()
+    xs = [net_oracle.synth_image(4, 3, 256, 256, 300 + i).to(cuda) for i in range(3)]
+
+    def grab(o):
+        return [o["semi"].clone(), o["desc"].clone(), o["objects"][0].clone()] + [t.clone() for t in o["objects"][1]]
+    with torch.no_grad():
+        monkeypatch.setenv("YP_INFER_LANES", "0")
+        ref = [grab(m(x)) for x in xs]
+        monkeypatch.setenv("YP_INFER_LANES", "1")
+        monkeypatch.setenv("YP_LANES_EAGER", "0" if capture else "1")
+        m.model._plans.clear()
+        m.model.use_graph = True
+        for rnd in range(2):
+            for i, x in enumerate(xs):
+                got = grab(m(x))
+                plan = next(iter(m.model._plans.values()))[0]
+                assert plan.has_lanes and plan.graph == capture
+                for j, (g, r) in enumerate(zip(got, ref[i])):
+                    assert torch.equal(g, r), (rnd, i, j)
 
 
 @pytest.mark.parametrize("version,B,S,dtype", [("n", 2, 64, "f32"), ("s", 1, 128, "f32"), ("s", 1, 128, "f16")])

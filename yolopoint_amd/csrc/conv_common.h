@@ -105,6 +105,7 @@ struct ConvKArgs {
     int stats_rows;                // partials lie together: the fold that follows reads them as contiguous runs)
     const float* scale_in;         // 8-bit input types: the accumulators are multiplied by *scale_in * *scale_w (device scalars: the
     const float* scale_w;          // dequantisation scales of the activation and of the filter) before the epilogue
+    unsigned mg_howo, mg_wo;       // conv_wsk.hip: ceil(2^32 / HoWo), ceil(2^32 / Wo) when M * HoWo < 2^32 (exact magic division), else 0
     int probe;                     // -DYP_PROBE8 builds of conv_mma8.hip: elimination experiments (1 no MFMA, 2 no steady-state DMA, 4 L2-resident pixels)
 };
 
@@ -216,3 +217,7 @@ __device__ __forceinline__ void yp_glds16_s(const void* sbase, unsigned voff, un
 // 8-wave 32x32x16 kernels (conv_mma8.hip), tile ids 41..44
 bool yp_mma8_tile_dims(int tile, int* bp, int* bc, int* stat_rows_px);
 hipError_t yp_mma8_launch(int tile, int dtype, bool out_f32, bool stats, const ConvKArgs& a, int nblk, hipStream_t st);
+
+// wave-private split-K kernels for the short-M layers (conv_wsk.hip), tile ids 71..73
+bool yp_wsk_tile_dims(int tile, int* bm, int* bn);
+hipError_t yp_wsk_launch(int tile, int dtype, bool out_f32, const ConvKArgs& a, int nblk, hipStream_t st);

@@ -1686,6 +1686,24 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
             return YP_OK;
         }
     }
+    {   // wave-private split-K kernels (conv_wsk.hip), tile ids 71..73: short-M 16-bit fast-path layers
+        int bm = 0, bn = 0;
+        if (yp_wsk_tile_dims(d->tile, &bm, &bn)) {
+            YP_REQUIRE(fast && (d->dtype == YP_F16 || d->dtype == YP_BF16) && det == nullptr && d->pre_weight == nullptr && ksplit == 1 && !a.atomic_out &&
+                       d->bn_partial == nullptr && Kreal % 32 == 0,
+                       "yp_conv2d: tile %d (wave-private split-K kernel) needs a plain 16-bit fast-path convolution", d->tile);
+            a.tiles_n = yp_cdiv(Cout, bn);
+            const int nblkw = yp_cdiv(a.M, bm) * a.tiles_n;
+            // (pixel index -> (b, y, x) by exact magic division: short-M layers only)
+            YP_REQUIRE((unsigned long long)(a.M + 127) * (unsigned long long)a.HoWo < (1ull << 32) && a.HoWo >= 2 && a.Wo >= 2,
+                       "yp_conv2d: tile %d serves M * Ho * Wo < 2^32 (M = %d, Ho * Wo = %d)", d->tile, a.M, a.HoWo);
+            a.mg_howo = (unsigned)(((1ull << 32) + a.HoWo - 1) / a.HoWo);
+            a.mg_wo = (unsigned)(((1ull << 32) + a.Wo - 1) / a.Wo);
+            e = yp_wsk_launch(d->tile, d->dtype, of32, a, nblkw, stream);
+            if (e != hipSuccess) { yp_set_error("yp_conv2d: wave-private split-K kernel launch failed: %s", hipGetErrorString(e)); return YP_ERR_HIP; }
+            return YP_OK;
+        }
+    }
     if (det != nullptr) {
         YP_REQUIRE(det->na > 0 && det->na <= 8 && det->no > 5 && det->na * det->no <= Cout && det->x_out != nullptr, "yp_conv2d_detect: bad detect descriptor");
         YP_REQUIRE(d->act == YP_ACT_NONE && d->res.C == 0 && d->out2.C == 0 && fast && d->pre_weight == nullptr, "yp_conv2d_detect: plain fast-path convolution required");

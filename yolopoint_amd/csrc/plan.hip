@@ -3,6 +3,7 @@
 // module-by-module dispatch (models/YOLOPoint.py:198-246): the host walks the module tree once,
 // emits descriptors, and every later forward is one C call.
 #include "yp_internal.h"
+#include <cstdlib>
 #include <vector>
 #include <cstring>
 
@@ -172,16 +173,24 @@ static int ensure_side(YpPlan* plan) {
 // kernels (one workgroup per CU, atomics-bound) run beside the dgrad / BatchNorm-backward chain, which never reads their output.
 static int run_eager(YpPlan* plan, hipStream_t st) {
     bool pending = false;
+    bool main_since_fork = true;        // a side op forks again only when the main lane has moved since the last fork: consecutive side ops are
+                                        // ordered by their own stream.  (Not only an economy: captured into a hipGraph, a main-lane node with many
+                                        // outgoing cross-stream edges -- every side op re-forking from the same position -- lost its SAME-stream
+                                        // successor edge at replay on ROCm 7.2: the next main op ran before it.)
     for (const PlanOp& op : plan->ops) {
         if (op.lane == YP_LANE_SIDE) {
             if (int rc = ensure_side(plan)) return rc;
-            YP_CHECK_HIP(hipEventRecord(plan->fork, st));
-            YP_CHECK_HIP(hipStreamWaitEvent(plan->side, plan->fork, 0));
+            if (main_since_fork) {
+                YP_CHECK_HIP(hipEventRecord(plan->fork, st));
+                YP_CHECK_HIP(hipStreamWaitEvent(plan->side, plan->fork, 0));
+                main_since_fork = false;
+            }
             const int rc = run_op(op, plan->side);
             if (rc != YP_OK) return rc;
             pending = true;
             continue;
         }
+        main_since_fork = true;
         if (op.lane == YP_LANE_JOIN && pending) {
             YP_CHECK_HIP(hipEventRecord(plan->join, plan->side));
             YP_CHECK_HIP(hipStreamWaitEvent(st, plan->join, 0));
@@ -322,6 +331,27 @@ extern "C" int yp_plan_instantiate_graph(YpPlan* plan, void* stream) {
             }
         }
     }
+    if (getenv("YP_GRAPH_DUMP")) {          // debug: the captured topology as node index -> indices of the nodes it waits for
+        std::vector<hipGraphNode_t> nodes(nn);
+        size_t cnt = nn;
+        if (nn && hipGraphGetNodes(g, nodes.data(), &cnt) == hipSuccess) {
+            for (size_t i = 0; i < cnt; ++i) {
+                size_t nd = 0;
+                (void)hipGraphNodeGetDependencies(nodes[i], nullptr, &nd);
+                std::vector<hipGraphNode_t> deps(nd ? nd : 1);
+                if (nd) (void)hipGraphNodeGetDependencies(nodes[i], deps.data(), &nd);
+                hipGraphNodeType ty;
+                (void)hipGraphNodeGetType(nodes[i], &ty);
+                fprintf(stderr, "[graph] node %zu type %d <-", i, (int)ty);
+                for (size_t k = 0; k < nd; ++k)
+                    for (size_t j = 0; j < cnt; ++j)
+                        if (nodes[j] == deps[k]) fprintf(stderr, " %zu", j);
+                fprintf(stderr, "\n");
+            }
+        }
+    }
+    for (const PlanOp& op : plan->ops)
+        if (op.lane == YP_LANE_SIDE) plan->parallel = true;     // (schedule lanes: the captured topology has a side branch)
     YP_CHECK_HIP(hipGraphInstantiate(&plan->exec, g, nullptr, nullptr, 0));
     return YP_OK;
 }

@@ -99,42 +99,58 @@ class YOLOPoint(HipModule):
             finally:
                 pb.scope.pop()
 
+        # Schedule (two lanes, PlanBuilder.side).  The keypoint head, the descriptor head and the first two Detect levels feed nothing but the
+        # caller, and the YOLO encoder / PAN chain behind Bottleneck3 is 30 dependent launches of 100-400 workgroups on 256 CUs: the heads
+        # (P3-sized launches that fill the chip) go to the plan's side lane and are forked behind Bottleneck4 -- legal anywhere behind
+        # Bottleneck2, they read only xa / x8 / xb -- so they run beside that chain instead of in front of it.  Measured (batch 8, 640x640,
+        # f16, same box): one lane 0.751 ms, heads forked behind Bottleneck2 / 3 / 4: 0.706 / 0.706 / 0.691 ms (eager two-stream replay).
         x = self._emit_stem(pb, img)
         x = run("Conv2", self.Conv2, x)
         xa = run("Bottleneck1", self.Bottleneck1, x)
         x8 = run("Conv3", self.Conv3, xa)
-        # keypoint head
-        t = run("BottleneckDet", self.BottleneckDet, x8)
-        pb.scope.append("ConvDet")
-        semi = pb.conv(t, self.ConvDet.weight.detach().float(), None, 1, 1, 0, _hip.YP_ACT_NONE, out_f32=True)
-        pb.scope.pop()
         xb = run("Bottleneck2", self.Bottleneck2, x8)
-        # descriptor head
-        dA = run("ConvDescA", self.ConvDescA, xa)
-        dB = run("ConvDescB", self.ConvDescB, xb)
-        d = run("BottleneckDesc", self.BottleneckDesc, [dA, dB.up()])
-        pb.scope.append("ConvDesc")
-        desc = pb.conv(d, self.ConvDesc.weight.detach().float(), None, 3, 1, 1, _hip.YP_ACT_NONE, out_f32=True)
-        pb.l2norm(desc, desc, self.ConvDesc.out_channels)
-        pb.scope.pop()
         # YOLO encoder
         x = run("Conv4", self.Conv4, xb)
         xc = run("Bottleneck3", self.Bottleneck3, x)
         x = run("Conv5", self.Conv5, xc)
         x = run("Bottleneck4", self.Bottleneck4, x)
+        with pb.side():
+            # keypoint head
+            t = run("BottleneckDet", self.BottleneckDet, x8)
+            pb.scope.append("ConvDet")
+            semi = pb.conv(t, self.ConvDet.weight.detach().float(), None, 1, 1, 0, _hip.YP_ACT_NONE, out_f32=True)
+            pb.scope.pop()
+            # descriptor head
+            dA = run("ConvDescA", self.ConvDescA, xa)
+            dB = run("ConvDescB", self.ConvDescB, xb)
+            d = run("BottleneckDesc", self.BottleneckDesc, [dA, dB.up()])
+            pb.scope.append("ConvDesc")
+            desc = pb.conv(d, self.ConvDesc.weight.detach().float(), None, 3, 1, 1, _hip.YP_ACT_NONE, out_f32=True)
+            pb.l2norm(desc, desc, self.ConvDesc.out_channels)
+            pb.scope.pop()
         x = run("SPPooling", self.SPPooling, x)
-        # PAN head
+        # PAN head; every Detect level right behind the block it reads
+        pb.scope.append("Detect")
+        det = self.Detect.emit_begin(pb, [(xb.LH, xb.LW), (xb.LH // 2, xb.LW // 2), (xb.LH // 4, xb.LW // 4)], decode)
+        pb.scope.pop()
+
+        def detect_level(i, v, side):
+            pb.scope.append("Detect")
+            with pb.side(side):
+                self.Detect.emit_level(pb, det, i, v)
+            pb.scope.pop()
         xd = run("Conv6", self.Conv6, x)
         x = run("Bottleneck5", self.Bottleneck5, [xd.up(), xc])
         xe = run("Conv7", self.Conv7, x)
         xf = run("Bottleneck6", self.Bottleneck6, [xe.up(), xb])
+        detect_level(0, xf, True)
         x = run("Conv8", self.Conv8, xf)
         xg = run("Bottleneck7", self.Bottleneck7, [x, xe])
+        detect_level(1, xg, True)
         x = run("Conv9", self.Conv9, xg)
         p5 = run("Bottleneck8", self.Bottleneck8, [x, xd])
-        pb.scope.append("Detect")
-        z, xs = self.Detect.emit(pb, [xf, xg, p5], decode=decode)
-        pb.scope.pop()
+        detect_level(2, p5, False)
+        z, xs = det["z"], det["outs"]
         return {"semi": semi, "desc": desc, "z": z, "xs": xs}
 
     def build_plan(self, B, H, W, device, graph=False):
@@ -154,7 +170,10 @@ class YOLOPoint(HipModule):
             plan = pb.finish()
             plan.stem_launch = pb.stem_launch
             plan.stem_record = getattr(pb, "stem_record", None) if pb.stem_launch else None
-            if graph:
+            # A plan with schedule lanes replays EAGERLY on its two streams even when a graph was asked for: captured into a hipGraph the
+            # side branch bought 0-4 % (0.743 vs 0.752 ms at batch 8), the same launches on two plain streams 8 % (0.691 ms) -- the ~50
+            # launches of a forward cost the host ~0.2 ms, well inside the step.  YP_LANES_EAGER=0: capture them.
+            if graph and not (plan.has_lanes and __import__("os").environ.get("YP_LANES_EAGER", "1") != "0"):
                 plan.instantiate_graph()
             cache[key] = (plan, img, outs)
         return cache[key]
@@ -276,31 +295,42 @@ class YOLOPointv52(YOLOPoint):
         x = run("Conv2", self.Conv2, x)
         xa = run("Bottleneck1", self.Bottleneck1, x)
         x8 = run("Conv3", self.Conv3, xa)
-        semi = run("BottleneckDet", self.BottleneckDet, x8, out_f32=True)
         xb = run("Bottleneck2", self.Bottleneck2, x8)
-        dA = pb.new_buf(xa.LH // 2, xa.LW // 2, xa.C).view()
-        pb.scope.append("MaxPool")
-        pb.op(_hip.OP_MAXPOOL2, [xa], [dA], "", v=[xa, dA], i=[pb.code, pb.B])
-        pb.scope.pop()
-        dB = run("ConvDescB", self.ConvDescB, xb)
-        desc = run("BottleneckDesc", self.BottleneckDesc, [dA, dB.up()], out_f32=True)
-        pb.scope.append("BottleneckDesc")
-        pb.l2norm(desc, desc, self._desc_channels)
-        pb.scope.pop()
         x = run("Conv4", self.Conv4, xb)
         xc = run("Bottleneck3", self.Bottleneck3, x)
         x = run("Conv5", self.Conv5, xc)
         x = run("Bottleneck4", self.Bottleneck4, x)
+        with pb.side():                       # (heads and the first two Detect levels on the side lane: see YOLOPoint.emit)
+            semi = run("BottleneckDet", self.BottleneckDet, x8, out_f32=True)
+            dA = pb.new_buf(xa.LH // 2, xa.LW // 2, xa.C).view()
+            pb.scope.append("MaxPool")
+            pb.op(_hip.OP_MAXPOOL2, [xa], [dA], "", v=[xa, dA], i=[pb.code, pb.B])
+            pb.scope.pop()
+            dB = run("ConvDescB", self.ConvDescB, xb)
+            desc = run("BottleneckDesc", self.BottleneckDesc, [dA, dB.up()], out_f32=True)
+            pb.scope.append("BottleneckDesc")
+            pb.l2norm(desc, desc, self._desc_channels)
+            pb.scope.pop()
         xd = run("SPPooling", self.SPPooling, x)
+        pb.scope.append("Detect")
+        det = self.Detect.emit_begin(pb, [(xb.LH, xb.LW), (xb.LH // 2, xb.LW // 2), (xb.LH // 4, xb.LW // 4)], decode)
+        pb.scope.pop()
+
+        def detect_level(i, v, side):
+            pb.scope.append("Detect")
+            with pb.side(side):
+                self.Detect.emit_level(pb, det, i, v)
+            pb.scope.pop()
         xe = run("Bottleneck5", self.Bottleneck5, [xd.up(), xc])
         xf = run("Bottleneck6", self.Bottleneck6, [xe.up(), xb])
+        detect_level(0, xf, True)
         x = run("Conv8", self.Conv8, xf)
         xg = run("Bottleneck7", self.Bottleneck7, [x, xe])
+        detect_level(1, xg, True)
         x = run("Conv9", self.Conv9, xg)
         p5 = run("Bottleneck8", self.Bottleneck8, [x, xd])
-        pb.scope.append("Detect")
-        z, xs = self.Detect.emit(pb, [xf, xg, p5], decode=decode)
-        pb.scope.pop()
+        detect_level(2, p5, False)
+        z, xs = det["z"], det["outs"]
         return {"semi": semi, "desc": desc, "z": z, "xs": xs}
 
 

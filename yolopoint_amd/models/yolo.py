@@ -29,29 +29,34 @@ class Detect(HipModule):
         self.m = nn.ModuleList(nn.Conv2d(x, self.no * self.na, 1) for x in ch)
         self.inplace = inplace
 
+    def emit_begin(self, pb, dims, decode):
+        """Allocate the outputs of an nl-level head over feature maps of sizes dims = [(ny, nx)]; the levels are then emitted one by one
+        (emit_level) wherever their inputs become available in the launch list."""
+        assert len(dims) == self.nl
+        rows = [self.na * ny * nx for ny, nx in dims]
+        z = pb.new_tensor((pb.B, sum(rows), self.no)) if decode else None
+        return dict(z=z, rows=rows, total=sum(rows), outs=[None] * self.nl)
+
+    def emit_level(self, pb, st, i, v):
+        pb.scope.append(f"m.{i}")
+        ny, nx = v.LH, v.LW
+        assert self.na * ny * nx == st["rows"][i]
+        xo = pb.new_tensor((pb.B, self.na, ny, nx, self.no))
+        stride = float(self.stride[i])
+        anchors_px = (self.anchors[i].detach().float().cpu() * stride).reshape(-1).tolist()
+        # 1x1 conv + (view/permute/sigmoid/grid decode/concat) in ONE launch: the raw logits never round-trip HBM
+        pb.conv(v, self.m[i].weight.detach().float(), self.m[i].bias.detach().float(), 1, 1, 0, _hip.YP_ACT_NONE, out_f32=True,
+                detect=dict(na=self.na, no=self.no, stride=stride, anchors_px=anchors_px, x_out=xo, z_out=st["z"],
+                            rows_total=st["total"], row_offset=sum(st["rows"][:i])))
+        pb.scope.pop()
+        st["outs"][i] = xo
+
     def emit(self, pb, xs, decode):
         """xs: list of nl feature Views.  Returns (z or None, [x_i])."""
-        assert len(xs) == self.nl
-        B = pb.B
-        rows = [self.na * v.LH * v.LW for v in xs]
-        total = sum(rows)
-        z = pb.new_tensor((B, total, self.no)) if decode else None
-        outs = []
-        off = 0
+        st = self.emit_begin(pb, [(v.LH, v.LW) for v in xs], decode)
         for i, v in enumerate(xs):
-            pb.scope.append(f"m.{i}")
-            ny, nx = v.LH, v.LW
-            xo = pb.new_tensor((B, self.na, ny, nx, self.no))
-            stride = float(self.stride[i])
-            anchors_px = (self.anchors[i].detach().float().cpu() * stride).reshape(-1).tolist()
-            # 1x1 conv + (view/permute/sigmoid/grid decode/concat) in ONE launch: the raw logits never round-trip HBM
-            pb.conv(v, self.m[i].weight.detach().float(), self.m[i].bias.detach().float(), 1, 1, 0, _hip.YP_ACT_NONE, out_f32=True,
-                    detect=dict(na=self.na, no=self.no, stride=stride, anchors_px=anchors_px, x_out=xo, z_out=z,
-                                rows_total=total, row_offset=off))
-            pb.scope.pop()
-            outs.append(xo)
-            off += rows[i]
-        return z, outs
+            self.emit_level(pb, st, i, v)
+        return st["z"], st["outs"]
 
     def forward(self, x):
         """x: list of nl NCHW cuda tensors (like the reference, which it mutates in place)."""

@@ -7,6 +7,7 @@ through a 2x nearest upsample.  torch.cat never happens: producers write into sl
 shared buffer, or a conv takes two source views.  Weights are packed once per plan as
 [Cout_pad][Kpad] rows with k = (r*S + s)*Cin + c.
 """
+import contextlib
 import ctypes as C
 import os
 import math
@@ -192,6 +193,10 @@ _TUNE_CACHE = {}
 # when it does not apply)
 # 41..44 / 57: the 8-wave 32x32x16 kernels of csrc/conv_mma8.hip (256x256 / 256x128 / 128x256 / 128x128 tiles; 57 = 256x256 with two-step
 # phases, 58 = 256x256 free-running), for 16-bit layers whose channel counts are multiples of 64
+# 71..76: the wave-private split-K kernels of csrc/conv_wsk.hip (64x64 tiles with 8 / 4 waves, 128x64 with 4; 71-73 interleave the k tiles over
+# the waves, 74-76 give every wave a contiguous k range) for the short-M layers.  Like 31 / 33 they are reachable by explicit id only: their
+# fp32 sums run as NW partial sums (bit-reproducible, but the last bits differ from the sequential tiles), and although they win several
+# P5 layers in isolation (Conv9 16.6 -> 12.0 us, Conv5 22.8 -> 19.7) the forward did not move with them (0.691 vs 0.691 ms, three A/B pairs).
 _TUNE_CANDIDATES = (1, 2, 3, 4, 5, 21, 22, 23, 24, 25, 26, 27, 10, 11, 12, 13, 14, 15, 41, 42, 43, 44, 57, 58)
 # pixels per BatchNorm-statistics row of the variants whose rows are plain pixel blocks (the 3x3 halo kernels write one row per image tile)
 _STAT_ROW_PX = {41: 128, 57: 128, 58: 128}
@@ -556,6 +561,20 @@ class PlanBuilder:
         self._track(reads, writes)
         self.records.append(OpRecord(self.name(name), "aux"))
 
+    @contextlib.contextmanager
+    def side(self, enable=True):
+        """Ops added inside this block go to the plan's SIDE lane (a second stream; under graph capture a parallel branch): each waits for
+        every op added before it and for the side ops before it, and nothing outside the block waits for them before the plan ends.  For
+        branches whose results only the caller reads (the keypoint / descriptor heads and the Detect levels of the inference plan): the
+        plan then replays as a main chain + one side chain instead of per-slice dependency edges.  YP_INFER_LANES=0 disables it."""
+        n0 = lib().yp_plan_num_ops(self.handle)
+        yield
+        if enable and os.environ.get("YP_INFER_LANES", "1") != "0":
+            for j in range(n0, lib().yp_plan_num_ops(self.handle)):
+                check(lib().yp_plan_set_lane(self.handle, j, _hip.LANE_SIDE))
+                self.has_lanes = True
+                self.__dict__.setdefault("side_ops", set()).add(j)
+
     def set_lane(self, lane):
         """Put the op added last on a schedule lane (_hip.LANE_SIDE: beside the following ops; _hip.LANE_JOIN: after all side ops)."""
         check(lib().yp_plan_set_lane(self.handle, lib().yp_plan_num_ops(self.handle) - 1, lane))
@@ -654,6 +673,20 @@ class PlanBuilder:
         assert len(self.accesses) == len(self.records) == lib().yp_plan_num_ops(self.handle)
         if os.environ.get("YP_GRAPH_LINEAR") == "1":      # A/B: replay every plan as a linear chain
             parallel = False
+        if os.environ.get("YP_PLAN_DEBUG"):
+            for j, r in enumerate(self.records):
+                print(f"[plan] {j:3d} {'SIDE' if j in getattr(self, 'side_ops', ()) else 'main'} {r.name} ({r.kind})", flush=True)
+        if getattr(self, "has_lanes", False):             # explicit schedule lanes: the captured topology (main chain + side chain) is the schedule
+            parallel = False
+            # the lane assignment must agree with the data dependencies: nothing on the main lane may touch what a side op writes or is
+            # still reading (a side op waits for every op in front of it, so the other direction is covered by construction)
+            side = getattr(self, "side_ops", set())
+            for j, d in enumerate(self.dependencies()):
+                if j not in side:
+                    bad = [i for i in d if i in side]
+                    if bad:
+                        raise _hip.YpError(f"plan lanes: main-lane op {j} ({self.records[j].name}) depends on side-lane op(s) "
+                                           f"{[(i, self.records[i].name) for i in bad]}")
         self.deps = self.dependencies() if parallel else None
         if self.deps is not None:
             for j, d in enumerate(self.deps):
@@ -671,6 +704,8 @@ class ExecPlan:
         self.deps = pb.deps
         self.refreshers = pb.refreshers
         self.graph = False
+        self.has_lanes = bool(getattr(pb, "has_lanes", False))     # ops on the side lane: replays on two streams (graph: a forked branch)
+        self.parallel = self.has_lanes
 
     def num_ops(self):
         return lib().yp_plan_num_ops(self.handle)
@@ -684,8 +719,12 @@ class ExecPlan:
         with torch.cuda.stream(s):
             check(lib().yp_plan_instantiate_graph(self.handle, _hip.stream_ptr(s)))
         torch.cuda.current_stream().wait_stream(s)
+        # Everything the build enqueued (zero fills of the output tensors, filter uploads) must have retired before the FIRST replay: a graph
+        # with a side branch (schedule lanes) runs that branch on a stream of its own, which the runtime orders behind the launch stream's
+        # earlier KERNELS only through the graph's root -- measured: the Detect outputs of the first replay came out zero-filled in parts.
+        torch.cuda.synchronize(self.device)
         self.graph = True
-        self.parallel = bool(lib().yp_plan_graph_is_parallel(self.handle))
+        self.parallel = bool(lib().yp_plan_graph_is_parallel(self.handle)) or self.has_lanes
 
     def refresh(self):
         for fn in self.refreshers:
