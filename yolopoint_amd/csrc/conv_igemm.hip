@@ -1457,12 +1457,8 @@ hipError_t launch_tile(const ConvKArgs& a, int nblk, hipStream_t st) {
     constexpr size_t lds = (size_t)NS * (KPB > 0 ? KPB : 1) * (BM / 16 + BN / 16) * 1024;
     auto kern = conv_igemm_kernel<DT, OUT_F32, FAST, DETECT, BM, BN, WAVES_M, WAVES_N, NS, STATS, KPB, WSK>;
     if constexpr (lds > 65536) {
-        static bool attr_set = false;        // per instantiation
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            attr_set = true;
-        }
+        static YpLdsAttr attr;        // per instantiation, per device
+        if (hipError_t e = yp_set_max_lds(attr, (const void*)kern, (int)lds); e != hipSuccess) return e;
     }
     kern<<<dim3(nblk, a.ksplit), 256, lds, st>>>(a);
     return hipGetLastError();
@@ -1505,12 +1501,8 @@ hipError_t launch_halo(const ConvKArgs& a, int nblk, hipStream_t st) {
     constexpr size_t lds2 = (size_t)2 * HSLOTS * 1024 + (size_t)3 * 3 * (BN / 16) * 1024;
     const size_t lds = lds2 - (a.Cin > 32 ? 0 : (size_t)HSLOTS * 1024);
     auto kern = conv3x3_halo_kernel<DT, OUT_F32, STRIDE, BN, WAVES_M, TH, STATS>;
-    static bool attr_set = false;        // per instantiation
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static YpLdsAttr attr;        // per instantiation, per device
+    if (hipError_t e = yp_set_max_lds(attr, (const void*)kern, (int)lds2); e != hipSuccess) return e;
     kern<<<nblk, 256, lds, st>>>(a);
     return hipGetLastError();
 }
@@ -1537,12 +1529,8 @@ hipError_t launch_bneck(const ConvKArgs& a, int nblk, hipStream_t st) {
     constexpr size_t lds = hid + ring + ub;
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = bottleneck_halo_kernel<DT, C, BN, WAVES_M, POST>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static YpLdsAttr attr;        // per instantiation, per device
+    if (hipError_t e = yp_set_max_lds(attr, (const void*)kern, (int)lds); e != hipSuccess) return e;
     kern<<<nblk, 256, lds, st>>>(a);
     return hipGetLastError();
 }

@@ -511,12 +511,8 @@ hipError_t launch_mma8(const ConvKArgs& a, int nblk, hipStream_t st) {
     constexpr size_t lds = (size_t)NS * (BP + BC) * 128;
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = conv_mma8_kernel<DT, OUT_F32, BP, BC, WP, WC, NS, STATS, SCHED>;
-    static bool attr_set = false;        // per instantiation
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static YpLdsAttr attr;        // per instantiation, per device
+    if (hipError_t e = yp_set_max_lds(attr, (const void*)kern, (int)lds); e != hipSuccess) return e;
     kern<<<nblk, 512, lds, st>>>(a);
     return hipGetLastError();
 }

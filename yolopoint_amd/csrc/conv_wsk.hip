@@ -298,8 +298,8 @@ hipError_t launch_wsk(const ConvKArgs& a, int nblk, hipStream_t st) {
     constexpr size_t ring = (size_t)NW * 2 * (BM / 16 + 4) * 1024, red = (size_t)NW * 4 * (BM / 16) * 1024;
     constexpr size_t lds = ring > red ? ring : red;
     auto kern = conv_wsk_kernel<DT, OUT_F32, BM, NW, CONTIG>;
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // (per device; cheap)
-    if (e != hipSuccess) return e;
+    static YpLdsAttr attr;        // per instantiation, per device
+    if (hipError_t e = yp_set_max_lds(attr, (const void*)kern, (int)lds); e != hipSuccess) return e;
     kern<<<nblk, 64 * NW, lds, st>>>(a);
     return hipGetLastError();
 }

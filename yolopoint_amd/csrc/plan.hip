@@ -4,6 +4,7 @@
 // emits descriptors, and every later forward is one C call.
 #include "yp_internal.h"
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 #include <cstring>
 
@@ -81,7 +82,6 @@ extern "C" int yp_plan_destroy(YpPlan* plan) {
     if (plan->graph) (void)hipGraphDestroy(plan->graph);
     if (plan->fork) (void)hipEventDestroy(plan->fork);
     if (plan->join) (void)hipEventDestroy(plan->join);
-    if (plan->side) (void)hipStreamDestroy(plan->side);
     delete plan;
     return YP_OK;
 }
@@ -159,9 +159,22 @@ extern "C" int yp_plan_add_op(YpPlan* plan, const YpOpArgs* a) {
 
 extern "C" int yp_plan_num_ops(const YpPlan* plan) { return plan ? (int)plan->ops.size() : 0; }
 
+// The side lane of every plan of a device is ONE stream, created on first use and kept for the life of the process: plans come and go by
+// the hundred (one per input shape and weight version), and a stream per plan that is destroyed with it left the runtime in a state in
+// which a later, unrelated hipGraphLaunch crashed (ROCm 7.2; reproducible only after ~400 tests in one process).  Sharing is harmless:
+// a plan orders its side ops with its own fork / join events.
+static hipStream_t g_side_streams[64] = {};
+static std::mutex g_side_mutex;
 static int ensure_side(YpPlan* plan) {
     if (plan->side) return YP_OK;
-    YP_CHECK_HIP(hipStreamCreateWithFlags(&plan->side, hipStreamNonBlocking));
+    int dev = 0;
+    YP_CHECK_HIP(hipGetDevice(&dev));
+    {
+        std::lock_guard<std::mutex> lock(g_side_mutex);
+        hipStream_t& s = g_side_streams[dev & 63];
+        if (!s) YP_CHECK_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        plan->side = s;
+    }
     YP_CHECK_HIP(hipEventCreateWithFlags(&plan->fork, hipEventDisableTiming));
     YP_CHECK_HIP(hipEventCreateWithFlags(&plan->join, hipEventDisableTiming));
     return YP_OK;

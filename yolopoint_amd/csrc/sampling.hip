@@ -335,11 +335,12 @@ __global__ __launch_bounds__(256) void csr_sort_kernel(const int* __restrict__ o
 
 // Grid cap of the large launches in this file (yp_sampling_set_max_workgroups; 0 = none): the label work of a training step runs on a side
 // stream beside the forward pass, and thousands of tiny workgroups would take the CU slots the convolutions wait for.
-static int g_max_wgs = 0;
-static unsigned capped(size_t want) { return (unsigned)(g_max_wgs > 0 && want > (size_t)g_max_wgs ? (size_t)g_max_wgs : want); }
+// (a process-wide tuning knob -- results never depend on it; atomic so that a setter on one thread and launches on another do not race)
+static std::atomic<int> g_max_wgs{0};
+static unsigned capped(size_t want) { const int cap = g_max_wgs.load(std::memory_order_relaxed); return (unsigned)(cap > 0 && want > (size_t)cap ? (size_t)cap : want); }
 extern "C" int yp_sampling_set_max_workgroups(int n) {
     YP_REQUIRE(n >= 0, "yp_sampling_set_max_workgroups: n >= 0");
-    g_max_wgs = n;
+    g_max_wgs.store(n, std::memory_order_relaxed);
     return YP_OK;
 }
 
@@ -355,11 +356,8 @@ extern "C" int yp_nce_select(const unsigned char* valid, const float* uvb, int B
     YP_REQUIRE(valid && uvb && uab && meta && B > 0 && B <= 1024 && Hc > 0 && Wc > 0 && samples > 0, "yp_nce_select: bad arguments (B <= 1024)");
     const size_t lds = (size_t)Hc * Wc * sizeof(unsigned);
     YP_REQUIRE(Hc * Wc < 65536 && lds <= 144 * 1024, "yp_nce_select: %d x %d cells do not fit the workgroup's LDS", Hc, Wc);
-    static bool attr_set = false;
-    if (!attr_set) {
-        YP_CHECK_HIP(hipFuncSetAttribute((const void*)nce_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-        attr_set = true;
-    }
+    static YpLdsAttr attr;              // per device
+    YP_CHECK_HIP(yp_set_max_lds(attr, (const void*)nce_select_kernel, 144 * 1024));
     nce_select_kernel<<<B, 1024, lds, (hipStream_t)stream>>>(valid, uvb, B, Hc, Wc, samples, (unsigned long long)seed, uab, meta);
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;

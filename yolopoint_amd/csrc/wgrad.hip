@@ -303,12 +303,8 @@ hipError_t launch_wgrad(const WgradArgs& a, dim3 grid, hipStream_t st) {
     constexpr int XR = TAPS == 9 ? (HROWS + 31) / 32 * 32 : 128;
     constexpr size_t lds = (size_t)2 * (2 * NB * XR * 32 + 2 * NB * TH * 16 * 32);
     auto kern = wgrad_kernel<DT, TAPS, ST, NB>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static YpLdsAttr attr;        // per instantiation, per device
+    if (hipError_t e = yp_set_max_lds(attr, (const void*)kern, (int)lds); e != hipSuccess) return e;
     kern<<<grid, 256, lds, st>>>(a);
     return hipGetLastError();
 }
@@ -449,12 +445,8 @@ template <int DT, int NCB>
 static hipError_t launch_stem_wgrad(const StemWgradArgs& a, int grid, hipStream_t st) {
     constexpr size_t lds = (size_t)2 * (8192 + NCB * 128 * 32);
     auto kern = stem_wgrad_kernel<DT, NCB>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static YpLdsAttr attr;        // per instantiation, per device
+    if (hipError_t e = yp_set_max_lds(attr, (const void*)kern, (int)lds); e != hipSuccess) return e;
     kern<<<grid, 256, lds, st>>>(a);
     return hipGetLastError();
 }
@@ -606,12 +598,8 @@ static hipError_t launch_wgrad_group(const WgradArgs* table, int n, int blocks, 
     constexpr int XR = TAPS == 9 ? (HROWS + 31) / 32 * 32 : 128;
     constexpr size_t lds = (size_t)2 * (2 * NB * XR * 32 + 2 * NB * TH * 16 * 32);
     auto kern = wgrad_group_kernel<DT, TAPS, ST, NB>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static YpLdsAttr attr;        // per instantiation, per device
+    if (hipError_t e = yp_set_max_lds(attr, (const void*)kern, (int)lds); e != hipSuccess) return e;
     kern<<<blocks, 256, lds, st>>>(table, n);
     return hipGetLastError();
 }

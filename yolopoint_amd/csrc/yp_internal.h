@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdint>
+#include <atomic>
 #include "../../include/yolopoint_hip.h"
 
 void yp_set_error(const char* fmt, ...);
@@ -25,6 +26,21 @@ void yp_set_error(const char* fmt, ...);
             return YP_ERR_INVALID;                                                 \
         }                                                                          \
     } while (0)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, DEVICE): function attributes are per device, so a process
+// that drives several GPUs must raise the limit on each of them (a process-wide flag left every device but the first at 64 KiB).
+// One YpLdsAttr (a device bit set) per launcher instantiation; lock-free, idempotent.
+struct YpLdsAttr { std::atomic<unsigned long long> done{0}; };
+static inline hipError_t yp_set_max_lds(YpLdsAttr& st, const void* fn, int bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (st.done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) st.done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
 
 static inline int yp_dtype_bytes(int dtype) { return dtype == YP_F32 ? 4 : ((dtype == YP_FP8 || dtype == YP_FP8_BF8) ? 1 : 2); }
 static inline int yp_cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -179,11 +179,29 @@ class TrainStep:
     # (tests/test_gpu_training.py) -- and no ATen / rocPRIM / hipBLASLt kernel in a steady-state step.  YP_NATIVE_STAGE=0: the autograd
     # formulation (also what YOLOPointv52, two-graph mode and CPU tensors use).
     # ------------------------------------------------------------------------------------------------------------------------------
+    def loss_terms(self):
+        """[total, detector, descriptor, object] of the last micro-batch as Python floats (one host read-back).  The device-count form of the
+        native stage cannot raise when an image has no valid cell under the warp (the pool is empty; the reference would average over nothing:
+        NaN) -- that step runs WITHOUT a descriptor term.  A real InfoNCE value is never exactly zero, so the condition is reported here."""
+        t = getattr(self, "last_loss_terms", None)
+        if t is None:
+            return None
+        v = [float(x) for x in t.detach().float().cpu().tolist()]
+        if len(v) >= 3 and v[2] == 0.0:
+            import warnings
+            warnings.warn("TrainStep: the last step ran without a descriptor (InfoNCE) term -- an image of the batch had no valid cell under its "
+                          "homography (empty sampling pool); check the warps / valid masks of the batch")
+        return v
+
     def _native_stage_ok(self, batch):
         if not self.pair or os.environ.get("YP_NATIVE_STAGE", "1") == "0" or type(self.model.model).__name__ != "YOLOPoint":
             return False
         img = batch['image']
         ok = img.is_cuda and img.dim() == 4 and img.shape[-1] % 8 == 0 and img.shape[-2] % 8 == 0 and tuple(batch['warped_image'].shape) == tuple(img.shape)
+        # the stage consumes the device-side sampling (utils.loss_functions._prepare_native with the sorted pair index): the same predicate
+        # as infonce_prepare's, or the step would trip over `assert sync` / a 4-tuple in the middle of a step with the graph marked busy
+        ok = ok and (img.shape[-2] // 8) * (img.shape[-1] // 8) < 36864 and os.environ.get("YP_NATIVE_PREPARE", "1") != "0" \
+            and os.environ.get("YP_SAMPLE_SORTED", "1") != "0"
         for k in ('labels_2D', 'warped_labels', 'valid_mask', 'warped_valid_mask'):
             t = batch[k]
             ok = ok and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == img.shape[0] * img.shape[-2] * img.shape[-1]
@@ -361,7 +379,14 @@ class TrainStep:
         from .training import run_native_backward, run_native_backward_pair
         m, dev = self.model, self.device
         if prepare and self._native_stage_ok(batch):
-            return self._loss_and_grads_native(batch, first_micro, scale)
+            try:
+                return self._loss_and_grads_native(batch, first_micro, scale)
+            except BaseException:
+                for g in getattr(m.model, "_train_graphs", {}).values():      # an exception inside the stage must not leak a busy graph
+                    for gg in (g if isinstance(g, (list, tuple)) else [g]):
+                        if hasattr(gg, "busy"):
+                            gg.busy = False
+                raise
         self.reducer.bind_grads(zero=first_micro)   # (instead of optimizer.zero_grad: gradients accumulate straight into the all-reduce buckets)
         img = batch['image']
         B, S = img.shape[0], img.shape[-1]

@@ -588,17 +588,44 @@ class PlanBuilder:
         """Pick the fastest kernel variant for this convolution by timing each candidate on the plan's own buffers
         (HIP events on the current stream).  Every variant computes the same convolution; the choice is cached per
         signature so that equal layers always run the same kernel within a process."""
-        if key in _TUNE_CACHE:
-            return _TUNE_CACHE[key]
         # Data-parallel runs: every rank builds the same plans in the same order; rank 0 times the candidates and broadcasts its choice, so that
         # all replicas run the SAME kernel variant for a layer (timings differ by a few percent from GPU to GPU: per-process tuning let ranks
         # pick different tiles -- different fp32 summation orders and step times across the replicas of one job).  YP_TUNE_SHARED=0: per rank.
+        # The exchange does not depend on the state of a rank's cache: EVERY call takes part in one broadcast (rank 0 sends its choice, cached
+        # or freshly timed, with a checksum of the signature), so ranks whose caches differ (an extra validation plan on rank 0, a restarted
+        # rank) cannot fall out of step; a receiver checks the signature, and that the tile applies to ITS descriptor, before it adopts it.
         shared = _shared_tuning_group()
-        if shared is not None and shared[1] != 0:
-            t = torch.zeros(2, dtype=torch.float32, device=self.device)
-            shared[0].broadcast(t, src=0)
-            _TUNE_CACHE[key] = (int(t[0].item()), (float(t[1].item()) if float(t[1].item()) > 0 else None))
-            return _TUNE_CACHE[key]
+        if shared is None:
+            if key in _TUNE_CACHE:
+                return _TUNE_CACHE[key]
+        else:
+            import zlib
+            sig = zlib.crc32(repr(key).encode()) & 0x7fffffff
+            if shared[1] == 0:
+                choice = _TUNE_CACHE[key] if key in _TUNE_CACHE else self._autotune_local(d, det, key, stat_group_px)
+                msg = torch.tensor([sig, int(choice[0]), int(round((choice[1] or 0.0) * 1e9))], dtype=torch.int64, device=self.device)
+                shared[0].broadcast(msg, src=0)
+                return choice
+            msg = torch.zeros(3, dtype=torch.int64, device=self.device)
+            shared[0].broadcast(msg, src=0)
+            rsig, best, ns = (int(v) for v in msg.tolist())
+            ok = rsig == sig
+            if ok:                                     # does rank 0's variant apply to this rank's descriptor?
+                d.tile = best
+                ok = (lib().yp_conv2d_detect(C.byref(d), C.byref(det), _hip.stream_ptr()) if det is not None
+                      else lib().yp_conv2d(C.byref(d), _hip.stream_ptr())) == 0
+            if ok:
+                _TUNE_CACHE[key] = (best, (ns * 1e-9 if ns > 0 else None))
+                return _TUNE_CACHE[key]
+            import warnings
+            warnings.warn(f"shared autotuning: rank {shared[1]} received tile {best} for another signature or one that does not apply here "
+                          f"({self.name()}); the ranks are building different plans -- tuning this layer locally")
+            if key in _TUNE_CACHE:
+                return _TUNE_CACHE[key]
+        return self._autotune_local(d, det, key, stat_group_px)
+
+    def _autotune_local(self, d, det, key, stat_group_px=None):
+        """Time every applicable variant on this GPU and cache the fastest (see _autotune)."""
         st = _hip.stream_ptr()
         if det is not None:
             run = lambda: lib().yp_conv2d_detect(C.byref(d), C.byref(det), st)
@@ -643,8 +670,6 @@ class PlanBuilder:
             if os.environ.get("YP_TUNE_DEBUG"):
                 print(f"[tune-random] {self.name():44s} pick {best:2d} of {applicable} zs={int(d.in0_zero_stuffed)} k={d.R}x{d.S} s={d.stride_h} Cin={d.in0.C}+{d.in1.C} N={d.Npad} M={d.B * d.Ho * d.Wo}", flush=True)
         _TUNE_CACHE[key] = (best, (best_ms / 8 if best_ms is not None else None))
-        if shared is not None:
-            shared[0].broadcast(torch.tensor([float(best), float(best_ms / 8 if best_ms is not None else 0.0)], dtype=torch.float32, device=self.device), src=0)
         return _TUNE_CACHE[key]
 
     def sppf_pool(self, x, y1, y2, y3):

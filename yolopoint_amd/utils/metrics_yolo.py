@@ -19,12 +19,14 @@ def bbox_iou(box1, box2, xywh=True, GIoU=False, DIoU=False, CIoU=False, eps=1e-7
     max(0, min(hi1, hi2) - max(lo1, lo2)) with lo/hi = c -/+ e/2, the enclosing box spans max(hi) - min(lo)."""
     import math
 
-    def centre_extent(b):
+    def corners_extent(b):
+        """(lo, hi, extent, centre); corner boxes keep their corners as given (no clamping of a degenerate height, as the reference)."""
         if xywh:
-            return b[..., :2], b[..., 2:4]
-        return (b[..., :2] + b[..., 2:4]) * 0.5, torch.stack((b[..., 2] - b[..., 0], (b[..., 3] - b[..., 1]).clamp(eps)), -1)
-    (c1, e1), (c2, e2) = centre_extent(box1), centre_extent(box2)
-    lo1, hi1, lo2, hi2 = c1 - e1 * 0.5, c1 + e1 * 0.5, c2 - e2 * 0.5, c2 + e2 * 0.5
+            c, e = b[..., :2], b[..., 2:4]
+            return c - e * 0.5, c + e * 0.5, e, c
+        lo, hi = b[..., :2], b[..., 2:4]
+        return lo, hi, hi - lo, (lo + hi) * 0.5
+    (lo1, hi1, e1, c1), (lo2, hi2, e2, c2) = corners_extent(box1), corners_extent(box2)
     inter = (torch.minimum(hi1, hi2) - torch.maximum(lo1, lo2)).clamp(0).prod(-1, keepdim=True)
     union = e1.prod(-1, keepdim=True) + e2.prod(-1, keepdim=True) - inter + eps
     iou = inter / union
@@ -37,7 +39,7 @@ def bbox_iou(box1, box2, xywh=True, GIoU=False, DIoU=False, CIoU=False, eps=1e-7
     centre_term = ((c2 - c1) ** 2).sum(-1, keepdim=True) / ((span ** 2).sum(-1, keepdim=True) + eps)
     if not CIoU:
         return iou - centre_term
-    aspect = (4.0 / math.pi ** 2) * (torch.atan(e2[..., :1] / e2[..., 1:]) - torch.atan(e1[..., :1] / e1[..., 1:])) ** 2
+    aspect = (4.0 / math.pi ** 2) * (torch.atan(e2[..., :1] / (e2[..., 1:] + eps)) - torch.atan(e1[..., :1] / (e1[..., 1:] + eps))) ** 2
     with torch.no_grad():
         weight = aspect / (aspect - iou + (1.0 + eps))
     return iou - (centre_term + aspect * weight)
