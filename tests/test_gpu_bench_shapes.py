@@ -22,12 +22,12 @@ pytestmark = pytest.mark.gpu
 # PyTorch's half-precision arithmetic (fp16 storage of activations and BN-folded filters, fp32 accumulation:
 # oracle.net_oracle.half_storage) differs from the fp32 oracle by floor(t) for every head tensor t; the HIP path must stay within
 #   relative L2   <= 1.15 x floor    (measured: 1.00 - 1.10 x at configs[1] and configs[3])
-#   max-abs error <= 3.0  x floor    (the maximum of ~1e7 rounding errors is a heavy-tailed statistic -- one decoded box of `pred` decides it:
+#   max-abs error <= 2.5  x floor    (the maximum of ~1e7 rounding errors is a heavy-tailed statistic -- one decoded box of `pred` decides it:
 #                                     measured 0.88 - 1.36 x with the autotuned kernel variants, 0.9 - 2.13 x over random variant mixtures,
 #                                     YP_TUNE_RANDOM: other summation orders, while the L2 ratio stays within 1.00 - 1.10)
 # and every keypoint cell whose argmax differs from the fp32 oracle's must be a near-tie of the REFERENCE within one 16-bit step of the
 # logit scale (2^-10 max|semi|), no more such cells than 1.5 x the floor's own count + 5.
-F16_L2, F16_MAX = 1.15, 3.0
+F16_L2, F16_MAX = 1.15, 2.5
 
 
 def _heads(o):

@@ -56,17 +56,18 @@ def test_two_ranks_run_the_same_kernel_variants(cuda):
     assert got[0] == got[1] and len(got[0]) == 3, got
 
 
-def _step_worker(rank, world, port, q):
+def _step_worker(rank, world, port, q, backend="gloo"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)     # RCCL: one device per rank; gloo: both ranks on this one GPU
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": dev} if backend == "nccl" else {}))
     try:
         import sys
         sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
         from helpers import make_model
         from yolopoint_amd.engine import TrainStep, synthetic_batch
-        dev = torch.device("cuda:0")
-        torch.cuda.set_device(dev)
         m, _ = make_model("n", 5, dtype="bf16")                 # same initial weights on every rank
         m = m.to(dev).train()
         step = TrainStep(m, dev, img_size=128)
@@ -77,7 +78,8 @@ def _step_worker(rank, world, port, q):
             losses.append(float(step(synthetic_batch(2, 128, dev, 1000 * rank + it))))
         torch.cuda.synchronize()
         flat = torch.cat([p.detach().float().flatten() for p in m.parameters()])
-        q.put((rank, losses, float(flat.double().sum()), float(flat.double().abs().sum()), list(step.reducer.launch_log)))
+        q.put((rank, losses, float(flat.double().sum()), float(flat.double().abs().sum()), list(step.reducer.launch_log),
+               getattr(step.reducer, "exposed_ms", None)))
     finally:
         dist.destroy_process_group()
 
@@ -95,7 +97,26 @@ def test_two_ranks_train_in_lockstep(cuda):
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    (l0, s0, a0, log0), (l1, s1, a1, log1) = got[0], got[1]
+    (l0, s0, a0, log0, _), (l1, s1, a1, log1, _) = got[0], got[1]
     assert l0 != l1                                   # different batches
     assert s0 == s1 and a0 == a1, (s0, s1, a0, a1)    # the same weights after the same averaged updates
     assert log0 == log1 and len(log0) > 0
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL refuses two ranks on one device: needs >= 2 visible GPUs")
+def test_two_ranks_train_in_lockstep_over_rccl():
+    """The same two-rank step over RCCL (backend "nccl"), one MI355X per rank: what `bench.py --gpus N` runs.  Parameters bit-identical on
+    both ranks, the bucket launch order non-empty and equal, and the reducer reports its exposed wait (HIP events around finish())."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_step_worker, args=(r, 2, port, q, "nccl")) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {r: rest for r, *rest in (q.get(timeout=900) for _ in procs)}
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    (l0, s0, a0, log0, ex0), (l1, s1, a1, log1, ex1) = got[0], got[1]
+    assert l0 != l1 and s0 == s1 and a0 == a1 and log0 == log1 and len(log0) > 0
+    assert ex0 is None or isinstance(ex0, (int, float))

@@ -59,6 +59,52 @@ def test_cell_validity_and_matches(cuda, B, H, W, kind):
         assert bad_u <= 1e-3 * total
 
 
+def _fixture_cases():
+    """The inputs of tests/golden/nce_cells.npz, regenerated exactly as tests/golden/make_golden.py::nce_cells_cases builds them."""
+    cases = []
+    for name, B, H, W, kind in (("identity", 3, 128, 192, "identity"), ("shift", 2, 256, 256, "shift"), ("general", 4, 128, 128, "general"),
+                                ("general_320", 2, 320, 320, "general")):
+        g = torch.Generator().manual_seed(H + B)
+        mask = torch.ones(B, 1, H, W)
+        mask[:, :, H // 3:H // 3 + 20, W // 4:W // 4 + 50] = 0.0
+        mask[:, :, :, -9:] = 0.0
+        inv_h = torch.eye(3).repeat(B, 1, 1)
+        if kind == "shift":
+            inv_h[:, 0, 2] = 2.0 * 16 / (W - 1)
+            inv_h[:, 1, 2] = -2.0 * 8 / (H - 1)
+        elif kind == "general":
+            inv_h = inv_h + (torch.rand(B, 3, 3, generator=g) - 0.5) * torch.tensor([[0.2, 0.2, 0.3], [0.2, 0.2, 0.3], [0.05, 0.05, 0.0]])
+        cases.append((name, kind, mask, inv_h.contiguous()))
+    return cases
+
+
+@pytest.mark.parametrize("idx", range(4))
+def test_cell_validity_and_matches_against_the_reference_fixture(cuda, idx):
+    """yp_nce_cells against tests/golden/nce_cells.npz: the valid-cell mask and the rounded warped cell coordinates produced by the
+    REFERENCE's own functions (warp_image_batch / getMasks / homography_scaling / warp_points, utils/loss_functions.py:499-523, imported in
+    tests/golden/make_golden.py::gen_nce_cells).  Exact for the identity and for a translation by whole pixels; under a general homography a
+    cell whose pixel coordinate sits within one fp32 rounding of a .5 boundary may land on the other side: <= 0.1 % of the cells."""
+    import os
+    import numpy as np
+    name, kind, mask, inv_h = _fixture_cases()[idx]
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nce_cells.npz"))
+    assert np.array_equal(gold[name + ".inv_h"], inv_h.numpy())           # same inputs as the generator's
+    B, _, H, W = mask.shape
+    Nc = (H // 8) * (W // 8)
+    ref_valid = torch.from_numpy(np.unpackbits(gold[name + ".valid"], axis=-1)[:, :Nc].astype(np.bool_))
+    ref_uvb = torch.from_numpy(gold[name + ".uv_b"].astype(np.float32))
+    valid, uvb = _cells(mask.to(cuda), inv_h.to(cuda))
+    valid, uvb = valid.bool().cpu(), uvb.cpu()
+    bad_v = int((valid != ref_valid).sum())
+    # coordinates matter where the reference keeps the cell (the others are dropped by the mask)
+    bad_u = int(((uvb != ref_uvb).any(-1) & ref_valid).sum())
+    total = valid.numel()
+    if kind == "general":
+        assert bad_v <= 1e-3 * total and bad_u <= 1e-3 * total, (name, bad_v, bad_u, total)
+    else:
+        assert bad_v == 0 and bad_u == 0, (name, bad_v, bad_u)
+
+
 def test_uniform_draw_of_the_matched_cells(cuda):
     B, Hc, Wc, samples = 3, 12, 16, 40
     Nc = Hc * Wc
