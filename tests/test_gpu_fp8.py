@@ -329,8 +329,8 @@ class _FakeQuantTraining:
 FP8_GRAD = dict(median=1.15, p90=1.15, worst=1.25, worst_abs=0.05, cosine=0.5)
 
 
-def test_fp8_parameter_gradients_against_the_fake_quantised_oracle(cuda):
-    """All parameter gradients of YOLOPoint-l with fp8 Conv operands (forward e4m3 x e4m3, dgrad e5m2 x e4m3, 16-bit weight gradients)
+def _fp8_gradient_check(cuda, version, B, S, seed, min_q8, min_stable):
+    """All parameter gradients of YOLOPoint-<version> with fp8 Conv operands (forward e4m3 x e4m3, dgrad e5m2 x e4m3, 16-bit weight gradients)
     against PyTorch autograd through the oracle with the same rule (_FakeQuantTraining).  e4m3 / e5m2 rounding is discontinuous, so two
     PyTorch statements of the same network that differ only by bf16 storage between layers already end far apart; that distance is the
     floor, and the product -- which IS the bf16-storage variant -- must sit within 1.15x of it on the median and the 90th percentile of
@@ -340,7 +340,6 @@ def test_fp8_parameter_gradients_against_the_fake_quantised_oracle(cuda):
     from helpers import make_model, rel_err
     from oracle import net_oracle
     from yolopoint_amd.models.common import invalidate_packed_weights
-    version, B, S, seed = "s", 4, 128, 41
     m, sd = make_model(version, seed, dtype="bf16")
     m = m.to(cuda).train()
     m.model.fp8_train = True
@@ -363,7 +362,7 @@ def test_fp8_parameter_gradients_against_the_fake_quantised_oracle(cuda):
         net_oracle.projected_loss(out, proj, cuda).backward()
         invalidate_packed_weights()
     graph = next(iter(m.model._train_graphs.values()))[0]
-    assert graph.fp8 and graph.n_q8 >= 60, graph.n_q8     # forward AND dgrad convolutions ran on 8-bit operands
+    assert graph.fp8 and graph.n_q8 >= min_q8, graph.n_q8     # forward AND dgrad convolutions ran on 8-bit operands
     ref, floor_leaf = grads[None], grads[torch.bfloat16]
     hip, floor, cosines = [], [], []
     cosine = lambda a, b: float(torch.nn.functional.cosine_similarity(a.detach().cpu().flatten().double(), b.detach().cpu().flatten().double(), dim=0))
@@ -389,6 +388,36 @@ def test_fp8_parameter_gradients_against_the_fake_quantised_oracle(cuda):
     stable = [(c_hip, c_floor, name) for c_hip, c_floor, name in cosines if c_floor >= 0.8]
     print(f"{len(stable)} of {n} tensors keep their direction in the floor (cosine >= 0.8); lowest HIP cosine among them "
           f"{min((c[0] for c in stable), default=1.0):.3f}")
-    assert len(stable) >= 4
+    assert len(stable) >= min_stable
     for c_hip, c_floor, name in stable:
         assert c_hip >= c_floor - 0.1, (name, c_hip, c_floor)
+    return graph
+
+
+def test_fp8_parameter_gradients_against_the_fake_quantised_oracle(cuda):
+    """YOLOPoint-s, 4 x 128 x 128 (see _fp8_gradient_check)."""
+    _fp8_gradient_check(cuda, "s", 4, 128, 41, min_q8=60, min_stable=4)
+
+
+def test_fp8_gradients_of_yolopoint_l_through_the_block_scaled_kernels(cuda, monkeypatch):
+    """The same check on YOLOPoint-l (configs[4]'s model: every channel count a multiple of 64, most of 128) at 2 x 128 x 128 with the
+    autotuner restricted to tile 57 -- the 8-wave kernel on block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 -- so that every forward and
+    dgrad convolution it applies to (C % 128 == 0) runs THROUGH it inside a whole training step (the other layers take the library's default
+    tile); the byte-level tests cover that kernel in isolation only.  Asserts that those signatures really were served by tile 57."""
+    from yolopoint_amd import plan, _hip
+    monkeypatch.setattr(plan, "_TUNE_CANDIDATES", (57,))
+    saved = dict(plan._TUNE_CACHE)
+    plan._TUNE_CACHE.clear()
+    try:
+        graph = _fp8_gradient_check(cuda, "l", 2, 128, 43, min_q8=100, min_stable=4)
+        q8_keys = [k for k in plan._TUNE_CACHE if k[0] in (_hip.YP_FP8, _hip.YP_FP8_BF8)]
+        served = [k for k in q8_keys if plan._TUNE_CACHE[k][0] == 57]
+        fwd57 = [k for k in served if k[0] == _hip.YP_FP8]
+        bwd57 = [k for k in served if k[0] == _hip.YP_FP8_BF8]
+        print(f"8-bit convolution signatures: {len(q8_keys)}, served by the block-scaled tile 57: {len(fwd57)} forward (e4m3 x e4m3), {len(bwd57)} dgrad (e5m2 x e4m3)")
+        assert len(fwd57) >= 8 and len(bwd57) >= 8, (len(fwd57), len(bwd57), len(q8_keys))
+        assert graph.n_q8 >= 100
+    finally:
+        plan._TUNE_CACHE.clear()
+        plan._TUNE_CACHE.update(saved)
+
