@@ -4,6 +4,6 @@ cd /tmp
 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_inf -o t -- python $ROOT/bench.py --no-cpu-baseline --only none --steps 20 --warmup 5 > $OUT/trace_inf.log 2>&1
 cd $ROOT
 f=$(find $OUT/trace_inf -name "*kernel_trace.csv" | head -1)
-python tools/probe/infer_sequence.py $f > $OUT/infer_sequence.txt
+python tools/infer_sequence.py $f > $OUT/infer_sequence.txt
 cp $f $OUT/infer_trace.csv; rm -rf $OUT/trace_inf
 cat $OUT/infer_sequence.txt

@@ -15,6 +15,8 @@ python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 python bench.py --no-cpu-baseline --only none --steps 300 --warmup 30 --layers $OUT/layers.txt > $OUT/bench_long.json 2>> $OUT/bench_default.err
 cd /tmp
 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o t -- $BENCH > $OUT/trace.log 2>&1
+# one forward in start order (start offset, duration, overlap with the other lane): the two-lane schedule as it ran
+python $ROOT/tools/infer_sequence.py $(find $OUT/trace -name "*kernel_trace.csv" | head -1) 50 > $OUT/${R}_infer_sequence.txt 2>/dev/null
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o f -- $BENCH > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o w -- $BENCH > $OUT/pmc_write.log 2>&1
 # MFMA utilisation: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 4 SIMDs x 256 CUs); eager replay so that the dispatch order is the plan order
