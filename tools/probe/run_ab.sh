@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for i in 1 2 3; do
-YP_SIDE_PRIORITY=0 python bench.py --no-cpu-baseline --only none 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('side default prio', d['ms_per_step'])"
-python bench.py --no-cpu-baseline --only none 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('side lowest prio ', d['ms_per_step'])"
-done
+for b in 1 2 4; do
+for cfg in "YP_INFER_LANES=0" "YP_LANES_EAGER=0" "YP_LANES_EAGER=1"; do
+env $cfg python bench.py --no-cpu-baseline --only none --batch $b 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('batch', $b, '$cfg', d['ms_per_step'], d['value'])"
+done; done
