@@ -643,7 +643,7 @@ def run_frame(dev, version, S, dtype, steps, warmup, cpu_threads=None):
     from yolopoint_amd.models.model_wrap import PointTracker
     from yolopoint_amd.utils.synthetic import synth_image
     m, _ = build_model(version, dtype, dev)
-    m.model.use_graph = True          # the forward as one hipGraph replay (its independent head branches run side by side), as the headline record
+    m.model.use_graph = True          # (two-lane plans replay eagerly on two streams, as the headline record; the keypoint decode / NMS hang into the side lane)
     fe = YoloPointFrontend(m, dev, yolo_config=dict(conf_thres_box=0.25, iou_thres_box=0.45, max_det=300), filter_pts=True)
     frames = [synth_image(1, 3, S, S, 100 + i).to(dev) for i in range(4)]
     # Seeded random heads saturate (every pixel a keypoint, every anchor a box), which is not the load of a trained model: the
@@ -661,17 +661,7 @@ def run_frame(dev, version, S, dtype, steps, warmup, cpu_threads=None):
         semis.append(torch.from_numpy(np.log(np.concatenate((cells, dust), 0) + 1e-12).astype(np.float32))[None].to(dev))
         preds.append(torch.from_numpy(planted_predictions(1, nrows, 80, 2000, 20 + i, img=S)).to(dev))
 
-    class PlantedHeads(torch.nn.Module):          # the real forward, then the planted semi / pred (the descriptors stay the model's)
-        def __init__(self, model):
-            super().__init__()
-            self.model, self.i = model, 0
-
-        def forward(self, x):
-            o = self.model(x)
-            k = self.i % len(semis)
-            self.i += 1
-            return {"semi": semis[k], "desc": o["desc"], "objects": (preds[k], o["objects"][1])}
-    fe.model = PlantedHeads(m)
+    fe.planted = list(zip(semis, preds))          # the real forward, then the planted semi / pred feed the post-processing (the descriptors stay the model's)
     tr = PointTracker()
     prev = [None]
     stats = {}

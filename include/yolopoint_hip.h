@@ -656,6 +656,12 @@ int yp_plan_graph_is_parallel(const YpPlan* plan);
  * plan always joins.  The caller guarantees that no later main-lane op touches what a side op reads or writes. */
 enum { YP_LANE_MAIN = 0, YP_LANE_SIDE = 1, YP_LANE_JOIN = 2 };
 int yp_plan_set_lane(YpPlan* plan, int op, int lane);
+/* A callback op: when the replay reaches it, fn(user, stream) runs on the host and may enqueue launches of its own on `stream` (the op's lane).
+ * Replaces the host-side sequencing of reference demo.py:138-160 (forward -> numpy decode -> NMS): the keypoint post-processing needs the
+ * keypoint head only, so the front end (yolopoint_amd/frontend.py) hangs it into the forward's side lane.  A plan with callback ops cannot
+ * be captured into a hipGraph (yp_plan_instantiate_graph refuses); it replays eagerly.  fn returns YP_OK or an error code. */
+typedef int (*yp_plan_callback_t)(void* user, void* stream);
+int yp_plan_add_callback(YpPlan* plan, yp_plan_callback_t fn, void* user);
 /* capture the op list into a hipGraph on `stream` (call once, after the last add) */
 int yp_plan_instantiate_graph(YpPlan* plan, void* stream);
 /* enqueue all ops (graph launch when instantiated) */

@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for b in 1 2 4; do
-for cfg in "YP_INFER_LANES=0" "YP_LANES_EAGER=0" "YP_LANES_EAGER=1"; do
-env $cfg python bench.py --no-cpu-baseline --only none --batch $b 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('batch', $b, '$cfg', d['ms_per_step'], d['value'])"
+for m in "" 55555555 0000ffff 33333333 0f0f0f0f 77777777 00ffffff; do
+for h in 2 4; do
+YP_SIDE_CUMASK=$m python bench.py --no-cpu-baseline --only none 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('cumask', '$m' or 'none', d['ms_per_step'])"
 done; done

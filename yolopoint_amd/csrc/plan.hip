@@ -27,7 +27,7 @@ extern "C" int yp_device_count(void) {
     return n;
 }
 
-enum OpKind { OP_CONV = 0, OP_SPPF = 1, OP_L2NORM = 2, OP_DETECT = 3, OP_GENERIC = 4 };
+enum OpKind { OP_CONV = 0, OP_SPPF = 1, OP_L2NORM = 2, OP_DETECT = 3, OP_GENERIC = 4, OP_CALLBACK = 5 };
 
 struct PlanOp {
     int kind;
@@ -43,6 +43,8 @@ struct PlanOp {
     float* z_out;
     bool has_deps = false;
     std::vector<int> deps;      // earlier op indices this op must wait for (true data dependencies)
+    yp_plan_callback_t cb = nullptr;    // OP_CALLBACK: the caller's function enqueues its own launches on the op's stream
+    void* cb_user = nullptr;
     int lane = YP_LANE_MAIN;    // YP_LANE_SIDE: runs beside the ops that follow it; YP_LANE_JOIN: waits for every side op first
 };
 
@@ -65,6 +67,11 @@ static int run_op(const PlanOp& op, hipStream_t st) {
                                     op.row_offset, st);
     }
     if (op.kind == OP_GENERIC) return yp_run_op(&op.gen, st);
+    if (op.kind == OP_CALLBACK) {
+        const int rc = op.cb(op.cb_user, (void*)st);
+        if (rc != YP_OK) yp_set_error("plan: a callback op returned %d", rc);
+        return rc;
+    }
     yp_set_error("plan: unknown op kind %d", op.kind);
     return YP_ERR_INVALID;
 }
@@ -157,6 +164,21 @@ extern "C" int yp_plan_add_op(YpPlan* plan, const YpOpArgs* a) {
     return YP_OK;
 }
 
+// A callback op: when the replay reaches it, `fn(user, stream)` is called on the host and may enqueue launches of its own on `stream` (the
+// lane's stream).  For work that belongs INSIDE the schedule of a plan without being a plan op -- the frame pipeline's keypoint
+// post-processing, which only needs the keypoint head and runs on the side lane beside the rest of the forward.  Plans with callback ops
+// replay eagerly (a capture would freeze the launches the callback made at capture time).
+extern "C" int yp_plan_add_callback(YpPlan* plan, yp_plan_callback_t fn, void* user) {
+    YP_PLAN_MUTABLE(plan);
+    YP_REQUIRE(fn != nullptr, "yp_plan_add_callback: null function");
+    PlanOp op{};
+    op.kind = OP_CALLBACK;
+    op.cb = fn;
+    op.cb_user = user;
+    plan->ops.push_back(op);
+    return YP_OK;
+}
+
 extern "C" int yp_plan_num_ops(const YpPlan* plan) { return plan ? (int)plan->ops.size() : 0; }
 
 // The side lane of every plan of a device is ONE stream, created on first use and kept for the life of the process: plans come and go by
@@ -186,33 +208,55 @@ static int ensure_side(YpPlan* plan) {
 // graph edges, so the side ops form a parallel branch of the hipGraph.  Used by the training backward: the weight-gradient
 // kernels (one workgroup per CU, atomics-bound) run beside the dgrad / BatchNorm-backward chain, which never reads their output.
 static int run_eager(YpPlan* plan, hipStream_t st) {
-    bool pending = false;
+    bool pending = false;               // side work in flight that the main lane has not joined
     bool main_since_fork = true;        // a side op forks again only when the main lane has moved since the last fork: consecutive side ops are
                                         // ordered by their own stream.  (Not only an economy: captured into a hipGraph, a main-lane node with many
                                         // outgoing cross-stream edges -- every side op re-forking from the same position -- lost its SAME-stream
                                         // successor edge at replay on ROCm 7.2: the next main op ran before it.)
+    // ENQUEUE order.  A run of side ops waits for the fork event recorded where the run starts in the op list, but its launches are handed to
+    // the runtime ALTERNATELY with the main-lane ops that follow (one side op behind each main op; the rest when the next run / join / end
+    // comes).  When the host is a whole step ahead of the device the order is irrelevant; when every frame ends in a host read-back (the
+    // frame pipeline) the device executes launches almost as they arrive, and a block of ten side launches enqueued in one go left the main
+    // lane empty meanwhile: the lanes took turns instead of overlapping.
+    std::vector<const PlanOp*> queued;
+    auto issue_one = [&]() -> int {
+        const PlanOp* q = queued.front();
+        queued.erase(queued.begin());
+        return run_op(*q, plan->side);
+    };
+    auto flush = [&]() -> int {
+        while (!queued.empty())
+            if (int rc = issue_one()) return rc;
+        return YP_OK;
+    };
     for (const PlanOp& op : plan->ops) {
         if (op.lane == YP_LANE_SIDE) {
             if (int rc = ensure_side(plan)) return rc;
             if (main_since_fork) {
+                if (int rc = flush()) return rc;           // (earlier side work keeps its place in the side stream's order)
                 YP_CHECK_HIP(hipEventRecord(plan->fork, st));
                 YP_CHECK_HIP(hipStreamWaitEvent(plan->side, plan->fork, 0));
                 main_since_fork = false;
+                if (int rc = run_op(op, plan->side)) return rc;    // the first op of a run goes out at once
+            } else {
+                queued.push_back(&op);
             }
-            const int rc = run_op(op, plan->side);
-            if (rc != YP_OK) return rc;
             pending = true;
             continue;
         }
         main_since_fork = true;
         if (op.lane == YP_LANE_JOIN && pending) {
+            if (int rc = flush()) return rc;
             YP_CHECK_HIP(hipEventRecord(plan->join, plan->side));
             YP_CHECK_HIP(hipStreamWaitEvent(st, plan->join, 0));
             pending = false;
         }
         const int rc = run_op(op, st);
         if (rc != YP_OK) return rc;
+        if (!queued.empty())
+            if (int rc2 = issue_one()) return rc2;
     }
+    if (int rc = flush()) return rc;
     if (pending) {
         YP_CHECK_HIP(hipEventRecord(plan->join, plan->side));
         YP_CHECK_HIP(hipStreamWaitEvent(st, plan->join, 0));
@@ -250,6 +294,7 @@ extern "C" int yp_plan_instantiate_graph(YpPlan* plan, void* stream) {
     YP_REQUIRE(plan->exec == nullptr, "yp_plan_instantiate_graph: already instantiated");
     hipStream_t st = (hipStream_t)stream;
     YP_REQUIRE(st != nullptr, "yp_plan_instantiate_graph: capture needs a non-default stream");
+    for (const PlanOp& op : plan->ops) YP_REQUIRE(op.kind != OP_CALLBACK, "yp_plan_instantiate_graph: a plan with callback ops replays eagerly");
     const size_t n = plan->ops.size();
     for (const PlanOp& op : plan->ops)
         if (op.lane == YP_LANE_SIDE) { if (int rc = ensure_side(plan)) return rc; break; }     // (no stream creation inside a capture)

@@ -29,6 +29,14 @@ class YoloPointFrontend:
         self.sp_config = dict(SP_DEFAULT, **(sp_config or {}))
         self.yolo_config = dict(YOLO_DEFAULT, **(yolo_config or {}))
         self.filter_pts, self.border_remove, self.cell = filter_pts, border_remove, cell
+        # benchmarking aid: a list of (semi [1,65,Hc,Wc], pred [1,rows,no]) device tensors fed to the post-processing IN PLACE of the model's
+        # keypoint / Detect outputs, frame i taking entry i % len (random-weight heads saturate: SURVEY.md 8d); the forward still runs in full
+        self.planted, self._frame = None, 0
+        # the keypoint post-processing hangs into the forward's side lane (see process_tensor) when the model is this package's YOLOPoint
+        net = getattr(self.model, "model", None)
+        self._net = net if hasattr(net, "_emit_heads_hook") else None
+        if self._net is not None:
+            self._net.heads_hook = True
 
     # -- demo.py:111-121: make both dims divisible by 32 by a centred crop
     @staticmethod
@@ -50,26 +58,55 @@ class YoloPointFrontend:
         if inp.dim() != 4 or inp.shape[0] != 1:
             raise _hip.YpError("YoloPointFrontend.process_tensor: one frame per call ([1,3,H,W])")
         l, st, dev = _hip.lib(), _hip.stream_ptr(), inp.device
-        outs = self.model(inp)
-        semi, coarse, (pred, _) = outs["semi"], outs["desc"], outs["objects"]
-        B, _, Hc, Wc = semi.shape
-        H, W = Hc * 8, Wc * 8
-        # keypoints: demo softmax -> heat map -> threshold, grid NMS, border removal, sort by confidence
+        _, _, H, W = inp.shape
+        Hc, Wc = H // 8, W // 8
         heat = torch.empty((1, H, W), dtype=torch.float32, device=dev)
-        sb, sc, sy, sx = semi.stride()
-        _hip.check(l.yp_kp_decode(semi.data_ptr(), 1, Hc, Wc, sb, sc, sy, sx, 1, heat.data_ptr(), st))
         radius = int(self.sp_config["nms"])
         step = radius + 1
         max_pts = max(1, -(-H // step) * -(-W // step))
         pts = torch.empty((max_pts, 3), dtype=torch.float32, device=dev)
         counts = torch.zeros((5,), dtype=torch.int32, device=dev)   # [points after NMS, boxes, points after filtering, NMS candidates left undecided, pixels >= threshold]
         ws = workspace(dev, l.yp_kp_nms_workspace_bytes(1, H, W), "kp_nms")
-        kp_args = (heat.data_ptr(), 1, H, W, float(self.sp_config["detection_threshold"]), radius, int(self.border_remove), pts.data_ptr(),
-                   counts.data_ptr(), max_pts, ws.data_ptr(), ws.numel())
-        if sync_nms:
-            _hip.check(l.yp_kp_nms(*kp_args, st))
-        else:       # a fixed number of fix-point rounds, no host synchronisation inside; convergence is checked with the frame's counters
-            _hip.check(l.yp_kp_nms_async(*kp_args, self.NMS_ROUNDS, counts[3:4].data_ptr(), st))
+        planted = self.planted[self._frame % len(self.planted)] if self.planted else None
+        self._frame += 1
+
+        def keypoints(semi, stream):
+            """demo softmax -> heat map -> threshold, grid NMS, border removal, sort by confidence, on `stream`"""
+            sb, sc, sy, sx = semi.stride()
+            _hip.check(l.yp_kp_decode(semi.data_ptr(), 1, Hc, Wc, sb, sc, sy, sx, 1, heat.data_ptr(), stream))
+            kp_args = (heat.data_ptr(), 1, H, W, float(self.sp_config["detection_threshold"]), radius, int(self.border_remove), pts.data_ptr(),
+                       counts.data_ptr(), max_pts, ws.data_ptr(), ws.numel())
+            if sync_nms:
+                _hip.check(l.yp_kp_nms(*kp_args, stream))
+            else:       # a fixed number of fix-point rounds, no host synchronisation inside; convergence is checked with the frame's counters
+                _hip.check(l.yp_kp_nms_async(*kp_args, self.NMS_ROUNDS, counts[3:4].data_ptr(), stream))
+
+        # The keypoint post-processing needs the keypoint head only.  A YOLOPoint plan with `heads_hook` calls back from its SIDE lane once the
+        # heads are enqueued there (models/YOLOPoint.py::_emit_heads_hook): decode + NMS (~0.35 ms at 1280 x 1280) then run beside the YOLO
+        # encoder / PAN chain of the forward instead of behind it; the plan's join orders them before everything below.
+        net = self._net
+        fired = []
+        if net is not None and not sync_nms:
+            def hook(stream):
+                if planted is not None:
+                    semi_ = planted[0]
+                else:
+                    v = next(iter(net._plans.values()))[2]["semi"]
+                    semi_ = v.buf.t[..., :65].permute(0, 3, 1, 2)
+                keypoints(semi_, C.c_void_p(stream))
+                fired.append(True)
+            net._heads_cb = hook
+        try:
+            outs = self.model(inp)
+        finally:
+            if net is not None:
+                net._heads_cb = None
+        semi, coarse, (pred, _) = outs["semi"], outs["desc"], outs["objects"]
+        if planted is not None:
+            semi, pred = planted
+        assert tuple(semi.shape[-2:]) == (Hc, Wc)
+        if not fired:
+            keypoints(semi, st)
         # boxes: multi-label, class-agnostic NMS as the demo calls it (demo.py:168-174)
         p = pred if (pred.dtype == torch.float32 and pred.is_contiguous()) else pred.float().contiguous()
         N, no = p.shape[1], p.shape[2]
@@ -93,6 +130,7 @@ class YoloPointFrontend:
         counts[4:5].copy_(ws[off:off + 4].view(torch.int32))
         n_nms, n_box, n_pts, undecided, n_cand = counts.cpu().tolist()            # the frame's only host sync
         if undecided:                                                              # the greedy NMS needed more rounds than enqueued: redo with the
+            self._frame -= 1                                                       # (same planted entry, if any)
             return self.process_tensor(inp, sync_nms=True)                         # converging variant (not seen on real or planted heat maps)
         if n_box < 0:
             raise _hip.YpError("YoloPointFrontend: box NMS candidate list overflowed its workspace")

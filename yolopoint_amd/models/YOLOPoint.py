@@ -128,6 +128,7 @@ class YOLOPoint(HipModule):
             desc = pb.conv(d, self.ConvDesc.weight.detach().float(), None, 3, 1, 1, _hip.YP_ACT_NONE, out_f32=True)
             pb.l2norm(desc, desc, self.ConvDesc.out_channels)
             pb.scope.pop()
+            self._emit_heads_hook(pb)
         x = run("SPPooling", self.SPPooling, x)
         # PAN head; every Detect level right behind the block it reads
         pb.scope.append("Detect")
@@ -153,6 +154,13 @@ class YOLOPoint(HipModule):
         z, xs = det["z"], det["outs"]
         return {"semi": semi, "desc": desc, "z": z, "xs": xs}
 
+    def _emit_heads_hook(self, pb):
+        """`heads_hook = True` (set by frontend.YoloPointFrontend): a callback op behind the keypoint / descriptor heads on the side lane.  At
+        replay it calls `self._heads_cb(stream)` if one is set -- the front end enqueues the keypoint decode / NMS there, so that the post-
+        processing that needs `semi` only runs beside the YOLO encoder / PAN chain instead of behind the whole forward."""
+        if getattr(self, "heads_hook", False):
+            pb.callback(lambda stream: (self.__dict__.get("_heads_cb") or (lambda s_: None))(stream), "heads_hook")
+
     def build_plan(self, B, H, W, device, graph=False):
         """Build (and cache) the native plan for a [B, inp_ch, H, W] input."""
         if H % 32 or W % 32:
@@ -160,7 +168,7 @@ class YOLOPoint(HipModule):
         if self.Detect.stride is None:
             raise _hip.YpError("Detect.stride is not set (construct through models.Model)")
         code = _hip.dtype_code(self.compute_dtype)
-        key = (B, H, W, code, self.training, self._weights_version(), torch.device(device).index, bool(graph))
+        key = (B, H, W, code, self.training, self._weights_version(), torch.device(device).index, bool(graph), bool(getattr(self, "heads_hook", False)))
         cache = self.__dict__.setdefault("_plans", {})
         if key not in cache:
             cache.clear()
@@ -173,7 +181,7 @@ class YOLOPoint(HipModule):
             # A plan with schedule lanes replays EAGERLY on its two streams even when a graph was asked for: captured into a hipGraph the
             # side branch bought 0-4 % (0.743 vs 0.752 ms at batch 8), the same launches on two plain streams 8 % (0.691 ms) -- the ~50
             # launches of a forward cost the host ~0.2 ms, well inside the step.  YP_LANES_EAGER=0: capture them.
-            if graph and not (plan.has_lanes and __import__("os").environ.get("YP_LANES_EAGER", "1") != "0"):
+            if graph and not plan.has_callbacks and not (plan.has_lanes and __import__("os").environ.get("YP_LANES_EAGER", "1") != "0"):
                 plan.instantiate_graph()
             cache[key] = (plan, img, outs)
         return cache[key]
@@ -311,6 +319,7 @@ class YOLOPointv52(YOLOPoint):
             pb.scope.append("BottleneckDesc")
             pb.l2norm(desc, desc, self._desc_channels)
             pb.scope.pop()
+            self._emit_heads_hook(pb)
         xd = run("SPPooling", self.SPPooling, x)
         pb.scope.append("Detect")
         det = self.Detect.emit_begin(pb, [(xb.LH, xb.LW), (xb.LH // 2, xb.LW // 2), (xb.LH // 4, xb.LW // 4)], decode)

@@ -218,6 +218,9 @@ def _shared_tuning_group():
     return dist, dist.get_rank()
 
 
+_CALLBACK_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+
+
 class PlanBuilder:
     """Collects launches into a native YpPlan; owns every buffer the plan touches."""
 
@@ -575,6 +578,24 @@ class PlanBuilder:
                 self.has_lanes = True
                 self.__dict__.setdefault("side_ops", set()).add(j)
 
+    def callback(self, fn, name="callback"):
+        """Append a callback op: at replay `fn(stream_ptr)` is called (stream_ptr: the raw HIP stream of the op's lane as an int) and may
+        enqueue launches of its own there.  Plans with callbacks replay eagerly (ExecPlan.instantiate_graph is skipped by the callers)."""
+        def tramp(user, stream):
+            try:
+                fn(int(stream or 0))
+                return 0
+            except Exception as e:               # an exception cannot cross the C frame: keep it for the caller of run()
+                self.callback_error = e
+                return -1
+        cfn = _CALLBACK_T(tramp)
+        self.keep.append(cfn)
+        self.__dict__.setdefault("callbacks", []).append(cfn)
+        check(lib().yp_plan_add_callback(self.handle, C.cast(cfn, C.c_void_p), None))
+        self._track([], [])
+        self.records.append(OpRecord(self.name(name), "aux"))
+        self.has_callbacks = True
+
     def set_lane(self, lane):
         """Put the op added last on a schedule lane (_hip.LANE_SIDE: beside the following ops; _hip.LANE_JOIN: after all side ops)."""
         check(lib().yp_plan_set_lane(self.handle, lib().yp_plan_num_ops(self.handle) - 1, lane))
@@ -730,6 +751,8 @@ class ExecPlan:
         self.refreshers = pb.refreshers
         self.graph = False
         self.has_lanes = bool(getattr(pb, "has_lanes", False))     # ops on the side lane: replays on two streams (graph: a forked branch)
+        self.has_callbacks = bool(getattr(pb, "has_callbacks", False))
+        self._pb = pb if self.has_callbacks else None              # (callback trampolines report exceptions through the builder)
         self.parallel = self.has_lanes
 
     def num_ops(self):
@@ -756,7 +779,11 @@ class ExecPlan:
             fn()
 
     def run(self, stream=None):
-        check(lib().yp_plan_run(self.handle, _hip.stream_ptr(stream)))
+        rc = lib().yp_plan_run(self.handle, _hip.stream_ptr(stream))
+        if rc != 0 and self._pb is not None and getattr(self._pb, "callback_error", None) is not None:
+            e, self._pb.callback_error = self._pb.callback_error, None
+            raise e
+        check(rc)
 
     def profile(self, stream=None):
         n = self.num_ops()
