@@ -222,6 +222,40 @@ def test_all_parameter_gradients_bf16(cuda, version, B, S):
     assert hm <= BF16_REL["median"] * tm and h9 <= BF16_REL["p90"] * t9 and hw <= BF16_REL["worst"] * tw + BF16_REL["worst_abs"]
 
 
+def test_config2_gradient_spot_check_8x640(cuda):
+    """configs[2] at ITS shape: YOLOPoint-s, 8 samples of 640 x 640 per GPU, bf16 -- the plans, tiles and BatchNorm group sizes the training
+    benchmark runs (the all-parameter test above runs at 4 x 128 x 128, where the autotuner picks other kernels).  Ten parameter tensors
+    spread over the network (stem, each backbone stage, PAN, the three heads) against fp32 CPU autograd through the oracle: every sampled
+    gradient points the way of the fp32 one (cosine > 0.8) and stays inside the bf16 noise measured at the small shape (relative L2 <= 0.6,
+    the worst small-shape tensor being 0.45-0.55); the train-mode head outputs agree to 2.5e-2."""
+    version, B, S, seed = "s", 8, 640, 52
+    m, sd = make_model(version, seed, dtype="bf16")
+    m = m.to(cuda).train()
+    x = net_oracle.synth_image(B, 3, S, S, seed)
+    torch.set_num_threads(min(32, torch.get_num_threads() or 8))
+    leaf = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in sd.items()}
+    o = net_oracle.yolopoint_forward(leaf, x, version, training=True, stats={})
+    proj = net_oracle.output_projections(o, seed)
+    net_oracle.projected_loss(o, proj).backward()
+    out = m(x.to(cuda))
+    for k in ("semi", "desc"):
+        assert rel_err(out[k], o[k])[1] < 2.5e-2, k
+    net_oracle.projected_loss(out, proj, cuda).backward()
+    params = dict(m.named_parameters())
+    names = ["model.Conv1.conv.weight", "model.Conv2.conv.weight", "model.Bottleneck1.m.0.cv2.conv.weight", "model.Conv3.bn.weight",
+             "model.Bottleneck2.cv3.conv.weight", "model.Bottleneck3.m.1.cv1.conv.weight", "model.SPPooling.cv2.conv.weight",
+             "model.Bottleneck6.cv1.conv.weight", "model.ConvDesc.weight", "model.Detect.m.1.weight"]
+    rows = []
+    for name in names:
+        g, g32 = params[name].grad, leaf[name].grad
+        assert g is not None and torch.isfinite(g).all(), name
+        cos = float(torch.nn.functional.cosine_similarity(g.detach().cpu().flatten().double(), g32.flatten().double(), dim=0))
+        rows.append((name, rel_err(g, g32)[1], cos))
+    print("configs[2] shape, bf16 vs fp32 autograd: " + "; ".join(f"{n.replace('model.', '')} l2 {e:.3f} cos {c:.3f}" for n, e, c in rows))
+    for name, e, c in rows:
+        assert c > 0.8 and e <= 0.6, (name, e, c)
+
+
 def test_bf16_gradients_are_deterministic(cuda):
     """Two identical bf16 forward/backward passes give bit-identical parameter gradients (the weight-gradient reduction has a fixed
     order: per-workgroup partials folded by a second pass, no floating-point atomics)."""
