@@ -688,7 +688,7 @@ def run_frame(dev, version, S, dtype, steps, warmup, cpu_threads=None):
            "config": {"workload": "BASELINE.json configs[3] shape: one frame end to end, device-resident, 2 host syncs per frame (front-end counters, match count)",
                       "image": [S, S], "post_processing_inputs": "planted heat map / predictions (SURVEY.md 8d), model descriptors", **stats},
            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS.get(dtype, 2500.0), "unit": "TFLOP/s",
-                        "frac": round(achieved / PEAK_TFLOPS.get(dtype, 2500.0), 4), "traffic": None, "algorithmic_gflop_per_frame": round(gflop, 2),
+                        "frac": round(achieved / PEAK_TFLOPS.get(dtype, 2500.0), 4), "traffic": train_traffic_record("frame_" + version, S, dtype), "algorithmic_gflop_per_frame": round(gflop, 2),
                         "note": "whole frame (post-processing and host syncs included) against the forward's algorithmic conv FLOP"}}
     del fe, m
     torch.cuda.empty_cache()
