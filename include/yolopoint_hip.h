@@ -517,7 +517,9 @@ enum {
     YP_OP_BN_STATS = 10,      /* v0=raw; i0=dtype i1=B; s0=eps s1=momentum; g0=mean g1=invstd g2=running_mean g3=running_var; p0=ws n0=ws_bytes;
                                  i2=rows > 0: finalize only (yp_bn_finalize) from p1 = the partial sums a convolution wrote; i3=groups (0 = 1) */
     YP_OP_BN_APPLY = 11,      /* v0=raw v1=out v2=res; i0=dtype i1=B i2=act i3=groups; f0=mean f1=invstd f2=gamma f3=beta; v3=1-byte twin (ptr NULL: none) g2=its scale g3=its amax */
-    YP_OP_BN_BWD = 12,        /* v0=raw v1=dy v2=dx; i0=dtype i1=B i2=act i3=accumulate i4=groups; f0..f3 as above; g0=dgamma g1=dbeta; p0=ws n0=ws_bytes; v3 / g2 / g3: 1-byte twin of dx as for BN_APPLY */
+    YP_OP_BN_BWD = 12,        /* v0=raw v1=dy v2=dx; i0=dtype i1=B i2=act i3=accumulate i4=groups; f0..f3 as above; g0=dgamma g1=dbeta; p0=ws n0=ws_bytes; v3 / g2 / g3: 1-byte twin of dx as for BN_APPLY;
+                               * p1 != NULL: the shortcut gradient of a Bottleneck (x + cv2(cv1(x)), models/common.py:79-89) -- a tensor of dy's geometry at p1, channel stride i5,
+                               * channel offset i6 -- receives dy (i7 = 1: accumulates it) in the same row pass */
     YP_OP_UPS2_BWD = 13,      /* v0=in v1=out; i0=dtype i1=B i2=accumulate */
     YP_OP_ADD_VIEWS = 14,     /* v0=src v1=dst; i0=dtype i1=B i2=accumulate */
     YP_OP_MAXPOOL5_BWD = 15,  /* v0=x v1=dy v2=dx; i0=dtype i1=B i2=accumulate; p0=ws n0=ws_bytes */

@@ -381,7 +381,9 @@ __global__ __launch_bounds__(256) void bn_rows_fast_kernel(const char* __restric
                                                            const float* __restrict__ gamma, const float* __restrict__ beta, int act,
                                                            const float* __restrict__ dgamma, const float* __restrict__ dbeta,
                                                            unsigned char* __restrict__ q8, int qcs, int qco, const float* __restrict__ qscale,
-                                                           float* __restrict__ qamax) {
+                                                           float* __restrict__ qamax, char* __restrict__ gsum = nullptr, int gcs = 0, int gco = 0, int gacc = 0) {
+    // gsum != nullptr (BWD only): the shortcut of a Bottleneck -- out = x + act(bn(raw)) -- hands dy on to the gradient of x unchanged:
+    // gsum[row] (+)= dy[row] in this pass, which reads dy anyway (a separate add pass re-read it: yp_add_views, 13 / 39 launches per step)
     // blockIdx.y = statistics group: M rows each, mean / invstd / dgamma / dbeta [groups][C]
     // q8 != nullptr (fp8 training): the result is ALSO written as 1-byte values q8[row * qcs + qco + c] = saturate(result / *qscale) --
     // e4m3 for the forward output (the next Conv's activation), e5m2 for the backward's dx (the dgrad's output gradient) -- and its
@@ -398,6 +400,7 @@ __global__ __launch_bounds__(256) void bn_rows_fast_kernel(const char* __restric
         if (dy != nullptr) dy += roff * dcs * esize<DT>();
         if (res != nullptr) res += roff * scs * esize<DT>();
         if (q8 != nullptr) q8 += roff * qcs;
+        if (gsum != nullptr) gsum += roff * gcs * esize<DT>();
     }
     const float qinv = q8 != nullptr ? 1.0f / qscale[0] : 0.f;
     float qmx = 0.f;
@@ -428,6 +431,20 @@ __global__ __launch_bounds__(256) void bn_rows_fast_kernel(const char* __restric
             }
         }
         store8<DT>(out, r * ocs + oco + ch * 8, o);
+        if constexpr (BWD) {
+            if (gsum != nullptr) {
+                float a8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a8[j] = g[j];
+                if (gacc) {
+                    float old8[8];
+                    load8<DT>(gsum, r * gcs + gco + ch * 8, old8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a8[j] = old8[j] + g[j];       // (same operand order as yp_add_views: dst + src)
+                }
+                store8<DT>(gsum, r * gcs + gco + ch * 8, a8);
+            }
+        }
         if (q8 != nullptr) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) qmx = fmaxf(qmx, fabsf(o[j]));
@@ -839,9 +856,20 @@ extern "C" int yp_bn_act_bwd_grouped(YpView raw, YpView dy, YpView dx, int dtype
     return yp_bn_act_bwd_grouped_q8(raw, dy, dx, dtype, B, groups, mean, invstd, gamma, beta, act, dgamma, dbeta, accumulate_param_grads, ws, ws_bytes, none, nullptr,
                                     nullptr, stream);
 }
+static int bn_act_bwd_impl(YpView raw, YpView dy, YpView dx, int dtype, int B, int groups, const float* mean, const float* invstd,
+                           const float* gamma, const float* beta, int act, float* dgamma, float* dbeta, int accumulate_param_grads,
+                           void* ws, size_t ws_bytes, YpView q8, const float* q_scale, float* q_amax, YpView gsum, int gacc, void* stream);
 extern "C" int yp_bn_act_bwd_grouped_q8(YpView raw, YpView dy, YpView dx, int dtype, int B, int groups, const float* mean, const float* invstd,
                                         const float* gamma, const float* beta, int act, float* dgamma, float* dbeta, int accumulate_param_grads,
                                         void* ws, size_t ws_bytes, YpView q8, const float* q_scale, float* q_amax, void* stream) {
+    YpView none{};
+    return bn_act_bwd_impl(raw, dy, dx, dtype, B, groups, mean, invstd, gamma, beta, act, dgamma, dbeta, accumulate_param_grads, ws, ws_bytes, q8, q_scale, q_amax,
+                           none, 0, stream);
+}
+// gsum.ptr != nullptr: the shortcut gradient gsum (+)= dy rides in the row pass (YP_OP_BN_BWD with p1 / i5..i7)
+static int bn_act_bwd_impl(YpView raw, YpView dy, YpView dx, int dtype, int B, int groups, const float* mean, const float* invstd,
+                           const float* gamma, const float* beta, int act, float* dgamma, float* dbeta, int accumulate_param_grads,
+                           void* ws, size_t ws_bytes, YpView q8, const float* q_scale, float* q_amax, YpView gsum, int gacc, void* stream) {
     if (int rc = check_view8(raw, "yp_bn_act_bwd")) return rc;
     if (int rc = check_view8(dy, "yp_bn_act_bwd")) return rc;
     if (int rc = check_view8(dx, "yp_bn_act_bwd")) return rc;
@@ -875,8 +903,11 @@ extern "C" int yp_bn_act_bwd_grouped_q8(YpView raw, YpView dy, YpView dx, int dt
         const int gf = grid_for((Mg * (raw.C / 8) + 1) / 2, 256, (size_t)(256 * 16) / groups);
         YP_DT_SWITCH(dtype, (bn_rows_fast_kernel<DT, true><<<dim3(gf, groups), 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, (const char*)dy.ptr, dy.cstride, dy.coff,
                                                                               (char*)dx.ptr, dx.cstride, dx.coff, nullptr, 0, 0, (unsigned)Mg, raw.C, lg, mean, invstd, gamma, beta,
-                                                                              act, dg, db, (unsigned char*)q8.ptr, q8.cstride, q8.coff, q_scale, q_amax)));
+                                                                              act, dg, db, (unsigned char*)q8.ptr, q8.cstride, q8.coff, q_scale, q_amax,
+                                                                              (char*)gsum.ptr, gsum.cstride, gsum.coff, gacc)));
     } else {
+        if (gsum.ptr != nullptr)
+            if (int rc = yp_add_views(dy, gsum, dtype, B, gacc, stream)) return rc;
         YP_DT_SWITCH(dtype, (bn_bwd_apply_kernel<DT><<<g, 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, (const char*)dy.ptr, dy.cstride, dy.coff,
                                                                         (char*)dx.ptr, dx.cstride, dx.coff, M, Mg, raw.C, mean, invstd, gamma, beta, act, dg, db)));
     }
@@ -1277,9 +1308,14 @@ extern "C" int yp_run_op(const YpOpArgs* a, void* stream) {
         case YP_OP_BN_APPLY:
             return yp_bn_act_apply_grouped_q8(a->v[0], a->v[1], a->v[2], dt, B, a->i[3] > 0 ? a->i[3] : 1, a->f[0], a->f[1], a->f[2], a->f[3], a->i[2], a->v[3],
                                               a->g[2], a->g[3], stream);
-        case YP_OP_BN_BWD:
-            return yp_bn_act_bwd_grouped_q8(a->v[0], a->v[1], a->v[2], dt, B, a->i[4] > 0 ? a->i[4] : 1, a->f[0], a->f[1], a->f[2], a->f[3], a->i[2], a->g[0], a->g[1],
-                                            a->i[3], a->p[0], a->n[0], a->v[3], a->g[2], a->g[3], stream);
+        case YP_OP_BN_BWD: {
+            // p1 != NULL: the shortcut gradient [B, H, W, .] at p1 with channel stride i5 / offset i6 receives (i7 = 1: accumulates) dy in the same pass
+            YpView gs{};
+            if (a->p[1] != nullptr) { gs = a->v[1]; gs.ptr = a->p[1]; gs.cstride = a->i[5]; gs.coff = a->i[6]; }
+            YP_REQUIRE(a->p[1] == nullptr || (a->i[5] % 8 == 0 && a->i[6] % 8 == 0 && a->i[5] >= a->i[6] + a->v[1].C), "YP_OP_BN_BWD: bad shortcut-gradient view");
+            return bn_act_bwd_impl(a->v[0], a->v[1], a->v[2], dt, B, a->i[4] > 0 ? a->i[4] : 1, a->f[0], a->f[1], a->f[2], a->f[3], a->i[2], a->g[0], a->g[1],
+                                   a->i[3], a->p[0], a->n[0], a->v[3], a->g[2], a->g[3], gs, a->i[7], stream);
+        }
         case YP_OP_UPS2_BWD: return yp_ups2_bwd(a->v[0], a->v[1], dt, B, a->i[2], stream);
         case YP_OP_ADD_VIEWS: return yp_add_views(a->v[0], a->v[1], dt, B, a->i[2], stream);
         case YP_OP_MAXPOOL5_BWD: return yp_maxpool5_bwd(a->v[0], a->v[1], a->v[2], dt, B, a->i[2], a->p[0], a->n[0], stream);

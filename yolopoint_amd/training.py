@@ -286,20 +286,26 @@ class TrainGraph:
             b = self.bwd
             B = b.B                  # (the plan's samples: in pair mode the image pass's B for the YOLO-branch plan -- statistics group 0)
             gy = self.gread(out)
+            fuse_res = res is not None and os.environ.get("YP_BN_BWD_RES", "1") != "0"
+            gr = None
             if res is not None:
                 gr, acc = self.gview(res)
-                b.op(_hip.OP_ADD_VIEWS, [gy, gr], [gr], "res_add", v=[gy, gr], i=[code, B, int(acc)])
+                if not fuse_res:
+                    b.op(_hip.OP_ADD_VIEWS, [gy, gr], [gr], "res_add", v=[gy, gr], i=[code, B, int(acc)])
+            # (the shortcut gradient gr (+)= gy rides in the BatchNorm backward's row pass, which reads gy anyway: p1 / i5..i7 of YP_OP_BN_BWD)
+            rs = dict(p1=gr.buf.t.data_ptr(), i567=[gr.cstride, gr.coff, int(acc)]) if fuse_res else dict(p1=None, i567=[0, 0, 0])
+            rw = [gr] if fuse_res else []
             draw = b.new_buf(raw.H, raw.W, raw.C).view()
             gw_, gb_ = self.pgrad(bn.weight), self.pgrad(bn.bias)
             dg, db = (b.new_tensor((Cp,)), b.new_tensor((Cp,))) if padded else (gw_, gb_)
             # fp8 mode: the e5m2 twin of dx (the dgrad's operand) comes out of the same pass
             tw = self.q8_produced(b, draw, 1) if (os.environ.get("YP_FP8_DGRAD", "1") != "0" and not image) else None
             if tw is None:
-                b.op(_hip.OP_BN_BWD, [raw, gy], [draw, self.T(self.ws)], "bn_act_bwd", v=[raw, gy, draw], i=[code, B, act, 0, self.bG],
-                     f=[mean, invstd, gamma, beta], g=[dg, db], p=[self.ws], n=[self.ws.numel()])
+                b.op(_hip.OP_BN_BWD, [raw, gy] + rw, [draw, self.T(self.ws)] + rw, "bn_act_bwd", v=[raw, gy, draw], i=[code, B, act, 0, self.bG] + rs["i567"],
+                     f=[mean, invstd, gamma, beta], g=[dg, db], p=[self.ws, rs["p1"]], n=[self.ws.numel()])
             else:
-                b.op(_hip.OP_BN_BWD, [raw, gy], [draw, self.T(self.ws), tw[0]], "bn_act_bwd", v=[raw, gy, draw, tw[0]], i=[code, B, act, 0, self.bG],
-                     f=[mean, invstd, gamma, beta], g=[dg, db, tw[1], tw[2]], p=[self.ws], n=[self.ws.numel()])
+                b.op(_hip.OP_BN_BWD, [raw, gy] + rw, [draw, self.T(self.ws), tw[0]] + rw, "bn_act_bwd", v=[raw, gy, draw, tw[0]],
+                     i=[code, B, act, 0, self.bG] + rs["i567"], f=[mean, invstd, gamma, beta], g=[dg, db, tw[1], tw[2]], p=[self.ws, rs["p1"]], n=[self.ws.numel()])
             if padded:
                 self.collect.append(lambda dg=dg, db=db, gw_=gw_, gb_=gb_: (gw_.copy_(dg[:Cc]), gb_.copy_(db[:Cc])))
             self.conv_backward(srcs, conv.weight, None, draw, k, s, p)
