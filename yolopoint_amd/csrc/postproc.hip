@@ -269,15 +269,16 @@ __device__ __forceinline__ u64 box_key(float conf, unsigned id) {
 }
 
 // (block-aggregated like kp_threshold_kernel: a workgroup counts the candidates of its row span, reserves its slice of the key list
-// with one atomic and writes it in a second walk over the rows that passed the objectness test.)  grid = (BOX_SPANS, B)
-constexpr int BOX_SPANS = 128;
+// with one atomic and writes it in a second walk over the rows that passed the objectness test.)  grid = (spans, B): 128 row spans per image,
+// 512 for a single image (one frame of the frame pipeline: 128 workgroups walked the 34 MB of [1, 100800, 85] at 0.9 TB/s)
+static inline int box_spans(int B) { return B >= 4 ? 128 : (B == 1 ? 512 : 256); }
 __global__ __launch_bounds__(256) void box_candidates_kernel(const float* __restrict__ pred, int B, int N, int nc, float conf_thres, int multi_label,
                                                              const unsigned* __restrict__ class_mask, u64* __restrict__ keys, int cap, int* __restrict__ count) {
     __shared__ int wave_cnt[4];
     __shared__ int base_s;
     const int no = nc + 5;
     const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int span = (N + BOX_SPANS - 1) / BOX_SPANS;
+    const int span = (N + (int)gridDim.x - 1) / (int)gridDim.x;
     const int r0 = blockIdx.x * span, r1 = min(r0 + span, N);
     const float* pb = pred + (long)b * N * no;
     auto visit = [&](int row, int& pos, bool write) {
@@ -919,7 +920,7 @@ extern "C" int yp_box_nms_classes(const float* pred, int B, int N, int nc, float
     int* count = (int*)workspace;
     u64* keys = (u64*)((char*)workspace + align_up((size_t)B * 4, 256));
     YP_CHECK_HIP(hipMemsetAsync(count, 0, (size_t)B * 4, st));
-    box_candidates_kernel<<<dim3(BOX_SPANS, B), 256, 0, st>>>(pred, B, N, nc, conf_thres, multi_label, class_mask, keys, cap2, count);
+    box_candidates_kernel<<<dim3(box_spans(B), B), 256, 0, st>>>(pred, B, N, nc, conf_thres, multi_label, class_mask, keys, cap2, count);
     box_sort_nms_kernel<<<B, BOX_THREADS, 0, st>>>(pred, N, nc, iou_thres, conf_thres, agnostic, max_det, max_nms, max_wh, keys, cap, cap2, count,
                                                    out_det, out_count);
     YP_CHECK_HIP(hipGetLastError());
