@@ -521,27 +521,37 @@ __global__ __launch_bounds__(BOX_THREADS) void box_sort_nms_kernel(const float* 
     auto run_nms = [&](const u64* list, int cnt) {
     if (t == 0) s_nkept = 0;
     __syncthreads();
-    for (int base = 0; base < cnt; base += 64) {
-        const int nk0 = s_nkept;
-        if (nk0 >= max_det) break;
-        const int ci = base + lane;
-        const bool valid = ci < cnt;
-        BoxF bx{0.f, 0.f, 0.f, 0.f};
-        float area = 0.f, conf = 0.f;
-        unsigned id = 0;
-        if (valid) {
+    // (software-pipelined: the candidates of chunk c+1 -- key -> prediction row -> box, two dependent global loads, 1-2 us cold -- are fetched
+    // while chunk c is tested and resolved; they were fetched at the top of their own iteration, and a frame's box NMS spent most of its
+    // ~130 us waiting for them)
+    struct Cand { BoxF bx; float area, conf; unsigned id; bool valid; };
+    auto load_cand = [&](int ci) -> Cand {
+        Cand c{BoxF{0.f, 0.f, 0.f, 0.f}, 0.f, 0.f, 0u, ci < cnt};
+        if (c.valid) {
             const u64 key = list[ci];
-            id = (unsigned)(key & 0xFFFFFFFFu);
-            conf = __uint_as_float(0xFFFFFFFFu - (unsigned)(key >> 32));
-            const unsigned row = id / (unsigned)nc, cls = id - row * (unsigned)nc;
+            c.id = (unsigned)(key & 0xFFFFFFFFu);
+            c.conf = __uint_as_float(0xFFFFFFFFu - (unsigned)(key >> 32));
+            const unsigned row = c.id / (unsigned)nc, cls = c.id - row * (unsigned)nc;
             const float* r = pb + (long)row * no;
             const float cx = r[0], cy = r[1], w = r[2], h = r[3];
             const float off = agnostic ? 0.f : (float)cls * max_wh;
             // xywh2xyxy (utils/general_yolo.py:623-630) then "+ c" (:216-217), both in fp32
-            bx.x1 = (cx - w / 2) + off; bx.y1 = (cy - h / 2) + off;
-            bx.x2 = (cx + w / 2) + off; bx.y2 = (cy + h / 2) + off;
-            area = (bx.x2 - bx.x1) * (bx.y2 - bx.y1);
+            c.bx.x1 = (cx - w / 2) + off; c.bx.y1 = (cy - h / 2) + off;
+            c.bx.x2 = (cx + w / 2) + off; c.bx.y2 = (cy + h / 2) + off;
+            c.area = (c.bx.x2 - c.bx.x1) * (c.bx.y2 - c.bx.y1);
         }
+        return c;
+    };
+    Cand nxt = load_cand(lane);
+    for (int base = 0; base < cnt; base += 64) {
+        const int nk0 = s_nkept;
+        if (nk0 >= max_det) break;
+        const Cand cur = nxt;
+        nxt = load_cand(base + 64 + lane);
+        const bool valid = cur.valid;
+        const BoxF bx = cur.bx;
+        const float area = cur.area, conf = cur.conf;
+        const unsigned id = cur.id;
         // every wave tests the chunk against a strided share of the kept list
         bool sup = false;
         for (int k = wave; k < nk0 && !sup; k += NW) sup = iou_gt(kbox[k], karea[k], bx, area, iou_thres);
