@@ -97,6 +97,29 @@ def test_fuse_matches_unfused(cuda):
     assert rel_err(b["semi"], a["semi"])[0] < 1e-5 and rel_err(b["desc"], a["desc"])[0] < 1e-5
 
 
+def test_frozen_weights_skip_the_version_walk_but_not_invalidations(cuda):
+    """HipModule.freeze_weights() (what frontend.YoloPointFrontend sets): no per-forward walk over the parameters' version counters; an
+    in-place edit of a parameter is then not seen -- the documented contract -- while invalidate_packed_weights() / an optimizer step /
+    load_state_dict (the generation counter) still re-derive the packed filters, and freeze_weights(False) restores the per-forward check."""
+    from yolopoint_amd.models.common import invalidate_packed_weights
+    m, sd = make_model("n", 3, dtype="f16")
+    m = m.to(cuda)
+    x = net_oracle.synth_image(1, 3, 64, 64, 3).to(cuda)
+    net = m.model
+    a = m(x)["semi"].clone()
+    net.freeze_weights()
+    with torch.no_grad():
+        net.ConvDet.weight.mul_(2.0)
+    assert torch.equal(m(x)["semi"], a)                 # frozen: the edit is not seen
+    invalidate_packed_weights()
+    b = m(x)["semi"].clone()
+    assert not torch.equal(b, a) and rel_err(b, 2.0 * a)[0] < 2e-3
+    net.freeze_weights(False)
+    with torch.no_grad():
+        net.ConvDet.weight.mul_(0.5)
+    assert rel_err(m(x)["semi"], a)[0] < 2e-3           # unfrozen: version counters are read again
+
+
 def test_cpu_tensor_raises():
     from yolopoint_amd import _hip
     m, _ = make_model("n", 1)

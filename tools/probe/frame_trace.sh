@@ -23,3 +23,19 @@ for k,v in sorted(agg.items(), key=lambda kv:-sum(kv[1])):
 open('gpurun_out/frame_kernels.txt','w').write("\n".join(lines[:40])+"\n")
 print("\n".join(lines[:22]))
 PY
+python - <<'PY'
+# the last complete frame in start order: start offset, duration, gap to the end of the latest-ending earlier kernel
+import csv, re
+rows=sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open('gpurun_out/prof_frame/f_kernel_trace.csv'))))
+idx=[i for i,r in enumerate(rows) if "mnn_select_kernel" in r[2]]
+win=rows[idx[-2]+1: idx[-1]+1]
+t0=win[0][0]; latest=None; out=[f"# one frame, {len(win)} kernels, span {(win[-1][1]-t0)/1e3:.1f} us"]
+for s,e,n in win:
+    n=re.sub(r"\(anonymous namespace\)::","",n); n=re.sub(r"^void ","",n).split("(")[0][:60]
+    gap=(s-latest)/1e3 if latest else 0.0
+    if gap>3 or gap<-3 or "conv" not in n and "bottleneck" not in n:
+        out.append(f"{(s-t0)/1e3:9.1f} {(e-s)/1e3:8.1f} {gap:8.1f}  {n}")
+    latest=e if latest is None else max(latest,e)
+open('gpurun_out/frame_sequence.txt','w').write("\n".join(out)+"\n")
+print("\n".join(out))
+PY

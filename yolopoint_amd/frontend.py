@@ -20,7 +20,7 @@ YOLO_DEFAULT = dict(conf_thres_box=0.25, iou_thres_box=0.45, max_det=300)
 
 
 class YoloPointFrontend:
-    def __init__(self, model, device, sp_config=None, yolo_config=None, filter_pts=True, border_remove=4, cell=8, crop_resize=None):
+    def __init__(self, model, device, sp_config=None, yolo_config=None, filter_pts=True, border_remove=4, cell=8, crop_resize=None, freeze_weights=True):
         if crop_resize:
             raise _hip.YpError("YoloPointFrontend: crop_resize needs cv2.resize and is not part of the device pipeline")
         if cell != 8:
@@ -37,6 +37,8 @@ class YoloPointFrontend:
         self._net = net if hasattr(net, "_emit_heads_hook") else None
         if self._net is not None:
             self._net.heads_hook = True
+            if freeze_weights:
+                self._net.freeze_weights()
 
     # -- demo.py:111-121: make both dims divisible by 32 by a centred crop
     @staticmethod

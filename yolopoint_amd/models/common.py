@@ -66,7 +66,7 @@ class HipModule(nn.Module):
     """Base class: standalone forward through a cached native plan."""
 
     compute_dtype = "f16"
-    _NATIVE_CACHES = ("_plans", "_train_graphs", "_pack_states", "_mods_cache")      # per-object native plans / graphs / caches: never copied or pickled
+    _NATIVE_CACHES = ("_plans", "_train_graphs", "_pack_states", "_mods_cache", "_frozen_version")      # per-object native plans / graphs / caches: never copied or pickled
 
     def __deepcopy__(self, memo):
         import copy
@@ -90,11 +90,24 @@ class HipModule(nn.Module):
         # count alone misses a same-shape replacement, which would keep replaying a plan packed from the old module's filters) -- or an
         # explicit invalidation; the tensors are read from the modules' own dicts every time, so replaced parameters are seen.)
         gen = weights_generation()
+        fz = self.__dict__.get("_frozen_version")
+        if fz is not None and fz[0] == gen:               # freeze_weights(): the caller vouches that nothing but optimizers / load_state_dict
+            return fz                                      # (which bump the generation) touches the parameters -- no walk per forward
         cache = self.__dict__.get("_mods_cache")
         if cache is None or cache[0] != gen or cache[1] != tuple(id(c) for m in cache[2] for c in m._modules.values()):
             mods = list(self.modules())
             cache = self.__dict__["_mods_cache"] = (gen, tuple(id(c) for m in mods for c in m._modules.values()), mods)
         return (gen,) + tuple((t._version, t.data_ptr()) for m in cache[2] for d in (m._parameters, m._buffers) for t in d.values() if t is not None)
+
+    def freeze_weights(self, frozen=True):
+        """Inference servers (frontend.YoloPointFrontend) load a checkpoint once: with frozen weights the per-forward walk over every
+        parameter's version counter (0.3 ms of host time for YOLOPoint-l, in front of the first launch of every frame) is skipped.  An
+        optimizer step, load_state_dict or invalidate_packed_weights() still invalidates the plans (they bump the generation); in-place
+        edits of a parameter tensor are NOT seen until freeze_weights(False)."""
+        self.__dict__.pop("_frozen_version", None)
+        if frozen:
+            self.__dict__["_frozen_version"] = self._weights_version()
+        return self
 
     def _plan_key(self, x):
         return (tuple(x.shape), _hip.dtype_code(self.compute_dtype), self.training, self._weights_version(), x.device.index)
