@@ -588,6 +588,32 @@ def test_parallel_training_graphs_equal_the_eager_launch_order(cuda, monkeypatch
         assert torch.equal(a, b)
 
 
+def test_forward_lanes_equal_the_single_lane_plan(cuda, monkeypatch):
+    """The training forward replays on two lanes (keypoint + descriptor heads on the plan's side stream beside the YOLO encoder / PAN /
+    Detect chain, each lane with its own BatchNorm workspace).  Inputs CHANGE from pass to pass (a schedule that let a lane read a
+    buffer too early would still be right on a static input); gradients and BatchNorm statistics must be BIT-identical to the one-lane plan."""
+    got = {}
+    for lanes in ("0", "1"):
+        monkeypatch.setenv("YP_TRAIN_FWD_LANES", lanes)
+        m, _ = make_model("s", 3, dtype="bf16")
+        m = m.to(cuda).train()
+        outs = []
+        for it in range(3):
+            x = net_oracle.synth_image(2, 3, 128, 128, 4 + it).to(cuda)
+            m.zero_grad(set_to_none=True)
+            o = m(x)
+            (o["semi"].square().mean() + o["desc"].mean() + sum(t.tanh().mean() for t in o["objects"])).backward()
+            outs.append([o["semi"].detach().clone(), o["desc"].detach().clone()] + [p.grad.clone() for p in m.parameters()])
+        g = next(iter(m.model._train_graphs.values()))[0]
+        assert g.fwd_plan.has_lanes == (lanes == "1")
+        got[lanes] = (outs, [b.clone() for b in m.buffers()])
+    for pa, pb in zip(got["0"][0], got["1"][0]):
+        for a, b in zip(pa, pb):
+            assert torch.equal(a, b)
+    for a, b in zip(got["0"][1], got["1"][1]):
+        assert torch.equal(a, b)
+
+
 def test_flat_adam_matches_torch_adam(cuda):
     """optim.FlatAdam (one launch over the flat parameter / gradient / moment arrays) against torch.optim.Adam on the same gradients, five
     steps with a changing learning rate; state_dict round trip into torch.optim.Adam."""

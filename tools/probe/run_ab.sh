@@ -1,5 +1,3 @@
-cd $GRAFT_REPO_ROOT
-for cfg in "4 4" "3 4" "2 4" "4 5" "3 5" "5 4" "2 3"; do set -- $cfg
-for i in 1 2; do
-YP_KP_AT=$1 YP_DESC_AT=$2 python bench.py --no-cpu-baseline --only none 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('kp_at $1 desc_at $2', d['ms_per_step'])"
-done; done
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r4a
+timeout 1500 python -m pytest tests/test_gpu_training.py -q -p no:cacheprovider -k "lanes or parallel or determin" > gpurun_out/r4a/tl.log 2>&1
+grep -E "passed|failed|^FAILED|^ERROR|Error" gpurun_out/r4a/tl.log | tail -12

@@ -24,6 +24,7 @@ object loss: reference train.py:220-241), then the shared trunk + keypoint / des
 the two-graph schedule for the same arithmetic.
 """
 import ctypes as C
+import contextlib
 import os
 import weakref
 
@@ -74,7 +75,9 @@ class TrainGraph:
         self.keep = []
         self.busy = False
         wsb = lib().yp_bn_workspace_bytes(B, H // 2, W // 2, 1024) + 8 * self.G * 2048 + 4096
-        self.ws = torch.empty(wsb, dtype=torch.uint8, device=device)
+        # one statistics workspace per schedule lane (ops of the two lanes run side by side)
+        self._ws = {False: torch.empty(wsb, dtype=torch.uint8, device=device), True: torch.empty(wsb, dtype=torch.uint8, device=device)}
+        self._side_emit = False
         self.Bpad = round_up(B, 8)
         self._nbt = None
         # device scalars the backward plans read: [0] = the upstream factor of the Detect-level gradients (1 unless a caller that hands the
@@ -98,6 +101,23 @@ class TrainGraph:
         self._build()
 
     # ------------------------------------------------------------------ helpers
+    @property
+    def ws(self):
+        return self._ws[self._side_emit]
+
+    @contextlib.contextmanager
+    def side_lane(self, pb, enable=True):
+        """Emit the block's ops on `pb`'s side lane (PlanBuilder.side) with the side lane's own statistics workspace."""
+        if not enable:
+            yield
+            return
+        self._side_emit = True
+        try:
+            with pb.side():
+                yield
+        finally:
+            self._side_emit = False
+
     def pgrad(self, param):
         parts = self.vparts.get(id(param))
         if parts is not None:
@@ -548,11 +568,15 @@ class TrainGraph:
         xa = blk(net.Bottleneck1, x)
         x8 = self.conv_bn_act(net.Conv3, xa)
         # keypoint head: C3 + plain 1x1 conv (fp32) | v52: a 65-channel C2f whose BN + SiLU output IS semi
-        if v52:
-            semi = self.c2f(net.BottleneckDet, x8)
-        else:
-            t = self.c3(net.BottleneckDet, x8)
-            semi = self.conv_plain(net.ConvDet.weight, None, t, 1, 1, 0, "ConvDet")
+        # Forward lanes (YP_TRAIN_FWD_LANES=0 turns them off): the two heads and the P3 / P4 Detect levels on the forward plan's side lane, beside the YOLO encoder / PAN / Detect chain (whose P4 / P5
+        # layers leave most CUs idle); the plan then replays eagerly on two streams (see PlanBuilder.side)
+        fwd_lanes = os.environ.get("YP_TRAIN_FWD_LANES", "1") != "0" and not self.lanes
+        with self.side_lane(f, fwd_lanes):
+            if v52:
+                semi = self.c2f(net.BottleneckDet, x8)
+            else:
+                t = self.c3(net.BottleneckDet, x8)
+                semi = self.conv_plain(net.ConvDet.weight, None, t, 1, 1, 0, "ConvDet")
         # The head gradients arrive from autograd as [B,C,H,W]-shaped tensors (usually already channels-innermost in memory: the heads are
         # handed out as permuted views).  backward() copies them straight into the NHWC gradient buffers through permuted views
         # (Tensor.copy_ converts layout and dtype in one pass) -- no NCHW staging buffer and no pack launch (2 x 95 us per step).
@@ -564,34 +588,35 @@ class TrainGraph:
             self.seed_semi = head_view(gsemi_v, 65)
         xb = blk(net.Bottleneck2, x8)
         # descriptor head
-        if v52:
-            # MaxPool(xa) ++ up(ConvDescB(xb)) -> C2f; the L2 normalisation is applied (and differentiated) by the caller in PyTorch
-            dA = self.maxpool2(xa)
-            dB = self.conv_bn_act(net.ConvDescB, xb)
-            craw = self.c2f(net.BottleneckDesc, [dA, dB.up()])
-            c3ch = net._desc_channels
-            dnorm = craw
+        with self.side_lane(f, fwd_lanes):
+            if v52:
+                # MaxPool(xa) ++ up(ConvDescB(xb)) -> C2f; the L2 normalisation is applied (and differentiated) by the caller in PyTorch
+                dA = self.maxpool2(xa)
+                dB = self.conv_bn_act(net.ConvDescB, xb)
+                craw = self.c2f(net.BottleneckDesc, [dA, dB.up()])
+                c3ch = net._desc_channels
+                dnorm = craw
 
-            def desc_seed():
-                gcraw, _ = self.gview(craw)
-                self.seed_desc = head_view(gcraw, c3ch)
-        else:
-            dA = self.conv_bn_act(net.ConvDescA, xa)
-            dB = self.conv_bn_act(net.ConvDescB, xb)
-            d = self.c3(net.BottleneckDesc, [dA, dB.up()])
-            craw = self.conv_plain(net.ConvDesc.weight, None, d, 3, 1, 1, "ConvDesc")
-            c3ch = net.ConvDesc.out_channels
-            dnorm = f.new_buf(Hc, Wc, craw.C, f32=True).view()
-            f.op(_hip.OP_L2NORM, [craw], [dnorm], "l2norm", v=[craw, dnorm], i=[0, B, c3ch])
-            gd = Buf(B, Hc, Wc, craw.C, torch.float32, self.device)
-            self.keep.append(gd.flat)
+                def desc_seed():
+                    gcraw, _ = self.gview(craw)
+                    self.seed_desc = head_view(gcraw, c3ch)
+            else:
+                dA = self.conv_bn_act(net.ConvDescA, xa)
+                dB = self.conv_bn_act(net.ConvDescB, xb)
+                d = self.c3(net.BottleneckDesc, [dA, dB.up()])
+                craw = self.conv_plain(net.ConvDesc.weight, None, d, 3, 1, 1, "ConvDesc")
+                c3ch = net.ConvDesc.out_channels
+                dnorm = f.new_buf(Hc, Wc, craw.C, f32=True).view()
+                f.op(_hip.OP_L2NORM, [craw], [dnorm], "l2norm", v=[craw, dnorm], i=[0, B, c3ch])
+                gd = Buf(B, Hc, Wc, craw.C, torch.float32, self.device)
+                self.keep.append(gd.flat)
 
-            def desc_seed():
-                b = self.bwd
-                gcraw, _ = self.gview(craw)
-                self.seed_desc = head_view(gd.view(), c3ch)
-                self.seed_desc_buf = gd
-                b.op(_hip.OP_L2NORM_BWD, [craw, gd.view()], [gcraw], "l2norm_bwd", v=[craw, gd.view(), gcraw], i=[0, b.B, c3ch])
+                def desc_seed():
+                    b = self.bwd
+                    gcraw, _ = self.gview(craw)
+                    self.seed_desc = head_view(gd.view(), c3ch)
+                    self.seed_desc_buf = gd
+                    b.op(_hip.OP_L2NORM_BWD, [craw, gd.view()], [gcraw], "l2norm_bwd", v=[craw, gd.view(), gcraw], i=[0, b.B, c3ch])
         self.desc_channels = c3ch
         # YOLO encoder + PAN: nothing below feeds semi / desc
         self.branch = "yolo"
@@ -610,15 +635,14 @@ class TrainGraph:
             x = self.c3(net.Bottleneck5, [xd.up(), xc])
             xe = self.conv_bn_act(net.Conv7, x)
             xf = self.c3(net.Bottleneck6, [xe.up(), xb])
-        x = self.conv_bn_act(net.Conv8, xf)
-        xg = blk(net.Bottleneck7, [x, xe])
-        x = self.conv_bn_act(net.Conv9, xg)
-        p5 = blk(net.Bottleneck8, [x, xd])
-        # Detect (train mode: permuted raw logits only)
+        # Detect (train mode: permuted raw logits only).  YP_TRAIN_DET_LANES=1 puts the P3 / P4 levels on the side lane as the inference plan
+        # does -- measured slower here (8.12 vs 7.37 ms per step: they queue behind the heads on the one side stream and the object loss,
+        # the head of the backward's critical path, waits for them), so they stay on the main lane.
         det = net.Detect
         self.xs, self.g_xs = [], []
         det_seeds = []
-        for i, v in enumerate([xf, xg, p5]):
+
+        def detect_level(i, v):
             ny, nx = v.LH, v.LW
             xo = f.new_tensor((B, det.na, ny, nx, det.no))
             stride = float(det.stride[i])
@@ -636,6 +660,16 @@ class TrainGraph:
                 b.op(_hip.OP_DETECT_BWD_PACK, [self.T(gx)], [draw], "seed_det", f=[gx, self.head_scale], v=[draw], i=[code, b.B, det.na, det.no])
                 self.conv_backward([v], mi.weight, mi.bias, draw, 1, 1, 0)
             det_seeds.append(det_backward)
+        det_lanes = fwd_lanes and os.environ.get("YP_TRAIN_DET_LANES", "0") == "1"
+        with self.side_lane(f, det_lanes):
+            detect_level(0, xf)
+        x = self.conv_bn_act(net.Conv8, xf)
+        xg = blk(net.Bottleneck7, [x, xe])
+        with self.side_lane(f, det_lanes):
+            detect_level(1, xg)
+        x = self.conv_bn_act(net.Conv9, xg)
+        p5 = blk(net.Bottleneck8, [x, xd])
+        detect_level(2, p5)
         self.semi_v, self.desc_v = semi, dnorm
         # YP_TRAIN_PARALLEL=1: replay the launch lists as the DAG of their data dependencies (multi-kernel ops keep their inner chain) instead
         # of linear chains.  Measured SLOWER for the training step (14.4 vs 13.1 ms: the concurrent BatchNorm / weight-gradient / dgrad
@@ -720,7 +754,7 @@ class TrainGraph:
             self.bwd_plan, self.bwd_params, self.bwd_collect = emit(("yolo",), self.Bs, 1)
             self.bwd_kp_plan, self.bwd_kp_params, self.bwd_kp_collect = emit(("kp",), B, self.G, fresh=False)
         mode = os.environ.get("YP_TRAIN_GRAPH", "1")         # replay the launch lists as hipGraphs (284 / 455 / 230 launches)
-        if mode in ("1", "fwd"):
+        if mode in ("1", "fwd") and not (self.fwd_plan.has_lanes and os.environ.get("YP_LANES_EAGER", "1") != "0"):
             self.fwd_plan.instantiate_graph()
         if mode in ("1", "bwd"):
             self.bwd_plan.instantiate_graph()
