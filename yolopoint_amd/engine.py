@@ -346,10 +346,13 @@ class TrainStep:
             side.wait_event(fwd_done)
             with torch.cuda.stream(side):
                 detector_losses()
+                det_done = side.record_event()
                 out4 = infonce_chain(side, obj_done)
                 out4.record_stream(main)
             nce_done = side.record_event()
             join = lambda: main.wait_event(nce_done)
+            if getattr(g, "bwd_lanes", False):
+                main.wait_event(det_done)           # (the keypoint head's backward rides on the YOLO-branch plan's side lane: its seed must be final)
         elif lanes == 1:
             side.wait_event(main.record_event())
             with torch.cuda.stream(side):

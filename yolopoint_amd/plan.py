@@ -598,7 +598,10 @@ class PlanBuilder:
 
     def set_lane(self, lane):
         """Put the op added last on a schedule lane (_hip.LANE_SIDE: beside the following ops; _hip.LANE_JOIN: after all side ops)."""
-        check(lib().yp_plan_set_lane(self.handle, lib().yp_plan_num_ops(self.handle) - 1, lane))
+        j = lib().yp_plan_num_ops(self.handle) - 1
+        check(lib().yp_plan_set_lane(self.handle, j, lane))
+        if lane == _hip.LANE_JOIN:
+            self.__dict__.setdefault("join_ops", []).append(j)
 
     def refresh(self):
         """Re-derive every packed weight from its source (call before each training step)."""
@@ -725,11 +728,13 @@ class PlanBuilder:
         if getattr(self, "has_lanes", False):             # explicit schedule lanes: the captured topology (main chain + side chain) is the schedule
             parallel = False
             # the lane assignment must agree with the data dependencies: nothing on the main lane may touch what a side op writes or is
-            # still reading (a side op waits for every op in front of it, so the other direction is covered by construction)
+            # still reading (a side op waits for every op in front of it, so the other direction is covered by construction) -- unless a
+            # LANE_JOIN op in between has made the main lane wait for the side lane
             side = getattr(self, "side_ops", set())
+            joins = getattr(self, "join_ops", [])
             for j, d in enumerate(self.dependencies()):
                 if j not in side:
-                    bad = [i for i in d if i in side]
+                    bad = [i for i in d if i in side and not any(i < k <= j for k in joins)]
                     if bad:
                         raise _hip.YpError(f"plan lanes: main-lane op {j} ({self.records[j].name}) depends on side-lane op(s) "
                                            f"{[(i, self.records[i].name) for i in bad]}")

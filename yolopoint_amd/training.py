@@ -66,6 +66,7 @@ class TrainGraph:
         self.n_q8 = 0              # convolutions emitted with 8-bit operands
         self.tape = []             # (branch, emitter): 'kp' feeds the keypoint / descriptor heads, 'yolo' only the Detect head
         self.branch = "kp"
+        self.tape_tag = None       # 'kph': entries of the keypoint head (pair mode: their backward runs beside the YOLO-branch plan)
         self.touched = set()       # parameters whose gradient the plan being emitted writes
         self.gbufs = {}            # data_ptr of an activation buffer -> its gradient Buf
         self.gwritten = {}         # data_ptr -> list of written (lo, hi) channel ranges
@@ -91,6 +92,7 @@ class TrainGraph:
         # BatchNorm chain that never reads them.  Measured: 20.5 ms per step against 19.2 ms on one lane -- the concurrent kernels
         # fight over CUs / LDS / L2 (as the sub-batch stream experiment of the forward did) -- so it stays off.
         self.lanes = os.environ.get("YP_TRAIN_LANES", "0") == "1"
+        self.bwd_lanes = False
         # YP_WGRAD_GROUP=0: one launch per weight gradient instead of one per filter class and backward pass
         self.group_wgrad = not self.lanes and os.environ.get("YP_WGRAD_GROUP", "1") != "0"
         self.dw_arena = torch.zeros(round_up(2 * sum(p_.numel() for p_ in net.parameters()) + (1 << 20), 64), dtype=torch.float32, device=device)
@@ -329,7 +331,7 @@ class TrainGraph:
             if padded:
                 self.collect.append(lambda dg=dg, db=db, gw_=gw_, gb_=gb_: (gw_.copy_(dg[:Cc]), gb_.copy_(db[:Cc])))
             self.conv_backward(srcs, conv.weight, None, draw, k, s, p)
-        self.tape.append((self.branch, backward))
+        self.tape.append((self.branch, backward, self.tape_tag))
         return out
 
     def conv_plain(self, weight, bias, x, k, s, p, name):
@@ -346,7 +348,7 @@ class TrainGraph:
                 draw = b.new_buf(out.H, out.W, out.C).view()
                 b.op(_hip.OP_CAST_F32, [g32], [draw], "cast", v=[g32, draw], i=[self.code, b.B])
             self.conv_backward([x], weight, bias, draw, k, s, p)
-        self.tape.append((self.branch, backward))
+        self.tape.append((self.branch, backward, self.tape_tag))
         return out
 
     def conv_backward(self, srcs, weight, bias, draw, k, s, p):
@@ -387,7 +389,7 @@ class TrainGraph:
                 # nothing in the rest of the backward reads dW or overwrites x / dy: the weight gradients of a filter class are
                 # collected and run as ONE grouped launch at the end of the pass (emit())
                 # (a class = filter size, stride and the workgroup block size the entry runs with: one kernel instantiation per launch)
-                self.wgroups.setdefault((k, s, lib().yp_wgrad_block(src.c(), draw.c(), B, k)), []).append((src, draw, dwb, 2 * B * Ho * Wo * Cj * k * k * Cout))
+                self.wgroups.setdefault((k, s, lib().yp_wgrad_block(src.c(), draw.c(), B, k), B), []).append((src, draw, dwb, 2 * B * Ho * Wo * Cj * k * k * Cout))
             elif image and code != _hip.YP_F32 and (k, s, p) == (6, 2, 2) and Cout_pad <= 80 and os.environ.get("YP_STEM_WGRAD", "1") != "0":
                 # the stem: its own kernel over the packed image (no pixel-major copies of the two largest tensors of the pass)
                 nsl = lib().yp_stem_wgrad_slabs(B, Hi, Wi)
@@ -535,7 +537,7 @@ class TrainGraph:
             gy = self.gread(y)
             gx, acc = self.gview(x)
             self.bwd.op(_hip.OP_MAXPOOL2_BWD, [x, gy, gx], [gx], "maxpool2_bwd", v=[x, gy, gx], i=[code, self.bwd.B, int(acc)])
-        self.tape.append((self.branch, backward))
+        self.tape.append((self.branch, backward, self.tape_tag))
         return y
 
     def sppf(self, m, x):
@@ -553,7 +555,7 @@ class TrainGraph:
             b.op(_hip.OP_MAXPOOL5_BWD, [s2, g3, g2], [g2, self.T(self.ws)], "pool_bwd3", v=[s2, g3, g2], i=[code, B, 1], p=[self.ws], n=[self.ws.numel()])
             b.op(_hip.OP_MAXPOOL5_BWD, [s1, g2, g1], [g1, self.T(self.ws)], "pool_bwd2", v=[s1, g2, g1], i=[code, B, 1], p=[self.ws], n=[self.ws.numel()])
             b.op(_hip.OP_MAXPOOL5_BWD, [s0, g1, g0], [g0, self.T(self.ws)], "pool_bwd1", v=[s0, g1, g0], i=[code, B, 1], p=[self.ws], n=[self.ws.numel()])
-        self.tape.append((self.branch, backward))
+        self.tape.append((self.branch, backward, self.tape_tag))
         return self.conv_bn_act(m.cv2, cat.view())
 
     # ------------------------------------------------------------------ the graph
@@ -571,12 +573,14 @@ class TrainGraph:
         # Forward lanes (YP_TRAIN_FWD_LANES=0 turns them off): the two heads and the P3 / P4 Detect levels on the forward plan's side lane, beside the YOLO encoder / PAN / Detect chain (whose P4 / P5
         # layers leave most CUs idle); the plan then replays eagerly on two streams (see PlanBuilder.side)
         fwd_lanes = os.environ.get("YP_TRAIN_FWD_LANES", "1") != "0" and not self.lanes
+        self.tape_tag = "kph"
         with self.side_lane(f, fwd_lanes):
             if v52:
                 semi = self.c2f(net.BottleneckDet, x8)
             else:
                 t = self.c3(net.BottleneckDet, x8)
                 semi = self.conv_plain(net.ConvDet.weight, None, t, 1, 1, 0, "ConvDet")
+        self.tape_tag = None
         # The head gradients arrive from autograd as [B,C,H,W]-shaped tensors (usually already channels-innermost in memory: the heads are
         # handed out as permuted views).  backward() copies them straight into the NHWC gradient buffers through permuted views
         # (Tensor.copy_ converts layout and dtype in one pass) -- no NCHW staging buffer and no pack launch (2 x 95 us per step).
@@ -682,10 +686,12 @@ class TrainGraph:
         # Two variants: the full one, and one that only back-propagates the semi / desc sub-graph -- the reference's second
         # forward of a step (warped image) has no object loss, so autograd never visits its Detect / PAN / YOLO-encoder
         # layers (4 F_fwd + 2 F_kp per sample, not 6 F_fwd).
-        def emit(branches, B, groups, fresh=True):
+        def emit(branches, B, groups, fresh=True, side=None, skip=()):
             """One backward plan over the tape entries of `branches` ('kp': trunk + keypoint / descriptor heads, 'yolo': YOLO encoder + PAN +
             Detect), B samples, `groups` statistics groups.  fresh=False: the activation gradients an earlier plan of the same pass wrote
-            stay valid (pair mode: the trunk plan accumulates onto what the YOLO-branch plan left in the backbone output's gradient)."""
+            stay valid (pair mode: the trunk plan accumulates onto what the YOLO-branch plan left in the backbone output's gradient).
+            side = (tag, samples, groups): the tape entries tagged `tag` run on the plan's side lane over their own sample count (pair mode: the
+            keypoint head's backward beside the YOLO-branch chain); skip: tags left to another plan."""
             self.bwd = bb = PlanBuilder(B, code, self.device)
             bb.fp8 = self.fwd.fp8
             self.bG = groups
@@ -698,16 +704,26 @@ class TrainGraph:
                 self.wpart = None         # (pair mode: one slab arena per plan -- the two plans differ in batch)
             self.dw_used = 0              # (the plans of a graph run one after another and unpack their accumulators at their end)
             bb.op(_hip.OP_MEMSET0, [], [self.T(self.dw_arena)], "zero_dw", p=[self.dw_arena], n=[self.dw_arena.numel() * 4])
+            if side is not None:
+                bb.B, self.bG = side[1], side[2]
+                with self.side_lane(bb):
+                    semi_seed()
+                    for _, fn, tag in reversed(self.tape):
+                        if tag == side[0]:
+                            fn()
+                bb.B, self.bG = B, groups
             if "kp" in branches:
-                semi_seed()
+                if "kph" not in skip:
+                    semi_seed()
                 desc_seed()
             if "yolo" in branches:
                 for fn in det_seeds:      # Detect backward runs before the PAN blocks' backward (it writes their output gradients)
                     fn()
-            for branch, fn in reversed(self.tape):
-                if branch in branches:
+            for branch, fn, tag in reversed(self.tape):
+                if branch in branches and tag not in skip:
                     fn()
-            for (gk, gs, gblk), ents in sorted(self.wgroups.items()):
+            joined = side is None
+            for (gk, gs, gblk, gB), ents in sorted(self.wgroups.items()):
                 n = len(ents)
                 xs, dys = (_hip.YpView * n)(*[e[0].c() for e in ents]), (_hip.YpView * n)(*[e[1].c() for e in ents])
                 dws = (C.c_void_p * n)(*[e[2].flat.data_ptr() for e in ents])
@@ -716,23 +732,26 @@ class TrainGraph:
                 if self.det_wgrad:
                     # deterministic reduction: every pixel slice of an entry writes its own slab, a second launch sums them in order.
                     # The slab arena is shared by the filter classes of all backward plans of this graph (they run one after another).
-                    sizes = [round_up(lib().yp_wgrad_partial_elems(e[0].c(), e[1].c(), code, B, gk, gs, gblk), 64) for e in ents]
+                    sizes = [round_up(lib().yp_wgrad_partial_elems(e[0].c(), e[1].c(), code, gB, gk, gs, gblk), 64) for e in ents]
                     if self.wpart is None:      # sized by the largest filter class of the FULL backward (emitted first; the keypoint-only plan is a subset)
-                        self.wpart = torch.empty(max(sum(round_up(lib().yp_wgrad_partial_elems(e[0].c(), e[1].c(), code, B, k_, s_, b_), 64) for e in es)
-                                                     for (k_, s_, b_), es in self.wgroups.items()), dtype=torch.float32, device=self.device)
+                        self.wpart = torch.empty(max(sum(round_up(lib().yp_wgrad_partial_elems(e[0].c(), e[1].c(), code, B_, k_, s_, b_), 64) for e in es)
+                                                     for (k_, s_, b_, B_), es in self.wgroups.items()), dtype=torch.float32, device=self.device)
                         self.keep.append(self.wpart)
                     assert sum(sizes) <= self.wpart.numel()
                     offs = [sum(sizes[:i]) for i in range(n)]
                     parts = (C.c_void_p * n)(*[self.wpart.data_ptr() + 4 * o for o in offs])
-                    check(lib().yp_wgrad_group_pack_det(xs, dys, dws, parts, n, code, B, gk, gs, gblk, host, C.byref(blocks), C.byref(fold)))
+                    check(lib().yp_wgrad_group_pack_det(xs, dys, dws, parts, n, code, gB, gk, gs, gblk, host, C.byref(blocks), C.byref(fold)))
                 else:
-                    check(lib().yp_wgrad_group_pack(xs, dys, dws, n, code, B, gk, gs, gblk, host, C.byref(blocks)))
+                    check(lib().yp_wgrad_group_pack(xs, dys, dws, n, code, gB, gk, gs, gblk, host, C.byref(blocks)))
                 wtab = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(self.device)
                 self.keep.append(wtab)
                 bb.op(_hip.OP_WGRAD_GROUP, [v for e in ents for v in e[:2]], [e[2].view() for e in ents] + ([self.T(self.wpart)] if self.det_wgrad else []),
                       f"wgrad_k{gk}s{gs}" + ("b128" if gblk == 128 else ""), p=[wtab],
                       i=[code, n, blocks.value, gk, gs, fold.value, gblk])
                 bb.records[-1].kind, bb.records[-1].flops = "conv", sum(e[3] for e in ents)
+                if not joined:            # the grouped launches read the side lane's output gradients
+                    bb.set_lane(_hip.LANE_JOIN)
+                    joined = True
             rows, tile0 = [], 0
             for u in self.unpack:
                 rows.append([u["dw"].flat.data_ptr(), u["grad"].data_ptr(), u["rows"], u["cout"], u["cout_pad"], u["out_stride"], u["out_off"], tile0,
@@ -751,13 +770,23 @@ class TrainGraph:
         else:
             # pair mode: the YOLO-branch layers over the image pass's samples (statistics group 0 = the first Bs samples of every buffer),
             # then the trunk + keypoint / descriptor heads over both passes
-            self.bwd_plan, self.bwd_params, self.bwd_collect = emit(("yolo",), self.Bs, 1)
-            self.bwd_kp_plan, self.bwd_kp_params, self.bwd_kp_collect = emit(("kp",), B, self.G, fresh=False)
+            # YP_TRAIN_BWD_LANES=1: the keypoint head's backward (over both passes; its seed, the detector loss, is ready long before the
+            # InfoNCE gradient the descriptor head waits for) on the YOLO-branch plan's side lane.  Measured slower (7.60 vs 7.40 ms per
+            # step): that plan already shares the GPU with the InfoNCE gathers of the loss stream, and the head's full-width kernels delay
+            # the YOLO chain's small ones.  Off by default.
+            self.bwd_lanes = fwd_lanes and os.environ.get("YP_TRAIN_BWD_LANES", "0") == "1" and not self.fp8
+            if self.bwd_lanes:
+                self.bwd_plan, self.bwd_params, self.bwd_collect = emit(("yolo",), self.Bs, 1, side=("kph", B, self.G))
+                self.bwd_kp_plan, self.bwd_kp_params, self.bwd_kp_collect = emit(("kp",), B, self.G, fresh=False, skip=("kph",))
+            else:
+                self.bwd_plan, self.bwd_params, self.bwd_collect = emit(("yolo",), self.Bs, 1)
+                self.bwd_kp_plan, self.bwd_kp_params, self.bwd_kp_collect = emit(("kp",), B, self.G, fresh=False)
         mode = os.environ.get("YP_TRAIN_GRAPH", "1")         # replay the launch lists as hipGraphs (284 / 455 / 230 launches)
         if mode in ("1", "fwd") and not (self.fwd_plan.has_lanes and os.environ.get("YP_LANES_EAGER", "1") != "0"):
             self.fwd_plan.instantiate_graph()
         if mode in ("1", "bwd"):
-            self.bwd_plan.instantiate_graph()
+            if not (self.bwd_plan.has_lanes and os.environ.get("YP_LANES_EAGER", "1") != "0"):
+                self.bwd_plan.instantiate_graph()
             self.bwd_kp_plan.instantiate_graph()
         self.params = [p_ for p_ in net.parameters()]
 
@@ -855,19 +884,25 @@ class TrainGraph:
                 dst[:self.Bs].zero_()
             else:
                 dst[:self.Bs].copy_(src)
+        def seed(dst, src):
+            if src is SEEDED:
+                return
+            if src is None:
+                dst.zero_()
+            else:
+                dst.copy_(src)
+        early = getattr(self, "bwd_lanes", False)     # (the keypoint head's backward is part of the first plan: its side lane)
+        if early:
+            seed(self.seed_semi, g_semi)
         self.bwd_plan.run()
         for fn in self.bwd_collect:
             fn()
         first = {p_: self.pgrads[p_] for p_ in self.params if p_ in self.bwd_params}
         if between is not None:
             between(first)
-        for dst, src in ((self.seed_semi, g_semi), (self.seed_desc, g_desc)):
-            if src is SEEDED:
-                continue
-            if src is None:
-                dst.zero_()
-            else:
-                dst.copy_(src)
+        if not early:
+            seed(self.seed_semi, g_semi)
+        seed(self.seed_desc, g_desc)
         self.bwd_kp_plan.run()
         for fn in self.bwd_kp_collect:
             fn()
