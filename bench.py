@@ -521,7 +521,8 @@ def run_v52(dev, steps, warmup, threads, with_cpu):
                                   "keypoint head), batch 8, 640x640, BN folded, " + ("two-lane eager replay" if getattr(plan, "has_lanes", False) and not plan.graph else "hipGraph replay"),
                       "ops_per_step": len(per_op)},
            "roofline": {"bound": "mfma", "achieved": round(conv_flops / (conv_ms * 1e-3) / 1e12, 2) if conv_ms > 0 else None, "peak": 2500.0, "unit": "TFLOP/s",
-                        "frac": round(conv_flops / (conv_ms * 1e-3) / 1e12 / 2500.0, 4) if conv_ms > 0 else None, "traffic": None,
+                        "frac": round(conv_flops / (conv_ms * 1e-3) / 1e12 / 2500.0, 4) if conv_ms > 0 else None,
+                        "traffic": train_traffic_record("v52_s", 8, "f16"),
                         "algorithmic_gflop_per_step": round(conv_flops / 1e9, 3),
                         "note": "conv FLOP per step / the timed step (two lanes overlap)" if getattr(plan, "has_lanes", False) else "conv launches of the plan (eager, HIP events) against their algorithmic FLOP"}}
     if with_cpu:

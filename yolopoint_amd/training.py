@@ -570,58 +570,70 @@ class TrainGraph:
         xa = blk(net.Bottleneck1, x)
         x8 = self.conv_bn_act(net.Conv3, xa)
         # keypoint head: C3 + plain 1x1 conv (fp32) | v52: a 65-channel C2f whose BN + SiLU output IS semi
-        # Forward lanes (YP_TRAIN_FWD_LANES=0 turns them off): the two heads and the P3 / P4 Detect levels on the forward plan's side lane, beside the YOLO encoder / PAN / Detect chain (whose P4 / P5
-        # layers leave most CUs idle); the plan then replays eagerly on two streams (see PlanBuilder.side)
+        # Forward lanes (YP_TRAIN_FWD_LANES=0 turns them off): the two heads on the forward plan's side lane, beside the YOLO encoder / PAN /
+        # Detect chain (whose P4 / P5 layers leave most CUs idle); the plan then replays eagerly on two streams (see PlanBuilder.side)
         fwd_lanes = os.environ.get("YP_TRAIN_FWD_LANES", "1") != "0" and not self.lanes
-        self.tape_tag = "kph"
-        with self.side_lane(f, fwd_lanes):
-            if v52:
-                semi = self.c2f(net.BottleneckDet, x8)
-            else:
-                t = self.c3(net.BottleneckDet, x8)
-                semi = self.conv_plain(net.ConvDet.weight, None, t, 1, 1, 0, "ConvDet")
-        self.tape_tag = None
-        # The head gradients arrive from autograd as [B,C,H,W]-shaped tensors (usually already channels-innermost in memory: the heads are
-        # handed out as permuted views).  backward() copies them straight into the NHWC gradient buffers through permuted views
-        # (Tensor.copy_ converts layout and dtype in one pass) -- no NCHW staging buffer and no pack launch (2 x 95 us per step).
+        # Each head is emitted (= forked) right behind the last tensor it reads: Conv3 (x8) for the keypoint head, Bottleneck2 (xb) for the
+        # descriptor head.  Later forks measured slower (both heads behind Bottleneck2 / 3 / 4: 7.60 / 7.84 / 8.01 ms per step).
+        hd = {}
+
         def head_view(gv, C_):
+            # The head gradients arrive from autograd as [B,C,H,W]-shaped tensors (usually already channels-innermost in memory: the heads
+            # are handed out as permuted views).  backward() copies them straight into the NHWC gradient buffers through permuted views
+            # (Tensor.copy_ converts layout and dtype in one pass) -- no NCHW staging buffer and no pack launch (2 x 95 us per step).
             return gv.buf.t[..., gv.coff:gv.coff + C_].permute(0, 3, 1, 2)
 
         def semi_seed():
-            gsemi_v, _ = self.gview(semi)
+            gsemi_v, _ = self.gview(hd["semi"])
             self.seed_semi = head_view(gsemi_v, 65)
+
+        def desc_seed():
+            hd["desc_seed"]()
+
+        def emit_kp_head():
+            self.tape_tag = "kph"
+            with self.side_lane(f, fwd_lanes):
+                if v52:
+                    hd["semi"] = self.c2f(net.BottleneckDet, x8)
+                else:
+                    t = self.c3(net.BottleneckDet, x8)
+                    hd["semi"] = self.conv_plain(net.ConvDet.weight, None, t, 1, 1, 0, "ConvDet")
+            self.tape_tag = None
+
+        def emit_desc_head():
+            with self.side_lane(f, fwd_lanes):
+                if v52:
+                    # MaxPool(xa) ++ up(ConvDescB(xb)) -> C2f; the L2 normalisation is applied (and differentiated) by the caller in PyTorch
+                    dA = self.maxpool2(xa)
+                    dB = self.conv_bn_act(net.ConvDescB, xb)
+                    craw = self.c2f(net.BottleneckDesc, [dA, dB.up()])
+                    c3ch = net._desc_channels
+                    dnorm = craw
+
+                    def seed():
+                        gcraw, _ = self.gview(craw)
+                        self.seed_desc = head_view(gcraw, c3ch)
+                else:
+                    dA = self.conv_bn_act(net.ConvDescA, xa)
+                    dB = self.conv_bn_act(net.ConvDescB, xb)
+                    d = self.c3(net.BottleneckDesc, [dA, dB.up()])
+                    craw = self.conv_plain(net.ConvDesc.weight, None, d, 3, 1, 1, "ConvDesc")
+                    c3ch = net.ConvDesc.out_channels
+                    dnorm = f.new_buf(Hc, Wc, craw.C, f32=True).view()
+                    f.op(_hip.OP_L2NORM, [craw], [dnorm], "l2norm", v=[craw, dnorm], i=[0, B, c3ch])
+                    gd = Buf(B, Hc, Wc, craw.C, torch.float32, self.device)
+                    self.keep.append(gd.flat)
+
+                    def seed():
+                        b = self.bwd
+                        gcraw, _ = self.gview(craw)
+                        self.seed_desc = head_view(gd.view(), c3ch)
+                        self.seed_desc_buf = gd
+                        b.op(_hip.OP_L2NORM_BWD, [craw, gd.view()], [gcraw], "l2norm_bwd", v=[craw, gd.view(), gcraw], i=[0, b.B, c3ch])
+            hd["desc_seed"], hd["dnorm"], hd["c3ch"] = seed, dnorm, c3ch
+        emit_kp_head()
         xb = blk(net.Bottleneck2, x8)
-        # descriptor head
-        with self.side_lane(f, fwd_lanes):
-            if v52:
-                # MaxPool(xa) ++ up(ConvDescB(xb)) -> C2f; the L2 normalisation is applied (and differentiated) by the caller in PyTorch
-                dA = self.maxpool2(xa)
-                dB = self.conv_bn_act(net.ConvDescB, xb)
-                craw = self.c2f(net.BottleneckDesc, [dA, dB.up()])
-                c3ch = net._desc_channels
-                dnorm = craw
-
-                def desc_seed():
-                    gcraw, _ = self.gview(craw)
-                    self.seed_desc = head_view(gcraw, c3ch)
-            else:
-                dA = self.conv_bn_act(net.ConvDescA, xa)
-                dB = self.conv_bn_act(net.ConvDescB, xb)
-                d = self.c3(net.BottleneckDesc, [dA, dB.up()])
-                craw = self.conv_plain(net.ConvDesc.weight, None, d, 3, 1, 1, "ConvDesc")
-                c3ch = net.ConvDesc.out_channels
-                dnorm = f.new_buf(Hc, Wc, craw.C, f32=True).view()
-                f.op(_hip.OP_L2NORM, [craw], [dnorm], "l2norm", v=[craw, dnorm], i=[0, B, c3ch])
-                gd = Buf(B, Hc, Wc, craw.C, torch.float32, self.device)
-                self.keep.append(gd.flat)
-
-                def desc_seed():
-                    b = self.bwd
-                    gcraw, _ = self.gview(craw)
-                    self.seed_desc = head_view(gd.view(), c3ch)
-                    self.seed_desc_buf = gd
-                    b.op(_hip.OP_L2NORM_BWD, [craw, gd.view()], [gcraw], "l2norm_bwd", v=[craw, gd.view(), gcraw], i=[0, b.B, c3ch])
-        self.desc_channels = c3ch
+        emit_desc_head()
         # YOLO encoder + PAN: nothing below feeds semi / desc
         self.branch = "yolo"
         self.kp_ptrs = set(t_.data_ptr() for t_ in f.keep)        # the trunk / keypoint-branch buffers (gview: pair mode)
@@ -674,7 +686,7 @@ class TrainGraph:
         x = self.conv_bn_act(net.Conv9, xg)
         p5 = blk(net.Bottleneck8, [x, xd])
         detect_level(2, p5)
-        self.semi_v, self.desc_v = semi, dnorm
+        self.semi_v, self.desc_v, self.desc_channels = hd["semi"], hd["dnorm"], hd["c3ch"]
         # YP_TRAIN_PARALLEL=1: replay the launch lists as the DAG of their data dependencies (multi-kernel ops keep their inner chain) instead
         # of linear chains.  Measured SLOWER for the training step (14.4 vs 13.1 ms: the concurrent BatchNorm / weight-gradient / dgrad
         # kernels fight over CUs and L2, as the two-lane schedule and the sub-batch streams of the forward did), so it is off by default;
