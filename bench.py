@@ -332,9 +332,9 @@ def main():
         # BASELINE configs[4]: YOLOPoint-l, 16 samples per GPU (bs 128 over 8 GPUs), fp8 Conv operands, data parallel over all N ranks;
         # at N = 1 the bf16 step of the same model is timed beside it
         torch.cuda.empty_cache()
-        rec = run_train(a, rank, world, dev, "l", 16, max(4, a.train_steps // 4), 2, gas=1, dtype="fp8")
+        rec = run_train(a, rank, world, dev, "l", 16, max(8, a.train_steps // 2), 3, gas=1, dtype="fp8")
         if world == 1:
-            ref = run_train(a, rank, world, dev, "l", 16, max(4, a.train_steps // 4), 2, gas=1, dtype="bf16")
+            ref = run_train(a, rank, world, dev, "l", 16, max(8, a.train_steps // 2), 3, gas=1, dtype="bf16")
             rec["bf16_ms_per_step"] = ref["ms_per_step"]
         if rank == 0:
             out["train_l_fp8"] = rec

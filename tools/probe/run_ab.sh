@@ -1,9 +1,8 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r4a
-for cfg in "YP_TRAIN_DESCA_EARLY=0" "YP_TRAIN_DESCA_EARLY=1" "YP_TRAIN_DESCA_EARLY=0" "YP_TRAIN_DESCA_EARLY=1"; do
-env $cfg python bench.py --mode train 2>&1 | tail -1 | python -c "
+show() { python -c "
 import json,sys
-l=sys.stdin.readline()
-try:
-    d=json.loads(l); print('$cfg', d['ms_per_step'])
-except Exception as e: print('$cfg', 'ERR', l[:300])"
-done
+d=json.loads(sys.stdin.readline()); r=d['train_l_fp8']; print('$1 fp8', r['ms_per_step'], 'bf16', r.get('bf16_ms_per_step'), 'frame', d.get('frame',{}).get('ms_per_step'))"; }
+python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | show full
+python bench.py --no-cpu-baseline --only fp8 2>/dev/null | tail -1 | show only_fp8
+python bench.py --no-cpu-baseline --only train,fp8 2>/dev/null | tail -1 | show train_fp8
+python bench.py --no-cpu-baseline --only train64,fp8 2>/dev/null | tail -1 | show train64_fp8

@@ -340,56 +340,162 @@ __device__ __forceinline__ bool iou_gt(const BoxF& a, float aarea, const BoxF& b
     return ovr > thr;
 }
 
+// The same predicate without the division wherever the outcome is not within rounding distance of the threshold: inter/union > thr is
+// decided by inter against thr*union with a 1e-6 relative guard band (the correctly rounded quotient and the product are each within 2^-24
+// of their exact values); inside the band, or for a degenerate union, the exact expression above decides.  (The greedy pass of a frame is
+// ~1 M of these on one CU: the division sequence was most of its time.)
+__device__ __forceinline__ bool iou_gt_banded(const BoxF& a, float aarea, const BoxF& b, float barea, float thr) {
+    const float xx1 = fmaxf(a.x1, b.x1), yy1 = fmaxf(a.y1, b.y1);
+    const float xx2 = fminf(a.x2, b.x2), yy2 = fminf(a.y2, b.y2);
+    const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
+    const float inter = w * h;
+    const float uni = aarea + barea - inter;
+    const float tt = thr * uni;
+    const bool sure_t = inter > tt * 1.000001f, sure_f = inter < tt * 0.999999f;
+    if (uni > 0.f && uni < 3e38f && tt > 1e-30f && (sure_t || sure_f)) return sure_t;
+    return inter / uni > thr;
+}
+
 constexpr int BOX_THREADS = 1024;
 constexpr int BOX_MAX_DET = 2048;
+constexpr int BOX_TILE = 4096;                                  // keys of one LDS sort tile
+// dynamic LDS of box_sort_nms_kernel: [sort tile | bin prefix | kept boxes | kept area, id, confidence | staged candidate boxes]
+constexpr int BOX_LDS_SORT = 0, BOX_LDS_PRE = BOX_TILE * 8, BOX_LDS_KBOX = BOX_LDS_PRE + BOX_TILE * 4, BOX_LDS_KAUX = BOX_LDS_KBOX + BOX_MAX_DET * 16;
+constexpr int BOX_LDS_CBOX = BOX_LDS_KAUX + 3 * BOX_MAX_DET * 4;            // boxes of the 1024 sorted candidates being resolved
+constexpr int BOX_LDS_BYTES = BOX_LDS_CBOX + BOX_THREADS * 16;
 
-// one workgroup per image: bitonic sort of the candidate keys, then chunked greedy NMS.
+__device__ __forceinline__ unsigned long long box_shfl_xor_u64(unsigned long long v, int m) {
+    const unsigned lo = __shfl_xor((unsigned)(v & 0xFFFFFFFFu), m, 64);
+    const unsigned hi = __shfl_xor((unsigned)(v >> 32), m, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// Ascending bitonic sort of sk[0..p2) (p2 = E * threads-in-use, a power of two <= 4096) by one 1024-thread workgroup.  Every thread holds E
+// consecutive keys in registers: compare-exchange steps with partner distance j < E stay in the thread, j < 64 E go through lane
+// shuffles (no barrier), only j >= 64 E is exchanged through LDS (10 of the 78 steps of a 4096-key sort; all 78 took a barrier before).
+template <int E>
+__device__ __forceinline__ void box_tile_sort(unsigned long long* sk, int p2, int t) {
+    using u64_ = unsigned long long;
+    const bool act = t * E < p2;
+    u64_ v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = act ? sk[t * E + e] : ~0ull;
+    for (int k = 2; k <= p2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j < E) {                                           // (constant register indices: a runtime v[e ^ j] would live in scratch)
+                auto cx = [&](int e, int f) {
+                    const bool up = ((t * E + e) & k) == 0;
+                    const u64_ a = v[e], c = v[f];
+                    if ((a > c) == up) { v[e] = c; v[f] = a; }
+                };
+                if constexpr (E == 4) {
+                    if (j == 2) { cx(0, 2); cx(1, 3); }
+                    else { cx(0, 1); cx(2, 3); }
+                } else if constexpr (E == 2) {
+                    cx(0, 1);
+                }
+            } else if (j < 64 * E) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int idx = t * E + e;
+                    const u64_ c = box_shfl_xor_u64(v[e], j / E);
+                    const bool lower = (idx & j) == 0, up = (idx & k) == 0;
+                    const u64_ mn = v[e] < c ? v[e] : c, mx = v[e] < c ? c : v[e];
+                    v[e] = (lower == up) ? mn : mx;
+                }
+            } else {
+                __syncthreads();                                   // (earlier partner reads are done)
+                if (act) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) sk[t * E + e] = v[e];
+                }
+                __syncthreads();
+                if (act) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const int idx = t * E + e;
+                        const u64_ c = sk[idx ^ j];
+                        const bool lower = (idx & j) == 0, up = (idx & k) == 0;
+                        const u64_ mn = v[e] < c ? v[e] : c, mx = v[e] < c ? c : v[e];
+                        v[e] = (lower == up) ? mn : mx;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (act) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) sk[t * E + e] = v[e];
+    }
+    __syncthreads();
+}
+
+// one workgroup per image: candidate keys in confidence order, then chunked greedy NMS.
+//   n <= 4096 keys: one LDS sort, the NMS reads the sorted keys from LDS.
+//   more: the keys are consumed in ROUNDS of whole confidence bins (4096-bin histogram over the confidence word of the keys; a round takes
+//   the next bins that together fit the 4096-key tile, so equal confidences stay together), each round sorted in LDS and fed to the SAME
+//   greedy pass, which stops at max_det boxes -- usually inside the first round, long before it has seen 30 000 candidates.  (The first
+//   version sorted the whole list in global memory and restarted the NMS when the first 4096 did not yield max_det boxes: a frame's
+//   6 500 candidates / 300 boxes paid ~90 us for that.)  A single bin that overflows the tile: full bitonic sort through global memory.
 __global__ __launch_bounds__(BOX_THREADS) void box_sort_nms_kernel(const float* __restrict__ pred, int N, int nc, float iou_thres, float conf_lo,
                                                                     int agnostic, int max_det, int max_nms, float max_wh,
                                                                     u64* __restrict__ keys_all, int cap, int cap_pow2,
                                                                     int* __restrict__ count, float* __restrict__ out_det,
                                                                     int* __restrict__ out_count) {
-    __shared__ __attribute__((aligned(16))) char kraw[BOX_MAX_DET * sizeof(BoxF)];       // sort tile first (4096 keys), kept boxes afterwards
-    BoxF* kbox = reinterpret_cast<BoxF*>(kraw);
-    __shared__ __attribute__((aligned(16))) char kaux[3 * BOX_MAX_DET * 4];              // selection histogram first (4096 bins), then:
-    float* karea = reinterpret_cast<float*>(kaux);
-    unsigned* kid = reinterpret_cast<unsigned*>(kaux + BOX_MAX_DET * 4);
-    float* kconf = reinterpret_cast<float*>(kaux + 2 * BOX_MAX_DET * 4);
+    extern __shared__ __attribute__((aligned(16))) char box_lds[];
+    u64* sk = reinterpret_cast<u64*>(box_lds + BOX_LDS_SORT);
+    int* pre = reinterpret_cast<int*>(box_lds + BOX_LDS_PRE);
+    BoxF* kbox = reinterpret_cast<BoxF*>(box_lds + BOX_LDS_KBOX);
+    float* karea = reinterpret_cast<float*>(box_lds + BOX_LDS_KAUX);
+    unsigned* kid = reinterpret_cast<unsigned*>(box_lds + BOX_LDS_KAUX + BOX_MAX_DET * 4);
+    float* kconf = reinterpret_cast<float*>(box_lds + BOX_LDS_KAUX + 2 * BOX_MAX_DET * 4);
+    BoxF* cbox = reinterpret_cast<BoxF*>(box_lds + BOX_LDS_CBOX);
     __shared__ u64 supmask[BOX_THREADS / 64];
+    __shared__ u64 cmask[64];
+    __shared__ int wsum[BOX_THREADS / 64];
     __shared__ int s_nkept, s_bsel, s_cnt;
+    constexpr int TILE = BOX_TILE;
 
     const int b = blockIdx.x;
     const int t = threadIdx.x;
     u64* keys = keys_all + (long)b * cap_pow2;
     const bool overflow = count[b] > cap_pow2;
-    int n = min(count[b], cap_pow2);
-    // ---- bitonic sort (ascending u64), padded with ~0
+    const int n = min(count[b], cap_pow2);
     int P = 1;
     while (P < n) P <<= 1;
-    constexpr int TILE = (int)(BOX_MAX_DET * sizeof(BoxF) / sizeof(u64));     // 4096
-    u64* sk = reinterpret_cast<u64*>(kraw);
     const int lane = t & 63, wave = t >> 6;
-    for (int i = n + t; i < P; i += BOX_THREADS) keys[i] = ~0ull;
+    const int n_all = min(n, max_nms);
+    const int n_up = (n + BOX_THREADS - 1) / BOX_THREADS * BOX_THREADS;          // whole waves stay in the key loops (ballots)
+    // the first 8192 keys live in registers (one global round trip for all passes over them)
+    constexpr int KR = 8;
+    u64 kreg[KR];
+#pragma unroll
+    for (int q = 0; q < KR; ++q) { const int i = t + q * BOX_THREADS; kreg[q] = i < n ? keys[i] : ~0ull; }
+    if (t == 0) s_nkept = 0;
     __syncthreads();
-    auto lds_sort = [&](int cntp2) {                 // sk[0..cntp2), cntp2 a power of two <= TILE
-        for (int k = 2; k <= cntp2; k <<= 1) {
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int i = t; i < cntp2; i += BOX_THREADS) {
-                    const int ixj = i ^ j;
-                    if (ixj > i) {
-                        const u64 a = sk[i], c = sk[ixj];
-                        const bool up = (i & k) == 0;
-                        if ((a > c) == up) { sk[i] = c; sk[ixj] = a; }
-                    }
-                }
-                __syncthreads();
-            }
-        }
+#ifdef YP_PROBE_BOX
+    u64* dbg = keys + cap_pow2 - 64; int dbi = 0;
+#define BOXTL(v) do { if (t == 0) { dbg[dbi++] = wall_clock64(); dbg[dbi++] = (u64)(v); } } while (0)
+#else
+#define BOXTL(v) do { } while (0)
+#endif
+    BOXTL(n);
+
+    auto sort_tile = [&](int m) {                    // sk[0..m) -> ascending (padded with ~0 to a power of two)
+        int p2 = 1;
+        while (p2 < m) p2 <<= 1;
+        for (int i = m + t; i < p2; i += BOX_THREADS) sk[i] = ~0ull;
+        __syncthreads();
+        if (p2 >= 4 * BOX_THREADS) box_tile_sort<4>(sk, p2, t);
+        else if (p2 >= 2 * BOX_THREADS) box_tile_sort<2>(sk, p2, t);
+        else box_tile_sort<1>(sk, p2, t);
     };
-    // Full sort: bitonic network; every compare-exchange step whose partner distance j is < 4096 stays inside a 4096-key tile, so those
-    // steps run on tiles held in LDS (all stages k <= 4096 in one visit per tile, then the tail j = 2048..1 of each later stage); only
-    // the j >= 4096 steps go through global memory.  30 000 multi-label candidates (P = 32768): 120 global passes before, 6 now.
+    // Full sort (fallback): bitonic network; every compare-exchange step whose partner distance j is < 4096 stays inside a 4096-key tile, so
+    // those steps run on tiles held in LDS; only the j >= 4096 steps go through global memory.
     auto full_sort = [&]() {
+        for (int i = n + t; i < P; i += BOX_THREADS) keys[i] = ~0ull;
+        __syncthreads();
         auto tile_pass = [&](int kfirst, int klast) {      // stages kfirst..klast (powers of two), steps j = min(k/2, TILE/2) .. 1, per tile
             for (int t0 = 0; t0 < P; t0 += TILE) {
                 const int tn = min(TILE, P - t0);
@@ -428,167 +534,197 @@ __global__ __launch_bounds__(BOX_THREADS) void box_sort_nms_kernel(const float* 
             tile_pass(k, k);
         }
     };
-    // Top-of-the-list shortcut: the greedy NMS stops at max_det boxes, usually long before it has seen 30 000 candidates.  When there
-    // are more than 4096, the best <= 4096 are SELECTED exactly (4096-bin histogram over the confidence word of the keys, whole bins
-    // only, so equal confidences stay together), sorted in LDS and copied behind the list; the NMS runs on that prefix of the
-    // fully sorted order.  Only if it runs out of them before max_det boxes are kept is the whole list sorted and the NMS redone.
-    const int n_all = min(n, max_nms);
-    const u64* src = keys;
-    int src_n = n_all;
-    // (worth trying only when the prefix is likely to suffice: max_det well below the tile; otherwise it is paid on top of the full sort)
-    bool shortcut = n > TILE && (long)P + TILE <= (long)cap_pow2 && max_det * 8 <= TILE;
-    if (shortcut) {
-        int* hist = reinterpret_cast<int*>(kaux);
-        if (t == 0) { s_bsel = -1; s_cnt = 0; }
-        for (int i = t; i < TILE; i += BOX_THREADS) hist[i] = 0;
-        __syncthreads();
-        // confidences lie in (conf_thres, 1]: the key's confidence word (0xFFFFFFFF - float bits) in [~bits(1), ~bits(conf_thres)]
-        const unsigned base_h = 0xFFFFFFFFu - __float_as_uint(1.0f);
-        const unsigned span_h = (0xFFFFFFFFu - __float_as_uint(conf_lo)) - base_h;
-        int shift = 0;
-        while ((span_h >> shift) >= (unsigned)TILE) ++shift;
-#pragma unroll 4
-        for (int i = t; i < n; i += BOX_THREADS) {
-            const unsigned h = (unsigned)(keys[i] >> 32);
-            const unsigned bin = h <= base_h ? 0u : min((h - base_h) >> shift, (unsigned)TILE - 1u);
-            atomicAdd(&hist[bin], 1);
-        }
-        __syncthreads();
-        // inclusive prefix over the bins (4 per thread), largest bin whose prefix still fits the tile
-        int v[4], sum = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { v[q] = hist[4 * t + q]; sum += v[q]; }
-        int incl = sum;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
-        __syncthreads();
-        int* wsum = reinterpret_cast<int*>(supmask);                // 16 wave totals (32 ints fit)
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        int before = incl - sum;
-        for (int w = 0; w < wave; ++w) before += wsum[w];
-        int run = before;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            run += v[q];
-            if (run <= TILE && v[q] > 0) atomicMax(&s_bsel, 4 * t + q);
-        }
-        __syncthreads();
-        const int bsel = s_bsel;
-        if (bsel < 0) shortcut = false;                              // the best bin alone overflows the tile: full sort
-        else {
-            __syncthreads();
-            const int n_up = (n + BOX_THREADS - 1) / BOX_THREADS * BOX_THREADS;          // whole waves stay in the loop (ballots)
-            for (int i = t; i < n_up; i += BOX_THREADS) {
-                const u64 key = i < n ? keys[i] : ~0ull;
-                const unsigned h = (unsigned)(key >> 32);
-                const unsigned bin = h <= base_h ? 0u : min((h - base_h) >> shift, (unsigned)TILE - 1u);
-                const bool sel = i < n && (int)bin <= bsel;
-                const u64 mk = __ballot(sel);                    // one LDS atomic per wave (64 returning atomics on one address serialise)
-                if (mk == 0) continue;
-                const int leader = __ffsll((long long)mk) - 1;
-                int wbase = 0;
-                if (lane == leader) wbase = atomicAdd(&s_cnt, __popcll(mk));
-                wbase = __shfl(wbase, leader, 64);
-                if (sel) sk[wbase + __popcll(mk & ((1ull << lane) - 1ull))] = key;
-            }
-            __syncthreads();
-            const int m = s_cnt;
-            int p2 = 1;
-            while (p2 < m) p2 <<= 1;
-            for (int i = m + t; i < p2; i += BOX_THREADS) sk[i] = ~0ull;
-            __syncthreads();
-            lds_sort(p2);
-            u64* top = keys + P;
-            for (int i = t; i < m; i += BOX_THREADS) top[i] = sk[i];
-            __syncthreads();
-            src = top;
-            src_n = min(m, n_all);
-        }
-    }
-    if (!shortcut) {
-        full_sort();
-        src = keys;
-        src_n = n_all;
-    }
-    if (max_wh < 0.f) src_n = 0;          // (probe: negative max_wh = sort only)
 
-
-    // ---- greedy NMS over sorted candidates, 64 at a time
+    // ---- greedy NMS over a sorted run of candidates, 64 at a time; continues from the kept list in LDS (s_nkept)
     const int no = nc + 5;
     const float* pb = pred + (long)b * N * no;
     constexpr int NW = BOX_THREADS / 64;
     auto run_nms = [&](const u64* list, int cnt) {
-    if (t == 0) s_nkept = 0;
-    __syncthreads();
-    // (software-pipelined: the candidates of chunk c+1 -- key -> prediction row -> box, two dependent global loads, 1-2 us cold -- are fetched
-    // while chunk c is tested and resolved; they were fetched at the top of their own iteration, and a frame's box NMS spent most of its
-    // ~130 us waiting for them)
-    struct Cand { BoxF bx; float area, conf; unsigned id; bool valid; };
-    auto load_cand = [&](int ci) -> Cand {
-        Cand c{BoxF{0.f, 0.f, 0.f, 0.f}, 0.f, 0.f, 0u, ci < cnt};
-        if (c.valid) {
-            const u64 key = list[ci];
-            c.id = (unsigned)(key & 0xFFFFFFFFu);
-            c.conf = __uint_as_float(0xFFFFFFFFu - (unsigned)(key >> 32));
-            const unsigned row = c.id / (unsigned)nc, cls = c.id - row * (unsigned)nc;
+    // The boxes of 1024 sorted candidates at a time are staged in LDS by all threads at once (key -> prediction row -> box: dependent
+    // global loads, 1-2 us cold; the next 1024 are in flight while the current ones are resolved).  Fetched per 64-candidate chunk -- even
+    // one chunk ahead -- every chunk waited about a microsecond for them.
+    auto fetch = [&](int ci) -> BoxF {
+        BoxF bx{0.f, 0.f, 0.f, 0.f};
+        if (ci < cnt) {
+            const unsigned id = (unsigned)(list[ci] & 0xFFFFFFFFu);
+            const unsigned row = id / (unsigned)nc, cls = id - row * (unsigned)nc;
             const float* r = pb + (long)row * no;
             const float cx = r[0], cy = r[1], w = r[2], h = r[3];
             const float off = agnostic ? 0.f : (float)cls * max_wh;
             // xywh2xyxy (utils/general_yolo.py:623-630) then "+ c" (:216-217), both in fp32
-            c.bx.x1 = (cx - w / 2) + off; c.bx.y1 = (cy - h / 2) + off;
-            c.bx.x2 = (cx + w / 2) + off; c.bx.y2 = (cy + h / 2) + off;
-            c.area = (c.bx.x2 - c.bx.x1) * (c.bx.y2 - c.bx.y1);
+            bx.x1 = (cx - w / 2) + off; bx.y1 = (cy - h / 2) + off;
+            bx.x2 = (cx + w / 2) + off; bx.y2 = (cy + h / 2) + off;
         }
-        return c;
+        return bx;
     };
-    Cand nxt = load_cand(lane);
-    for (int base = 0; base < cnt; base += 64) {
+    BoxF staged = fetch(t);
+    bool full = false;
+    for (int blk0 = 0; blk0 < cnt && !full; blk0 += BOX_THREADS) {
+    __syncthreads();                                   // (the previous block's readers are done)
+    cbox[t] = staged;
+    staged = fetch(blk0 + BOX_THREADS + t);
+    __syncthreads();
+    const int blk_end = min(cnt, blk0 + BOX_THREADS);
+    for (int base = blk0; base < blk_end; base += 64) {
         const int nk0 = s_nkept;
-        if (nk0 >= max_det) break;
-        const Cand cur = nxt;
-        nxt = load_cand(base + 64 + lane);
-        const bool valid = cur.valid;
-        const BoxF bx = cur.bx;
-        const float area = cur.area, conf = cur.conf;
-        const unsigned id = cur.id;
+        if (nk0 >= max_det) { full = true; break; }
+        const int ci = base + lane;
+        const bool valid = ci < cnt;
+        const BoxF bx = cbox[ci - blk0];
+        const float area = (bx.x2 - bx.x1) * (bx.y2 - bx.y1);
+        const u64 key = valid ? list[ci] : 0ull;
+        const unsigned id = (unsigned)(key & 0xFFFFFFFFu);
+        const float conf = __uint_as_float(0xFFFFFFFFu - (unsigned)(key >> 32));
         // every wave tests the chunk against a strided share of the kept list
+        // (four kept boxes per step so that their LDS reads are in flight together; a wave leaves the loop once all its candidates are gone)
         bool sup = false;
-        for (int k = wave; k < nk0 && !sup; k += NW) sup = iou_gt(kbox[k], karea[k], bx, area, iou_thres);
+        int k = wave;
+        for (; k + 3 * NW < nk0; k += 4 * NW) {
+            const BoxF b0 = kbox[k], b1 = kbox[k + NW], b2 = kbox[k + 2 * NW], b3 = kbox[k + 3 * NW];
+            const float a0 = karea[k], a1 = karea[k + NW], a2 = karea[k + 2 * NW], a3 = karea[k + 3 * NW];
+            sup = sup | iou_gt_banded(b0, a0, bx, area, iou_thres) | iou_gt_banded(b1, a1, bx, area, iou_thres) | iou_gt_banded(b2, a2, bx, area, iou_thres) |
+                  iou_gt_banded(b3, a3, bx, area, iou_thres);
+            if (__ballot(valid && !sup) == 0) break;
+        }
+        for (; k < nk0 && !sup; k += NW) sup = iou_gt_banded(kbox[k], karea[k], bx, area, iou_thres);
         const u64 m = __ballot(sup && valid);
         if (lane == 0) supmask[wave] = m;
+        // ... and four rows of the chunk's own 64 x 64 suppression matrix (row i: the later candidates j > i that box i suppresses), which does
+        // not depend on the kept list: the serial part below is then bit arithmetic only (it was one broadcast + IoU + ballot per kept box,
+        // ~150 clocks x up to 64 per chunk, on the critical path of every chunk)
+#pragma unroll
+        for (int r = 0; r < 64 / NW; ++r) {
+            const int i = __builtin_amdgcn_readfirstlane(wave * (64 / NW) + r);
+            BoxF bi;
+            bi.x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx.x1), i));
+            bi.y1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx.y1), i));
+            bi.x2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx.x2), i));
+            bi.y2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx.y2), i));
+            const float ai = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(area), i));
+            const u64 row = __ballot(valid && lane > i && iou_gt_banded(bi, ai, bx, area, iou_thres));
+            if (lane == 0) cmask[i] = row;
+        }
         __syncthreads();
         if (wave == 0) {
             u64 dead = 0;
 #pragma unroll
             for (int w = 0; w < NW; ++w) dead |= supmask[w];
             u64 alive = __ballot(valid) & ~dead;
+            const u64 mine = cmask[lane];
+            const unsigned mlo = (unsigned)(mine & 0xFFFFFFFFu), mhi = (unsigned)(mine >> 32);
             int nk = nk0;
+            u64 keep = 0;
             while (alive != 0 && nk < max_det) {
-                const int i = __builtin_amdgcn_readfirstlane(__ffsll((long long)alive) - 1);     // (uniform: a scalar lane index)
-                BoxF bi;                                                                            // v_readlane instead of ds_bpermute
-                bi.x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx.x1), i));
-                bi.y1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx.y1), i));
-                bi.x2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx.x2), i));
-                bi.y2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx.y2), i));
-                const float ai = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(area), i));
-                if (lane == i) { kbox[nk] = bx; karea[nk] = area; kid[nk] = id; kconf[nk] = conf; }
+                const int i = __ffsll((long long)alive) - 1;                                       // (uniform: alive lives in scalar registers)
+                const u64 mi = ((u64)(unsigned)__builtin_amdgcn_readlane((int)mhi, i) << 32) | (unsigned)__builtin_amdgcn_readlane((int)mlo, i);
+                keep |= 1ull << i;
                 ++nk;
-                const bool mine = ((alive >> lane) & 1ull) && lane > i;
-                const bool die = mine && iou_gt(bi, ai, bx, area, iou_thres);
                 alive &= ~(1ull << i);
-                alive &= ~__ballot(die);
+                alive &= ~mi;
+            }
+            if ((keep >> lane) & 1ull) {
+                const int slot = nk0 + __popcll(keep & ((1ull << lane) - 1ull));
+                kbox[slot] = bx; karea[slot] = area; kid[slot] = id; kconf[slot] = conf;
             }
             if (lane == 0) s_nkept = nk;
         }
         __syncthreads();
     }
+    }
     };
-    run_nms(src, src_n);
-    if (shortcut && s_nkept < max_det && src_n < n_all && !(max_wh < 0.f)) {      // the selected prefix ran out: sort everything, redo
+
+    const bool probe_sort_only = max_wh < 0.f;           // (probe: negative max_wh = ordering work only)
+    bool fallback = false;
+    if (n <= TILE) {
+#pragma unroll
+        for (int q = 0; q < TILE / BOX_THREADS; ++q) { const int i = t + q * BOX_THREADS; if (i < n) sk[i] = kreg[q]; }
         __syncthreads();
+        sort_tile(n);
+        if (!probe_sort_only) run_nms(sk, n_all);
+    } else {
+        // confidences lie in (conf_thres, 1]: the key's confidence word (0xFFFFFFFF - float bits) in [~bits(1), ~bits(conf_thres)]
+        const unsigned base_h = 0xFFFFFFFFu - __float_as_uint(1.0f);
+        const unsigned span_h = (0xFFFFFFFFu - __float_as_uint(conf_lo)) - base_h;
+        int shift = 0;
+        while ((span_h >> shift) >= (unsigned)TILE) ++shift;
+        auto bin_of = [&](u64 key) -> int {
+            const unsigned h = (unsigned)(key >> 32);
+            return h <= base_h ? 0 : (int)min((h - base_h) >> shift, (unsigned)TILE - 1u);
+        };
+        // f(i, key) over all keys, whole waves (i may be >= n: key = ~0)
+        auto for_keys = [&](auto&& f) {
+#pragma unroll
+            for (int q = 0; q < KR; ++q)
+                if (q * BOX_THREADS < n_up) f(t + q * BOX_THREADS, kreg[q]);
+            for (int i = t + KR * BOX_THREADS; i < n_up; i += BOX_THREADS) f(i, i < n ? keys[i] : ~0ull);
+        };
+        for (int i = t; i < TILE; i += BOX_THREADS) pre[i] = 0;
+        __syncthreads();
+        for_keys([&](int i, u64 key) { if (i < n) atomicAdd(&pre[bin_of(key)], 1); });
+        __syncthreads();
+        {   // inclusive prefix over the bins (4 per thread)
+            int v[4], sum = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { v[q] = pre[4 * t + q]; sum += v[q]; }
+            int incl = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+            if (lane == 63) wsum[wave] = incl;
+            __syncthreads();
+            int run = incl - sum;
+            for (int w = 0; w < wave; ++w) run += wsum[w];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { run += v[q]; pre[4 * t + q] = run; }
+            __syncthreads();
+        }
+        BOXTL(2);
+        int lo = -1, taken = 0;                           // bins <= lo (taken keys) are consumed
+        while (taken < n_all) {
+            // the next bins that together fit the tile: hi = the largest bin > lo with pre[hi] - taken <= TILE that holds keys itself
+            if (t == 0) s_bsel = -1;
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int bin = 4 * t + q;
+                const int upto = pre[bin], own = upto - (bin ? pre[bin - 1] : 0);
+                if (bin > lo && own > 0 && upto - taken <= TILE) atomicMax(&s_bsel, bin);
+            }
+            __syncthreads();
+            const int hi = s_bsel;
+            if (hi < 0) { fallback = true; break; }      // the next bin alone overflows the tile
+            if (t == 0) s_cnt = 0;
+            __syncthreads();
+            for_keys([&](int i, u64 key) {
+                const int bin = bin_of(key);
+                const bool sel = i < n && bin > lo && bin <= hi;
+                const u64 mk = __ballot(sel);                    // one LDS atomic per wave (64 returning atomics on one address serialise)
+                if (mk != 0) {
+                    const int leader = __ffsll((long long)mk) - 1;
+                    int wbase = 0;
+                    if (lane == leader) wbase = atomicAdd(&s_cnt, __popcll(mk));
+                    wbase = __shfl(wbase, leader, 64);
+                    if (sel) sk[wbase + __popcll(mk & ((1ull << lane) - 1ull))] = key;
+                }
+            });
+            __syncthreads();
+            const int m = s_cnt;
+            BOXTL(m);
+            // (measured and dropped: a counting sort by bin + per-bin insertion sort instead of the network -- 50 us, and planted confidences
+            // put more than 16 keys into single bins, which needs the network anyway)
+            sort_tile(m);
+            BOXTL(1);
+            if (!probe_sort_only) run_nms(sk, min(m, n_all - taken));
+            BOXTL(s_nkept);
+            taken += m;
+            lo = hi;
+            if (probe_sort_only || s_nkept >= max_det) break;
+        }
+    }
+    if (fallback) {                                       // sort everything through global memory, redo the greedy pass on the whole list
+        __syncthreads();
+        if (t == 0) s_nkept = 0;
         full_sort();
-        run_nms(keys, n_all);
+        if (!probe_sort_only) run_nms(keys, n_all);
     }
     // ---- emit (x1,y1,x2,y2,conf,cls) without the class offset
     const int nk = min(s_nkept, max_det);
@@ -931,8 +1067,10 @@ extern "C" int yp_box_nms_classes(const float* pred, int B, int N, int nc, float
     u64* keys = (u64*)((char*)workspace + align_up((size_t)B * 4, 256));
     YP_CHECK_HIP(hipMemsetAsync(count, 0, (size_t)B * 4, st));
     box_candidates_kernel<<<dim3(box_spans(B), B), 256, 0, st>>>(pred, B, N, nc, conf_thres, multi_label, class_mask, keys, cap2, count);
-    box_sort_nms_kernel<<<B, BOX_THREADS, 0, st>>>(pred, N, nc, iou_thres, conf_thres, agnostic, max_det, max_nms, max_wh, keys, cap, cap2, count,
-                                                   out_det, out_count);
+    static YpLdsAttr attr;
+    YP_CHECK_HIP(yp_set_max_lds(attr, (const void*)box_sort_nms_kernel, BOX_LDS_BYTES));
+    box_sort_nms_kernel<<<B, BOX_THREADS, BOX_LDS_BYTES, st>>>(pred, N, nc, iou_thres, conf_thres, agnostic, max_det, max_nms, max_wh, keys, cap, cap2, count,
+                                                               out_det, out_count);
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
 }
