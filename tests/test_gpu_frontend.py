@@ -34,6 +34,30 @@ def test_pts_box_filter_matches_numpy_slice_painting(cuda):
     assert int(cnt.item()) == 700 and torch.equal(out, p)
 
 
+def test_pts_box_filter_two_pass_path(cuda):
+    """More than 1024 points and 16 boxes: the box tests run on all CUs first (verdicts parked in the output buffer), then the
+    order-keeping compaction -- 9 000 points (three 4096-point compaction passes), 40 boxes, counts read from the device, capacity larger
+    than the count; exact list and order against the reference's slice painting."""
+    H, W = 480, 640
+    rng = np.random.default_rng(11)
+    n, cap = 9000, 12000
+    pts = np.stack([rng.integers(0, W, cap), rng.integers(0, H, cap), rng.random(cap)]).astype(np.float32)
+    c = rng.uniform([0, 0], [W, H], (40, 2))
+    wh = rng.uniform(10, 120, (40, 2))
+    boxes = np.concatenate([c - wh / 2, c + wh / 2, rng.random((40, 1)), np.zeros((40, 1))], 1).astype(np.float32)
+    boxes[3, :4] = [-50.5, 100.2, 30.7, 900.0]                                          # negative / out-of-range bounds (numpy slice semantics)
+    ref = postproc_oracle.filter_points(boxes[:37], pts[:, :n].astype(np.float64), H, W)
+    p = torch.from_numpy(np.ascontiguousarray(pts.T)).to(cuda)
+    b = torch.from_numpy(boxes).to(cuda)
+    out, cnt = torch.full_like(p, -1.0), torch.zeros(1, dtype=torch.int32, device=cuda)
+    n_dev, nb_dev = torch.tensor([n], dtype=torch.int32, device=cuda), torch.tensor([37], dtype=torch.int32, device=cuda)
+    _hip.check(_hip.lib().yp_pts_box_filter(p.data_ptr(), n_dev.data_ptr(), cap, b.data_ptr(), nb_dev.data_ptr(), 40, 6, H, W, out.data_ptr(), cnt.data_ptr(),
+                                            _hip.stream_ptr()))
+    k = int(cnt.item())
+    assert 0 < k < n and k == ref.shape[1]
+    np.testing.assert_array_equal(out[:k].cpu().numpy().T, ref.astype(np.float32))
+
+
 @pytest.mark.parametrize("filter_pts", [True, False])
 def test_frontend_matches_oracle_postprocessing(cuda, filter_pts):
     m, _ = make_model("n", 17, dtype="f32")
