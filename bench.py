@@ -322,13 +322,9 @@ def main():
     del plan, img, outs
     net.__dict__.pop("_plans", None)
     torch.cuda.empty_cache()
-    if "train" in only:
-        rec = run_train(a, rank, world, dev, a.version, 8, a.train_steps, a.train_warmup, gas=1)
-        if rank == 0:
-            out["train"] = rec
-    if world == 1 and "train64" in only:
-        out["train_bs64"] = run_train(a, rank, world, dev, a.version, 8, max(3, a.train_steps // 4), 1, gas=8)
     if "fp8" in only:
+        # (first among the sub-records: measured after the -s training records, one of the two -l steps came out ~2 ms slower -- which
+        # one depended on what had run before; on a fresh process both agree with their stand-alone runs)
         # BASELINE configs[4]: YOLOPoint-l, 16 samples per GPU (bs 128 over 8 GPUs), fp8 Conv operands, data parallel over all N ranks;
         # at N = 1 the bf16 step of the same model is timed beside it
         torch.cuda.empty_cache()
@@ -338,6 +334,12 @@ def main():
             rec["bf16_ms_per_step"] = ref["ms_per_step"]
         if rank == 0:
             out["train_l_fp8"] = rec
+    if "train" in only:
+        rec = run_train(a, rank, world, dev, a.version, 8, a.train_steps, a.train_warmup, gas=1)
+        if rank == 0:
+            out["train"] = rec
+    if world == 1 and "train64" in only:
+        out["train_bs64"] = run_train(a, rank, world, dev, a.version, 8, max(3, a.train_steps // 4), 1, gas=8)
     if world == 1 and "frame" in only:
         torch.cuda.empty_cache()
         out["frame"] = run_frame(dev, "l", 1280, a.dtype, a.frame_steps, max(3, a.frame_steps // 6), cpu_threads=a.cpu_threads)

@@ -662,6 +662,12 @@ int yp_plan_set_lane(YpPlan* plan, int op, int lane);
  * Replaces the host-side sequencing of reference demo.py:138-160 (forward -> numpy decode -> NMS): the keypoint post-processing needs the
  * keypoint head only, so the front end (yolopoint_amd/frontend.py) hangs it into the forward's side lane.  A plan with callback ops cannot
  * be captured into a hipGraph (yp_plan_instantiate_graph refuses); it replays eagerly.  fn returns YP_OK or an error code. */
+/* A stream of the library's per-device pool that really runs BESIDE `main_stream` (tested once per caller stream: the runtime maps all
+ * streams of a process onto a few hardware queues, and two streams on one queue serialise).  slot 0: the plans' side lane; slot 1: an
+ * auxiliary stream for the caller (engine.TrainStep's loss / label stream).  The streams live as long as the process.
+ * (no reference counterpart: the reference runs everything on PyTorch's current stream) */
+int yp_stream_pick(void* main_stream, int slot, void** out_stream);
+
 typedef int (*yp_plan_callback_t)(void* user, void* stream);
 int yp_plan_add_callback(YpPlan* plan, yp_plan_callback_t fn, void* user);
 /* capture the op list into a hipGraph on `stream` (call once, after the last add) */

@@ -196,3 +196,34 @@ def test_forward_v52(cuda, version, B, S, dtype):
     assert rel_err(got["objects"][0], ref["objects"][0])[1 if dtype != "f32" else 0] < (1e-3 if dtype == "f32" else 2e-2)
     if dtype == "f32":
         assert torch.equal(got["semi"].argmax(1).cpu(), ref["semi"].argmax(1))
+
+
+def test_stream_pick_returns_tested_companions(cuda):
+    """yp_stream_pick: the companion streams of a caller's stream come from the library's pool, differ from the caller's and from each
+    other, stay the same for the life of the process, and -- the point of the test kernels -- work queued on slot 0 completes while the
+    caller's stream is still busy (different hardware queues)."""
+    import ctypes as C
+    from yolopoint_amd import _hip
+    l = _hip.lib()
+    main = torch.cuda.Stream(device=cuda)
+    picks = []
+    for slot in (0, 1, 0, 1):
+        out = C.c_void_p()
+        _hip.check(l.yp_stream_pick(C.c_void_p(main.cuda_stream), slot, C.byref(out)))
+        picks.append(out.value)
+    assert picks[0] == picks[2] and picks[1] == picks[3]
+    assert len({main.cuda_stream, picks[0], picks[1]}) == 3
+    side = torch.cuda.ExternalStream(picks[0], device=cuda)
+    x = torch.randn(4096, 4096, device=cuda)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(main):
+        for _ in range(40):                       # ~ms of work on the caller's stream
+            x = x @ x * 1e-3
+        busy = main.record_event()
+    with torch.cuda.stream(side):
+        y = torch.zeros(8, device=cuda) + 1
+        done = side.record_event()
+    done.synchronize()
+    assert not busy.query(), "the side lane's work waited for the caller's stream: the two share a hardware queue"
+    torch.cuda.synchronize()
+    assert float(y.sum()) == 8.0

@@ -3,6 +3,7 @@
 // module-by-module dispatch (models/YOLOPoint.py:198-246): the host walks the module tree once,
 // emits descriptors, and every later forward is one C call.
 #include "yp_internal.h"
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <vector>
@@ -181,25 +182,112 @@ extern "C" int yp_plan_add_callback(YpPlan* plan, yp_plan_callback_t fn, void* u
 
 extern "C" int yp_plan_num_ops(const YpPlan* plan) { return plan ? (int)plan->ops.size() : 0; }
 
-// The side lane of every plan of a device is ONE stream, created on first use and kept for the life of the process: plans come and go by
-// the hundred (one per input shape and weight version), and a stream per plan that is destroyed with it left the runtime in a state in
-// which a later, unrelated hipGraphLaunch crashed (ROCm 7.2; reproducible only after ~400 tests in one process).  Sharing is harmless:
-// a plan orders its side ops with its own fork / join events.
-static hipStream_t g_side_streams[64] = {};
-static std::mutex g_side_mutex;
-static int ensure_side(YpPlan* plan) {
-    if (plan->side) return YP_OK;
+// ---------------------------------------------------------------------------------------------
+// Streams that really run beside the caller's.  The runtime multiplexes all HIP streams of a process onto a handful of hardware queues
+// (four by default); two streams that land on the same queue execute strictly one after the other, and which queue a stream gets depends
+// on how many streams the process (PyTorch's pool included) has created before it.  Measured: a second TrainStep in one process put the
+// plans' side lane on the main stream's queue -- the two-lane forward then ran SLOWER than one lane (9.5 vs 7.4 ms per step), and with
+// GPU_MAX_HW_QUEUES=2 the inference forward fell back to its one-lane time.  So the library keeps a small pool of streams (created once per
+// device, never destroyed: see below) and, the first time a caller's stream asks for a companion, TESTS candidates: a 200 us spin kernel on
+// the caller's stream, an empty kernel on the candidate -- when the empty kernel's event completes while the spin's has not, the two
+// streams are on different queues.  slot 0 = the plans' side lane, slot 1 = an auxiliary stream (engine.TrainStep's loss / label stream);
+// the picks of one caller are tested against each other too.  YP_STREAM_PICK=0: no tests, pool order.
+//
+// (One side stream per plan, destroyed with the plan, left the runtime in a state in which a later, unrelated hipGraphLaunch crashed --
+// ROCm 7.2, reproducible only after ~400 tests in one process.  Sharing is harmless: a plan orders its side ops with its own events.)
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int POOL_STREAMS = 8, PICK_SLOTS = 2;
+struct StreamSet { hipStream_t main; hipStream_t pick[PICK_SLOTS]; };
+struct DevStreams { std::vector<hipStream_t> pool; std::vector<StreamSet> sets; };
+DevStreams g_dev_streams[64];
+std::mutex g_side_mutex;
+
+__global__ void yp_spin_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+__global__ void yp_nop_kernel() {}
+
+// true when work on `b` completes while `a` is still busy
+bool streams_concurrent(hipStream_t a, hipStream_t b) {
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (hipEventCreateWithFlags(&ea, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&eb, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        return true;
+    }
+    yp_spin_kernel<<<1, 64, 0, a>>>(20000);              // 200 us of the 100 MHz wall clock
+    (void)hipEventRecord(ea, a);
+    yp_nop_kernel<<<1, 64, 0, b>>>();
+    (void)hipEventRecord(eb, b);
+    (void)hipEventSynchronize(eb);
+    const bool conc = hipEventQuery(ea) == hipErrorNotReady;
+    (void)hipGetLastError();
+    (void)hipEventSynchronize(ea);
+    (void)hipEventDestroy(ea);
+    (void)hipEventDestroy(eb);
+    return conc;
+}
+}  // namespace
+
+extern "C" int yp_stream_pick(void* main_stream, int slot, void** out) {
+    YP_REQUIRE(out != nullptr && slot >= 0 && slot < PICK_SLOTS, "yp_stream_pick: bad arguments");
+    hipStream_t main = (hipStream_t)main_stream;
     int dev = 0;
     YP_CHECK_HIP(hipGetDevice(&dev));
-    {
-        std::lock_guard<std::mutex> lock(g_side_mutex);
-        hipStream_t& s = g_side_streams[dev & 63];
-        // (a lowest-priority side stream was measured: no effect on the two-lane forward, 0.687-0.693 vs 0.686-0.702 ms)
-        if (!s) YP_CHECK_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        plan->side = s;
+    std::lock_guard<std::mutex> lock(g_side_mutex);
+    DevStreams& ds = g_dev_streams[dev & 63];
+    StreamSet* set = nullptr;
+    for (StreamSet& s : ds.sets)
+        if (s.main == main) { set = &s; break; }
+    if (set == nullptr) {
+        ds.sets.push_back(StreamSet{main, {nullptr, nullptr}});
+        set = &ds.sets.back();
     }
-    YP_CHECK_HIP(hipEventCreateWithFlags(&plan->fork, hipEventDisableTiming));
-    YP_CHECK_HIP(hipEventCreateWithFlags(&plan->join, hipEventDisableTiming));
+    if (set->pick[slot] == nullptr) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        const bool capturing = main != nullptr && hipStreamIsCapturing(main, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+        (void)hipGetLastError();
+        const char* env = getenv("YP_STREAM_PICK");
+        const bool test = !(env && env[0] == '0') && !capturing;
+        while ((int)ds.pool.size() < POOL_STREAMS) {
+            hipStream_t s = nullptr;
+            // (a lowest-priority side stream was measured: no effect on the two-lane forward, 0.687-0.693 vs 0.686-0.702 ms)
+            YP_CHECK_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+            ds.pool.push_back(s);
+        }
+        hipStream_t chosen = nullptr;
+        for (hipStream_t cand : ds.pool) {
+            bool taken = cand == main;
+            for (int k = 0; k < PICK_SLOTS; ++k) taken = taken || set->pick[k] == cand;
+            if (taken) continue;
+            bool ok = !test || streams_concurrent(main, cand);
+            for (int k = 0; k < PICK_SLOTS && ok && test; ++k)
+                if (set->pick[k] != nullptr) ok = streams_concurrent(set->pick[k], cand);
+            if (getenv("YP_STREAM_DEBUG")) fprintf(stderr, "[yp_stream_pick] main %p slot %d candidate %p: %s\n", (void*)main, slot, (void*)cand, ok ? "concurrent" : "shares a queue");
+            if (ok) { chosen = cand; break; }
+        }
+        if (chosen == nullptr)                            // nothing passed: pool order
+            for (hipStream_t cand : ds.pool) {
+                bool taken = cand == main;
+                for (int k = 0; k < PICK_SLOTS; ++k) taken = taken || set->pick[k] == cand;
+                if (!taken) { chosen = cand; break; }
+            }
+        if (capturing) { *out = chosen; return YP_OK; }   // (not remembered: decided again, with the test, outside the capture)
+        set->pick[slot] = chosen;
+    }
+    *out = set->pick[slot];
+    return YP_OK;
+}
+
+static int ensure_side(YpPlan* plan, hipStream_t st) {
+    void* s = nullptr;
+    if (int rc = yp_stream_pick((void*)st, 0, &s)) return rc;
+    plan->side = (hipStream_t)s;
+    if (plan->fork == nullptr) {
+        YP_CHECK_HIP(hipEventCreateWithFlags(&plan->fork, hipEventDisableTiming));
+        YP_CHECK_HIP(hipEventCreateWithFlags(&plan->join, hipEventDisableTiming));
+    }
     return YP_OK;
 }
 
@@ -229,9 +317,13 @@ static int run_eager(YpPlan* plan, hipStream_t st) {
             if (int rc = issue_one()) return rc;
         return YP_OK;
     };
+    bool have_side = false;
     for (const PlanOp& op : plan->ops) {
         if (op.lane == YP_LANE_SIDE) {
-            if (int rc = ensure_side(plan)) return rc;
+            if (!have_side) {
+                if (int rc = ensure_side(plan, st)) return rc;
+                have_side = true;
+            }
             if (main_since_fork) {
                 if (int rc = flush()) return rc;           // (earlier side work keeps its place in the side stream's order)
                 YP_CHECK_HIP(hipEventRecord(plan->fork, st));
@@ -297,7 +389,7 @@ extern "C" int yp_plan_instantiate_graph(YpPlan* plan, void* stream) {
     for (const PlanOp& op : plan->ops) YP_REQUIRE(op.kind != OP_CALLBACK, "yp_plan_instantiate_graph: a plan with callback ops replays eagerly");
     const size_t n = plan->ops.size();
     for (const PlanOp& op : plan->ops)
-        if (op.lane == YP_LANE_SIDE) { if (int rc = ensure_side(plan)) return rc; break; }     // (no stream creation inside a capture)
+        if (op.lane == YP_LANE_SIDE) { if (int rc = ensure_side(plan, st)) return rc; break; }     // (no stream creation inside a capture)
     bool rewire = n > 1;
     for (const PlanOp& op : plan->ops) rewire = rewire && op.has_deps && op.lane == YP_LANE_MAIN;
     YP_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));

@@ -115,12 +115,35 @@ class TrainStep:
             from . import _hip
             _hip.check(_hip.lib().yp_sampling_set_max_workgroups(int(os.environ.get("YP_SIDE_WGS", "256"))))
         self._in_flight, self._max_in_flight = collections.deque(), int(os.environ.get("YP_STEPS_IN_FLIGHT", "2"))
-        self.side_stream = torch.cuda.Stream(device=device) if os.environ.get("YP_TRAIN_SIDE_STREAM", "1") == "1" and torch.device(device).type == "cuda" else None
+        # the loss / label stream: the stream the library TESTED to run beside the step's main stream (yp_stream_pick: streams that share a
+        # hardware queue serialise -- a torch.cuda.Stream() from PyTorch's pool landed on the main stream's queue or not depending on how many
+        # streams the process had handed out before: 7.4 or 9.4 ms per step).  It IS the plans' side lane (slot 0): the label kernels, the
+        # heads of the forward and the InfoNCE chain are all background work for the main chain, and one queue for them measured faster than
+        # two (7.45 vs 7.68 ms; YP_AUX_STREAM=pick: a third queue, =torch: a PyTorch pool stream)
+        self._use_side = os.environ.get("YP_TRAIN_SIDE_STREAM", "1") == "1" and torch.device(device).type == "cuda"
+        self._side_streams = {}
         self.reducer.broadcast_parameters(model)
 
     def __call__(self, batch):
         with torch.cuda.device(self.device):
             return self._step(batch)
+
+    def _side_for(self, main):
+        if not self._use_side:
+            return None
+        key = main.cuda_stream
+        s = self._side_streams.get(key)
+        if s is None:
+            import ctypes as C
+            from . import _hip
+            out = C.c_void_p()
+            mode = os.environ.get("YP_AUX_STREAM", "lane")
+            if mode == "torch":
+                s = self._side_streams[key] = torch.cuda.Stream(device=self.device)
+                return s
+            _hip.check(_hip.lib().yp_stream_pick(C.c_void_p(key), 0 if mode == "lane" else 1, C.byref(out)))
+            s = self._side_streams[key] = torch.cuda.ExternalStream(out.value, device=self.device)
+        return s
 
     def _step(self, batch):
         """batch: one micro-batch (gas == 1) or a sequence of `gas` micro-batches."""
@@ -227,7 +250,7 @@ class TrainStep:
         B, H, W = img.shape[0], img.shape[-2], img.shape[-1]
         Hc, Wc = H // 8, W // 8
         main = torch.cuda.current_stream(dev)
-        side = self.side_stream if self.side_stream is not None else main
+        side = self._side_for(main) or main
         fork = main.record_event() if side is not main else None
         g = net._train_graph(img, pair=True, fp8=bool(getattr(net, "fp8_train", False)))
         g.busy = True
@@ -398,7 +421,7 @@ class TrainStep:
         # stream at a point BEFORE the forward: they execute beside the forward pass instead of between it and the losses, and the host
         # synchronisation waits for the side stream only.  YP_TRAIN_SIDE_STREAM=0: everything on the main stream, after the forward launch.
         main = torch.cuda.current_stream(dev)
-        side = self.side_stream if (prepare and self.side_stream is not None) else main
+        side = (self._side_for(main) if prepare else None) or main
         fork = main.record_event() if side is not main else None      # (the batch tensors were produced on the main stream before this point)
 
         def label_work():
