@@ -23,4 +23,8 @@ cp $S/bench_frame.json profiles/${R}_bench_frame.json
 cp $S/bench_export.json profiles/${R}_bench_export.json
 cp $S/train_traffic.json profiles/train_traffic.json
 cp $S/${R}_conv_bench_*.txt $S/${R}_mma8_pmc_*.txt profiles/
+cp $S/${R}_bn_bench.txt profiles/ 2>/dev/null || true
+# the frame pipeline's kernel table + one frame in start order (tools/probe/frame_trace.sh, run after the round)
+cp gpurun_out/frame_kernels.txt profiles/${R}_frame_kernels.txt 2>/dev/null || true
+cp gpurun_out/frame_sequence.txt profiles/${R}_frame_sequence.txt 2>/dev/null || true
 ls -la profiles/
