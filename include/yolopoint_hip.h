@@ -149,6 +149,15 @@ typedef struct YpConvDesc {
      * zero-stuffed tensor: a quarter of the multiply-adds.  No out2 / Detect / bn_partial / ksplit / pointwise prologue. */
     int32_t out_phase;
     int32_t reserved_;
+    /* Fused stem (reference models/YOLOPoint.py:156-157, `Conv1` then `Conv2`): when stem_x != NULL this 3x3 / stride-2 / pad-1 convolution over 32
+     * channels reads act(stem(x)) -- the 6x6 / stride-2 / pad-2 stem of yp_stem_conv applied to the caller's NCHW fp32 image -- instead of in0: the
+     * stem's output (the largest activation of the network) lives in LDS only.  in0 then only DESCRIBES that tensor (H, W, C = 32, any non-null
+     * ptr); stem_weight / stem_bias / stem_Kpad / stem_act are yp_stem_conv's arguments, stem_C the image channels (<= 4).  16-bit types, out.C <= 64,
+     * no residual / second output / Detect / bn_partial. */
+    const float* stem_x;
+    const void* stem_weight;
+    const float* stem_bias;
+    int32_t stem_Kpad, stem_act, stem_C, stem_reserved_;
 } YpConvDesc;
 
 /* Number of bn_partial rows the launch described by `d` (its tile id included) writes; rows are batch-major, so with `groups` statistics

@@ -227,3 +227,28 @@ def test_stream_pick_returns_tested_companions(cuda):
     assert not busy.query(), "the side lane's work waited for the caller's stream: the two share a hardware queue"
     torch.cuda.synchronize()
     assert float(y.sum()) == 8.0
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("model_name", ["YOLOPoint", "YOLOPointv52"])
+def test_fused_stem_conv2_equals_the_two_launches(cuda, monkeypatch, dtype, model_name):
+    """Conv1 + Conv2 as one launch (stem output in LDS only; -s width) against the two-launch plan: non-square input whose Conv2 tiles are
+    ragged in both directions (H / 4 = 40 rows = 10 tiles of 4, W / 4 = 56 columns = 3.5 tiles of 16), image borders on every side.  The
+    stem output is rounded to 16 bits in both forms and Conv2 sums its taps in the same order: every head must agree to the last bit
+    or, where the two-launch plan's tile sums in another order, to 2 ulp of the 16-bit storage."""
+    from helpers import make_model
+    from oracle import net_oracle
+    outs = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("YP_FUSE_STEM2", fuse)
+        m, _ = make_model("s", 29, dtype=dtype, model_name=model_name)
+        m = m.to(cuda).eval()
+        m.fuse()
+        x = net_oracle.synth_image(2, 3, 160, 224, 31).to(cuda)
+        with torch.no_grad():
+            o = m(x)
+        plan = next(iter(m.model._plans.values()))[0]
+        assert ("Conv2" in plan.stem_record.name) == (fuse == "1"), plan.stem_record.name
+        outs[fuse] = [o["semi"].float().clone(), o["desc"].float().clone(), o["objects"][0].float().clone()]
+    for a, b in zip(outs["1"], outs["0"]):
+        assert float((a - b).abs().max()) <= 2.0 ** -7 * float(b.abs().max()) * (1 if dtype == "bf16" else 0.125) + 1e-6

@@ -38,7 +38,9 @@ class YpConvDesc(C.Structure):
                 ("pre_act", C.c_int32), ("post_act", C.c_int32),
                 ("post_weight", C.c_void_p), ("post_bias", C.c_void_p), ("post_Kpad", C.c_int32), ("post_Npad", C.c_int32),
                 ("bn_partial", C.c_void_p), ("split_slabs", C.c_void_p), ("split_stride", C.c_int64),
-                ("scale_in", C.c_void_p), ("scale_w", C.c_void_p), ("out_phase", C.c_int32), ("reserved_", C.c_int32)]
+                ("scale_in", C.c_void_p), ("scale_w", C.c_void_p), ("out_phase", C.c_int32), ("reserved_", C.c_int32),
+                ("stem_x", C.c_void_p), ("stem_weight", C.c_void_p), ("stem_bias", C.c_void_p),
+                ("stem_Kpad", C.c_int32), ("stem_act", C.c_int32), ("stem_C", C.c_int32), ("stem_reserved_", C.c_int32)]
 
 
 class YpDetectDesc(C.Structure):

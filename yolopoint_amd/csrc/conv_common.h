@@ -106,6 +106,10 @@ struct ConvKArgs {
     const float* scale_in;         // 8-bit input types: the accumulators are multiplied by *scale_in * *scale_w (device scalars: the
     const float* scale_w;          // dequantisation scales of the activation and of the filter) before the epilogue
     unsigned mg_howo, mg_wo;       // conv_wsk.hip: ceil(2^32 / HoWo), ceil(2^32 / Wo) when M * HoWo < 2^32 (exact magic division), else 0
+    const float* stem_x;           // fused stem + 3x3 / stride-2 convolution (stem_conv2_kernel): the caller's NCHW fp32 image, the stem's paired-pixel
+    const char* stem_wgt;          // filter / bias, the image's dims and channel count
+    const float* stem_bias;
+    int stem_Kpad, stem_act, stem_C, stem_H, stem_W;
     int probe;                     // -DYP_PROBE8 builds of conv_mma8.hip: elimination experiments (1 no MFMA, 2 no steady-state DMA, 4 L2-resident pixels)
 };
 

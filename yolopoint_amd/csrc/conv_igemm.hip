@@ -1433,6 +1433,224 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
     }
 }
 
+// ==========================================================================================
+// Fused stem + Conv2 (reference models/YOLOPoint.py:156-157): out = act2(conv3x3/s2(act1(stem6x6/s2(image)))) with 32 stem channels.
+// The stem's output is the largest activation of the network (8 x 320 x 320 x 32 halves = 52 MB at batch 8, 640 x 640): written once and
+// read once, it is 104 of the 169 MB the first two launches move.  Here it never leaves the workgroup:
+//   phase A  the image halo of a TH x 16 tile of Conv2 outputs -- (4 TH + 6) rows x 72 columns of the fp32 planes -- is read, converted
+//            and stored as 4-channel pixel PAIRS exactly as stem_conv_kernel does; the stem outputs the tile needs ((2 TH + 1) rows x 33
+//            columns) are computed by MFMA in fragments of 16 pixels that follow the stride-2 halo layout of conv3x3_halo_kernel (a halo
+//            row = the 17 odd-side columns, then the 16 even-side ones: fragments of 16 consecutive LDS rows read every other pixel pair),
+//            get bias + activation, are zeroed outside the stem's output image (Conv2's padding acts on the stem OUTPUT) and are stored
+//            as 16-bit rows in the swizzled 64-byte-row format the halo DMA would have produced;
+//   phase B  conv3x3_halo_kernel's stride-2 tap arithmetic over that resident halo; wave w computes channels [16 w, 16 w + 16) of every pixel of
+//            the tile with its nine filter fragments in registers (no filter ring in LDS).
+// A workgroup loops over tiles (two resident workgroups per CU), so the filter fragments are fetched once.  HBM traffic: the image once
+// (+ halo overlap) and Conv2's output once.  Measured (batch 8, 640 x 640, f16): 49-52 us against 35 + 26 for the two launches; what is left
+// is the stem's activation arithmetic (26 M SiLU on the VALU, two transcendentals each), which the two-launch form hid behind its
+// memory time.  (A first version with `__launch_bounds__(256, 4)` spilled 9 registers: the scratch set-up alone cost ~20 us per launch.)
+// ==========================================================================================
+template <int DT, int TH>
+__global__ __launch_bounds__(256, 2) void stem_conv2_kernel(const ConvKArgs a) {
+    using E = Elem<DT>;
+    using frag_t = typename E::frag;
+    using sc = typename E::scalar;
+    static_assert(E::BYTES == 2, "fused stem: 16-bit element types");
+    constexpr int EB = 2, TW = 16, BN = 64, CH = 32;
+    constexpr int FM = TH, LPG = 4;                                    // phase B: wave w computes channels [16 w, 16 w + 16) of all TH x 16 pixels
+    constexpr int HH = 2 * TH + 1, HP = 34, HROWS = HH * HP, HSLOTS = (HROWS + 15) / 16, HBYTES = HSLOTS * 1024;
+    constexpr int IH = 4 * TH + 6, IP = 36, QUADS = IP / 2, ITEMS = IH * QUADS, NIT = (ITEMS + 255) / 256, IBYTES = IH * IP * 16;
+    constexpr int FN1 = CH / 16, LPG1 = 4 * FN1;                      // stem: 32 channels = 2 fragments, a lane holds 8 consecutive channels
+    constexpr int NFRAG = 2 * HH + (HH + 15) / 16;                     // per halo row: slots 0..15 and 17..32; then the slot-16 pixels of all rows
+    static_assert(LPG1 == 8 && BN == 64, "unsupported tile");
+
+    extern __shared__ __attribute__((aligned(1024))) char hsm[];      // [hidden halo][image halo]
+    sc* img = reinterpret_cast<sc*>(hsm + HBYTES);
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int p = lane & 15, g = lane >> 4;
+
+    // ---- Conv2's filter stays in registers: wave w multiplies its 16 channels against every pixel of the tile, so it needs 9 fragments
+    // (lane (n = p, g): W2[16 w + p][tap][8 g .. 8 g + 8)) and no LDS ring at all -- LDS holds the two halos only, four workgroups per CU
+    frag_t wf2[9];
+    {
+        const int n = wave * 16 + p;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (n < a.Npad) wf2[tap] = *reinterpret_cast<const frag_t*>(a.wgt + ((size_t)n * a.Kpad + tap * CH + g * 8) * EB);
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) wf2[tap][j] = (sc)0.f;
+            }
+        }
+    }
+    // ---- stem filter fragments + biases (once per workgroup: it loops over tiles -- with one tile per workgroup the 19 filter
+    // fragments per lane were 250 MB of L2 reads per launch, more than the image and the output together)
+    frag_t wf1[FN1][5];
+#pragma unroll
+    for (int f = 0; f < FN1; ++f) {
+        const int n = (p >> 2) * LPG1 + f * 4 + (p & 3);
+#pragma unroll
+        for (int kk = 0; kk < 5; ++kk) {
+            const int q = 4 * kk + g;
+            if (q < 18) wf1[f][kk] = *reinterpret_cast<const frag_t*>(a.stem_wgt + ((size_t)n * a.stem_Kpad + q * 8) * 2);
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) wf1[f][kk][j] = (sc)0.f;
+            }
+        }
+    }
+    float bv1[LPG1];
+#pragma unroll
+    for (int j = 0; j < LPG1; ++j) bv1[j] = a.stem_bias != nullptr ? a.stem_bias[g * LPG1 + j] : 0.f;
+    const int nb = wave * 16 + g * LPG;
+    float bias[LPG];
+    yp_load_bias<LPG>(a, nb, bias);
+    const int H1 = a.Hi, W1 = a.Wi;
+    const int ntiles = a.stats_rows;                  // (host: B * tiles_y * tiles_x)
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int bid = tile;
+    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y;
+    const int b = bid / a.tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    // ---- image halo: rows 4 y0 - 4 .. , columns 4 x0 - 4 .. (72 of them), all channels; every load in flight before the first is consumed
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    const int H = a.stem_H, W = a.stem_W, C = a.stem_C;
+    const size_t plane = (size_t)H * W;
+    f32x4 v[NIT][4];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int item = t + 256 * it;
+        const int row = item / QUADS, q = item - row * QUADS;
+        const int iy = 4 * y0 - 4 + row, ix = 4 * x0 - 4 + 4 * q;
+        const bool rowok = item < ITEMS && (unsigned)iy < (unsigned)H;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            v[it][ch] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (rowok && ch < C) {
+                const float* src = a.stem_x + ((size_t)b * C + ch) * plane + (size_t)iy * W + ix;
+                if (ix >= 0 && ix + 3 < W) v[it][ch] = *reinterpret_cast<const f32x4u*>(src);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if ((unsigned)(ix + e) < (unsigned)W) v[it][ch][e] = src[e];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int item = t + 256 * it;
+        if (item >= ITEMS) continue;
+        const int row = item / QUADS, q = item - row * QUADS;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            u32x4 pk;
+            sc* e = reinterpret_cast<sc*>(&pk);
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) { e[ch] = (sc)v[it][ch][2 * pr]; e[4 + ch] = (sc)v[it][ch][2 * pr + 1]; }
+            *reinterpret_cast<u32x4*>(&img[(row * IP + 2 * q + pr) * 8]) = pk;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase A: the stem outputs of the halo, fragment by fragment
+    // (two fragments per step: four independent MFMA chains, and the activation arithmetic of one pair overlaps the MFMAs of the next)
+    for (int fid0 = wave; fid0 < NFRAG; fid0 += 8) {
+        int hy[2], slot[2], pair[2];
+        bool lane_ok[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            int fid = fid0 + 4 * u;
+            lane_ok[u] = fid < NFRAG;
+            if (fid >= NFRAG) fid = fid0;
+            if (fid < 2 * HH) {
+                hy[u] = fid >> 1;
+                if (fid & 1) { slot[u] = 17 + p; pair[u] = 2 * p + 1; } else { slot[u] = p; pair[u] = 2 * p; }
+            } else {
+                hy[u] = p + 16 * (fid - 2 * HH);
+                lane_ok[u] = lane_ok[u] && hy[u] < HH;
+                if (hy[u] >= HH) hy[u] = HH - 1;
+                slot[u] = 16; pair[u] = 32;
+            }
+        }
+        f32x4 acc1[2][FN1];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int f = 0; f < FN1; ++f) acc1[u][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 5; ++kk) {
+            const int q = 4 * kk + g;
+            const int r = q / 3, sp = q - r * 3;
+            frag_t xv[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (q < 18) xv[u] = *reinterpret_cast<const frag_t*>(&img[((2 * hy[u] + r) * IP + pair[u] + sp) * 8]);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xv[u][j] = (sc)0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int f = 0; f < FN1; ++f) acc1[u][f] = E::mma(wf1[f][kk], xv[u], acc1[u][f]);
+        }
+        const int nfr = fid0 + 4 < NFRAG ? 2 : 1;           // (wave-uniform: the activation arithmetic is the expensive part of a fragment)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u >= nfr) break;
+            const int sy = 2 * y0 - 1 + hy[u];
+            const int sx = slot[u] < 17 ? 2 * (x0 + slot[u]) - 1 : 2 * (x0 + slot[u] - 17);
+            const bool inside = (unsigned)sy < (unsigned)H1 && (unsigned)sx < (unsigned)W1;
+            u32x4 pk;
+            sc* e = reinterpret_cast<sc*>(&pk);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float x = acc1[u][j >> 2][j & 3] + bv1[j];
+                if (a.stem_act == YP_ACT_SILU) x = yp_silu(x);
+                e[j] = (sc)(inside ? x : 0.0f);
+            }
+            const int rho = hy[u] * HP + slot[u];
+            const int sw = (0x3300 >> (((rho >> 2) & 3) * 4)) & 3;
+            if (lane_ok[u]) *reinterpret_cast<u32x4*>(hsm + rho * 64 + ((g ^ sw) << 4)) = pk;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // ---- phase B: 3x3 / stride 2 over the resident halo
+    f32x4 acc[FM];
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) acc[fm] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            constexpr int XC2[3] = {0, 17, 1};
+            const int xc = XC2[s] + r * HP + p;
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) {
+                const int rho = (fm * 2) * HP + xc;
+                const int sw = (0x3300 >> (((rho >> 2) & 3) * 4)) & 3;
+                const frag_t xf = *reinterpret_cast<const frag_t*>(hsm + rho * 64 + ((g ^ sw) << 4));
+                acc[fm] = E::mma(wf2[r * 3 + s], xf, acc[fm]);
+            }
+        }
+    }
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) {
+        const int oy = y0 + fm, ox = x0 + p;
+        if (oy >= a.Ho || ox >= a.Wo) continue;
+        const int m = (b * a.Ho + oy) * a.Wo + ox;
+        yp_epilogue_pixel<DT, false, LPG>(a, m, nb, bias, [&](int cj) { return acc[fm][cj]; });
+    }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -1715,6 +1933,37 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
                            d->stride_h == d->stride_w && (d->stride_h == 1 || d->stride_h == 2) && d->in0.ups == 0 && ksplit == 1 && !d->atomic_accumulate &&
                            in0_bytes + (size_t)d->in0.cstride * eb + 64 < (1ull << 31);
     const bool halo_ok = halo_base && (d->in1.C == 0 || post);
+    if (d->stem_x != nullptr) {          // fused stem + this 3x3 / stride-2 convolution: the stem's output lives in LDS
+        YP_REQUIRE(halo_base && d->stride_h == 2 && !of32 && d->in0.C == 32 && d->in1.C == 0 && d->res.C == 0 && d->out2.C == 0 && det == nullptr &&
+                   d->bn_partial == nullptr && d->pre_weight == nullptr && d->out_phase == 0 && Cout <= 64 && Cout % 8 == 0,
+                   "yp_conv2d: the fused stem needs a plain 16-bit 3x3 / stride 2 / pad 1 convolution of 32 -> <= 64 channels");
+        YP_REQUIRE(d->stem_weight != nullptr && d->stem_Kpad >= 144 && d->stem_C >= 1 && d->stem_C <= 4 && d->Hi % 2 == 0 && d->Wi % 2 == 0,
+                   "yp_conv2d: bad fused-stem arguments");
+        YP_REQUIRE(d->tile == 0, "yp_conv2d: tile %d does not apply to the fused stem", d->tile);
+        a.stem_x = d->stem_x; a.stem_wgt = (const char*)d->stem_weight; a.stem_bias = d->stem_bias; a.stem_Kpad = d->stem_Kpad; a.stem_act = d->stem_act;
+        a.stem_C = d->stem_C; a.stem_H = 2 * d->Hi; a.stem_W = 2 * d->Wi;
+        constexpr int TH = 4;
+        a.tiles_n = 1;
+        a.tiles_x = yp_cdiv(d->Wo, 16);
+        a.tiles_y = yp_cdiv(d->Ho, TH);
+        a.Ho = d->Ho;
+        const int ntl = d->B * a.tiles_y * a.tiles_x;
+        a.stats_rows = ntl;                 // (the tile count: workgroups loop over tiles)
+        const int nbs = ntl < 2 * 256 ? ntl : 2 * 256;     // (two resident workgroups per CU: 216 VGPRs)
+        constexpr int HSL = ((2 * TH + 1) * 34 + 15) / 16;
+        constexpr size_t lds = (size_t)HSL * 1024 + (size_t)(4 * TH + 6) * 36 * 16;
+        if (d->dtype == YP_F16) {
+            static YpLdsAttr attr;
+            e = yp_set_max_lds(attr, (const void*)stem_conv2_kernel<YP_F16, TH>, (int)lds);
+            if (e == hipSuccess) { stem_conv2_kernel<YP_F16, TH><<<nbs, 256, lds, stream>>>(a); e = hipGetLastError(); }
+        } else {
+            static YpLdsAttr attr;
+            e = yp_set_max_lds(attr, (const void*)stem_conv2_kernel<YP_BF16, TH>, (int)lds);
+            if (e == hipSuccess) { stem_conv2_kernel<YP_BF16, TH><<<nbs, 256, lds, stream>>>(a); e = hipGetLastError(); }
+        }
+        if (e != hipSuccess) { yp_set_error("yp_conv2d: fused stem launch failed: %s", hipGetErrorString(e)); return YP_ERR_HIP; }
+        return YP_OK;
+    }
     if (d->pre_weight != nullptr) {      // fused Bottleneck: 1x1 prologue + 3x3, hidden tensor in LDS
         const int Cc = d->in0.C;
         YP_REQUIRE(halo_ok && d->stride_h == 1 && !of32 && d->out2.C == 0, "yp_conv2d: the pointwise prologue needs a 16-bit 3x3 / stride 1 / pad 1 convolution with tail_zero buffers");

@@ -90,6 +90,24 @@ class YOLOPoint(HipModule):
         pb.scope.pop()
         return out
 
+    def _emit_stem_conv2(self, pb, img, run):
+        """Conv1 + Conv2.  -s width (32 stem channels, 3x3 / stride-2 Conv2 of <= 64 channels), 16-bit eval plans: ONE launch whose stem output
+        stays in LDS (PlanBuilder.stem_conv2; YP_FUSE_STEM2=0: the two launches)."""
+        import os
+        c1, c2 = self.Conv1.conv, self.Conv2.conv
+        ok = (pb.code != _hip.YP_F32 and c1.kernel_size == (6, 6) and c1.stride == (2, 2) and c1.padding == (2, 2) and c1.in_channels <= 4
+              and c1.out_channels == 32 and isinstance(self.Conv1.act, nn.SiLU) and getattr(self, "fuse_stem", True)
+              and c2.kernel_size == (3, 3) and c2.stride == (2, 2) and c2.padding == (1, 1) and c2.in_channels == 32 and c2.out_channels <= 64
+              and c2.out_channels % 8 == 0 and isinstance(self.Conv2.act, nn.SiLU) and img.H % 4 == 0 and img.W % 4 == 0
+              and os.environ.get("YP_FUSE_STEM", "1") != "0" and os.environ.get("YP_FUSE_STEM2", "1") != "0")
+        if not ok:
+            return run("Conv2", self.Conv2, self._emit_stem(pb, img))
+        (w1, b1), (w2, b2) = self.Conv1.folded(), self.Conv2.folded()
+        pb.scope.append("Conv1+Conv2")
+        out, pb.stem_launch = pb.stem_conv2(w1, b1, _hip.YP_ACT_SILU, img.H, img.W, w2, b2, _hip.YP_ACT_SILU)
+        pb.scope.pop()
+        return out
+
     def emit(self, pb, img, decode=True):
         """Dataflow of reference models/YOLOPoint.py:198-246; cat/ups are views, never copies."""
         def run(name, mod, x, **kw):
@@ -104,8 +122,7 @@ class YOLOPoint(HipModule):
         # (P3-sized launches that fill the chip) go to the plan's side lane and are forked behind Bottleneck4 -- legal anywhere behind
         # Bottleneck2, they read only xa / x8 / xb -- so they run beside that chain instead of in front of it.  Measured (batch 8, 640x640,
         # f16, same box): one lane 0.751 ms, heads forked behind Bottleneck2 / 3 / 4: 0.706 / 0.706 / 0.691 ms (eager two-stream replay).
-        x = self._emit_stem(pb, img)
-        x = run("Conv2", self.Conv2, x)
+        x = self._emit_stem_conv2(pb, img, run)
         xa = run("Bottleneck1", self.Bottleneck1, x)
         x8 = run("Conv3", self.Conv3, xa)
         xb = run("Bottleneck2", self.Bottleneck2, x8)
@@ -299,8 +316,7 @@ class YOLOPointv52(YOLOPoint):
             finally:
                 pb.scope.pop()
 
-        x = self._emit_stem(pb, img)
-        x = run("Conv2", self.Conv2, x)
+        x = self._emit_stem_conv2(pb, img, run)
         xa = run("Bottleneck1", self.Bottleneck1, x)
         x8 = run("Conv3", self.Conv3, xa)
         xb = run("Bottleneck2", self.Bottleneck2, x8)

@@ -544,6 +544,40 @@ class PlanBuilder:
         self.stem_record = OpRecord(self.name("stem"), "conv", 2 * M * Cout * Kreal, B * w.shape[1] * H * W * 4 + M * Cout * 2 + Cout * Kreal * 2, M, Cout, Kreal)
         return out, launch
 
+    def stem_conv2(self, w1, b1, act1, H, W, w2, b2, act2):
+        """Fused stem + the 3x3 / stride-2 convolution behind it (YpConvDesc.stem_*: the stem's 32-channel output stays in LDS).  Returns
+        (Conv2's output view, launch(x_nchw_fp32)); like stem(), the launch is enqueued eagerly in front of the plan replay."""
+        C1, C2 = w1.shape[0], w2.shape[0]
+        assert C1 == 32 and tuple(w2.shape[1:]) == (32, 3, 3) and C2 <= 64 and H % 4 == 0 and W % 4 == 0
+        H1, W1, H2, W2 = H // 2, W // 2, H // 4, W // 4
+        out = self.new_buf(H2, W2, round_up(C2, 8)).view()
+        wp1, bp1, Kpad1, _ = pack_stem_weight(w1, b1, self.code, self.device)
+        wp2, bp2, Kpad2, Npad2 = pack_conv_weight(w2, b2, self.code, self.device)
+        self.keep += [wp1, bp1, wp2, bp2]
+        d = YpConvDesc()
+        hidden = _hip.YpView()      # describes the stem's output, which is never materialised
+        hidden.ptr, hidden.H, hidden.W, hidden.cstride, hidden.coff, hidden.C, hidden.ups = wp2.data_ptr(), H1, W1, C1, 0, C1, 0
+        d.in0, d.in1, d.out, d.res, d.out2 = hidden, NULL_VIEW, out.c(), NULL_VIEW, NULL_VIEW
+        d.weight, d.bias = wp2.data_ptr(), (bp2.data_ptr() if b2 is not None else None)
+        d.dtype, d.out_f32, d.B = self.code, 0, self.B
+        d.Hi, d.Wi, d.Ho, d.Wo = H1, W1, H2, W2
+        d.R, d.S, d.stride_h, d.stride_w, d.pad_h, d.pad_w = 3, 3, 2, 2, 1, 1
+        d.dil_h = d.dil_w = 1
+        d.ksplit = 1
+        d.Kpad, d.Npad, d.act, d.tile, d.tail_zero = Kpad2, Npad2, act2, 0, 1
+        d.stem_weight, d.stem_bias = wp1.data_ptr(), (bp1.data_ptr() if b1 is not None else None)
+        d.stem_Kpad, d.stem_act = Kpad1, act1
+        self.keep.append(d)
+
+        def launch(x, stream=None):
+            d.stem_x, d.stem_C = x.data_ptr(), x.shape[1]
+            check(lib().yp_conv2d(C.byref(d), _hip.stream_ptr(stream)))
+        K1, K2 = w1.shape[1] * w1.shape[2] * w1.shape[3], 32 * 9
+        M1, M2 = self.B * H1 * W1, self.B * H2 * W2
+        self.stem_record = OpRecord(self.name("stem+Conv2"), "conv", 2 * M1 * C1 * K1 + 2 * M2 * C2 * K2,
+                                    self.B * w1.shape[1] * H * W * 4 + M2 * C2 * 2 + (C1 * K1 + C2 * K2) * 2, M2, C2, K2)
+        return out, launch
+
     def op(self, code, reads, writes, name, **kw):
         """Append a generic launch record (training-path kernels); kw: v=[Views], f/g/p=[tensors|ptr], n=[sizes], i=[ints], s=[floats]."""
         a = YpOpArgs()
