@@ -142,7 +142,7 @@ def test_cabi_exports_every_declared_symbol():
 
 
 def test_cabi_struct_sizes_and_argument_errors():
-    assert ctypes.sizeof(_hip.YpView) == 32 and ctypes.sizeof(_hip.YpConvDesc) == 5 * 32 + 16 + 23 * 4 + 4 + 16 + 16 + 16 + 8 + 8 + 16 + 16 + 8
+    assert ctypes.sizeof(_hip.YpView) == 32 and ctypes.sizeof(_hip.YpConvDesc) == 5 * 32 + 16 + 23 * 4 + 4 + 16 + 16 + 16 + 8 + 8 + 16 + 16 + 8 + 24 + 16       # (+ the fused-stem fields)
     l = _hip.lib()
     # argument validation happens before any device work, so it is testable on a CPU-only host
     rc = l.yp_conv2d(None, None)
