@@ -198,6 +198,162 @@ __global__ __launch_bounds__(256) void infonce_bwd_b2_kernel(const float* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Second generation of the two gathers (round 4).  The first one keeps 4 rows of 8-byte-per-lane loads in flight per wave and runs
+// beside a backward plan under a workgroup cap (3 waves per SIMD): by Little's law that is ~6 MB in flight on the chip, ~3.9 TB/s of
+// Infinity-Cache hits.  Here
+//   * a row is read with 16-byte loads by HL = D/4 lanes, so ONE load instruction fetches RPL = 64/HL rows (D = 128: two rows, one per
+//     half wave; D = 256: one) and the dot products reduce inside a lane group (5 instead of 6 shuffle steps for two rows at once);
+//   * U = 8 load instructions are in flight per wave (16 rows at D = 128, 8 at D = 256);
+//   * the E column indices of the anchor (and the logits on their way back) go through a wave-private LDS row: the index of a row is
+//     an LDS broadcast read instead of a dependent global load in front of every gather;
+//   * every lane group runs its own streaming softmax over the rows it fetched; the groups merge once per anchor.
+// The summation order differs from the first generation (groups interleave the rows); it is fixed, so results are bit-reproducible.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int HL> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = HL / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+template <int HL>
+__global__ __launch_bounds__(256) void infonce_fwd_grad2_kernel(const float* __restrict__ da, const float* __restrict__ db, const int* __restrict__ idx, int n, int E,
+                                                                float inv_tau, float* __restrict__ logits, float* __restrict__ loss,
+                                                                float* __restrict__ lse, float* __restrict__ dda_u, const int* __restrict__ n_dev) {
+    constexpr int D = HL * 4, RPL = 64 / HL, U = 8;
+    __shared__ int s_idx[4][512];
+    __shared__ float s_lg[4][512];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int g = lane / HL, gl = lane % HL;
+    if (n_dev != nullptr) { n = n_dev[0]; db = da + (size_t)n * D; }
+    int* li = s_idx[wv];
+    float* lg = s_lg[wv];
+    for (int i = blockIdx.x * 4 + wv; i < n; i += gridDim.x * 4) {
+        const float4 a = ld4(da + (size_t)i * D + gl * 4);
+        const int* row = idx + (size_t)i * E;
+        for (int j = lane; j < E; j += 64) li[j] = row[j];
+        __builtin_amdgcn_wave_barrier();
+        float mx = -3.0e38f, s = 0.f, l0 = 0.f;
+        float4 acc = {0.f, 0.f, 0.f, 0.f}, b0 = {0.f, 0.f, 0.f, 0.f};
+        for (int j0 = 0; j0 < E; j0 += RPL * U) {
+            float4 b[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + u * RPL + g;
+                const int r = li[j < E ? j : E - 1];
+                b[u] = ld4(db + (size_t)r * D + gl * 4);
+            }
+            float d[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) d[u] = group_sum<HL>(a.x * b[u].x + a.y * b[u].y + a.z * b[u].z + a.w * b[u].w) * inv_tau;
+            float cmx = mx;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (j0 + u * RPL + g < E) cmx = fmaxf(cmx, d[u]);
+            const float resc = __expf(mx - cmx);
+            s *= resc; acc.x *= resc; acc.y *= resc; acc.z *= resc; acc.w *= resc;
+            mx = cmx;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + u * RPL + g;
+                if (j < E) {
+                    const float e = __expf(d[u] - mx);
+                    s += e;
+                    acc.x += e * b[u].x; acc.y += e * b[u].y; acc.z += e * b[u].z; acc.w += e * b[u].w;
+                    if (j == 0) { l0 = d[u]; b0 = b[u]; }
+                    if (gl == 0) lg[j] = d[u];
+                }
+            }
+        }
+        // merge the lane groups' running softmax states (a group that saw no row: mx = -3e38, s = 0 -> factor 0)
+#pragma unroll
+        for (int o = HL; o < 64; o <<= 1) {
+            const float mx2 = __shfl_xor(mx, o, 64), s2 = __shfl_xor(s, o, 64);
+            float4 a2;
+            a2.x = __shfl_xor(acc.x, o, 64); a2.y = __shfl_xor(acc.y, o, 64); a2.z = __shfl_xor(acc.z, o, 64); a2.w = __shfl_xor(acc.w, o, 64);
+            const float m = fmaxf(mx, mx2);
+            // (identical expression on both partners -- own term first would differ in the last bit between them: order by group index)
+            const bool lo = (lane & o) == 0;
+            const float f_lo = __expf((lo ? mx : mx2) - m), f_hi = __expf((lo ? mx2 : mx) - m);
+            s = (lo ? s : s2) * f_lo + (lo ? s2 : s) * f_hi;
+            acc.x = (lo ? acc.x : a2.x) * f_lo + (lo ? a2.x : acc.x) * f_hi;
+            acc.y = (lo ? acc.y : a2.y) * f_lo + (lo ? a2.y : acc.y) * f_hi;
+            acc.z = (lo ? acc.z : a2.z) * f_lo + (lo ? a2.z : acc.z) * f_hi;
+            acc.w = (lo ? acc.w : a2.w) * f_lo + (lo ? a2.w : acc.w) * f_hi;
+            mx = m;
+        }
+        l0 = __shfl(l0, 0, 64);
+        const float ls = mx + logf(s);
+        __builtin_amdgcn_wave_barrier();
+        float* lrow = logits + (size_t)i * E;
+        for (int j = lane; j < E; j += 64) lrow[j] = __expf(lg[j] - ls) - (j == 0 ? 1.0f : 0.0f);
+        if (lane == 0) { loss[i] = ls - l0; lse[i] = ls; }
+        if (g == 0) {
+            const float inv_s = 1.0f / s;
+            float4 o4;
+            o4.x = acc.x * inv_s - b0.x; o4.y = acc.y * inv_s - b0.y; o4.z = acc.z * inv_s - b0.z; o4.w = acc.w * inv_s - b0.w;
+            *reinterpret_cast<float4*>(dda_u + (size_t)i * D + gl * 4) = o4;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ddb[k] = scale * sum over the edges (i, j) with idx[i][j] == k of w[i][j] * da[i]; edges sorted by k.  A wave stages 256 edges of its
+// column at a time (anchor row i = edge / E and weight, coalesced) in its LDS rows; lane group g adds the edges e0 + RPL * t + g.
+template <int HL>
+__global__ __launch_bounds__(256) void infonce_bwd_b3_kernel(const float* __restrict__ da, const float* __restrict__ logits, const int* __restrict__ order,
+                                                             const int* __restrict__ offsets, int n, int E, const float* __restrict__ gscale,
+                                                             float* __restrict__ ddb, const int* __restrict__ n_dev) {
+    constexpr int D = HL * 4, RPL = 64 / HL, U = 8;
+    __shared__ int s_i[4][256];
+    __shared__ float s_w[4][256];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int g = lane / HL, gl = lane % HL;
+    if (n_dev != nullptr) { n = n_dev[0]; ddb += (size_t)n * D; }
+    int* li = s_i[wv];
+    float* lw = s_w[wv];
+    const float scale = gscale[0];
+    for (int k = blockIdx.x * 4 + wv; k < n; k += gridDim.x * 4) {
+        const int e0 = offsets[k], e1 = offsets[k + 1];
+        float4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int c0 = e0; c0 < e1; c0 += 256) {
+            const int cn = e1 - c0 < 256 ? e1 - c0 : 256;
+            __builtin_amdgcn_wave_barrier();
+            for (int q = lane; q < cn; q += 64) {
+                const int edge = order[c0 + q];
+                li[q] = (int)((unsigned)edge / (unsigned)E);
+                lw[q] = logits[edge];
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int q0 = 0; q0 < cn; q0 += RPL * U) {
+                float4 a[U];
+                float we[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int q = q0 + u * RPL + g;
+                    const int qq = q < cn ? q : cn - 1;
+                    a[u] = ld4(da + (size_t)li[qq] * D + gl * 4);
+                    we[u] = q < cn ? lw[qq] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) { acc.x += we[u] * a[u].x; acc.y += we[u] * a[u].y; acc.z += we[u] * a[u].z; acc.w += we[u] * a[u].w; }
+            }
+        }
+#pragma unroll
+        for (int o = HL; o < 64; o <<= 1) {
+            const float x = __shfl_xor(acc.x, o, 64), y = __shfl_xor(acc.y, o, 64), z = __shfl_xor(acc.z, o, 64), w = __shfl_xor(acc.w, o, 64);
+            const bool lo = (lane & o) == 0;             // (lower group's term first on both partners: same bits)
+            acc.x = lo ? acc.x + x : x + acc.x; acc.y = lo ? acc.y + y : y + acc.y; acc.z = lo ? acc.z + z : z + acc.z; acc.w = lo ? acc.w + w : w + acc.w;
+        }
+        if (g == 0) {
+            float4 o4;
+            o4.x = acc.x * scale; o4.y = acc.y * scale; o4.z = acc.z * scale; o4.w = acc.w * scale;
+            *reinterpret_cast<float4*>(ddb + (size_t)k * D + gl * 4) = o4;
+        }
+    }
+}
+
 // w[i][j] = (softmax_j - [j == 0]) * scale  and  dda[i] = sum_j w[i][j] * db[idx[i][j]]
 template <int VPL>
 __global__ __launch_bounds__(256) void infonce_bwd_a_kernel(const float* __restrict__ db, const int* __restrict__ idx, const float* __restrict__ logits, int n, int E,
@@ -784,6 +940,11 @@ extern "C" int yp_infonce_fwd(const float* da, const float* db, const int* idx, 
 
 // Workgroups of the two gather kernels: one wave per row, four rows per workgroup; max_workgroups > 0 caps the grid (the workgroups then
 // walk the rows), which leaves CU slots to kernels of another stream (engine.TrainStep runs this chain beside a backward plan).
+// YP_NCE_GEN=1: the first-generation gathers (one row per load instruction, 4 in flight) -- kept for A/B runs and for D = 192
+static int nce_generation() {
+    static const int gen = [] { const char* e = getenv("YP_NCE_GEN"); return e ? atoi(e) : 2; }();
+    return gen;
+}
 static int nce_grid(int n, int cap) {
     const int g = (n + 3) / 4;
     return cap > 0 && g > cap ? cap : g;
@@ -794,7 +955,15 @@ extern "C" int yp_infonce_fwd_grad(const float* da, const float* db, const int* 
     YP_REQUIRE(da && (db || n_dev) && idx && logits && loss_rows && lse && dda_unscaled && n > 0 && E > 0 && E <= 512 && D > 0 && D % 64 == 0,
                "yp_infonce_fwd_grad: bad arguments (E <= 512, D %% 64 == 0)");
     const int grid = nce_grid(n, max_workgroups);
-    YP_VPL_SWITCH(D, (infonce_fwd_grad_kernel<VPL><<<grid, 256, 0, (hipStream_t)stream>>>(da, db, idx, n, E, D, inv_tau, logits, loss_rows, lse, dda_unscaled, n_dev)));
+    hipStream_t st = (hipStream_t)stream;
+    if (nce_generation() >= 2 && (D == 64 || D == 128 || D == 256)) {
+        if (D == 64) infonce_fwd_grad2_kernel<16><<<grid, 256, 0, st>>>(da, db, idx, n, E, inv_tau, logits, loss_rows, lse, dda_unscaled, n_dev);
+        else if (D == 128) infonce_fwd_grad2_kernel<32><<<grid, 256, 0, st>>>(da, db, idx, n, E, inv_tau, logits, loss_rows, lse, dda_unscaled, n_dev);
+        else infonce_fwd_grad2_kernel<64><<<grid, 256, 0, st>>>(da, db, idx, n, E, inv_tau, logits, loss_rows, lse, dda_unscaled, n_dev);
+        YP_CHECK_HIP(hipGetLastError());
+        return YP_OK;
+    }
+    YP_VPL_SWITCH(D, (infonce_fwd_grad_kernel<VPL><<<grid, 256, 0, st>>>(da, db, idx, n, E, D, inv_tau, logits, loss_rows, lse, dda_unscaled, n_dev)));
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
 }
@@ -803,7 +972,15 @@ extern "C" int yp_infonce_bwd_db(const float* da, const int* order, const int* o
                                  const float* grad_scale_dev, float* ddb, const int* n_dev, int max_workgroups, void* stream) {
     YP_REQUIRE(da && order && offsets && logits && lse && grad_scale_dev && ddb && n > 0 && E > 0 && D > 0 && D % 64 == 0, "yp_infonce_bwd_db: bad arguments");
     const int grid = nce_grid(n, max_workgroups);
-    YP_VPL_SWITCH(D, (infonce_bwd_b2_kernel<VPL><<<grid, 256, 0, (hipStream_t)stream>>>(da, logits, lse, order, offsets, n, E, D, grad_scale_dev, ddb, n_dev)));
+    hipStream_t st = (hipStream_t)stream;
+    if (nce_generation() >= 2 && (D == 64 || D == 128 || D == 256)) {
+        if (D == 64) infonce_bwd_b3_kernel<16><<<grid, 256, 0, st>>>(da, logits, order, offsets, n, E, grad_scale_dev, ddb, n_dev);
+        else if (D == 128) infonce_bwd_b3_kernel<32><<<grid, 256, 0, st>>>(da, logits, order, offsets, n, E, grad_scale_dev, ddb, n_dev);
+        else infonce_bwd_b3_kernel<64><<<grid, 256, 0, st>>>(da, logits, order, offsets, n, E, grad_scale_dev, ddb, n_dev);
+        YP_CHECK_HIP(hipGetLastError());
+        return YP_OK;
+    }
+    YP_VPL_SWITCH(D, (infonce_bwd_b2_kernel<VPL><<<grid, 256, 0, st>>>(da, logits, lse, order, offsets, n, E, D, grad_scale_dev, ddb, n_dev)));
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
 }

@@ -201,6 +201,8 @@ _TUNE_CANDIDATES = (1, 2, 3, 4, 5, 21, 22, 23, 24, 25, 26, 27, 10, 11, 12, 13, 1
 # pixels per BatchNorm-statistics row of the variants whose rows are plain pixel blocks (the 3x3 halo kernels write one row per image tile)
 _STAT_ROW_PX = {41: 128, 57: 128, 58: 128}
 _TUNE_ITERS = int(os.environ.get("YP_TUNE_ITERS", "8"))      # timed launches per candidate
+_TUNE_COLD = int(os.environ.get("YP_TUNE_COLD", "0"))        # MB swept through the L2s in front of every timed launch (0: back-to-back, hot)
+_TUNE_FLUSH = None
 if os.environ.get("YP_TUNE_ONLY"):           # A/B experiments: restrict the autotuner to a subset of the variants
     _TUNE_CANDIDATES = tuple(int(v) for v in os.environ["YP_TUNE_ONLY"].split(","))
 
@@ -704,14 +706,33 @@ class PlanBuilder:
                 applicable.append(cand)
                 continue
             run()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             iters = _TUNE_ITERS
-            e0.record()
-            for _ in range(iters):
-                run()
-            e1.record()
-            e1.synchronize()
-            ms = e0.elapsed_time(e1) * 8.0 / iters          # (kept in units of 8 launches: the cache stores ms / 8)
+            if _TUNE_COLD:
+                # COLD timing: inside a step a layer runs once, with its filters and input fetched through the fabric (the step's other
+                # tensors have been through the L2s since the last time); back-to-back launches of one layer time it with a hot L2.
+                # A write sweep over _TUNE_COLD MB in front of every timed launch evicts the eight L2s (4 MB each).
+                global _TUNE_FLUSH
+                if _TUNE_FLUSH is None or _TUNE_FLUSH.device != self.device:
+                    _TUNE_FLUSH = torch.empty((_TUNE_COLD << 20,), dtype=torch.uint8, device=self.device)
+                evs = []
+                for it in range(iters):
+                    _TUNE_FLUSH.fill_(it & 1)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    run()
+                    e1.record()
+                    evs.append((e0, e1))
+                evs[-1][1].synchronize()
+                ts = sorted(a.elapsed_time(b) for a, b in evs)
+                ms = ts[len(ts) // 2] * 8.0                # median launch, in the cache's units of 8 launches
+            else:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(iters):
+                    run()
+                e1.record()
+                e1.synchronize()
+                ms = e0.elapsed_time(e1) * 8.0 / iters          # (kept in units of 8 launches: the cache stores ms / 8)
             if os.environ.get("YP_TUNE_DEBUG"):
                 print(f"[tune] {self.name():40s} cand {cand:2d}: {ms / 8 * 1e3:7.1f} us", flush=True)
             if best_ms is None or ms < best_ms:
