@@ -19,8 +19,8 @@ Sub-records of the same line (each measured in this process, after the top-level
                 losses, native backward, bucketed gradient all-reduce overlapped with the trunk backward plan, one-launch Adam), 8 samples per
                 GPU, 640x640, bf16 -- DATA PARALLEL over all N ranks (weak scaling: 8 samples per GPU); reports the bucket plan, payload
                 and the time the compute stream waits for the collectives (exposed communication)
-  train_bs64    (N = 1) the metric's "train bs=64" on one GPU the way the reference reaches its nominal batch (train.py:38-43):
-                gas = 8 micro-batches of 8 per optimizer step
+  train_bs64    (N = 1) the metric's "train bs=64" on one GPU: ONE batch of 64 samples per optimizer step (train.py:38-43 with
+                train_batch_size 64: gas = 1); `gas8_ms_per_step` = the same nominal batch as 8 micro-batches of 8 (train_batch_size 8)
   train_l_fp8   BASELINE configs[4]: YOLOPoint-l optimizer step, 16 samples per GPU (bs 128 over 8 GPUs), data parallel over all N ranks, fp8 Conv
                 operands (e4m3 x e4m3 forward, e5m2 x e4m3 dgrad, bf16 storage / BatchNorm / weight gradients); at N = 1 `bf16_ms_per_step` = the
                 same step in bf16
@@ -339,7 +339,16 @@ def main():
         if rank == 0:
             out["train"] = rec
     if world == 1 and "train64" in only:
-        out["train_bs64"] = run_train(a, rank, world, dev, a.version, 8, max(3, a.train_steps // 4), 1, gas=8)
+        # train.py:38-43: gas = max(round(64 / (train_batch_size * devices)), 1) -- with train_batch_size 64 on one device that is ONE batch
+        # of 64 samples per optimizer step (BatchNorm statistics over the 128 images of the batch); train_batch_size 8 reaches the nominal
+        # batch with 8 micro-batches (`gas8_ms_per_step`).  One pass over 64 samples: 46.1 ms, eight passes over 8: 59.0 ms (same box).
+        torch.cuda.empty_cache()
+        cpu_threads, a.cpu_threads = a.cpu_threads, None          # (the CPU baseline of the training step rides with the `train` record)
+        rec64 = run_train(a, rank, world, dev, a.version, 64, max(3, a.train_steps // 4), 1, gas=1)
+        a.cpu_threads = cpu_threads
+        torch.cuda.empty_cache()
+        rec64["gas8_ms_per_step"] = run_train(a, rank, world, dev, a.version, 8, max(3, a.train_steps // 4), 1, gas=8)["ms_per_step"]
+        out["train_bs64"] = rec64
     if world == 1 and "frame" in only:
         torch.cuda.empty_cache()
         out["frame"] = run_frame(dev, "l", 1280, a.dtype, a.frame_steps, max(3, a.frame_steps // 6), cpu_threads=a.cpu_threads)

@@ -138,11 +138,26 @@ def main():
             open(os.path.join(OUT, f"{R}_train_step_kernels.txt"), "w").write("\n".join(sl[:70]) + "\n")
             # the same step in launch order: start offset, duration, gap to the previous kernel's end
             t0, prev = int(win[0]["Start_Timestamp"]), None
-            seq = ["# launch order of the step above: start_us dur_us gap_us kernel"]
+            seq = ["# launch order of the step above: start_us dur_us gap_us(to the previous kernel's end, any lane) lane kernel"]
+            lane_key = "Stream_Id" if "Stream_Id" in win[0] and len({r["Stream_Id"] for r in win}) > 1 else ("Queue_Id" if "Queue_Id" in win[0] else None)
+            lanes = {}
             for r in win:
                 st_, en_ = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-                seq.append(f"{(st_ - t0) / 1e3:9.1f} {(en_ - st_) / 1e3:8.1f} {((st_ - prev) / 1e3 if prev else 0):7.1f}  {short(r['Kernel_Name'])[:110]}")
+                ln = r[lane_key] if lane_key else "0"
+                lanes.setdefault(ln, []).append((st_, en_, short(r["Kernel_Name"])[:60]))
+                seq.append(f"{(st_ - t0) / 1e3:9.1f} {(en_ - st_) / 1e3:8.1f} {((st_ - prev) / 1e3 if prev else 0):7.1f}  L{ln:<3s} {short(r['Kernel_Name'])[:110]}")
                 prev = en_
+            # per lane (HIP stream / hardware queue): busy time, and the waits of the lane with the most kernels (the step's main chain) --
+            # every pause of more than 10 us between two of ITS kernels, with what the other lanes ran meanwhile
+            seq.append(f"# lanes by {lane_key}: " + "; ".join(f"L{k}: {len(v)} kernels, busy {sum(e - s for s, e, _ in v) / 1e3:.0f} us, "
+                                                               f"from {(v[0][0] - t0) / 1e3:.0f} to {(v[-1][1] - t0) / 1e3:.0f} us" for k, v in lanes.items()))
+            main = max(lanes, key=lambda k: len(lanes[k]))
+            mv = lanes[main]
+            waits = [(mv[i + 1][0] - mv[i][1], mv[i][1], mv[i + 1][0], mv[i][2], mv[i + 1][2]) for i in range(len(mv) - 1) if mv[i + 1][0] - mv[i][1] > 10000]
+            seq.append(f"# main lane L{main}: {len(waits)} pauses > 10 us between its own kernels, {sum(w[0] for w in waits) / 1e3:.0f} us in all")
+            for w, a_, b_, ka, kb in waits:
+                other = sum(min(e, b_) - max(s_, a_) for k, v in lanes.items() if k != main for s_, e, _ in v if e > a_ and s_ < b_)
+                seq.append(f"#   {w / 1e3:7.1f} us at {(a_ - t0) / 1e3:8.1f}: {ka} -> {kb}; other lanes busy {other / 1e3:.1f} us meanwhile")
             open(os.path.join(OUT, f"{R}_train_step_sequence.txt"), "w").write("\n".join(seq) + "\n")
     json.dump(res, open(os.path.join(OUT, f"{R}_collect.json"), "w"), indent=1)
     print(json.dumps(res, indent=1))

@@ -254,7 +254,19 @@ class TrainStep:
         fork = main.record_event() if side is not main else None
         g = net._train_graph(img, pair=True, fp8=bool(getattr(net, "fp8_train", False)))
         g.busy = True
-        g.forward(img, img_w, export=False)
+        # Enqueue ORDER of the side lane (YP_LABELS_ORDER).  The label-only kernels share the side stream with the forward plan's head ops.
+        #   "after" (rounds 3-4): all of them enqueued behind the forward launch -- since the heads moved to this stream they queue behind
+        #           the heads, run AFTER the forward, and the main lane waits for all of them in front of the object loss (lane-annotated
+        #           trace, tools/profile_collect.py: ONE pause of 1.12 ms per -s step with only the side lane busy);
+        #   "first": all of them in front of the forward launch -- the heads then start ~1.1 ms late and the main lane waits for THEM;
+        #   "split" (default): target assignment + cell masks (what the object / detector losses read: ~60 us) in front of the forward
+        #           launch, the InfoNCE sampling and its two CSR sorts (~1 ms, read by the InfoNCE chain on this same stream only) behind
+        #           the heads; the main lane waits for the small part only.
+        order = os.environ.get("YP_LABELS_ORDER", "split") if side is not main else "after"
+        if order == "split" and int(os.environ.get("YP_LOSS_LANES", "2")) < 2:
+            order = "after"                       # (the InfoNCE chain runs on the main stream there: it needs the sampling joined)
+        if order == "after":
+            g.forward(img, img_w, export=False)
         D = g.desc_channels
         stg = getattr(g, "_stage", None)
         if stg is None:
@@ -273,22 +285,36 @@ class TrainStep:
         shapes = [(B, det.na, H // st, W // st, det.no) for st in self._det_strides()]
         scal = stg.scal.data_ptr()           # floats: [0:3] object-loss sums, [4:6] detector losses, [6:8] mask sums, [12] InfoNCE gradient scale
 
-        def label_work():
+        def small_labels():
             tgt_ = self.obj_loss.assign(shapes, batch['box_labels'])
-            nce_ = infonce_prepare(batch['warped_valid_mask'], batch['inv_homographies'], (B, D, Hc, Wc), True, self.sparse['num_samples_per_image'],
-                                   self.sparse['num_masked_non_matches_per_match'], 8, dev, pair_index=True,
-                                   sync=os.environ.get("YP_PREPARE_SYNC", "0") == "1" or os.environ.get("YP_NATIVE_PREPARE", "1") == "0")
             for j, key in enumerate(('valid_mask', 'warped_valid_mask')):
                 check(lib.yp_cell_mask(batch[key].data_ptr(), B, H, W, stg.mask[j].data_ptr(), scal + 4 * (6 + j), stg.ws_side.data_ptr(), stg.ws_bytes, sp()))
-            return tgt_, nce_
+            return tgt_
+
+        def nce_labels():
+            return infonce_prepare(batch['warped_valid_mask'], batch['inv_homographies'], (B, D, Hc, Wc), True, self.sparse['num_samples_per_image'],
+                                   self.sparse['num_masked_non_matches_per_match'], 8, dev, pair_index=True,
+                                   sync=os.environ.get("YP_PREPARE_SYNC", "0") == "1" or os.environ.get("YP_NATIVE_PREPARE", "1") == "0")
         if side is not main:
             side.wait_event(fork)
             with torch.cuda.stream(side):
-                early = label_work()
-                _record_stream(early, main)
-            main.wait_stream(side)
+                tgt_e = small_labels()
+                _record_stream(tgt_e, main)
+                small_done = side.record_event()
+                nce_e = nce_labels() if order != "split" else None
+                labels_done = side.record_event()
+            if order != "after":
+                g.forward(img, img_w, export=False)
+            if order == "split":
+                with torch.cuda.stream(side):
+                    nce_e = nce_labels()          # behind the forward's head ops in the side stream's order
+                main.wait_event(small_done)
+            else:
+                _record_stream(nce_e, main)
+                main.wait_event(labels_done)
+            early = (tgt_e, nce_e)
         else:
-            early = label_work()
+            early = (small_labels(), nce_labels())
         tgt, nce = early
         f32 = np.float32
         # ---- object loss (reference utils/loss_functions.py:90-176): value into scal[0:3], UNSCALED gradient straight into the backward
