@@ -352,9 +352,11 @@ class TrainStep:
         def infonce_chain(stream, small_done):
             # (beside the backward plan the gathers get 3 workgroups per CU: uncapped they take every slot and the plan's kernels queue behind
             # them -- -s 7.85 -> 7.55 ms, -l 35.8 -> 35.4 at 768; 1024: 7.67, 512: 7.66, 256: 9.06)
-            # second-generation gathers (16 rows in flight per wave, csrc/losses.hip): at D <= 128 they reach the first generation's rate
-            # with a third of the workgroups -- 256: 7.32 ms, 384 / 512 / 768: 7.38 / 7.42 / 7.55 (-s); -l (D = 256) is flat in the cap
-            nce_wgs = int(os.environ.get("YP_NCE_WGS", "256" if D <= 128 else "768")) if lanes >= 2 else 0
+            # second-generation gathers (8 load instructions in flight per wave, csrc/losses.hip): they hold their rate with far fewer
+            # workgroups, and the fewer they occupy the less the backward plan beside them is slowed -- until the chain itself becomes the
+            # critical path.  -s (D = 128): 256 workgroups 7.32 ms, 128 / 384 / 512 / 768: 7.36 / 7.38 / 7.42 / 7.55; -l (D = 256, 16
+            # samples): 128 workgroups 34.6-34.8 ms, 256 / 384 / 768: 34.9 / 35.0 / 35.5, 96 / 64 / 32: 35.3 / 38.5 / 49.6
+            nce_wgs = int(os.environ.get("YP_NCE_WGS", "256" if D <= 128 else "128")) if lanes >= 2 else 0
             out4_ = torch.empty((4,), dtype=torch.float32, device=dev)
             if isinstance(nce, dict):
                 # counts on the device (infonce_prepare(sync=False)): arrays at their capacity, the kernels read points-per-image / matched rows
