@@ -61,3 +61,47 @@ def test_infonce_kernels_vs_reference(cuda):
     np.testing.assert_allclose(loss.item(), G["nce64.loss"], rtol=1e-5)
     loss.backward()
     assert rel_err(d1.grad, G["nce64.grad_d1"])[1] < 1e-5 and rel_err(d2.grad, G["nce64.grad_d2"])[1] < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D", [64, 128, 256])
+def test_infonce_gather_generations_agree(cuda, monkeypatch, D):
+    """The second-generation gathers (csrc/losses.hip: infonce_fwd_grad2 / infonce_bwd_b3 -- 16-byte loads by D/4 lanes, 8 loads in flight,
+    per-lane-group streaming softmax) against the first generation (YP_NCE_GEN=1) and against the sums written out in fp64: loss rows,
+    softmax weights, both gradients; ragged edge lists (a column nobody drew, one drawn by every row), E not a multiple of the lanes' stride."""
+    from yolopoint_amd import _hip
+    from yolopoint_amd.utils.loss_functions import infonce_edges
+    n, negs, tau = 777, 37, 0.07
+    g = torch.Generator().manual_seed(5 + D)
+    dab = torch.nn.functional.normalize(torch.randn((2 * n, D), generator=g), dim=1).to(cuda)
+    rnd = torch.randint(1, n, (n, negs), generator=g)
+    rnd[:, 3] = 11                                       # column 11 is drawn by every row, column 0 by none
+    idx, order, offsets = infonce_edges(rnd.to(cuda))
+    E = idx.shape[1]
+    lib = _hip.lib()
+    scale = torch.full((1,), 1.0 / (tau * n), dtype=torch.float32, device=cuda)
+    res = {}
+    for gen in ("1", "2"):
+        monkeypatch.setenv("YP_NCE_GEN", gen)
+        w = torch.empty((n, E), dtype=torch.float32, device=cuda)
+        rows, lse = torch.empty((n,), dtype=torch.float32, device=cuda), torch.empty((n,), dtype=torch.float32, device=cuda)
+        grad, out = torch.empty_like(dab), torch.zeros_like(dab)
+        for cap in (0, 7):                                # uncapped, and a grid that walks the rows
+            _hip.check(lib.yp_infonce_fwd_grad(dab.data_ptr(), dab.data_ptr() + 4 * n * D, idx.data_ptr(), n, E, D, 1.0 / tau, w.data_ptr(), rows.data_ptr(),
+                                               lse.data_ptr(), grad.data_ptr(), None, cap, _hip.stream_ptr()))
+            _hip.check(lib.yp_infonce_bwd_db(dab.data_ptr(), order.data_ptr(), offsets.data_ptr(), w.data_ptr(), lse.data_ptr(), n, E, D, scale.data_ptr(),
+                                             out.data_ptr() + 4 * n * D, None, cap, _hip.stream_ptr()))
+            res[(gen, cap)] = (rows.clone(), w.clone(), grad[:n].clone(), out[n:].clone())
+    a, b = dab[:n].double(), dab[n:].double()
+    lg = (a[:, None, :] * b[idx.long()]).sum(-1) / tau
+    wref = torch.softmax(lg, 1)
+    wref[:, 0] -= 1.0
+    ref = (torch.logsumexp(lg, 1) - lg[:, 0], wref, (wref[:, :, None] * b[idx.long()]).sum(1),
+           torch.zeros((n, D), dtype=torch.float64, device=cuda).index_add_(0, idx.long().flatten(), (wref[:, :, None] * a[:, None, :]).reshape(-1, D)) * float(scale))
+    for key, got in res.items():
+        for name, x, r in zip(("loss", "w", "dda", "ddb"), got, ref):
+            err = float((x.double() - r).abs().max() / r.abs().max())
+            assert err < 5e-6, (key, name, err)
+    for cap in (0, 7):                                    # a capped grid changes which wave takes a row, not the row's arithmetic
+        for x, y in zip(res[("2", 0)], res[("2", cap)]):
+            assert torch.equal(x, y)

@@ -829,8 +829,10 @@ def test_loss_stage_lanes_and_the_bound_on_queued_steps(cuda, monkeypatch):
     batch = synthetic_batch(2, 128, cuda, 77)
     batch['warped_valid_mask'][:, :, 30:70, 20:90] = 0.0
     out = []
-    for lanes in ("0", "1", "2"):
+    # (lanes, order of the label work on the side stream: YP_LABELS_ORDER -- "split" is the default, "after" the round-3/4 order)
+    for lanes, order in (("0", "after"), ("1", "after"), ("2", "after"), ("2", "split"), ("2", "first")):
         monkeypatch.setenv("YP_LOSS_LANES", lanes)
+        monkeypatch.setenv("YP_LABELS_ORDER", order)
         mm = copy.deepcopy(m0)
         step = TrainStep(mm, cuda, img_size=128)
         step.sparse = dict(num_samples_per_image=100, num_masked_non_matches_per_match=30)

@@ -942,8 +942,8 @@ extern "C" int yp_infonce_fwd(const float* da, const float* db, const int* idx, 
 // walk the rows), which leaves CU slots to kernels of another stream (engine.TrainStep runs this chain beside a backward plan).
 // YP_NCE_GEN=1: the first-generation gathers (one row per load instruction, 4 in flight) -- kept for A/B runs and for D = 192
 static int nce_generation() {
-    static const int gen = [] { const char* e = getenv("YP_NCE_GEN"); return e ? atoi(e) : 2; }();
-    return gen;
+    const char* e = getenv("YP_NCE_GEN");             // (read per launch: the tests switch it inside one process)
+    return e ? atoi(e) : 2;
 }
 static int nce_grid(int n, int cap) {
     const int g = (n + 3) / 4;
