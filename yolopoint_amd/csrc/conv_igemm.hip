@@ -101,6 +101,37 @@ __device__ __forceinline__ void yp_load_bias(const ConvKArgs& a, int nb, float (
     }
 }
 
+// Recursive-halving reduction of per-lane channel sums over the 16 pixel lanes of a lane group (the BatchNorm-statistics epilogues): at
+// offset O a lane keeps one half of its N channels and hands the other half to lane ^ O; with one channel left the remaining offsets are
+// plain butterfly adds.  N and O are compile-time values, so every array index is static and sv / sq stay in registers (the run-time
+// form of the same loop kept `n` in a variable: the compiler indexed the arrays dynamically and put them in SCRATCH memory -- 80-144
+// bytes per lane in all 56 STATS instantiations of the generic and the halo kernel).  Same operations in the same order: same bits.
+template <int N, int O>
+struct YpHalve {
+    template <int LPG>
+    static __device__ __forceinline__ void run(float (&sv)[LPG], float (&sq)[LPG], int p, int& mych) {
+        if constexpr (O < 16) {
+            const bool up = (p & O) != 0;
+            if constexpr (N > 1) {
+                constexpr int hn = N / 2;
+#pragma unroll
+                for (int j = 0; j < hn; ++j) {
+                    const float keep_s = up ? sv[hn + j] : sv[j], give_s = up ? sv[j] : sv[hn + j];
+                    const float keep_q = up ? sq[hn + j] : sq[j], give_q = up ? sq[j] : sq[hn + j];
+                    sv[j] = keep_s + __shfl_xor(give_s, O, 64);
+                    sq[j] = keep_q + __shfl_xor(give_q, O, 64);
+                }
+                mych += up ? hn : 0;
+                YpHalve<hn, O * 2>::run(sv, sq, p, mych);
+            } else {
+                sv[0] += __shfl_xor(sv[0], O, 64);
+                sq[0] += __shfl_xor(sq[0], O, 64);
+                YpHalve<1, O * 2>::run(sv, sq, p, mych);
+            }
+        }
+    }
+};
+
 // 16 zero bytes: out-of-image taps / padded k / padded filter rows are fetched from here, so every
 // LDS-DMA lane always has a valid source and no predication or LDS pre-clearing is needed.
 __device__ __attribute__((aligned(16))) unsigned int yp_zero16[4] = {0u, 0u, 0u, 0u};
@@ -576,28 +607,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
         // reduce over the 16 pixel lanes by recursive halving: at offset o a lane keeps one half of its channels and hands the other half
         // to lane ^ o (LPG/2 + LPG/4 + ... exchanges instead of 4 * LPG); once a single channel is left the remaining offsets are plain
         // butterfly adds.  Lane p ends up with the total of channel `mych` of its group's LPG channels.
-        int n = LPG, mych = 0;
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-            const bool up = (p & o) != 0;
-            if (n > 1) {
-                const int hn = n / 2;
-#pragma unroll
-                for (int j = 0; j < LPG / 2; ++j) {
-                    if (j < hn) {
-                        const float keep_s = up ? sv[hn + j] : sv[j], give_s = up ? sv[j] : sv[hn + j];
-                        const float keep_q = up ? sq[hn + j] : sq[j], give_q = up ? sq[j] : sq[hn + j];
-                        sv[j] = keep_s + __shfl_xor(give_s, o, 64);
-                        sq[j] = keep_q + __shfl_xor(give_q, o, 64);
-                    }
-                }
-                mych += up ? hn : 0;
-                n = hn;
-            } else {
-                sv[0] += __shfl_xor(sv[0], o, 64);
-                sq[0] += __shfl_xor(sq[0], o, 64);
-            }
-        }
+        int mych = 0;
+        YpHalve<LPG, 1>::run(sv, sq, p, mych);
         constexpr int HALVES = BM / 64;
         constexpr int WPH = WAVES_M / HALVES > 0 ? WAVES_M / HALVES : 1;       // waves sharing a 64-pixel row block (per channel range)
         constexpr int OWNERS = LPG < 16 ? LPG : 16;           // lanes p < OWNERS of a 16-lane group each own one channel total
@@ -876,28 +887,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvKArgs a) {
                 for (int j = 0; j < LPG; ++j) { const float v = acc[j >> 2][fm][j & 3]; sv[j] += v; sq[j] += v * v; }
             }
         }
-        int nleft = LPG, mych = 0;
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-            const bool up = (p & o) != 0;
-            if (nleft > 1) {
-                const int hn = nleft / 2;
-#pragma unroll
-                for (int j = 0; j < LPG / 2; ++j) {
-                    if (j < hn) {
-                        const float keep_s = up ? sv[hn + j] : sv[j], give_s = up ? sv[j] : sv[hn + j];
-                        const float keep_q = up ? sq[hn + j] : sq[j], give_q = up ? sq[j] : sq[hn + j];
-                        sv[j] = keep_s + __shfl_xor(give_s, o, 64);
-                        sq[j] = keep_q + __shfl_xor(give_q, o, 64);
-                    }
-                }
-                mych += up ? hn : 0;
-                nleft = hn;
-            } else {
-                sv[0] += __shfl_xor(sv[0], o, 64);
-                sq[0] += __shfl_xor(sq[0], o, 64);
-            }
-        }
+        int mych = 0;
+        YpHalve<LPG, 1>::run(sv, sq, p, mych);
         constexpr int OWNERS = LPG < 16 ? LPG : 16;
         float* red = reinterpret_cast<float*>(hsm);            // [WAVES_M][2][BN] in the idle pipeline LDS; fixed summation order
         __syncthreads();
