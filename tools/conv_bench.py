@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--dtype", default="f16")
     ap.add_argument("--min-cin", type=int, default=0)
     ap.add_argument("--act", type=int, default=1)
+    ap.add_argument("--stats", action="store_true", help="training-forward form: raw output + BatchNorm column sums from the epilogue (bn_partial)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     code = _hip.dtype_code(a.dtype)
@@ -74,7 +75,11 @@ def main():
             b = torch.randn(c2) * 0.1
             p = 2 if k == 6 else k // 2
             try:
-                pb.conv(xin.view(), w, b, k, s, p, _hip.YP_ACT_SILU if a.act else _hip.YP_ACT_NONE, tile=tile)
+                extra = None
+                if a.stats:
+                    M_ = batch * Ho * Ho
+                    extra = dict(bn_partial=torch.empty(((M_ + 63) // 64 + 8, 2, (c2 + 63) // 64 * 64 + 64), dtype=torch.float32, device=dev))
+                pb.conv(xin.view(), w, None if a.stats else b, k, s, p, _hip.YP_ACT_SILU if (a.act and not a.stats) else _hip.YP_ACT_NONE, tile=tile, extra=extra)
             except _hip.YpError:
                 res.append(None)
                 continue

@@ -628,7 +628,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
             float v = 0.f;
 #pragma unroll
             for (int w = 0; w < WPH; ++w) v += red[((h * WPH + w) * 2 + w2) * BN + cl];
+#ifndef YP_PROBE_NOSTATSTORE
             if (c < a.Cout && rb * 64 < a.M) a.stats[((size_t)w2 * a.Cout + c) * a.stats_rows + rb] = v;
+#else
+            if (v == 1.2345e-30f) a.stats[0] = v;
+#endif
         }
     }
     YP_TL(41);
@@ -904,7 +908,11 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvKArgs a) {
             float v = 0.f;
 #pragma unroll
             for (int w = 0; w < WAVES_M; ++w) v += red[(w * 2 + w2) * BN + cl];
+#ifndef YP_PROBE_NOSTATSTORE
             if (c < a.Cout) a.stats[((size_t)w2 * a.Cout + c) * a.stats_rows + tile] = v;
+#else
+            if (v == 1.2345e-30f) a.stats[0] = v;
+#endif
         }
     }
     YP_TL(41);

@@ -467,8 +467,12 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
         const int c = nb + mych;
         const int rb = (tile_m * 2 + g) * WP + wp;
         if (owner && c < a.Cout && (size_t)rb * (32 * PT) < (size_t)a.M) {
+#ifndef YP_PROBE_NOSTATSTORE
             a.stats[((size_t)0 * a.Cout + c) * a.stats_rows + rb] = sv[0];
             a.stats[((size_t)1 * a.Cout + c) * a.stats_rows + rb] = sq[0];
+#else
+            if (sv[0] == 1.2345e-30f) { a.stats[0] = sv[0]; a.stats[1] = sq[0]; }
+#endif
         }
     }
     float bias[16 * CT];
