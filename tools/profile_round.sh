@@ -61,7 +61,7 @@ rm -rf $OUT/pmc_tf $OUT/pmc_tw
 # ... and of one forward of the v52 record (YOLOPointv52-s, bs 8, 640x640): the dispatches between its last two stem launches
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_tf -o f -- python $ROOT/bench.py --no-cpu-baseline --only v52 --steps 5 --warmup 2 > $OUT/pmc_tf.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_tw -o w -- python $ROOT/bench.py --no-cpu-baseline --only v52 --steps 5 --warmup 2 > $OUT/pmc_tw.log 2>&1
-python $ROOT/tools/train_traffic.py $OUT/pmc_tf $OUT/pmc_tw v52_s_8_f16 $OUT/train_traffic.json stem_conv_kernel
+python $ROOT/tools/train_traffic.py $OUT/pmc_tf $OUT/pmc_tw v52_s_8_f16 $OUT/train_traffic.json stem_conv
 rm -rf $OUT/pmc_tf $OUT/pmc_tw
 cd $ROOT
 # the 8-wave kernels: per-layer tables (16-bit and 8-bit) and the SQ / LDS counters of one deep layer per schedule
