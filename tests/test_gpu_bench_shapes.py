@@ -256,6 +256,38 @@ def test_config2_gradient_spot_check_8x640(cuda):
         assert c > 0.8 and e <= 0.6, (name, e, c)
 
 
+def test_train_bs64_batch_gradient_spot_check_128x128x128(cuda):
+    """The `train_bs64` record runs ONE batch of 64 samples (128 images) per optimizer step: the same spot check at that batch -- 128
+    images of 128 x 128 through one train-mode forward / backward (BatchNorm statistics over all 128 images, 2-D grids and partial-row
+    counts of the large batch) against fp32 CPU autograd through the oracle."""
+    version, B, S, seed = "s", 128, 128, 64
+    m, sd = make_model(version, seed, dtype="bf16")
+    m = m.to(cuda).train()
+    x = net_oracle.synth_image(B, 3, S, S, seed)
+    torch.set_num_threads(min(32, torch.get_num_threads() or 8))
+    leaf = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in sd.items()}
+    o = net_oracle.yolopoint_forward(leaf, x, version, training=True, stats={})
+    proj = net_oracle.output_projections(o, seed)
+    net_oracle.projected_loss(o, proj).backward()
+    out = m(x.to(cuda))
+    for k in ("semi", "desc"):
+        assert rel_err(out[k], o[k])[1] < 2.5e-2, k
+    net_oracle.projected_loss(out, proj, cuda).backward()
+    params = dict(m.named_parameters())
+    names = ["model.Conv1.conv.weight", "model.Conv2.conv.weight", "model.Bottleneck1.m.0.cv2.conv.weight", "model.Conv3.bn.weight",
+             "model.Bottleneck2.cv3.conv.weight", "model.Bottleneck3.m.1.cv1.conv.weight", "model.SPPooling.cv2.conv.weight",
+             "model.Bottleneck6.cv1.conv.weight", "model.ConvDesc.weight", "model.Detect.m.1.weight"]
+    rows = []
+    for name in names:
+        g, g32 = params[name].grad, leaf[name].grad
+        assert g is not None and torch.isfinite(g).all(), name
+        cos = float(torch.nn.functional.cosine_similarity(g.detach().cpu().flatten().double(), g32.flatten().double(), dim=0))
+        rows.append((name, rel_err(g, g32)[1], cos))
+    print("128 images of 128 x 128, bf16 vs fp32 autograd: " + "; ".join(f"{n.replace('model.', '')} l2 {e:.3f} cos {c:.3f}" for n, e, c in rows))
+    for name, e, c in rows:
+        assert c > 0.8 and e <= 0.6, (name, e, c)
+
+
 def test_bf16_gradients_are_deterministic(cuda):
     """Two identical bf16 forward/backward passes give bit-identical parameter gradients (the weight-gradient reduction has a fixed
     order: per-workgroup partials folded by a second pass, no floating-point atomics)."""
