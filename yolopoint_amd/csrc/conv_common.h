@@ -225,3 +225,19 @@ hipError_t yp_mma8_launch(int tile, int dtype, bool out_f32, bool stats, const C
 // wave-private split-K kernels for the short-M layers (conv_wsk.hip), tile ids 71..73
 bool yp_wsk_tile_dims(int tile, int* bm, int* bn);
 hipError_t yp_wsk_launch(int tile, int dtype, bool out_f32, const ConvKArgs& a, int nblk, hipStream_t st);
+
+// x of lane ^ O.  O = 1, 2, 4, 8 stay inside a row of 16 lanes: DPP moves on the VALU (quad_perm, row_shl / row_shr under bank masks,
+// row_ror) instead of ds_bpermute round trips through the LDS crossbar (what __shfl_xor compiles to); larger O: __shfl_xor.
+// Used by the BatchNorm-statistics epilogues (their butterflies over the pixel lanes were two thirds of the epilogue's cost).
+template <int O>
+__device__ __forceinline__ float yp_xor_lane(float x) {
+    const int v = __float_as_int(x);
+    if constexpr (O == 1) return __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true));        // quad_perm [1,0,3,2]
+    else if constexpr (O == 2) return __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    else if constexpr (O == 4) {
+        int t = __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xA, false);      // row_shr:4 into banks 1, 3 (lanes 4-7, 12-15 <- 0-3, 8-11)
+        t = __builtin_amdgcn_update_dpp(t, v, 0x104, 0xF, 0x5, false);          // row_shl:4 into banks 0, 2 (lanes 0-3, 8-11 <- 4-7, 12-15)
+        return __int_as_float(t);
+    } else if constexpr (O == 8) return __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, true));   // row_ror:8
+    else return __shfl_xor(x, O, 64);
+}

@@ -118,14 +118,14 @@ struct YpHalve {
                 for (int j = 0; j < hn; ++j) {
                     const float keep_s = up ? sv[hn + j] : sv[j], give_s = up ? sv[j] : sv[hn + j];
                     const float keep_q = up ? sq[hn + j] : sq[j], give_q = up ? sq[j] : sq[hn + j];
-                    sv[j] = keep_s + __shfl_xor(give_s, O, 64);
-                    sq[j] = keep_q + __shfl_xor(give_q, O, 64);
+                    sv[j] = keep_s + yp_xor_lane<O>(give_s);
+                    sq[j] = keep_q + yp_xor_lane<O>(give_q);
                 }
                 mych += up ? hn : 0;
                 YpHalve<hn, O * 2>::run(sv, sq, p, mych);
             } else {
-                sv[0] += __shfl_xor(sv[0], O, 64);
-                sq[0] += __shfl_xor(sq[0], O, 64);
+                sv[0] += yp_xor_lane<O>(sv[0]);
+                sq[0] += yp_xor_lane<O>(sq[0]);
                 YpHalve<1, O * 2>::run(sv, sq, p, mych);
             }
         }

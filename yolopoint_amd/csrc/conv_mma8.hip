@@ -441,6 +441,9 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
             sv[j] = s; sq[j] = q;
         }
         int mych = 0;
+        auto xorl = [](float x, int st) {                           // (st is a constant after unrolling: the DPP forms of conv_common.h)
+            return st == 0 ? yp_xor_lane<1>(x) : st == 1 ? yp_xor_lane<2>(x) : st == 2 ? yp_xor_lane<4>(x) : st == 3 ? yp_xor_lane<8>(x) : yp_xor_lane<16>(x);
+        };
 #pragma unroll
         for (int st = 0; st < 5; ++st) {
             const int o = 1 << st;
@@ -453,14 +456,14 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
                     if (j < hn) {
                         const float keep_s = up ? sv[hn + j] : sv[j], give_s = up ? sv[j] : sv[hn + j];
                         const float keep_q = up ? sq[hn + j] : sq[j], give_q = up ? sq[j] : sq[hn + j];
-                        sv[j] = keep_s + __shfl_xor(give_s, o, 64);
-                        sq[j] = keep_q + __shfl_xor(give_q, o, 64);
+                        sv[j] = keep_s + xorl(give_s, st);
+                        sq[j] = keep_q + xorl(give_q, st);
                     }
                 }
                 mych += up ? hn : 0;
             } else {
-                sv[0] += __shfl_xor(sv[0], o, 64);
-                sq[0] += __shfl_xor(sq[0], o, 64);
+                sv[0] += xorl(sv[0], st);
+                sq[0] += xorl(sq[0], st);
             }
         }
         const bool owner = NV >= 32 || (lr & 16) == 0;            // (NV = 16: lanes lr and lr ^ 16 hold the same total)
