@@ -153,7 +153,11 @@ typedef struct YpConvDesc {
      * channels reads act(stem(x)) -- the 6x6 / stride-2 / pad-2 stem of yp_stem_conv applied to the caller's NCHW fp32 image -- instead of in0: the
      * stem's output (the largest activation of the network) lives in LDS only.  in0 then only DESCRIBES that tensor (H, W, C = 32, any non-null
      * ptr); stem_weight / stem_bias / stem_Kpad / stem_act are yp_stem_conv's arguments, stem_C the image channels (<= 4).  16-bit types, out.C <= 64,
-     * no residual / second output / Detect / bn_partial. */
+     * no residual / second output / Detect / bn_partial.
+     * With stem_weight AND post_weight set, post_weight / post_bias / post_Kpad / post_Npad / post_act describe a 64 -> 64 POINTWISE convolution
+     * behind this one (reference models/common.py:133-135: `cv1` and `cv2` of the C3 block that follows Conv2, as one filter): the launch then
+     * writes out (+ out2: the split destination of the pointwise stage, out.C + out2.C = 64) and this convolution's own 64-channel output
+     * is never materialised either (bias / act stay this convolution's, applied before the pointwise stage). */
     const float* stem_x;
     const void* stem_weight;
     const float* stem_bias;

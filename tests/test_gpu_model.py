@@ -252,3 +252,31 @@ def test_fused_stem_conv2_equals_the_two_launches(cuda, monkeypatch, dtype, mode
         outs[fuse] = [o["semi"].float().clone(), o["desc"].float().clone(), o["objects"][0].float().clone()]
     for a, b in zip(outs["1"], outs["0"]):
         assert float((a - b).abs().max()) <= 2.0 ** -7 * float(b.abs().max()) * (1 if dtype == "bf16" else 0.125) + 1e-6
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_fused_stem_conv2_c3_head_equals_the_separate_launch(cuda, monkeypatch, dtype):
+    """Conv1 + Conv2 + Bottleneck1.cv1/cv2 as ONE launch (Conv2's output lives in LDS only; YP_FUSE_STEM3) against the plan with the
+    pointwise launch behind the fused stem + Conv2: the same ragged, non-square input; Conv2's output is rounded to 16 bits in both forms
+    and the pointwise filter sums its 64 inputs in two 32-deep steps in both: heads to 2 ulp of the 16-bit storage.  Also at batch 1
+    and with an input that changes between replays (the fused launch sits outside the plan: its destinations are plan buffers)."""
+    from helpers import make_model
+    from oracle import net_oracle
+    outs = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("YP_FUSE_STEM3", fuse)
+        m, _ = make_model("s", 29, dtype=dtype)
+        m = m.to(cuda).eval()
+        m.fuse()
+        res = []
+        for seed, B in ((31, 2), (32, 2), (33, 1)):
+            x = net_oracle.synth_image(B, 3, 160, 224, seed).to(cuda)
+            with torch.no_grad():
+                o = m(x)
+            plan = next(iter(m.model._plans.values()))[0]
+            assert ("cv1+cv2" in plan.stem_record.name) == (fuse == "1"), plan.stem_record.name
+            res.append([o["semi"].float().clone(), o["desc"].float().clone(), o["objects"][0].float().clone()])
+        outs[fuse] = res
+    for ra, rb in zip(outs["1"], outs["0"]):
+        for a, b in zip(ra, rb):
+            assert float((a - b).abs().max()) <= 2.0 ** -7 * float(b.abs().max()) * (1 if dtype == "bf16" else 0.125) + 1e-6

@@ -1449,7 +1449,11 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
 // is the stem's activation arithmetic (26 M SiLU on the VALU, two transcendentals each), which the two-launch form hid behind its
 // memory time.  (A first version with `__launch_bounds__(256, 4)` spilled 9 registers: the scratch set-up alone cost ~20 us per launch.)
 // ==========================================================================================
-template <int DT, int TH>
+//   phase C  (POST: the 1x1 convolution behind Conv2 -- C3.cv1 + C3.cv2 of Bottleneck1 as one 64 -> 64 filter, a.post_*)  Conv2's activated
+//            output of the tile goes to LDS as 128-byte pixel rows (it overwrites the hidden halo), wave w multiplies its 16 output
+//            channels (two filter fragments in registers) against every pixel and writes through the ordinary split-destination store:
+//            Conv2's output -- read by nothing else -- never reaches HBM either (-52 MB and one launch at batch 8).
+template <int DT, int TH, bool POST = false>
 __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(const ConvKArgs a) {
     using E = Elem<DT>;
     using frag_t = typename E::frag;
@@ -1506,6 +1510,22 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(const ConvKArgs a) {
     const int nb = wave * 16 + g * LPG;
     float bias[LPG];
     yp_load_bias<LPG>(a, nb, bias);
+    // POST: the pointwise filter behind Conv2 (64 input channels = two k steps) and its bias, in registers like wf2
+    frag_t wf3[2];
+    float b3[LPG];
+    if constexpr (POST) {
+        const int n = wave * 16 + p;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (n < a.post_Npad) wf3[ks] = *reinterpret_cast<const frag_t*>(a.post_wgt + ((size_t)n * a.post_Kpad + ks * 32 + g * 8) * EB);
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) wf3[ks][j] = (sc)0.f;
+            }
+        }
+        const f32x4 b4 = (a.post_bias != nullptr && nb < a.post_N) ? *reinterpret_cast<const f32x4*>(a.post_bias + nb) : f32x4{0.f, 0.f, 0.f, 0.f};
+        b3[0] = b4[0]; b3[1] = b4[1]; b3[2] = b4[2]; b3[3] = b4[3];
+    }
     const int H1 = a.Hi, W1 = a.Wi;
     const int ntiles = a.stats_rows;                  // (host: B * tiles_y * tiles_x)
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -1640,12 +1660,58 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(const ConvKArgs a) {
             }
         }
     }
+    if constexpr (POST) {
+        // ---- phase C: y = act2(Conv2) as 128-byte pixel rows in LDS (16-byte chunks swizzled by the pixel), then the 64 -> 64 pointwise filter
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                     // every wave has read its last hidden-halo fragment
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) {
+            const int pix = fm * 16 + p;
+            u32x2 pk;
+            sc* e = reinterpret_cast<sc*>(&pk);
+#pragma unroll
+            for (int cj = 0; cj < LPG; ++cj) {
+                float x = acc[fm][cj] + bias[cj];
+                if (a.act == YP_ACT_SILU) x = yp_silu(x);
+                e[cj] = (sc)x;
+            }
+            *reinterpret_cast<u32x2*>(hsm + pix * 128 + (((2 * wave + (g >> 1)) ^ (pix & 7)) << 4) + (g & 1) * 8) = pk;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        f32x4 acc3[FM];
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) acc3[fm] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) {
+                const int pix = fm * 16 + p;
+                const frag_t yf = *reinterpret_cast<const frag_t*>(hsm + pix * 128 + (((4 * ks + g) ^ (pix & 7)) << 4));
+                acc3[fm] = E::mma(wf3[ks], yf, acc3[fm]);
+            }
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) {
+            const int oy = y0 + fm, ox = x0 + p;
+            if (oy >= a.Ho || ox >= a.Wo || nb >= a.Cout) continue;
+            const int m = (b * a.Ho + oy) * a.Wo + ox;
+            float v[LPG];
+#pragma unroll
+            for (int cj = 0; cj < LPG; ++cj) {
+                float x = acc3[fm][cj] + b3[cj];
+                if (a.post_act == YP_ACT_SILU) x = yp_silu(x);
+                v[cj] = x;
+            }
+            yp_store_chunk<DT, false, LPG>(a, m, nb, v);
+        }
+    } else {
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm) {
         const int oy = y0 + fm, ox = x0 + p;
         if (oy >= a.Ho || ox >= a.Wo) continue;
         const int m = (b * a.Ho + oy) * a.Wo + ox;
         yp_epilogue_pixel<DT, false, LPG>(a, m, nb, bias, [&](int cj) { return acc[fm][cj]; });
+    }
     }
     }
 }
@@ -1791,7 +1857,7 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
                "yp_conv2d: 8-bit inputs need scale_in / scale_w, tail_zero buffers and a plain 16-bit-output convolution");
     // fused C3 tail (post_weight): in1 is the second input of the TAIL convolution and `out` its destination; the 3x3 itself maps
     // in0.C -> in0.C channels
-    const bool post = d->post_weight != nullptr;
+    const bool post = d->post_weight != nullptr && d->stem_weight == nullptr;      // (with stem_weight, post_weight is the fused stem's pointwise stage)
     const int Cin = post ? d->in0.C : d->in0.C + d->in1.C;
     const int Cout = post ? d->in0.C : d->out.C + d->out2.C;
     YP_REQUIRE(d->in0.ptr && (d->out.ptr || det) && d->weight, "yp_conv2d: null buffer");
@@ -1933,9 +1999,12 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
                            in0_bytes + (size_t)d->in0.cstride * eb + 64 < (1ull << 31);
     const bool halo_ok = halo_base && (d->in1.C == 0 || post);
     if (d->stem_x != nullptr) {          // fused stem + this 3x3 / stride-2 convolution: the stem's output lives in LDS
-        YP_REQUIRE(halo_base && d->stride_h == 2 && !of32 && d->in0.C == 32 && d->in1.C == 0 && d->res.C == 0 && d->out2.C == 0 && det == nullptr &&
+        const bool post3 = d->post_weight != nullptr;          // ... and the 64 -> 64 pointwise convolution behind it (out / out2 are ITS destinations)
+        YP_REQUIRE(halo_base && d->stride_h == 2 && !of32 && d->in0.C == 32 && d->in1.C == 0 && d->res.C == 0 && (d->out2.C == 0 || post3) && det == nullptr &&
                    d->bn_partial == nullptr && d->pre_weight == nullptr && d->out_phase == 0 && Cout <= 64 && Cout % 8 == 0,
                    "yp_conv2d: the fused stem needs a plain 16-bit 3x3 / stride 2 / pad 1 convolution of 32 -> <= 64 channels");
+        YP_REQUIRE(!post3 || (Cout == 64 && d->post_Kpad >= 64 && d->post_Kpad % 32 == 0 && d->post_Npad >= 64 && d->Npad >= 64),
+                   "yp_conv2d: the pointwise stage behind the fused stem maps 64 -> 64 channels (packed [>= 64][>= 64])");
         YP_REQUIRE(d->stem_weight != nullptr && d->stem_Kpad >= 144 && d->stem_C >= 1 && d->stem_C <= 4 && d->Hi % 2 == 0 && d->Wi % 2 == 0,
                    "yp_conv2d: bad fused-stem arguments");
         YP_REQUIRE(d->tile == 0, "yp_conv2d: tile %d does not apply to the fused stem", d->tile);
@@ -1951,15 +2020,16 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
         const int nbs = ntl < 2 * 256 ? ntl : 2 * 256;     // (two resident workgroups per CU: 216 VGPRs)
         constexpr int HSL = ((2 * TH + 1) * 34 + 15) / 16;
         constexpr size_t lds = (size_t)HSL * 1024 + (size_t)(4 * TH + 6) * 36 * 16;
-        if (d->dtype == YP_F16) {
-            static YpLdsAttr attr;
-            e = yp_set_max_lds(attr, (const void*)stem_conv2_kernel<YP_F16, TH>, (int)lds);
-            if (e == hipSuccess) { stem_conv2_kernel<YP_F16, TH><<<nbs, 256, lds, stream>>>(a); e = hipGetLastError(); }
-        } else {
-            static YpLdsAttr attr;
-            e = yp_set_max_lds(attr, (const void*)stem_conv2_kernel<YP_BF16, TH>, (int)lds);
-            if (e == hipSuccess) { stem_conv2_kernel<YP_BF16, TH><<<nbs, 256, lds, stream>>>(a); e = hipGetLastError(); }
+        static_assert((size_t)HSL * 1024 >= (size_t)TH * 16 * 128, "phase C's pixel rows fit the hidden halo");
+        if (post3) {
+            a.post_wgt = (const char*)d->post_weight; a.post_bias = d->post_bias; a.post_Kpad = d->post_Kpad; a.post_Npad = d->post_Npad;
+            a.post_act = d->post_act; a.post_N = Cout;
         }
+#define YP_STEM2(DTC, P3) { static YpLdsAttr attr; e = yp_set_max_lds(attr, (const void*)stem_conv2_kernel<DTC, TH, P3>, (int)lds); \
+                            if (e == hipSuccess) { stem_conv2_kernel<DTC, TH, P3><<<nbs, 256, lds, stream>>>(a); e = hipGetLastError(); } }
+        if (d->dtype == YP_F16) { if (post3) YP_STEM2(YP_F16, true) else YP_STEM2(YP_F16, false) }
+        else { if (post3) YP_STEM2(YP_BF16, true) else YP_STEM2(YP_BF16, false) }
+#undef YP_STEM2
         if (e != hipSuccess) { yp_set_error("yp_conv2d: fused stem launch failed: %s", hipGetErrorString(e)); return YP_ERR_HIP; }
         return YP_OK;
     }

@@ -90,7 +90,7 @@ class YOLOPoint(HipModule):
         pb.scope.pop()
         return out
 
-    def _emit_stem_conv2(self, pb, img, run):
+    def _emit_stem_conv2(self, pb, img, run, block=None):
         """Conv1 + Conv2.  -s width (32 stem channels, 3x3 / stride-2 Conv2 of <= 64 channels), 16-bit eval plans: ONE launch whose stem output
         stays in LDS (PlanBuilder.stem_conv2; YP_FUSE_STEM2=0: the two launches)."""
         import os
@@ -101,12 +101,28 @@ class YOLOPoint(HipModule):
               and c2.out_channels % 8 == 0 and isinstance(self.Conv2.act, nn.SiLU) and img.H % 4 == 0 and img.W % 4 == 0
               and os.environ.get("YP_FUSE_STEM", "1") != "0" and os.environ.get("YP_FUSE_STEM2", "1") != "0")
         if not ok:
-            return run("Conv2", self.Conv2, self._emit_stem(pb, img))
+            out = run("Conv2", self.Conv2, self._emit_stem(pb, img))
+            return (out, False) if block is not None else out
         (w1, b1), (w2, b2) = self.Conv1.folded(), self.Conv2.folded()
+        # ... and Bottleneck1's cv1 + cv2 (a C3 of hidden width 32 over Conv2's 64 channels: one 64 -> 64 pointwise filter) in the same
+        # launch: Conv2's output feeds nothing else, so it is never written (YP_FUSE_STEM3=0: two launches).  Returns the block's output.
+        from .common import C3
+        b1m = self.Bottleneck1
+        if (block is not None and isinstance(b1m, C3) and c2.out_channels == 64 and b1m.cv1.conv.in_channels == 64 and b1m.cv1.conv.out_channels == 32
+                and isinstance(b1m.cv1.act, nn.SiLU) and isinstance(b1m.cv2.act, nn.SiLU) and os.environ.get("YP_FUSE_STEM3", "1") != "0"):
+            w12, b12 = b1m.merged_cv12()
+            H2, W2 = img.H // 4, img.W // 4
+            cat = pb.new_buf(H2, W2, 64)
+            t = pb.new_buf(H2, W2, 32).view()
+            pb.scope.append("Conv1+Conv2+Bottleneck1.cv1+cv2")
+            _, pb.stem_launch = pb.stem_conv2(w1, b1, _hip.YP_ACT_SILU, img.H, img.W, w2, b2, _hip.YP_ACT_SILU,
+                                              post=(w12, b12, _hip.YP_ACT_SILU, t, cat.view(32, 32)))
+            pb.scope.pop()
+            return block("Bottleneck1", b1m, None, pre=(t, cat)), True
         pb.scope.append("Conv1+Conv2")
         out, pb.stem_launch = pb.stem_conv2(w1, b1, _hip.YP_ACT_SILU, img.H, img.W, w2, b2, _hip.YP_ACT_SILU)
         pb.scope.pop()
-        return out
+        return (out, False) if block is not None else out
 
     def emit(self, pb, img, decode=True):
         """Dataflow of reference models/YOLOPoint.py:198-246; cat/ups are views, never copies."""
@@ -122,8 +138,8 @@ class YOLOPoint(HipModule):
         # (P3-sized launches that fill the chip) go to the plan's side lane and are forked behind Bottleneck4 -- legal anywhere behind
         # Bottleneck2, they read only xa / x8 / xb -- so they run beside that chain instead of in front of it.  Measured (batch 8, 640x640,
         # f16, same box): one lane 0.751 ms, heads forked behind Bottleneck2 / 3 / 4: 0.706 / 0.706 / 0.691 ms (eager two-stream replay).
-        x = self._emit_stem_conv2(pb, img, run)
-        xa = run("Bottleneck1", self.Bottleneck1, x)
+        x, fused_b1 = self._emit_stem_conv2(pb, img, run, block=run)
+        xa = x if fused_b1 else run("Bottleneck1", self.Bottleneck1, x)
         x8 = run("Conv3", self.Conv3, xa)
         xb = run("Bottleneck2", self.Bottleneck2, x8)
         # YOLO encoder

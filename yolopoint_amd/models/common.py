@@ -240,17 +240,28 @@ class C3(HipModule):
     def _standalone_out_channels(self):
         return self.cv3.conv.out_channels
 
-    def emit(self, pb, x, out=None):
-        c_ = self.cv1.conv.out_channels
-        x0 = x[0] if isinstance(x, (list, tuple)) else x
-        cat = pb.new_buf(x0.LH, x0.LW, 2 * c_)
-        # cv1 and cv2 are 1x1 convolutions of the same input: one launch, N = 2*c_, split destination
-        # (cv1 -> its own buffer feeding the bottleneck chain, cv2 -> channels [c_, 2c_) of the concat)
+    def merged_cv12(self):
+        """cv1 and cv2 as ONE 1x1 filter [2 c_, c1] + bias (BN folded): they read the same input."""
         (w1, b1), (w2, b2) = self.cv1.folded(), self.cv2.folded()
-        t = pb.new_buf(x0.LH, x0.LW, c_).view()
-        pb.scope.append("cv1+cv2")
-        pb.conv(x, torch.cat((w1, w2), 0), torch.cat((b1, b2), 0), 1, 1, 0, _hip.YP_ACT_SILU, out=t, out2=cat.view(c_, c_))
-        pb.scope.pop()
+        return torch.cat((w1, w2), 0), torch.cat((b1, b2), 0)
+
+    def emit(self, pb, x, out=None, pre=None):
+        """pre = (t, cat): cv1 + cv2 have already been emitted by the caller (inside the launch that produces this block's input:
+        PlanBuilder.stem_conv2(post=...)) into t = cv1's output view and channels [c_, 2 c_) of the concat buffer `cat`."""
+        c_ = self.cv1.conv.out_channels
+        if pre is not None:
+            t, cat = pre
+            x0 = t
+        else:
+            x0 = x[0] if isinstance(x, (list, tuple)) else x
+            cat = pb.new_buf(x0.LH, x0.LW, 2 * c_)
+            # cv1 and cv2 are 1x1 convolutions of the same input: one launch, N = 2*c_, split destination
+            # (cv1 -> its own buffer feeding the bottleneck chain, cv2 -> channels [c_, 2c_) of the concat)
+            w12, b12 = self.merged_cv12()
+            t = pb.new_buf(x0.LH, x0.LW, c_).view()
+            pb.scope.append("cv1+cv2")
+            pb.conv(x, w12, b12, 1, 1, 0, _hip.YP_ACT_SILU, out=t, out2=cat.view(c_, c_))
+            pb.scope.pop()
         n = len(self.m)
         last = self.m[n - 1]
         # C3 tail fusion: cv3 runs inside the last Bottleneck's kernel (its output never reaches HBM); hidden widths 32 / 64

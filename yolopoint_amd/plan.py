@@ -546,20 +546,32 @@ class PlanBuilder:
         self.stem_record = OpRecord(self.name("stem"), "conv", 2 * M * Cout * Kreal, B * w.shape[1] * H * W * 4 + M * Cout * 2 + Cout * Kreal * 2, M, Cout, Kreal)
         return out, launch
 
-    def stem_conv2(self, w1, b1, act1, H, W, w2, b2, act2):
+    def stem_conv2(self, w1, b1, act1, H, W, w2, b2, act2, post=None):
         """Fused stem + the 3x3 / stride-2 convolution behind it (YpConvDesc.stem_*: the stem's 32-channel output stays in LDS).  Returns
-        (Conv2's output view, launch(x_nchw_fp32)); like stem(), the launch is enqueued eagerly in front of the plan replay."""
+        (Conv2's output view, launch(x_nchw_fp32)); like stem(), the launch is enqueued eagerly in front of the plan replay.
+        post = (w3 [64, 64, 1, 1], b3, act3, out view, out2 view | None): the pointwise convolution behind Conv2 (C3.cv1 + C3.cv2 of the
+        next block) runs inside the same launch and writes out / out2; Conv2's own output is never materialised (returns (None, launch))."""
         C1, C2 = w1.shape[0], w2.shape[0]
         assert C1 == 32 and tuple(w2.shape[1:]) == (32, 3, 3) and C2 <= 64 and H % 4 == 0 and W % 4 == 0
         H1, W1, H2, W2 = H // 2, W // 2, H // 4, W // 4
-        out = self.new_buf(H2, W2, round_up(C2, 8)).view()
+        if post is not None:
+            w3, b3, act3, o1, o2 = post
+            assert C2 == 64 and tuple(w3.shape) == (64, 64, 1, 1) and o1.C + (o2.C if o2 is not None else 0) == 64
+            out = o1
+        else:
+            out = self.new_buf(H2, W2, round_up(C2, 8)).view()
         wp1, bp1, Kpad1, _ = pack_stem_weight(w1, b1, self.code, self.device)
         wp2, bp2, Kpad2, Npad2 = pack_conv_weight(w2, b2, self.code, self.device)
         self.keep += [wp1, bp1, wp2, bp2]
         d = YpConvDesc()
         hidden = _hip.YpView()      # describes the stem's output, which is never materialised
         hidden.ptr, hidden.H, hidden.W, hidden.cstride, hidden.coff, hidden.C, hidden.ups = wp2.data_ptr(), H1, W1, C1, 0, C1, 0
-        d.in0, d.in1, d.out, d.res, d.out2 = hidden, NULL_VIEW, out.c(), NULL_VIEW, NULL_VIEW
+        d.in0, d.in1, d.out, d.res, d.out2 = hidden, NULL_VIEW, out.c(), NULL_VIEW, (post[4].c() if post is not None and post[4] is not None else NULL_VIEW)
+        if post is not None:
+            wp3, bp3, Kpad3, Npad3 = pack_conv_weight(w3, b3, self.code, self.device)
+            self.keep += [wp3, bp3]
+            d.post_weight, d.post_bias = wp3.data_ptr(), (bp3.data_ptr() if b3 is not None else None)
+            d.post_Kpad, d.post_Npad, d.post_act = Kpad3, Npad3, act3
         d.weight, d.bias = wp2.data_ptr(), (bp2.data_ptr() if b2 is not None else None)
         d.dtype, d.out_f32, d.B = self.code, 0, self.B
         d.Hi, d.Wi, d.Ho, d.Wo = H1, W1, H2, W2
@@ -576,9 +588,12 @@ class PlanBuilder:
             check(lib().yp_conv2d(C.byref(d), _hip.stream_ptr(stream)))
         K1, K2 = w1.shape[1] * w1.shape[2] * w1.shape[3], 32 * 9
         M1, M2 = self.B * H1 * W1, self.B * H2 * W2
-        self.stem_record = OpRecord(self.name("stem+Conv2"), "conv", 2 * M1 * C1 * K1 + 2 * M2 * C2 * K2,
-                                    self.B * w1.shape[1] * H * W * 4 + M2 * C2 * 2 + (C1 * K1 + C2 * K2) * 2, M2, C2, K2)
-        return out, launch
+        fl3 = 2 * M2 * 64 * 64 if post is not None else 0
+        self.stem_record = OpRecord(self.name("stem+Conv2" + ("+cv1+cv2" if post is not None else "")), "conv", 2 * M1 * C1 * K1 + 2 * M2 * C2 * K2 + fl3,
+                                    self.B * w1.shape[1] * H * W * 4 + M2 * C2 * 2 + (C1 * K1 + C2 * K2 + (64 * 64 if post is not None else 0)) * 2, M2, C2, K2)
+        if post is not None:                  # the launch writes the destinations of the pointwise stage (dependency tracking of the plan's later ops)
+            self.stem_writes = [post[3]] + ([post[4]] if post[4] is not None else [])
+        return (None if post is not None else out), launch
 
     def op(self, code, reads, writes, name, **kw):
         """Append a generic launch record (training-path kernels); kw: v=[Views], f/g/p=[tensors|ptr], n=[sizes], i=[ints], s=[floats]."""
