@@ -119,6 +119,16 @@ class YOLOPoint(HipModule):
                                               post=(w12, b12, _hip.YP_ACT_SILU, t, cat.view(32, 32)))
             pb.scope.pop()
             return block("Bottleneck1", b1m, None, pre=(t, cat)), True
+        from .common import C2f
+        if (block is not None and isinstance(b1m, C2f) and c2.out_channels == 64 and b1m.cv1.conv.in_channels == 64 and b1m.cv1.conv.out_channels == 64
+                and b1m.cv1.conv.kernel_size == (1, 1) and isinstance(b1m.cv1.act, nn.SiLU) and os.environ.get("YP_FUSE_STEM3", "1") != "0"):
+            wc, bc = b1m.cv1.folded()                   # (v52: the C2f's cv1 fills channels [0, 2c) of its concat buffer)
+            cat = pb.new_buf(img.H // 4, img.W // 4, (2 + len(b1m.m)) * b1m.c)
+            pb.scope.append("Conv1+Conv2+Bottleneck1.cv1")
+            _, pb.stem_launch = pb.stem_conv2(w1, b1, _hip.YP_ACT_SILU, img.H, img.W, w2, b2, _hip.YP_ACT_SILU,
+                                              post=(wc, bc, _hip.YP_ACT_SILU, cat.view(0, 64), None))
+            pb.scope.pop()
+            return block("Bottleneck1", b1m, None, pre=cat), True
         pb.scope.append("Conv1+Conv2")
         out, pb.stem_launch = pb.stem_conv2(w1, b1, _hip.YP_ACT_SILU, img.H, img.W, w2, b2, _hip.YP_ACT_SILU)
         pb.scope.pop()
@@ -332,8 +342,8 @@ class YOLOPointv52(YOLOPoint):
             finally:
                 pb.scope.pop()
 
-        x = self._emit_stem_conv2(pb, img, run)
-        xa = run("Bottleneck1", self.Bottleneck1, x)
+        x, fused_b1 = self._emit_stem_conv2(pb, img, run, block=run)
+        xa = x if fused_b1 else run("Bottleneck1", self.Bottleneck1, x)
         x8 = run("Conv3", self.Conv3, xa)
         xb = run("Bottleneck2", self.Bottleneck2, x8)
         x = run("Conv4", self.Conv4, xb)

@@ -317,13 +317,17 @@ class C2f(HipModule):
     def _standalone_out_channels(self):
         return self.cv2.conv.out_channels
 
-    def emit(self, pb, x, out=None, out_f32=False):
+    def emit(self, pb, x, out=None, out_f32=False, pre=None):
+        """pre = the concat buffer whose channels [0, 2c) the caller's launch has already filled with cv1's output (PlanBuilder.stem_conv2(post=...))."""
         c, n = self.c, len(self.m)
         if c % 8:
             raise _hip.YpError(f"C2f hidden width {c} must be a multiple of 8")
-        x0 = x[0] if isinstance(x, (list, tuple)) else x
-        cat = pb.new_buf(x0.LH, x0.LW, (2 + n) * c)
-        pb.scope.append("cv1"); self.cv1.emit(pb, x, out=cat.view(0, 2 * c)); pb.scope.pop()
+        if pre is not None:
+            cat = pre
+        else:
+            x0 = x[0] if isinstance(x, (list, tuple)) else x
+            cat = pb.new_buf(x0.LH, x0.LW, (2 + n) * c)
+            pb.scope.append("cv1"); self.cv1.emit(pb, x, out=cat.view(0, 2 * c)); pb.scope.pop()
         for i, blk in enumerate(self.m):
             pb.scope.append(f"m.{i}"); blk.emit(pb, cat.view((1 + i) * c, c), out=cat.view((2 + i) * c, c)); pb.scope.pop()
         pb.scope.append("cv2"); y = self.cv2.emit(pb, cat.view(), out=out, out_f32=out_f32); pb.scope.pop()
