@@ -591,8 +591,6 @@ class PlanBuilder:
         fl3 = 2 * M2 * 64 * 64 if post is not None else 0
         self.stem_record = OpRecord(self.name("stem+Conv2" + ("+cv1+cv2" if post is not None else "")), "conv", 2 * M1 * C1 * K1 + 2 * M2 * C2 * K2 + fl3,
                                     self.B * w1.shape[1] * H * W * 4 + M2 * C2 * 2 + (C1 * K1 + C2 * K2 + (64 * 64 if post is not None else 0)) * 2, M2, C2, K2)
-        if post is not None:                  # the launch writes the destinations of the pointwise stage (dependency tracking of the plan's later ops)
-            self.stem_writes = [post[3]] + ([post[4]] if post[4] is not None else [])
         return (None if post is not None else out), launch
 
     def op(self, code, reads, writes, name, **kw):
