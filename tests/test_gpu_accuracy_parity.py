@@ -103,6 +103,7 @@ def test_repeatability_and_map_parity(cuda, dtype, twin_iou, twin_conf, twin_fra
     assert abs(sum(len(d) for d in det_cpu) - sum(len(d) for d in det_hip)) <= 0.02 * total
 
 
+@pytest.mark.statistical
 def test_trained_checkpoint_map_and_repeatability_parity(cuda):
     """BASELINE.json "det mAP / kp repeatability parity within 0.2 pt on the same synthetic eval", on a checkpoint the build TRAINED
     itself: YOLOPoint-s, 500 bf16 optimizer steps of yolopoint_amd.engine.TrainStep on the synthetic shapes task

@@ -3,6 +3,7 @@ kernel's YP_FP8 (e4m3 x e4m3, forward) / YP_FP8_BF8 (filter e4m3 x dy e5m2, dgra
 8-bit operands (torch.float8_e4m3fn / float8_e5m2 are the OCP formats gfx950 implements): the kernel's only freedom is the fp32
 accumulation order and the final bf16 rounding."""
 import ctypes as C
+import os
 
 import pytest
 import torch
@@ -233,42 +234,75 @@ def test_fp8_forward_matches_the_fake_quantised_oracle(cuda):
         assert float(cos) > 0.9, (k, float(cos))
 
 
-# per-step |loss_fp8 - loss_bf16| / loss_bf16 over the first 20 optimizer steps: measured max 0.114 / mean 0.035 (the loss falls 13 -> ~5 in
-# those steps, so a step's value moves ~10 % per step by itself); bars at about twice that
-FP8_EARLY_STEP, FP8_EARLY_MEAN = 0.25, 0.08
+# The early-step statistic, calibrated on a DISTRIBUTION (tools/probe/fp8_curve_dist.py, gpurun_out/fp8_curve_dist.json: 11 kernel-variant
+# mixtures -- the autotuner's picks + YP_TUNE_RANDOM seeds 1..10 -- x {bf16, fp8 margin 1, fp8 margin 2} on one lease, plus the driver's
+# round-4 box).  d_t = |loss_x(t) - loss_bf16(t)| / loss_bf16(t) over the first 20 optimizer steps, while the loss falls 13 -> 5:
+#   bf16 under ANOTHER variant mixture vs bf16 (the control: same arithmetic, other fp32 summation orders):
+#       max_t d_t 0.10 - 0.17, mean 0.026 - 0.054, median 0.011 - 0.054, tail (last 20 of 200 steps) within 3.8 %
+#   fp8 vs bf16 (22 runs + the driver's): max_t d_t 0.09 - 0.31, mean 0.026 - 0.069, median 0.013 - 0.057, tail within 2.9 %
+# i.e. the fp8 deviation IS the trajectory noise of this 200-step Adam run at lr 1e-3 (a second bf16 run is as far from the first as the fp8
+# run is), and doubling the scale margin (YP_FP8_MARGIN=2: one binade of headroom against a scale that lags the activations) changes
+# nothing -- the round-4 failure (a single-step bar of 0.25 derived from ONE run, 0.306 measured on the driver's box) was the tail of that
+# noise, not a scale-lag event.  The single-step maximum is therefore only printed; asserted are the robust statistics, at >= 2 x the worst
+# of the 33 observations, for the fp8 run AND for the in-test bf16 control (which shows what the bars measure): a broken 8-bit path
+# (wrong scale, wrong operand format) is off by O(1) in all of them.
+FP8_EARLY_MEAN, FP8_EARLY_MEDIAN, FP8_TAIL = 0.15, 0.12, 0.10
 
 
-def test_fp8_loss_curve_tracks_bf16(cuda):
+@pytest.mark.statistical
+def test_fp8_loss_curve_tracks_bf16(cuda, monkeypatch):
     """200 optimizer steps of the reference training step (engine.TrainStep: both forwards, detector + object + InfoNCE losses, backward,
-    Adam) on YOLOPoint-l at 2 x 128 x 128, the same initial weights and the same batches, once in bf16 and once with fp8 Conv operands:
-    the loss curves stay together (mean of the last 20 steps within 10 % of each other) and both come down from where they started."""
+    Adam) on YOLOPoint-l at 2 x 128 x 128, the same initial weights and the same batches: in bf16, in bf16 under another kernel-variant
+    mixture (the control) and with fp8 Conv operands.  The loss curves stay together (mean of the last 20 steps within 10 % of each other,
+    mean / median per-step deviation over the first 20 steps inside the bars above) and all come down from where they started."""
     import copy
     from helpers import make_model
+    from yolopoint_amd import plan as yplan
     from yolopoint_amd.engine import TrainStep, synthetic_batch
-    m, _ = make_model("l", 11, dtype="bf16")
-    m = m.to(cuda).train()
-    m8 = copy.deepcopy(m)
+    from yolopoint_amd.models.common import invalidate_packed_weights
+    m0, _ = make_model("l", 11, dtype="bf16")
+    m0 = m0.to(cuda).train()
     batches = [synthetic_batch(2, 128, cuda, 100 + i) for i in range(4)]     # (a small fixed set: the loss can actually be driven down)
-    curves = []
-    for model, fp8 in ((m, False), (m8, True)):
-        step = TrainStep(model, cuda, img_size=128, lr=1e-3, fp8=fp8)
-        step.sparse = dict(num_samples_per_image=100, num_masked_non_matches_per_match=30)
-        losses = []
-        for it in range(200):
-            torch.manual_seed(1000 + it)             # the InfoNCE sampling of both runs draws the same cells / negatives
-            losses.append(float(step(batches[it % 4])))
-        curves.append(losses)
-        assert all(l == l and abs(l) < 1e6 for l in losses), ("fp8" if fp8 else "bf16", losses[-5:])
-    b, f = curves
+    saved, outer = dict(yplan._TUNE_CACHE), os.environ.get("YP_TUNE_RANDOM")
+    curves = {}
+    try:
+        for name, fp8, mix in (("bf16", False, None), ("bf16 (other variant mixture)", False, "control"), ("fp8", True, None)):
+            if mix is not None:
+                yplan._TUNE_CACHE.clear()
+                monkeypatch.setenv("YP_TUNE_RANDOM", (outer or "") + mix)
+            invalidate_packed_weights()
+            step = TrainStep(copy.deepcopy(m0), cuda, img_size=128, lr=1e-3, fp8=fp8)
+            step.sparse = dict(num_samples_per_image=100, num_masked_non_matches_per_match=30)
+            losses = []
+            for it in range(200):
+                torch.manual_seed(1000 + it)             # the InfoNCE sampling of all runs draws the same cells / negatives
+                losses.append(float(step(batches[it % 4])))
+            curves[name] = losses
+            assert all(l == l and abs(l) < 1e6 for l in losses), (name, losses[-5:])
+            del step
+            if mix is not None:
+                if outer is None:
+                    monkeypatch.delenv("YP_TUNE_RANDOM")
+                else:
+                    monkeypatch.setenv("YP_TUNE_RANDOM", outer)
+                yplan._TUNE_CACHE.clear()
+                yplan._TUNE_CACHE.update(saved)
+    finally:
+        yplan._TUNE_CACHE.clear()
+        yplan._TUNE_CACHE.update(saved)
+    b = curves["bf16"]
     head = lambda c: sum(c[:20]) / 20
     tail = lambda c: sum(c[-20:]) / 20
-    print("loss bf16: first20 %.4f last20 %.4f | fp8: first20 %.4f last20 %.4f" % (head(b), tail(b), head(f), tail(f)))
-    assert tail(b) < head(b) and tail(f) < head(f)
-    assert abs(tail(f) - tail(b)) <= 0.10 * abs(tail(b)), (tail(b), tail(f))
-    # step by step over the first 20 optimizer steps (same weights, same batches, same draws: the runs have not had time to drift apart)
-    early = [abs(x - y) / max(abs(y), 1e-6) for x, y in zip(f[:20], b[:20])]
-    print("per-step |fp8 - bf16| / bf16 over the first 20 steps: max %.4f mean %.4f" % (max(early), sum(early) / 20))
-    assert max(early) <= FP8_EARLY_STEP and sum(early) / 20 <= FP8_EARLY_MEAN, early
+    for name, c in curves.items():
+        assert tail(c) < 0.5 * head(c), (name, head(c), tail(c))
+        if c is b:
+            continue
+        early = [abs(x - y) / max(abs(y), 1e-6) for x, y in zip(c[:20], b[:20])]
+        mean, median = sum(early) / 20, sorted(early)[10]
+        print("%-30s first20 %.4f last20 %.4f (bf16 %.4f / %.4f) | per-step deviation over the first 20 steps: mean %.4f median %.4f max %.4f at step %d"
+              % (name, head(c), tail(c), head(b), tail(b), mean, median, max(early), early.index(max(early))))
+        assert abs(tail(c) - tail(b)) <= FP8_TAIL * abs(tail(b)), (name, tail(b), tail(c))
+        assert mean <= FP8_EARLY_MEAN and median <= FP8_EARLY_MEDIAN, (name, mean, median, early)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -403,11 +437,13 @@ def _fp8_gradient_check(cuda, version, B, S, seed, min_q8, min_stable):
     return graph
 
 
+@pytest.mark.statistical
 def test_fp8_parameter_gradients_against_the_fake_quantised_oracle(cuda):
     """YOLOPoint-s, 4 x 128 x 128 (see _fp8_gradient_check)."""
     _fp8_gradient_check(cuda, "s", 4, 128, 41, min_q8=60, min_stable=4)
 
 
+@pytest.mark.statistical
 def test_fp8_gradients_of_yolopoint_l_through_the_block_scaled_kernels(cuda, monkeypatch):
     """The same check on YOLOPoint-l (configs[4]'s model: every channel count a multiple of 64, most of 128) at 2 x 128 x 128 with the
     autotuner restricted to tile 57 -- the 8-wave kernel on block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 -- so that every forward and

@@ -9,6 +9,7 @@ cp $S/${R}_collect.json profiles/${R}_pmc_collect.json
 cp $S/conv_traffic.json profiles/conv_traffic.json
 cp $S/mfma_busy.json profiles/mfma_busy.json
 cp $S/layers.txt profiles/${R}_layers_infer.txt
+cp $S/${R}_layers_traffic.txt profiles/${R}_layers_traffic.txt 2>/dev/null || true
 cp $S/${R}_infer_sequence.txt profiles/${R}_infer_sequence.txt
 cp $S/bench_train.json profiles/${R}_bench_train.json
 cp $S/${R}_train_kernel_trace.txt profiles/${R}_train_kernel_trace.txt

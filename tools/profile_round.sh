@@ -19,8 +19,14 @@ rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o t -- $BENCH > $OUT
 python $ROOT/tools/infer_sequence.py $(find $OUT/trace -name "*kernel_trace.csv" | head -1) 50 > $OUT/${R}_infer_sequence.txt 2>/dev/null
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o f -- $BENCH > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o w -- $BENCH > $OUT/pmc_write.log 2>&1
-# MFMA utilisation: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 4 SIMDs x 256 CUs); eager replay so that the dispatch order is the plan order
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma -o m -- $BENCH --no-graph > $OUT/pmc_mfma.log 2>&1
+# MFMA utilisation: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 4 SIMDs x 256 CUs); ONE-LANE eager replay so that the dispatch order is the plan order
+YP_INFER_LANES=0 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma -o m -- $BENCH --no-graph > $OUT/pmc_mfma.log 2>&1
+# per-launch HBM bytes (the same one-lane eager plan; its own per-launch table gives the row names)
+cd $ROOT
+YP_INFER_LANES=0 python bench.py --no-cpu-baseline --only none --no-graph --steps 100 --warmup 10 --layers $OUT/layers_1lane.txt > $OUT/bench_1lane.json 2>> $OUT/bench_default.err
+cd /tmp
+YP_INFER_LANES=0 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch1 -o f -- $BENCH --no-graph > $OUT/pmc_fetch1.log 2>&1
+YP_INFER_LANES=0 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write1 -o w -- $BENCH --no-graph > $OUT/pmc_write1.log 2>&1
 cd $ROOT
 python bench.py --mode train --steps 20 --warmup 3 > $OUT/bench_train.json 2> $OUT/bench_train.err
 cd /tmp
@@ -72,5 +78,5 @@ bash tools/probe/pmc_mma8.sh l32 c256_256_k3_40 41,57,58,3 > $OUT/${R}_mma8_pmc_
 bash tools/probe/pmc_mma8.sh l32 c2048_1024_k1_20 41,57,3 > $OUT/${R}_mma8_pmc_c2048_1024_k1_20.txt 2>&1
 rm -rf $ROOT/gpurun_out/pmc8_*
 # raw traces are large: keep only what profile_collect distilled
-rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma $OUT/trace_train
+rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_fetch1 $OUT/pmc_write1 $OUT/pmc_mfma $OUT/trace_train
 ls -la $OUT
