@@ -587,10 +587,31 @@ def run_train(a, rank, world, dev, version, batch, steps, warmup, gas=1, size=64
         dist.all_reduce(x, op=dist.ReduceOp.MAX)
         return float(x.item())
     wall = timed_region(lambda: step(arg), steps, warmup, torch.cuda.synchronize, (dist.barrier if world > 1 else (lambda: None)), reduce_max)
-    exposed = None
+    exposed, launch_order, rccl_note = None, list(step.reducer.launch_log), None
     if step.comm_events:
         ev = step.comm_events[-steps:]
         exposed = round(sum(e0.elapsed_time(e1) for e0, e1 in ev) / len(ev), 4)
+    if world == 1 and gas == 1 and os.environ.get("YP_BENCH_RCCL_N1", "1") != "0":
+        # N = 1: the bucketed all-reduce does not run in the timed region (one rank has nothing to exchange).  So that the RCCL path -- bucket
+        # launch order behind the backward plans, async work handles, the compute stream's wait in front of Adam -- is exercised on a single GPU
+        # as well, a few EXTRA steps (after the timed region, not part of `value`) run with the collectives forced through a one-rank RCCL group.
+        try:
+            if not dist.is_initialized():
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+                dist.init_process_group("nccl", rank=0, world_size=1)
+            step.reducer.force_collectives, step.comm_events = True, []
+            for _ in range(6):
+                step(arg)
+            torch.cuda.synchronize()
+            ev = step.comm_events[2:]
+            exposed = round(sum(e0.elapsed_time(e1) for e0, e1 in ev) / len(ev), 4)
+            launch_order = list(step.reducer.launch_log)
+            rccl_note = "N = 1: measured on 4 extra steps behind the timed region with the collectives forced through a ONE-rank RCCL group (force_collectives)"
+        except Exception as e:          # (a box without a usable RCCL must not lose the record)
+            rccl_note = f"one-rank RCCL leg failed: {type(e).__name__}: {e}"[:200]
+        finally:
+            step.reducer.force_collectives, step.comm_events = False, None
     samples = batch * gas * world * steps
     gflop_sample = TRAIN_GFLOP_PER_SAMPLE.get(version, 0.0) * (size / 640.0) ** 2
     achieved = gflop_sample * samples / wall / 1e3 / max(world, 1)          # TFLOP/s per GPU
@@ -603,7 +624,7 @@ def run_train(a, rank, world, dev, version, batch, steps, warmup, gas=1, size=64
            "ms_per_step": round(wall / steps * 1e3, 3), "steps": steps, "warmup": warmup, "n_gpus": world, "dtype": dtype, "scaling": "weak",
            "per_gpu_batch": batch, "gas": gas, "global_batch": batch * gas * world, "parallelism": f"dp{world}",
            "grad_allreduce_bytes": step.reducer.payload_bytes(), "buckets": step.reducer.describe(),
-           "bucket_launch_order": list(step.reducer.launch_log), "exposed_comm_ms_per_step": exposed,
+           "bucket_launch_order": launch_order, "exposed_comm_ms_per_step": exposed, "comm_note": rccl_note,
            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS[dtype], 4),
                         "traffic": train_traffic_record(version, batch, dtype), "per_gpu": True, "algorithmic_gflop_per_sample": round(gflop_sample, 2),
                         "note": "whole step (losses, BN / elementwise passes, optimizer included) against the conv FLOP the reference executes per sample"

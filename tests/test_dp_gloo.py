@@ -206,3 +206,49 @@ def test_overlapped_bucket_schedule_and_dp_equivalence(world, pair):
         assert a1 == det + kpb                                          # the keypoint buckets follow the second pass
         assert r["worst_rel"] < 1e-5, r["worst_rel"]                    # == single-process gradients of the concatenated batch (per-shard BN)
     assert len({round(r["grad0"], 9) for r in res.values()}) == 1       # every rank ends with the same gradients
+
+
+def _worker_bf16(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), YP_DP_COMM="bf16")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from yolopoint_amd.dp import GradAllReducer
+    torch.manual_seed(7)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.BatchNorm2d(8), torch.nn.Conv2d(8, 4, 1))
+    red = GradAllReducer(net.parameters(), bucket_bytes=256)
+    red.bind_grads()
+    g = torch.Generator().manual_seed(50 + rank)
+    mine = [torch.randn(p.shape, generator=g) for p in net.parameters()]
+    for _ in range(2):                                  # two micro-batches accumulate in the fp32 buckets
+        for p, m_ in zip(net.parameters(), mine):
+            p.grad += m_
+    ptrs = [p.grad.data_ptr() for p in net.parameters()]
+    red.all_reduce()
+    q.put((rank, {"grads": [p.grad.flatten().tolist() for p in net.parameters()], "mine": [(2 * m_).flatten().tolist() for m_ in mine],
+                  "same_storage": ptrs == [p.grad.data_ptr() for p in net.parameters()], "fp32": all(p.grad.dtype == torch.float32 for p in net.parameters()),
+                  "payload": red.payload_bytes(), "numel": sum(f.numel() for f, _ in red.buckets)}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sixteen_bit_gradient_exchange_two_ranks():
+    """YP_DP_COMM=bf16: the buckets travel as bf16 (half the bytes), the gradients the optimizer reads stay fp32 views of the same buckets and
+    equal the rank mean of the fp32-accumulated contributions to bf16 resolution."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_bf16, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    a, b = res[0], res[1]
+    assert a["same_storage"] and b["same_storage"] and a["fp32"] and b["fp32"]
+    assert a["payload"] == 2 * a["numel"]
+    assert a["grads"] == b["grads"]                                             # every rank holds the same average
+    for ga, ma, mb in zip(a["grads"], a["mine"], b["mine"]):
+        for x, u, v in zip(ga, ma, mb):
+            want = 0.5 * (u + v)
+            assert abs(x - want) <= 2e-2 * max(abs(u), abs(v), 1e-3), (x, want)
+        assert any(x != 0.5 * (u + v) for x, u, v in zip(ga, ma, mb)) or len(ga) < 4   # (it really went through 16 bits)

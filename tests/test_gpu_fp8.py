@@ -237,16 +237,16 @@ def test_fp8_forward_matches_the_fake_quantised_oracle(cuda):
 # The early-step statistic, calibrated on a DISTRIBUTION (tools/probe/fp8_curve_dist.py, gpurun_out/fp8_curve_dist.json: 11 kernel-variant
 # mixtures -- the autotuner's picks + YP_TUNE_RANDOM seeds 1..10 -- x {bf16, fp8 margin 1, fp8 margin 2} on one lease, plus the driver's
 # round-4 box).  d_t = |loss_x(t) - loss_bf16(t)| / loss_bf16(t) over the first 20 optimizer steps, while the loss falls 13 -> 5:
-#   bf16 under ANOTHER variant mixture vs bf16 (the control: same arithmetic, other fp32 summation orders):
-#       max_t d_t 0.10 - 0.17, mean 0.026 - 0.054, median 0.011 - 0.054, tail (last 20 of 200 steps) within 3.8 %
-#   fp8 vs bf16 (22 runs + the driver's): max_t d_t 0.09 - 0.31, mean 0.026 - 0.069, median 0.013 - 0.057, tail within 2.9 %
+#   bf16 under ANOTHER variant mixture vs bf16 (the control: same arithmetic, other fp32 summation orders; 20 runs on two leases):
+#       max_t d_t 0.10 - 0.49, mean 0.026 - 0.064, median 0.011 - 0.054, tail (last 20 of 200 steps) within 4.9 %
+#   fp8 vs bf16 (32 runs + the driver's): max_t d_t 0.09 - 0.31, mean 0.026 - 0.078, median 0.013 - 0.072, tail within 3.0 %
 # i.e. the fp8 deviation IS the trajectory noise of this 200-step Adam run at lr 1e-3 (a second bf16 run is as far from the first as the fp8
 # run is), and doubling the scale margin (YP_FP8_MARGIN=2: one binade of headroom against a scale that lags the activations) changes
 # nothing -- the round-4 failure (a single-step bar of 0.25 derived from ONE run, 0.306 measured on the driver's box) was the tail of that
 # noise, not a scale-lag event.  The single-step maximum is therefore only printed; asserted are the robust statistics, at >= 2 x the worst
-# of the 33 observations, for the fp8 run AND for the in-test bf16 control (which shows what the bars measure): a broken 8-bit path
+# of the 53 observations, for the fp8 run AND for the in-test bf16 control (which shows what the bars measure): a broken 8-bit path
 # (wrong scale, wrong operand format) is off by O(1) in all of them.
-FP8_EARLY_MEAN, FP8_EARLY_MEDIAN, FP8_TAIL = 0.15, 0.12, 0.10
+FP8_EARLY_MEAN, FP8_EARLY_MEDIAN, FP8_TAIL = 0.16, 0.15, 0.10
 
 
 @pytest.mark.statistical
@@ -369,7 +369,7 @@ class _FakeQuantTraining:
         return False
 
 
-FP8_GRAD = dict(median=1.15, p90=1.15, worst=1.25, worst_abs=0.05, cosine=0.5)
+FP8_GRAD = dict(median=1.15, p90=1.15, worst=1.25, worst_abs=0.05, cosine_stable=0.4, cosine_drop_median=0.05, cosine_drop_p90=0.15)
 
 
 def _fp8_gradient_check(cuda, version, B, S, seed, min_q8, min_stable):
@@ -429,11 +429,20 @@ def _fp8_gradient_check(cuda, version, B, S, seed, min_q8, min_stable):
     # statements (median relative error ~1.0, cosines around 0): there only the error STATISTICS above are comparable.  Where the floor
     # itself keeps the direction (the layers within a few convolutions of the loss), the product must keep it as well.
     stable = [(c_hip, c_floor, name) for c_hip, c_floor, name in cosines if c_floor >= 0.8]
+    drop = sorted(c_floor - c_hip for c_hip, c_floor, _ in stable)
+    low = min(stable, default=(1.0, 1.0, ""))
     print(f"{len(stable)} of {n} tensors keep their direction in the floor (cosine >= 0.8); lowest HIP cosine among them "
-          f"{min((c[0] for c in stable), default=1.0):.3f}")
+          f"{low[0]:.3f} (floor {low[1]:.3f}, {low[2]}); floor - HIP cosine over them: median {drop[len(drop) // 2] if drop else 0:.3f} "
+          f"p90 {drop[int(len(drop) * 0.9)] if drop else 0:.3f} max {drop[-1] if drop else 0:.3f}")
     assert len(stable) >= min_stable
+    # Calibrated on 10 kernel-variant mixtures (tools/probe/stat_tests_seeds.sh: the autotuner's picks + YP_TUNE_RANDOM 1..9): the tensor that
+    # sits lowest is the same in every run, one whose floor cosine (0.82) is itself marginal, at 0.61 - 0.77 -- the old per-tensor bar
+    # (floor - 0.1) was one run's value and failed for 2 of the 10 mixtures.  Asserted now: every stable tensor keeps a clearly positive
+    # direction (>= 0.4: 1.5 x the worst observed distance from 1; decorrelated tensors sit around 0), and over the stable set as a whole the
+    # product loses no more direction than a few hundredths (median / 90th percentile of floor - HIP).
     for c_hip, c_floor, name in stable:
-        assert c_hip >= c_floor - 0.1, (name, c_hip, c_floor)
+        assert c_hip >= t["cosine_stable"], (name, c_hip, c_floor)
+    assert drop[len(drop) // 2] <= t["cosine_drop_median"] and drop[int(len(drop) * 0.9)] <= t["cosine_drop_p90"], drop
     return graph
 
 

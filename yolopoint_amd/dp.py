@@ -69,6 +69,9 @@ class GradAllReducer:
         self.expected = {id(p): 1 for p in self.params}     # gradient contributions per micro-batch (set_expected)
         self.sync = True
         self.force_collectives = False          # run the collectives even for a single rank (exercises the RCCL path on one GPU)
+        import os
+        self.comm_dtype = {"bf16": torch.bfloat16, "f16": torch.float16}.get(os.environ.get("YP_DP_COMM", "fp32"))      # None: fp32 buckets as they are
+        self._stage = None
         self.launch_log = []                    # bucket indices in launch order (tests, bench reporting)
         self._pending, self._works, self._launched = None, {}, set()
 
@@ -184,7 +187,16 @@ class GradAllReducer:
                 torch._foreach_copy_([flat[off:off + n] for _, off, n in have], [p.grad.reshape(-1) for p, _, _ in have])
         avg = dist.get_backend(self.group) == "nccl"
         op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
-        self._works[bi] = (dist.all_reduce(flat, op=op, group=self.group, async_op=True), avg)
+        stage = None
+        if self.comm_dtype is not None:
+            # 16-bit exchange (YP_DP_COMM=bf16): the fp32 bucket is rounded into a staging buffer, the collective moves half the bytes over
+            # xGMI, and finish() widens the rank average back into the fp32 bucket the optimizer reads (the accumulation over micro-batches
+            # and Adam's arithmetic stay fp32; what is rounded is each rank's contribution to the average, once per optimizer step)
+            if self._stage is None:
+                self._stage = [torch.empty(f.numel(), dtype=self.comm_dtype, device=f.device) for f, _ in self.buckets]
+            stage = self._stage[bi]
+            stage.copy_(flat)
+        self._works[bi] = (dist.all_reduce(flat if stage is None else stage, op=op, group=self.group, async_op=True), avg, stage)
 
     def finish(self):
         """Launch whatever has not been launched (parameters without a gradient count as zeros), then make the current stream wait
@@ -197,9 +209,11 @@ class GradAllReducer:
         for bi in range(len(self.buckets)):
             self._launch(bi)
         inv = 1.0 / self.world
-        for bi, (work, avg) in sorted(self._works.items()):
+        for bi, (work, avg, stage) in sorted(self._works.items()):
             work.wait()
             flat, entries = self.buckets[bi]
+            if stage is not None:
+                flat.copy_(stage)
             if not avg:
                 flat.mul_(inv)
             if self._bound(bi):
@@ -218,7 +232,7 @@ class GradAllReducer:
         self.finish()
 
     def payload_bytes(self):
-        return sum(f.numel() * 4 for f, _ in self.buckets)
+        return sum(f.numel() * (4 if self.comm_dtype is None else 2) for f, _ in self.buckets)
 
     def describe(self):
         return [{"group": g, "mbytes": round(f.numel() * 4 / 1e6, 2), "params": len(e)} for g, (f, e) in zip(self.bucket_group, self.buckets)]
