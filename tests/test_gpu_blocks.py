@@ -160,9 +160,12 @@ def test_conv3x3_halo_kernel(cuda, case, dtype):
 
 
 BNECK_CASES = [
-    # C, B, H, W, tile (0 auto, 10/11/12 = 32/64/128 output channels per workgroup), shortcut
+    # C, B, H, W, tile (0 auto, 10/11/12 = 32/64/128 output channels per workgroup, four wavefronts), shortcut
     (32, 2, 24, 40, 0, True), (32, 1, 19, 23, 10, False), (64, 2, 20, 20, 11, True), (64, 1, 17, 33, 10, True),
     (128, 1, 16, 16, 12, True), (128, 2, 9, 21, 11, False), (128, 1, 40, 40, 10, True),
+    # 17 / 18 / 19: the same kernel with EIGHT wavefronts per workgroup (two per SIMD), BN = 32 / 64 / 128
+    (32, 2, 24, 40, 17, True), (64, 1, 17, 33, 17, True), (64, 2, 20, 20, 18, False), (128, 1, 40, 40, 17, True), (128, 2, 9, 21, 18, True),
+    (128, 1, 16, 16, 19, False), (128, 2, 40, 40, 18, True),
 ]
 
 
@@ -234,6 +237,40 @@ def test_c3_tail_fused_into_last_bottleneck(cuda, c1, c2, n, B, H, W, dtype):
             C3.fuse_tail = True
     assert rel_err(outs[True], ref)[0] < TOL[dtype] * 2
     assert torch.equal(outs[True], outs[False]), float((outs[True] - outs[False]).abs().max())
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("B,H,W", [(4, 104, 200), (3, 99, 190), (1, 24, 40)])
+def test_persistent_bottleneck_c32_equals_the_one_tile_kernel(cuda, monkeypatch, B, H, W, dtype):
+    """Tile 16 (bneck32_persist_kernel: the three filters resident in LDS, a workgroup walks its tiles, the next tile's halo and cv2-branch
+    tile prefetched into the other half of a double buffer, shortcut read from the resident halo) against tile 10 (one tile per workgroup):
+    the same fragments in the same MFMA order -- bit-identical; sizes with more tiles than resident workgroups (676 / 507 tiles for 512:
+    the loop, the buffer flip, ragged right / bottom tiles) and fewer (one tile per workgroup, no prefetch); and against the oracle."""
+    from yolopoint_amd import plan as yplan
+    c1 = c2 = 64
+    m = C3(c1, c2, 1).eval()
+    sd = block_state(m, 9, "blk.")
+    x = net_oracle.synth_image(B, c1, H, W, 4) - 0.5
+    ref = net_oracle.c3(sd, "blk", x, 1)
+    outs = {}
+    saved = dict(yplan._TUNE_CACHE)
+    try:
+        for tile in (10, 16):
+            monkeypatch.setattr(yplan, "_TUNE_CANDIDATES", (1, 2, 4, 5, tile))      # (the fused launch has exactly one applicable candidate)
+            yplan._TUNE_CACHE.clear()
+            mm = C3(c1, c2, 1).eval()
+            mm.load_state_dict(m.state_dict())
+            for mod in mm.modules():
+                if hasattr(mod, "compute_dtype"):
+                    mod.compute_dtype = dtype
+            outs[tile] = mm.to(cuda)(x.to(cuda)).float().cpu()
+            fused = [k for k, v in yplan._TUNE_CACHE.items() if v[0] == tile]
+            assert fused, (tile, list(yplan._TUNE_CACHE.values()))                  # the fused Bottleneck + tail really ran on this tile id
+    finally:
+        yplan._TUNE_CACHE.clear()
+        yplan._TUNE_CACHE.update(saved)
+    assert rel_err(outs[16], ref)[0] < TOL[dtype] * 2
+    assert torch.equal(outs[16], outs[10]), float((outs[16] - outs[10]).abs().max())
 
 
 def test_fused_bottleneck_rejects_unsupported(cuda):

@@ -934,30 +934,35 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvKArgs a) {
 // HBM traffic: x once (+ the shortcut re-read of the tile centre, an L2 hit) and out once -- the hidden
 // tensor's write + 9-tap read of the two-launch form disappear, as does one launch.
 // ==========================================================================================
-template <int DT, int C, int BN, int WAVES_M, bool POST = false>
-__global__ __launch_bounds__(256) void bottleneck_halo_kernel(const ConvKArgs a) {
+// NWAVES = 8 (two wavefronts per SIMD, 512 threads): the phases of a tile are latency chains of ONE wave per SIMD (measured at C = 128, 40 x 40
+// x 8: 27.9 k clocks per tile -- setup 2.2 k, phase A DMA + MFMAs 4.8 k, bias + SiLU + hidden write 5.6 k, twelve filter-row steps at ~0.9 k
+// each with 0.38 k of MFMA work per wave, epilogue 3.7 k -- and a launch is ONE round of 240 workgroups); with eight waves every phase has half
+// the work per wave and a second wave per SIMD to issue while the first waits for LDS.  Same fragments, same k order: bit-identical.
+template <int DT, int C, int BN, int WAVES_M, bool POST = false, int NWAVES = 4>
+__global__ __launch_bounds__(64 * NWAVES) void bottleneck_halo_kernel(const ConvKArgs a) {
     using E = Elem<DT>;
     using frag_t = typename E::frag;
     using sc = typename E::scalar;
     static_assert(E::BYTES == 2, "fused bottleneck: 16-bit element types");
     constexpr int EB = 2, BK = 32;
     constexpr int TH = 8, TW = 16;
-    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int WAVES_N = NWAVES / WAVES_M;
     constexpr int FM = TH / WAVES_M;
     constexpr int TN = BN / WAVES_N, FN = TN / 16, LPG = 4 * FN;
     constexpr int HH = 10, HP = 18;
-    constexpr int HROWS = HH * HP, HSLOTS = 12, NH = 3, HBYTES = HSLOTS * 1024;
+    constexpr int HROWS = HH * HP, HSLOTS = 12, NH = (HSLOTS + NWAVES - 1) / NWAVES, HBYTES = HSLOTS * 1024;
     constexpr int NCH = C / BK;                         // 32-channel chunks of x / of the hidden tensor
     constexpr int NSUB = C / 32;                        // 32-channel sub-tiles of the hidden tensor (2 fragments each)
-    constexpr int WASLOTS = C / 16, NWA = (WASLOTS + 3) / 4, WABYTES = WASLOTS * 1024;
+    constexpr int WASLOTS = C / 16, NWA = (WASLOTS + NWAVES - 1) / NWAVES, WABYTES = WASLOTS * 1024;
     constexpr int ASTAGE = HBYTES + WABYTES;
-    constexpr int WSLOTS_TAP = BN / 16, WSLOTS = 3 * WSLOTS_TAP, NW = (WSLOTS + 3) / 4, WBYTES = WSLOTS * 1024;
+    constexpr int WSLOTS_TAP = BN / 16, WSLOTS = 3 * WSLOTS_TAP, NW = (WSLOTS + NWAVES - 1) / NWAVES, WBYTES = WSLOTS * 1024;
     constexpr int NLA = NH + NWA;                       // DMA instructions per wave per phase-A chunk
     static_assert(HROWS <= HSLOTS * 16 && BN <= C && FN >= 1 && FM >= 1, "unsupported tile");
     // POST: the C3 tail.  out = act(W3 . cat(bottleneck output, in1) + b3), N3 = K3 = 2C; the bottleneck output never leaves LDS.
     constexpr int N3 = 2 * C, FN3 = N3 / 16, LPG3 = 4 * FN3, KCH3 = N3 / BK;      // one wave column: every wave holds all N3 channels
     constexpr int W3BYTES = KCH3 * N3 * 64, NW3 = KCH3 * (N3 / 16) / 4, NU = NCH * 8 / 4;
-    static_assert(!POST || (BN == C && WAVES_M == 4), "C3 tail: all channels of a pixel in one workgroup");
+    static_assert(!POST || (BN == C && WAVES_M == 4 && NWAVES == 4), "C3 tail: all channels of a pixel in one workgroup");
+    constexpr int NPF = (HSLOTS + NWAVES - 1) / NWAVES;      // phase A: pixel fragments (16 halo rows each) per wave -- fragment wave + NWAVES * i
 
     extern __shared__ __attribute__((aligned(1024))) char hsm[];      // [hidden | bottleneck output][ring: phase A operands | filter rows | W3][POST: in1 tile]
     const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)hsm);
@@ -987,9 +992,13 @@ __global__ __launch_bounds__(256) void bottleneck_halo_kernel(const ConvKArgs a)
 
     // ---- per-lane DMA byte offsets
     unsigned hoff[NH];
+    int hslot[NH];
 #pragma unroll
     for (int i = 0; i < NH; ++i) {
-        const int rho = (wave + 4 * i) * 16 + lrow;
+        int sl = wave + NWAVES * i;
+        if (sl > HSLOTS - 1) sl = HSLOTS - 1;           // (8 waves: surplus instructions re-fetch the last slot, same bytes)
+        hslot[i] = sl;
+        const int rho = sl * 16 + lrow;
         const int hy = rho / HP, hx = rho - hy * HP;
         const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
         const bool valid = rho < HROWS && (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi;
@@ -999,7 +1008,7 @@ __global__ __launch_bounds__(256) void bottleneck_halo_kernel(const ConvKArgs a)
     int waslot[NWA];
 #pragma unroll
     for (int i = 0; i < NWA; ++i) {
-        int sl = wave + 4 * i;
+        int sl = wave + NWAVES * i;
         if (sl > WASLOTS - 1) sl = WASLOTS - 1;
         waslot[i] = sl;
         const int rho = sl * 16 + lrow;                 // LDS row -> hidden channel (lanes own 8 consecutive channels per sub-tile)
@@ -1011,7 +1020,7 @@ __global__ __launch_bounds__(256) void bottleneck_halo_kernel(const ConvKArgs a)
     int wslot[NW];
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
-        int sl = wave + 4 * i;
+        int sl = wave + NWAVES * i;
         if (sl > WSLOTS - 1) sl = WSLOTS - 1;
         wslot[i] = sl;
         const int tap_s = sl / WSLOTS_TAP, rs = sl - tap_s * WSLOTS_TAP;
@@ -1061,17 +1070,17 @@ __global__ __launch_bounds__(256) void bottleneck_halo_kernel(const ConvKArgs a)
         const char* hk = in0 + (size_t)(in0_co + c * BK) * EB;
         const char* wk = pre_wgt + (size_t)(c * BK) * EB;
 #pragma unroll
-        for (int i = 0; i < NH; ++i) yp_glds16_s(hk, hoff[i], ldsR + c * ASTAGE + (wave + 4 * i) * 1024);
+        for (int i = 0; i < NH; ++i) yp_glds16_s(hk, hoff[i], ldsR + c * ASTAGE + hslot[i] * 1024);
 #pragma unroll
         for (int i = 0; i < NWA; ++i) yp_glds16_s(wk, waoff[i], ldsR + c * ASTAGE + HBYTES + waslot[i] * 1024);
     }
-    f32x4 hacc[NSUB][2][3];
+    f32x4 hacc[NSUB][2][NPF];
 #pragma unroll
     for (int sb = 0; sb < NSUB; ++sb)
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
-            for (int i = 0; i < 3; ++i) hacc[sb][f][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < NPF; ++i) hacc[sb][f][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int a_rd = p * 64 + ((g ^ swr) << 4);          // fragment row p, k group g (both operand images use the same swizzle key)
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -1083,9 +1092,12 @@ __global__ __launch_bounds__(256) void bottleneck_halo_kernel(const ConvKArgs a)
         YP_TL(2 + c);
         const char* xb = hsm + RING + c * ASTAGE;
         const char* wb = xb + HBYTES;
-        frag_t xf[3];
+        frag_t xf[NPF];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) xf[i] = *reinterpret_cast<const frag_t*>(xb + (wave * 3 + i) * 1024 + a_rd);
+        for (int i = 0; i < NPF; ++i) {                  // (a wave without an i-th fragment re-reads the last one; its result is not stored)
+            const int fr = wave + NWAVES * i < HSLOTS ? wave + NWAVES * i : HSLOTS - 1;
+            xf[i] = *reinterpret_cast<const frag_t*>(xb + fr * 1024 + a_rd);
+        }
 #pragma unroll
         for (int sb = 0; sb < NSUB; ++sb) {
             frag_t wf[2];
@@ -1094,7 +1106,8 @@ __global__ __launch_bounds__(256) void bottleneck_halo_kernel(const ConvKArgs a)
 #pragma unroll
             for (int f = 0; f < 2; ++f)
 #pragma unroll
-                for (int i = 0; i < 3; ++i) hacc[sb][f][i] = E::mma(wf[f], xf[i], hacc[sb][f][i]);
+                for (int i = 0; i < NPF; ++i)
+                    if (NWAVES * i + NWAVES <= HSLOTS || wave + NWAVES * i < HSLOTS) hacc[sb][f][i] = E::mma(wf[f], xf[i], hacc[sb][f][i]);
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1115,8 +1128,9 @@ __global__ __launch_bounds__(256) void bottleneck_halo_kernel(const ConvKArgs a)
 
     // ---- hidden = act(hacc + b1), zero outside the image, 16-bit, into the resident halo image
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int rho = (wave * 3 + i) * 16 + p;
+    for (int i = 0; i < NPF; ++i) {
+        if (wave + NWAVES * i >= HSLOTS) break;          // (wave-uniform)
+        const int rho = (wave + NWAVES * i) * 16 + p;
         const int hy = rho / HP, hx = rho - hy * HP;
         const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
         const bool inside = (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi;      // rows >= HROWS are never read
@@ -1292,6 +1306,285 @@ __global__ __launch_bounds__(256) void bottleneck_halo_kernel(const ConvKArgs a)
             }
         }
         YP_TL(42);
+    }
+}
+
+
+// ==========================================================================================
+// Persistent form of the fused Bottleneck + C3 tail for C = 32 (Bottleneck1.m.0 > cv3 of YOLOPoint-s: M = 204 800 pixels at batch 8, 1 600
+// tiles of 8 x 16 pixels).  bottleneck_halo_kernel<DT, 32, 32, 4, true> ran one tile per workgroup: every tile fetched the three filters again
+// (28 KB through L2 -> LDS against 36 KB of activations in + out) and stood at seven barriers, each behind a DMA wait -- ~12 us per tile,
+// four resident workgroups per CU, 26 us per launch for 52 MB (1.7 TB/s).  Here a workgroup keeps W1 (2 KB), W2 (18 KB) and W3 (8 KB) in LDS
+// for its whole life, walks its tiles, and the halo of x and the cv2-branch tile of the NEXT tile are in flight (LDS-DMA into the other
+// half of a double buffer) while the current one is multiplied: one counted wait and four barriers per tile, none of them behind a fresh
+// DMA.  The shortcut (res = x) is read from the resident halo instead of from global memory (an ordinary load would make the compiler's
+// vmcnt wait drain the prefetch).  Same fragments, same MFMA order, same roundings as the one-tile kernel: bit-identical
+// (tests/test_gpu_blocks.py::test_persistent_bottleneck_c32_equals_the_one_tile_kernel).
+// LDS: hidden | B-out 12 KB, x halo 2 x 12 KB, in1 tile 2 x 8 KB, W1 2 KB, W2 18 KB, W3 8 KB = 80 KB -> two workgroups per CU.
+// ==========================================================================================
+template <int DT>
+__global__ __launch_bounds__(256, 2) void bneck32_persist_kernel(const ConvKArgs a) {
+    using E = Elem<DT>;
+    using frag_t = typename E::frag;
+    using sc = typename E::scalar;
+    static_assert(E::BYTES == 2, "fused bottleneck: 16-bit element types");
+    constexpr int EB = 2, BK = 32, C = 32, BN = 32;
+    constexpr int TH = 8, TW = 16, FM = 2, FN = 2, LPG = 8;
+    constexpr int HH = 10, HP = 18, HROWS = HH * HP, NH = 3, HBYTES = 12 * 1024;
+    constexpr int WBYTES = 6 * 1024;                     // one filter row of the 3x3: 3 taps x 2 slots of 16 output channels
+    constexpr int N3 = 64, FN3 = 4, LPG3 = 16, KCH3 = 2;
+    constexpr int UBYTES = 8 * 1024;
+    constexpr int OFF_HID = 0, OFF_X = HBYTES, OFF_U = OFF_X + 2 * HBYTES, OFF_WA = OFF_U + 2 * UBYTES, OFF_WB = OFF_WA + 2048, OFF_W3 = OFF_WB + 3 * WBYTES;
+    static_assert(OFF_W3 + 8192 == 80 * 1024, "LDS layout");
+
+    extern __shared__ __attribute__((aligned(1024))) char hsm[];
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)hsm);
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int lrow = lane >> 2;
+    const int jl = (lane & 3) ^ ((0x3300 >> ((lane >> 4) * 4)) & 3);
+    const int p = lane & 15, g = lane >> 4;
+    const int swr = (0x3300 >> ((p >> 2) * 4)) & 3;
+
+    YP_PIN2(const char*, in0); YP_PIN2(const char*, in1);
+    YP_PIN2(int, in0_cs); YP_PIN2(int, in0_co); YP_PIN2(int, in1_cs); YP_PIN2(int, in1_co); YP_PIN2(int, Hi); YP_PIN2(int, Wi);
+    YP_PIN2(unsigned, in0_zoff); YP_PIN2(unsigned, in1_zoff);
+
+    // ---- the three filters, once per workgroup
+    {
+        int sl = wave < 2 ? wave : 1;                    // W1: 2 slots (rows = hidden channels in the lane-owns-8-consecutive order)
+        int rho = sl * 16 + lrow;
+        int q = rho & 31;
+        int n = ((q & 15) >> 2) * 8 + (q >> 4) * 4 + (q & 3);
+        yp_glds16_s(a.pre_wgt, (unsigned)n * (unsigned)a.pre_Kpad * EB + (unsigned)jl * 16u, lds0 + OFF_WA + sl * 1024);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const char* wk = a.wgt + (size_t)(r * 3) * C * EB;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                sl = wave + 4 * i;
+                if (sl > 5) sl = 5;
+                const int tap_s = sl >> 1, rs = sl & 1;
+                rho = rs * 16 + lrow;
+                const int f = rho >> 4, g_ = (rho & 15) >> 2, r_ = rho & 3;
+                n = g_ * LPG + f * 4 + r_;
+                const unsigned off = ((n < a.Npad) ? (unsigned)n * (unsigned)a.Kpad * EB : a.wgt_zrow) + (unsigned)jl * 16u + (unsigned)(tap_s * C * EB);
+                yp_glds16_s(wk, off, lds0 + OFF_WB + r * WBYTES + sl * 1024);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            sl = wave + 4 * i;                           // W3: KCH3 chunks x 4 slots
+            const int kc = sl >> 2, rs = sl & 3;
+            rho = rs * 16 + lrow;
+            n = ((rho & 15) >> 2) * LPG3 + (rho >> 4) * 4 + (rho & 3);
+            yp_glds16_s(a.post_wgt, (unsigned)n * (unsigned)a.post_Kpad * EB + (unsigned)(kc * BK * EB) + (unsigned)jl * 16u, lds0 + OFF_W3 + sl * 1024);
+        }
+    }
+    // ---- biases (ordinary loads, once)
+    float b1[8];
+    {
+        f32x4 lo = f32x4{0.f, 0.f, 0.f, 0.f}, hi = lo;
+        if (a.pre_bias != nullptr) { lo = *reinterpret_cast<const f32x4*>(a.pre_bias + g * 8); hi = *reinterpret_cast<const f32x4*>(a.pre_bias + g * 8 + 4); }
+        b1[0] = lo[0]; b1[1] = lo[1]; b1[2] = lo[2]; b1[3] = lo[3]; b1[4] = hi[0]; b1[5] = hi[1]; b1[6] = hi[2]; b1[7] = hi[3];
+    }
+    const int wm = wave;                                 // WAVES_M = 4: wave w owns tile rows 2 w, 2 w + 1
+    const int nb = g * LPG;
+    float bias[LPG];
+    yp_load_bias<LPG>(a, nb, bias);
+    float b3[LPG3];
+#pragma unroll
+    for (int q = 0; q < LPG3 / 4; ++q) {
+        f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.post_bias != nullptr) b4 = *reinterpret_cast<const f32x4*>(a.post_bias + g * LPG3 + 4 * q);
+        b3[4 * q] = b4[0]; b3[4 * q + 1] = b4[1]; b3[4 * q + 2] = b4[2]; b3[4 * q + 3] = b4[3];
+    }
+
+    const int ntiles = a.stats_rows;                     // (host: B * tiles_y * tiles_x)
+    auto decode = [&](int tile, int& b, int& y0, int& x0) {
+        int bid = tile;
+        const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+        const int ty = bid % a.tiles_y;
+        b = bid / a.tiles_y; y0 = ty * TH; x0 = tx * TW;
+    };
+    auto issue_inputs = [&](int tile, int buf) {
+        int b, y0, x0;
+        decode(tile, b, y0, x0);
+        const char* hk = in0 + (size_t)in0_co * EB;
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            const int rho = (wave + 4 * i) * 16 + lrow;
+            const int hy = rho / HP, hx = rho - hy * HP;
+            const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+            const bool valid = rho < HROWS && (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi;
+            const unsigned off = valid ? (unsigned)(((b * Hi + iy) * Wi + ix) * in0_cs * EB) + (unsigned)jl * 16u : in0_zoff;
+            yp_glds16_s(hk, off, lds0 + OFF_X + buf * HBYTES + (wave + 4 * i) * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int sl = wave + 4 * i;                 // 8 slots of 16 pixel rows
+            const int rho = sl * 16 + lrow;
+            const int oy = y0 + (rho >> 4), ox = x0 + (rho & 15);
+            const bool ok = oy < a.Ho && ox < a.Wo;
+            const unsigned off = ok ? (unsigned)((((b * a.Ho + oy) * a.Wo + ox) * in1_cs + in1_co) * EB) + (unsigned)jl * 16u : in1_zoff;
+            yp_glds16_s(in1, off, lds0 + OFF_U + buf * UBYTES + sl * 1024);
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) issue_inputs(tile, 0);
+    const int a_rd = p * 64 + ((g ^ swr) << 4);
+    const int w_rd = p * 64 + ((g ^ swr) << 4);          // (one wave column: wn = 0)
+    int buf = 0;
+    for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+        int b, y0, x0;
+        decode(tile, b, y0, x0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                    // this tile's inputs (and, the first time, the filters) have landed; every wave is done with the previous tile
+        if (tile + (int)gridDim.x < ntiles) issue_inputs(tile + gridDim.x, buf ^ 1);
+
+        // ---- phase A: hidden = act1(W1 . x + b1) on the 192 halo rows (3 fragments of 16 rows per wave)
+        f32x4 hacc[2][3];
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) hacc[f][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            const char* xb = hsm + OFF_X + buf * HBYTES;
+            const char* wb = hsm + OFF_WA;
+            frag_t xf[3], wf[2];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) xf[i] = *reinterpret_cast<const frag_t*>(xb + (wave * 3 + i) * 1024 + a_rd);
+#pragma unroll
+            for (int f = 0; f < 2; ++f) wf[f] = *reinterpret_cast<const frag_t*>(wb + (f * 16) * 64 + a_rd);
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) hacc[f][i] = E::mma(wf[f], xf[i], hacc[f][i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int rho = (wave * 3 + i) * 16 + p;
+            const int hy = rho / HP, hx = rho - hy * HP;
+            const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+            const bool inside = (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi;
+            u32x4 pk;
+            sc* e = reinterpret_cast<sc*>(&pk);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = hacc[j >> 2][i][j & 3] + b1[j];
+                if (a.pre_act == YP_ACT_SILU) v = yp_silu(v);
+                e[j] = (sc)(inside ? v : 0.0f);
+            }
+            *reinterpret_cast<u32x4*>(hsm + OFF_HID + rho * 64 + ((g ^ swr) << 4)) = pk;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+
+        // ---- phase B: 3x3 over the resident hidden halo, all nine taps of the filter resident
+        f32x4 acc[FN][FM];
+#pragma unroll
+        for (int f = 0; f < FN; ++f)
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) acc[f][fm] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const char* hb = hsm + OFF_HID;
+            const char* wb = hsm + OFF_WB + r * WBYTES;
+#pragma unroll
+            for (int s_ = 0; s_ < 3; ++s_) {
+                const int xc = s_ + r * HP;
+                frag_t wf[FN], xf[FM];
+#pragma unroll
+                for (int f = 0; f < FN; ++f) wf[f] = *reinterpret_cast<const frag_t*>(wb + w_rd + (s_ * BN + f * 16) * 64);
+#pragma unroll
+                for (int fm = 0; fm < FM; ++fm) {
+                    const int rho = (wm * FM + fm) * HP + p + xc;
+                    const int sw = (0x3300 >> (((rho >> 2) & 3) * 4)) & 3;
+                    xf[fm] = *reinterpret_cast<const frag_t*>(hb + rho * 64 + ((g ^ sw) << 4));
+                }
+#pragma unroll
+                for (int f = 0; f < FN; ++f)
+#pragma unroll
+                    for (int fm = 0; fm < FM; ++fm) acc[f][fm] = E::mma(wf[f], xf[fm], acc[f][fm]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                    // every wave has read its last hidden fragment: the bottleneck output replaces it
+
+        // ---- bottleneck output = act(acc + bias) + x (the shortcut: the halo's centre pixel, still resident), 16-bit, into LDS
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) {
+            const int ly = wm * FM + fm;
+            const int oy = y0 + ly, ox = x0 + p;
+            const bool inside = oy < a.Ho && ox < a.Wo;
+            const int rho = ly * 16 + p;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float x = acc[j >> 2][fm][j & 3] + bias[j];
+                if (a.act == YP_ACT_SILU) x = yp_silu(x);
+                v[j] = x;
+            }
+            if (a.has_res && inside) {
+                const int hr = (ly + 1) * HP + p + 1;
+                const int sw = (0x3300 >> (((hr >> 2) & 3) * 4)) & 3;
+                const u32x4 raw = *reinterpret_cast<const u32x4*>(hsm + OFF_X + buf * HBYTES + hr * 64 + ((g ^ sw) << 4));
+                const sc* e = reinterpret_cast<const sc*>(&raw);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
+            }
+            u32x4 pk;
+            sc* e = reinterpret_cast<sc*>(&pk);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = (sc)v[j];
+            *reinterpret_cast<u32x4*>(hsm + OFF_HID + rho * 64 + ((g ^ swr) << 4)) = pk;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+
+        // ---- C3 tail: out = act(W3 . cat(bottleneck output, in1) + b3)
+        f32x4 acc3[FN3][FM];
+#pragma unroll
+        for (int f = 0; f < FN3; ++f)
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) acc3[f][fm] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int rd = p * 64 + ((g ^ swr) << 4);
+#pragma unroll
+        for (int kc = 0; kc < KCH3; ++kc) {
+            const char* xb = kc == 0 ? hsm + OFF_HID : hsm + OFF_U + buf * UBYTES;
+            const char* wb = hsm + OFF_W3 + kc * (N3 * 64);
+            frag_t xf[FM];
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) xf[fm] = *reinterpret_cast<const frag_t*>(xb + (wm * FM + fm) * 1024 + rd);
+#pragma unroll
+            for (int f = 0; f < FN3; ++f) {
+                const frag_t wf = *reinterpret_cast<const frag_t*>(wb + f * 1024 + rd);
+#pragma unroll
+                for (int fm = 0; fm < FM; ++fm) acc3[f][fm] = E::mma(wf, xf[fm], acc3[f][fm]);
+            }
+        }
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) {
+            const int oy = y0 + wm * FM + fm, ox = x0 + p;
+            if (oy >= a.Ho || ox >= a.Wo) continue;
+            const size_t m = (size_t)(b * a.Ho + oy) * a.Wo + ox;
+            char* op = a.out + (m * a.out_cs + a.out_co + g * LPG3) * EB;
+#pragma unroll
+            for (int h = 0; h < LPG3 / 8; ++h) {
+                if (g * LPG3 + h * 8 >= a.post_N) continue;
+                u32x4 pk;
+                sc* e = reinterpret_cast<sc*>(&pk);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float x = acc3[(h * 8 + j) >> 2][fm][(h * 8 + j) & 3] + b3[h * 8 + j];
+                    if (a.post_act == YP_ACT_SILU) x = yp_silu(x);
+                    e[j] = (sc)x;
+                }
+                *reinterpret_cast<u32x4*>(op + h * 16) = pk;
+            }
+        }
     }
 }
 
@@ -1528,37 +1821,47 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(const ConvKArgs a) {
     }
     const int H1 = a.Hi, W1 = a.Wi;
     const int ntiles = a.stats_rows;                  // (host: B * tiles_y * tiles_x)
+    // ---- image halo of a tile: rows 4 y0 - 4 .. , columns 4 x0 - 4 .. (72 of them), all channels.  The loads of tile i + 1 are issued as soon as
+    // tile i's values have been converted into LDS (same registers), so they are in flight during the three MFMA phases of tile i: with two
+    // workgroups per CU the load latency of a tile (HBM under load: 2-4 k clocks of a ~17 k clock tile) was exposed about half the time.
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    const int H = a.stem_H, W = a.stem_W, C = a.stem_C;
+    const size_t plane = (size_t)H * W;
+    f32x4 v[NIT][4];
+    auto load_tile = [&](int tl) {
+        int bid = tl;
+        const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+        const int ty = bid % a.tiles_y;
+        const int b = bid / a.tiles_y;
+        const int y0 = ty * TH, x0 = tx * TW;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int item = t + 256 * it;
+            const int row = item / QUADS, q = item - row * QUADS;
+            const int iy = 4 * y0 - 4 + row, ix = 4 * x0 - 4 + 4 * q;
+            const bool rowok = item < ITEMS && (unsigned)iy < (unsigned)H;
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                v[it][ch] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (rowok && ch < C) {
+                    const float* src = a.stem_x + ((size_t)b * C + ch) * plane + (size_t)iy * W + ix;
+                    if (ix >= 0 && ix + 3 < W) v[it][ch] = *reinterpret_cast<const f32x4u*>(src);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if ((unsigned)(ix + e) < (unsigned)W) v[it][ch][e] = src[e];
+                    }
+                }
+            }
+        }
+    };
+    if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     int bid = tile;
     const int tx = bid % a.tiles_x; bid /= a.tiles_x;
     const int ty = bid % a.tiles_y;
     const int b = bid / a.tiles_y;
     const int y0 = ty * TH, x0 = tx * TW;
-    // ---- image halo: rows 4 y0 - 4 .. , columns 4 x0 - 4 .. (72 of them), all channels; every load in flight before the first is consumed
-    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-    const int H = a.stem_H, W = a.stem_W, C = a.stem_C;
-    const size_t plane = (size_t)H * W;
-    f32x4 v[NIT][4];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int item = t + 256 * it;
-        const int row = item / QUADS, q = item - row * QUADS;
-        const int iy = 4 * y0 - 4 + row, ix = 4 * x0 - 4 + 4 * q;
-        const bool rowok = item < ITEMS && (unsigned)iy < (unsigned)H;
-#pragma unroll
-        for (int ch = 0; ch < 4; ++ch) {
-            v[it][ch] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (rowok && ch < C) {
-                const float* src = a.stem_x + ((size_t)b * C + ch) * plane + (size_t)iy * W + ix;
-                if (ix >= 0 && ix + 3 < W) v[it][ch] = *reinterpret_cast<const f32x4u*>(src);
-                else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if ((unsigned)(ix + e) < (unsigned)W) v[it][ch][e] = src[e];
-                }
-            }
-        }
-    }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int item = t + 256 * it;
@@ -1573,6 +1876,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(const ConvKArgs a) {
             *reinterpret_cast<u32x4*>(&img[(row * IP + 2 * q + pr) * 8]) = pk;
         }
     }
+    if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
     __syncthreads();
 
     // ---- phase A: the stem outputs of the halo, fragment by fragment
@@ -1638,7 +1942,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(const ConvKArgs a) {
             if (lane_ok[u]) *reinterpret_cast<u32x4*>(hsm + rho * 64 + ((g ^ sw) << 4)) = pk;
         }
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the hidden-halo writes; NOT vmcnt: the next tile's image loads stay in flight)
     __builtin_amdgcn_s_barrier();
 
     // ---- phase B: 3x3 / stride 2 over the resident halo
@@ -1803,7 +2107,7 @@ hipError_t dispatch_halo(int stride, int bn, int th, const ConvKArgs& a, int nbl
 #undef YP_HALO
 }
 
-template <int DT, int C, int BN, int WAVES_M, bool POST>
+template <int DT, int C, int BN, int WAVES_M, bool POST, int NWAVES = 4>
 hipError_t launch_bneck(const ConvKArgs& a, int nblk, hipStream_t st) {
     constexpr size_t hid = (size_t)(C / 32) * 12 * 1024;
     constexpr size_t opa = (size_t)(C / 32) * (12 + C / 16) * 1024, opb = (size_t)3 * 3 * (BN / 16) * 1024;
@@ -1811,16 +2115,34 @@ hipError_t launch_bneck(const ConvKArgs& a, int nblk, hipStream_t st) {
     constexpr size_t ring = opa > opb ? (opa > w3 ? opa : w3) : (opb > w3 ? opb : w3);
     constexpr size_t lds = hid + ring + ub;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = bottleneck_halo_kernel<DT, C, BN, WAVES_M, POST>;
+    auto kern = bottleneck_halo_kernel<DT, C, BN, WAVES_M, POST, NWAVES>;
     static YpLdsAttr attr;        // per instantiation, per device
     if (hipError_t e = yp_set_max_lds(attr, (const void*)kern, (int)lds); e != hipSuccess) return e;
-    kern<<<nblk, 256, lds, st>>>(a);
+    kern<<<nblk, 64 * NWAVES, lds, st>>>(a);
     return hipGetLastError();
 }
 
 template <int DT>
-hipError_t dispatch_bneck(int c, int bn, bool post, const ConvKArgs& a, int nblk, hipStream_t st) {
+hipError_t launch_bneck32_persist(const ConvKArgs& a, int ntiles, hipStream_t st) {
+    constexpr size_t lds = 80 * 1024;
+    auto kern = bneck32_persist_kernel<DT>;
+    static YpLdsAttr attr;        // per instantiation, per device
+    if (hipError_t e = yp_set_max_lds(attr, (const void*)kern, (int)lds); e != hipSuccess) return e;
+    const int nb = ntiles < 2 * 256 ? ntiles : 2 * 256;       // (two resident workgroups per CU)
+    kern<<<nb, 256, lds, st>>>(a);
+    return hipGetLastError();
+}
+
+template <int DT>
+hipError_t dispatch_bneck(int c, int bn, bool post, bool waves8, const ConvKArgs& a, int nblk, hipStream_t st) {
     if (post) return c == 32 ? launch_bneck<DT, 32, 32, 4, true>(a, nblk, st) : launch_bneck<DT, 64, 64, 4, true>(a, nblk, st);
+    if (waves8) {                // tile ids 17 / 18 / 19: eight wavefronts (two per SIMD), BN = 32 / 64 / 128
+        if (c == 32) return launch_bneck<DT, 32, 32, 8, false, 8>(a, nblk, st);
+        if (c == 64) return bn == 32 ? launch_bneck<DT, 64, 32, 8, false, 8>(a, nblk, st) : launch_bneck<DT, 64, 64, 4, false, 8>(a, nblk, st);
+        if (bn == 32) return launch_bneck<DT, 128, 32, 8, false, 8>(a, nblk, st);
+        if (bn == 64) return launch_bneck<DT, 128, 64, 4, false, 8>(a, nblk, st);
+        return launch_bneck<DT, 128, 128, 4, false, 8>(a, nblk, st);
+    }
     if (c == 32) return launch_bneck<DT, 32, 32, 4, false>(a, nblk, st);
     if (c == 64) return bn == 32 ? launch_bneck<DT, 64, 32, 4, false>(a, nblk, st) : launch_bneck<DT, 64, 64, 4, false>(a, nblk, st);
     if (bn == 32) return launch_bneck<DT, 128, 32, 4, false>(a, nblk, st);
@@ -2038,15 +2360,19 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
         YP_REQUIRE(halo_ok && d->stride_h == 1 && !of32 && d->out2.C == 0, "yp_conv2d: the pointwise prologue needs a 16-bit 3x3 / stride 1 / pad 1 convolution with tail_zero buffers");
         YP_REQUIRE(Cout == Cc && (Cc == 32 || Cc == 64 || Cc == 128), "yp_conv2d: pointwise prologue: in = hidden = out channels must be 32, 64 or 128 (got %d -> %d)", Cc, Cout);
         YP_REQUIRE(d->pre_Npad >= Cc && d->pre_Kpad >= Cc && d->pre_Kpad % 32 == 0, "yp_conv2d: bad packed prologue filter %dx%d", d->pre_Npad, d->pre_Kpad);
-        YP_REQUIRE(d->tile == 0 || (d->tile >= 10 && d->tile <= 12), "yp_conv2d: tile %d does not apply to the fused bottleneck", d->tile);
+        // tile 16: the persistent form (bneck32_persist_kernel: C = 32 with the C3 tail, shortcut = the input itself); tile 0 takes it when a
+        // workgroup would walk at least two tiles
+        const bool persist_ok = post && Cc == 32 && (d->res.C == 0 || (d->res.ptr == d->in0.ptr && d->res.cstride == d->in0.cstride && d->res.coff == d->in0.coff));
+        const bool waves8 = d->tile >= 17 && d->tile <= 19 && !post;      // 17 / 18 / 19: the 8-wave form with BN = 32 / 64 / 128
+        YP_REQUIRE(d->tile == 0 || (d->tile >= 10 && d->tile <= 12) || (d->tile == 16 && persist_ok) || waves8, "yp_conv2d: tile %d does not apply to the fused bottleneck", d->tile);
         int bn = Cc < 64 ? Cc : 64;
-        if (d->tile == 10) bn = 32; else if (d->tile == 11) bn = 64; else if (d->tile == 12) bn = 128;
+        if (d->tile == 10 || d->tile == 17) bn = 32; else if (d->tile == 11 || d->tile == 18) bn = 64; else if (d->tile == 12 || d->tile == 19) bn = 128;
         YP_REQUIRE(bn <= Cc, "yp_conv2d: fused bottleneck tile of %d channels > %d", bn, Cc);
         a.pre_wgt = (const char*)d->pre_weight; a.pre_bias = d->pre_bias; a.pre_Kpad = d->pre_Kpad; a.pre_act = d->pre_act;
         if (post) {
             YP_REQUIRE(Cc <= 64 && d->in1.C == Cc && d->in1.ups == 0 && d->in1.H == d->Ho && d->in1.W == d->Wo && d->out.C == 2 * Cc,
                        "yp_conv2d: fused C3 tail needs hidden channels <= 64, in1 = the other %d-channel branch at the output size, out.C = %d", Cc, 2 * Cc);
-            YP_REQUIRE(d->post_Npad >= 2 * Cc && d->post_Kpad >= 2 * Cc && d->post_Kpad % 32 == 0 && (d->tile == 0 || d->tile == (Cc == 32 ? 10 : 11)),
+            YP_REQUIRE(d->post_Npad >= 2 * Cc && d->post_Kpad >= 2 * Cc && d->post_Kpad % 32 == 0 && (d->tile == 0 || d->tile == 16 || d->tile == (Cc == 32 ? 10 : 11)),
                        "yp_conv2d: bad packed C3-tail filter %dx%d / tile %d", d->post_Npad, d->post_Kpad, d->tile);
             bn = Cc;
             a.post_wgt = (const char*)d->post_weight; a.post_bias = d->post_bias; a.post_Kpad = d->post_Kpad; a.post_Npad = d->post_Npad;
@@ -2057,7 +2383,11 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
         a.tiles_y = yp_cdiv(d->Ho, 8);
         a.Ho = d->Ho;
         const int nb3 = d->B * a.tiles_y * a.tiles_x * a.tiles_n;
-        e = d->dtype == YP_F16 ? dispatch_bneck<YP_F16>(Cc, bn, post, a, nb3, stream) : dispatch_bneck<YP_BF16>(Cc, bn, post, a, nb3, stream);
+        if (persist_ok && (d->tile == 16 || (d->tile == 0 && nb3 >= 4 * 256))) {
+            a.stats_rows = nb3;                 // (the tile count: workgroups loop over tiles)
+            e = d->dtype == YP_F16 ? launch_bneck32_persist<YP_F16>(a, nb3, stream) : launch_bneck32_persist<YP_BF16>(a, nb3, stream);
+        } else
+        e = d->dtype == YP_F16 ? dispatch_bneck<YP_F16>(Cc, bn, post, waves8, a, nb3, stream) : dispatch_bneck<YP_BF16>(Cc, bn, post, waves8, a, nb3, stream);
         if (e != hipSuccess) {
             yp_set_error("yp_conv2d: fused bottleneck launch failed: %s", hipGetErrorString(e));
             return YP_ERR_HIP;

@@ -190,14 +190,15 @@ _TUNE_CACHE = {}
 # k order, so the output bits do not depend on the tuner's pick; the waves-split-k tiles (31, 33: four interleaved partial sums) are
 # reachable by explicit id only; 10..12 the 3x3 halo kernel
 # with 32/64/128 output channels per workgroup on 8x16 pixel tiles, 13..15 the same on 4x16 tiles (rejected by the library
-# when it does not apply)
+# when it does not apply); 16 the persistent fused Bottleneck + C3 tail for C = 32 (csrc/conv_igemm.hip::bneck32_persist_kernel: filters resident,
+# next tile's inputs prefetched; bit-identical to tile 10); 17 / 18 / 19 the fused Bottleneck with EIGHT wavefronts per workgroup (BN = 32 / 64 / 128)
 # 41..44 / 57: the 8-wave 32x32x16 kernels of csrc/conv_mma8.hip (256x256 / 256x128 / 128x256 / 128x128 tiles; 57 = 256x256 with two-step
 # phases, 58 = 256x256 free-running), for 16-bit layers whose channel counts are multiples of 64
 # 71..76: the wave-private split-K kernels of csrc/conv_wsk.hip (64x64 tiles with 8 / 4 waves, 128x64 with 4; 71-73 interleave the k tiles over
 # the waves, 74-76 give every wave a contiguous k range) for the short-M layers.  Like 31 / 33 they are reachable by explicit id only: their
 # fp32 sums run as NW partial sums (bit-reproducible, but the last bits differ from the sequential tiles), and although they win several
 # P5 layers in isolation (Conv9 16.6 -> 12.0 us, Conv5 22.8 -> 19.7) the forward did not move with them (0.691 vs 0.691 ms, three A/B pairs).
-_TUNE_CANDIDATES = (1, 2, 3, 4, 5, 21, 22, 23, 24, 25, 26, 27, 10, 11, 12, 13, 14, 15, 41, 42, 43, 44, 57, 58)
+_TUNE_CANDIDATES = (1, 2, 3, 4, 5, 21, 22, 23, 24, 25, 26, 27, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 41, 42, 43, 44, 57, 58)
 # pixels per BatchNorm-statistics row of the variants whose rows are plain pixel blocks (the 3x3 halo kernels write one row per image tile)
 _STAT_ROW_PX = {41: 128, 57: 128, 58: 128}
 _TUNE_ITERS = int(os.environ.get("YP_TUNE_ITERS", "8"))      # timed launches per candidate
@@ -708,7 +709,7 @@ class PlanBuilder:
         rnd = os.environ.get("YP_TUNE_RANDOM")        # stress mode (tests): a pseudo-random applicable variant per signature instead of the fastest
         applicable = []
         for cand in _TUNE_CANDIDATES:
-            if det is not None and 10 <= cand <= 15:
+            if det is not None and 10 <= cand <= 19:
                 continue
             if stat_group_px and d.bn_partial and stat_group_px % _STAT_ROW_PX.get(cand, 64 if cand < 10 or cand > 15 else 1):
                 continue                              # a statistics row of this variant would straddle two BatchNorm statistics groups
