@@ -1123,6 +1123,9 @@ __global__ __launch_bounds__(64 * NWAVES) void bottleneck_halo_kernel(const Conv
 #pragma unroll
         for (int i = 0; i < NW; ++i) yp_glds16_s(wk, woff[i], ldsR + r * WBYTES + wslot[i] * 1024);
     };
+    // (Measured and dropped, round 5: a deeper filter ring -- up to six stages fit the ring region at C = 128 -- changes nothing (tile 11:
+    // 14.4 vs 14.4 us, tile 18: 12.6 vs 12.6): the tap loop is bound by its LDS fragment reads (18 ds_read_b128 per 24 MFMAs per wave and
+    // step; a wave alone on its SIMD issues one every ~29 clocks), not by the filter DMA.  What helps is a second wave per SIMD: NWAVES = 8.)
     issueW(0, 0);
     issueW(0, 1);
 
