@@ -331,6 +331,15 @@ size_t yp_wgrad_partial_elems(YpView x, YpView dy, int dtype, int B, int k, int 
 int yp_wgrad_group_pack_det(const YpView* xs, const YpView* dys, float* const* dws, float* const* parts, int n, int dtype, int B, int k, int stride,
                             int block, void* table_host, int* total_blocks, int* fold_chunks);
 int yp_wgrad_group_run_det(const void* table_dev, int n, int total_blocks, int fold_chunks, int dtype, int k, int stride, int block, void* stream);
+/* 8-bit operands (BASELINE.json configs[4]; no reference counterpart -- the reference trains 16-bit, src/train.py:45-46,206): x8 = the e4m3
+ * twin of the layer's input, dy8 = the e5m2 twin of its output gradient (1-byte NHWC views, 16-channel aligned: the bytes the forward /
+ * dgrad convolutions of the same layer multiply, yp_quantize_fp8), *sx / *sdy their per-tensor scales (device scalars, real = stored x scale).
+ * dw as yp_conv_wgrad (fp32, the sums multiplied by *sx x *sdy).  Grouped form: yp_wgrad_group_pack_q8 = yp_wgrad_group_pack_det with
+ * dtype YP_FP8 and one scale pair per entry (parts may be NULL: fp32 atomics); run with yp_wgrad_group_run_det(..., dtype = YP_FP8, ...);
+ * yp_wgrad_partial_elems / yp_wgrad_block take dtype YP_FP8 for such views. */
+int yp_conv_wgrad_q8(YpView x8, YpView dy8, const float* sx, const float* sdy, int B, int k, int stride, float* dw, void* stream);
+int yp_wgrad_group_pack_q8(const YpView* xs, const YpView* dys, float* const* dws, float* const* parts, const float* const* sx, const float* const* sdy,
+                           int n, int B, int k, int stride, int block, void* table_host, int* total_blocks, int* fold_chunks);
 
 /* dw[ci][r][s][co] (fp32, Cout_pad channels per tap: the layout yp_conv_wgrad / the wgrad-as-convolution path produce)
  * -> grad[co][c0+ci][r][s] for ci < creal, co < Cout: the reference layout of conv.weight.grad */

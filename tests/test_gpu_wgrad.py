@@ -118,3 +118,55 @@ def test_stem_wgrad_rejects_bad_arguments(cuda):
     assert lib().yp_stem_wgrad(view(dy, 0, 16), view(dy, 0, 16), _hip.YP_BF16, 1, s.data_ptr(), dw.data_ptr(), None) != 0
     assert b"packed 4-channel image" in lib().yp_last_error()
     assert lib().yp_stem_wgrad(view(img, 0, 4), view(img, 0, 4), _hip.YP_BF16, 1, s.data_ptr(), dw.data_ptr(), None) != 0
+
+
+Q8_CASES = [
+    # Cin, Cout, k, B, H, W, ups[, stride]: channel counts are multiples of 64 wherever the training graph uses 8-bit operands; offsets are
+    # multiples of 16 bytes
+    (64, 64, 1, 2, 24, 40, 0), (128, 64, 1, 3, 20, 20, 1), (256, 256, 1, 1, 10, 10, 0), (64, 128, 1, 1, 17, 13, 0),
+    (1024, 1024, 1, 2, 40, 40, 0), (256, 128, 1, 4, 160, 160, 1),                          # 128 x 128 blocks
+    (64, 64, 3, 1, 20, 20, 0), (64, 128, 3, 2, 19, 23, 0), (128, 128, 3, 1, 16, 16, 0), (256, 256, 3, 1, 8, 8, 0), (64, 64, 3, 1, 16, 16, 1),
+    (64, 128, 3, 1, 22, 18, 0, 2), (128, 256, 3, 1, 40, 40, 0, 2), (64, 64, 3, 2, 32, 48, 0, 2),
+]
+
+
+@pytest.mark.parametrize("case", Q8_CASES)
+def test_wgrad_q8_matches_autograd_on_the_same_bytes(cuda, case):
+    """yp_conv_wgrad_q8 (x = e4m3 bytes, dy = e5m2 bytes, per-tensor scales; ds_read_b64_tr_b8 fragments, v_mfma_f32_16x16x32_fp8_bf8) against
+    torch autograd's conv2d weight gradient on the SAME 8-bit operands (torch.float8_e4m3fn / float8_e5m2 widened to fp32, times the scales):
+    the kernel's only freedom is the fp32 accumulation order."""
+    Cin, Cout, k, B, H, W, ups = case[:7]
+    st = case[7] if len(case) > 7 else 1
+    torch.manual_seed(Cin + Cout + H + k)
+    hs, ws = (H // 2, W // 2) if ups else (H, W)
+    if ups:
+        H, W = hs * 2, ws * 2
+    sx, sdy = 0.37, 2.5e-4
+    x8 = (torch.randn(B, hs, ws, Cin + 32, device=cuda) * 2.0).clamp(-440, 440).to(torch.float8_e4m3fn)       # view = channels [16, 16 + Cin)
+    dy8 = (torch.randn(B, H // st, W // st, Cout + 16, device=cuda) * 30.0).to(torch.float8_e5m2)              # view = channels [0, Cout)
+    scales = torch.tensor([sx, sdy], device=cuda)
+    dw = torch.zeros(Cin, k, k, Cout, device=cuda)
+    xb, dyb = x8.view(torch.uint8), dy8.view(torch.uint8)
+    check(lib().yp_conv_wgrad_q8(view(xb, 16, Cin, ups), view(dyb, 0, Cout), scales.data_ptr(), scales.data_ptr() + 4, B, k, st, dw.data_ptr(), _hip.stream_ptr()))
+    torch.cuda.synchronize()
+    # fp64 reference (the products of two 8-bit values are exact in fp32; what differs is the order of the fp32 sums)
+    x = (x8[..., 16:16 + Cin].double() * sx).permute(0, 3, 1, 2)
+    if ups:
+        x = torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest")
+    dy = (dy8[..., :Cout].double() * sdy).permute(0, 3, 1, 2)
+    w = torch.zeros(Cout, Cin, k, k, device=cuda, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(x, w, None, st, k // 2).backward(dy)
+    ref = w.grad.permute(1, 2, 3, 0)
+    err = float((dw.double() - ref).abs().max() / ref.abs().max())
+    # measured 0.3 - 4.0e-5 over these cases (the 16-bit kernel: < 2e-5): v_mfma_f32_16x16x32_fp8_bf8 adds its 32 exact products with less than
+    # fp32 precision inside the instruction before the fp32 accumulate -- two orders of magnitude below the 8-bit operands' own resolution
+    assert err < 1e-4, (case, err)
+
+
+def test_wgrad_q8_rejects_unaligned_views(cuda):
+    x = torch.zeros(1, 8, 8, 72, device=cuda, dtype=torch.uint8)
+    dw = torch.zeros(64, 1, 1, 64, device=cuda)
+    s = torch.ones(2, device=cuda)
+    assert lib().yp_conv_wgrad_q8(view(x, 8, 64), view(x, 0, 64), s.data_ptr(), s.data_ptr() + 4, 1, 1, 1, dw.data_ptr(), None) != 0
+    assert b"16-channel aligned" in lib().yp_last_error()
+    assert lib().yp_conv_wgrad_q8(view(x, 0, 64), view(x, 0, 64), None, s.data_ptr(), 1, 1, 1, dw.data_ptr(), None) != 0

@@ -112,6 +112,8 @@ SIGNATURES = {
     "yp_wgrad_group_run": (_i, [_p, _i, _i, _i, _i, _i, _i, _p]),
     "yp_wgrad_partial_elems": (_sz, [YpView, YpView, _i, _i, _i, _i, _i]),
     "yp_wgrad_group_pack_det": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "yp_conv_wgrad_q8": (_i, [YpView, YpView, _p, _p, _i, _i, _i, _p, _p]),
+    "yp_wgrad_group_pack_q8": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
     "yp_wgrad_group_run_det": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "yp_pack_weight_batch": (_i, [_p, _i, _i, _i, _p]),
     "yp_wgrad_unpack_batch": (_i, [_p, _i, _i, _p]),

@@ -42,6 +42,8 @@ struct WgradArgs {
     int g_blk0, g_nblk, g_split;           // grouped launch: first flat workgroup of this entry, its (ci x co) blocks and pixel split
     float* part;                           // deterministic mode: partial slabs [g_split][Cj][taps][Cout_pad] (plain stores, folded in order by
     int f_chunk0, f_chunks;                // wgrad_fold_kernel: this entry's first 1024-element chunk and chunk count); nullptr: fp32 atomics into dw
+    const float* sx;                       // 8-bit operands (wgrad_body8: x e4m3, dy e5m2): device scalars, real = stored * scale; the sums are
+    const float* sdy;                      // multiplied by *sx * *sdy before they leave the workgroup
 };
 
 __device__ __forceinline__ void wg_glds16(const void* gsrc, unsigned lds_dst) {
@@ -244,6 +246,205 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bx, con
             }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same reduction on 8-BIT operands (BASELINE.json configs[4]): x = the e4m3 twin of the layer's input, dy = the e5m2 twin of its output
+// gradient -- the bytes the forward / dgrad convolutions of the same layer multiply (csrc/fp8.hip: per-tensor scales, real = stored * scale).
+// Half the bytes from HBM and through LDS; the MFMA rate is the 16-bit one (v_mfma_f32_16x16x32_fp8_bf8), which these kernels do not reach.
+//   LDS: 16-channel blocks of 16-BYTE pixel rows; one DMA instruction moves 64 pixel rows of one channel block (lane l = row l).
+//   Fragments: ds_read_b64_tr_b8 -- in each 16-lane group lane i supplies the address of 8 contiguous bytes of row i/2 (bytes 8 (i%2) ..) of
+//   an 8-row block and receives column i of those 8 rows (semantics pinned by tools/probe/tr8_probe.hip): ONE read = the 8 k values
+//   (consecutive pixels of channel i) of an MFMA 16x16x32 operand; group g takes pixels 8 g .. 8 g + 7 of the 32-pixel k step for both
+//   operands, so the k order is the same on both sides.
+// Accumulation in fp32 as before; the per-tensor scales multiply the sums once, in the epilogue.
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ long wg_tr8b(const char* lds) {
+    const i32x2 v = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) i32x2*)lds);
+    return ((long)(unsigned)v[1] << 32) | (unsigned)v[0];
+}
+
+template <int TAPS, int ST, int NB = 2>
+__device__ __forceinline__ void wgrad_body8(const WgradArgs& a, const int bx, const int first, const int step) {
+    constexpr int KS = TAPS == 9 ? 3 : 1;
+    constexpr int TH = (TAPS == 9 && ST == 2) ? 4 : 8;
+    constexpr int HP = 16 * ST + (ST == 1 ? 2 : 1);
+    constexpr int HROWS = (TH * ST + (ST == 1 ? 2 : 1)) * HP;
+    constexpr int NPIX = TH * 16;
+    constexpr int KK = NPIX / 32;
+    constexpr int XR = TAPS == 9 ? (HROWS + 63) / 64 * 64 : 128;   // LDS rows (pixels) of the x image per 16-channel block: 192 | 320 | 128
+    constexpr int XI = XR / 64;                            // DMA instructions per channel block (64 rows x 16 B each)
+    constexpr int DYI = NPIX / 64;
+    constexpr int NCB = 2 * NB;
+    constexpr int XBYTES = NCB * XR * 16, DYBYTES = NCB * NPIX * 16, STAGE = XBYTES + DYBYTES;
+    constexpr int XN = (XI * NCB + 3) / 4, DYN = (DYI * NCB + 3) / 4;    // DMA instructions per wave and tile (x | dy)
+    constexpr int NDMA = XN + DYN;
+    static_assert(TAPS == 9 || ST == 1, "1x1: stride 1 only");
+    static_assert(NB == 2 || TAPS == 1, "128 x 128 blocks: 1x1 filters only");
+    static_assert(DYI >= 1 && (DYI * NCB) % 4 == 0, "dy rows: whole DMA instructions per wave");
+
+    extern __shared__ __attribute__((aligned(1024))) char wsm[];      // 2 stages of [x: NCB cb][XR][16 B] [dy: NCB cb][NPIX][16 B]
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)wsm);
+
+    const int ci0 = (bx / a.n_co_blk) * (32 * NB), co0 = (bx % a.n_co_blk) * (32 * NB);
+    const int t = threadIdx.x, l = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+
+    auto issue = [&](int tile, int stage) {
+        const unsigned sb = lds0 + stage * STAGE;
+        int b, y0, x0;
+        if constexpr (TAPS == 9) {
+            int r_ = tile;
+            const int tx = r_ % a.tiles_x; r_ /= a.tiles_x;
+            const int ty = r_ % a.tiles_y;
+            b = r_ / a.tiles_y; y0 = ty * TH; x0 = tx * 16;
+        } else { b = 0; y0 = 0; x0 = 0; }
+#pragma unroll
+        for (int i = 0; i < XN; ++i) {
+            int q = wave + 4 * i;                          // q in [0, NCB*XI): channel block q / XI, row slab q % XI
+            if (q > NCB * XI - 1) q = NCB * XI - 1;         // (surplus instructions re-fetch the last slab: same bytes)
+            const int cb = q / XI, rb = q - cb * XI;
+            const int row = rb * 64 + l;
+            const int ch = ci0 + cb * 16;
+            bool ok = ch < a.Cj;
+            int bb, iy, ix;
+            if constexpr (TAPS == 9) {
+                const int hy = row / HP, hx = row - hy * HP;
+                bb = b; iy = y0 * ST - 1 + hy; ix = x0 * ST - 1 + hx;
+                ok = ok && row < HROWS && (unsigned)iy < (unsigned)(a.H * ST) && (unsigned)ix < (unsigned)(a.W * ST);
+            } else {
+                const int m = tile * 128 + row;
+                ok = ok && m < a.M;
+                bb = m / (a.H * a.W);
+                const int rem = m - bb * (a.H * a.W);
+                iy = rem / a.W; ix = rem - iy * a.W;
+            }
+            const long pix = ((long)bb * a.x_H + (iy >> a.x_ups)) * a.x_W + (ix >> a.x_ups);
+            const char* src = a.x + (pix * a.x_cs + a.x_co + ch);
+            wg_glds16(ok ? (const void*)src : (const void*)wg_zero16, sb + (cb * XR + rb * 64) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < DYN; ++i) {
+            const int q = wave + 4 * i;                    // q in [0, NCB*DYI)
+            const int cb = q / DYI, rb = q - cb * DYI;
+            const int row = rb * 64 + l;
+            const int ch = co0 + cb * 16;
+            bool ok = ch < a.Cout_pad;
+            long pix;
+            if constexpr (TAPS == 9) {
+                const int oy = y0 + (row >> 4), ox = x0 + (row & 15);
+                ok = ok && oy < a.H && ox < a.W;
+                pix = ((long)b * a.H + oy) * a.W + ox;
+            } else {
+                pix = (long)tile * 128 + row;
+                ok = ok && pix < a.M;
+            }
+            const char* src = a.dy + (pix * a.dy_cs + a.dy_co + ch);
+            wg_glds16(ok ? (const void*)src : (const void*)wg_zero16, sb + XBYTES + (cb * NPIX + rb * 64) * 16);
+        }
+    };
+
+    // ---- fragment read addressing: lane i of group g addresses row (pixel) 8 g + i/2 of the 32-pixel k step, bytes 8 (i%2) .. of its 16
+    const int li = l & 15, g = l >> 4;
+    const int k32 = g * 8 + (li >> 1);
+    int xoff, yoff;
+    if constexpr (TAPS == 9) xoff = (((k32 >> 4) * ST * HP) + (k32 & 15) * ST) * 16 + (li & 1) * 8;
+    else xoff = k32 * 16 + (li & 1) * 8;
+    yoff = k32 * 16 + (li & 1) * 8;
+    const int wci = wave & 1, wco = wave >> 1;
+
+    f32x4 acc[TAPS][NB][NB];
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+        for (int fa = 0; fa < NB; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < NB; ++fb) acc[tp][fa][fb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (first < a.ntiles) issue(first, 0);
+    int it = 0;
+    for (int tile = first; tile < a.ntiles; tile += step, ++it) {
+        const bool more = tile + step < a.ntiles;
+        if (more) issue(tile + step, (it + 1) & 1);
+        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const char* xs = wsm + (it & 1) * STAGE;
+        const char* ys = xs + XBYTES;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            long yf[NB];
+#pragma unroll
+            for (int fb = 0; fb < NB; ++fb) yf[fb] = wg_tr8b(ys + ((wco * NB + fb) * NPIX + kk * 32) * 16 + yoff);
+#pragma unroll
+            for (int tp = 0; tp < TAPS; ++tp) {
+                const int r = tp / KS, s = tp - r * KS;
+                long xf[NB];
+#pragma unroll
+                for (int fa = 0; fa < NB; ++fa)
+                    xf[fa] = wg_tr8b(xs + (wci * NB + fa) * XR * 16 + (TAPS == 9 ? (kk * 2 * ST * HP + r * HP + s) * 16 : kk * 32 * 16) + xoff);
+#pragma unroll
+                for (int fa = 0; fa < NB; ++fa)
+#pragma unroll
+                    for (int fb = 0; fb < NB; ++fb) acc[tp][fa][fb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(xf[fa], yf[fb], acc[tp][fa][fb], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    const float sc = a.sx[0] * a.sdy[0];
+    if (a.part != nullptr) {
+        float* slab = a.part + (size_t)first * a.Cj * TAPS * a.Cout_pad;
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+            for (int fa = 0; fa < NB; ++fa)
+#pragma unroll
+                for (int fb = 0; fb < NB; ++fb) {
+                    const int co = co0 + (wco * NB + fb) * 16 + li;
+                    if (co >= a.Cout_pad) continue;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int ci = ci0 + (wci * NB + fa) * 16 + 4 * g + jj;
+                        if (ci < a.Cj) slab[((size_t)ci * TAPS + tp) * a.Cout_pad + co] = acc[tp][fa][fb][jj] * sc;
+                    }
+                }
+        return;
+    }
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+        for (int fa = 0; fa < NB; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < NB; ++fb) {
+                const int co = co0 + (wco * NB + fb) * 16 + li;
+                if (co >= a.Cout_pad) continue;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int ci = ci0 + (wci * NB + fa) * 16 + 4 * g + jj;
+                    if (ci < a.Cj && !a.skip_store) atomicAdd(a.dw + ((size_t)ci * TAPS + tp) * a.Cout_pad + co, acc[tp][fa][fb][jj] * sc);
+                }
+            }
+}
+
+template <int TAPS, int ST, int NB = 2>
+__global__ __launch_bounds__(256) void wgrad8_kernel(const WgradArgs a) {
+    wgrad_body8<TAPS, ST, NB>(a, blockIdx.x, blockIdx.y, gridDim.y);
+}
+
+template <int TAPS, int ST, int NB = 2>
+__global__ __launch_bounds__(256) void wgrad8_group_kernel(const WgradArgs* __restrict__ table, int n_entries) {
+    const int bid = blockIdx.x;
+    int e = 0;
+    for (int lo = 0, hi = n_entries - 1; lo <= hi;) {
+        const int mid = (lo + hi) >> 1;
+        if (table[mid].g_blk0 <= bid) { e = mid; lo = mid + 1; } else hi = mid - 1;
+    }
+    const WgradArgs a = table[e];
+    const int local = bid - a.g_blk0;
+    wgrad_body8<TAPS, ST, NB>(a, local % a.g_nblk, local / a.g_nblk, a.g_split);
+}
+
 template <int DT, int TAPS, int ST, int NB = 2>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     wgrad_body<DT, TAPS, ST, NB>(a, blockIdx.x, blockIdx.y, gridDim.y);
@@ -307,6 +508,30 @@ hipError_t launch_wgrad(const WgradArgs& a, dim3 grid, hipStream_t st) {
     if (hipError_t e = yp_set_max_lds(attr, (const void*)kern, (int)lds); e != hipSuccess) return e;
     kern<<<grid, 256, lds, st>>>(a);
     return hipGetLastError();
+}
+
+template <int TAPS, int ST, int NB = 2>
+constexpr size_t wgrad8_lds() {
+    constexpr int TH = (TAPS == 9 && ST == 2) ? 4 : 8;
+    constexpr int HP = 16 * ST + (ST == 1 ? 2 : 1);
+    constexpr int HROWS = (TH * ST + (ST == 1 ? 2 : 1)) * HP;
+    constexpr int XR = TAPS == 9 ? (HROWS + 63) / 64 * 64 : 128;
+    return (size_t)2 * (2 * NB * XR * 16 + 2 * NB * TH * 16 * 16);
+}
+
+template <int TAPS, int ST, int NB = 2>
+hipError_t launch_wgrad8(const WgradArgs& a, dim3 grid, hipStream_t st) {
+    constexpr size_t lds = wgrad8_lds<TAPS, ST, NB>();
+    auto kern = wgrad8_kernel<TAPS, ST, NB>;
+    static YpLdsAttr attr;        // per instantiation, per device
+    if (hipError_t e = yp_set_max_lds(attr, (const void*)kern, (int)lds); e != hipSuccess) return e;
+    kern<<<grid, 256, lds, st>>>(a);
+    return hipGetLastError();
+}
+
+static hipError_t dispatch_wgrad8(int k, int stride, const WgradArgs& a, dim3 grid, hipStream_t st) {
+    if (k == 1) return a.blk == 128 ? launch_wgrad8<1, 1, 4>(a, grid, st) : launch_wgrad8<1, 1>(a, grid, st);
+    return stride == 2 ? launch_wgrad8<9, 2>(a, grid, st) : launch_wgrad8<9, 1>(a, grid, st);
 }
 
 template <int DT>
@@ -500,7 +725,10 @@ static int wgrad_make_args(YpView x, YpView dy, int dtype, int B, int k, int str
                            int block = 0) {
     YP_REQUIRE(block == 0 || block == 64 || (block == 128 && k == 1), "yp_conv_wgrad: block is 64, or 128 for 1x1 filters");
     const int blk = block == 0 ? (wgrad_big_ok(x, dy, B, k) ? 128 : 64) : block;
-    YP_REQUIRE(dtype == YP_F16 || dtype == YP_BF16, "yp_conv_wgrad: 16-bit element types only");
+    const bool q8 = dtype == YP_FP8;        // x = e4m3 bytes, dy = e5m2 bytes (the twins of csrc/fp8.hip)
+    YP_REQUIRE(dtype == YP_F16 || dtype == YP_BF16 || q8, "yp_conv_wgrad: 16-bit element types, or YP_FP8 (x e4m3, dy e5m2)");
+    YP_REQUIRE(!q8 || (x.C % 16 == 0 && x.cstride % 16 == 0 && x.coff % 16 == 0 && dy.C % 16 == 0 && dy.cstride % 16 == 0 && dy.coff % 16 == 0),
+               "yp_conv_wgrad: 8-bit views must be 16-channel aligned");
     YP_REQUIRE((k == 1 && stride == 1) || (k == 3 && (stride == 1 || stride == 2)), "yp_conv_wgrad: 1x1 (stride 1) or 3x3 (pad 1, stride 1 | 2) filters only");
     YP_REQUIRE(x.ptr && dy.ptr && dw && B > 0, "yp_conv_wgrad: null buffer");
     YP_REQUIRE(x.C > 0 && x.C % 8 == 0 && x.cstride % 8 == 0 && x.coff % 8 == 0 && dy.C > 0 && dy.C % 8 == 0 && dy.cstride % 8 == 0 && dy.coff % 8 == 0,
@@ -549,6 +777,18 @@ extern "C" int yp_conv_wgrad(YpView x, YpView dy, int dtype, int B, int k, int s
     return YP_OK;
 }
 
+// 8-bit operands: x = e4m3 twin, dy = e5m2 twin of the same logical views, sx / sdy their per-tensor scales (device scalars)
+extern "C" int yp_conv_wgrad_q8(YpView x8, YpView dy8, const float* sx, const float* sdy, int B, int k, int stride, float* dw, void* stream) {
+    YP_REQUIRE(sx != nullptr && sdy != nullptr, "yp_conv_wgrad_q8: null scale");
+    WgradArgs a;
+    int nblk, split;
+    if (int rc = wgrad_make_args(x8, dy8, YP_FP8, B, k, stride, dw, &a, &nblk, &split)) return rc;
+    a.sx = sx; a.sdy = sdy;
+    const hipError_t e = dispatch_wgrad8(k, stride, a, dim3(nblk, split), (hipStream_t)stream);
+    if (e != hipSuccess) { yp_set_error("yp_conv_wgrad_q8: launch failed: %s", hipGetErrorString(e)); return YP_ERR_HIP; }
+    return YP_OK;
+}
+
 extern "C" size_t yp_wgrad_group_entry_bytes(void) { return sizeof(WgradArgs); }
 
 extern "C" int yp_wgrad_group_pack(const YpView* xs, const YpView* dys, float* const* dws, int n, int dtype, int B, int k, int stride, int block, void* table_host,
@@ -590,6 +830,29 @@ extern "C" int yp_wgrad_group_pack_det(const YpView* xs, const YpView* dys, floa
     return YP_OK;
 }
 
+// The grouped table for 8-bit entries: yp_wgrad_group_pack_det with dtype = YP_FP8 plus one (sx, sdy) pair of device scalars per entry
+extern "C" int yp_wgrad_group_pack_q8(const YpView* xs, const YpView* dys, float* const* dws, float* const* parts, const float* const* sx, const float* const* sdy,
+                                      int n, int B, int k, int stride, int block, void* table_host, int* total_blocks, int* fold_chunks) {
+    YP_REQUIRE(sx != nullptr && sdy != nullptr, "yp_wgrad_group_pack_q8: null scale tables");
+    if (int rc = yp_wgrad_group_pack_det(xs, dys, dws, parts, n, YP_FP8, B, k, stride, block, table_host, total_blocks, fold_chunks)) return rc;
+    WgradArgs* t = (WgradArgs*)table_host;
+    for (int i = 0; i < n; ++i) {
+        YP_REQUIRE(sx[i] != nullptr && sdy[i] != nullptr, "yp_wgrad_group_pack_q8: null scale of entry %d", i);
+        t[i].sx = sx[i]; t[i].sdy = sdy[i];
+    }
+    return YP_OK;
+}
+
+template <int TAPS, int ST, int NB = 2>
+static hipError_t launch_wgrad8_group(const WgradArgs* table, int n, int blocks, hipStream_t st) {
+    constexpr size_t lds = wgrad8_lds<TAPS, ST, NB>();
+    auto kern = wgrad8_group_kernel<TAPS, ST, NB>;
+    static YpLdsAttr attr;        // per instantiation, per device
+    if (hipError_t e = yp_set_max_lds(attr, (const void*)kern, (int)lds); e != hipSuccess) return e;
+    kern<<<blocks, 256, lds, st>>>(table, n);
+    return hipGetLastError();
+}
+
 template <int DT, int TAPS, int ST, int NB = 2>
 static hipError_t launch_wgrad_group(const WgradArgs* table, int n, int blocks, hipStream_t st) {
     constexpr int TH = (TAPS == 9 && ST == 2) ? 4 : 8;
@@ -609,14 +872,17 @@ extern "C" int yp_wgrad_group_run(const void* table_dev, int n, int total_blocks
 }
 
 extern "C" int yp_wgrad_group_run_det(const void* table_dev, int n, int total_blocks, int fold_chunks, int dtype, int k, int stride, int block, void* stream) {
-    YP_REQUIRE(table_dev && n > 0 && total_blocks > 0 && fold_chunks >= 0 && (dtype == YP_F16 || dtype == YP_BF16), "yp_wgrad_group_run: bad arguments");
+    YP_REQUIRE(table_dev && n > 0 && total_blocks > 0 && fold_chunks >= 0 && (dtype == YP_F16 || dtype == YP_BF16 || dtype == YP_FP8), "yp_wgrad_group_run: bad arguments");
     YP_REQUIRE(block == 64 || (block == 128 && k == 1), "yp_wgrad_group_run: block is 64, or 128 for 1x1 filters");
     YP_REQUIRE((k == 1 && stride == 1) || (k == 3 && (stride == 1 || stride == 2)), "yp_wgrad_group_run: 1x1 (stride 1) or 3x3 (stride 1 | 2)");
     const WgradArgs* t = (const WgradArgs*)table_dev;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e;
 #define YP_G(DT) (k == 1 ? (block == 128 ? launch_wgrad_group<DT, 1, 1, 4>(t, n, total_blocks, st) : launch_wgrad_group<DT, 1, 1>(t, n, total_blocks, st)) : (stride == 2 ? launch_wgrad_group<DT, 9, 2>(t, n, total_blocks, st) : launch_wgrad_group<DT, 9, 1>(t, n, total_blocks, st)))
-    e = dtype == YP_F16 ? YP_G(YP_F16) : YP_G(YP_BF16);
+    if (dtype == YP_FP8)
+        e = k == 1 ? (block == 128 ? launch_wgrad8_group<1, 1, 4>(t, n, total_blocks, st) : launch_wgrad8_group<1, 1>(t, n, total_blocks, st))
+                   : (stride == 2 ? launch_wgrad8_group<9, 2>(t, n, total_blocks, st) : launch_wgrad8_group<9, 1>(t, n, total_blocks, st));
+    else e = dtype == YP_F16 ? YP_G(YP_F16) : YP_G(YP_BF16);
 #undef YP_G
     if (e != hipSuccess) { yp_set_error("yp_wgrad_group_run: launch failed: %s", hipGetErrorString(e)); return YP_ERR_HIP; }
     if (fold_chunks > 0) {           // deterministic mode: sum the slices' slabs in order
