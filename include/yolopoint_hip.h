@@ -563,7 +563,7 @@ enum {
     YP_OP_SUM_SLABS = 32,     /* p0=slabs p1=dst; n0=elements per slab (multiple of 4) n1=slabs: dst = slab0 + slab1 + ... in order */
     YP_OP_QUANT_FP8 = 34,     /* v0=src (16-bit) v1=dst (1-byte); i0=src dtype i1=B i2=format (0 e4m3 | 1 e5m2); p0=scale p1=amax: yp_quantize_fp8 */
     YP_OP_STEM_WGRAD = 33,    /* v0=image v1=dy; i0=dtype i1=B; p0=slabs p1=dw */
-    YP_OP_WGRAD_GROUP = 31,   /* p0=device table (yp_wgrad_group_pack[_det]); i0=dtype i1=entries i2=total blocks i3=k i4=stride i5=fold chunks (0: atomics) i6=block (0 = 64) */
+    YP_OP_WGRAD_GROUP = 31,   /* p0=device table (yp_wgrad_group_pack[_det | _q8]); i0=dtype (YP_FP8: 8-bit entries) i1=entries i2=total blocks i3=k i4=stride i5=fold chunks (0: atomics) i6=block (0 = 64) */
     YP_OP_PACK_WEIGHT = 26    /* f0=w f1=bias; g0=bias_dst; p0=dst; i0=dtype i1=Cout i2=Cin i3=R i4=S i5=c0 i6=Cj i7=mode; n0=Kpad n1=Npad | Cout_pad<<32 */
 };
 typedef struct YpOpArgs {

@@ -312,7 +312,7 @@ class _FakeQuantTraining:
     """The oracle with the product's 8-bit rule stated in PyTorch autograd (BASELINE.json configs[4] has no reference implementation; the
     rule is csrc/fp8.hip's): every Conv block whose input channels are a multiple of 64 multiplies e4m3(x) by e4m3(w) (per-tensor scale
     amax / 448); its input gradient is conv_transpose(e5m2(dy), e4m3(w)) (scale amax / 57344) when the OUTPUT channels are a multiple of 64;
-    weight gradients use the unquantised x and dy.  `storage`: None (fp32 between layers) or torch.bfloat16 (the product's storage: each
+    its weight gradient multiplies the same e4m3(x) and e5m2(dy) where both conditions hold (1x1 / 3x3 filters), the 16-bit x and dy elsewhere.  `storage`: None (fp32 between layers) or torch.bfloat16 (the product's storage: each
     convolution's input, output and both gradients rounded to bf16) -- the distance between the two is the resolution of an end-to-end
     comparison, exactly as the 16-bit floor of tests/test_gpu_bench_shapes.py."""
 
@@ -334,16 +334,17 @@ class _FakeQuantTraining:
                 q_fwd, q_bwd = quant and x.shape[1] % 64 == 0, quant and w.shape[0] % 64 == 0
                 wq = q4(w) if (q_fwd or q_bwd) else rnd(w)
                 ctx.save_for_backward(xs, wq if q_bwd else rnd(w))
-                ctx.cfg = (stride, pad, q_bwd, tuple(w.shape))
+                ctx.cfg = (stride, pad, q_bwd, tuple(w.shape), q_fwd and q_bwd and tuple(w.shape[2:]) in ((1, 1), (3, 3)))
                 return rnd(F0.conv2d(q4(xs) if q_fwd else xs, wq if q_fwd else rnd(w), None, stride, pad))
 
             @staticmethod
             def backward(ctx, dy):
                 xs, wb = ctx.saved_tensors
-                stride, pad, q_bwd, wshape = ctx.cfg
+                stride, pad, q_bwd, wshape, q_w = ctx.cfg
                 dys = rnd(dy)
                 dx = torch.nn.grad.conv2d_input(xs.shape, wb, q5(dys) if q_bwd else dys, stride, pad)
-                dw = torch.nn.grad.conv2d_weight(xs, wshape, dys, stride, pad)
+                # weight gradient: the same two 8-bit tensors (e4m3 input x e5m2 output gradient) where the layer has both, 16-bit operands elsewhere
+                dw = torch.nn.grad.conv2d_weight(q4(xs) if q_w else xs, wshape, q5(dys) if q_w else dys, stride, pad)
                 return rnd(dx), dw, None, None, None
 
         class Shim:
@@ -373,7 +374,7 @@ FP8_GRAD = dict(median=1.15, p90=1.15, worst=1.25, worst_abs=0.05, cosine_stable
 
 
 def _fp8_gradient_check(cuda, version, B, S, seed, min_q8, min_stable):
-    """All parameter gradients of YOLOPoint-<version> with fp8 Conv operands (forward e4m3 x e4m3, dgrad e5m2 x e4m3, 16-bit weight gradients)
+    """All parameter gradients of YOLOPoint-<version> with fp8 Conv operands (forward e4m3 x e4m3, dgrad e5m2 x e4m3, weight gradients e4m3 x e5m2)
     against PyTorch autograd through the oracle with the same rule (_FakeQuantTraining).  e4m3 / e5m2 rounding is discontinuous, so two
     PyTorch statements of the same network that differ only by bf16 storage between layers already end far apart; that distance is the
     floor, and the product -- which IS the bf16-storage variant -- must sit within 1.15x of it on the median and the 90th percentile of

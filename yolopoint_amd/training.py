@@ -64,6 +64,7 @@ class TrainGraph:
             self.fwd.fp8 = self.pack["pb"].fp8 = self.pack["fp8"]
         self.twins = {}            # fp8 mode: (address of a 16-bit activation buffer, format) -> its 1-byte twin Buf
         self.n_q8 = 0              # convolutions emitted with 8-bit operands
+        self.n_q8w = 0             # weight gradients emitted with 8-bit operands
         self.tape = []             # (branch, emitter): 'kp' feeds the keypoint / descriptor heads, 'yolo' only the Detect head
         self.branch = "kp"
         self.tape_tag = None       # 'kph': entries of the keypoint head (pair mode: their backward runs beside the YOLO-branch plan)
@@ -259,11 +260,13 @@ class TrainGraph:
             partial = torch.zeros((rows, 2, round_up(conv.out_channels, 8)), dtype=torch.float32, device=self.device)
         q8 = self.fp8 and not image and self.q8_ok(srcs) and os.environ.get("YP_FP8_FWD", "1") != "0"
         conv_srcs, extra = srcs, (dict(bn_partial=partial, stat_group_px=(self.Bs * Ho_ * Wo_ if G > 1 else None)) if fuse_stats else {})
+        x8 = None
         if q8:
             conv_srcs, slot = self.q8_sources(f, srcs, 0)
             wsrc = MasterWeight(conv.weight, q8=True)
             extra["q8"] = dict(dtype=_hip.YP_FP8, slot=slot)
             self.n_q8 += 1
+            x8 = (conv_srcs, slot)           # the e4m3 twins of the sources + their scale slot: the weight gradient's operand as well
         raw = f.conv(conv_srcs, wsrc, None, k, s, p, _hip.YP_ACT_NONE, extra=extra or None)
         if fuse_stats:
             partial.zero_()          # (the autotuner ran several kernel variants, which write different row sets: start from zeros with the chosen one)
@@ -330,7 +333,7 @@ class TrainGraph:
                      i=[code, B, act, 0, self.bG] + rs["i567"], f=[mean, invstd, gamma, beta], g=[dg, db, tw[1], tw[2]], p=[self.ws, rs["p1"]], n=[self.ws.numel()])
             if padded:
                 self.collect.append(lambda dg=dg, db=db, gw_=gw_, gb_=gb_: (gw_.copy_(dg[:Cc]), gb_.copy_(db[:Cc])))
-            self.conv_backward(srcs, conv.weight, None, draw, k, s, p)
+            self.conv_backward(srcs, conv.weight, None, draw, k, s, p, x8=x8)
         self.tape.append((self.branch, backward, self.tape_tag))
         return out
 
@@ -351,8 +354,9 @@ class TrainGraph:
         self.tape.append((self.branch, backward, self.tape_tag))
         return out
 
-    def conv_backward(self, srcs, weight, bias, draw, k, s, p):
-        """Emit wgrad (+ bias grad) and dgrad of a convolution whose output gradient is `draw` [B,Ho,Wo,Cout_pad]."""
+    def conv_backward(self, srcs, weight, bias, draw, k, s, p, x8=None):
+        """Emit wgrad (+ bias grad) and dgrad of a convolution whose output gradient is `draw` [B,Ho,Wo,Cout_pad].
+        x8 (fp8 mode): (e4m3 twin views of `srcs`, their scale slot) as the forward convolution read them."""
         b, code = self.bwd, self.code
         B = b.B
         Bpad = round_up(B, 8)
@@ -376,8 +380,16 @@ class TrainGraph:
         direct = code != _hip.YP_F32 and p == k // 2 and ((k == 1 and s == 1) or (k == 3 and s in (1, 2)))
         dyp = None
         dq = None
+        # fp8 mode: the e5m2 copy of the output gradient (one per convolution: the operand of its sources' dgrads AND of its weight gradients)
+        q8_dy = (self.fp8 and bias is None and draw.buf.t.dtype == torch.bfloat16 and self.q8_ok([draw]) and os.environ.get("YP_FP8_DGRAD", "1") != "0")
+        if q8_dy and all(src.C % 8 == 0 and not (src.geom is None and src.cstride == 4 and src.C == 4) for src in srcs):
+            dq = self.q8_sources(b, [draw], 1)
+        # 8-bit weight gradients (csrc/wgrad.hip::wgrad_body8): x = the e4m3 twin the forward convolution multiplied, dy = the e5m2 twin the dgrad
+        # multiplies -- half the bytes of the 16-bit operands; the layers where both twins exist (all channel counts multiples of 64)
+        q8_w = (x8 is not None and dq is not None and direct and self.group_wgrad and os.environ.get("YP_FP8_WGRAD", "1") != "0"
+                and all(v.C % 16 == 0 and v.coff % 16 == 0 and v.cstride % 16 == 0 for v in x8[0]))
         c0 = 0
-        for src in srcs:
+        for j, src in enumerate(srcs):
             image = src.geom is None and src.cstride == 4 and src.C == 4
             Cj = src.C
             Hi, Wi = src.LH, src.LW
@@ -389,7 +401,14 @@ class TrainGraph:
                 # nothing in the rest of the backward reads dW or overwrites x / dy: the weight gradients of a filter class are
                 # collected and run as ONE grouped launch at the end of the pass (emit())
                 # (a class = filter size, stride and the workgroup block size the entry runs with: one kernel instantiation per launch)
-                self.wgroups.setdefault((k, s, lib().yp_wgrad_block(src.c(), draw.c(), B, k), B), []).append((src, draw, dwb, 2 * B * Ho * Wo * Cj * k * k * Cout))
+                if q8_w:
+                    st8 = b.fp8
+                    self.wgroups.setdefault((k, s, lib().yp_wgrad_block(src.c(), draw.c(), B, k), B, True), []).append(
+                        (x8[0][j], dq[0][0], dwb, 2 * B * Ho * Wo * Cj * k * k * Cout, st8.scale_ptr(x8[1]), st8.scale_ptr(dq[1])))
+                    self.n_q8w += 1
+                else:
+                    self.wgroups.setdefault((k, s, lib().yp_wgrad_block(src.c(), draw.c(), B, k), B, False), []).append(
+                        (src, draw, dwb, 2 * B * Ho * Wo * Cj * k * k * Cout))
             elif image and code != _hip.YP_F32 and (k, s, p) == (6, 2, 2) and Cout_pad <= 80 and os.environ.get("YP_STEM_WGRAD", "1") != "0":
                 # the stem: its own kernel over the packed image (no pixel-major copies of the two largest tensors of the pass)
                 nsl = lib().yp_stem_wgrad_slabs(B, Hi, Wi)
@@ -434,8 +453,7 @@ class TrainGraph:
                 cs, ce_ = c0, c0 + Cj
 
                 # dgrad = convolution with the flipped, channel-transposed filter [Cj, Cout_pad, k, k], packed on the device
-                q8 = (self.fp8 and bias is None and draw.buf.t.dtype == torch.bfloat16 and self.q8_ok([draw]) and Cj % 8 == 0
-                      and os.environ.get("YP_FP8_DGRAD", "1") != "0")
+                q8 = q8_dy and Cj % 8 == 0
                 w_dgrad = MasterWeight(weight, mode=1, c0=cs, cj=Cj, cout_pad=Cout_pad, q8=q8)
                 dsrc, dextra = draw, {}
                 if q8:      # e5m2 copy of the output gradient (one per convolution, shared by its sources' dgrads) x e4m3 filter
@@ -735,31 +753,37 @@ class TrainGraph:
                 if branch in branches and tag not in skip:
                     fn()
             joined = side is None
-            for (gk, gs, gblk, gB), ents in sorted(self.wgroups.items()):
+            for (gk, gs, gblk, gB, g8), ents in sorted(self.wgroups.items()):
                 n = len(ents)
+                gcode = _hip.YP_FP8 if g8 else code       # (8-bit entries: x / dy are the 1-byte twins, e[4] / e[5] their scale pointers)
                 xs, dys = (_hip.YpView * n)(*[e[0].c() for e in ents]), (_hip.YpView * n)(*[e[1].c() for e in ents])
                 dws = (C.c_void_p * n)(*[e[2].flat.data_ptr() for e in ents])
                 host = (C.c_char * (n * lib().yp_wgrad_group_entry_bytes()))()
                 blocks, fold = C.c_int(0), C.c_int(0)
+                parts = None
                 if self.det_wgrad:
                     # deterministic reduction: every pixel slice of an entry writes its own slab, a second launch sums them in order.
                     # The slab arena is shared by the filter classes of all backward plans of this graph (they run one after another).
-                    sizes = [round_up(lib().yp_wgrad_partial_elems(e[0].c(), e[1].c(), code, gB, gk, gs, gblk), 64) for e in ents]
+                    sizes = [round_up(lib().yp_wgrad_partial_elems(e[0].c(), e[1].c(), gcode, gB, gk, gs, gblk), 64) for e in ents]
                     if self.wpart is None:      # sized by the largest filter class of the FULL backward (emitted first; the keypoint-only plan is a subset)
-                        self.wpart = torch.empty(max(sum(round_up(lib().yp_wgrad_partial_elems(e[0].c(), e[1].c(), code, B_, k_, s_, b_), 64) for e in es)
-                                                     for (k_, s_, b_, B_), es in self.wgroups.items()), dtype=torch.float32, device=self.device)
+                        self.wpart = torch.empty(max(sum(round_up(lib().yp_wgrad_partial_elems(e[0].c(), e[1].c(), _hip.YP_FP8 if q_ else code, B_, k_, s_, b_), 64)
+                                                         for e in es) for (k_, s_, b_, B_, q_), es in self.wgroups.items()), dtype=torch.float32, device=self.device)
                         self.keep.append(self.wpart)
                     assert sum(sizes) <= self.wpart.numel()
                     offs = [sum(sizes[:i]) for i in range(n)]
                     parts = (C.c_void_p * n)(*[self.wpart.data_ptr() + 4 * o for o in offs])
+                if g8:
+                    sxs, sdys = (C.c_void_p * n)(*[e[4] for e in ents]), (C.c_void_p * n)(*[e[5] for e in ents])
+                    check(lib().yp_wgrad_group_pack_q8(xs, dys, dws, parts, sxs, sdys, n, gB, gk, gs, gblk, host, C.byref(blocks), C.byref(fold) if parts is not None else None))
+                elif self.det_wgrad:
                     check(lib().yp_wgrad_group_pack_det(xs, dys, dws, parts, n, code, gB, gk, gs, gblk, host, C.byref(blocks), C.byref(fold)))
                 else:
                     check(lib().yp_wgrad_group_pack(xs, dys, dws, n, code, gB, gk, gs, gblk, host, C.byref(blocks)))
                 wtab = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(self.device)
                 self.keep.append(wtab)
                 bb.op(_hip.OP_WGRAD_GROUP, [v for e in ents for v in e[:2]], [e[2].view() for e in ents] + ([self.T(self.wpart)] if self.det_wgrad else []),
-                      f"wgrad_k{gk}s{gs}" + ("b128" if gblk == 128 else ""), p=[wtab],
-                      i=[code, n, blocks.value, gk, gs, fold.value, gblk])
+                      f"wgrad_k{gk}s{gs}" + ("b128" if gblk == 128 else "") + ("q8" if g8 else ""), p=[wtab],
+                      i=[gcode, n, blocks.value, gk, gs, fold.value, gblk])
                 bb.records[-1].kind, bb.records[-1].flops = "conv", sum(e[3] for e in ents)
                 if not joined:            # the grouped launches read the side lane's output gradients
                     bb.set_lane(_hip.LANE_JOIN)
