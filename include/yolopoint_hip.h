@@ -670,6 +670,10 @@ int yp_plan_add_detect_decode(YpPlan* plan, YpView raw, int B, int na, int no, f
                               int rows_total, int row_offset);
 int yp_plan_add_op(YpPlan* plan, const YpOpArgs* a);
 int yp_plan_num_ops(const YpPlan* plan);
+/* Replace view `slot` (0..3) of generic op `op` (added with yp_plan_add_op) before yp_plan_instantiate_graph.  Used by the training graph to clear
+ * the 16-bit output view of a BatchNorm op (YP_OP_BN_APPLY v[1], YP_OP_BN_BWD v[2]) whose readers all take the 1-byte twin: with a NULL 16-bit
+ * view and a twin, yp_bn_act_apply_grouped_q8 / yp_bn_act_bwd_grouped_q8 store the twin only. */
+int yp_plan_patch_op_view(YpPlan* plan, int op, int slot, YpView v);
 /* true data dependencies of op `op`: the earlier ops it must wait for.  When every op has a
  * dependency list, yp_plan_instantiate_graph replaces the captured chain's edges by these, so
  * independent branches run concurrently.  Eager yp_plan_run ignores them (single stream order). */

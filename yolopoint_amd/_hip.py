@@ -170,6 +170,7 @@ SIGNATURES = {
     "yp_plan_add_l2norm": (_i, [_p, YpView, YpView, _i, _i]),
     "yp_plan_add_detect_decode": (_i, [_p, YpView, _i, _i, _i, _f, C.POINTER(_f), _p, _p, _i, _i]),
     "yp_plan_num_ops": (_i, [_p]),
+    "yp_plan_patch_op_view": (_i, [_p, _i, _i, YpView]),
     "yp_plan_set_deps": (_i, [_p, _i, C.POINTER(_i), _i]),
     "yp_plan_graph_is_parallel": (_i, [_p]),
     "yp_plan_instantiate_graph": (_i, [_p, _p]),

@@ -182,6 +182,16 @@ extern "C" int yp_plan_add_callback(YpPlan* plan, yp_plan_callback_t fn, void* u
 
 extern "C" int yp_plan_num_ops(const YpPlan* plan) { return plan ? (int)plan->ops.size() : 0; }
 
+// Replace view `slot` of generic op `op` (yp_plan_add_op) before the plan is instantiated: a builder that learns only AFTER it has emitted an op
+// that one of its outputs has no reader (fp8 training: the 16-bit copy of a BatchNorm output all of whose consumers read the 1-byte twin)
+// clears that view's pointer.
+extern "C" int yp_plan_patch_op_view(YpPlan* plan, int op, int slot, YpView v) {
+    YP_PLAN_MUTABLE(plan);
+    YP_REQUIRE(op >= 0 && op < (int)plan->ops.size() && slot >= 0 && slot < 4 && plan->ops[op].kind == OP_GENERIC, "yp_plan_patch_op_view: op %d / view %d is not a view of a generic op", op, slot);
+    plan->ops[op].gen.v[slot] = v;
+    return YP_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Streams that really run beside the caller's.  The runtime multiplexes all HIP streams of a process onto a handful of hardware queues
 // (four by default); two streams that land on the same queue execute strictly one after the other, and which queue a stream gets depends

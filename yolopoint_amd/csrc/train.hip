@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void bn_rows_fast_kernel(const char* __restric
     {
         const size_t roff = (size_t)blockIdx.y * M;
         raw += roff * rcs * esize<DT>();
-        out += roff * ocs * esize<DT>();
+        if (out != nullptr) out += roff * ocs * esize<DT>();      // (out == nullptr: only the 1-byte twin is written -- no 16-bit reader)
         if (dy != nullptr) dy += roff * dcs * esize<DT>();
         if (res != nullptr) res += roff * scs * esize<DT>();
         if (q8 != nullptr) q8 += roff * qcs;
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void bn_rows_fast_kernel(const char* __restric
                 o[j] = z + g[j];
             }
         }
-        store8<DT>(out, r * ocs + oco + ch * 8, o);
+        if (out != nullptr) store8<DT>(out, r * ocs + oco + ch * 8, o);
         if constexpr (BWD) {
             if (gsum != nullptr) {
                 float a8[8];
@@ -822,14 +822,17 @@ extern "C" int yp_bn_act_apply_grouped(YpView raw, YpView out, YpView res, int d
 extern "C" int yp_bn_act_apply_grouped_q8(YpView raw, YpView out, YpView res, int dtype, int B, int groups, const float* mean, const float* invstd,
                                           const float* gamma, const float* beta, int act, YpView q8, const float* q_scale, float* q_amax, void* stream) {
     if (int rc = check_view8(raw, "yp_bn_act_apply")) return rc;
-    if (int rc = check_view8(out, "yp_bn_act_apply")) return rc;
-    YP_REQUIRE(out.C == raw.C && (res.C == 0 || res.C == raw.C) && mean && invstd && gamma && beta && groups >= 1 && B % groups == 0, "yp_bn_act_apply: bad arguments");
+    // out.ptr == NULL with a twin: the 16-bit result is not stored at all (fp8 training: every consumer of this tensor reads the 1-byte twin)
+    const bool twin_only = out.ptr == nullptr && q8.ptr != nullptr;
+    if (!twin_only) { if (int rc = check_view8(out, "yp_bn_act_apply")) return rc; }
+    YP_REQUIRE((twin_only || out.C == raw.C) && (res.C == 0 || res.C == raw.C) && mean && invstd && gamma && beta && groups >= 1 && B % groups == 0, "yp_bn_act_apply: bad arguments");
     const size_t M = (size_t)B * raw.H * raw.W, Mg = M / groups;
     hipStream_t st = (hipStream_t)stream;
     const int g = grid_for(M * (raw.C / 8), 256);
     const int lg = fast_lg(raw.C);
     YP_REQUIRE(q8.ptr == nullptr || (lg >= 0 && M < (1ull << 31) && q8.C == raw.C && q8.H == raw.H && q8.W == raw.W && q8.cstride % 8 == 0 && q8.coff % 8 == 0 && q_scale),
                "yp_bn_act_apply: the 1-byte twin needs C/8 a power of two <= 256, a matching view and a scale");
+    YP_REQUIRE(!twin_only || (lg >= 0 && M < (1ull << 31)), "yp_bn_act_apply: a twin-only output needs the fast path");
     if (lg >= 0 && M < (1ull << 31)) {
         const int gf = grid_for((Mg * (raw.C / 8) + 1) / 2, 256, (size_t)(256 * 16) / groups);      // ~2 rows per thread
         YP_DT_SWITCH(dtype, (bn_rows_fast_kernel<DT, false><<<dim3(gf, groups), 256, 0, st>>>((const char*)raw.ptr, raw.cstride, raw.coff, nullptr, 0, 0, (char*)out.ptr, out.cstride,
@@ -872,8 +875,9 @@ static int bn_act_bwd_impl(YpView raw, YpView dy, YpView dx, int dtype, int B, i
                            void* ws, size_t ws_bytes, YpView q8, const float* q_scale, float* q_amax, YpView gsum, int gacc, void* stream) {
     if (int rc = check_view8(raw, "yp_bn_act_bwd")) return rc;
     if (int rc = check_view8(dy, "yp_bn_act_bwd")) return rc;
-    if (int rc = check_view8(dx, "yp_bn_act_bwd")) return rc;
-    YP_REQUIRE(dy.C == raw.C && dx.C == raw.C && mean && invstd && gamma && beta && dgamma && dbeta && ws && raw.C <= 2048 && groups >= 1 && groups <= 8 && B % groups == 0,
+    const bool twin_only = dx.ptr == nullptr && q8.ptr != nullptr;       // (as yp_bn_act_apply: dx only as its 1-byte twin)
+    if (!twin_only) { if (int rc = check_view8(dx, "yp_bn_act_bwd")) return rc; }
+    YP_REQUIRE(dy.C == raw.C && (twin_only || dx.C == raw.C) && mean && invstd && gamma && beta && dgamma && dbeta && ws && raw.C <= 2048 && groups >= 1 && groups <= 8 && B % groups == 0,
                "yp_bn_act_bwd: bad arguments");
     YP_REQUIRE(ws_bytes >= yp_bn_workspace_bytes(B, raw.H, raw.W, raw.C) + 2 * (size_t)groups * raw.C * 4, "yp_bn_act_bwd: workspace too small");
     const size_t M = (size_t)B * raw.H * raw.W, Mg = M / groups;
@@ -886,6 +890,7 @@ static int bn_act_bwd_impl(YpView raw, YpView dy, YpView dx, int dtype, int B, i
     const bool fastp = lg >= 0 && M < (1ull << 31);
     YP_REQUIRE(q8.ptr == nullptr || (fastp && q8.C == raw.C && q8.H == raw.H && q8.W == raw.W && q8.cstride % 8 == 0 && q8.coff % 8 == 0 && q_scale),
                "yp_bn_act_bwd: the 1-byte twin needs C/8 a power of two <= 256, a matching view and a scale");
+    YP_REQUIRE(!twin_only || fastp, "yp_bn_act_bwd: a twin-only output needs the fast path");
     if (fastp) {
         unsigned rpb;
         nbg = fast_reduce_blocks(Mg, lg, &rpb, 2048 / groups);

@@ -32,7 +32,7 @@ import torch
 
 from . import _hip
 from ._hip import lib, check
-from .plan import PlanBuilder, Buf, View, MasterWeight, Fp8State, round_up, pack_input
+from .plan import PlanBuilder, Buf, View, MasterWeight, Fp8State, round_up, pack_input, NULL_VIEW
 from .models.common import weights_generation
 
 
@@ -65,6 +65,9 @@ class TrainGraph:
         self.twins = {}            # fp8 mode: (address of a 16-bit activation buffer, format) -> its 1-byte twin Buf
         self.n_q8 = 0              # convolutions emitted with 8-bit operands
         self.n_q8w = 0             # weight gradients emitted with 8-bit operands
+        self.twin_only = []        # (plan builder, op index, view slot, 16-bit view) of the BatchNorm outputs that also have a 1-byte twin
+        self.builders = []         # every plan builder of this graph (the access lists behind _drop_unread_16bit_copies)
+        self.n_twin_only = 0
         self.tape = []             # (branch, emitter): 'kp' feeds the keypoint / descriptor heads, 'yolo' only the Detect head
         self.branch = "kp"
         self.tape_tag = None       # 'kph': entries of the keypoint head (pair mode: their backward runs beside the YOLO-branch plan)
@@ -306,6 +309,7 @@ class TrainGraph:
         else:
             f.op(_hip.OP_BN_APPLY, [raw, res, self.T(mean), self.T(invstd)], [out, tw[0]], "bn_act", v=[raw, out, res, tw[0]], i=[code, B, act, G],
                  f=[mean, invstd, gamma, beta], g=[None, None, tw[1], tw[2]])
+            self.twin_only.append((f, lib().yp_plan_num_ops(f.handle) - 1, 1, out))       # (see _drop_unread_16bit_copies)
 
         def backward():
             b = self.bwd
@@ -331,6 +335,7 @@ class TrainGraph:
             else:
                 b.op(_hip.OP_BN_BWD, [raw, gy] + rw, [draw, self.T(self.ws), tw[0]] + rw, "bn_act_bwd", v=[raw, gy, draw, tw[0]],
                      i=[code, B, act, 0, self.bG] + rs["i567"], f=[mean, invstd, gamma, beta], g=[dg, db, tw[1], tw[2]], p=[self.ws, rs["p1"]], n=[self.ws.numel()])
+                self.twin_only.append((b, lib().yp_plan_num_ops(b.handle) - 1, 2, draw))
             if padded:
                 self.collect.append(lambda dg=dg, db=db, gw_=gw_, gb_=gb_: (gw_.copy_(dg[:Cc]), gb_.copy_(db[:Cc])))
             self.conv_backward(srcs, conv.weight, None, draw, k, s, p, x8=x8)
@@ -723,6 +728,7 @@ class TrainGraph:
             side = (tag, samples, groups): the tape entries tagged `tag` run on the plan's side lane over their own sample count (pair mode: the
             keypoint head's backward beside the YOLO-branch chain); skip: tags left to another plan."""
             self.bwd = bb = PlanBuilder(B, code, self.device)
+            self.builders.append(bb)
             bb.fp8 = self.fwd.fp8
             self.bG = groups
             bb.pack_target = self.fwd.pack_target
@@ -817,6 +823,7 @@ class TrainGraph:
             else:
                 self.bwd_plan, self.bwd_params, self.bwd_collect = emit(("yolo",), self.Bs, 1)
                 self.bwd_kp_plan, self.bwd_kp_params, self.bwd_kp_collect = emit(("kp",), B, self.G, fresh=False)
+        self._drop_unread_16bit_copies(net)
         mode = os.environ.get("YP_TRAIN_GRAPH", "1")         # replay the launch lists as hipGraphs (284 / 455 / 230 launches)
         if mode in ("1", "fwd") and not (self.fwd_plan.has_lanes and os.environ.get("YP_LANES_EAGER", "1") != "0"):
             self.fwd_plan.instantiate_graph()
@@ -825,6 +832,32 @@ class TrainGraph:
                 self.bwd_plan.instantiate_graph()
             self.bwd_kp_plan.instantiate_graph()
         self.params = [p_ for p_ in net.parameters()]
+
+    def _drop_unread_16bit_copies(self, net):
+        """fp8 mode, after ALL plans of the graph have been emitted: a BatchNorm pass that writes a 1-byte twin beside its 16-bit result (the
+        activation in the forward, dy of the convolution in the backward) stops writing the 16-bit copy when nothing reads it -- every
+        consumer is an 8-bit convolution / dgrad / weight gradient (csrc/wgrad.hip::wgrad_body8), which read the twin.  Readers are taken from
+        the access lists of every plan builder of the graph (the lists behind the hipGraph dependency edges); residual inputs, pools, Detect /
+        head convolutions with a bias, 16-bit layers (channel counts that are not multiples of 64) keep their 16-bit source.  An unread copy is
+        filled with NaN once: a reader this analysis missed cannot go unnoticed (non-finite loss / gradients in the fp8 tests).
+        3 -> 1 bytes written per element in those passes.  YP_FP8_TWIN_ONLY=0: keep every copy."""
+        if not self.fp8 or not self.twin_only or os.environ.get("YP_FP8_TWIN_ONLY", "1") == "0" or type(net).__name__ != "YOLOPoint":
+            return          # (YOLOPointv52 differentiates its descriptor normalisation in PyTorch, outside the plans' access lists)
+        reads = [r for pb in [self.fwd] + self.builders for rd, _ in pb.accesses for r in rd]
+
+        def overlap(a, b):
+            if a[0] != b[0]:
+                return False
+            if a[1] == b[1]:
+                return a[2] < b[3] and b[2] < a[3]
+            return a[4] < b[5] and b[4] < a[5]
+        for pb, op, slot, view in self.twin_only:
+            rng = PlanBuilder._rng(view)
+            if any(overlap(rng, r) for r in reads):
+                continue
+            check(lib().yp_plan_patch_op_view(pb.handle, op, slot, NULL_VIEW))
+            view.buf.t[..., view.coff:view.coff + view.C] = float("nan")
+            self.n_twin_only += 1
 
     # ------------------------------------------------------------------ run
     def forward(self, x, x_w=None, export=True):
