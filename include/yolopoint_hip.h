@@ -416,6 +416,15 @@ int yp_infonce_fwd_grad(const float* da, const float* db, const int* idx, int n,
                        float* dda_unscaled, const int* n_dev, int max_workgroups, void* stream);
 int yp_infonce_bwd_db(const float* da, const int* order, const int* offsets, const float* logits, const float* lse, int n, int E, int D,
                       const float* grad_scale_dev, float* ddb, const int* n_dev, int max_workgroups, void* stream);
+/* The two gathers over a 16-bit copy of the descriptor table (bf16 rows: half the gathered bytes; sums / softmax state in fp32).  rows16 =
+ * yp_infonce_rows16(rows = the fp32 table [2n][D]: anchors then matches, count = 2 n D elements); yp_infonce_fwd_grad_h reads the anchor's own
+ * row from the fp32 table `da` and gathers the match rows from rows16 + n D; yp_infonce_bwd_db_h gathers the anchor rows from rows16.
+ * D in {64, 128, 256}.  For the 16-bit training modes (engine.TrainStep); the fp32 forms above are what the reference fixtures pin. */
+int yp_infonce_rows16(const float* rows, size_t count, void* rows16, void* stream);
+int yp_infonce_fwd_grad_h(const float* da, const void* rows16, const int* idx, int n, int E, int D, float inv_tau, float* logits, float* loss_rows, float* lse,
+                          float* dda_unscaled, const int* n_dev, int max_workgroups, void* stream);
+int yp_infonce_bwd_db_h(const void* rows16, const int* order, const int* offsets, const float* logits, int n, int E, int D, const float* grad_scale_dev,
+                        float* ddb, const int* n_dev, int max_workgroups, void* stream);
 /* max_workgroups (both): 0 = one workgroup per four rows.  > 0 caps the grid, the workgroups then walk the rows -- for a caller that runs
  * these gathers on one stream beside other kernels on another (they are latency-bound and would otherwise take every CU slot): the training
  * step passes 768 (3 per CU), which is worth 4 % of the step at -s; 256 starves the gathers themselves. */

@@ -105,3 +105,52 @@ def test_infonce_gather_generations_agree(cuda, monkeypatch, D):
     for cap in (0, 7):                                    # a capped grid changes which wave takes a row, not the row's arithmetic
         for x, y in zip(res[("2", 0)], res[("2", cap)]):
             assert torch.equal(x, y)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D", [64, 128, 256])
+def test_infonce_gathers_over_16_bit_rows(cuda, D):
+    """yp_infonce_fwd_grad_h / yp_infonce_bwd_db_h (the gathered rows as bf16: half the gathered bytes; what engine.TrainStep runs for bf16 / fp8
+    graphs) -- (a) exact against the fp64 sums over the SAME bf16-rounded rows (the kernels' only freedom is the fp32 summation order: 5e-6),
+    (b) against the fp32-row kernels' definition: the difference is the bf16 rounding of the gathered rows and nothing else (loss rows,
+    softmax weights and both gradients within 1e-2 of their scale); yp_infonce_rows16 = torch's round-to-nearest-even bf16 cast, bit for bit;
+    a capped grid gives the same bits."""
+    from yolopoint_amd import _hip
+    from yolopoint_amd.utils.loss_functions import infonce_edges
+    n, negs, tau = 777, 37, 0.07
+    g = torch.Generator().manual_seed(15 + D)
+    dab = torch.nn.functional.normalize(torch.randn((2 * n, D), generator=g), dim=1).to(cuda)
+    rnd = torch.randint(1, n, (n, negs), generator=g)
+    rnd[:, 3] = 11
+    idx, order, offsets = infonce_edges(rnd.to(cuda))
+    E = idx.shape[1]
+    lib = _hip.lib()
+    scale = torch.full((1,), 1.0 / (tau * n), dtype=torch.float32, device=cuda)
+    rows16 = torch.empty((2 * n, D), dtype=torch.bfloat16, device=cuda)
+    _hip.check(lib.yp_infonce_rows16(dab.data_ptr(), 2 * n * D, rows16.data_ptr(), _hip.stream_ptr()))
+    assert torch.equal(rows16, dab.bfloat16())
+    res = {}
+    for cap in (0, 7):
+        w = torch.empty((n, E), dtype=torch.float32, device=cuda)
+        rows, lse = torch.empty((n,), dtype=torch.float32, device=cuda), torch.empty((n,), dtype=torch.float32, device=cuda)
+        grad, out = torch.empty_like(dab), torch.zeros_like(dab)
+        _hip.check(lib.yp_infonce_fwd_grad_h(dab.data_ptr(), rows16.data_ptr(), idx.data_ptr(), n, E, D, 1.0 / tau, w.data_ptr(), rows.data_ptr(),
+                                             lse.data_ptr(), grad.data_ptr(), None, cap, _hip.stream_ptr()))
+        _hip.check(lib.yp_infonce_bwd_db_h(rows16.data_ptr(), order.data_ptr(), offsets.data_ptr(), w.data_ptr(), n, E, D, scale.data_ptr(),
+                                           out.data_ptr() + 4 * n * D, None, cap, _hip.stream_ptr()))
+        res[cap] = (rows.clone(), w.clone(), grad[:n].clone(), out[n:].clone())
+    for x, y in zip(res[0], res[7]):
+        assert torch.equal(x, y)
+
+    def sums(a, b, a_gathered):
+        lg = (a[:, None, :] * b[idx.long()]).sum(-1) / tau
+        wref = torch.softmax(lg, 1)
+        wref[:, 0] -= 1.0
+        return (torch.logsumexp(lg, 1) - lg[:, 0], wref, (wref[:, :, None] * b[idx.long()]).sum(1),
+                torch.zeros((n, D), dtype=torch.float64, device=cuda).index_add_(0, idx.long().flatten(), (wref[:, :, None] * a_gathered[:, None, :]).reshape(-1, D)) * float(scale))
+    h = rows16.double()
+    exact = sums(dab[:n].double(), h[n:], h[:n])           # anchors' own rows fp32, every GATHERED row bf16 -- what the kernels compute
+    full = sums(dab[:n].double(), dab[n:].double(), dab[:n].double())
+    for name, x, r, f in zip(("loss", "w", "dda", "ddb"), res[0], exact, full):
+        assert float((x.double() - r).abs().max() / r.abs().max()) < 5e-6, name
+        assert float((x.double() - f).abs().max() / f.abs().max()) < 1e-2, name

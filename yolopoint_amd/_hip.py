@@ -121,6 +121,9 @@ SIGNATURES = {
     "yp_sampling_set_max_workgroups": (_i, [_i]),
     "yp_infonce_fwd_grad": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p, _i, _p]),
     "yp_infonce_bwd_db": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _i, _p]),
+    "yp_infonce_rows16": (_i, [_p, C.c_size_t, _p, _p]),
+    "yp_infonce_fwd_grad_h": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p, _i, _p]),
+    "yp_infonce_bwd_db_h": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _i, _p]),
     "yp_infonce_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p]),
     "yp_homo_combine": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p]),
     "yp_points_sample_taps": (_i, [_p, _i, _i, _i, _i, _p, _p, _p]),

@@ -354,6 +354,199 @@ __global__ __launch_bounds__(256) void infonce_bwd_b3_kernel(const float* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same two gathers over a 16-BIT copy of the descriptor table (rows as bf16: yp_infonce_rows16): the gathered rows are the traffic of these
+// kernels (n x E rows of D floats per pass: 9.9 GB at YOLOPoint-l sizes, a fifth of the training step's HBM / fabric bytes), the table is
+// what the 16-bit training modes produce from 16-bit activations anyway, and at D = 256 both generations sat at the ~8 TB/s the fabric delivers
+// to random 1 KB reads -- half the bytes per row is the lever left.  A row is read with 16-byte loads of EIGHT elements by HL = D / 8 lanes (one
+// load instruction fetches 64 / HL rows: 2 at D = 256, 4 at D = 128), sums and softmax state in fp32 as before; the anchor's own row (read
+// once) stays fp32.  Used by engine.TrainStep when the compute dtype is bf16 (incl. fp8 mode); the fp32 kernels above remain the ones the
+// reference fixtures pin (tests/test_gpu_losses_golden.py) and what fp32 / f16 graphs run.
+typedef unsigned int nce_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ld8h(const unsigned short* p, float (&v)[8]) {
+    const nce_u32x4 raw = *reinterpret_cast<const nce_u32x4*>(p);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { v[2 * q] = __uint_as_float(raw[q] << 16); v[2 * q + 1] = __uint_as_float(raw[q] & 0xffff0000u); }
+}
+
+template <int HL>
+__global__ __launch_bounds__(256) void infonce_fwd_grad2h_kernel(const float* __restrict__ da, const unsigned short* __restrict__ dbh, const int* __restrict__ idx, int n, int E,
+                                                                 float inv_tau, float* __restrict__ logits, float* __restrict__ loss,
+                                                                 float* __restrict__ lse, float* __restrict__ dda_u, const int* __restrict__ n_dev) {
+    constexpr int D = HL * 8, RPL = 64 / HL, U = 8;
+    __shared__ int s_idx[4][512];
+    __shared__ float s_lg[4][512];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int g = lane / HL, gl = lane % HL;
+    if (n_dev != nullptr) n = n_dev[0];
+    dbh += (size_t)n * D;                              // (the 16-bit table holds both sides: anchors [0, n), matches [n, 2n))
+    int* li = s_idx[wv];
+    float* lg = s_lg[wv];
+    for (int i = blockIdx.x * 4 + wv; i < n; i += gridDim.x * 4) {
+        float a[8];
+        {
+            const float4 a0 = ld4(da + (size_t)i * D + gl * 8), a1 = ld4(da + (size_t)i * D + gl * 8 + 4);
+            a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
+        }
+        const int* row = idx + (size_t)i * E;
+        for (int j = lane; j < E; j += 64) li[j] = row[j];
+        __builtin_amdgcn_wave_barrier();
+        float mx = -3.0e38f, s = 0.f, l0 = 0.f;
+        float acc[8], b0[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { acc[c] = 0.f; b0[c] = 0.f; }
+        for (int j0 = 0; j0 < E; j0 += RPL * U) {
+            float b[U][8];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + u * RPL + g;
+                const int r = li[j < E ? j : E - 1];
+                ld8h(dbh + (size_t)r * D + gl * 8, b[u]);
+            }
+            float d[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float t = 0.f;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) t += a[c] * b[u][c];
+                d[u] = group_sum<HL>(t) * inv_tau;
+            }
+            float cmx = mx;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (j0 + u * RPL + g < E) cmx = fmaxf(cmx, d[u]);
+            const float resc = __expf(mx - cmx);
+            s *= resc;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[c] *= resc;
+            mx = cmx;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + u * RPL + g;
+                if (j < E) {
+                    const float e = __expf(d[u] - mx);
+                    s += e;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) acc[c] += e * b[u][c];
+                    if (j == 0) {
+                        l0 = d[u];
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) b0[c] = b[u][c];
+                    }
+                    if (gl == 0) lg[j] = d[u];
+                }
+            }
+        }
+#pragma unroll
+        for (int o = HL; o < 64; o <<= 1) {
+            const float mx2 = __shfl_xor(mx, o, 64), s2 = __shfl_xor(s, o, 64);
+            const float m = fmaxf(mx, mx2);
+            const bool lo = (lane & o) == 0;
+            const float f_lo = __expf((lo ? mx : mx2) - m), f_hi = __expf((lo ? mx2 : mx) - m);
+            s = (lo ? s : s2) * f_lo + (lo ? s2 : s) * f_hi;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float a2 = __shfl_xor(acc[c], o, 64);
+                acc[c] = (lo ? acc[c] : a2) * f_lo + (lo ? a2 : acc[c]) * f_hi;
+            }
+            mx = m;
+        }
+        l0 = __shfl(l0, 0, 64);
+        const float ls = mx + logf(s);
+        __builtin_amdgcn_wave_barrier();
+        float* lrow = logits + (size_t)i * E;
+        for (int j = lane; j < E; j += 64) lrow[j] = __expf(lg[j] - ls) - (j == 0 ? 1.0f : 0.0f);
+        if (lane == 0) { loss[i] = ls - l0; lse[i] = ls; }
+        if (g == 0) {
+            const float inv_s = 1.0f / s;
+            float4 o0, o1;
+            o0.x = acc[0] * inv_s - b0[0]; o0.y = acc[1] * inv_s - b0[1]; o0.z = acc[2] * inv_s - b0[2]; o0.w = acc[3] * inv_s - b0[3];
+            o1.x = acc[4] * inv_s - b0[4]; o1.y = acc[5] * inv_s - b0[5]; o1.z = acc[6] * inv_s - b0[6]; o1.w = acc[7] * inv_s - b0[7];
+            *reinterpret_cast<float4*>(dda_u + (size_t)i * D + gl * 8) = o0;
+            *reinterpret_cast<float4*>(dda_u + (size_t)i * D + gl * 8 + 4) = o1;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int HL>
+__global__ __launch_bounds__(256) void infonce_bwd_b3h_kernel(const unsigned short* __restrict__ dah, const float* __restrict__ logits, const int* __restrict__ order,
+                                                              const int* __restrict__ offsets, int n, int E, const float* __restrict__ gscale,
+                                                              float* __restrict__ ddb, const int* __restrict__ n_dev) {
+    constexpr int D = HL * 8, RPL = 64 / HL, U = 8;
+    __shared__ int s_i[4][256];
+    __shared__ float s_w[4][256];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int g = lane / HL, gl = lane % HL;
+    if (n_dev != nullptr) { n = n_dev[0]; ddb += (size_t)n * D; }
+    int* li = s_i[wv];
+    float* lw = s_w[wv];
+    const float scale = gscale[0];
+    for (int k = blockIdx.x * 4 + wv; k < n; k += gridDim.x * 4) {
+        const int e0 = offsets[k], e1 = offsets[k + 1];
+        float acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+        for (int c0 = e0; c0 < e1; c0 += 256) {
+            const int cn = e1 - c0 < 256 ? e1 - c0 : 256;
+            __builtin_amdgcn_wave_barrier();
+            for (int q = lane; q < cn; q += 64) {
+                const int edge = order[c0 + q];
+                li[q] = (int)((unsigned)edge / (unsigned)E);
+                lw[q] = logits[edge];
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int q0 = 0; q0 < cn; q0 += RPL * U) {
+                float a[U][8];
+                float we[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int q = q0 + u * RPL + g;
+                    const int qq = q < cn ? q : cn - 1;
+                    ld8h(dah + (size_t)li[qq] * D + gl * 8, a[u]);
+                    we[u] = q < cn ? lw[qq] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) acc[c] += we[u] * a[u][c];
+            }
+        }
+#pragma unroll
+        for (int o = HL; o < 64; o <<= 1) {
+            const bool lo = (lane & o) == 0;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float x = __shfl_xor(acc[c], o, 64);
+                acc[c] = lo ? acc[c] + x : x + acc[c];
+            }
+        }
+        if (g == 0) {
+            float4 o0, o1;
+            o0.x = acc[0] * scale; o0.y = acc[1] * scale; o0.z = acc[2] * scale; o0.w = acc[3] * scale;
+            o1.x = acc[4] * scale; o1.y = acc[5] * scale; o1.z = acc[6] * scale; o1.w = acc[7] * scale;
+            *reinterpret_cast<float4*>(ddb + (size_t)k * D + gl * 8) = o0;
+            *reinterpret_cast<float4*>(ddb + (size_t)k * D + gl * 8 + 4) = o1;
+        }
+    }
+}
+
+// fp32 rows -> bf16 (round to nearest even), 8 elements per thread
+__global__ __launch_bounds__(256) void nce_rows16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const float4 a = ld4(src + i * 8), b = ld4(src + i * 8 + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        nce_u32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned lo = __float_as_uint(v[2 * q]), hi = __float_as_uint(v[2 * q + 1]);
+            lo += 0x7fffu + ((lo >> 16) & 1u); hi += 0x7fffu + ((hi >> 16) & 1u);
+            o[q] = (lo >> 16) | (hi & 0xffff0000u);
+        }
+        *reinterpret_cast<nce_u32x4*>(dst + i * 8) = o;
+    }
+}
+
 // w[i][j] = (softmax_j - [j == 0]) * scale  and  dda[i] = sum_j w[i][j] * db[idx[i][j]]
 template <int VPL>
 __global__ __launch_bounds__(256) void infonce_bwd_a_kernel(const float* __restrict__ db, const int* __restrict__ idx, const float* __restrict__ logits, int n, int E,
@@ -981,6 +1174,44 @@ extern "C" int yp_infonce_bwd_db(const float* da, const int* order, const int* o
         return YP_OK;
     }
     YP_VPL_SWITCH(D, (infonce_bwd_b2_kernel<VPL><<<grid, 256, 0, st>>>(da, logits, lse, order, offsets, n, E, D, grad_scale_dev, ddb, n_dev)));
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
+// 16-bit rows: rows16 = bf16 copy [2n][D] of the table [anchors | matches] (yp_infonce_rows16); arguments otherwise as yp_infonce_fwd_grad /
+// yp_infonce_bwd_db.  D in {64, 128, 256}.  With n_dev the row count, and with it the start of the match half, is read on the device.
+extern "C" int yp_infonce_rows16(const float* rows, size_t count, void* rows16, void* stream) {
+    YP_REQUIRE(rows && rows16 && count > 0 && count % 8 == 0, "yp_infonce_rows16: bad arguments (count %% 8 == 0)");
+    size_t g = (count / 8 + 255) / 256;
+    if (g > 2048) g = 2048;
+    nce_rows16_kernel<<<(unsigned)g, 256, 0, (hipStream_t)stream>>>(rows, (unsigned short*)rows16, count / 8);
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
+extern "C" int yp_infonce_fwd_grad_h(const float* da, const void* rows16, const int* idx, int n, int E, int D, float inv_tau, float* logits, float* loss_rows,
+                                     float* lse, float* dda_unscaled, const int* n_dev, int max_workgroups, void* stream) {
+    YP_REQUIRE(da && rows16 && idx && logits && loss_rows && lse && dda_unscaled && n > 0 && E > 0 && E <= 512 && (D == 64 || D == 128 || D == 256),
+               "yp_infonce_fwd_grad_h: bad arguments (E <= 512, D in {64, 128, 256})");
+    const int grid = nce_grid(n, max_workgroups);
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned short* h = (const unsigned short*)rows16;
+    if (D == 64) infonce_fwd_grad2h_kernel<8><<<grid, 256, 0, st>>>(da, h, idx, n, E, inv_tau, logits, loss_rows, lse, dda_unscaled, n_dev);
+    else if (D == 128) infonce_fwd_grad2h_kernel<16><<<grid, 256, 0, st>>>(da, h, idx, n, E, inv_tau, logits, loss_rows, lse, dda_unscaled, n_dev);
+    else infonce_fwd_grad2h_kernel<32><<<grid, 256, 0, st>>>(da, h, idx, n, E, inv_tau, logits, loss_rows, lse, dda_unscaled, n_dev);
+    YP_CHECK_HIP(hipGetLastError());
+    return YP_OK;
+}
+
+extern "C" int yp_infonce_bwd_db_h(const void* rows16, const int* order, const int* offsets, const float* logits, int n, int E, int D,
+                                   const float* grad_scale_dev, float* ddb, const int* n_dev, int max_workgroups, void* stream) {
+    YP_REQUIRE(rows16 && order && offsets && logits && grad_scale_dev && ddb && n > 0 && E > 0 && (D == 64 || D == 128 || D == 256), "yp_infonce_bwd_db_h: bad arguments");
+    const int grid = nce_grid(n, max_workgroups);
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned short* h = (const unsigned short*)rows16;
+    if (D == 64) infonce_bwd_b3h_kernel<8><<<grid, 256, 0, st>>>(h, logits, order, offsets, n, E, grad_scale_dev, ddb, n_dev);
+    else if (D == 128) infonce_bwd_b3h_kernel<16><<<grid, 256, 0, st>>>(h, logits, order, offsets, n, E, grad_scale_dev, ddb, n_dev);
+    else infonce_bwd_b3h_kernel<32><<<grid, 256, 0, st>>>(h, logits, order, offsets, n, E, grad_scale_dev, ddb, n_dev);
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
 }

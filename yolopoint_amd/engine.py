@@ -356,7 +356,8 @@ class TrainStep:
             # workgroups, and the fewer they occupy the less the backward plan beside them is slowed -- until the chain itself becomes the
             # critical path.  -s (D = 128): 256 workgroups 7.32 ms, 128 / 384 / 512 / 768: 7.36 / 7.38 / 7.42 / 7.55; -l (D = 256, 16
             # samples): 128 workgroups 34.6-34.8 ms, 256 / 384 / 768: 34.9 / 35.0 / 35.5, 96 / 64 / 32: 35.3 / 38.5 / 49.6
-            nce_wgs = int(os.environ.get("YP_NCE_WGS", "256" if D <= 128 else "128")) if lanes >= 2 else 0
+            # (16-bit rows, D = 256: 96 / 128 / 192 workgroups 29.94 / 30.35 / 29.96 ms per -l fp8 step, same box)
+            nce_wgs = int(os.environ.get("YP_NCE_WGS", "256" if D <= 128 else ("96" if g.code == _hip.YP_BF16 and os.environ.get("YP_NCE_ROWS", "bf16") == "bf16" else "128"))) if lanes >= 2 else 0
             out4_ = torch.empty((4,), dtype=torch.float32, device=dev)
             if isinstance(nce, dict):
                 # counts on the device (infonce_prepare(sync=False)): arrays at their capacity, the kernels read points-per-image / matched rows
@@ -377,14 +378,27 @@ class TrainStep:
             w = torch.empty((n, E), dtype=torch.float32, device=dev)
             rows, lse = torch.empty((n,), dtype=torch.float32, device=dev), torch.empty((n,), dtype=torch.float32, device=dev)
             check(lib.yp_points_sample_fwd(stg.desc_ptr, 2 * B, Hc, Wc, D, uab.data_ptr(), pool, dab.data_ptr(), p_dev, sp()))
-            check(lib.yp_infonce_fwd_grad(dab.data_ptr(), None if n_dev else dab.data_ptr() + 4 * n * D, idx.data_ptr(), n, E, D, 1.0 / tau, w.data_ptr(),
-                                          rows.data_ptr(), lse.data_ptr(), grad.data_ptr(), n_dev, nce_wgs, sp()))
+            # bf16 graphs (incl. fp8 mode): the gathers read a 16-bit copy of the sampled-descriptor table -- half the gathered bytes (the rows
+            # of these two kernels are a fifth of the -l step's HBM / fabric traffic); fp32 / f16 graphs keep the fp32 rows.  YP_NCE_ROWS=fp32: off
+            rows16 = None
+            if g.code == _hip.YP_BF16 and D in (64, 128, 256) and os.environ.get("YP_NCE_ROWS", "bf16") == "bf16":
+                rows16 = torch.empty((2 * n, D), dtype=torch.bfloat16, device=dev)
+                check(lib.yp_infonce_rows16(dab.data_ptr(), 2 * n * D, rows16.data_ptr(), sp()))
+                check(lib.yp_infonce_fwd_grad_h(dab.data_ptr(), rows16.data_ptr(), idx.data_ptr(), n, E, D, 1.0 / tau, w.data_ptr(),
+                                                rows.data_ptr(), lse.data_ptr(), grad.data_ptr(), n_dev, nce_wgs, sp()))
+            else:
+                check(lib.yp_infonce_fwd_grad(dab.data_ptr(), None if n_dev else dab.data_ptr() + 4 * n * D, idx.data_ptr(), n, E, D, 1.0 / tau, w.data_ptr(),
+                                              rows.data_ptr(), lse.data_ptr(), grad.data_ptr(), n_dev, nce_wgs, sp()))
             if small_done is not None:
                 stream.wait_event(small_done)
             check(lib.yp_loss_combine(scal + 16, 2, rows.data_ptr(), n, scal, LAMBDA_DESC, LAMBDA_OBJ, float(scale), desc_scale, out4_.data_ptr(), scal + 48, n_dev,
                                       float(g_desc), tau, sp()))
-            check(lib.yp_infonce_bwd_db(dab.data_ptr(), order.data_ptr(), offsets.data_ptr(), w.data_ptr(), lse.data_ptr(), n, E, D, scal + 48,
-                                        grad.data_ptr() if n_dev else grad.data_ptr() + 4 * n * D, n_dev, nce_wgs, sp()))
+            if rows16 is not None:
+                check(lib.yp_infonce_bwd_db_h(rows16.data_ptr(), order.data_ptr(), offsets.data_ptr(), w.data_ptr(), n, E, D, scal + 48,
+                                              grad.data_ptr() if n_dev else grad.data_ptr() + 4 * n * D, n_dev, nce_wgs, sp()))
+            else:
+                check(lib.yp_infonce_bwd_db(dab.data_ptr(), order.data_ptr(), offsets.data_ptr(), w.data_ptr(), lse.data_ptr(), n, E, D, scal + 48,
+                                            grad.data_ptr() if n_dev else grad.data_ptr() + 4 * n * D, n_dev, nce_wgs, sp()))
             check(lib.yp_points_sample_bwd_sorted(grad.data_ptr(), 2 * B, Hc, Wc, D, uab.data_ptr(), pool, s_order.data_ptr(), s_offsets.data_ptr(), scal + 48, n,
                                                   stg.gdesc_ptr, n_dev, sp()))
             return out4_
