@@ -786,9 +786,13 @@ def test_native_loss_stage_equals_the_autograd_stage(cuda, monkeypatch, gas):
     """engine.TrainStep's native loss stage (losses read the heads in the plan's buffers and write final head gradients into the backward
     plans' seeds; label preparation and the loss sum of train.py:232-241 as native launches) against the autograd formulation of the same
     step (YP_NATIVE_STAGE=0): same draws, same weights -> every parameter gradient bit for bit, the loss to fp32 rounding, and the same
-    weights after the optimizer steps.  gas = 2 exercises the 1 / gas factor on every head."""
+    weights after the optimizer steps.  gas = 2 exercises the 1 / gas factor on every head.
+    (The native stage of a bf16 graph gathers its InfoNCE rows from a 16-bit copy of the descriptor table by default -- round 5, half the
+    gathered bytes; the autograd formulation gathers fp32 rows.  The equivalence of the two FORMULATIONS is about the same arithmetic:
+    YP_NCE_ROWS=fp32 here; the 16-bit gathers have their own test, tests/test_gpu_losses_golden.py::test_infonce_gathers_over_16_bit_rows.)"""
     import copy
     from yolopoint_amd.engine import TrainStep, synthetic_batch
+    monkeypatch.setenv("YP_NCE_ROWS", "fp32")
     m, _ = make_model("n", 21, dtype="bf16")
     m = m.to(cuda).train()
     m2 = copy.deepcopy(m)

@@ -132,6 +132,17 @@ struct YpHalve {
     }
 };
 
+#ifdef YP_PROBE_BNFUSE
+// Probe build (make probebn; tools/probe/bnfuse_bench.py): the 1x1 convolution applies x = silu(scale[c] * y + shift[c]) to its input tile in
+// LDS between the DMA's landing and the fragment reads -- the consumer-side BatchNorm + SiLU of review item 4 (rounds 2-5), as a measurement.
+__device__ const float* yp_xf_scale = nullptr;
+__device__ const float* yp_xf_shift = nullptr;
+extern "C" int yp_debug_set_xform(const float* scale, const float* shift) {
+    if (hipMemcpyToSymbol(HIP_SYMBOL(yp_xf_scale), &scale, sizeof(scale)) != hipSuccess) return -1;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(yp_xf_shift), &shift, sizeof(shift));
+}
+#endif
+
 // 16 zero bytes: out-of-image taps / padded k / padded filter rows are fetched from here, so every
 // LDS-DMA lane always has a valid source and no predication or LDS pre-clearing is needed.
 __device__ __attribute__((aligned(16))) unsigned int yp_zero16[4] = {0u, 0u, 0u, 0u};
@@ -521,6 +532,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
             }
         }
     } else {
+#ifdef YP_PROBE_BNFUSE
+    // (scale, shift) of every input channel into LDS behind the ring, before the pipeline starts (plain loads: older than every DMA)
+    float* xf_tab = reinterpret_cast<float*>(smem + NS * STAGE);
+    const float* xfs = yp_xf_scale;
+    const float* xfh = yp_xf_shift;
+    const bool xf_on = xfs != nullptr && FAST && E::BYTES == 2 && a.RS == 1;
+    if (xf_on) {
+        for (int i = t; i < a.Kpad; i += 256) { xf_tab[2 * i] = i < a.Cin ? xfs[i] : 0.f; xf_tab[2 * i + 1] = i < a.Cin ? xfh[i] : 0.f; }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+#endif
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) issue_tile(kt0 + s, s * STAGE);
@@ -536,6 +559,32 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
         else if (younger == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS > 5 ? 4 * NL : 0) : "memory");
         else if (younger == 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS > 6 ? 5 * NL : 0) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS > 7 ? 6 * NL : 0) : "memory");
+#ifdef YP_PROBE_BNFUSE
+        if constexpr (E::BYTES == 2 && FAST) {
+            if (xf_on) {
+                // this wave's own pixel slots of tile kt (its DMA instructions have landed: the counted wait above): lane l holds row l/4,
+                // physical chunk l%4 = logical chunk jl = channels kt * 32 + 8 jl .. + 7
+                using sc_t = typename E::scalar;
+                char* sp = smem + (kt % NS) * STAGE;
+                const float* tb = xf_tab + 2 * ((kt0 + kt) * BK + jl * 8);
+                float cs[8], ch[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(tb + 4 * q);
+                    cs[2 * q] = v4[0]; ch[2 * q] = v4[1]; cs[2 * q + 1] = v4[2]; ch[2 * q + 1] = v4[3];
+                }
+#pragma unroll
+                for (int i = 0; i < NLA; ++i) {
+                    char* q_ = sp + (wave_u + 4 * i) * 1024 + lane * 16;
+                    u32x4 raw = *reinterpret_cast<const u32x4*>(q_);
+                    sc_t* e = reinterpret_cast<sc_t*>(&raw);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) e[j] = (sc_t)yp_silu((float)e[j] * cs[j] + ch[j]);
+                    *reinterpret_cast<u32x4*>(q_) = raw;
+                }
+            }
+        }
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (this wave's reads of tile kt-1 have retired before its stage is refilled)
 #ifndef YP_PROBE_NOBAR
         __builtin_amdgcn_s_barrier();
@@ -2044,12 +2093,19 @@ constexpr TileCfg kTiles[] = {{1, 128, 32}, {2, 128, 64}, {3, 128, 128}, {4, 64,
 
 template <int DT, bool OUT_F32, bool FAST, bool DETECT, int BM, int BN, int WAVES_M, int WAVES_N, int NS, bool STATS = false, int KPB = 0, bool WSK = false>
 hipError_t launch_tile(const ConvKArgs& a, int nblk, hipStream_t st) {
+#ifdef YP_PROBE_BNFUSE
+    constexpr size_t lds0 = (size_t)NS * (KPB > 0 ? KPB : 1) * (BM / 16 + BN / 16) * 1024;
+    const size_t lds = lds0 + (KPB == 0 ? (size_t)a.Kpad * 8 : 0);
+    auto kern = conv_igemm_kernel<DT, OUT_F32, FAST, DETECT, BM, BN, WAVES_M, WAVES_N, NS, STATS, KPB, WSK>;
+    { static YpLdsAttr attr; if (hipError_t e = yp_set_max_lds(attr, (const void*)kern, 96 * 1024); e != hipSuccess) return e; }
+#else
     constexpr size_t lds = (size_t)NS * (KPB > 0 ? KPB : 1) * (BM / 16 + BN / 16) * 1024;
     auto kern = conv_igemm_kernel<DT, OUT_F32, FAST, DETECT, BM, BN, WAVES_M, WAVES_N, NS, STATS, KPB, WSK>;
     if constexpr (lds > 65536) {
         static YpLdsAttr attr;        // per instantiation, per device
         if (hipError_t e = yp_set_max_lds(attr, (const void*)kern, (int)lds); e != hipSuccess) return e;
     }
+#endif
     kern<<<dim3(nblk, a.ksplit), 256, lds, st>>>(a);
     return hipGetLastError();
 }
@@ -2282,6 +2338,7 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
             return YP_OK;
         }
     }
+#ifdef YP_WITH_WSK      // (probe build only: make probewsk)
     {   // wave-private split-K kernels (conv_wsk.hip), tile ids 71..73: short-M 16-bit fast-path layers
         int bm = 0, bn = 0;
         if (yp_wsk_tile_dims(d->tile, &bm, &bn)) {
@@ -2300,6 +2357,7 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
             return YP_OK;
         }
     }
+#endif
     if (det != nullptr) {
         YP_REQUIRE(det->na > 0 && det->na <= 8 && det->no > 5 && det->na * det->no <= Cout && det->x_out != nullptr, "yp_conv2d_detect: bad detect descriptor");
         YP_REQUIRE(d->act == YP_ACT_NONE && d->res.C == 0 && d->out2.C == 0 && fast && d->pre_weight == nullptr, "yp_conv2d_detect: plain fast-path convolution required");

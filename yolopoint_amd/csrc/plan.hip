@@ -305,8 +305,8 @@ static int ensure_side(YpPlan* plan, hipStream_t st) {
 // nothing after them waits for them until an op on YP_LANE_JOIN (or the end of the plan).  Under stream capture the events become
 // graph edges, so the side ops form a parallel branch of the hipGraph.  Used by the training backward: the weight-gradient
 // kernels (one workgroup per CU, atomics-bound) run beside the dgrad / BatchNorm-backward chain, which never reads their output.
-static int run_eager(YpPlan* plan, hipStream_t st) {
-    bool pending = false;               // side work in flight that the main lane has not joined
+static int run_eager_ops(YpPlan* plan, hipStream_t st, bool& pending) {
+    pending = false;                    // side work in flight that the main lane has not joined
     bool main_since_fork = true;        // a side op forks again only when the main lane has moved since the last fork: consecutive side ops are
                                         // ordered by their own stream.  (Not only an economy: captured into a hipGraph, a main-lane node with many
                                         // outgoing cross-stream edges -- every side op re-forking from the same position -- lost its SAME-stream
@@ -364,6 +364,20 @@ static int run_eager(YpPlan* plan, hipStream_t st) {
         YP_CHECK_HIP(hipStreamWaitEvent(st, plan->join, 0));
     }
     return YP_OK;
+}
+
+// On an error return (a callback op that failed, a launch that was rejected) side-lane work already enqueued may still be running: the
+// caller's stream is made to wait for it before the error propagates -- the buffers such kernels write (the front end's temporaries, which
+// return to the main stream's allocator pool when its hook raises) must not be handed out again under them.  Queued side ops that were not
+// issued yet are dropped with the error.
+static int run_eager(YpPlan* plan, hipStream_t st) {
+    bool pending = false;
+    const int rc = run_eager_ops(plan, st, pending);
+    if (rc != YP_OK && pending && plan->side != nullptr && plan->join != nullptr) {
+        if (hipEventRecord(plan->join, plan->side) == hipSuccess) (void)hipStreamWaitEvent(st, plan->join, 0);
+        else (void)hipStreamSynchronize(plan->side);
+    }
+    return rc;
 }
 
 extern "C" int yp_plan_set_lane(YpPlan* plan, int op, int lane) {

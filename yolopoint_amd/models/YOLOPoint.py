@@ -99,6 +99,9 @@ class YOLOPoint(HipModule):
               and c1.out_channels == 32 and isinstance(self.Conv1.act, nn.SiLU) and getattr(self, "fuse_stem", True)
               and c2.kernel_size == (3, 3) and c2.stride == (2, 2) and c2.padding == (1, 1) and c2.in_channels == 32 and c2.out_channels <= 64
               and c2.out_channels % 8 == 0 and isinstance(self.Conv2.act, nn.SiLU) and img.H % 4 == 0 and img.W % 4 == 0
+              # (the never-materialised stem output is addressed with 32-bit byte offsets: B (H/2) (W/2) 32 channels x 2 bytes < 2^31 -- beyond
+              # that, ~328 images of 640 x 640, the library refuses the fused launch and the two-launch plan, which has no such limit, is taken)
+              and pb.B * (img.H // 2) * (img.W // 2) * 32 * 2 + 32 * 2 + 64 < (1 << 31)
               and os.environ.get("YP_FUSE_STEM", "1") != "0" and os.environ.get("YP_FUSE_STEM2", "1") != "0")
         if not ok:
             out = run("Conv2", self.Conv2, self._emit_stem(pb, img))

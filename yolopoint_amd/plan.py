@@ -194,12 +194,11 @@ _TUNE_CACHE = {}
 # next tile's inputs prefetched; bit-identical to tile 10); 17 / 18 / 19 the fused Bottleneck with EIGHT wavefronts per workgroup (BN = 32 / 64 / 128)
 # 41..44 / 57: the 8-wave 32x32x16 kernels of csrc/conv_mma8.hip (256x256 / 256x128 / 128x256 / 128x128 tiles; 57 = 256x256 with two-step
 # phases, 58 = 256x256 free-running), for 16-bit layers whose channel counts are multiples of 64
-# 71..76: the wave-private split-K kernels of csrc/conv_wsk.hip (64x64 tiles with 8 / 4 waves, 128x64 with 4; 71-73 interleave the k tiles over
-# the waves, 74-76 give every wave a contiguous k range) for the short-M layers: fp32 sums run as NW partial sums (bit-reproducible; the last
-# bits differ from the sequential tiles).  Candidates since round 5: the tuner takes them for Conv5 / Conv9 / SPPF.cv2 / Bottleneck4.m.0.cv2 of
-# configs[1] (back-to-back 22.8 -> 19.2, 16.6 -> 12.1 us; inside the plan, where every launch also pays ~4 us of boundary + prologue + first
-# fetch, Conv5 26.0 -> 24.6, Conv9 19.4 -> 17.3; the step 0.6558 -> 0.6535 ms over two same-box pairs, tools/probe/wsk_ab.sh).
-_TUNE_CANDIDATES = (1, 2, 3, 4, 5, 21, 22, 23, 24, 25, 26, 27, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 41, 42, 43, 44, 57, 58, 71, 72, 73, 74, 75, 76)
+# (71..76, the wave-private split-K kernels of csrc/conv_wsk.hip, live in the probe build `make -C yolopoint_amd/csrc probewsk` only since
+# round 5: back-to-back they win Conv5 / Conv9 / SPPF.cv2 of configs[1] (22.8 -> 19.2, 16.6 -> 12.1 us), inside the plan -- where every launch also
+# pays ~4 us of boundary + prologue + first fetch -- Conv5 26.0 -> 24.6, Conv9 19.4 -> 17.3 and the step 0.6558 -> 0.6535 ms, inside the box noise
+# (tools/probe/wsk_ab.sh); as tuner candidates under a random variant mixture they broke the fused-stem equivalence tests.)
+_TUNE_CANDIDATES = (1, 2, 3, 4, 5, 21, 22, 23, 24, 25, 26, 27, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 41, 42, 43, 44, 57, 58)
 # pixels per BatchNorm-statistics row of the variants whose rows are plain pixel blocks (the 3x3 halo kernels write one row per image tile)
 _STAT_ROW_PX = {41: 128, 57: 128, 58: 128}
 _TUNE_ITERS = int(os.environ.get("YP_TUNE_ITERS", "8"))      # timed launches per candidate
