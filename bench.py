@@ -371,7 +371,7 @@ def main():
     head = {k_: out[k_] for k_ in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step")}
     head["summary"] = summ
     head.update({k_: v_ for k_, v_ in out.items() if k_ not in head})
-    print(json.dumps(head), flush=True)
+    emit(json.dumps(head))
     if world > 1 or __import__("torch").distributed.is_initialized():
         try:
             __import__("torch").distributed.destroy_process_group()
@@ -666,7 +666,7 @@ def bench_train(a, rank, world, dev):
            "roofline": rec["roofline"]}
     if "cpu_baseline" in rec:
         top["cpu_baseline"] = rec["cpu_baseline"]
-    print(json.dumps(top), flush=True)
+    emit(json.dumps(top))
     import torch.distributed as dist
     if dist.is_initialized():
         dist.destroy_process_group()
@@ -678,7 +678,7 @@ def bench_frame(a, dev):
     top = {"metric": rec["metric"], "value": rec["value"], "unit": "frames/s", "n_gpus": 1, "steps": rec["steps"], "warmup": rec["warmup"],
            "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
            "config": rec["config"], "roofline": rec["roofline"]}
-    print(json.dumps(top), flush=True)
+    emit(json.dumps(top))
 
 
 FWD_GFLOP_PER_IMAGE = {"n": 5.642, "s": 21.023, "m": 61.477, "l": 135.526}       # SURVEY.md 8(d) F_fwd at 640x640
@@ -797,12 +797,11 @@ def bench_export(a, dev):
         npts = exp.export_sample(sample).shape[0]
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    print(json.dumps({"metric": f"source images/sec, homography-adaptation export ({N} views of {S}x{S} per image, YOLOPoint-{a.version}, {a.dtype})",
+    emit(json.dumps({"metric": f"source images/sec, homography-adaptation export ({N} views of {S}x{S} per image, YOLOPoint-{a.version}, {a.dtype})",
                       "value": round(steps / wall, 2), "unit": "images/s", "views_per_s": round(steps * N / wall, 1), "n_gpus": 1, "steps": steps,
                       "warmup": max(1, a.warmup // 5), "ms_per_step": round(wall / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                       "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-                      "config": {"workload": "reference configs/coco_export.yaml: 100 views, detection_threshold 0.085, nms 4, top_k 1000", "points": npts}}),
-          flush=True)
+                      "config": {"workload": "reference configs/coco_export.yaml: 100 views, detection_threshold 0.085, nms 4, top_k 1000", "points": npts}}))
 
 
 def bench_postproc(dev):
@@ -836,5 +835,27 @@ def bench_postproc(dev):
     return res
 
 
+_REAL_STDOUT_FD = None
+
+
+def emit(line):
+    """The ONE JSON line of the contract.  Libraries write to the process's stdout as well (RCCL prints a version banner from C stdio when its
+    first communicator comes up -- also for the one-rank group of the N = 1 `train` record -- and libc flushes it at exit, BEHIND anything Python
+    printed): the whole run therefore has file descriptor 1 pointed at stderr, and only this line goes to the real stdout."""
+    if _REAL_STDOUT_FD is None:
+        print(line, flush=True)
+        return
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    os.write(_REAL_STDOUT_FD, (line + "\n").encode())
+
+
 if __name__ == "__main__":
+    sys.stdout.flush()
+    _REAL_STDOUT_FD = os.dup(1)
+    os.dup2(2, 1)           # everything else any library prints: stderr
     main()

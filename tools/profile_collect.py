@@ -6,7 +6,7 @@ import collections, csv, glob, json, os, re, sys
 R = sys.argv[1] if len(sys.argv) > 1 else "r01"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out", f"prof_{R}")
-CONV = re.compile(r"conv_igemm_kernel|conv_mma8_kernel|conv_wsk_kernel|conv3x3_halo_kernel|bottleneck_halo_kernel|stem_conv_kernel|stem_conv2_kernel|chain_")
+CONV = re.compile(r"conv_igemm_kernel|conv_mma8_kernel|conv_wsk_kernel|conv3x3_halo_kernel|bottleneck_halo_kernel|bneck32_persist_kernel|stem_conv_kernel|stem_conv2_kernel")
 STEM = re.compile(r"stem_conv_kernel|stem_conv2_kernel")
 STEPS, WARMUP = 50, 10
 

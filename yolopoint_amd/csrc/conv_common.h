@@ -105,7 +105,8 @@ struct ConvKArgs {
     int stats_rows;                // partials lie together: the fold that follows reads them as contiguous runs)
     const float* scale_in;         // 8-bit input types: the accumulators are multiplied by *scale_in * *scale_w (device scalars: the
     const float* scale_w;          // dequantisation scales of the activation and of the filter) before the epilogue
-    unsigned mg_howo, mg_wo;       // conv_wsk.hip: ceil(2^32 / HoWo), ceil(2^32 / Wo) when M * HoWo < 2^32 (exact magic division), else 0
+    unsigned mg_howo, mg_wo;       // ceil(2^32 / HoWo), ceil(2^32 / Wo) when M * HoWo < 2^32 (exact magic division), else 0
+    unsigned mg_tn;                // ceil(2^32 / tiles_n) (generic kernel: workgroup -> (tile_m, tile_n)), 0: divide
     const float* stem_x;           // fused stem + 3x3 / stride-2 convolution (stem_conv2_kernel): the caller's NCHW fp32 image, the stem's paired-pixel
     const char* stem_wgt;          // filter / bias, the image's dims and channel count
     const float* stem_bias;

@@ -207,8 +207,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
         const int xcd = bid & 7, idx = bid >> 3;
         logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tile_n = logical % a.tiles_n;
-    const int tile_m = logical / a.tiles_n;
+    // (exact magic division where the host could guarantee it -- yp_conv2d_launch: a.mg_* != 0 -- instead of the ~35-instruction run-time
+    // division sequences: the setup of a launch is 0.8-1.7 us of a 4-6 us kernel on the short layers)
+    const int tile_m = a.mg_tn ? (int)__umulhi((unsigned)logical, a.mg_tn) : logical / a.tiles_n;
+    const int tile_n = logical - tile_m * a.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int t = threadIdx.x;
@@ -222,9 +224,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     for (int i = 0; i < NLA; ++i) {
         const int m = m0 + (wave + 4 * i) * 16 + lrow;
         if (m < a.M) {
-            const int b = m / a.HoWo;
+            const int b = a.mg_howo ? (int)__umulhi((unsigned)m, a.mg_howo) : m / a.HoWo;
             const int rem = m - b * a.HoWo;
-            const int ho = rem / a.Wo;
+            const int ho = a.mg_howo ? (int)__umulhi((unsigned)rem, a.mg_wo) : rem / a.Wo;
             const int wo = rem - ho * a.Wo;
             hi0[i] = ho * a.sh - a.ph;
             wi0[i] = wo * a.sw - a.pw;
@@ -2302,6 +2304,12 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
     YP_REQUIRE(tc != nullptr, "yp_conv2d: unknown tile id %d", tile);
     a.tiles_n = yp_cdiv(Cout, tc->bn);
     const int nblk = yp_cdiv(a.M, tc->bm) * a.tiles_n;
+    // ceil(2^32 / d) divides every n with n * d < 2^32 exactly by one multiply-high: pixel index -> (b, y, x) and workgroup -> (tile_m, tile_n)
+    if ((unsigned long long)(a.M + 255) * (unsigned long long)a.HoWo < (1ull << 32) && a.HoWo >= 2 && a.Wo >= 2) {
+        a.mg_howo = (unsigned)(((1ull << 32) + a.HoWo - 1) / a.HoWo);
+        a.mg_wo = (unsigned)(((1ull << 32) + a.Wo - 1) / a.Wo);
+    }
+    if (a.tiles_n >= 2 && (unsigned long long)(nblk + 8) * (unsigned long long)a.tiles_n < (1ull << 32)) a.mg_tn = (unsigned)(((1ull << 32) + a.tiles_n - 1) / a.tiles_n);
 
     // FAST DMA addressing: wave-uniform taps (k tile never straddles a tap or the source boundary), 16 zero
     // bytes behind each input buffer and a zero filter row behind the packed weights, 32-bit byte offsets.
