@@ -130,6 +130,17 @@ def test_frontend_process_img_reference_formats(cuda):
     np.testing.assert_allclose(np.linalg.norm(desc, axis=0), 1.0, atol=1e-4)
     with pytest.raises(_hip.YpError):
         YoloPointFrontend(m, cuda, crop_resize=[0, 1, 0, 1, 2])
+    # the front end changes the wrapped model while it lives (heads hook in its plans, frozen weights); close() / `with` gives it back
+    assert m.model.heads_hook is True and "_frozen_version" in m.model.__dict__
+    fe.close()
+    assert m.model.heads_hook is False and "_frozen_version" not in m.model.__dict__
+    with YoloPointFrontend(m, cuda, filter_pts=True) as fe2:
+        assert m.model.heads_hook is True
+        pts2, _, _ = fe2.process_img(img)
+        assert pts2.shape[0] == 3
+    assert m.model.heads_hook is False
+    x = torch.rand(1, 3, 96, 128, device=cuda)
+    assert torch.isfinite(m(x)["semi"]).all()            # the model still runs on its own, hook-free plans
 
 
 @pytest.mark.parametrize("i", [0, 1, 2])

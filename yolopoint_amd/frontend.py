@@ -35,10 +35,32 @@ class YoloPointFrontend:
         # the keypoint post-processing hangs into the forward's side lane (see process_tensor) when the model is this package's YOLOPoint
         net = getattr(self.model, "model", None)
         self._net = net if hasattr(net, "_emit_heads_hook") else None
+        # (both change the WRAPPED model for as long as this front end lives: its plans carry a callback op -- they replay eagerly, also for
+        # other callers -- and, with freeze_weights, in-place edits / .to() / .half() of its parameters are not seen until
+        # freeze_weights(False).  close() -- or leaving the `with` block -- puts the model back as it was.)
+        self._restore = None
         if self._net is not None:
+            self._restore = (bool(getattr(self._net, "heads_hook", False)), "_frozen_version" in self._net.__dict__)
             self._net.heads_hook = True
             if freeze_weights:
                 self._net.freeze_weights()
+
+    def close(self):
+        """Give the wrapped model back: no heads hook in the plans it builds from now on, weights unfrozen unless they were frozen before."""
+        if self._net is not None and self._restore is not None:
+            hook, frozen = self._restore
+            self._net.heads_hook = hook
+            self._net.__dict__.pop("_heads_cb", None)
+            if not frozen:
+                self._net.freeze_weights(False)
+            self._restore = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     # -- demo.py:111-121: make both dims divisible by 32 by a centred crop
     @staticmethod
