@@ -20,9 +20,9 @@ plan.run(); torch.cuda.synchronize()
 assert l.yp_debug_timeline(buf) == 0
 t = list(buf)
 print(f"conv {c1}->{c2} k{k} {H}x{H} B=8 tile {tile}: {ms*1e3:.1f} us per launch (back-to-back)")
-names = {0: "entry", 1: "setup done, bias loads issued", 40: "k loop done", 41: "epilogue stores issued"}
+names = {0: "entry", 1: "setup done, bias loads issued", 40: "k loop done", 41: "epilogue stores issued", 50: "  (tile decoded: first arguments in)", 51: "  (pixel rows decoded)", 52: "  (filter offsets, arguments pinned)"}
 for kt in range(24): names[2 + kt] = f"k tile {kt} landed"
 prev = t[0]
-for i in sorted(names):
+for i in sorted(names, key=lambda i: t[i] if t[i] else 1 << 62):
     if t[i] and (i < 2 or i >= 40 or t[i] > t[1]):
         print(f"  {names[i]:34s} +{t[i]-prev:6d}  = {t[i]-t[0]:7d} clk"); prev = t[i]

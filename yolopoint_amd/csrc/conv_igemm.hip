@@ -212,6 +212,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     const int tile_m = a.mg_tn ? (int)__umulhi((unsigned)logical, a.mg_tn) : logical / a.tiles_n;
     const int tile_n = logical - tile_m * a.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    YP_TL(50);                                                    // (first kernel arguments have arrived, tile decoded)
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -237,6 +238,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
             bb[i] = 0;
         }
     }
+    YP_TL(51);                                                    // (pixel rows decoded)
     const char* b_src[NLB];
     unsigned b_off[NLB];
     int b_slot[NLB];
@@ -279,6 +281,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     YP_PIN(int, in0_ups); YP_PIN(int, in1_ups); YP_PIN(int, in0_H); YP_PIN(int, in1_H); YP_PIN(int, in0_W); YP_PIN(int, in1_W);
     YP_PIN(int, Hi); YP_PIN(int, Wi); YP_PIN(int, Cin); YP_PIN(int, S); YP_PIN(int, invS); YP_PIN(int, dt); YP_PIN(int, dc);
 #undef YP_PIN
+    YP_TL(52);                                                    // (filter offsets, arguments pinned)
     const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     // FAST path state: every lane of the workgroup is in the same filter tap (Cin % BK == 0), so the tap
