@@ -10,7 +10,7 @@ c1, c2, k, Ho, B = 256, 256, 3, 40, 32
 dev = torch.device("cuda:0")
 pb = PlanBuilder(B, _hip.YP_BF16, dev)
 x = pb.new_buf(Ho, Ho, c1); x.t.normal_()
-pb.conv(x.view(), torch.randn(c2, c1, k, k) * 0.02, torch.zeros(c2), k, 1, k // 2, _hip.YP_ACT_SILU, tile=tile)
+pb.conv(x.view(), torch.randn(c2, c1, k, k) * 0.02, torch.zeros(c2), k, 1, k // 2, _hip.YP_ACT_SILU if os.environ.get('YP_TL_ACT', '1') == '1' else _hip.YP_ACT_NONE, tile=tile)
 plan = pb.finish()
 for _ in range(3):
     plan.run()

@@ -125,16 +125,72 @@ __device__ __forceinline__ float yp_silu(float x) {
 
 // Epilogue tail shared by the convolution kernels: (+ residual) -> convert -> store CW consecutive
 // channels [nc, nc+CW) of output pixel m as 8/16-byte vectors, into `out` or (nc >= split) `out2`.
-template <int DT, bool OUT_F32, int CW>
-__device__ __forceinline__ void yp_store_chunk(const ConvKArgs& a, int m, int nc, float (&v)[CW]) {
-    using E = Elem<DT>;
-    constexpr int EB = E::OBYTES;        // (results and the residual they add are 16-bit for the 8-bit input types)
-    if (a.out_sub) {                     // pixel (b, y, x) of the Ho x Wo launch grid -> (b, 2y + py, 2x + px) of the tensor behind `out` / `res`
+// RES: 1 = the launch adds a residual, 0 = it does not, -1 = test a.has_res here.  Callers hoist the test around their store loops
+// (YP_RES_DISPATCH): with the residual load under a branch INSIDE the loop the compiler must place `s_waitcnt vmcnt(0)` at the join in front of
+// every store -- loads and stores share the counter, so each store waited for the previous one's write acknowledgement (~700 clocks): the
+// epilogue of the 256 x 256 kernels was 19-32 k clocks with the stores and 2.6-4.8 k without (round 5, tools/probe/mma8_timeline.py).
+// pixel (b, y, x) of the Ho x Wo launch grid -> (b, 2y + py, 2x + px) of the tensor behind `out` / `res` (a.out_sub launches)
+__device__ __forceinline__ int yp_out_pixel(const ConvKArgs& a, int m) {
+    if (a.out_sub) {
         const int b = m / a.HoWo, rem = m - b * a.HoWo, y = rem / a.Wo, x = rem - y * a.Wo;
         m = (b * 2 * (a.HoWo / a.Wo) + 2 * y + a.out_py) * (2 * a.Wo) + 2 * x + a.out_px;
     }
-    if (a.has_res) {
-        const char* rp = a.res + ((size_t)m * a.res_cs + a.res_co + nc) * EB;
+    return m;
+}
+
+// The residual's CW channels [nc, nc+CW) of output pixel m, as fetched (16-bit types: 8 / 16 bytes; fp32: CW floats): issued for ALL chunks of a
+// pixel before the first of them is used (yp_epilogue_pixel, RES = 1), so that a wave waits once per pixel, not once per chunk.
+template <int DT, int CW>
+struct YpResRaw { u32x4 q[(DT == YP_F32 ? CW * 4 : CW * 2) / 16 > 0 ? (DT == YP_F32 ? CW * 4 : CW * 2) / 16 : 1]; };
+template <int DT, int CW>
+__device__ __forceinline__ YpResRaw<DT, CW> yp_res_fetch(const char* row_rp, int nc) {
+    constexpr int EB = Elem<DT>::OBYTES;
+    const char* rp = row_rp + (size_t)nc * EB;
+    YpResRaw<DT, CW> r;
+    if constexpr (CW * EB >= 16) {
+#pragma unroll
+        for (int i = 0; i < CW * EB / 16; ++i) r.q[i] = *reinterpret_cast<const u32x4*>(rp + 16 * i);
+    } else {
+        const u32x2 lo = *reinterpret_cast<const u32x2*>(rp);
+        r.q[0] = u32x4{lo[0], lo[1], 0u, 0u};
+    }
+    return r;
+}
+template <int DT, int CW>
+__device__ __forceinline__ void yp_res_add(const YpResRaw<DT, CW>& r, float (&v)[CW]) {
+    if constexpr (DT == YP_F32) {
+        const float* e = reinterpret_cast<const float*>(&r);
+#pragma unroll
+        for (int j = 0; j < CW; ++j) v[j] += e[j];
+    } else {
+        using sc = typename Elem<DT>::scalar;
+        const sc* e = reinterpret_cast<const sc*>(&r);
+#pragma unroll
+        for (int j = 0; j < CW; ++j) v[j] += (float)e[j];
+    }
+}
+
+// Row pointers of one output pixel: computed ONCE per pixel (pixel remap of out_sub launches, 64-bit multiplies), a chunk then adds its channel
+// offset and picks its destination with two selects -- branch-free.  (The per-chunk form evaluated both destinations' index arithmetic under
+// exec masks for every chunk: ~190 instructions per 16-byte store.)
+struct YpOutRow { char* p1; char* p2; const char* rp; };
+template <int DT, bool OUT_F32>
+__device__ __forceinline__ YpOutRow yp_out_row(const ConvKArgs& a, int m) {
+    constexpr int OB = (OUT_F32 || DT == YP_F32) ? 4 : 2, EB = Elem<DT>::OBYTES;
+    const size_t mo = (size_t)yp_out_pixel(a, m);
+    YpOutRow r;
+    r.p1 = a.out + (mo * a.out_cs + a.out_co) * OB;
+    r.p2 = a.out2 + ((long)(mo * a.out2_cs + a.out2_co) - (long)a.split) * OB;      // (+ nc * OB for nc >= split; never dereferenced when out2 is unused)
+    r.rp = a.res + (mo * a.res_cs + a.res_co) * EB;
+    return r;
+}
+
+template <int DT, bool OUT_F32, int CW, int RES = -1>
+__device__ __forceinline__ void yp_store_chunk_at(const ConvKArgs& a, const YpOutRow& row, int nc, float (&v)[CW]) {
+    using E = Elem<DT>;
+    constexpr int EB = E::OBYTES;        // (results and the residual they add are 16-bit for the 8-bit input types)
+    if (RES == 1 || (RES < 0 && a.has_res)) {
+        const char* rp = row.rp + (size_t)nc * EB;
         if constexpr (DT == YP_F32) {
 #pragma unroll
             for (int j = 0; j < CW; j += 4) {
@@ -156,16 +212,13 @@ __device__ __forceinline__ void yp_store_chunk(const ConvKArgs& a, int m, int nc
             }
         }
     }
-    const bool second = nc >= a.split;
-    char* const obase = second ? a.out2 : a.out;
-    const size_t oidx = second ? (size_t)m * a.out2_cs + a.out2_co + (nc - a.split) : (size_t)m * a.out_cs + a.out_co + nc;
     if constexpr (OUT_F32 || DT == YP_F32) {
-        char* op = obase + oidx * 4;
+        char* op = (nc >= a.split ? row.p2 : row.p1) + (size_t)nc * 4;
 #pragma unroll
         for (int j = 0; j < CW; j += 4) *reinterpret_cast<f32x4*>(op + j * 4) = f32x4{v[j], v[j + 1], v[j + 2], v[j + 3]};
     } else {
         using sc = typename E::scalar;
-        char* op = obase + oidx * 2;
+        char* op = (nc >= a.split ? row.p2 : row.p1) + (size_t)nc * 2;
         if constexpr (CW == 8) {
             u32x4 pk;
             sc* e = reinterpret_cast<sc*>(&pk);
@@ -181,6 +234,24 @@ __device__ __forceinline__ void yp_store_chunk(const ConvKArgs& a, int m, int nc
         }
     }
 }
+
+template <int DT, bool OUT_F32, int CW, int RES = -1>
+__device__ __forceinline__ void yp_store_chunk(const ConvKArgs& a, int m, int nc, float (&v)[CW]) {
+    yp_store_chunk_at<DT, OUT_F32, CW, RES>(a, yp_out_row<DT, OUT_F32>(a, m), nc, v);
+}
+
+// "These registers have ARRIVED" on every path that follows: a common use of values fetched with global loads (the bias), placed in front of
+// a store loop whose bodies run under lane masks (`if (m >= M) continue`).  Without it the compiler re-waits for the load at the first use inside
+// every masked block -- `s_waitcnt vmcnt(0)`, which also waits for every store issued meanwhile: the stores of a wave ran one write round trip
+// (~700 clocks) apart in every convolution kernel until round 5.
+template <int N>
+__device__ __forceinline__ void yp_pin_arrived(float (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i]));
+}
+
+// body(std::integral_constant<int, RES>) with RES = 1 / 0 by the launch's has_res (see yp_store_chunk)
+#define YP_RES_DISPATCH(a_, body_) do { if ((a_).has_res) body_(std::integral_constant<int, 1>{}); else body_(std::integral_constant<int, 0>{}); } while (0)
 
 // bias -> activation -> yp_store_chunk for the LPG consecutive channels [nb, nb+LPG) a lane owns at pixel m;
 // acc(j) returns the accumulator of lane-local channel j.

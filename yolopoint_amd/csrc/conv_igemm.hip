@@ -52,9 +52,10 @@ extern "C" int yp_debug_wg_times(unsigned long long* out_host, int nwg) { return
 #endif
 
 
-template <int DT, bool OUT_F32, int LPG, typename AccFn>
+template <int DT, bool OUT_F32, int LPG, int RES = -1, typename AccFn>
 __device__ __forceinline__ void yp_epilogue_pixel(const ConvKArgs& a, int m, int nb, const float (&bias)[LPG], AccFn acc) {
     constexpr int CW = LPG < 8 ? LPG : 8;
+    const YpOutRow row = yp_out_row<DT, OUT_F32>(a, m);
 #pragma unroll
     for (int h = 0; h < LPG / CW; ++h) {
         const int nc = nb + h * CW;
@@ -66,7 +67,7 @@ __device__ __forceinline__ void yp_epilogue_pixel(const ConvKArgs& a, int m, int
             if (a.act == YP_ACT_SILU) x = yp_silu(x);
             v[j] = x;
         }
-        yp_store_chunk<DT, OUT_F32, CW>(a, m, nc, v);
+        yp_store_chunk_at<DT, OUT_F32, CW, RES>(a, row, nc, v);
     }
 }
 
@@ -624,6 +625,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     }
     YP_TL(40);
     // ---- epilogue: bias -> activation -> (+ residual) -> store, 16-byte vectors per pixel
+    yp_pin_arrived(bias);
+    auto epilogue = [&](auto res_c) {
+    constexpr int RES = decltype(res_c)::value;
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm) {
         const int m = m0 + wm * TM + fm * 16 + p;
@@ -639,10 +643,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
                 for (int j = 0; j < LPG; ++j)
                     if (nb + j < a.Cout) atomicAdd(reinterpret_cast<float*>(a.out) + (size_t)m * a.out_cs + a.out_co + nb + j, acc[j >> 2][fm][j & 3]);
             } else {
-                yp_epilogue_pixel<DT, OUT_F32, LPG>(a, m, nb, bias, [&](int cj) { return acc[cj >> 2][fm][cj & 3]; });
+                yp_epilogue_pixel<DT, OUT_F32, LPG, RES>(a, m, nb, bias, [&](int cj) { return acc[cj >> 2][fm][cj & 3]; });
             }
         }
     }
+    };
+    YP_RES_DISPATCH(a, epilogue);
     if constexpr (STATS) {
         // BatchNorm statistics of the raw output straight from the accumulators (training forward of a 1x1 Conv: the separate reduction
         // pass re-read the tensor, 5.8 us per layer): per lane sum / sum of squares over its pixels, 16-lane butterfly over the pixel
@@ -924,13 +930,17 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvKArgs a) {
 #pragma unroll
             for (int fm = 0; fm < FM; ++fm) acc[f][fm] *= osc;
     }
+    yp_pin_arrived(bias);
+    auto epilogue = [&](auto res_c) {
 #pragma unroll
-    for (int fm = 0; fm < FM; ++fm) {
-        const int oy = y0 + wm * FM + fm, ox = x0 + p;
-        if (oy >= a.Ho || ox >= a.Wo) continue;
-        const int m = (b * a.Ho + oy) * a.Wo + ox;
-        yp_epilogue_pixel<DT, OUT_F32, LPG>(a, m, nb, bias, [&](int cj) { return acc[cj >> 2][fm][cj & 3]; });
-    }
+        for (int fm = 0; fm < FM; ++fm) {
+            const int oy = y0 + wm * FM + fm, ox = x0 + p;
+            if (oy >= a.Ho || ox >= a.Wo) continue;
+            const int m = (b * a.Ho + oy) * a.Wo + ox;
+            yp_epilogue_pixel<DT, OUT_F32, LPG, decltype(res_c)::value>(a, m, nb, bias, [&](int cj) { return acc[cj >> 2][fm][cj & 3]; });
+        }
+    };
+    YP_RES_DISPATCH(a, epilogue);
     if constexpr (STATS) {
         // BatchNorm statistics of the raw output from the accumulators (training forward of a 3x3 Conv; see the generic kernel): one
         // partial row per pixel tile, stats[(tile*2 + {0,1})*Cout + c] -- the reduction pass that re-read the tensor disappears.
@@ -1257,13 +1267,17 @@ __global__ __launch_bounds__(64 * NWAVES) void bottleneck_halo_kernel(const Conv
 
     YP_TL(40);
     if constexpr (!POST) {
+        yp_pin_arrived(bias);
+        auto epilogue = [&](auto res_c) {
 #pragma unroll
-        for (int fm = 0; fm < FM; ++fm) {
-            const int oy = y0 + wm * FM + fm, ox = x0 + p;
-            if (oy >= a.Ho || ox >= a.Wo) continue;
-            const int m = (b * a.Ho + oy) * a.Wo + ox;
-            yp_epilogue_pixel<DT, false, LPG>(a, m, nb, bias, [&](int cj) { return acc[cj >> 2][fm][cj & 3]; });
-        }
+            for (int fm = 0; fm < FM; ++fm) {
+                const int oy = y0 + wm * FM + fm, ox = x0 + p;
+                if (oy >= a.Ho || ox >= a.Wo) continue;
+                const int m = (b * a.Ho + oy) * a.Wo + ox;
+                yp_epilogue_pixel<DT, false, LPG, decltype(res_c)::value>(a, m, nb, bias, [&](int cj) { return acc[cj >> 2][fm][cj & 3]; });
+            }
+        };
+        YP_RES_DISPATCH(a, epilogue);
         YP_TL(41);
     } else {
         // ---- C3 tail.  The ring is free: fetch W3 (all of it), meanwhile finish the bottleneck output into LDS (it replaces the
@@ -1320,6 +1334,7 @@ __global__ __launch_bounds__(64 * NWAVES) void bottleneck_halo_kernel(const Conv
             b3[4 * q] = b4[0]; b3[4 * q + 1] = b4[1]; b3[4 * q + 2] = b4[2]; b3[4 * q + 3] = b4[3];
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        yp_pin_arrived(b3);
         __builtin_amdgcn_s_barrier();
         YP_TL(41);
         f32x4 acc3[FN3][FM];
@@ -2051,6 +2066,8 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(const ConvKArgs a) {
                 const frag_t yf = *reinterpret_cast<const frag_t*>(hsm + pix * 128 + (((4 * ks + g) ^ (pix & 7)) << 4));
                 acc3[fm] = E::mma(wf3[ks], yf, acc3[fm]);
             }
+        yp_pin_arrived(b3);
+        auto epilogue3 = [&](auto res_c) {
 #pragma unroll
         for (int fm = 0; fm < FM; ++fm) {
             const int oy = y0 + fm, ox = x0 + p;
@@ -2063,16 +2080,22 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(const ConvKArgs a) {
                 if (a.post_act == YP_ACT_SILU) x = yp_silu(x);
                 v[cj] = x;
             }
-            yp_store_chunk<DT, false, LPG>(a, m, nb, v);
+            yp_store_chunk<DT, false, LPG, decltype(res_c)::value>(a, m, nb, v);
         }
+        };
+        YP_RES_DISPATCH(a, epilogue3);
     } else {
+    yp_pin_arrived(bias);
+    auto epilogue = [&](auto res_c) {
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm) {
         const int oy = y0 + fm, ox = x0 + p;
         if (oy >= a.Ho || ox >= a.Wo) continue;
         const int m = (b * a.Ho + oy) * a.Wo + ox;
-        yp_epilogue_pixel<DT, false, LPG>(a, m, nb, bias, [&](int cj) { return acc[fm][cj]; });
+        yp_epilogue_pixel<DT, false, LPG, decltype(res_c)::value>(a, m, nb, bias, [&](int cj) { return acc[fm][cj]; });
     }
+    };
+    YP_RES_DISPATCH(a, epilogue);
     }
     }
 }
@@ -2332,7 +2355,7 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
         if (yp_mma8_tile_dims(d->tile, &bp8, &bc8, &srows)) {
             const int cg = q8 ? 128 : 64;        // channels per 128-byte k row; the 8-bit (block-scaled MFMA) instantiation exists for tile 57 only
             YP_REQUIRE(fast && d->dtype != YP_F32 && (!q8 || d->tile == 57) && Cin % cg == 0 && d->in0.C % cg == 0 && d->Kpad % cg == 0 && det == nullptr &&
-                       d->pre_weight == nullptr && ksplit == 1 && !a.atomic_out,
+                       d->pre_weight == nullptr && ksplit == 1 && !a.atomic_out && d->R * d->S <= 32,
                        "yp_conv2d: tile %d (8-wave kernel) needs a 16-bit (8-bit: tile 57) fast-path convolution with channel counts %% %d == 0 (Cin %d, in0.C %d)", d->tile, cg, Cin, d->in0.C);
             a.tiles_n = yp_cdiv(Cout, bc8);
             const int nblk8 = yp_cdiv(a.M, bp8) * a.tiles_n;

@@ -75,8 +75,13 @@ template <> struct Mma32<YP_FP8_BF8> {
 // Measured and dropped (same layer, same session; all within +-5 % of schedule 0): DMA inside the MFMA segments,
 // phases of two steps with the DMA split between a load and an MFMA segment, 64-byte rows with a 4-stage ring, one barrier per k tile
 // without the early publication of schedule 8.  tools/probe/mfma_lds_probe.hip reproduces the plateau outside the kernel.
-template <int DT, bool OUT_F32, int BP, int BC, int WP, int WC, int NS, bool STATS, int SCHED = 0>
-__global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
+//
+// NW = 4 (round 5): ONE wavefront per SIMD, a wave = BP pixels x 64 channels (PT = BP / 32 accumulator tiles x 2: up to 256 accumulator
+// registers of the 512 a lone wave owns), free-running schedule only.  No second wave competes for the matrix pipe, so the waves of a
+// workgroup reach the k-tile barrier together (the ~350-clock arrival skew of the 8-wave form is what its 0.73 loop efficiency loses),
+// and BP is any multiple of 32: the host picks the row count that fills the 256 CUs (224 rows: 229 workgroups for M = 51 200 instead of 200).
+template <int DT, bool OUT_F32, int BP, int BC, int WP, int WC, int NS, bool STATS, int SCHED = 0, int NW = 8>
+__global__ __launch_bounds__(NW * 64) void conv_mma8_kernel(const ConvKArgs a) {
     using MM = Mma32<DT>;
     using frag_t = typename MM::frag;
     constexpr int EB = Elem<DT>::BYTES;                                   // 2, or 1 (OCP fp8: a 128-byte row holds 128 k elements = two K = 64 MFMA steps)
@@ -84,12 +89,14 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
     constexpr int ROWB = 128, BK = ROWB / EB;
     constexpr int RPI = 1024 / ROWB, CPR = ROWB / 16, KS = ROWB / (Q8 ? 64 : 32);      // rows per DMA instruction, 16-byte chunks per row, MFMA steps per k tile
     static_assert(!Q8 || SCHED == 7, "8-bit inputs: the two-phase schedule");
-    constexpr int TP = BP / (2 * WP), TC = BC / WC, PT = TP / 32, CT = TC / 32;
-    constexpr int NLP = BP / (8 * RPI), NLW = BC / (8 * RPI), NL = NLP + NLW;           // DMA instructions per wave per k tile
+    constexpr int NG = NW / 4;                                            // wave groups (one wave of each group per SIMD)
+    static_assert(NW == 8 || (NW == 4 && SCHED == 8), "four waves: the free-running schedule");
+    constexpr int TP = BP / (NG * WP), TC = BC / WC, PT = TP / 32, CT = TC / 32;
+    constexpr int NLP = BP / (NW * RPI), NLW = BC / (NW * RPI), NL = NLP + NLW;         // DMA instructions per wave per k tile
     constexpr int STAGE = (BP + BC) * ROWB;
     constexpr int PH = (SCHED == 7) ? KS / 2 : 1, NPH = KS / PH;          // MFMA steps per phase, phases per k tile
     constexpr bool OWNP = SCHED == 7;                                     // pixel-row DMA of a wave covers its own group's rows only                  // 16-deep MFMA steps per phase, phases per k tile
-    static_assert(WP * WC == 4 && PT >= 1 && CT >= 1 && BP % (8 * RPI) == 0 && BC % (8 * RPI) == 0 && NS >= 2 && NS <= 4, "unsupported tile");
+    static_assert(WP * WC == 4 && PT >= 1 && CT >= 1 && TP % 32 == 0 && BP % (NW * RPI) == 0 && BC % (NW * RPI) == 0 && NS >= 2 && NS <= 4, "unsupported tile");
     static_assert((NS - 1) * NL <= 60, "vmcnt immediate range");
 
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -124,7 +131,7 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
     int hi0[NLP], wi0[NLP], bb[NLP];
 #pragma unroll
     for (int i = 0; i < NLP; ++i) {
-        const int m = m0 + RPI * (OWNP ? g * (BP / (2 * RPI)) + wi + 4 * i : wave + 8 * i) + lrow;
+        const int m = m0 + RPI * (OWNP ? g * (BP / (2 * RPI)) + wi + 4 * i : wave + NW * i) + lrow;
         if (m < a.M) {
             const int b = m / a.HoWo;
             const int rem = m - b * a.HoWo;
@@ -150,10 +157,35 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
         pb0[i] = (unsigned)((bb[i] * in0_H + hi0[i]) * in0_W + wi0[i]) * (unsigned)(in0_cs * EB) + lanec;
         pb1[i] = (unsigned)((bb[i] * in1_H + hi0[i]) * in1_W + wi0[i]) * (unsigned)(in1_cs * EB) + lanec;
     }
+    // Tap validity per pixel row as a bit mask (bit kr * S + ks: the tap reads inside the image): a segment change is then four independent VALU
+    // instructions per row.  (The compare / select form with its scalar hops measured ~1 500 clocks per change on a wave alone on its SIMD --
+    // every fourth k tile of a 256-channel 3x3 layer, 7 % of the kernel.)
+    unsigned okm[NLP];
+#pragma unroll
+    for (int i = 0; i < NLP; ++i) okm[i] = 0;
+    if (!slow) {
+        // rows kr in [max(0, -hi0), min(R, Hi - hi0)) and columns ks in [max(0, -wi0), min(S, Wi - wi0)) are inside: two bit ranges per pixel row in
+        // closed form, the tap mask is their outer product (R * S <= 32, host-checked)
+        const int R_ = a.R;
+        auto range = [](int lo, int hi) -> unsigned { return hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u; };
+        unsigned rowm[NLP], colm[NLP];
+#pragma unroll
+        for (int i = 0; i < NLP; ++i) {
+            const int rlo = min(max(0, -hi0[i]), R_), rhi = max(min(R_, Hi - hi0[i]), 0);
+            const int clo = min(max(0, -wi0[i]), S), chi = max(min(S, Wi - wi0[i]), 0);
+            rowm[i] = range(rlo, rhi);
+            colm[i] = range(clo, chi);
+        }
+#pragma unroll 1
+        for (int kr = 0; kr < R_; ++kr) {
+#pragma unroll
+            for (int i = 0; i < NLP; ++i) okm[i] |= (0u - ((rowm[i] >> kr) & 1u)) & (colm[i] << (kr * S));
+        }
+    }
     unsigned w_off[NLW];
 #pragma unroll
     for (int i = 0; i < NLW; ++i) {
-        const int rl = RPI * (wave + 8 * i) + lrow;              // LDS filter row -> output channel (see the header comment)
+        const int rl = RPI * (wave + NW * i) + lrow;             // LDS filter row -> output channel (see the header comment)
         const int wcx = rl / TC, q = rl % TC;
         const int ct = q >> 5, rho = q & 31;
         const int n = n0 + wcx * TC + ((rho >> 2) & 1) * (16 * CT) + ct * 16 + (rho >> 3) * 4 + (rho & 3);
@@ -186,12 +218,14 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
             seg_base = base + (size_t)((s0 ? in0_co : in1_co) + c_in_src) * EB;
             const int csb = cs * EB;
             if (!slow) {
-                const unsigned d = (unsigned)((kr * Wp + ks) * csb);
+                // offset = valid ? pixel base + tap offset : the zero tail behind the buffer; branch-free: zoff + ((pb + d - zoff) & -valid)
+                const unsigned dz = (unsigned)((kr * Wp + ks) * csb) - zoff;
+                if (s0) {
 #pragma unroll
-                for (int i = 0; i < NLP; ++i) {
-                    const int hi = hi0[i] + kr, wi_ = wi0[i] + ks;
-                    const bool ok = (unsigned)hi < (unsigned)Hi && (unsigned)wi_ < (unsigned)Wi;
-                    seg_voff[i] = ok ? (s0 ? pb0[i] : pb1[i]) + d : zoff;      // (out-of-image rows read the zero tail behind the buffer)
+                    for (int i = 0; i < NLP; ++i) seg_voff[i] = zoff + ((pb0[i] + dz) & (unsigned)__builtin_amdgcn_sbfe((int)okm[i], s_tap, 1));
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NLP; ++i) seg_voff[i] = zoff + ((pb1[i] + dz) & (unsigned)__builtin_amdgcn_sbfe((int)okm[i], s_tap, 1));
                 }
             } else {
 #pragma unroll
@@ -214,8 +248,8 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
     // DMA instruction idx of the prepared k tile -> ring stage `stage` (pixel rows first, then filter rows)
     auto issue_one = [&](int stage, int idx) {
         const unsigned sbase = lds0 + (unsigned)stage * STAGE;
-        if (idx < NLP) yp_glds16_s(cur_p, seg_voff[idx < NLP ? idx : 0], sbase + (unsigned)(OWNP ? g * (BP / (2 * RPI)) + wi + 4 * idx : wave + 8 * idx) * 1024u);
-        else yp_glds16_s(cur_w, w_off[idx >= NLP ? idx - NLP : 0], sbase + (unsigned)(BP * ROWB) + (unsigned)(wave + 8 * (idx - NLP)) * 1024u);
+        if (idx < NLP) yp_glds16_s(cur_p, seg_voff[idx < NLP ? idx : 0], sbase + (unsigned)(OWNP ? g * (BP / (2 * RPI)) + wi + 4 * idx : wave + NW * idx) * 1024u);
+        else yp_glds16_s(cur_w, w_off[idx >= NLP ? idx - NLP : 0], sbase + (unsigned)(BP * ROWB) + (unsigned)(wave + NW * (idx - NLP)) * 1024u);
     };
     // schedule 0: the instructions [dma_lo(p), dma_lo(p + 1)) go out in the load segment of phase p (none in the last phase)
     auto dma_lo = [](int slot) -> int { return slot >= 3 ? NL : (slot * NL + 2) / 3; };
@@ -235,7 +269,7 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
             return *reinterpret_cast<const frag_t*>(base + (rd_lane ^ (step << 5)));
         }
     };
-    const char* const p_rd = smem + (g * (BP / 2) + wp * TP) * ROWB;
+    const char* const p_rd = smem + (g * (BP / NG) + wp * TP) * ROWB;
     const char* const w_rd = smem + (BP + wc * TC) * ROWB;
 
     f32x16 acc[CT][PT];
@@ -296,13 +330,50 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
         int stage = 0;
         for (int kt = 0; kt < nk; ++kt) {
             const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+            YP8_TS(0);
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                if (p < 3) load(stage, p + 1, wf[(p + 1) & 1], pf[(p + 1) & 1]);
-                else if (more1) load(stage ^ 1, 0, wf[0], pf[0]);
-                __builtin_amdgcn_sched_barrier(0);
                 const int lo = p == 0 ? DA : (p == 1 ? DB : 0), hi = p == 0 ? DB : (p == 1 ? NL : (p == 3 ? DA : 0));
                 const int nd = hi - lo;
+                if constexpr (NW == 4) {
+                    // One wave per SIMD: nothing else fills the matrix pipe while this wave issues LDS reads (one ds_read_b128 per ~29 clocks
+                    // from a lone wave) or DMA instructions (60-80 clocks each), so they go out ONE PER MFMA, under the 32 clocks the matrix
+                    // pipe spends on it: the step's CT + PT fragment reads for the NEXT step first (w0, p0 .. p(PT-1), w1 ..: the order in which
+                    // the next step's MFMAs consume them), then this step's DMA part.
+                    constexpr int NR = CT + PT;
+                    const int nops = NR + nd;
+                    const char* const rs_p = p_rd + (p < 3 ? stage : stage ^ 1) * STAGE;
+                    const char* const rs_w = w_rd + (p < 3 ? stage : stage ^ 1) * STAGE;
+                    const bool rd_on = p < 3 || more1;
+                    const bool dma_on = (p == 3 ? more2 : more1) && !(probe & 2);
+                    YP8_TS(1 + 4 * p);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < NM; ++i) {
+                        const int ct = i / PT, pt = i % PT;
+                        if (!(probe & 1)) acc[ct][pt] = MM::mma(wf[p & 1][ct], pf[p & 1][pt], acc[ct][pt]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int j = 0; j < nops; ++j) {
+                            if (j * NM / nops != i) continue;
+                            if (j < NR) {
+                                if (rd_on) {
+                                    const int step = (p + 1) & 3;
+                                    if (j == 0) wf[(p + 1) & 1][0] = ld_frag(rs_w, step);
+                                    else if (j <= PT) pf[(p + 1) & 1][j - 1] = ld_frag(rs_p + (j - 1) * 32 * ROWB, step);
+                                    else wf[(p + 1) & 1][j - PT] = ld_frag(rs_w + (j - PT) * 32 * ROWB, step);
+                                }
+                            } else if (dma_on) {
+                                issue_one(p == 3 ? stage : stage ^ 1, lo + j - NR);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+                if (p < 3) load(stage, p + 1, wf[(p + 1) & 1], pf[(p + 1) & 1]);
+                else if (more1) load(stage ^ 1, 0, wf[0], pf[0]);
+                YP8_TS(1 + 4 * p);
+                __builtin_amdgcn_sched_barrier(0);
                 const int every = nd > 0 ? (NM / nd > 0 ? NM / nd : 1) : NM + 1;
                 __builtin_amdgcn_s_setprio(1);                     // (tools/probe/mfma_lds_probe.hip mode 7 vs 5: -8 % with the MFMA cluster prioritised)
 #pragma unroll
@@ -317,15 +388,22 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_setprio(0);
+                }
+                YP8_TS(2 + 4 * p);
                 if (p == 2) {
-                    if (more2) prepare();                          // (tile kt+2: its part A goes out in step 3, behind the barrier)
+                    if (more2 && !(probe & 8)) prepare();          // (tile kt+2: its part A goes out in step 3, behind the barrier)
+                    YP8_TS(18);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    YP8_TS(11);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    YP8_TS(19);
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
+                    YP8_TS(12);
                 }
             }
+            YP8_TS(17);
             stage ^= 1;
         }
     } else {
@@ -468,7 +546,7 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
         }
         const bool owner = NV >= 32 || (lr & 16) == 0;            // (NV = 16: lanes lr and lr ^ 16 hold the same total)
         const int c = nb + mych;
-        const int rb = (tile_m * 2 + g) * WP + wp;
+        const int rb = (tile_m * NG + g) * WP + wp;
         if (owner && c < a.Cout && (size_t)rb * (32 * PT) < (size_t)a.M) {
 #ifndef YP_PROBE_NOSTATSTORE
             a.stats[((size_t)0 * a.Cout + c) * a.stats_rows + rb] = sv[0];
@@ -485,11 +563,25 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
         if (a.bias != nullptr && nb + 4 * q < a.Cout) b4 = *reinterpret_cast<const f32x4*>(a.bias + nb + 4 * q);
         bias[4 * q] = b4[0]; bias[4 * q + 1] = b4[1]; bias[4 * q + 2] = b4[2]; bias[4 * q + 3] = b4[3];
     }
+    // (the bias has ARRIVED on every path into the store loop: without this common use the compiler re-waits -- vmcnt(0), behind the stores
+    // issued meanwhile -- wherever a lane-masked block `m >= M` could have skipped the first use)
+    yp_pin_arrived(bias);
     YP8_TSX(4);
+    auto epilogue = [&](auto res_c) {
+    constexpr int RES = decltype(res_c)::value;
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
-        const int m = m0 + g * (BP / 2) + wp * TP + pt * 32 + lr;
+        const int m = m0 + g * (BP / NG) + wp * TP + pt * 32 + lr;
         if (m >= a.M) continue;
+        const YpOutRow row = yp_out_row<DT, OUT_F32>(a, m);
+        YpResRaw<DT, 8> raw[CT][2];              // (RES: the pixel's residual chunks, fetched together -- one wait per pixel)
+        if constexpr (RES == 1) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int h8 = 0; h8 < 2; ++h8)
+                    if (nb + ct * 16 + h8 * 8 < a.Cout) raw[ct][h8] = yp_res_fetch<DT, 8>(row.rp, nb + ct * 16 + h8 * 8);
+        }
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
@@ -503,24 +595,27 @@ __global__ __launch_bounds__(512) void conv_mma8_kernel(const ConvKArgs a) {
                     if (a.act == YP_ACT_SILU) x = yp_silu(x);
                     v[j] = x;
                 }
-                yp_store_chunk<DT, OUT_F32, 8>(a, m, nc, v);
+                if constexpr (RES == 1) yp_res_add<DT, 8>(raw[ct][h8], v);
+                if (!(probe & 32) || v[0] == 1.2345e-30f) yp_store_chunk_at<DT, OUT_F32, 8, 0>(a, row, nc, v);
             }
         }
     }
+    };
+    YP_RES_DISPATCH(a, epilogue);
     YP8_TSX(5);
     YP8_TS_FLUSH2();
 }
 
 namespace {
 
-template <int DT, bool OUT_F32, int BP, int BC, int WP, int WC, int NS, bool STATS, int SCHED = 0>
+template <int DT, bool OUT_F32, int BP, int BC, int WP, int WC, int NS, bool STATS, int SCHED = 0, int NW = 8>
 hipError_t launch_mma8(const ConvKArgs& a, int nblk, hipStream_t st) {
     constexpr size_t lds = (size_t)NS * (BP + BC) * 128;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = conv_mma8_kernel<DT, OUT_F32, BP, BC, WP, WC, NS, STATS, SCHED>;
+    auto kern = conv_mma8_kernel<DT, OUT_F32, BP, BC, WP, WC, NS, STATS, SCHED, NW>;
     static YpLdsAttr attr;        // per instantiation, per device
     if (hipError_t e = yp_set_max_lds(attr, (const void*)kern, (int)lds); e != hipSuccess) return e;
-    kern<<<nblk, 512, lds, st>>>(a);
+    kern<<<nblk, NW * 64, lds, st>>>(a);
     return hipGetLastError();
 }
 
@@ -533,6 +628,11 @@ hipError_t dispatch_mma8(int tile, const ConvKArgs& a, int nblk, hipStream_t st)
         case 44: return launch_mma8<DT, OUT_F32, 128, 128, 1, 4, 2, STATS>(a, nblk, st);
         case 57: return launch_mma8<DT, OUT_F32, 256, 256, 1, 4, 2, STATS, 7>(a, nblk, st);
         case 58: return launch_mma8<DT, OUT_F32, 256, 256, 1, 4, 2, STATS, 8>(a, nblk, st);
+        // one wave per SIMD (NW = 4), BP x 256 tiles with BP = 256 / 224 / 192 / 160
+        case 61: return launch_mma8<DT, OUT_F32, 256, 256, 1, 4, 2, STATS, 8, 4>(a, nblk, st);
+        case 62: return launch_mma8<DT, OUT_F32, 224, 256, 1, 4, 2, STATS, 8, 4>(a, nblk, st);
+        case 63: return launch_mma8<DT, OUT_F32, 192, 256, 1, 4, 2, STATS, 8, 4>(a, nblk, st);
+        case 64: return launch_mma8<DT, OUT_F32, 160, 256, 1, 4, 2, STATS, 8, 4>(a, nblk, st);
         default: return hipErrorInvalidValue;
     }
 }
@@ -546,6 +646,10 @@ bool yp_mma8_tile_dims(int tile, int* bp, int* bc, int* stat_rows_px) {
         case 42: p = 256; c = 128; r = 64; break;
         case 43: p = 128; c = 256; r = 64; break;
         case 44: p = 128; c = 128; r = 64; break;
+        case 61: p = 256; c = 256; r = 256; break;
+        case 62: p = 224; c = 256; r = 224; break;
+        case 63: p = 192; c = 256; r = 192; break;
+        case 64: p = 160; c = 256; r = 160; break;
         default: return false;
     }
     if (bp) *bp = p;

@@ -200,7 +200,7 @@ _TUNE_CACHE = {}
 # (tools/probe/wsk_ab.sh); as tuner candidates under a random variant mixture they broke the fused-stem equivalence tests.)
 _TUNE_CANDIDATES = (1, 2, 3, 4, 5, 21, 22, 23, 24, 25, 26, 27, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 41, 42, 43, 44, 57, 58)
 # pixels per BatchNorm-statistics row of the variants whose rows are plain pixel blocks (the 3x3 halo kernels write one row per image tile)
-_STAT_ROW_PX = {41: 128, 57: 128, 58: 128}
+_STAT_ROW_PX = {41: 128, 57: 128, 58: 128, 61: 256, 62: 224, 63: 192, 64: 160}
 _TUNE_ITERS = int(os.environ.get("YP_TUNE_ITERS", "8"))      # timed launches per candidate
 _TUNE_COLD = int(os.environ.get("YP_TUNE_COLD", "0"))        # MB swept through the L2s in front of every timed launch (0: back-to-back, hot)
 _TUNE_FLUSH = None
