@@ -601,7 +601,58 @@ __global__ __launch_bounds__(NW * 64) void conv_mma8_kernel(const ConvKArgs a) {
         }
     }
     };
-    YP_RES_DISPATCH(a, epilogue);
+    // 16-bit output without residual / pixel remap, waves of TP x 64 outputs: the wave's block goes through the (now idle) pipeline LDS so that a
+    // store instruction writes 8 whole 128-byte lines (lane -> row lane / 8, 16-byte chunk lane % 8) instead of 16-byte pieces of 32 lines
+    // (one wave per SIMD: epilogue 18.4 k -> 15.8 k clocks at 224 rows).  Same fp32 arithmetic, same single rounding: bit-identical outputs.
+    bool staged = false;
+    if constexpr (!OUT_F32 && WP == 1 && CT == 2) {
+        if (!a.has_res && !a.out_sub) {
+            staged = true;
+            using sc = typename Elem<DT>::scalar;
+            __syncthreads();                                          // (every wave is done with the last k tile's fragments)
+            char* const my = smem + wave * (TP * 128);                // wave-private: TP rows x 128 bytes (64 channels); NW * TP = 4 * BP rows in all
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int h8 = 0; h8 < 2; ++h8) {
+                        u32x4 pk;
+                        sc* e = reinterpret_cast<sc*>(&pk);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            float x = acc[ct][pt][h8 * 8 + j] + bias[ct * 16 + h8 * 8 + j];
+                            if (a.act == YP_ACT_SILU) x = yp_silu(x);
+                            e[j] = (sc)x;
+                        }
+                        const int c = hh * (2 * CT) + ct * 2 + h8;    // 16-byte chunk of the pixel's 64 channels
+                        *reinterpret_cast<u32x4*>(my + (pt * 32 + lr) * 128 + ((c ^ (lr & 7)) << 4)) = pk;
+                    }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (own writes only: the block is wave-private)
+            const int rr = lane >> 3, cc = lane & 7;
+            const int nc = n0 + wc * TC + cc * 8;
+            const bool second = nc >= a.split;
+            char* const obase = second ? a.out2 : a.out;
+            const size_t ocs = second ? (size_t)a.out2_cs : (size_t)a.out_cs;
+            const long oco = second ? (long)a.out2_co - (long)a.split + nc : (long)a.out_co + nc;
+            constexpr int NB = 8;                                     // rows-of-8 per batch: NB reads in flight, then NB stores (TP / 16: no faster)
+#pragma unroll
+            for (int j0 = 0; j0 < TP / 8; j0 += NB) {
+                u32x4 d[NB];
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    if (j0 + j < TP / 8) d[j] = *reinterpret_cast<const u32x4*>(my + ((j0 + j) * 8 + rr) * 128 + ((cc ^ rr) << 4));
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    if (j0 + j >= TP / 8) continue;
+                    const int m = m0 + g * (BP / NG) + wp * TP + (j0 + j) * 8 + rr;
+                    if (m < a.M && nc < a.Cout && !((probe & 32) && d[j][0] != 0x12345678u))
+                        *reinterpret_cast<u32x4*>(obase + ((size_t)m * ocs + oco) * 2) = d[j];
+                }
+            }
+        }
+    }
+    if (!staged) YP_RES_DISPATCH(a, epilogue);
     YP8_TSX(5);
     YP8_TS_FLUSH2();
 }
@@ -628,11 +679,11 @@ hipError_t dispatch_mma8(int tile, const ConvKArgs& a, int nblk, hipStream_t st)
         case 44: return launch_mma8<DT, OUT_F32, 128, 128, 1, 4, 2, STATS>(a, nblk, st);
         case 57: return launch_mma8<DT, OUT_F32, 256, 256, 1, 4, 2, STATS, 7>(a, nblk, st);
         case 58: return launch_mma8<DT, OUT_F32, 256, 256, 1, 4, 2, STATS, 8>(a, nblk, st);
-        // one wave per SIMD (NW = 4), BP x 256 tiles with BP = 256 / 224 / 192 / 160
+        // one wave per SIMD (NW = 4), BP x 256 tiles with BP = 256 / 224  (192 and 160 rows were built and measured: 111 / 431 us against 69 on the
+        // 256 -> 256 3x3 layer at 40 x 40 x 32 -- the DMA path per MFMA grows as the tile shrinks -- and removed; a wave of 128 x 128 outputs, 8 fragment
+        // reads per 16 MFMAs, needs 256 accumulator + 64 double-buffered fragment registers beside the addressing state and spills: 1 290 us)
         case 61: return launch_mma8<DT, OUT_F32, 256, 256, 1, 4, 2, STATS, 8, 4>(a, nblk, st);
         case 62: return launch_mma8<DT, OUT_F32, 224, 256, 1, 4, 2, STATS, 8, 4>(a, nblk, st);
-        case 63: return launch_mma8<DT, OUT_F32, 192, 256, 1, 4, 2, STATS, 8, 4>(a, nblk, st);
-        case 64: return launch_mma8<DT, OUT_F32, 160, 256, 1, 4, 2, STATS, 8, 4>(a, nblk, st);
         default: return hipErrorInvalidValue;
     }
 }
@@ -648,8 +699,6 @@ bool yp_mma8_tile_dims(int tile, int* bp, int* bc, int* stat_rows_px) {
         case 44: p = 128; c = 128; r = 64; break;
         case 61: p = 256; c = 256; r = 256; break;
         case 62: p = 224; c = 256; r = 224; break;
-        case 63: p = 192; c = 256; r = 192; break;
-        case 64: p = 160; c = 256; r = 160; break;
         default: return false;
     }
     if (bp) *bp = p;
