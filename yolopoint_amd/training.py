@@ -699,7 +699,10 @@ class TrainGraph:
                 b.op(_hip.OP_DETECT_BWD_PACK, [self.T(gx)], [draw], "seed_det", f=[gx, self.head_scale], v=[draw], i=[code, b.B, det.na, det.no])
                 self.conv_backward([v], mi.weight, mi.bias, draw, 1, 1, 0)
             det_seeds.append(det_backward)
-        det_lanes = fwd_lanes and os.environ.get("YP_TRAIN_DET_LANES", "0") == "1"
+        # Detect levels 0 / 1 (a 1x1 convolution + its epilogue each) on the side lane beside Conv8 / Conv9 of the PAN.  Round 5, after the convolution
+        # epilogues stopped waiting for their own stores: -s step 7.19 -> 6.83 ms at batch 8 (same box, two pairs; 7.02 -> 6.79 with the previous
+        # library), -l and batch 64 unchanged (33.4 / 33.4, 29.6 / 29.7, 41.8 / 42.1 ms).  YP_TRAIN_DET_LANES=0: off.  Same kernels, same bits.
+        det_lanes = fwd_lanes and os.environ.get("YP_TRAIN_DET_LANES", "1") == "1"
         with self.side_lane(f, det_lanes):
             detect_level(0, xf)
         x = self.conv_bn_act(net.Conv8, xf)
