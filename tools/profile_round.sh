@@ -71,10 +71,10 @@ python $ROOT/tools/train_traffic.py $OUT/pmc_tf $OUT/pmc_tw v52_s_8_f16 $OUT/tra
 rm -rf $OUT/pmc_tf $OUT/pmc_tw
 cd $ROOT
 # the 8-wave kernels: per-layer tables (16-bit and 8-bit) and the SQ / LDS counters of one deep layer per schedule
-python tools/conv_bench.py --set l32 --dtype bf16 --tiles 0,3,41,42,43,44,57,58 --min-cin 64 > $OUT/${R}_conv_bench_l32_bf16.txt 2>/dev/null
+python tools/conv_bench.py --set l32 --dtype bf16 --tiles 0,3,41,42,43,44,57,58,61,62 --min-cin 64 --iters 50 > $OUT/${R}_conv_bench_l32_bf16.txt 2>/dev/null
 python tools/conv_bench.py --set s64 --dtype f16 --tiles 0,3,41,42,43,44,57,58 --min-cin 64 > $OUT/${R}_conv_bench_s64_f16.txt 2>/dev/null
 python tools/conv_bench_fp8.py --tiles 0,2,3,57 > $OUT/${R}_conv_bench_fp8_l32.txt 2>/dev/null
-bash tools/probe/pmc_mma8.sh l32 c256_256_k3_40 41,57,58,3 > $OUT/${R}_mma8_pmc_c256_256_k3_40.txt 2>&1
+bash tools/probe/pmc_mma8.sh l32 c256_256_k3_40 41,57,58,62,3 > $OUT/${R}_mma8_pmc_c256_256_k3_40.txt 2>&1
 bash tools/probe/pmc_mma8.sh l32 c2048_1024_k1_20 41,57,3 > $OUT/${R}_mma8_pmc_c2048_1024_k1_20.txt 2>&1
 rm -rf $ROOT/gpurun_out/pmc8_*
 # raw traces are large: keep only what profile_collect distilled
