@@ -74,18 +74,34 @@ __device__ __forceinline__ void yp_epilogue_pixel(const ConvKArgs& a, int m, int
 // Detect-head decode of one element (reference models/yolo.py:53-68): channel n = a*no + o of pixel
 // (b, rem = y*nx + x) goes to x_out[b, a, y, x, o] untouched and, decoded, to z[b, row_off + (a*ny + y)*nx + x, o]:
 //   xy = (2*sigmoid - 0.5 + grid) * stride, wh = (2*sigmoid)^2 * anchor_px, the rest = sigmoid.
-__device__ __forceinline__ void yp_detect_store(const ConvKArgs& a, int b, int rem, int y, int x, int n, float v) {
+// The anchor of a lane's (dynamic) anchor index, selected from the table held in registers.  Indexing a.det_anchor[] per lane is a GLOBAL load out
+// of the kernel-argument segment whose wait, `vmcnt(0)`, also waits for every store issued before it: one write round trip per loop iteration of
+// the Detect epilogue until round 5.
+struct YpAnchors {
+    float t[16];
+    __device__ __forceinline__ void load(const ConvKArgs& a) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t[i] = a.det_anchor[i];          // constant indices: scalar loads
+    }
+    __device__ __forceinline__ void pick(int an, float& aw, float& ah) const {
+        aw = t[0]; ah = t[1];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) { aw = an == k ? t[2 * k] : aw; ah = an == k ? t[2 * k + 1] : ah; }
+    }
+};
+__device__ __forceinline__ void yp_detect_store(const ConvKArgs& a, const YpAnchors& anchors, int b, int rem, int y, int x, int n, float v) {
     const int no = a.det_no;
     const int an = (n * a.det_invno) >> 16, o = n - an * no;
     const size_t cell = (size_t)(b * a.det_na + an) * a.HoWo + rem;
     a.det_x[cell * no + o] = v;
     if (a.det_z != nullptr) {
         const float s = yp_sigmoid(v);
-        float z;
+        float z, aw, ah;
+        anchors.pick(an, aw, ah);
         if (o == 0) z = (s * 2.0f - 0.5f + (float)x) * a.det_stride;
         else if (o == 1) z = (s * 2.0f - 0.5f + (float)y) * a.det_stride;
-        else if (o == 2) { const float t2 = s * 2.0f; z = t2 * t2 * a.det_anchor[an * 2]; }
-        else if (o == 3) { const float t2 = s * 2.0f; z = t2 * t2 * a.det_anchor[an * 2 + 1]; }
+        else if (o == 2) { const float t2 = s * 2.0f; z = t2 * t2 * aw; }
+        else if (o == 3) { const float t2 = s * 2.0f; z = t2 * t2 * ah; }
         else z = s;
         const size_t row = (size_t)a.det_row_off + (size_t)an * a.HoWo + rem;
         a.det_z[((size_t)b * a.det_rows_total + row) * no + o] = z;
@@ -702,6 +718,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
         constexpr int PITCH = BN + (BN < 128 ? 1 : 0);
         static_assert(BM * PITCH * 4 <= NS * STAGE, "detect staging tile must fit the pipeline LDS");
         float* tile = reinterpret_cast<float*>(smem);
+        YpAnchors anchors;
+        anchors.load(a);
         __syncthreads();                  // every wave has consumed the last k tile (its DMAs were drained above)
 #pragma unroll
         for (int fm = 0; fm < FM; ++fm)
@@ -731,6 +749,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
                 if (a.det_z != nullptr) {
                     float zz[4];
                     const float vv[4] = {v0, v1, v2, v3};
+                    float aw, ah;
+                    anchors.pick(an, aw, ah);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float sg = yp_sigmoid(vv[j]);
@@ -738,8 +758,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
                         float z;
                         if (oj == 0) z = (sg * 2.0f - 0.5f + (float)x) * a.det_stride;
                         else if (oj == 1) z = (sg * 2.0f - 0.5f + (float)y) * a.det_stride;
-                        else if (oj == 2) { const float t2 = sg * 2.0f; z = t2 * t2 * a.det_anchor[an * 2]; }
-                        else if (oj == 3) { const float t2 = sg * 2.0f; z = t2 * t2 * a.det_anchor[an * 2 + 1]; }
+                        else if (oj == 2) { const float t2 = sg * 2.0f; z = t2 * t2 * aw; }
+                        else if (oj == 3) { const float t2 = sg * 2.0f; z = t2 * t2 * ah; }
                         else z = sg;
                         zz[j] = z;
                     }
@@ -750,7 +770,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (n + j < nreal) yp_detect_store(a, b, rem, y, x, n + j, src[j]);
+                    if (n + j < nreal) yp_detect_store(a, anchors, b, rem, y, x, n + j, src[j]);
             }
         }
     }
