@@ -567,21 +567,54 @@ __global__ __launch_bounds__(NW * 64) void conv_mma8_kernel(const ConvKArgs a) {
     // issued meanwhile -- wherever a lane-masked block `m >= M` could have skipped the first use)
     yp_pin_arrived(bias);
     YP8_TSX(4);
+    YpResRaw<DT, 8> res_next[CT][2];                // (residual launches: the next pixel's chunks, in flight across this pixel's stores)
     auto epilogue = [&](auto res_c) {
     constexpr int RES = decltype(res_c)::value;
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
         const int m = m0 + g * (BP / NG) + wp * TP + pt * 32 + lr;
-        if (m >= a.M) continue;
-        const YpOutRow row = yp_out_row<DT, OUT_F32>(a, m);
-        YpResRaw<DT, 8> raw[CT][2];              // (RES: the pixel's residual chunks, fetched together -- one wait per pixel)
         if constexpr (RES == 1) {
+            // Residual launches: NO control flow between the pixel's fetches and its stores (rows / chunks outside the tensor fetch a valid
+            // address and skip only the store), and the NEXT pixel's residual is fetched before this pixel's stores go out: the wait for it then
+            // leaves those stores in flight (loads and stores retire through one in-order counter).
+            auto fetch = [&](int pt_, YpResRaw<DT, 8> (&r)[CT][2]) {
+                const int m_ = m0 + g * (BP / NG) + wp * TP + pt_ * 32 + lr;
+                const YpOutRow row_ = yp_out_row<DT, OUT_F32>(a, m_ < a.M ? m_ : a.M - 1);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int h8 = 0; h8 < 2; ++h8) {
+                        const int nc = nb + ct * 16 + h8 * 8;
+                        r[ct][h8] = yp_res_fetch<DT, 8>(row_.rp, nc < a.Cout ? nc : 0);
+                    }
+            };
+            YpResRaw<DT, 8> raw[CT][2];
+            if (pt == 0) fetch(0, res_next);
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                for (int h8 = 0; h8 < 2; ++h8)
-                    if (nb + ct * 16 + h8 * 8 < a.Cout) raw[ct][h8] = yp_res_fetch<DT, 8>(row.rp, nb + ct * 16 + h8 * 8);
-        }
+                for (int h8 = 0; h8 < 2; ++h8) raw[ct][h8] = res_next[ct][h8];
+            if (pt + 1 < PT) fetch(pt + 1, res_next);
+            const YpOutRow row = yp_out_row<DT, OUT_F32>(a, m < a.M ? m : a.M - 1);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+                for (int h8 = 0; h8 < 2; ++h8) {
+                    const int nc = nb + ct * 16 + h8 * 8;
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float x = acc[ct][pt][h8 * 8 + j] + bias[ct * 16 + h8 * 8 + j];
+                        if (a.act == YP_ACT_SILU) x = yp_silu(x);
+                        v[j] = x;
+                    }
+                    yp_res_add<DT, 8>(raw[ct][h8], v);
+                    if (m < a.M && nc < a.Cout) yp_store_chunk_at<DT, OUT_F32, 8, 0>(a, row, nc, v);
+                }
+            }
+        } else {
+        if (m >= a.M) continue;
+        const YpOutRow row = yp_out_row<DT, OUT_F32>(a, m);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
@@ -595,9 +628,9 @@ __global__ __launch_bounds__(NW * 64) void conv_mma8_kernel(const ConvKArgs a) {
                     if (a.act == YP_ACT_SILU) x = yp_silu(x);
                     v[j] = x;
                 }
-                if constexpr (RES == 1) yp_res_add<DT, 8>(raw[ct][h8], v);
                 if (!(probe & 32) || v[0] == 1.2345e-30f) yp_store_chunk_at<DT, OUT_F32, 8, 0>(a, row, nc, v);
             }
+        }
         }
     }
     };
