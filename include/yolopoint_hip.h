@@ -530,7 +530,9 @@ int yp_csr_build(const int* keys, int n_items, int n_buckets, int wide_buckets, 
  *   yp_loss_combine  train.py:232-241: out4[0] = (sum(det_losses[0..n_det)) + lambda_desc * mean(nce_rows[0..n_rows))) + lambda_obj *
  *                    sum(obj_sums[0..3)), times `scale` when it is not 1; out4[1..3] = the detector / descriptor / object terms;
  *                    *desc_scale_out = desc_scale (the device scalar yp_infonce_bwd_db reads; NULL: not written).  n_rows_dev (may be NULL):
- *                    the row count lives on the device (yp_nce_select's meta[1]); desc_scale is then g_desc / (tau * n) computed there */
+ *                    the row count lives on the device (yp_nce_select's meta[1]); desc_scale is then g_desc / (tau * n) computed there, and
+ *                    out4 has FIVE floats: out4[4] = n as a float (0: an image had no valid cell under its warp -- the step ran without a
+ *                    descriptor term, where the reference's mean over nothing would have been NaN) */
 typedef struct YpAddEntry {
     float* dst;
     const float* src;

@@ -871,7 +871,10 @@ def test_image_without_valid_cells_under_the_warp(cuda, monkeypatch):
                 step(batch)
             continue
         loss = float(step(batch))
-        total, det, desc, obj = step.last_loss_terms.tolist()
+        total, det, desc, obj = step.last_loss_terms.tolist()[:4]
         assert desc == 0.0 and math.isfinite(loss) and det > 0.0 and obj > 0.0
+        with pytest.warns(UserWarning, match="without a descriptor"):          # the explicit row count of the native stage (out4[4])
+            terms = step.loss_terms()
+        assert step.last_nce_rows == 0 and len(terms) == 4 and terms[2] == 0.0
         assert all(bool(torch.isfinite(p.grad).all()) for p in m.parameters() if p.grad is not None)
         assert all(bool(torch.isfinite(p).all()) for p in m.parameters())

@@ -42,7 +42,8 @@ __device__ __forceinline__ double wave_sum_f64(double a) {
 }
 
 // total = (sum of the detector-group losses + lambda_desc * mean(rows)) + lambda_obj * (obj[0] + obj[1] + obj[2]), times `scale` when it
-// is not 1 -- the expression of train.py:232-241 in its order; out[0..3] = total, detector, descriptor, object terms.
+// is not 1 -- the expression of train.py:232-241 in its order; out[0..3] = total, detector, descriptor, object terms; with a device-side row
+// count also out[4] = that count.
 // desc_scale_out (the scalar the InfoNCE backward multiplies its gradients with) = desc_scale.
 __global__ __launch_bounds__(256) void loss_combine_kernel(const float* __restrict__ det, int n_det, const float* __restrict__ rows, int n_rows,
                                                            const float* __restrict__ obj, float lambda_desc, float lambda_obj, float scale, float desc_scale,
@@ -65,6 +66,7 @@ __global__ __launch_bounds__(256) void loss_combine_kernel(const float* __restri
         float total = (l_det + lambda_desc * l_desc) + lambda_obj * l_obj;
         if (scale != 1.0f) total *= scale;
         out[0] = total; out[1] = l_det; out[2] = l_desc; out[3] = l_obj;
+        if (n_rows_dev != nullptr) out[4] = (float)n_rows;          // the InfoNCE row count the step ran with (0: empty sampling pool, no descriptor term)
         if (desc_scale_out != nullptr) *desc_scale_out = desc_scale;
     }
 }

@@ -205,12 +205,16 @@ class TrainStep:
     def loss_terms(self):
         """[total, detector, descriptor, object] of the last micro-batch as Python floats (one host read-back).  The device-count form of the
         native stage cannot raise when an image has no valid cell under the warp (the pool is empty; the reference would average over nothing:
-        NaN) -- that step runs WITHOUT a descriptor term.  A real InfoNCE value is never exactly zero, so the condition is reported here."""
+        NaN) -- that step runs WITHOUT a descriptor term.  The native stage reports its InfoNCE row count beside the terms (`last_nce_rows`,
+        0 = empty pool); the autograd formulation is recognised by a descriptor term of exactly zero."""
         t = getattr(self, "last_loss_terms", None)
         if t is None:
             return None
         v = [float(x) for x in t.detach().float().cpu().tolist()]
-        if len(v) >= 3 and v[2] == 0.0:
+        rows = v[4] if len(v) >= 5 else None                 # native stage: the InfoNCE row count of the step (yp_loss_combine's out4[4])
+        v = v[:4]
+        self.last_nce_rows = None if rows is None else int(rows)
+        if (rows == 0.0) if rows is not None else (len(v) >= 3 and v[2] == 0.0):
             import warnings
             warnings.warn("TrainStep: the last step ran without a descriptor (InfoNCE) term -- an image of the batch had no valid cell under its "
                           "homography (empty sampling pool); check the warps / valid masks of the batch")
@@ -358,7 +362,7 @@ class TrainStep:
             # samples): 128 workgroups 34.6-34.8 ms, 256 / 384 / 768: 34.9 / 35.0 / 35.5, 96 / 64 / 32: 35.3 / 38.5 / 49.6
             # (16-bit rows, D = 256: 96 / 128 / 192 workgroups 29.94 / 30.35 / 29.96 ms per -l fp8 step, same box)
             nce_wgs = int(os.environ.get("YP_NCE_WGS", "256" if D <= 128 else ("96" if g.code == _hip.YP_BF16 and os.environ.get("YP_NCE_ROWS", "bf16") == "bf16" else "128"))) if lanes >= 2 else 0
-            out4_ = torch.empty((4,), dtype=torch.float32, device=dev)
+            out4_ = torch.empty((8,), dtype=torch.float32, device=dev)        # [total, detector, descriptor, object, InfoNCE row count, -, -, -]
             if isinstance(nce, dict):
                 # counts on the device (infonce_prepare(sync=False)): arrays at their capacity, the kernels read points-per-image / matched rows
                 # from the sampling's meta words -- no host synchronisation anywhere in the step
