@@ -704,6 +704,9 @@ int yp_plan_set_lane(YpPlan* plan, int op, int lane);
  * auxiliary stream for the caller (engine.TrainStep's loss / label stream).  The streams live as long as the process.
  * (no reference counterpart: the reference runs everything on PyTorch's current stream) */
 int yp_stream_pick(void* main_stream, int slot, void** out_stream);
+/* Forget the picks made for `main_stream` on the current device ((void*)-1: for every stream): to be called when the caller destroys that
+ * stream -- a later stream at the same address would otherwise inherit companions tested against another queue assignment. */
+int yp_stream_forget(void* main_stream);
 
 typedef int (*yp_plan_callback_t)(void* user, void* stream);
 int yp_plan_add_callback(YpPlan* plan, yp_plan_callback_t fn, void* user);

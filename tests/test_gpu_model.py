@@ -227,6 +227,12 @@ def test_stream_pick_returns_tested_companions(cuda):
     assert not busy.query(), "the side lane's work waited for the caller's stream: the two share a hardware queue"
     torch.cuda.synchronize()
     assert float(y.sum()) == 8.0
+    # a caller that destroys its stream tells the library: the picks are made (and tested) again for whatever stream shows up at that address
+    _hip.check(l.yp_stream_forget(C.c_void_p(main.cuda_stream)))
+    out = C.c_void_p()
+    _hip.check(l.yp_stream_pick(C.c_void_p(main.cuda_stream), 0, C.byref(out)))
+    assert out.value is not None and out.value != main.cuda_stream
+    _hip.check(l.yp_stream_forget(C.c_void_p(-1)))
 
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])

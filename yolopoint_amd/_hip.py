@@ -100,6 +100,7 @@ SIGNATURES = {
     "yp_plan_set_lane": (_i, [_p, _i, _i]),
     "yp_plan_add_callback": (_i, [_p, _p, _p]),
     "yp_stream_pick": (_i, [_p, _i, _p]),
+    "yp_stream_forget": (_i, [_p]),
     "yp_bn_finalize": (_i, [_p, _i, _i, C.c_double, _f, _f, _p, _p, _p, _p, _p]),
     "yp_bn_stats_grouped": (_i, [YpView, _i, _i, _i, _f, _f, _p, _p, _p, _p, _p, _sz, _p]),
     "yp_bn_finalize_grouped": (_i, [_p, _i, _i, _i, C.c_double, _f, _f, _p, _p, _p, _p, _p]),

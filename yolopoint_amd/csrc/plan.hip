@@ -290,6 +290,20 @@ extern "C" int yp_stream_pick(void* main_stream, int slot, void** out) {
     return YP_OK;
 }
 
+// Forget the companions of `main_stream` on the current device (main_stream == (void*)-1: of every stream): a caller that DESTROYS a stream it
+// passed to yp_stream_pick (or to a plan replay with a side lane) calls this, because a later stream may reuse the handle's address and would
+// inherit picks that were tested against another hardware-queue assignment.  The pool streams themselves stay (never destroyed, see above).
+extern "C" int yp_stream_forget(void* main_stream) {
+    int dev = 0;
+    YP_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_side_mutex);
+    DevStreams& ds = g_dev_streams[dev & 63];
+    if (main_stream == (void*)-1) { ds.sets.clear(); return YP_OK; }
+    for (size_t i = 0; i < ds.sets.size(); ++i)
+        if (ds.sets[i].main == (hipStream_t)main_stream) { ds.sets.erase(ds.sets.begin() + i); break; }
+    return YP_OK;
+}
+
 static int ensure_side(YpPlan* plan, hipStream_t st) {
     void* s = nullptr;
     if (int rc = yp_stream_pick((void*)st, 0, &s)) return rc;
