@@ -155,26 +155,37 @@ class YOLOPoint(HipModule):
         xa = x if fused_b1 else run("Bottleneck1", self.Bottleneck1, x)
         x8 = run("Conv3", self.Conv3, xa)
         xb = run("Bottleneck2", self.Bottleneck2, x8)
+        fork = int(__import__("os").environ.get("YP_HEADS_FORK", "4"))        # the heads are forked behind Bottleneck<fork> (2 / 3 / 4; measurements above)
+        heads = {}
+
+        def emit_heads():
+            with pb.side():
+                # keypoint head
+                t = run("BottleneckDet", self.BottleneckDet, x8)
+                pb.scope.append("ConvDet")
+                heads["semi"] = pb.conv(t, self.ConvDet.weight.detach().float(), None, 1, 1, 0, _hip.YP_ACT_NONE, out_f32=True)
+                pb.scope.pop()
+                # descriptor head
+                dA = run("ConvDescA", self.ConvDescA, xa)
+                dB = run("ConvDescB", self.ConvDescB, xb)
+                d = run("BottleneckDesc", self.BottleneckDesc, [dA, dB.up()])
+                pb.scope.append("ConvDesc")
+                heads["desc"] = pb.conv(d, self.ConvDesc.weight.detach().float(), None, 3, 1, 1, _hip.YP_ACT_NONE, out_f32=True)
+                pb.l2norm(heads["desc"], heads["desc"], self.ConvDesc.out_channels)
+                pb.scope.pop()
+                self._emit_heads_hook(pb)
+        if fork <= 2:
+            emit_heads()
         # YOLO encoder
         x = run("Conv4", self.Conv4, xb)
         xc = run("Bottleneck3", self.Bottleneck3, x)
+        if fork == 3:
+            emit_heads()
         x = run("Conv5", self.Conv5, xc)
         x = run("Bottleneck4", self.Bottleneck4, x)
-        with pb.side():
-            # keypoint head
-            t = run("BottleneckDet", self.BottleneckDet, x8)
-            pb.scope.append("ConvDet")
-            semi = pb.conv(t, self.ConvDet.weight.detach().float(), None, 1, 1, 0, _hip.YP_ACT_NONE, out_f32=True)
-            pb.scope.pop()
-            # descriptor head
-            dA = run("ConvDescA", self.ConvDescA, xa)
-            dB = run("ConvDescB", self.ConvDescB, xb)
-            d = run("BottleneckDesc", self.BottleneckDesc, [dA, dB.up()])
-            pb.scope.append("ConvDesc")
-            desc = pb.conv(d, self.ConvDesc.weight.detach().float(), None, 3, 1, 1, _hip.YP_ACT_NONE, out_f32=True)
-            pb.l2norm(desc, desc, self.ConvDesc.out_channels)
-            pb.scope.pop()
-            self._emit_heads_hook(pb)
+        if fork >= 4:
+            emit_heads()
+        semi, desc = heads["semi"], heads["desc"]
         x = run("SPPooling", self.SPPooling, x)
         # PAN head; every Detect level right behind the block it reads
         pb.scope.append("Detect")
