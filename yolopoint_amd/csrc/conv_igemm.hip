@@ -21,6 +21,9 @@
 // :135,:229 (cat), models/YOLOPoint.py:186,195 (head convs), models/yolo.py:51 (Detect.m).
 #include "yp_internal.h"
 #include "conv_common.h"
+#ifndef YP_PART
+#define YP_PART 0      // 0: one translation unit (probe builds); 1 / 2: see "Two translation units" above the host code
+#endif
 
 struct __attribute__((packed, aligned(4))) YpF4U { f32x4 v; };      // a 16-byte vector at a 4-byte-aligned address (Detect rows: 85 floats)
 
@@ -2257,6 +2260,55 @@ hipError_t dispatch_bneck(int c, int bn, bool post, bool waves8, const ConvKArgs
     return launch_bneck<DT, 128, 128, 2, false>(a, nblk, st);
 }
 
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// Two translation units from this one file (compile time: 285 kernel instantiations, ~4.5 minutes in one piece).  -DYP_PART=1: the generic
+// kernel's instantiations + the host API; -DYP_PART=2: the halo family (conv3x3_halo / bottleneck_halo / bneck32_persist / stem_conv2 /
+// stem_conv) behind the plain functions below; YP_PART undefined (probe builds): everything, as before.  A kernel template is only compiled
+// where it is instantiated, so the split is a matter of where the launch helpers are CALLED.
+// ---------------------------------------------------------------------------------------------
+constexpr int YP_STEM2_TH = 4;          // output rows per tile of the fused stem (host tile count and kernel template agree on it)
+hipError_t yp_halo_dispatch(int dtype, bool of32, bool stats, int stride, int bn, int th, const ConvKArgs& a, int nblk, hipStream_t st);
+hipError_t yp_bneck_dispatch(int dtype, bool persist, int c, int bn, bool post, bool waves8, const ConvKArgs& a, int nblk, hipStream_t st);
+hipError_t yp_stem2_dispatch(int dtype, bool post3, const ConvKArgs& a, int nbs, hipStream_t st);
+#if YP_PART != 1
+hipError_t yp_halo_dispatch(int dtype, bool of32, bool stats, int stride, int bn, int th, const ConvKArgs& a, int nblk, hipStream_t st) {
+    if (stats) {
+        if (of32) return hipErrorInvalidValue;
+        return dtype == YP_F16 ? dispatch_halo<YP_F16, false, true>(stride, bn, th, a, nblk, st)
+             : dtype == YP_BF16 ? dispatch_halo<YP_BF16, false, true>(stride, bn, th, a, nblk, st)
+             : dtype == YP_FP8 ? dispatch_halo<YP_FP8, false, true>(stride, bn, th, a, nblk, st) : hipErrorInvalidValue;
+    }
+    if (dtype == YP_FP8) return dispatch_halo<YP_FP8, false>(stride, bn, th, a, nblk, st);
+    if (dtype == YP_FP8_BF8) return dispatch_halo<YP_FP8_BF8, false>(stride, bn, th, a, nblk, st);
+    if (dtype == YP_F16) return of32 ? dispatch_halo<YP_F16, true>(stride, bn, th, a, nblk, st) : dispatch_halo<YP_F16, false>(stride, bn, th, a, nblk, st);
+    if (dtype == YP_BF16) return of32 ? dispatch_halo<YP_BF16, true>(stride, bn, th, a, nblk, st) : dispatch_halo<YP_BF16, false>(stride, bn, th, a, nblk, st);
+    return hipErrorInvalidValue;
+}
+hipError_t yp_bneck_dispatch(int dtype, bool persist, int c, int bn, bool post, bool waves8, const ConvKArgs& a, int nblk, hipStream_t st) {
+    if (dtype != YP_F16 && dtype != YP_BF16) return hipErrorInvalidValue;
+    if (persist) return dtype == YP_F16 ? launch_bneck32_persist<YP_F16>(a, nblk, st) : launch_bneck32_persist<YP_BF16>(a, nblk, st);
+    return dtype == YP_F16 ? dispatch_bneck<YP_F16>(c, bn, post, waves8, a, nblk, st) : dispatch_bneck<YP_BF16>(c, bn, post, waves8, a, nblk, st);
+}
+hipError_t yp_stem2_dispatch(int dtype, bool post3, const ConvKArgs& a, int nbs, hipStream_t st) {
+    constexpr int TH = YP_STEM2_TH;
+    constexpr int HSL = ((2 * TH + 1) * 34 + 15) / 16;
+    constexpr size_t lds = (size_t)HSL * 1024 + (size_t)(4 * TH + 6) * 36 * 16;
+    static_assert((size_t)HSL * 1024 >= (size_t)TH * 16 * 128, "phase C's pixel rows fit the hidden halo");
+    hipError_t e = hipSuccess;
+#define YP_STEM2(DTC, P3) { static YpLdsAttr attr; e = yp_set_max_lds(attr, (const void*)stem_conv2_kernel<DTC, TH, P3>, (int)lds); \
+                            if (e == hipSuccess) { stem_conv2_kernel<DTC, TH, P3><<<nbs, 256, lds, st>>>(a); e = hipGetLastError(); } }
+    if (dtype == YP_F16) { if (post3) YP_STEM2(YP_F16, true) else YP_STEM2(YP_F16, false) }
+    else if (dtype == YP_BF16) { if (post3) YP_STEM2(YP_BF16, true) else YP_STEM2(YP_BF16, false) }
+    else e = hipErrorInvalidValue;
+#undef YP_STEM2
+    return e;
+}
+#endif
+
+#if YP_PART != 2
+namespace {
 int pick_tile(int M, int N) {
     auto blocks = [&](int bm, int bn) { return (long)yp_cdiv(M, bm) * yp_cdiv(N, bn); };
     const long fill = 2 * 256;   // >= 2 workgroups per CU before a bigger tile is worth it
@@ -2447,7 +2499,7 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
         YP_REQUIRE(d->tile == 0, "yp_conv2d: tile %d does not apply to the fused stem", d->tile);
         a.stem_x = d->stem_x; a.stem_wgt = (const char*)d->stem_weight; a.stem_bias = d->stem_bias; a.stem_Kpad = d->stem_Kpad; a.stem_act = d->stem_act;
         a.stem_C = d->stem_C; a.stem_H = 2 * d->Hi; a.stem_W = 2 * d->Wi;
-        constexpr int TH = 4;
+        constexpr int TH = YP_STEM2_TH;
         a.tiles_n = 1;
         a.tiles_x = yp_cdiv(d->Wo, 16);
         a.tiles_y = yp_cdiv(d->Ho, TH);
@@ -2455,18 +2507,11 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
         const int ntl = d->B * a.tiles_y * a.tiles_x;
         a.stats_rows = ntl;                 // (the tile count: workgroups loop over tiles)
         const int nbs = ntl < 2 * 256 ? ntl : 2 * 256;     // (two resident workgroups per CU: 216 VGPRs)
-        constexpr int HSL = ((2 * TH + 1) * 34 + 15) / 16;
-        constexpr size_t lds = (size_t)HSL * 1024 + (size_t)(4 * TH + 6) * 36 * 16;
-        static_assert((size_t)HSL * 1024 >= (size_t)TH * 16 * 128, "phase C's pixel rows fit the hidden halo");
         if (post3) {
             a.post_wgt = (const char*)d->post_weight; a.post_bias = d->post_bias; a.post_Kpad = d->post_Kpad; a.post_Npad = d->post_Npad;
             a.post_act = d->post_act; a.post_N = Cout;
         }
-#define YP_STEM2(DTC, P3) { static YpLdsAttr attr; e = yp_set_max_lds(attr, (const void*)stem_conv2_kernel<DTC, TH, P3>, (int)lds); \
-                            if (e == hipSuccess) { stem_conv2_kernel<DTC, TH, P3><<<nbs, 256, lds, stream>>>(a); e = hipGetLastError(); } }
-        if (d->dtype == YP_F16) { if (post3) YP_STEM2(YP_F16, true) else YP_STEM2(YP_F16, false) }
-        else { if (post3) YP_STEM2(YP_BF16, true) else YP_STEM2(YP_BF16, false) }
-#undef YP_STEM2
+        e = yp_stem2_dispatch(d->dtype, post3, a, nbs, stream);
         if (e != hipSuccess) { yp_set_error("yp_conv2d: fused stem launch failed: %s", hipGetErrorString(e)); return YP_ERR_HIP; }
         return YP_OK;
     }
@@ -2500,9 +2545,9 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
         const int nb3 = d->B * a.tiles_y * a.tiles_x * a.tiles_n;
         if (persist_ok && (d->tile == 16 || (d->tile == 0 && nb3 >= 4 * 256))) {
             a.stats_rows = nb3;                 // (the tile count: workgroups loop over tiles)
-            e = d->dtype == YP_F16 ? launch_bneck32_persist<YP_F16>(a, nb3, stream) : launch_bneck32_persist<YP_BF16>(a, nb3, stream);
+            e = yp_bneck_dispatch(d->dtype, true, Cc, bn, post, waves8, a, nb3, stream);
         } else
-        e = d->dtype == YP_F16 ? dispatch_bneck<YP_F16>(Cc, bn, post, waves8, a, nb3, stream) : dispatch_bneck<YP_BF16>(Cc, bn, post, waves8, a, nb3, stream);
+        e = yp_bneck_dispatch(d->dtype, false, Cc, bn, post, waves8, a, nb3, stream);
         if (e != hipSuccess) {
             yp_set_error("yp_conv2d: fused bottleneck launch failed: %s", hipGetErrorString(e));
             return YP_ERR_HIP;
@@ -2525,13 +2570,8 @@ int yp_conv2d_launch(const YpConvDesc* d, const YpDetectDesc* det, hipStream_t s
             a.stats = d->bn_partial;
             a.stats_rows = d->B * a.tiles_y * a.tiles_x;
             if (g_bn_rows_query != nullptr) { *g_bn_rows_query = a.stats_rows; return YP_OK; }
-            e = d->dtype == YP_F16 ? dispatch_halo<YP_F16, false, true>(d->stride_h, bn, th, a, nb3, stream)
-                : d->dtype == YP_BF16 ? dispatch_halo<YP_BF16, false, true>(d->stride_h, bn, th, a, nb3, stream)
-                : d->dtype == YP_FP8 ? dispatch_halo<YP_FP8, false, true>(d->stride_h, bn, th, a, nb3, stream) : hipErrorInvalidValue;
-        } else if (d->dtype == YP_FP8) e = dispatch_halo<YP_FP8, false>(d->stride_h, bn, th, a, nb3, stream);
-        else if (d->dtype == YP_FP8_BF8) e = dispatch_halo<YP_FP8_BF8, false>(d->stride_h, bn, th, a, nb3, stream);
-        else if (d->dtype == YP_F16) e = of32 ? dispatch_halo<YP_F16, true>(d->stride_h, bn, th, a, nb3, stream) : dispatch_halo<YP_F16, false>(d->stride_h, bn, th, a, nb3, stream);
-        else e = of32 ? dispatch_halo<YP_BF16, true>(d->stride_h, bn, th, a, nb3, stream) : dispatch_halo<YP_BF16, false>(d->stride_h, bn, th, a, nb3, stream);
+            e = yp_halo_dispatch(d->dtype, false, true, d->stride_h, bn, th, a, nb3, stream);
+        } else e = yp_halo_dispatch(d->dtype, (d->dtype == YP_F16 || d->dtype == YP_BF16) && of32, false, d->stride_h, bn, th, a, nb3, stream);
         if (e != hipSuccess) {
             yp_set_error("yp_conv2d: halo kernel launch failed: %s", hipGetErrorString(e));
             return YP_ERR_HIP;
@@ -2591,6 +2631,9 @@ extern "C" int yp_conv2d_detect(const YpConvDesc* d, const YpDetectDesc* det, vo
     return yp_conv2d_launch(d, det, (hipStream_t)stream);
 }
 
+#endif   // YP_PART != 2
+
+#if YP_PART != 1
 extern "C" int yp_stem_conv(const float* x_nchw, int B, int C, int H, int W, const void* weight, int Kpad, const float* bias, int act, YpView out,
                             int dtype, void* stream) {
     YP_REQUIRE(x_nchw && weight && out.ptr && B > 0 && C > 0 && C <= 4 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "yp_stem_conv: bad arguments");
@@ -2607,3 +2650,4 @@ extern "C" int yp_stem_conv(const float* x_nchw, int B, int C, int H, int W, con
     YP_CHECK_HIP(hipGetLastError());
     return YP_OK;
 }
+#endif   // YP_PART != 1
