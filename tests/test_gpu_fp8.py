@@ -513,4 +513,13 @@ def test_twin_only_batchnorm_outputs_change_nothing(cuda, monkeypatch, version, 
     # (the reported loss VALUE carries one ulp of run-to-run noise in every mode: the object loss adds its per-workgroup sums with a float
     # atomic, csrc/losses.hip::objloss_*_kernel -- tools/probe/fp8_loss_noise.py; gradients and weights do not)
     assert all(abs(a - b) <= 1e-6 * abs(b) for a, b in zip(l1, l0)), (l1, l0)
-    assert all(torch.equal(a, b) for a, b in zip(p1, p0))
+    names = [n_ for n_, _ in m.named_parameters()]
+    bad = [(names[i], float((a - b).abs().max())) for i, (a, b) in enumerate(zip(p1, p0)) if not torch.equal(a, b)]
+    if pair == "0":
+        # Two-graph mode (YP_TRAIN_PAIR=0, not the default) runs the loss stage through torch autograd (engine._native_stage_ok needs pair mode):
+        # its descriptor gradient carries run-to-run fp32 noise (observed 7e-12 on the head gradient, float atomics of the framework's scatter /
+        # sampling backward kernels), which now and then flips a 16-bit rounding of ConvDesc's output gradient -- two runs of the SAME twin-only
+        # setting differ as often as the two settings do (tools/probe/twin_only_dbg.py: one to two runs in five, |dw| <= 2e-6, tensors of the
+        # descriptor head).  A reader of a dropped (NaN-filled) copy would show up as NaN or as an error of the size of the weights.
+        bad = [(n_, e_) for n_, e_ in bad if e_ >= 1e-5]
+    assert not bad, (len(bad), bad[:6])

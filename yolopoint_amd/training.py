@@ -355,6 +355,7 @@ class TrainGraph:
             else:
                 draw = b.new_buf(out.H, out.W, out.C).view()
                 b.op(_hip.OP_CAST_F32, [g32], [draw], "cast", v=[g32, draw], i=[self.code, b.B])
+            self.__dict__.setdefault("head_debug", {})[name] = dict(x=x, g32=g32, draw=draw, out=out)      # (probes: tools/probe/twin_only_dbg.py)
             self.conv_backward([x], weight, bias, draw, k, s, p)
         self.tape.append((self.branch, backward, self.tape_tag))
         return out
