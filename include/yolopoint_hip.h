@@ -527,12 +527,13 @@ int yp_csr_build(const int* keys, int n_items, int n_buckets, int wide_buckets, 
  *   yp_multi_add     loss.backward()'s accumulation into p.grad for a whole table of (dst, src, n) at once: dst += src (mode 0) or
  *                    dst = src (mode 1); blocks of 1024 elements are numbered across the table, blk0 = an entry's first, sorted by blk0
  *   yp_counters_add  BatchNorm's num_batches_tracked (+= inc for every int64 counter of a device pointer table)
- *   yp_loss_combine  train.py:232-241: out4[0] = (sum(det_losses[0..n_det)) + lambda_desc * mean(nce_rows[0..n_rows))) + lambda_obj *
- *                    sum(obj_sums[0..3)), times `scale` when it is not 1; out4[1..3] = the detector / descriptor / object terms;
+ *   yp_loss_combine5 train.py:232-241: out5[0] = (sum(det_losses[0..n_det)) + lambda_desc * mean(nce_rows[0..n_rows))) + lambda_obj *
+ *                    sum(obj_sums[0..3)), times `scale` when it is not 1; out5[1..3] = the detector / descriptor / object terms;
+ *                    out5[4] = the InfoNCE row count the mean was taken over, as a float (always written; 0: an image had no valid cell
+ *                    under its warp -- the step ran without a descriptor term, where the reference's mean over nothing would have been NaN);
  *                    *desc_scale_out = desc_scale (the device scalar yp_infonce_bwd_db reads; NULL: not written).  n_rows_dev (may be NULL):
- *                    the row count lives on the device (yp_nce_select's meta[1]); desc_scale is then g_desc / (tau * n) computed there, and
- *                    out4 has FIVE floats: out4[4] = n as a float (0: an image had no valid cell under its warp -- the step ran without a
- *                    descriptor term, where the reference's mean over nothing would have been NaN) */
+ *                    the row count lives on the device (yp_nce_select's meta[1]); desc_scale is then g_desc / (tau * n) computed there.
+ *                    (Round 6: renamed from yp_loss_combine, whose output had four floats, so that a stale caller fails to link.) */
 typedef struct YpAddEntry {
     float* dst;
     const float* src;
@@ -541,8 +542,8 @@ typedef struct YpAddEntry {
 int yp_fill_zero(void* p, size_t bytes, void* stream);
 int yp_multi_add(const YpAddEntry* table_dev, int n_entries, int total_blocks, void* stream);
 int yp_counters_add(int64_t* const* table_dev, int n, int64_t inc, void* stream);
-int yp_loss_combine(const float* det_losses, int n_det, const float* nce_rows, int n_rows, const float* obj_sums, float lambda_desc, float lambda_obj, float scale,
-                    float desc_scale, float* out4, float* desc_scale_out, const int* n_rows_dev, float g_desc, double tau, void* stream);
+int yp_loss_combine5(const float* det_losses, int n_det, const float* nce_rows, int n_rows, const float* obj_sums, float lambda_desc, float lambda_obj, float scale,
+                     float desc_scale, float* out5, float* desc_scale_out, const int* n_rows_dev, float g_desc, double tau, void* stream);
 
 /* One generic launch record: `op` selects one of the functions above, the slots carry its arguments in the
  * order documented next to each opcode.  Lets training plans replay any mix of launches (yp_plan_add_op). */

@@ -256,6 +256,40 @@ def test_config2_gradient_spot_check_8x640(cuda):
         assert c > 0.8 and e <= 0.6, (name, e, c)
 
 
+def test_config2_gradient_f32_tight_8x640(cuda):
+    """configs[2] at ITS shape with a TIGHT bar: YOLOPoint-s, 8 samples of 640 x 640, the fp32 compute path (fp32 storage, exact-f32 MFMA chain),
+    the plans / tiles / BatchNorm partial-row counts / weight-gradient pixel splits the autotuner builds AT THIS SHAPE -- against fp32 CPU
+    autograd through the oracle at the north-star bar of 2e-3 relative L2 (the bf16 spot check above can only be judged against the bf16
+    noise floor, 0.3-0.6).  Tensors whose gradient does not pass through the SPPF max pools' argmax routing (Detect, PAN, SPPF's own
+    output convolution, the descriptor head): 2e-3.  Backbone tensors upstream of the pools: 2e-2 -- a max pool routes its gradient to the
+    FIRST maximum of a window and two activations closer than the fp32 summation-order noise may swap (conftest.fixed_kernel_variants), which
+    moves every upstream gradient by up to a percent; the kernels themselves are held to 2e-3 at the small shapes."""
+    version, B, S, seed = "s", 8, 640, 53
+    m, sd = make_model(version, seed, dtype="f32")
+    m = m.to(cuda).train()
+    x = net_oracle.synth_image(B, 3, S, S, seed)
+    torch.set_num_threads(min(32, torch.get_num_threads() or 8))
+    leaf = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in sd.items()}
+    o = net_oracle.yolopoint_forward(leaf, x, version, training=True, stats={})
+    proj = net_oracle.output_projections(o, seed)
+    net_oracle.projected_loss(o, proj).backward()
+    out = m(x.to(cuda))
+    for k in ("semi", "desc"):
+        assert rel_err(out[k], o[k])[0] < 1e-3, (k, rel_err(out[k], o[k]))
+    net_oracle.projected_loss(out, proj, cuda).backward()
+    params = dict(m.named_parameters())
+    tight = ["model.Detect.m.1.weight", "model.Bottleneck6.cv1.conv.weight", "model.ConvDesc.weight", "model.SPPooling.cv2.conv.weight", "model.ConvDet.weight"]
+    upstream = ["model.Conv1.conv.weight", "model.Conv2.conv.weight", "model.Bottleneck3.m.1.cv1.conv.weight"]
+    rows = []
+    for name in tight + upstream:
+        g, g32 = params[name].grad, leaf[name].grad
+        assert g is not None and torch.isfinite(g).all(), name
+        rows.append((name, rel_err(g, g32)[1]))
+    print("configs[2] shape, f32 compute vs fp32 autograd: " + "; ".join(f"{n.replace('model.', '')} l2 {e:.2e}" for n, e in rows))
+    for name, e in rows:
+        assert e <= (2e-3 if name in tight else 2e-2), (name, e)
+
+
 def test_train_bs64_batch_gradient_spot_check_128x128x128(cuda):
     """The `train_bs64` record runs ONE batch of 64 samples (128 images) per optimizer step: the same spot check at that batch -- 128
     images of 128 x 128 through one train-mode forward / backward (BatchNorm statistics over all 128 images, 2-D grids and partial-row

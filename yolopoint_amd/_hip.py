@@ -144,7 +144,7 @@ SIGNATURES = {
     "yp_fill_zero": (_i, [_p, _sz, _p]),
     "yp_multi_add": (_i, [_p, _i, _i, _p]),
     "yp_counters_add": (_i, [_p, _i, _i64, _p]),
-    "yp_loss_combine": (_i, [_p, _i, _p, _i, _p, _f, _f, _f, _f, _p, _p, _p, _f, C.c_double, _p]),
+    "yp_loss_combine5": (_i, [_p, _i, _p, _i, _p, _f, _f, _f, _f, _p, _p, _p, _f, C.c_double, _p]),
     "yp_objloss_level": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _i, _f, _f, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p]),
     "yp_objloss_level_dev": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _f, _f, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p]),
     "yp_build_targets": (_i, [_p, _i, _p, _i, _i, _p, _f, _i, _p, _p, _p, _p, _p, _p]),

@@ -42,8 +42,8 @@ __device__ __forceinline__ double wave_sum_f64(double a) {
 }
 
 // total = (sum of the detector-group losses + lambda_desc * mean(rows)) + lambda_obj * (obj[0] + obj[1] + obj[2]), times `scale` when it
-// is not 1 -- the expression of train.py:232-241 in its order; out[0..3] = total, detector, descriptor, object terms; with a device-side row
-// count also out[4] = that count.
+// is not 1 -- the expression of train.py:232-241 in its order; out[0..3] = total, detector, descriptor, object terms; out[4] = the InfoNCE
+// row count the sum was taken over (ALWAYS written: the host's n_rows or the device-side count).
 // desc_scale_out (the scalar the InfoNCE backward multiplies its gradients with) = desc_scale.
 __global__ __launch_bounds__(256) void loss_combine_kernel(const float* __restrict__ det, int n_det, const float* __restrict__ rows, int n_rows,
                                                            const float* __restrict__ obj, float lambda_desc, float lambda_obj, float scale, float desc_scale,
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void loss_combine_kernel(const float* __restri
         float total = (l_det + lambda_desc * l_desc) + lambda_obj * l_obj;
         if (scale != 1.0f) total *= scale;
         out[0] = total; out[1] = l_det; out[2] = l_desc; out[3] = l_obj;
-        if (n_rows_dev != nullptr) out[4] = (float)n_rows;          // the InfoNCE row count the step ran with (0: empty sampling pool, no descriptor term)
+        out[4] = (float)n_rows;          // the InfoNCE row count the step ran with (0: empty sampling pool, no descriptor term)
         if (desc_scale_out != nullptr) *desc_scale_out = desc_scale;
     }
 }
@@ -97,9 +97,12 @@ extern "C" int yp_counters_add(int64_t* const* table_dev, int n, int64_t inc, vo
     return YP_OK;
 }
 
-extern "C" int yp_loss_combine(const float* det_losses, int n_det, const float* nce_rows, int n_rows, const float* obj_sums, float lambda_desc, float lambda_obj,
-                               float scale, float desc_scale, float* out4, float* desc_scale_out, const int* n_rows_dev, float g_desc, double tau, void* stream) {
-    YP_REQUIRE(out4 && n_det >= 0 && n_rows >= 0 && (n_det == 0 || det_losses) && (n_rows == 0 || nce_rows), "yp_loss_combine: bad arguments");
+// (named ...5: the output is FIVE floats since round 5; a caller built against the four-float yp_loss_combine fails to link instead of
+// receiving a write behind its buffer)
+extern "C" int yp_loss_combine5(const float* det_losses, int n_det, const float* nce_rows, int n_rows, const float* obj_sums, float lambda_desc, float lambda_obj,
+                                float scale, float desc_scale, float* out5, float* desc_scale_out, const int* n_rows_dev, float g_desc, double tau, void* stream) {
+    float* const out4 = out5;
+    YP_REQUIRE(out5 && n_det >= 0 && n_rows >= 0 && (n_det == 0 || det_losses) && (n_rows == 0 || nce_rows), "yp_loss_combine5: bad arguments");
     loss_combine_kernel<<<1, 256, 0, (hipStream_t)stream>>>(det_losses, n_det, nce_rows, n_rows, obj_sums, lambda_desc, lambda_obj, scale, desc_scale, out4,
                                                            desc_scale_out, n_rows_dev, g_desc, tau);
     YP_CHECK_HIP(hipGetLastError());

@@ -70,7 +70,11 @@ class GradAllReducer:
         self.sync = True
         self.force_collectives = False          # run the collectives even for a single rank (exercises the RCCL path on one GPU)
         import os
-        self.comm_dtype = {"bf16": torch.bfloat16, "f16": torch.float16}.get(os.environ.get("YP_DP_COMM", "fp32"))      # None: fp32 buckets as they are
+        comm = os.environ.get("YP_DP_COMM", "fp32")
+        if comm not in ("fp32", "bf16"):
+            # (f16 is not offered: a SUM-reduced fp16 stage overflows at 65 504 on loss-scaled or large gradients; bf16 has fp32's range)
+            raise ValueError(f"YP_DP_COMM={comm!r}: the gradient exchange runs in 'fp32' (default, as accelerate / DDP reduce in the reference) or 'bf16'")
+        self.comm_dtype = torch.bfloat16 if comm == "bf16" else None      # None: fp32 buckets as they are
         self._stage = None
         self.launch_log = []                    # bucket indices in launch order (tests, bench reporting)
         self._pending, self._works, self._launched = None, {}, set()
@@ -195,7 +199,11 @@ class GradAllReducer:
             if self._stage is None:
                 self._stage = [torch.empty(f.numel(), dtype=self.comm_dtype, device=f.device) for f, _ in self.buckets]
             stage = self._stage[bi]
-            stage.copy_(flat)
+            if avg:
+                stage.copy_(flat)
+            else:                                  # SUM backends (gloo): the 1/world factor goes in BEFORE the rounding, the sum then stays a mean
+                torch.mul(flat, 1.0 / self.world, out=flat)
+                stage.copy_(flat)
         self._works[bi] = (dist.all_reduce(flat if stage is None else stage, op=op, group=self.group, async_op=True), avg, stage)
 
     def finish(self):
@@ -214,7 +222,7 @@ class GradAllReducer:
             flat, entries = self.buckets[bi]
             if stage is not None:
                 flat.copy_(stage)
-            if not avg:
+            if not avg and stage is None:
                 flat.mul_(inv)
             if self._bound(bi):
                 continue
@@ -235,7 +243,9 @@ class GradAllReducer:
         return sum(f.numel() * (4 if self.comm_dtype is None else 2) for f, _ in self.buckets)
 
     def describe(self):
-        return [{"group": g, "mbytes": round(f.numel() * 4 / 1e6, 2), "params": len(e)} for g, (f, e) in zip(self.bucket_group, self.buckets)]
+        nb = 4 if self.comm_dtype is None else 2          # bytes per element on the wire
+        return [{"group": g, "mbytes": round(f.numel() * nb / 1e6, 2), "params": len(e), "comm_dtype": "fp32" if nb == 4 else "bf16"}
+                for g, (f, e) in zip(self.bucket_group, self.buckets)]
 
 
 def shard_batch(n_global, rank, world):

@@ -183,6 +183,16 @@ class TrainStep:
             self.reducer.finish()                   # the compute stream waits for the collectives here, right before the optimizer reads
         if self.max_grad_norm:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=self.max_grad_norm)
+        if self.fp8 and not getattr(self, "_fp8_grads_checked", False):
+            # first fp8 optimizer step only (one host read-back): a 16-bit copy that training.TrainGraph._drop_unread_16bit_copies stopped
+            # writing is NaN-filled, so a reader its analysis missed shows up HERE as a non-finite gradient instead of training on garbage
+            self._fp8_grads_checked = True
+            dropped = sum(getattr(gg, "n_twin_only", 0) for g_ in getattr(self.model.model, "_train_graphs", {}).values()
+                          for gg in (g_ if isinstance(g_, (list, tuple)) else [g_]))
+            if dropped and not bool(torch.isfinite(self.reducer.arena).all()):
+                from ._hip import YpError
+                raise YpError(f"fp8 training: non-finite gradients after the first step with {dropped} twin-only BatchNorm outputs -- something reads a "
+                              f"16-bit copy the graph no longer writes (register it with TrainGraph.register_external_read, or set YP_FP8_TWIN_ONLY=0)")
         self.opt.step()
         # Nothing in the step makes the host wait for the device any more, so a loop that never reads a loss value would queue steps without
         # bound (and hold every step's side-stream buffers until the device catches up).  Back-pressure: at most YP_STEPS_IN_FLIGHT
@@ -210,9 +220,12 @@ class TrainStep:
         t = getattr(self, "last_loss_terms", None)
         if t is None:
             return None
+        import math
         v = [float(x) for x in t.detach().float().cpu().tolist()]
-        rows = v[4] if len(v) >= 5 else None                 # native stage: the InfoNCE row count of the step (yp_loss_combine's out4[4])
+        rows = v[4] if len(v) >= 5 else None                 # native stage: the InfoNCE row count of the step (yp_loss_combine5's out5[4])
         v = v[:4]
+        if rows is not None and not (math.isfinite(rows) and rows >= 0.0):
+            rows = None                                      # (not a count: fall back to the descriptor-term test)
         self.last_nce_rows = None if rows is None else int(rows)
         if (rows == 0.0) if rows is not None else (len(v) >= 3 and v[2] == 0.0):
             import warnings
@@ -362,7 +375,7 @@ class TrainStep:
             # samples): 128 workgroups 34.6-34.8 ms, 256 / 384 / 768: 34.9 / 35.0 / 35.5, 96 / 64 / 32: 35.3 / 38.5 / 49.6
             # (16-bit rows, D = 256: 96 / 128 / 192 workgroups 29.94 / 30.35 / 29.96 ms per -l fp8 step, same box)
             nce_wgs = int(os.environ.get("YP_NCE_WGS", "256" if D <= 128 else ("96" if g.code == _hip.YP_BF16 and os.environ.get("YP_NCE_ROWS", "bf16") == "bf16" else "128"))) if lanes >= 2 else 0
-            out4_ = torch.empty((8,), dtype=torch.float32, device=dev)        # [total, detector, descriptor, object, InfoNCE row count, -, -, -]
+            out4_ = torch.empty((8,), dtype=torch.float32, device=dev)        # [total, detector, descriptor, object, InfoNCE row count, -, -, -]: yp_loss_combine5 writes all five on both count paths
             if isinstance(nce, dict):
                 # counts on the device (infonce_prepare(sync=False)): arrays at their capacity, the kernels read points-per-image / matched rows
                 # from the sampling's meta words -- no host synchronisation anywhere in the step
@@ -395,7 +408,7 @@ class TrainStep:
                                               rows.data_ptr(), lse.data_ptr(), grad.data_ptr(), n_dev, nce_wgs, sp()))
             if small_done is not None:
                 stream.wait_event(small_done)
-            check(lib.yp_loss_combine(scal + 16, 2, rows.data_ptr(), n, scal, LAMBDA_DESC, LAMBDA_OBJ, float(scale), desc_scale, out4_.data_ptr(), scal + 48, n_dev,
+            check(lib.yp_loss_combine5(scal + 16, 2, rows.data_ptr(), n, scal, LAMBDA_DESC, LAMBDA_OBJ, float(scale), desc_scale, out4_.data_ptr(), scal + 48, n_dev,
                                       float(g_desc), tau, sp()))
             if rows16 is not None:
                 check(lib.yp_infonce_bwd_db_h(rows16.data_ptr(), order.data_ptr(), offsets.data_ptr(), w.data_ptr(), n, E, D, scal + 48,

@@ -31,6 +31,7 @@ _VERSIONS = {'n': (0.33, 0.25), 's': (0.33, 0.5), 'm': (0.67, 0.75), 'l': (1., 1
 
 class YOLOPoint(HipModule):
     """Shared CSPDarknet encoder + YOLO PAN/Detect head + keypoint (semi) head + descriptor head."""
+    plans_cover_all_reads = True           # every reader of its training buffers is a plan op (read through the class's own __dict__: subclasses must re-declare)
 
     def __init__(self, width_multiple=1., depth_multiple=1., inp_ch=3, nc=80, anchors=None):
         super().__init__()
@@ -317,6 +318,7 @@ class YOLOPoint(HipModule):
 class YOLOPointv52(YOLOPoint):
     """C2f variant (reference: models/YOLOPoint.py:248-342): no Conv6/Conv7, a 65-channel C2f as keypoint head, MaxPool2d(2,2)
     on the stride-4 features for the descriptor branch.  Inference (eval) only in this build."""
+    plans_cover_all_reads = False          # (its descriptor normalisation is differentiated in PyTorch, outside the plans' access lists)
 
     def __init__(self, width_multiple=1., depth_multiple=1., inp_ch=3, nc=80, anchors=None):
         HipModule.__init__(self)

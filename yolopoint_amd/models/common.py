@@ -66,6 +66,9 @@ class HipModule(nn.Module):
     """Base class: standalone forward through a cached native plan."""
 
     compute_dtype = "f16"
+    # True only for a model class whose training buffers are read by plan ops alone (training.TrainGraph._drop_unread_16bit_copies may then stop
+    # writing 16-bit copies nobody reads in fp8 mode).  NOT inherited by intent: a subclass that adds torch-side differentiation must not get it.
+    plans_cover_all_reads = False
     _NATIVE_CACHES = ("_plans", "_train_graphs", "_pack_states", "_mods_cache", "_frozen_version")      # per-object native plans / graphs / caches: never copied or pickled
 
     def __deepcopy__(self, memo):

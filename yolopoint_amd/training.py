@@ -68,6 +68,8 @@ class TrainGraph:
         self.twin_only = []        # (plan builder, op index, view slot, 16-bit view) of the BatchNorm outputs that also have a 1-byte twin
         self.builders = []         # every plan builder of this graph (the access lists behind _drop_unread_16bit_copies)
         self.n_twin_only = 0
+        self.external_reads = []   # views that code OUTSIDE the plans reads (torch-side differentiation, probes, exporters): register_external_read()
+        self.dropped_views = []    # the 16-bit views _drop_unread_16bit_copies stopped writing (NaN-filled): assert_readable() refuses them
         self.tape = []             # (branch, emitter): 'kp' feeds the keypoint / descriptor heads, 'yolo' only the Detect head
         self.branch = "kp"
         self.tape_tag = None       # 'kph': entries of the keypoint head (pair mode: their backward runs beside the YOLO-branch plan)
@@ -356,6 +358,8 @@ class TrainGraph:
                 draw = b.new_buf(out.H, out.W, out.C).view()
                 b.op(_hip.OP_CAST_F32, [g32], [draw], "cast", v=[g32, draw], i=[self.code, b.B])
             self.__dict__.setdefault("head_debug", {})[name] = dict(x=x, g32=g32, draw=draw, out=out)      # (probes: tools/probe/twin_only_dbg.py)
+            for v_ in (x, draw):                        # the probe dictionary hands these views to torch-side readers: keep their 16-bit copies
+                self.register_external_read(v_)
             self.conv_backward([x], weight, bias, draw, k, s, p)
         self.tape.append((self.branch, backward, self.tape_tag))
         return out
@@ -844,10 +848,15 @@ class TrainGraph:
         the access lists of every plan builder of the graph (the lists behind the hipGraph dependency edges); residual inputs, pools, Detect /
         head convolutions with a bias, 16-bit layers (channel counts that are not multiples of 64) keep their 16-bit source.  An unread copy is
         filled with NaN once: a reader this analysis missed cannot go unnoticed (non-finite loss / gradients in the fp8 tests).
-        3 -> 1 bytes written per element in those passes.  YP_FP8_TWIN_ONLY=0: keep every copy."""
-        if not self.fp8 or not self.twin_only or os.environ.get("YP_FP8_TWIN_ONLY", "1") == "0" or type(net).__name__ != "YOLOPoint":
-            return          # (YOLOPointv52 differentiates its descriptor normalisation in PyTorch, outside the plans' access lists)
-        reads = [r for pb in [self.fwd] + self.builders for rd, _ in pb.accesses for r in rd]
+        3 -> 1 bytes written per element in those passes.  YP_FP8_TWIN_ONLY=0: keep every copy.
+        The opt-in is structural: a model class declares `plans_cover_all_reads = True` when every reader of its training buffers is a plan op
+        (YOLOPoint; the default of HipModule is False, so a subclass / another model that differentiates anything in PyTorch -- YOLOPointv52's
+        descriptor normalisation -- keeps every copy unless it says otherwise), and whatever reads a view from outside the plans registers it
+        (register_external_read: the probe dictionary head_debug does).  Dropped views are recorded (dropped_views / assert_readable), and the
+        first fp8 optimizer step of engine.TrainStep checks the gradients for non-finite values."""
+        if not self.fp8 or not self.twin_only or os.environ.get("YP_FP8_TWIN_ONLY", "1") == "0" or not type(net).__dict__.get("plans_cover_all_reads", False):       # (the class's OWN declaration: not inherited)
+            return
+        reads = [r for pb in [self.fwd] + self.builders for rd, _ in pb.accesses for r in rd] + [PlanBuilder._rng(v_) for v_ in self.external_reads]
 
         def overlap(a, b):
             if a[0] != b[0]:
@@ -862,6 +871,25 @@ class TrainGraph:
             check(lib().yp_plan_patch_op_view(pb.handle, op, slot, NULL_VIEW))
             view.buf.t[..., view.coff:view.coff + view.C] = float("nan")
             self.n_twin_only += 1
+            self.dropped_views.append(view)
+
+    def register_external_read(self, view):
+        """Declare that code outside the plans (torch-side differentiation, a probe, an exporter) reads `view`: its 16-bit copy is kept in fp8
+        mode.  Must be called while the graph is emitted (before _drop_unread_16bit_copies)."""
+        if self.dropped_views:
+            raise _hip.YpError("register_external_read after the unread 16-bit copies were dropped: build the graph with YP_FP8_TWIN_ONLY=0")
+        self.external_reads.append(view)
+
+    def assert_readable(self, view):
+        """For accessors that hand a graph buffer to torch-side code (probes, debuggers): raises when the view's 16-bit copy is one the fp8
+        graph no longer writes (its memory holds NaN)."""
+        rng = PlanBuilder._rng(view)
+        for d in self.dropped_views:
+            r = PlanBuilder._rng(d)
+            if r[0] == rng[0] and ((r[1] == rng[1] and r[2] < rng[3] and rng[2] < r[3]) or (r[1] != rng[1] and r[4] < rng[5] and rng[4] < r[5])):
+                raise _hip.YpError("this activation's 16-bit copy is not written in fp8 twin-only mode (only its 1-byte twin is): "
+                                   "set YP_FP8_TWIN_ONLY=0 for tools that read activations")
+        return view
 
     # ------------------------------------------------------------------ run
     def forward(self, x, x_w=None, export=True):
