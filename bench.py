@@ -327,8 +327,10 @@ def main(a):
 
     # backbone conv stack (Conv1 .. SPPooling, SURVEY 8d F_bb) separately
     bb_names = ("Conv1", "Conv2", "Bottleneck1", "Conv3", "Bottleneck2", "Conv4", "Bottleneck3", "Conv5", "Bottleneck4", "SPPooling")
-    # (the fused stem launch is named "Conv1+Conv2+Bottleneck1.cv1|cv2": a fused record belongs to the stack when every part does)
-    bb = [(ms, r) for ms, r in zip(per_op, recs) if r.kind == "conv" and all(part.split(".")[0] in bb_names for part in r.name.split("+"))]
+    # (a fused launch is named after its parts -- "Conv1+Conv2+Bottleneck1.cv1+cv2...", "Bottleneck2.cv1+cv2", "...m.0.cv1>cv2>cv3": the module of
+    # its FIRST part decides; every fused launch lies inside one stage of the network)
+    import re
+    bb = [(ms, r) for ms, r in zip(per_op, recs) if r.kind == "conv" and re.split(r"[.+>]", r.name)[0] in bb_names]
     bb_ms, bb_flops = sum(ms for ms, _ in bb), sum(r.flops for _, r in bb)
     gpu_outs = None
     if world == 1 and not a.no_cpu_baseline:
