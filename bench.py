@@ -69,9 +69,15 @@ def parse():
     ap.add_argument("--gas", type=int, default=1, help="--mode train: micro-batches per optimizer step")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (nccl = RCCL over xGMI; gloo only with --dry)")
     ap.add_argument("--dry", action="store_true", help="launcher check: every rank joins the group, runs a stub step (no GPU, no model), rank 0 prints the line")
+    ap.add_argument("--rehearsal", action="store_true",
+                    help="N > 1 on a box with fewer than N GPUs: all ranks share the visible GPU(s) and exchange through gloo (RCCL refuses two ranks on one "
+                         "device).  Exercises the whole N > 1 control flow of this file -- replica timing, shared autotuning, data-parallel training with "
+                         "the real bucketed gradient all-reduce -- on real kernels; the record is marked `rehearsal` and its throughput means nothing")
     a = ap.parse_args()
-    if a.backend == "gloo" and not a.dry:
-        ap.error("--backend gloo is the launcher's dry mode only (--dry): the product has no CPU path")
+    if a.backend == "gloo" and not (a.dry or a.rehearsal):
+        ap.error("--backend gloo is for --dry (launcher check) and --rehearsal (ranks sharing a GPU) only: the product has no CPU path")
+    if a.rehearsal:
+        a.backend = "gloo"
     return a
 
 
@@ -82,7 +88,10 @@ def self_launch(a, argv):
     JSON line reaches this process's stdout unchanged.  Fails loudly when the box has fewer than N GPUs (never a silent N = 1 run)."""
     if not a.dry:
         have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-        if have < a.gpus:
+        if a.rehearsal and have < 1:
+            sys.stderr.write("bench.py: --rehearsal still needs one visible GPU\n")
+            sys.exit(2)
+        if have < a.gpus and not a.rehearsal:
             sys.stderr.write(f"bench.py: --gpus {a.gpus} needs {a.gpus} visible GPUs, this box has {have} "
                              f"(one rank per GPU over RCCL; there is no CPU path and no oversubscription of a GPU)\n")
             sys.exit(2)
@@ -225,7 +234,9 @@ def main(a):
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
+        dist.init_process_group(a.backend)
+    if a.rehearsal:
+        local = local % max(torch.cuda.device_count(), 1)          # ranks share the visible GPU(s)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -357,6 +368,7 @@ def main(a):
             "vs_baseline": None,
             "dtype": a.dtype,
             "data": "synthetic",
+            **({"rehearsal": "ranks share one GPU and exchange through gloo: control-flow check only, the numbers are not throughput"} if a.rehearsal else {}),
             "config": {"workload": f"BASELINE.json configs[1]: YOLOPoint-{a.version} inference forward (backbone + heads + Detect decode), batch {B}/GPU, "
                                    f"{S}x{S}, {a.dtype} / fp32 accumulate, BN folded, inputs resident in HBM",
                        "per_gpu_batch": B, "global_batch": B * world, "image": [S, S],

@@ -120,3 +120,27 @@ def test_two_ranks_train_in_lockstep_over_rccl():
     (l0, s0, a0, log0, ex0), (l1, s1, a1, log1, ex1) = got[0], got[1]
     assert l0 != l1 and s0 == s1 and a0 == a1 and log0 == log1 and len(log0) > 0
     assert ex0 is None or isinstance(ex0, (int, float))
+
+
+def test_bench_rehearsal_two_ranks_share_this_gpu():
+    """`bench.py --gpus 2 --rehearsal`: the WHOLE N > 1 control flow of bench.py -- self-launch under torch.distributed.run, process group, replica
+    timing with barrier + max over ranks, rank 0's shared autotuning broadcasts, the data-parallel `train` record with the real bucketed gradient
+    all-reduce and its exposed-communication events, rank 0 alone printing ONE line -- on real kernels, two ranks sharing this GPU over gloo
+    (RCCL refuses two ranks on one device; with >= 2 GPUs the driver's `--gpus N` runs the same code over RCCL)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearsal", "--only", "train", "--steps", "6", "--warmup", "2",
+                        "--train-steps", "3", "--train-warmup", "1"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[:500]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 16 and rec["config"]["parallelism"] == "replicas" and "rehearsal" in rec
+    tr = rec["train"]
+    assert tr["n_gpus"] == 2 and tr["parallelism"] == "dp2" and tr["global_batch"] == 16
+    assert tr["bucket_launch_order"] == [0, 1, 2, 3], tr["bucket_launch_order"]          # detector buckets behind the YOLO-branch plan, keypoint bucket last
+    assert isinstance(tr["exposed_comm_ms_per_step"], float)
+    assert "cpu_baseline" not in rec and "parity" not in tr                                   # (rank 0, N = 1 only)
