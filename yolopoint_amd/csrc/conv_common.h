@@ -263,6 +263,20 @@ __device__ __forceinline__ int yp_xcd_remap(int bid, int nblk) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// The persistent kernels' tile walk.  Workgroup b (on XCD b % 8) visits first, first + step, ... < end inside ITS XCD's contiguous run of tile
+// ids: the tiles in flight on one XCD at any moment are ~nwg / 8 CONSECUTIVE tiles (several neighbouring tile rows of one image), so the halo
+// lines two neighbouring tiles share are fetched into that XCD's L2 once.  (The plain walk b, b + nwg, ... puts neighbouring tiles on eight
+// different L2s: the fused stem stage fetched 102.8 MB for a 39.3 MB image, profiles/r05_layers_traffic.txt.)
+__device__ __forceinline__ void yp_xcd_walk(int bid, int nwg, int ntiles, int& first, int& end, int& step) {
+    if ((nwg & 7) != 0) { first = bid; end = ntiles; step = nwg; return; }
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int xcd = bid & 7, j = bid >> 3;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    first = start + j;
+    end = start + q + (xcd < r ? 1 : 0);
+    step = nwg >> 3;
+}
+
 // One LDS-DMA instruction: 64 lanes x 16 B -> 1 KiB at LDS byte address `lds_dst` (wave-uniform, in
 // an SGPR), lane l landing at lds_dst + 16*l.  Issued through inline asm so that the compiler's
 // LDS-DMA alias tracking does not put s_waitcnt vmcnt(0) in front of the fragment reads; the

@@ -1527,17 +1527,18 @@ __global__ __launch_bounds__(256, 2) void bneck32_persist_kernel(const ConvKArgs
         }
     };
 
-    int tile = blockIdx.x;
-    if (tile < ntiles) issue_inputs(tile, 0);
+    int tile, tile_end, tile_step;
+    yp_xcd_walk(blockIdx.x, gridDim.x, ntiles, tile, tile_end, tile_step);
+    if (tile < tile_end) issue_inputs(tile, 0);
     const int a_rd = p * 64 + ((g ^ swr) << 4);
     const int w_rd = p * 64 + ((g ^ swr) << 4);          // (one wave column: wn = 0)
     int buf = 0;
-    for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+    for (; tile < tile_end; tile += tile_step, buf ^= 1) {
         int b, y0, x0;
         decode(tile, b, y0, x0);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                    // this tile's inputs (and, the first time, the filters) have landed; every wave is done with the previous tile
-        if (tile + (int)gridDim.x < ntiles) issue_inputs(tile + gridDim.x, buf ^ 1);
+        if (tile + tile_step < tile_end) issue_inputs(tile + tile_step, buf ^ 1);
 
         // ---- phase A: hidden = act1(W1 . x + b1) on the 192 halo rows (3 fragments of 16 rows per wave)
         f32x4 hacc[2][3];
@@ -1950,8 +1951,10 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(const ConvKArgs a) {
             }
         }
     };
-    if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int tile_first, tile_end, tile_step;
+    yp_xcd_walk(blockIdx.x, gridDim.x, ntiles, tile_first, tile_end, tile_step);
+    if (tile_first < tile_end) load_tile(tile_first);
+    for (int tile = tile_first; tile < tile_end; tile += tile_step) {
     int bid = tile;
     const int tx = bid % a.tiles_x; bid /= a.tiles_x;
     const int ty = bid % a.tiles_y;
@@ -1971,7 +1974,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(const ConvKArgs a) {
             *reinterpret_cast<u32x4*>(&img[(row * IP + 2 * q + pr) * 8]) = pk;
         }
     }
-    if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
+    if (tile + tile_step < tile_end) load_tile(tile + tile_step);
     __syncthreads();
 
     // ---- phase A: the stem outputs of the halo, fragment by fragment
