@@ -288,3 +288,34 @@ def test_bbox_iou_public_helper_matches_the_oracle_ciou():
     assert float((bbox_iou(a, b, CIoU=True).squeeze(-1) - loss_oracle.ciou(a, b)).abs().max()) < 1e-6
     iou = bbox_iou(a, a)
     assert float((iou - 1).abs().max()) < 1e-4          # (eps = 1e-7 in the union of boxes with area ~1e-2)
+
+
+def test_every_environment_switch_is_registered():
+    """yolopoint_amd/switches.py is the only place the package reads `YP_*` variables: no `os.environ` / `getenv` access to a YP_ name elsewhere
+    in the Python sources, every getenv("YP_...") of the native sources is registered, sw() refuses unknown names, and an unregistered YP_*
+    variable in the environment is an error at import."""
+    import glob
+    import re
+    from yolopoint_amd import switches
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for path in glob.glob(os.path.join(root, "yolopoint_amd", "**", "*.py"), recursive=True):
+        if path.endswith("switches.py"):
+            continue
+        src = open(path).read()
+        assert not re.search(r"environ[^\n]*YP_|getenv\([^\n]*YP_", src), f"{path}: reads a YP_* variable outside switches.sw()"
+        for name in re.findall(r"\bsw\(\"(YP_[A-Z0-9_]+)\"\)|\bon\(\"(YP_[A-Z0-9_]+)\"\)", src):
+            assert (name[0] or name[1]) in switches.SWITCHES, (path, name)
+    for path in glob.glob(os.path.join(root, "yolopoint_amd", "csrc", "*.h*")):
+        for name in re.findall(r"getenv\(\"(YP_[A-Z0-9_]+)\"\)", open(path).read()):
+            assert name in switches.SWITCHES and switches.SWITCHES[name].kind == "native", (path, name)
+    for name in re.findall(r"YP_[A-Z0-9_]+", open(os.path.join(root, "bench.py")).read()):
+        if name.startswith(("YP_BENCH", "YP_PROFILE")):
+            assert name in switches.SWITCHES, name
+    with pytest.raises(KeyError):
+        switches.sw("YP_NO_SUCH_SWITCH")
+    with pytest.raises(RuntimeError):
+        switches.check_environment({"YP_TRIAN_PAIR": "0"})
+    for name, s_ in switches.SWITCHES.items():
+        assert s_.kind in ("path", "knob", "debug", "native"), name
+        if s_.kind == "path" and name != "YP_DP_COMM":
+            assert s_.alt and s_.scope, f"{name}: a path switch needs its alternative values and the harness scope that tests them"

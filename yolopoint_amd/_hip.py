@@ -6,6 +6,7 @@ without a HIP device raises.
 """
 import ctypes as C
 import os
+from .switches import sw
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libyolopoint_hip.so")
@@ -193,7 +194,7 @@ def lib():
         # PyTorch-ROCm bundles its own libamdhip64: it must be in the process first, so that this library binds to the SAME
         # HIP runtime (loading ours first pulls /opt/rocm's copy in, and torch then finds no usable device)
         import torch  # noqa: F401
-        path = os.environ.get("YP_HIP_LIB", LIB_PATH)      # override: A/B-compare two builds of the library in one session
+        path = sw("YP_HIP_LIB") or LIB_PATH      # override: A/B-compare two builds of the library in one session
         if not os.path.exists(path):
             raise YpError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback)")

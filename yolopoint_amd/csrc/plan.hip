@@ -201,7 +201,7 @@ extern "C" int yp_plan_patch_op_view(YpPlan* plan, int op, int slot, YpView v) {
 // device, never destroyed: see below) and, the first time a caller's stream asks for a companion, TESTS candidates: a 200 us spin kernel on
 // the caller's stream, an empty kernel on the candidate -- when the empty kernel's event completes while the spin's has not, the two
 // streams are on different queues.  slot 0 = the plans' side lane, slot 1 = an auxiliary stream (engine.TrainStep's loss / label stream);
-// the picks of one caller are tested against each other too.  YP_STREAM_PICK=0: no tests, pool order.
+// the picks of one caller are tested against each other too.
 //
 // (One side stream per plan, destroyed with the plan, left the runtime in a state in which a later, unrelated hipGraphLaunch crashed --
 // ROCm 7.2, reproducible only after ~400 tests in one process.  Sharing is harmless: a plan orders its side ops with its own events.)
@@ -258,8 +258,7 @@ extern "C" int yp_stream_pick(void* main_stream, int slot, void** out) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         const bool capturing = main != nullptr && hipStreamIsCapturing(main, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
         (void)hipGetLastError();
-        const char* env = getenv("YP_STREAM_PICK");
-        const bool test = !(env && env[0] == '0') && !capturing;
+        const bool test = !capturing;
         while ((int)ds.pool.size() < POOL_STREAMS) {
             hipStream_t s = nullptr;
             // (a lowest-priority side stream was measured: no effect on the two-lane forward, 0.687-0.693 vs 0.686-0.702 ms)

@@ -37,7 +37,7 @@ struct WgradArgs {
     int Cj, Cout_pad;
     int n_co_blk;
     int tiles_x, tiles_y, ntiles, M;
-    int skip_store;                        // probe only (YP_WG_NOSTORE): time the reduction without the final atomics
+    int skip_store;                        // always 0 in the product (round-3 probe: time the reduction without the final atomics
     int blk;                               // channels per (ci x co) block side: 64, or 128 (1x1 filters with >= 128 channels on both sides)
     int g_blk0, g_nblk, g_split;           // grouped launch: first flat workgroup of this entry, its (ci x co) blocks and pixel split
     float* part;                           // deterministic mode: partial slabs [g_split][Cj][taps][Cout_pad] (plain stores, folded in order by
@@ -715,7 +715,7 @@ extern "C" int yp_stem_wgrad(YpView x, YpView dy, int dtype, int B, float* slabs
 // (the larger block pays off when a workgroup still walks >= 12 pixel tiles after the pixel split -- with few tiles per workgroup its
 // longer fill / drain and the single workgroup per CU cost more than the better MFMA : LDS ratio wins: YOLOPoint-s at 8 samples per GPU)
 static bool wgrad_big_ok(YpView x, YpView dy, int B, int k) {
-    if (k != 1 || x.C < 128 || dy.C < 128 || getenv("YP_WG_BLOCK64") != nullptr) return false;
+    if (k != 1 || x.C < 128 || dy.C < 128) return false;
     const long ntiles = ((long)B * dy.H * dy.W + 127) / 128;
     const int nblk = yp_cdiv(x.C, 128) * yp_cdiv(dy.C, 128);
     const int split = yp_cdiv(128, nblk);
@@ -745,20 +745,18 @@ static int wgrad_make_args(YpView x, YpView dy, int dtype, int B, int k, int str
     a.B = B; a.H = dy.H; a.W = dy.W; a.Cj = x.C; a.Cout_pad = dy.C; a.M = (int)M;
     a.blk = blk;
     a.n_co_blk = yp_cdiv(dy.C, blk);
-    a.skip_store = getenv("YP_WG_NOSTORE") != nullptr;
+    a.skip_store = false;
     const int nblk = yp_cdiv(x.C, blk) * a.n_co_blk;
     if (k == 3) { a.tiles_x = yp_cdiv(dy.W, 16); a.tiles_y = yp_cdiv(dy.H, stride == 2 ? 4 : 8); a.ntiles = B * a.tiles_x * a.tiles_y; }
     else a.ntiles = yp_cdiv((int)M, 128);
     // pixel split: one workgroup per CU.  Every workgroup ends in 64*64*taps fp32 atomics and the chip retires only ~250 G of them
-    // per second (tools/probe/wgrad_bench.py: YP_WG_NOSTORE halves the total), so more, smaller workgroups lose: 768 -> 256
+    // per second (measured in round 3: skipping the flush halves the total), so more, smaller workgroups lose: 768 -> 256
     // workgroups took the 23 distinct YOLOPoint-s shapes from 863 to 612 us.  A single 64x64 block of a 3x3 filter (nblk = 1)
     // is best at ~96 when it has few tiles per workgroup anyway.
     // (grouped launches run dozens of entries side by side: 128 workgroups per entry keep the chip full with half the slab / flush traffic --
     // 13.7 -> 13.0 ms per training step)
-    if (const char* e = getenv("YP_WG_TARGET")) target = atoi(e);
     int split = yp_cdiv(target, nblk);
     int cap = (k == 3 && nblk == 1 && a.ntiles <= 800) ? 96 : 256;
-    if (const char* e = getenv("YP_WG_CAP")) cap = atoi(e);          // (tools/probe/wgrad_bench.py)
     if (split > cap) split = cap;
     if (split > a.ntiles) split = a.ntiles;
     if (split < 1) split = 1;

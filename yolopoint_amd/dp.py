@@ -22,6 +22,7 @@ to start early).  With `bind_grads()` (what TrainStep uses) the parameters' .gra
 gradient bytes other than the collectives themselves; without it the gradients are copied in and out.
 """
 import contextlib
+from .switches import sw
 
 import torch
 import torch.distributed as dist
@@ -70,7 +71,7 @@ class GradAllReducer:
         self.sync = True
         self.force_collectives = False          # run the collectives even for a single rank (exercises the RCCL path on one GPU)
         import os
-        comm = os.environ.get("YP_DP_COMM", "fp32")
+        comm = sw("YP_DP_COMM")
         if comm not in ("fp32", "bf16"):
             # (f16 is not offered: a SUM-reduced fp16 stage overflows at 65 504 on loss-scaled or large gradients; bf16 has fp32's range)
             raise ValueError(f"YP_DP_COMM={comm!r}: the gradient exchange runs in 'fp32' (default, as accelerate / DDP reduce in the reference) or 'bf16'")

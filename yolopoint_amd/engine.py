@@ -14,6 +14,7 @@ import collections
 import contextlib
 import ctypes as C
 import os
+from .switches import sw
 
 import torch
 
@@ -96,31 +97,31 @@ class TrainStep:
         self.reducer = GradAllReducer(None, group=group, groups=groups)
         kp = set(id(p) for p in groups[1][1])
         # YP_TRAIN_PAIR=0: the two forwards of a step as two native passes (two graphs, the schedule of round 1) instead of one 2B-sample pass
-        self.pair = os.environ.get("YP_TRAIN_PAIR", "1") != "0"
+        self.pair = sw("YP_TRAIN_PAIR") != "0"
         # contributions a gradient receives per micro-batch: pair mode -- one backward plan reaches each parameter; two-graph mode -- the
         # trunk / keypoint-head parameters are reached by both passes' backward
         self.reducer.set_expected({p: (2 if (id(p) in kp and not self.pair) else 1) for p in self.reducer.params})
         # the reference's optimizer (train.py:88).  Default: optim.FlatAdam -- parameters / gradients / moments as four flat arrays, one
         # launch per step (torch's fused multi-tensor Adam: 6 launches, 0.38 ms for the 7.6 M parameters of YOLOPoint-s; its default
         # multi-tensor one re-reads them in ~10 passes, 2.5-3 ms).  YP_ADAM=torch: torch.optim.Adam(fused=True) over the same parameters.
-        if os.environ.get("YP_ADAM", "flat") == "flat" and torch.device(device).type == "cuda":
+        if sw("YP_ADAM") == "flat" and torch.device(device).type == "cuda":
             from .optim import FlatAdam
             self.opt = FlatAdam(self.reducer, params=[p for p in model.parameters() if p.requires_grad], lr=lr, all_params=list(model.parameters()))
         else:
-            self.opt = torch.optim.Adam(model.parameters(), lr=lr, fused=torch.device(device).type == "cuda" and os.environ.get("YP_ADAM_FUSED", "1") != "0")
+            self.opt = torch.optim.Adam(model.parameters(), lr=lr, fused=torch.device(device).type == "cuda")
         self.scheduler = torch.optim.lr_scheduler.LambdaLR(self.opt, lr_lambda=lr_lambda) if lr_lambda is not None else None
         self.sparse = dict(SPARSE)
         self.comm_events = None
-        if torch.device(device).type == "cuda" and os.environ.get("YP_TRAIN_SIDE_STREAM", "1") == "1":
+        if torch.device(device).type == "cuda" and sw("YP_TRAIN_SIDE_STREAM") == "1":
             from . import _hip
-            _hip.check(_hip.lib().yp_sampling_set_max_workgroups(int(os.environ.get("YP_SIDE_WGS", "256"))))
-        self._in_flight, self._max_in_flight = collections.deque(), int(os.environ.get("YP_STEPS_IN_FLIGHT", "2"))
+            _hip.check(_hip.lib().yp_sampling_set_max_workgroups(int(sw("YP_SIDE_WGS"))))
+        self._in_flight, self._max_in_flight = collections.deque(), int(sw("YP_STEPS_IN_FLIGHT"))
         # the loss / label stream: the stream the library TESTED to run beside the step's main stream (yp_stream_pick: streams that share a
         # hardware queue serialise -- a torch.cuda.Stream() from PyTorch's pool landed on the main stream's queue or not depending on how many
         # streams the process had handed out before: 7.4 or 9.4 ms per step).  It IS the plans' side lane (slot 0): the label kernels, the
         # heads of the forward and the InfoNCE chain are all background work for the main chain, and one queue for them measured faster than
-        # two (7.45 vs 7.68 ms; YP_AUX_STREAM=pick: a third queue, =torch: a PyTorch pool stream)
-        self._use_side = os.environ.get("YP_TRAIN_SIDE_STREAM", "1") == "1" and torch.device(device).type == "cuda"
+        # two (7.45 vs 7.68 ms with a third queue; a PyTorch pool stream may share the main stream's queue)
+        self._use_side = sw("YP_TRAIN_SIDE_STREAM") == "1" and torch.device(device).type == "cuda"
         self._side_streams = {}
         self.reducer.broadcast_parameters(model)
 
@@ -137,11 +138,7 @@ class TrainStep:
             import ctypes as C
             from . import _hip
             out = C.c_void_p()
-            mode = os.environ.get("YP_AUX_STREAM", "lane")
-            if mode == "torch":
-                s = self._side_streams[key] = torch.cuda.Stream(device=self.device)
-                return s
-            _hip.check(_hip.lib().yp_stream_pick(C.c_void_p(key), 0 if mode == "lane" else 1, C.byref(out)))
+            _hip.check(_hip.lib().yp_stream_pick(C.c_void_p(key), 0, C.byref(out)))
             s = self._side_streams[key] = torch.cuda.ExternalStream(out.value, device=self.device)
         return s
 
@@ -234,14 +231,13 @@ class TrainStep:
         return v
 
     def _native_stage_ok(self, batch):
-        if not self.pair or os.environ.get("YP_NATIVE_STAGE", "1") == "0" or type(self.model.model).__name__ != "YOLOPoint":
+        if not self.pair or sw("YP_NATIVE_STAGE") == "0" or type(self.model.model).__name__ != "YOLOPoint":
             return False
         img = batch['image']
         ok = img.is_cuda and img.dim() == 4 and img.shape[-1] % 8 == 0 and img.shape[-2] % 8 == 0 and tuple(batch['warped_image'].shape) == tuple(img.shape)
         # the stage consumes the device-side sampling (utils.loss_functions._prepare_native with the sorted pair index): the same predicate
         # as infonce_prepare's, or the step would trip over `assert sync` / a 4-tuple in the middle of a step with the graph marked busy
-        ok = ok and (img.shape[-2] // 8) * (img.shape[-1] // 8) < 36864 and os.environ.get("YP_NATIVE_PREPARE", "1") != "0" \
-            and os.environ.get("YP_SAMPLE_SORTED", "1") != "0"
+        ok = ok and (img.shape[-2] // 8) * (img.shape[-1] // 8) < 36864 and sw("YP_NATIVE_PREPARE") != "0"
         for k in ('labels_2D', 'warped_labels', 'valid_mask', 'warped_valid_mask'):
             t = batch[k]
             ok = ok and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == img.shape[0] * img.shape[-2] * img.shape[-1]
@@ -279,8 +275,8 @@ class TrainStep:
         #   "split" (default): target assignment + cell masks (what the object / detector losses read: ~60 us) in front of the forward
         #           launch, the InfoNCE sampling and its two CSR sorts (~1 ms, read by the InfoNCE chain on this same stream only) behind
         #           the heads; the main lane waits for the small part only.
-        order = os.environ.get("YP_LABELS_ORDER", "split") if side is not main else "after"
-        if order == "split" and int(os.environ.get("YP_LOSS_LANES", "2")) < 2:
+        order = sw("YP_LABELS_ORDER") if side is not main else "after"
+        if order == "split" and int(sw("YP_LOSS_LANES")) < 2:
             order = "after"                       # (the InfoNCE chain runs on the main stream there: it needs the sampling joined)
         if order == "after":
             g.forward(img, img_w, export=False)
@@ -311,7 +307,7 @@ class TrainStep:
         def nce_labels():
             return infonce_prepare(batch['warped_valid_mask'], batch['inv_homographies'], (B, D, Hc, Wc), True, self.sparse['num_samples_per_image'],
                                    self.sparse['num_masked_non_matches_per_match'], 8, dev, pair_index=True,
-                                   sync=os.environ.get("YP_PREPARE_SYNC", "0") == "1" or os.environ.get("YP_NATIVE_PREPARE", "1") == "0")
+                                   sync=sw("YP_PREPARE_SYNC") == "1" or sw("YP_NATIVE_PREPARE") == "0")
         if side is not main:
             side.wait_event(fork)
             with torch.cuda.stream(side):
@@ -360,7 +356,7 @@ class TrainStep:
             for j, key in enumerate(('labels_2D', 'warped_labels')):
                 check(lib.yp_detloss2d(stg.semi_ptr + 4 * j * B * stg.zs[0], stg.zs, batch[key].data_ptr(), stg.mask[j].data_ptr(), scal + 4 * (6 + j), float(f32(scale)),
                                        B, H, W, stg.dsemi_ptr + 4 * j * B * stg.ds[0], stg.ds, scal + 4 * (4 + j), stg.ws_main.data_ptr(), stg.ws_bytes, sp()))
-        lanes = int(os.environ.get("YP_LOSS_LANES", "2")) if side is not main else 0
+        lanes = int(sw("YP_LOSS_LANES")) if side is not main else 0
         tau = 0.07
         g_desc = f32(f32(scale) * f32(LAMBDA_DESC)) if scale != 1.0 else f32(LAMBDA_DESC)
 
@@ -374,7 +370,7 @@ class TrainStep:
             # critical path.  -s (D = 128): 256 workgroups 7.32 ms, 128 / 384 / 512 / 768: 7.36 / 7.38 / 7.42 / 7.55; -l (D = 256, 16
             # samples): 128 workgroups 34.6-34.8 ms, 256 / 384 / 768: 34.9 / 35.0 / 35.5, 96 / 64 / 32: 35.3 / 38.5 / 49.6
             # (16-bit rows, D = 256: 96 / 128 / 192 workgroups 29.94 / 30.35 / 29.96 ms per -l fp8 step, same box)
-            nce_wgs = int(os.environ.get("YP_NCE_WGS", "256" if D <= 128 else ("96" if g.code == _hip.YP_BF16 and os.environ.get("YP_NCE_ROWS", "bf16") == "bf16" else "128"))) if lanes >= 2 else 0
+            nce_wgs = int(sw("YP_NCE_WGS") or ("256" if D <= 128 else ("96" if g.code == _hip.YP_BF16 and sw("YP_NCE_ROWS") == "bf16" else "128"))) if lanes >= 2 else 0
             out4_ = torch.empty((8,), dtype=torch.float32, device=dev)        # [total, detector, descriptor, object, InfoNCE row count, -, -, -]: yp_loss_combine5 writes all five on both count paths
             if isinstance(nce, dict):
                 # counts on the device (infonce_prepare(sync=False)): arrays at their capacity, the kernels read points-per-image / matched rows
@@ -398,7 +394,7 @@ class TrainStep:
             # bf16 graphs (incl. fp8 mode): the gathers read a 16-bit copy of the sampled-descriptor table -- half the gathered bytes (the rows
             # of these two kernels are a fifth of the -l step's HBM / fabric traffic); fp32 / f16 graphs keep the fp32 rows.  YP_NCE_ROWS=fp32: off
             rows16 = None
-            if g.code == _hip.YP_BF16 and D in (64, 128, 256) and os.environ.get("YP_NCE_ROWS", "bf16") == "bf16":
+            if g.code == _hip.YP_BF16 and D in (64, 128, 256) and sw("YP_NCE_ROWS") == "bf16":
                 rows16 = torch.empty((2 * n, D), dtype=torch.bfloat16, device=dev)
                 check(lib.yp_infonce_rows16(dab.data_ptr(), 2 * n * D, rows16.data_ptr(), sp()))
                 check(lib.yp_infonce_fwd_grad_h(dab.data_ptr(), rows16.data_ptr(), idx.data_ptr(), n, E, D, 1.0 / tau, w.data_ptr(),
@@ -435,8 +431,6 @@ class TrainStep:
                 out4.record_stream(main)
             nce_done = side.record_event()
             join = lambda: main.wait_event(nce_done)
-            if getattr(g, "bwd_lanes", False):
-                main.wait_event(det_done)           # (the keypoint head's backward rides on the YOLO-branch plan's side lane: its seed must be final)
         elif lanes == 1:
             side.wait_event(main.record_event())
             with torch.cuda.stream(side):

@@ -9,6 +9,7 @@ The forward itself is one native plan replay (csrc/plan.hip).
 """
 import math
 from copy import deepcopy
+from ..switches import sw
 
 import torch
 from torch import nn
@@ -77,7 +78,7 @@ class YOLOPoint(HipModule):
         c = self.Conv1.conv
         fusable = (pb.code != _hip.YP_F32 and c.kernel_size == (6, 6) and c.stride == (2, 2) and c.padding == (2, 2) and c.in_channels <= 4
                    and c.out_channels % 16 == 0 and c.out_channels <= 64 and isinstance(self.Conv1.act, nn.SiLU) and getattr(self, "fuse_stem", True)
-                   and __import__("os").environ.get("YP_FUSE_STEM", "1") != "0")
+                   and sw("YP_FUSE_STEM") != "0")
         pb.stem_launch = None
         if not fusable:
             pb.scope.append("Conv1")
@@ -103,7 +104,7 @@ class YOLOPoint(HipModule):
               # (the never-materialised stem output is addressed with 32-bit byte offsets: B (H/2) (W/2) 32 channels x 2 bytes < 2^31 -- beyond
               # that, ~328 images of 640 x 640, the library refuses the fused launch and the two-launch plan, which has no such limit, is taken)
               and pb.B * (img.H // 2) * (img.W // 2) * 32 * 2 + 32 * 2 + 64 < (1 << 31)
-              and os.environ.get("YP_FUSE_STEM", "1") != "0" and os.environ.get("YP_FUSE_STEM2", "1") != "0")
+              and sw("YP_FUSE_STEM") != "0" and sw("YP_FUSE_STEM2") != "0")
         if not ok:
             out = run("Conv2", self.Conv2, self._emit_stem(pb, img))
             return (out, False) if block is not None else out
@@ -113,7 +114,7 @@ class YOLOPoint(HipModule):
         from .common import C3
         b1m = self.Bottleneck1
         if (block is not None and isinstance(b1m, C3) and c2.out_channels == 64 and b1m.cv1.conv.in_channels == 64 and b1m.cv1.conv.out_channels == 32
-                and isinstance(b1m.cv1.act, nn.SiLU) and isinstance(b1m.cv2.act, nn.SiLU) and os.environ.get("YP_FUSE_STEM3", "1") != "0"):
+                and isinstance(b1m.cv1.act, nn.SiLU) and isinstance(b1m.cv2.act, nn.SiLU) and sw("YP_FUSE_STEM3") != "0"):
             w12, b12 = b1m.merged_cv12()
             H2, W2 = img.H // 4, img.W // 4
             cat = pb.new_buf(H2, W2, 64)
@@ -125,7 +126,7 @@ class YOLOPoint(HipModule):
             return block("Bottleneck1", b1m, None, pre=(t, cat)), True
         from .common import C2f
         if (block is not None and isinstance(b1m, C2f) and c2.out_channels == 64 and b1m.cv1.conv.in_channels == 64 and b1m.cv1.conv.out_channels == 64
-                and b1m.cv1.conv.kernel_size == (1, 1) and isinstance(b1m.cv1.act, nn.SiLU) and os.environ.get("YP_FUSE_STEM3", "1") != "0"):
+                and b1m.cv1.conv.kernel_size == (1, 1) and isinstance(b1m.cv1.act, nn.SiLU) and sw("YP_FUSE_STEM3") != "0"):
             wc, bc = b1m.cv1.folded()                   # (v52: the C2f's cv1 fills channels [0, 2c) of its concat buffer)
             cat = pb.new_buf(img.H // 4, img.W // 4, (2 + len(b1m.m)) * b1m.c)
             pb.scope.append("Conv1+Conv2+Bottleneck1.cv1")
@@ -156,7 +157,7 @@ class YOLOPoint(HipModule):
         xa = x if fused_b1 else run("Bottleneck1", self.Bottleneck1, x)
         x8 = run("Conv3", self.Conv3, xa)
         xb = run("Bottleneck2", self.Bottleneck2, x8)
-        fork = int(__import__("os").environ.get("YP_HEADS_FORK", "4"))        # the heads are forked behind Bottleneck<fork> (2 / 3 / 4; measurements above)
+        fork = int(sw("YP_HEADS_FORK"))        # the heads are forked behind Bottleneck<fork> (2 / 3 / 4; measurements above)
         heads = {}
 
         def emit_heads():
@@ -239,7 +240,7 @@ class YOLOPoint(HipModule):
             # A plan with schedule lanes replays EAGERLY on its two streams even when a graph was asked for: captured into a hipGraph the
             # side branch bought 0-4 % (0.743 vs 0.752 ms at batch 8), the same launches on two plain streams 8 % (0.691 ms) -- the ~50
             # launches of a forward cost the host ~0.2 ms, well inside the step.  YP_LANES_EAGER=0: capture them.
-            if graph and not plan.has_callbacks and not (plan.has_lanes and __import__("os").environ.get("YP_LANES_EAGER", "1") != "0"):
+            if graph and not plan.has_callbacks and not (plan.has_lanes and sw("YP_LANES_EAGER") != "0"):
                 plan.instantiate_graph()
             cache[key] = (plan, img, outs)
         return cache[key]

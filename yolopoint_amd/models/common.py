@@ -7,6 +7,7 @@ how to `emit` itself into a PlanBuilder; `forward(x)` runs a cached single-block
 can be called (and tested) on their own like the reference's.
 """
 import os
+from ..switches import sw
 
 import torch
 import torch.nn as nn
@@ -191,11 +192,13 @@ class Bottleneck(HipModule):
     # (one launch, hidden tensor never in HBM).  YP_FUSE_BOTTLENECK=0|1 overrides for A/B measurements.
     # Default True: back-to-back timing of the two-launch form ("auto") under-estimates its in-chain latency; the fused
     # form measured +5% whole-net throughput on YOLOPoint-s (bs8 640x640 f16) vs +3.8% for "auto".
-    fuse = {"0": False, "auto": "auto"}.get(os.environ.get("YP_FUSE_BOTTLENECK", ""), True)
+    @property
+    def fuse(self):
+        return {"0": False, "auto": "auto"}.get(sw("YP_FUSE_BOTTLENECK"), True)       # (read when a plan is emitted)
 
     def _fusable(self, pb, x):
         c1, c_, c2 = self.cv1.conv.in_channels, self.cv1.conv.out_channels, self.cv2.conv.out_channels
-        allowed = tuple(int(v) for v in os.environ["YP_FUSE_ONLY_C"].split(",")) if os.environ.get("YP_FUSE_ONLY_C") else (32, 64, 128)
+        allowed = (32, 64, 128)
         return (self.fuse and isinstance(x, View) and x.ups == 0 and c1 == c_ == c2 and c_ in allowed and pb.code != _hip.YP_F32
                 and self.cv2.conv.kernel_size == (3, 3) and self.cv2.conv.stride == (1, 1) and self.cv2.conv.padding == (1, 1)
                 and isinstance(self.cv1.act, nn.SiLU) and isinstance(self.cv2.act, nn.SiLU))
@@ -238,7 +241,7 @@ class C3(HipModule):
         self.m = nn.Sequential(*(Bottleneck(c_, c_, shortcut, g, e=1.0) for _ in range(n)))
 
     # YP_FUSE_C3_TAIL=0 disables the cv3-in-the-last-Bottleneck fusion (A/B measurements)
-    fuse_tail = os.environ.get("YP_FUSE_C3_TAIL", "1") != "0"
+    fuse_tail = sw("YP_FUSE_C3_TAIL") != "0"
 
     def _standalone_out_channels(self):
         return self.cv3.conv.out_channels

@@ -11,6 +11,7 @@ import contextlib
 import ctypes as C
 import os
 import math
+from .switches import sw
 
 import torch
 
@@ -203,16 +204,16 @@ _TUNE_CACHE = {}
 _TUNE_CANDIDATES = (1, 2, 3, 4, 5, 21, 22, 23, 24, 25, 26, 27, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 41, 42, 43, 44, 57, 58, 61, 62)
 # pixels per BatchNorm-statistics row of the variants whose rows are plain pixel blocks (the 3x3 halo kernels write one row per image tile)
 _STAT_ROW_PX = {41: 128, 57: 128, 58: 128, 61: 256, 62: 224}
-_TUNE_ITERS = int(os.environ.get("YP_TUNE_ITERS", "8"))      # timed launches per candidate
-_TUNE_COLD = int(os.environ.get("YP_TUNE_COLD", "0"))        # MB swept through the L2s in front of every timed launch (0: back-to-back, hot)
+_TUNE_ITERS = int(sw("YP_TUNE_ITERS"))      # timed launches per candidate
+_TUNE_COLD = int(sw("YP_TUNE_COLD"))        # MB swept through the L2s in front of every timed launch (0: back-to-back, hot)
 _TUNE_FLUSH = None
-if os.environ.get("YP_TUNE_ONLY"):           # A/B experiments: restrict the autotuner to a subset of the variants
-    _TUNE_CANDIDATES = tuple(int(v) for v in os.environ["YP_TUNE_ONLY"].split(","))
+if sw("YP_TUNE_ONLY"):           # A/B experiments: restrict the autotuner to a subset of the variants
+    _TUNE_CANDIDATES = tuple(int(v) for v in sw("YP_TUNE_ONLY").split(","))
 
 
 def _shared_tuning_group():
     """(torch.distributed module, rank) when the autotuner's choices are shared across the ranks of a data-parallel job, else None."""
-    if os.environ.get("YP_TUNE_SHARED", "1") == "0":
+    if sw("YP_TUNE_SHARED") == "0":
         return None
     try:
         import torch.distributed as dist
@@ -624,7 +625,7 @@ class PlanBuilder:
         plan then replays as a main chain + one side chain instead of per-slice dependency edges.  YP_INFER_LANES=0 disables it."""
         n0 = lib().yp_plan_num_ops(self.handle)
         yield
-        if enable and os.environ.get("YP_INFER_LANES", "1") != "0":
+        if enable and sw("YP_INFER_LANES") != "0":
             for j in range(n0, lib().yp_plan_num_ops(self.handle)):
                 check(lib().yp_plan_set_lane(self.handle, j, _hip.LANE_SIDE))
                 self.has_lanes = True
@@ -708,7 +709,7 @@ class PlanBuilder:
         else:
             run = lambda: lib().yp_conv2d(C.byref(d), st)
         best, best_ms = 0, None
-        rnd = os.environ.get("YP_TUNE_RANDOM")        # stress mode (tests): a pseudo-random applicable variant per signature instead of the fastest
+        rnd = sw("YP_TUNE_RANDOM")        # stress mode (tests): a pseudo-random applicable variant per signature instead of the fastest
         applicable = []
         for cand in _TUNE_CANDIDATES:
             if det is not None and 10 <= cand <= 19:
@@ -749,20 +750,17 @@ class PlanBuilder:
                 e1.record()
                 e1.synchronize()
                 ms = e0.elapsed_time(e1) * 8.0 / iters          # (kept in units of 8 launches: the cache stores ms / 8)
-            if os.environ.get("YP_TUNE_DEBUG"):
+            if sw("YP_TUNE_DEBUG"):
                 print(f"[tune] {self.name():40s} cand {cand:2d}: {ms / 8 * 1e3:7.1f} us", flush=True)
             if best_ms is None or ms < best_ms:
                 best, best_ms = cand, ms
         if rnd is not None and applicable:
             import random
             best, best_ms = random.Random(f"{rnd}:{len(_TUNE_CACHE)}").choice(applicable), None
-            force = dict(tuple(int(v) for v in kv.split(":")) for kv in os.environ.get("YP_TUNE_FORCE", "").split(",") if kv)
+            force = dict(tuple(int(v) for v in kv.split(":")) for kv in sw("YP_TUNE_FORCE").split(",") if kv)
             if force:                                             # explicit mixture: signature index -> variant, everything else the first one
                 best = force.get(len(_TUNE_CACHE), applicable[0])
-            lim = os.environ.get("YP_TUNE_RANDOM_LIMIT")          # bisecting a failing mixture: signatures past the limit take the first variant
-            if lim is not None and not any(int(r_.split(",")[0]) <= len(_TUNE_CACHE) < int(r_.split(",")[1]) for r_ in lim.split(";")):
-                best = applicable[0]
-            if os.environ.get("YP_TUNE_DEBUG"):
+            if sw("YP_TUNE_DEBUG"):
                 print(f"[tune-random] {self.name():44s} pick {best:2d} of {applicable} zs={int(d.in0_zero_stuffed)} k={d.R}x{d.S} s={d.stride_h} Cin={d.in0.C}+{d.in1.C} N={d.Npad} M={d.B * d.Ho * d.Wo}", flush=True)
         _TUNE_CACHE[key] = (best, (best_ms / 8 if best_ms is not None else None))
         return _TUNE_CACHE[key]
@@ -791,11 +789,8 @@ class PlanBuilder:
     def finish(self, parallel=True):
         """Freeze the plan; attach the data dependencies used when it is captured into a hipGraph."""
         assert len(self.accesses) == len(self.records) == lib().yp_plan_num_ops(self.handle)
-        if os.environ.get("YP_GRAPH_LINEAR") == "1":      # A/B: replay every plan as a linear chain
+        if sw("YP_GRAPH_LINEAR") == "1":      # A/B: replay every plan as a linear chain
             parallel = False
-        if os.environ.get("YP_PLAN_DEBUG"):
-            for j, r in enumerate(self.records):
-                print(f"[plan] {j:3d} {'SIDE' if j in getattr(self, 'side_ops', ()) else 'main'} {r.name} ({r.kind})", flush=True)
         if getattr(self, "has_lanes", False):             # explicit schedule lanes: the captured topology (main chain + side chain) is the schedule
             parallel = False
             # the lane assignment must agree with the data dependencies: nothing on the main lane may touch what a side op writes or is

@@ -27,6 +27,7 @@ import ctypes as C
 import contextlib
 import os
 import weakref
+from .switches import sw
 
 import torch
 
@@ -97,14 +98,13 @@ class TrainGraph:
         # YP_TRAIN_LANES=1: weight-gradient kernels on a second lane of the backward graph (yp_plan_set_lane), beside the dgrad /
         # BatchNorm chain that never reads them.  Measured: 20.5 ms per step against 19.2 ms on one lane -- the concurrent kernels
         # fight over CUs / LDS / L2 (as the sub-batch stream experiment of the forward did) -- so it stays off.
-        self.lanes = os.environ.get("YP_TRAIN_LANES", "0") == "1"
-        self.bwd_lanes = False
-        # YP_WGRAD_GROUP=0: one launch per weight gradient instead of one per filter class and backward pass
-        self.group_wgrad = not self.lanes and os.environ.get("YP_WGRAD_GROUP", "1") != "0"
+        self.lanes = sw("YP_TRAIN_LANES") == "1"
+        # (one launch per filter class and backward pass; per-layer launches only with the weight-gradient lane)
+        self.group_wgrad = not self.lanes
         self.dw_arena = torch.zeros(round_up(2 * sum(p_.numel() for p_ in net.parameters()) + (1 << 20), 64), dtype=torch.float32, device=device)
         self.dw_used = 0
-        # YP_WGRAD_DET=0: fp32 atomics instead of per-slice slabs + ordered fold (not bit-reproducible)
-        self.det_wgrad = self.group_wgrad and os.environ.get("YP_WGRAD_DET", "1") != "0"
+        # (per-slice slabs + ordered fold: bit-reproducible; the per-layer launches of the lane form use fp32 atomics)
+        self.det_wgrad = self.group_wgrad
         self.wpart = None
         self._build()
 
@@ -206,7 +206,7 @@ class TrainGraph:
 
     def q8_produced(self, pb, v, fmt):
         """Arguments that make a BatchNorm pass write view `v`'s twin (forward output: fmt 0 = e4m3; dx: fmt 1 = e5m2), or None."""
-        if not (self.fp8 and self.q8_ok([v]) and self.q8_fusable(v) and os.environ.get("YP_FP8_FUSE", "1") != "0"):
+        if not (self.fp8 and self.q8_ok([v]) and self.q8_fusable(v)):
             return None
         tb, slot, key = self.q8_twin(pb, v, fmt)
         pb.__dict__.setdefault("quantized", {}).setdefault(key, []).append((v.coff, v.coff + v.C))
@@ -252,10 +252,8 @@ class TrainGraph:
         wsrc = MasterWeight(conv.weight, mode="image" if image else 0)
         # The BatchNorm column sums come out of the convolution's epilogue (YpConvDesc.bn_partial: one partial row per block of 64 pixels in
         # the generic kernel, per pixel tile in the 3x3 halo kernels) -- no separate reduction pass over the raw output.
-        # YP_BN_EPILOGUE=0: the reduction kernel everywhere; =1: 1x1 convolutions only (the first version).
         chunk = 16 if code == _hip.YP_F32 else 32          # (the epilogue variant exists for the kernels' fast addressing mode: 64-byte k chunks)
-        mode = os.environ.get("YP_BN_EPILOGUE", "2")
-        fuse_stats = (not image and all(v.C % chunk == 0 for v in srcs) and mode != "0" and (k == 1 and s == 1 or (mode == "2" and k == 3 and code != _hip.YP_F32)))
+        fuse_stats = (not image and all(v.C % chunk == 0 for v in srcs) and (k == 1 and s == 1 or (k == 3 and code != _hip.YP_F32)))
         partial = None
         Ho_, Wo_ = (srcs[0].LH + 2 * p - k) // s + 1, (srcs[0].LW + 2 * p - k) // s + 1
         if G > 1 and (self.Bs * Ho_ * Wo_) % 64:
@@ -263,7 +261,7 @@ class TrainGraph:
         if fuse_stats:
             rows = max(-(-(B * Ho_ * Wo_) // 64), B * -(-Ho_ // 4) * -(-Wo_ // 16) if k == 3 else 0)
             partial = torch.zeros((rows, 2, round_up(conv.out_channels, 8)), dtype=torch.float32, device=self.device)
-        q8 = self.fp8 and not image and self.q8_ok(srcs) and os.environ.get("YP_FP8_FWD", "1") != "0"
+        q8 = self.fp8 and not image and self.q8_ok(srcs) and sw("YP_FP8_FWD") != "0"
         conv_srcs, extra = srcs, (dict(bn_partial=partial, stat_group_px=(self.Bs * Ho_ * Wo_ if G > 1 else None)) if fuse_stats else {})
         x8 = None
         if q8:
@@ -317,7 +315,7 @@ class TrainGraph:
             b = self.bwd
             B = b.B                  # (the plan's samples: in pair mode the image pass's B for the YOLO-branch plan -- statistics group 0)
             gy = self.gread(out)
-            fuse_res = res is not None and os.environ.get("YP_BN_BWD_RES", "1") != "0"
+            fuse_res = res is not None
             gr = None
             if res is not None:
                 gr, acc = self.gview(res)
@@ -330,7 +328,7 @@ class TrainGraph:
             gw_, gb_ = self.pgrad(bn.weight), self.pgrad(bn.bias)
             dg, db = (b.new_tensor((Cp,)), b.new_tensor((Cp,))) if padded else (gw_, gb_)
             # fp8 mode: the e5m2 twin of dx (the dgrad's operand) comes out of the same pass
-            tw = self.q8_produced(b, draw, 1) if (os.environ.get("YP_FP8_DGRAD", "1") != "0" and not image) else None
+            tw = self.q8_produced(b, draw, 1) if (sw("YP_FP8_DGRAD") != "0" and not image) else None
             if tw is None:
                 b.op(_hip.OP_BN_BWD, [raw, gy] + rw, [draw, self.T(self.ws)] + rw, "bn_act_bwd", v=[raw, gy, draw], i=[code, B, act, 0, self.bG] + rs["i567"],
                      f=[mean, invstd, gamma, beta], g=[dg, db], p=[self.ws, rs["p1"]], n=[self.ws.numel()])
@@ -391,12 +389,12 @@ class TrainGraph:
         dyp = None
         dq = None
         # fp8 mode: the e5m2 copy of the output gradient (one per convolution: the operand of its sources' dgrads AND of its weight gradients)
-        q8_dy = (self.fp8 and bias is None and draw.buf.t.dtype == torch.bfloat16 and self.q8_ok([draw]) and os.environ.get("YP_FP8_DGRAD", "1") != "0")
+        q8_dy = (self.fp8 and bias is None and draw.buf.t.dtype == torch.bfloat16 and self.q8_ok([draw]) and sw("YP_FP8_DGRAD") != "0")
         if q8_dy and all(src.C % 8 == 0 and not (src.geom is None and src.cstride == 4 and src.C == 4) for src in srcs):
             dq = self.q8_sources(b, [draw], 1)
         # 8-bit weight gradients (csrc/wgrad.hip::wgrad_body8): x = the e4m3 twin the forward convolution multiplied, dy = the e5m2 twin the dgrad
         # multiplies -- half the bytes of the 16-bit operands; the layers where both twins exist (all channel counts multiples of 64)
-        q8_w = (x8 is not None and dq is not None and direct and self.group_wgrad and os.environ.get("YP_FP8_WGRAD", "1") != "0"
+        q8_w = (x8 is not None and dq is not None and direct and self.group_wgrad and sw("YP_FP8_WGRAD") != "0"
                 and all(v.C % 16 == 0 and v.coff % 16 == 0 and v.cstride % 16 == 0 for v in x8[0]))
         c0 = 0
         for j, src in enumerate(srcs):
@@ -419,7 +417,7 @@ class TrainGraph:
                 else:
                     self.wgroups.setdefault((k, s, lib().yp_wgrad_block(src.c(), draw.c(), B, k), B, False), []).append(
                         (src, draw, dwb, 2 * B * Ho * Wo * Cj * k * k * Cout))
-            elif image and code != _hip.YP_F32 and (k, s, p) == (6, 2, 2) and Cout_pad <= 80 and os.environ.get("YP_STEM_WGRAD", "1") != "0":
+            elif image and code != _hip.YP_F32 and (k, s, p) == (6, 2, 2) and Cout_pad <= 80:
                 # the stem: its own kernel over the packed image (no pixel-major copies of the two largest tensors of the pass)
                 nsl = lib().yp_stem_wgrad_slabs(B, Hi, Wi)
                 slabs = torch.empty((nsl, 144 * Cout_pad), dtype=torch.float32, device=self.device)
@@ -477,7 +475,7 @@ class TrainGraph:
                     b.conv([dsrc], w_dgrad, None, k, 1, k - 1 - p, _hip.YP_ACT_NONE, out=tmp, extra=dict(zero_stuffed=(s == 2), **dextra))
                     gv, acc = self.gview(base)
                     b.op(_hip.OP_UPS2_BWD, [tmp, gv], [gv], "ups_bwd", v=[tmp, gv], i=[code, B, int(acc)])
-                elif (s == 2 and k == 3 and p == 1 and Hi == 2 * Ho and Wi == 2 * Wo and os.environ.get("YP_DGRAD_PHASES", "1") != "0"):
+                elif (s == 2 and k == 3 and p == 1 and Hi == 2 * Ho and Wi == 2 * Wo and sw("YP_DGRAD_PHASES") != "0"):
                     # stride 2: the input pixels of each parity class (py, px) receive only (1 + py) x (1 + px) of the nine taps -- four small
                     # stride-1 convolutions over dy that write their class of the gradient tensor, a quarter of the multiply-adds of one 3x3
                     # convolution over the zero-stuffed dy (YOLOPoint-l: 645 -> ~200 us for Conv2's dgrad)
@@ -502,7 +500,7 @@ class TrainGraph:
         back in memory (optim.FlatAdam's arena in training.grad_ready_groups order + training.link_siblings) they ARE one Conv with
         2c_ output channels -- returns that layer (a namespace with the attributes conv_bn_act reads), else None."""
         import types
-        if os.environ.get("YP_MERGE_SIBLINGS", "1") == "0" or type(a.act) is not type(b.act) or a.bn.eps != b.bn.eps or a.bn.momentum != b.bn.momentum:
+        if type(a.act) is not type(b.act) or a.bn.eps != b.bn.eps or a.bn.momentum != b.bn.momentum:
             return None
         pairs = [(a.conv.weight, b.conv.weight), (a.bn.weight, b.bn.weight), (a.bn.bias, b.bn.bias), (a.bn.running_mean, b.bn.running_mean),
                  (a.bn.running_var, b.bn.running_var)]
@@ -600,7 +598,7 @@ class TrainGraph:
         # keypoint head: C3 + plain 1x1 conv (fp32) | v52: a 65-channel C2f whose BN + SiLU output IS semi
         # Forward lanes (YP_TRAIN_FWD_LANES=0 turns them off): the two heads on the forward plan's side lane, beside the YOLO encoder / PAN /
         # Detect chain (whose P4 / P5 layers leave most CUs idle); the plan then replays eagerly on two streams (see PlanBuilder.side)
-        fwd_lanes = os.environ.get("YP_TRAIN_FWD_LANES", "1") != "0" and not self.lanes
+        fwd_lanes = sw("YP_TRAIN_FWD_LANES") != "0" and not self.lanes
         # Each head is emitted (= forked) right behind the last tensor it reads: Conv3 (x8) for the keypoint head, Bottleneck2 (xb) for the
         # descriptor head.  Later forks measured slower (both heads behind Bottleneck2 / 3 / 4: 7.60 / 7.84 / 8.01 ms per step).
         hd = {}
@@ -707,7 +705,7 @@ class TrainGraph:
         # Detect levels 0 / 1 (a 1x1 convolution + its epilogue each) on the side lane beside Conv8 / Conv9 of the PAN.  Round 5, after the convolution
         # epilogues stopped waiting for their own stores: -s step 7.19 -> 6.83 ms at batch 8 (same box, two pairs; 7.02 -> 6.79 with the previous
         # library), -l and batch 64 unchanged (33.4 / 33.4, 29.6 / 29.7, 41.8 / 42.1 ms).  YP_TRAIN_DET_LANES=0: off.  Same kernels, same bits.
-        det_lanes = fwd_lanes and os.environ.get("YP_TRAIN_DET_LANES", "1") == "1"
+        det_lanes = fwd_lanes and sw("YP_TRAIN_DET_LANES") == "1"
         with self.side_lane(f, det_lanes):
             detect_level(0, xf)
         x = self.conv_bn_act(net.Conv8, xf)
@@ -722,19 +720,17 @@ class TrainGraph:
         # of linear chains.  Measured SLOWER for the training step (14.4 vs 13.1 ms: the concurrent BatchNorm / weight-gradient / dgrad
         # kernels fight over CUs and L2, as the two-lane schedule and the sub-batch streams of the forward did), so it is off by default;
         # bit-identical results either way (tests/test_gpu_training.py).
-        self.par = not self.lanes and os.environ.get("YP_TRAIN_PARALLEL", "0") == "1"
+        self.par = not self.lanes and sw("YP_TRAIN_PARALLEL") == "1"
         self.fwd_plan = f.finish(parallel=self.par)
 
         # ---- backward plans: clear the weight-gradient arena, seed the head gradients, then the tape in reverse.
         # Two variants: the full one, and one that only back-propagates the semi / desc sub-graph -- the reference's second
         # forward of a step (warped image) has no object loss, so autograd never visits its Detect / PAN / YOLO-encoder
         # layers (4 F_fwd + 2 F_kp per sample, not 6 F_fwd).
-        def emit(branches, B, groups, fresh=True, side=None, skip=()):
+        def emit(branches, B, groups, fresh=True):
             """One backward plan over the tape entries of `branches` ('kp': trunk + keypoint / descriptor heads, 'yolo': YOLO encoder + PAN +
             Detect), B samples, `groups` statistics groups.  fresh=False: the activation gradients an earlier plan of the same pass wrote
-            stay valid (pair mode: the trunk plan accumulates onto what the YOLO-branch plan left in the backbone output's gradient).
-            side = (tag, samples, groups): the tape entries tagged `tag` run on the plan's side lane over their own sample count (pair mode: the
-            keypoint head's backward beside the YOLO-branch chain); skip: tags left to another plan."""
+            stay valid (pair mode: the trunk plan accumulates onto what the YOLO-branch plan left in the backbone output's gradient)."""
             self.bwd = bb = PlanBuilder(B, code, self.device)
             self.builders.append(bb)
             bb.fp8 = self.fwd.fp8
@@ -748,25 +744,15 @@ class TrainGraph:
                 self.wpart = None         # (pair mode: one slab arena per plan -- the two plans differ in batch)
             self.dw_used = 0              # (the plans of a graph run one after another and unpack their accumulators at their end)
             bb.op(_hip.OP_MEMSET0, [], [self.T(self.dw_arena)], "zero_dw", p=[self.dw_arena], n=[self.dw_arena.numel() * 4])
-            if side is not None:
-                bb.B, self.bG = side[1], side[2]
-                with self.side_lane(bb):
-                    semi_seed()
-                    for _, fn, tag in reversed(self.tape):
-                        if tag == side[0]:
-                            fn()
-                bb.B, self.bG = B, groups
             if "kp" in branches:
-                if "kph" not in skip:
-                    semi_seed()
+                semi_seed()
                 desc_seed()
             if "yolo" in branches:
                 for fn in det_seeds:      # Detect backward runs before the PAN blocks' backward (it writes their output gradients)
                     fn()
             for branch, fn, tag in reversed(self.tape):
-                if branch in branches and tag not in skip:
+                if branch in branches:
                     fn()
-            joined = side is None
             for (gk, gs, gblk, gB, g8), ents in sorted(self.wgroups.items()):
                 n = len(ents)
                 gcode = _hip.YP_FP8 if g8 else code       # (8-bit entries: x / dy are the 1-byte twins, e[4] / e[5] their scale pointers)
@@ -799,9 +785,6 @@ class TrainGraph:
                       f"wgrad_k{gk}s{gs}" + ("b128" if gblk == 128 else "") + ("q8" if g8 else ""), p=[wtab],
                       i=[gcode, n, blocks.value, gk, gs, fold.value, gblk])
                 bb.records[-1].kind, bb.records[-1].flops = "conv", sum(e[3] for e in ents)
-                if not joined:            # the grouped launches read the side lane's output gradients
-                    bb.set_lane(_hip.LANE_JOIN)
-                    joined = True
             rows, tile0 = [], 0
             for u in self.unpack:
                 rows.append([u["dw"].flat.data_ptr(), u["grad"].data_ptr(), u["rows"], u["cout"], u["cout_pad"], u["out_stride"], u["out_off"], tile0,
@@ -820,23 +803,16 @@ class TrainGraph:
         else:
             # pair mode: the YOLO-branch layers over the image pass's samples (statistics group 0 = the first Bs samples of every buffer),
             # then the trunk + keypoint / descriptor heads over both passes
-            # YP_TRAIN_BWD_LANES=1: the keypoint head's backward (over both passes; its seed, the detector loss, is ready long before the
-            # InfoNCE gradient the descriptor head waits for) on the YOLO-branch plan's side lane.  Measured slower (7.60 vs 7.40 ms per
-            # step): that plan already shares the GPU with the InfoNCE gathers of the loss stream, and the head's full-width kernels delay
-            # the YOLO chain's small ones.  Off by default.
-            self.bwd_lanes = fwd_lanes and os.environ.get("YP_TRAIN_BWD_LANES", "0") == "1" and not self.fp8
-            if self.bwd_lanes:
-                self.bwd_plan, self.bwd_params, self.bwd_collect = emit(("yolo",), self.Bs, 1, side=("kph", B, self.G))
-                self.bwd_kp_plan, self.bwd_kp_params, self.bwd_kp_collect = emit(("kp",), B, self.G, fresh=False, skip=("kph",))
-            else:
-                self.bwd_plan, self.bwd_params, self.bwd_collect = emit(("yolo",), self.Bs, 1)
-                self.bwd_kp_plan, self.bwd_kp_params, self.bwd_kp_collect = emit(("kp",), B, self.G, fresh=False)
+            # (Round 4 built a variant with the keypoint head's backward on the YOLO-branch plan's side lane, YP_TRAIN_BWD_LANES: measured slower,
+            # 7.60 vs 7.40 ms per step, and round 6's switch harness found that its gradients differ from the default's on 24 tensors -- removed.)
+            self.bwd_plan, self.bwd_params, self.bwd_collect = emit(("yolo",), self.Bs, 1)
+            self.bwd_kp_plan, self.bwd_kp_params, self.bwd_kp_collect = emit(("kp",), B, self.G, fresh=False)
         self._drop_unread_16bit_copies(net)
-        mode = os.environ.get("YP_TRAIN_GRAPH", "1")         # replay the launch lists as hipGraphs (284 / 455 / 230 launches)
-        if mode in ("1", "fwd") and not (self.fwd_plan.has_lanes and os.environ.get("YP_LANES_EAGER", "1") != "0"):
+        mode = sw("YP_TRAIN_GRAPH")         # replay the launch lists as hipGraphs (284 / 455 / 230 launches)
+        if mode in ("1", "fwd") and not (self.fwd_plan.has_lanes and sw("YP_LANES_EAGER") != "0"):
             self.fwd_plan.instantiate_graph()
         if mode in ("1", "bwd"):
-            if not (self.bwd_plan.has_lanes and os.environ.get("YP_LANES_EAGER", "1") != "0"):
+            if not (self.bwd_plan.has_lanes and sw("YP_LANES_EAGER") != "0"):
                 self.bwd_plan.instantiate_graph()
             self.bwd_kp_plan.instantiate_graph()
         self.params = [p_ for p_ in net.parameters()]
@@ -854,7 +830,7 @@ class TrainGraph:
         descriptor normalisation -- keeps every copy unless it says otherwise), and whatever reads a view from outside the plans registers it
         (register_external_read: the probe dictionary head_debug does).  Dropped views are recorded (dropped_views / assert_readable), and the
         first fp8 optimizer step of engine.TrainStep checks the gradients for non-finite values."""
-        if not self.fp8 or not self.twin_only or os.environ.get("YP_FP8_TWIN_ONLY", "1") == "0" or not type(net).__dict__.get("plans_cover_all_reads", False):       # (the class's OWN declaration: not inherited)
+        if not self.fp8 or not self.twin_only or sw("YP_FP8_TWIN_ONLY") == "0" or not type(net).__dict__.get("plans_cover_all_reads", False):       # (the class's OWN declaration: not inherited)
             return
         reads = [r for pb in [self.fwd] + self.builders for rd, _ in pb.accesses for r in rd] + [PlanBuilder._rng(v_) for v_ in self.external_reads]
 
@@ -912,9 +888,9 @@ class TrainGraph:
             if "fp8" in self.pack:
                 # once per optimizer step: last step's recorded maxima become this step's quantisation scales (delayed scaling), then
                 # the e4m3 filter copies are re-derived with their new scales
-                self.pack["fp8"].update(float(os.environ.get("YP_FP8_MARGIN", "1.0")))
+                self.pack["fp8"].update(float(sw("YP_FP8_MARGIN")))
             ents = getattr(self.pack["pb"], "pack_entries", [])
-            if len(ents) == nops and os.environ.get("YP_PACK_BATCH", "1") != "0":
+            if len(ents) == nops:
                 if self.pack.get("table_n") != nops:
                     rows, blk0 = [], 0
                     for e in ents:
@@ -992,17 +968,13 @@ class TrainGraph:
                 dst.zero_()
             else:
                 dst.copy_(src)
-        early = getattr(self, "bwd_lanes", False)     # (the keypoint head's backward is part of the first plan: its side lane)
-        if early:
-            seed(self.seed_semi, g_semi)
         self.bwd_plan.run()
         for fn in self.bwd_collect:
             fn()
         first = {p_: self.pgrads[p_] for p_ in self.params if p_ in self.bwd_params}
         if between is not None:
             between(first)
-        if not early:
-            seed(self.seed_semi, g_semi)
+        seed(self.seed_semi, g_semi)
         seed(self.seed_desc, g_desc)
         self.bwd_kp_plan.run()
         for fn in self.bwd_kp_collect:

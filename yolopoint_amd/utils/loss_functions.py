@@ -7,6 +7,7 @@ The random draws of `infonce` (match shuffling, negative sampling) can be inject
 so that the loss is reproducible in tests; by default they are the reference's torch.randperm / np.random.randint.
 """
 import os
+from ..switches import sw
 
 import numpy as np
 import torch
@@ -40,7 +41,7 @@ class ComputeDetectorLoss:
         losses of the sets (train.py:232: loss_det + loss_det_warp with both passes' logits in one tensor) -- one gradient tensor for
         the whole input instead of one zero-padded tensor per set."""
         if (inp.is_cuda and inp.dtype == torch.float32 and inp.dim() == 4 and inp.shape[1] == 65 and target.dtype == torch.float32
-                and os.environ.get("YP_NATIVE_DETLOSS", "1") != "0"):
+                and sw("YP_NATIVE_DETLOSS") != "0"):
             return _DetLossNative.apply(inp, target, mask.float().contiguous(), groups)
         if groups != 1:
             n = inp.shape[0] // groups
@@ -457,7 +458,7 @@ def _prepare_native(mask_valid_warp, inv_homographies, B, Hc, Wc, samples, negs,
     check(lib.yp_nce_negatives(n, negs, s1, meta.data_ptr(), idx.data_ptr(), 0, sp()))
     edges = (idx,) + _csr(idx.view(-1), n, wide=True)
     out = (uab[:B], uab[B:], idx[:, 1:], edges)
-    if pair_index and os.environ.get("YP_SAMPLE_SORTED", "1") != "0":
+    if pair_index:
         out = out + ((uab,) + point_sample_index(uab, Hc, Wc),)
     return out
 
@@ -483,13 +484,13 @@ def infonce(descriptors, descriptors_warped, mask_valid_warp, inv_homographies, 
 
     def sample(desc, idx, inverse=None):
         if (desc.is_cuda and desc.dtype == torch.float32 and desc.shape[1] % 64 == 0 and desc.shape[1] <= 256 and desc.stride(1) == 1
-                and desc.permute(0, 2, 3, 1).is_contiguous() and os.environ.get("YP_NATIVE_INFONCE", "1") != "0"):
+                and desc.permute(0, 2, 3, 1).is_contiguous() and sw("YP_NATIVE_INFONCE") != "0"):
             if inverse is not None:
                 return _PointSampleNative.apply(desc, idx.contiguous(), *inverse)
             return _PointSampleNative.apply(desc, idx.contiguous())
         return F.grid_sample(desc, idx.unsqueeze(1), mode='bilinear', align_corners=True).squeeze(2).transpose(1, 2)
 
-    if descriptors_pair is not None and rnd.shape[1] + 1 <= 512 and os.environ.get("YP_NATIVE_INFONCE", "1") != "0":
+    if descriptors_pair is not None and rnd.shape[1] + 1 <= 512 and sw("YP_NATIVE_INFONCE") != "0":
         # both passes' descriptor maps as one [2B, D, Hc, Wc] tensor (image pass first; `descriptors` / `descriptors_warped` are its halves):
         # one sampling launch, one loss call, ONE gradient map for the whole tensor
         # (prepared[4], when present: the pair's sample points and their cell-sorted tap list, built with the sampling)
@@ -502,7 +503,7 @@ def infonce(descriptors, descriptors_warped, mask_valid_warp, inv_homographies, 
     db = sample(descriptors_warped, ub)
     D = da.shape[-1]
     if (da.is_cuda and da.dtype == torch.float32 and D % 64 == 0 and D <= 256 and rnd.shape[1] + 1 <= 512
-            and os.environ.get("YP_NATIVE_INFONCE", "1") != "0"):
+            and sw("YP_NATIVE_INFONCE") != "0"):
         if edges is None:
             edges = infonce_edges(rnd)
         return _InfoNCENative.apply(da.flatten(0, 1), db.flatten(0, 1), *edges, float(tau))
@@ -526,7 +527,7 @@ def infonce_prepare(mask_valid_warp, inv_homographies, desc_shape, on_device, nu
     with torch.no_grad():
         B, Hc, Wc = desc_shape[0], desc_shape[2], desc_shape[3]
         if (perm_fn is None and randint_fn is None and on_device and mask_valid_warp.is_cuda and cell_size == 8 and Hc * Wc < 36864
-                and mask_valid_warp.shape[-2] == 8 * Hc and mask_valid_warp.shape[-1] == 8 * Wc and os.environ.get("YP_NATIVE_PREPARE", "1") != "0"):
+                and mask_valid_warp.shape[-2] == 8 * Hc and mask_valid_warp.shape[-1] == 8 * Wc and sw("YP_NATIVE_PREPARE") != "0"):
             return _prepare_native(mask_valid_warp, inv_homographies, B, Hc, Wc, num_samples_per_image, num_masked_non_matches_per_match, pair_index,
                                    sync=sync)
         assert sync, "infonce_prepare(sync=False) exists for the device-side formulation only"
@@ -577,7 +578,7 @@ def infonce_prepare(mask_valid_warp, inv_homographies, desc_shape, on_device, nu
             rnd = torch.from_numpy(np.ascontiguousarray(rnd.T)).to(ua.device)
         edges = infonce_edges(rnd) if (on_device and rnd.is_cuda) else None
         pair_inv = None
-        if pair_index and on_device and ua.is_cuda and os.environ.get("YP_SAMPLE_SORTED", "1") != "0":
+        if pair_index and on_device and ua.is_cuda:
             uab = torch.cat((ua, ub)).contiguous()
             pair_inv = (uab,) + point_sample_index(uab, Hc, Wc)
     return (ua, ub, rnd, edges, pair_inv) if pair_inv is not None else (ua, ub, rnd, edges)
