@@ -20,6 +20,7 @@ cp $S/${R}_train_step_sequence.txt profiles/${R}_train_step_sequence.txt
 cp $S/bench_train_l_fp8.json profiles/${R}_bench_train_l_fp8.json
 cp $S/bench_train_l_bf16.json profiles/${R}_bench_train_l_bf16.json
 cp $S/${R}_train_l_fp8_step_kernels.txt profiles/${R}_train_l_fp8_step_kernels.txt
+cp $S/${R}_train_bs64_step_kernels.txt profiles/${R}_train_bs64_step_kernels.txt 2>/dev/null || true
 cp $S/bench_frame.json profiles/${R}_bench_frame.json
 cp $S/bench_export.json profiles/${R}_bench_export.json
 cp $S/train_traffic.json profiles/train_traffic.json

@@ -50,6 +50,15 @@ cd $ROOT
 python tools/profile_collect.py $R > /dev/null 2>&1
 mv $OUT/${R}_train_step_kernels.txt $OUT/${R}_train_l_fp8_step_kernels.txt
 mv $OUT/fp8/* $OUT/ && rmdir $OUT/fp8
+# ... and one step of the `train_bs64` record (ONE batch of 64 samples, YOLOPoint-s, bf16)
+mkdir -p $OUT/keep && mv $OUT/${R}_train_step_kernels.txt $OUT/${R}_train_step_sequence.txt $OUT/${R}_train_kernel_trace.txt $OUT/keep/ 2>/dev/null
+rm -rf $OUT/trace_train
+cd /tmp
+rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_train -o t -- python $ROOT/bench.py --mode train --batch 64 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/trace_train_bs64.log 2>&1
+cd $ROOT
+python tools/profile_collect.py $R > /dev/null 2>&1
+mv $OUT/${R}_train_step_kernels.txt $OUT/${R}_train_bs64_step_kernels.txt
+mv $OUT/keep/* $OUT/ && rmdir $OUT/keep
 # HBM traffic of the training steps (roofline.traffic of the train / train_l_fp8 records): separate PMC passes
 cd /tmp
 for cfg in "s 8 bf16" "l 16 fp8"; do
