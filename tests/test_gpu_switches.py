@@ -121,3 +121,21 @@ def test_switch_value_matches_the_default(cuda, monkeypatch, fixed_kernel_varian
         assert errs[len(errs) // 2] < 0.5
         return
     _compare(got[0], ref[0], s.tol, f"{name}={value}")
+
+
+def test_default_tuner_times_its_candidates(cuda, monkeypatch):
+    """With no switch set the plan-time autotuner TIMES the applicable kernel variants and keeps the fastest (the registry hands out "" for an
+    unset debug switch: a check `is not None` on YP_TUNE_RANDOM once turned the random stress mode on for every run -- configs[1] 0.64 -> 0.86 ms)."""
+    from yolopoint_amd import _hip, plan
+    monkeypatch.delenv("YP_TUNE_RANDOM", raising=False)
+    before = set(plan._TUNE_CACHE)
+    pb = plan.PlanBuilder(3, _hip.YP_F16, cuda)
+    assert pb.autotune
+    x = pb.new_buf(24, 40, 96)
+    x.t.normal_()
+    g = torch.Generator().manual_seed(5)
+    pb.conv(x.view(), torch.randn(160, 96, 3, 3, generator=g) * 0.03, torch.zeros(160), 3, 1, 1, _hip.YP_ACT_SILU)
+    pb.finish().run()
+    torch.cuda.synchronize()
+    new = [v for k, v in plan._TUNE_CACHE.items() if k not in before]
+    assert new and all(t is not None and t > 0 for _, t in new), new

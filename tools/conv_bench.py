@@ -87,7 +87,7 @@ def main():
             st = torch.cuda.Stream()
             try:
                 with torch.cuda.stream(st):
-                    for _ in range(3):
+                    for _ in range(40):         # (warm: the GPU idled while the plan was built and has dropped its clocks)
                         plan.run()
                     ms = plan.time(a.iters)
             except _hip.YpError:            # (variants that refuse a shape at launch time)
