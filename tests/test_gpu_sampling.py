@@ -170,7 +170,7 @@ def test_negatives_follow_the_reference_rule(cuda):
     assert not torch.equal(idx, idx2)
 
 
-@pytest.mark.parametrize("n_items,n_buckets,wide", [(100000, 500, True), (4096, 20000, False), (37, 5, True), (60000, 48000, False), (9000, 3, True)])
+@pytest.mark.parametrize("n_items,n_buckets,wide", [(100000, 500, True), (4096, 20000, False), (37, 5, True), (60000, 48000, False), (9000, 3, True), (40000, 100, True), (27000, 100, True), (300000, 24000, True)])
 def test_counting_sort_into_csr(cuda, n_items, n_buckets, wide):
     g = torch.Generator(device=cuda).manual_seed(n_items)
     keys = torch.randint(0, n_buckets, (n_items,), device=cuda, generator=g).to(torch.int32)

@@ -285,8 +285,46 @@ __global__ __launch_bounds__(256) void csr_scatter_kernel(const int* __restrict_
     }
 }
 
-// every bucket into ascending item order.  WAVE: one wavefront per bucket (rank sort through LDS; buckets of ~E entries), else one thread
-// per bucket (insertion sort in place; buckets of a few entries)
+// Bitonic sort of 256 ints held four per lane (element e = 4 * lane + r), ascending over e.  Strides 1 and 2 are exchanges between a lane's own
+// registers, strides >= 4 one cross-lane read (__shfl_xor) + min / max / select per element: ~520 instructions for the 36 stages, against ~2 400 for
+// the rank sort of a 200-entry bucket (every lane compares each of its entries with all the others through LDS).
+__device__ __forceinline__ void wave_bitonic256(int (&v)[4], int lane) {
+    auto cx = [](int& x, int& y, bool asc) {              // in-lane compare-exchange: (x, y) ascending or descending
+        const int mn = x < y ? x : y, mx = x < y ? y : x;
+        x = asc ? mn : mx;
+        y = asc ? mx : mn;
+    };
+#pragma unroll
+    for (int size = 2; size <= 256; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (stride >= 4) {
+                const int ls = stride >> 2;
+                const bool keep_min = ((lane & ls) == 0) == (((4 * lane) & size) == 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = __shfl_xor(v[r], ls, 64);
+                    const int mn = v[r] < o ? v[r] : o, mx = v[r] < o ? o : v[r];
+                    v[r] = keep_min ? mn : mx;
+                }
+            } else if (stride == 2) {
+                const bool asc = ((4 * lane) & size) == 0;            // (size >= 4 here: the direction bit lies in the lane index)
+                cx(v[0], v[2], asc);
+                cx(v[1], v[3], asc);
+            } else {
+                if (size == 2) { cx(v[0], v[1], true); cx(v[2], v[3], false); }      // direction bit = bit 1 of r
+                else {
+                    const bool asc = ((4 * lane) & size) == 0;
+                    cx(v[0], v[1], asc);
+                    cx(v[2], v[3], asc);
+                }
+            }
+        }
+    }
+}
+
+// every bucket into ascending item order.  WAVE: one wavefront per bucket (<= 256 entries: the bitonic sort above, in registers; more: rank sort
+// through LDS), else one thread per bucket (insertion sort in place; buckets of a few entries)
 template <bool WAVE>
 __global__ __launch_bounds__(256) void csr_sort_kernel(const int* __restrict__ offsets, int n_buckets, int* __restrict__ order) {
     constexpr int CAP = 2048;
@@ -296,6 +334,18 @@ __global__ __launch_bounds__(256) void csr_sort_kernel(const int* __restrict__ o
         for (int bk = blockIdx.x * 4 + wave; bk < n_buckets; bk += gridDim.x * 4) {
         const int e0 = offsets[bk], k = offsets[bk + 1] - e0;
         if (k <= 1) continue;
+        if (k <= 256) {
+            // (the buckets of the InfoNCE edge list: ~E = 200 entries.  The rank sort below took 558 us per -s step -- the longest launch of the
+            // label stream, in front of the InfoNCE chain the trunk backward waits for -- 4.2 ms at 64 samples)
+            int v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = 4 * lane + r < k ? order[e0 + 4 * lane + r] : 0x7fffffff;
+            wave_bitonic256(v, lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * lane + r < k) order[e0 + 4 * lane + r] = v[r];
+            continue;
+        }
         if (k <= CAP) {
             int* st = stage + wave * CAP;
             for (int i = lane; i < k; i += 64) st[i] = order[e0 + i];
