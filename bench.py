@@ -6,8 +6,17 @@
 Top level (BASELINE.json configs[1], the configuration `metric` is quoted on that fits one GPU): YOLOPoint-s inference, batch 8 per GPU,
 640x640, fp16 compute (fp32 accumulate, fp32 head outputs), BN folded, seeded synthetic weights, synthetic images resident in HBM when
 the timed region starts.  One step = one forward of the batch through the native plan (fused stem reading the NCHW fp32 batch, 47
-convolution launches, SPPF pooling, descriptor L2 norm, Detect decode to [8, 25200, 85]) replayed as a hipGraph.  N > 1 (launched by
-torch.distributed.run): inference shards by independent images -- one replica per rank, no data-path collective, `scaling: weak`.
+convolution launches, SPPF pooling, descriptor L2 norm, Detect decode to [8, 25200, 85]) replayed on the plan's two lanes.  N > 1: inference
+shards by independent images -- one replica per rank, no data-path collective, `scaling: weak`.
+
+Launch forms.  `python bench.py --gpus N` (no launcher around it) starts the N ranks itself: it re-executes as `python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>`, one rank per GPU over RCCL (the reference's
+`accelerate launch src/train.py`, README.md:76); under a launcher (WORLD_SIZE set -- the driver's form) it takes the launcher's ranks and exits with
+code 2 when `--gpus` disagrees with WORLD_SIZE or the box has fewer than N GPUs.  Rank 0 prints the ONE line (`n_gpus`: N).  `--backend gloo --dry`:
+launcher + process group + timed-region protocol with a stub step, no GPU (tests/test_bench_launcher.py); `--rehearsal`: everything for real with
+the ranks sharing the visible GPU over gloo (control-flow check; tests/test_gpu_dp_tuning.py).
+The numbers of every sub-record also appear as short keys inside `config` and `roofline` (bs1_ms, train_ms, train_bs64_ms, l_fp8_ms, l_bf16_ms,
+fp8_over_bf16, *_frac, backbone_frac, *_grad_l2) and once more in `summary`.
 
 Sub-records of the same line (each measured in this process, after the top-level timing):
   parity        head outputs of the timed plan against the oracle's fp32 CPU forward on the same weights and input (the oracle forward
@@ -21,6 +30,8 @@ Sub-records of the same line (each measured in this process, after the top-level
                 and the time the compute stream waits for the collectives (exposed communication)
   train_bs64    (N = 1) the metric's "train bs=64" on one GPU: ONE batch of 64 samples per optimizer step (train.py:38-43 with
                 train_batch_size 64: gas = 1); `gas8_ms_per_step` = the same nominal batch as 8 micro-batches of 8 (train_batch_size 8)
+  (train / train_bs64 / train_l_fp8 carry a `parity` object: one 640x640 image pair through the record's final weights, train-mode heads and six
+                parameter gradients against fp32 CPU autograd through the oracle -- relative L2, cosine)
   train_l_fp8   BASELINE configs[4]: YOLOPoint-l optimizer step, 16 samples per GPU (bs 128 over 8 GPUs), data parallel over all N ranks, fp8 Conv
                 operands (e4m3 x e4m3 forward, e5m2 x e4m3 dgrad, bf16 storage / BatchNorm / weight gradients); at N = 1 `bf16_ms_per_step` = the
                 same step in bf16

@@ -2,7 +2,7 @@
 
 `make -C yolopoint_amd/csrc asan` builds the AddressSanitizer library, but this GPU pool cannot run it: the boxes are in xnack- mode (instrumented
 device code objects need xnack+) and the image has no ASan build of the ROCm runtime (the ASan runtime's HSA interceptors abort inside PyTorch's
-libamdhip64: gpurun_out/r6_asan_diag.txt).  The substitute that does run everywhere: every activation / gradient buffer
+libamdhip64: profiles/r06_asan_diag.txt).  The substitute that does run everywhere: every activation / gradient buffer
 of a plan (plan.Buf) is re-allocated between two 16 KiB CANARY bands, the plans run -- inference (all fusions, ragged non-square input, two
 lanes), a bf16 optimizer step, an fp8 optimizer step -- and afterwards
   * both canary bands of every buffer are untouched (no kernel wrote in front of a buffer or behind its tail), and

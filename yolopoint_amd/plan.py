@@ -198,7 +198,8 @@ _TUNE_CACHE = {}
 # (71..76, the wave-private split-K kernels of csrc/conv_wsk.hip, live in the probe build `make -C yolopoint_amd/csrc probewsk` only since
 # round 5: back-to-back they win Conv5 / Conv9 / SPPF.cv2 of configs[1] (22.8 -> 19.2, 16.6 -> 12.1 us), inside the plan -- where every launch also
 # pays ~4 us of boundary + prologue + first fetch -- Conv5 26.0 -> 24.6, Conv9 19.4 -> 17.3 and the step 0.6558 -> 0.6535 ms, inside the box noise
-# (tools/probe/wsk_ab.sh); as tuner candidates under a random variant mixture they broke the fused-stem equivalence tests.)
+# (tools/probe/wsk_ab.sh); as tuner candidates under a random variant mixture they failed the fused-stem equivalence tests: root-caused in round 6 as
+# summation order on the plan-unique layers, not corruption -- DESIGN.md 4.13, tests/test_gpu_model.py.)
 # 61 / 62: the same kernel with ONE wavefront per SIMD (four waves, a wave = all rows x 64 channels; free-running schedule, one fragment read or DMA
 # instruction per MFMA) on 256 / 224 x 256 tiles -- 224 rows make 229 workgroups of M = 51 200 instead of 200 (256 CUs)
 _TUNE_CANDIDATES = (1, 2, 3, 4, 5, 21, 22, 23, 24, 25, 26, 27, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 41, 42, 43, 44, 57, 58, 61, 62)
