@@ -319,3 +319,45 @@ def test_every_environment_switch_is_registered():
         assert s_.kind in ("path", "knob", "debug", "native"), name
         if s_.kind == "path" and name != "YP_DP_COMM":
             assert s_.alt and s_.scope, f"{name}: a path switch needs its alternative values and the harness scope that tests them"
+
+
+def test_bitonic_network_of_the_csr_bucket_sort_sorts():
+    """csrc/sampling.hip::wave_bitonic256 restated in numpy (64 lanes x 4 registers, element e = 4 * lane + r; strides 1 / 2 inside a lane,
+    strides >= 4 across lanes with partner lane ^ (stride / 4); direction bit = e & size): every stage schedule of the 36 stages sorts ascending
+    over e, with INT_MAX padding behind k <= 256 entries -- the rule the device code implements (GPU: tests/test_gpu_sampling.py)."""
+    rng = np.random.default_rng(7)
+    lane = np.arange(64)
+
+    def cx(x, y, asc):
+        mn, mx = np.minimum(x, y), np.maximum(x, y)
+        return np.where(asc, mn, mx), np.where(asc, mx, mn)
+    for k in (1, 2, 3, 63, 64, 65, 200, 255, 256):
+        for _ in range(5):
+            vals = rng.permutation(1 << 20)[:k].astype(np.int64)
+            flat = np.full(256, 0x7fffffff, dtype=np.int64)
+            flat[:k] = vals
+            v = flat.reshape(64, 4).copy()
+            size = 2
+            while size <= 256:
+                stride = size >> 1
+                while stride > 0:
+                    if stride >= 4:
+                        ls = stride >> 2
+                        keep_min = ((lane & ls) == 0) == (((4 * lane) & size) == 0)
+                        o = v[lane ^ ls]
+                        v = np.where(keep_min[:, None], np.minimum(v, o), np.maximum(v, o))
+                    elif stride == 2:
+                        asc = ((4 * lane) & size) == 0
+                        v[:, 0], v[:, 2] = cx(v[:, 0].copy(), v[:, 2].copy(), asc)
+                        v[:, 1], v[:, 3] = cx(v[:, 1].copy(), v[:, 3].copy(), asc)
+                    elif size == 2:
+                        v[:, 0], v[:, 1] = cx(v[:, 0].copy(), v[:, 1].copy(), np.ones(64, bool))
+                        v[:, 2], v[:, 3] = cx(v[:, 2].copy(), v[:, 3].copy(), np.zeros(64, bool))
+                    else:
+                        asc = ((4 * lane) & size) == 0
+                        v[:, 0], v[:, 1] = cx(v[:, 0].copy(), v[:, 1].copy(), asc)
+                        v[:, 2], v[:, 3] = cx(v[:, 2].copy(), v[:, 3].copy(), asc)
+                    stride >>= 1
+                size <<= 1
+            out = v.reshape(-1)
+            assert np.array_equal(out[:k], np.sort(vals)) and np.all(out[k:] == 0x7fffffff), k
