@@ -262,7 +262,7 @@ def test_fused_stem_conv2_equals_the_two_launches(cuda, monkeypatch, dtype, mode
 
 def test_fused_stem_equivalence_needs_order_preserving_variants_on_the_unfused_layers(cuda, monkeypatch):
     """Root cause of round 5's "the wave-private split-K tiles (71..76) broke the fused-stem equivalence tests under a random variant
-    mixture" (tools/probe/wsk_rootcause.py, gpurun_out/r6_wsk_rootcause.txt: 34 arms).  The equivalence tests above compare a fused-stem plan with
+    mixture" (tools/probe/wsk_rootcause.py, profiles/r06_wsk_rootcause.txt: 34 arms).  The equivalence tests above compare a fused-stem plan with
     a two-launch plan; every layer the two plans SHARE draws the same variant in both (the tuner caches per signature), so only the layers that
     exist in ONE of the plans -- `Conv2`, `Bottleneck1.cv1+cv2` of the two-launch form -- can make them differ, and they do so exactly when
     their variant sums k in another order than the fused stem's phases do.  Every failing mixture had drawn a split-K tile for one of those
