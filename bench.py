@@ -453,6 +453,10 @@ def main(a):
         torch.cuda.empty_cache()
         out["frame"] = run_frame(dev, "l", 1280, a.dtype, a.frame_steps, max(3, a.frame_steps // 6), cpu_threads=a.cpu_threads)
     if rank != 0:
+        import torch.distributed as dist          # (every rank leaves the group: a rank that just exits makes RCCL's teardown on rank 0 wait for its timeout)
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
         return
     if world == 1 and "v52" in only:
         torch.cuda.empty_cache()
@@ -489,8 +493,10 @@ def main(a):
     head["summary"] = summ
     head.update({k_: v_ for k_, v_ in out.items() if k_ not in head})
     emit(json.dumps(head))
-    if world > 1 or __import__("torch").distributed.is_initialized():
+    if __import__("torch").distributed.is_initialized():
         try:
+            if world > 1:
+                __import__("torch").distributed.barrier()          # (pairs with the other ranks' barrier in front of their teardown)
             __import__("torch").distributed.destroy_process_group()
         except Exception:
             pass
@@ -848,6 +854,9 @@ def bench_train(a, rank, world, dev):
     a.cpu_threads = None if a.no_cpu_baseline else min(os.cpu_count() or 1, 16)
     rec = run_train(a, rank, world, dev, a.version, a.batch, a.steps, a.warmup, gas=a.gas, size=a.size, dtype=dtype)
     if rank != 0:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.destroy_process_group()
         return
     top = {"metric": f"images/sec at {a.size}x{a.size} (YOLOPoint-{a.version} training, {a.batch} samples/GPU x gas {a.gas}, {dtype}); an image pair counts as 2 images",
            "value": rec["value"], "unit": "images/s", "samples_per_s": rec["samples_per_s"], "n_gpus": world, "steps": rec["steps"], "warmup": rec["warmup"],
