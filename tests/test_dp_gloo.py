@@ -252,3 +252,17 @@ def test_sixteen_bit_gradient_exchange_two_ranks():
             want = 0.5 * (u + v)
             assert abs(x - want) <= 2e-2 * max(abs(u), abs(v), 1e-3), (x, want)
         assert any(x != 0.5 * (u + v) for x, u, v in zip(ga, ma, mb)) or len(ga) < 4   # (it really went through 16 bits)
+
+
+def test_unknown_exchange_dtype_is_refused(monkeypatch):
+    """YP_DP_COMM accepts fp32 (default) and bf16; anything else raises instead of silently exchanging in fp32 (round-5 advice: 'fp16' / 'bfloat16'
+    used to map to fp32 without a word, and an f16 stage would overflow on SUM backends)."""
+    from yolopoint_amd.dp import GradAllReducer
+    net = torch.nn.Linear(4, 4)
+    for bad in ("f16", "fp16", "bfloat16"):
+        monkeypatch.setenv("YP_DP_COMM", bad)
+        with pytest.raises(ValueError):
+            GradAllReducer(net.parameters())
+    monkeypatch.setenv("YP_DP_COMM", "bf16")
+    r = GradAllReducer(net.parameters())
+    assert r.comm_dtype == torch.bfloat16 and r.describe()[0]["comm_dtype"] == "bf16" and r.payload_bytes() == sum(f.numel() for f, _ in r.buckets) * 2
