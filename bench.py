@@ -453,9 +453,8 @@ def main(a):
         torch.cuda.empty_cache()
         out["frame"] = run_frame(dev, "l", 1280, a.dtype, a.frame_steps, max(3, a.frame_steps // 6), cpu_threads=a.cpu_threads)
     if rank != 0:
-        import torch.distributed as dist          # (every rank leaves the group: a rank that just exits makes RCCL's teardown on rank 0 wait for its timeout)
+        import torch.distributed as dist          # (every rank leaves the group itself; no collective behind the last sub-record, so no barrier is needed)
         if dist.is_initialized():
-            dist.barrier()
             dist.destroy_process_group()
         return
     if world == 1 and "v52" in only:
@@ -495,8 +494,6 @@ def main(a):
     emit(json.dumps(head))
     if __import__("torch").distributed.is_initialized():
         try:
-            if world > 1:
-                __import__("torch").distributed.barrier()          # (pairs with the other ranks' barrier in front of their teardown)
             __import__("torch").distributed.destroy_process_group()
         except Exception:
             pass
